@@ -1,0 +1,270 @@
+"""hpg-variant_amd -- MI355X-native per-variant statistics engine for HPG Variant.
+
+Python is plumbing here: this module only loads the C-ABI shared library
+(include/hpgv.h) with ctypes and gives numpy-friendly wrappers for the tests
+and bench.  There is no CPU implementation behind it: if the HIP library is
+missing or no device is present, calls raise.
+
+The directory name has a hyphen, so import it with
+    importlib.import_module("hpg-variant_amd")
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+OK = 0
+TASK_CHISQ, TASK_FISHER = 1, 2
+COND_UNAFFECTED, COND_AFFECTED, COND_OTHER = 0, 1, 2
+SEX_MALE, SEX_FEMALE, SEX_UNKNOWN = 0, 1, 2
+LAYOUT_ASSOC, LAYOUT_TDT, LAYOUT_STATS = 0, 1, 2
+GT_MISSING = 0xFF
+
+# every symbol include/hpgv.h declares (checked by the CPU suite)
+SYMBOLS = [
+    "hpgv_version", "hpgv_device_count", "hpgv_create", "hpgv_destroy", "hpgv_last_error",
+    "hpgv_set_option", "hpgv_set_cohort", "hpgv_assoc_layout", "hpgv_set_families",
+    "hpgv_tdt_layout", "hpgv_set_logfact", "hpgv_set_stats_cohort", "hpgv_stats_layout",
+    "hpgv_dev_alloc", "hpgv_dev_free", "hpgv_memcpy_h2d", "hpgv_memcpy_d2h", "hpgv_stream_sync",
+    "hpgv_layout_dev", "hpgv_synth_dev", "hpgv_synth_raw_dev",
+    "hpgv_assoc_scan_dev", "hpgv_assoc_chisq_dev", "hpgv_assoc_fisher_dev",
+    "hpgv_tdt_scan_dev", "hpgv_tdt_stats_dev", "hpgv_stats_scan_dev", "hpgv_stats_hwe_dev",
+    "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_read_probe",
+]
+
+
+class HpgvError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    _build.build_all(force=force, verbose=verbose)
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Loads libhpgv.so.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_build.LIB):
+        raise HpgvError("%s is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                        "there is no CPU fallback" % _build.LIB)
+    L = C.CDLL(_build.LIB)
+    vp, sz, i32, u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
+    L.hpgv_version.restype = C.c_char_p
+    L.hpgv_last_error.restype = C.c_char_p
+    L.hpgv_last_error.argtypes = [vp]
+    L.hpgv_create.argtypes = [i32, C.POINTER(vp)]
+    L.hpgv_destroy.argtypes = [vp]
+    L.hpgv_destroy.restype = None
+    L.hpgv_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+    L.hpgv_set_cohort.argtypes = [vp, vp, i32]
+    L.hpgv_assoc_layout.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(sz)]
+    L.hpgv_set_families.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    L.hpgv_tdt_layout.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(sz)]
+    L.hpgv_set_logfact.argtypes = [vp, vp, sz]
+    L.hpgv_set_stats_cohort.argtypes = [vp, i32]
+    L.hpgv_stats_layout.argtypes = [vp, C.POINTER(sz)]
+    L.hpgv_dev_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.hpgv_dev_free.argtypes = [vp, vp]
+    L.hpgv_memcpy_h2d.argtypes = [vp, vp, vp, sz, vp]
+    L.hpgv_memcpy_d2h.argtypes = [vp, vp, vp, sz, vp]
+    L.hpgv_stream_sync.argtypes = [vp, vp]
+    L.hpgv_layout_dev.argtypes = [vp, i32, vp, sz, i32, vp, vp]
+    L.hpgv_synth_dev.argtypes = [vp, i32, u64, i32, vp, vp]
+    L.hpgv_synth_raw_dev.argtypes = [vp, u64, i32, i32, sz, vp, vp]
+    L.hpgv_assoc_scan_dev.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.hpgv_assoc_chisq_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    L.hpgv_assoc_fisher_dev.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.hpgv_tdt_scan_dev.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.hpgv_tdt_stats_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    L.hpgv_stats_scan_dev.argtypes = [vp, vp, i32, vp, vp]
+    L.hpgv_stats_hwe_dev.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.hpgv_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.hpgv_assoc.argtypes = [vp, i32, vp, sz, i32, vp] + [vp] * 7
+    L.hpgv_tdt.argtypes = [vp, vp, sz, i32, vp] + [vp] * 5
+    L.hpgv_stats.argtypes = [vp, vp, sz, i32, vp, vp, vp]
+    L.hpgv_read_probe.argtypes = [vp, vp, sz, i32, C.POINTER(C.c_float)]
+    _lib = L
+    return L
+
+
+def _np(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class Engine:
+    """One engine context on one device (thin wrapper over hpgv_ctx)."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.hpgv_create(device, C.byref(h))
+        if rc != OK:
+            raise HpgvError("hpgv_create(%d) -> %d: %s" % (device, rc, self.L.hpgv_last_error(None).decode()))
+        self.h = h
+        self.device = device
+        self._bufs = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            for b in self._bufs:
+                self.L.hpgv_dev_free(self.h, b)
+            self._bufs = []
+            self.L.hpgv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise HpgvError("hpgv error %d: %s" % (rc, self.L.hpgv_last_error(self.h).decode()))
+
+    def set_option(self, key, value):
+        self._chk(self.L.hpgv_set_option(self.h, key.encode(), int(value)))
+
+    # ---- cohort -----------------------------------------------------------
+    def set_cohort(self, condition):
+        c = _np(condition, np.uint8)
+        self._chk(self.L.hpgv_set_cohort(self.h, _ptr(c), len(c)))
+        return self.assoc_layout()
+
+    def assoc_layout(self):
+        a, u, p = C.c_int(), C.c_int(), C.c_size_t()
+        self._chk(self.L.hpgv_assoc_layout(self.h, C.byref(a), C.byref(u), C.byref(p)))
+        return a.value, u.value, p.value
+
+    def set_families(self, n_samples, father_col, mother_col, child_off, child_col, child_sex):
+        f, m = _np(father_col, np.int32), _np(mother_col, np.int32)
+        o, c, s = _np(child_off, np.int32), _np(child_col, np.int32), _np(child_sex, np.uint8)
+        assert len(o) == len(f) + 1 and len(c) == len(s)
+        self._chk(self.L.hpgv_set_families(self.h, n_samples, len(f), _ptr(f), _ptr(m), _ptr(o),
+                                           _ptr(c), _ptr(s)))
+        return self.tdt_layout()
+
+    def tdt_layout(self):
+        a, b, p = C.c_int(), C.c_int(), C.c_size_t()
+        self._chk(self.L.hpgv_tdt_layout(self.h, C.byref(a), C.byref(b), C.byref(p)))
+        return a.value, b.value, p.value
+
+    def set_logfact(self, table):
+        t = _np(table, np.float64)
+        self._chk(self.L.hpgv_set_logfact(self.h, _ptr(t), len(t)))
+
+    def set_stats_cohort(self, n_samples):
+        self._chk(self.L.hpgv_set_stats_cohort(self.h, n_samples))
+        p = C.c_size_t()
+        self._chk(self.L.hpgv_stats_layout(self.h, C.byref(p)))
+        return p.value
+
+    # ---- device memory ------------------------------------------------------
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.L.hpgv_dev_alloc(self.h, nbytes, C.byref(p)))
+        self._bufs.append(p)
+        return p
+
+    def free(self, p):
+        self._bufs = [b for b in self._bufs if b.value != p.value]
+        self._chk(self.L.hpgv_dev_free(self.h, p))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.L.hpgv_memcpy_h2d(self.h, dptr, _ptr(arr), arr.nbytes, None))
+
+    def d2h(self, dptr, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        self._chk(self.L.hpgv_memcpy_d2h(self.h, _ptr(out), dptr, out.nbytes, None))
+        return out
+
+    def sync(self, stream=None):
+        self._chk(self.L.hpgv_stream_sync(self.h, stream))
+
+    # ---- per-batch host entry points ---------------------------------------
+    def assoc(self, task, gt, is_x=None):
+        gt = _np(gt, np.uint8)
+        nv, pitch = gt.shape
+        x = None if is_x is None else _np(is_x, np.uint8)
+        A1, A2, U1, U2 = (np.zeros(nv, np.int32) for _ in range(4))
+        odds, chisq, p = (np.zeros(nv, np.float64) for _ in range(3))
+        self._chk(self.L.hpgv_assoc(self.h, task, _ptr(gt), pitch, nv, _ptr(x), _ptr(A1), _ptr(A2),
+                                    _ptr(U1), _ptr(U2), _ptr(odds),
+                                    _ptr(chisq) if task == TASK_CHISQ else None, _ptr(p)))
+        return dict(A1=A1, A2=A2, U1=U1, U2=U2, odds=odds,
+                    chisq=chisq if task == TASK_CHISQ else None, p=p)
+
+    def tdt(self, gt, is_x=None):
+        gt = _np(gt, np.uint8)
+        nv, pitch = gt.shape
+        x = None if is_x is None else _np(is_x, np.uint8)
+        t1, t2 = np.zeros(nv, np.int32), np.zeros(nv, np.int32)
+        odds, chisq, p = (np.zeros(nv, np.float64) for _ in range(3))
+        self._chk(self.L.hpgv_tdt(self.h, _ptr(gt), pitch, nv, _ptr(x), _ptr(t1), _ptr(t2),
+                                  _ptr(odds), _ptr(chisq), _ptr(p)))
+        return dict(t1=t1, t2=t2, odds=odds, chisq=chisq, p=p)
+
+    def stats(self, gt):
+        gt = _np(gt, np.uint8)
+        nv, pitch = gt.shape
+        c8 = np.zeros((nv, 8), np.int32)
+        chi2, p = np.zeros(nv, np.float64), np.zeros(nv, np.float64)
+        self._chk(self.L.hpgv_stats(self.h, _ptr(gt), pitch, nv, _ptr(c8), _ptr(chi2), _ptr(p)))
+        return dict(counts8=c8, hwe_chi2=chi2, hwe_p=p)
+
+    # ---- device-resident path (raw pointers; ints or c_void_p) ---------------
+    def synth(self, which, v0, n_variants, d_dst, stream=None):
+        self._chk(self.L.hpgv_synth_dev(self.h, which, v0, n_variants, d_dst, stream))
+
+    def synth_raw(self, v0, n_variants, n_samples, pitch, d_dst, stream=None):
+        self._chk(self.L.hpgv_synth_raw_dev(self.h, v0, n_variants, n_samples, pitch, d_dst, stream))
+
+    def layout(self, which, d_src, src_pitch, n_variants, d_dst, stream=None):
+        self._chk(self.L.hpgv_layout_dev(self.h, which, d_src, src_pitch, n_variants, d_dst, stream))
+
+    def assoc_scan(self, d_gt, n_variants, d_counts, d_is_x=None, stream=None):
+        self._chk(self.L.hpgv_assoc_scan_dev(self.h, d_gt, n_variants, d_is_x, d_counts, stream))
+
+    def assoc_chisq(self, d_counts, n_variants, d_odds, d_chisq, d_p, stream=None):
+        self._chk(self.L.hpgv_assoc_chisq_dev(self.h, d_counts, n_variants, d_odds, d_chisq, d_p, stream))
+
+    def assoc_fisher(self, d_counts, n_variants, d_odds, d_p, stream=None):
+        self._chk(self.L.hpgv_assoc_fisher_dev(self.h, d_counts, n_variants, d_odds, d_p, stream))
+
+    def tdt_scan(self, d_gt, n_variants, d_tu, d_is_x=None, stream=None):
+        self._chk(self.L.hpgv_tdt_scan_dev(self.h, d_gt, n_variants, d_is_x, d_tu, stream))
+
+    def tdt_stats(self, d_tu, n_variants, d_odds, d_chisq, d_p, stream=None):
+        self._chk(self.L.hpgv_tdt_stats_dev(self.h, d_tu, n_variants, d_odds, d_chisq, d_p, stream))
+
+    def stats_scan(self, d_gt, n_variants, d_counts8, stream=None):
+        self._chk(self.L.hpgv_stats_scan_dev(self.h, d_gt, n_variants, d_counts8, stream))
+
+    def stats_hwe(self, d_counts8, n_variants, d_chi2, d_p, stream=None):
+        self._chk(self.L.hpgv_stats_hwe_dev(self.h, d_counts8, n_variants, d_chi2, d_p, stream))
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(), C.c_float()
+        self._chk(self.L.hpgv_last_kernel_ms(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def read_probe(self, d_buf, nbytes, iters=5):
+        ms = C.c_float()
+        self._chk(self.L.hpgv_read_probe(self.h, d_buf, nbytes, iters, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,65 @@
+"""Build recipe of the gfx950 shared library (in-tree, so the .so travels with
+the repo snapshot).  hipcc cross-compiles without a GPU."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libhpgv.so")
+HOSTLIB = os.path.join(LIBDIR, "libhpgv_host.so")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-ffp-contract=off", "-Wall", "-Wextra"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the engine cannot be built")
+    return exe
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_device_lib(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    srcs.append(os.path.join(ROOT, "include", "hpgv.h"))
+    if not force and not _stale(LIB, srcs):
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB, os.path.join(CSRC, "hpgv_capi.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_host_lib(force=False, verbose=False):
+    hdir = os.path.join(HERE, "host")
+    if not os.path.isdir(hdir):
+        return None
+    srcs = [os.path.join(hdir, f) for f in sorted(os.listdir(hdir))]
+    srcs.append(os.path.join(ROOT, "include", "hpgv.h"))
+    if not force and not _stale(HOSTLIB, srcs + [LIB]):
+        return HOSTLIB
+    csrcs = [s for s in srcs if s.endswith(".c")]
+    cmd = ["gcc", "-O2", "-g", "-std=gnu99", "-fPIC", "-shared", "-fopenmp", "-Wall", "-Wextra",
+           "-I", os.path.join(ROOT, "include"), "-I", hdir, "-o", HOSTLIB] + csrcs + \
+          ["-L", LIBDIR, "-lhpgv", "-Wl,-rpath,$ORIGIN", "-lm"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HOSTLIB
+
+
+def build_all(force=False, verbose=False):
+    build_device_lib(force, verbose)
+    build_host_lib(force, verbose)

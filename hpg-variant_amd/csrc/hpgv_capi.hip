@@ -1,0 +1,766 @@
+// hpgv_capi.hip -- C ABI (include/hpgv.h) over the gfx950 kernels.
+//
+// There is no CPU path in this library: every entry point that computes
+// launches HIP kernels, and hpgv_create() fails without a device.
+#include "../../include/hpgv.h"
+#include "hpgv_kernels.h"
+#include "hpgv_tdt_stats_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Layout {
+    bool set = false;
+    int n_samples = 0;
+    size_t pitch = 0;
+    int chunks = 0;
+    std::vector<int32_t> col_of_pos;   // size pitch; -1 = pad
+    int32_t *d_col_of_pos = nullptr;
+};
+
+// per-call scratch of the synchronous host entry points
+struct Slot {
+    bool busy = false;
+    hipStream_t stream = nullptr;
+    void *buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+}  // namespace
+
+struct hpgv_ctx {
+    int device = 0;
+    mutable std::string err;
+    std::mutex mu;
+    // options
+    long row_align = 128;
+    long vpw = 4;
+    long nontemporal = 1;
+    long profile = 0;
+    // assoc
+    Layout assoc;
+    int nA = 0, nU = 0, chunksA = 0;
+    // tdt
+    Layout tdt;
+    hpgv::TdtPlan tdt_plan;
+    // stats
+    Layout stats;
+    // fisher
+    double *d_lf = nullptr;
+    size_t n_lf = 0;
+    // synth scratch
+    uint32_t *d_thr = nullptr;
+    size_t thr_cap = 0;
+    // profiling
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool have_scan_ev = false, have_stats_ev = false;
+    std::vector<Slot *> slots;
+    uint32_t *d_sink = nullptr;
+};
+
+namespace {
+
+int fail(const hpgv_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(ctx, HPGV_ERR_HIP, "%s failed: %s (%s:%d)", #call,                  \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                         \
+    } while (0)
+
+// makes ctx->device current for the scope of one API call
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+            changed = (hipSetDevice(dev) == hipSuccess);
+        }
+    }
+    ~DeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+};
+
+size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int upload_layout(hpgv_ctx *ctx, Layout &L) {
+    if (L.d_col_of_pos) { (void)hipFree(L.d_col_of_pos); L.d_col_of_pos = nullptr; }
+    HIPCHK(ctx, hipMalloc(&L.d_col_of_pos, L.col_of_pos.size() * sizeof(int32_t)));
+    HIPCHK(ctx, hipMemcpy(L.d_col_of_pos, L.col_of_pos.data(), L.col_of_pos.size() * sizeof(int32_t),
+                          hipMemcpyHostToDevice));
+    L.chunks = (int)(L.pitch / 16);
+    L.set = true;
+    return HPGV_OK;
+}
+
+// packed per-lane 16-bit partial sums bound the row length (hpgv_kernels.h)
+constexpr int kScanUnroll = 8;
+bool pitch_supported(size_t pitch) { return pitch / 16 / 64 + kScanUnroll + 1 <= 2047; }
+
+int ensure(hpgv_ctx *ctx, Slot *s, int idx, size_t bytes) {
+    if (s->cap[idx] >= bytes) return HPGV_OK;
+    if (s->buf[idx]) { (void)hipFree(s->buf[idx]); s->buf[idx] = nullptr; s->cap[idx] = 0; }
+    size_t want = round_up(bytes + bytes / 4, 256);
+    HIPCHK(ctx, hipMalloc(&s->buf[idx], want));
+    s->cap[idx] = want;
+    return HPGV_OK;
+}
+
+int acquire_slot(hpgv_ctx *ctx, Slot **out) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (Slot *s : ctx->slots)
+        if (!s->busy) { s->busy = true; *out = s; return HPGV_OK; }
+    Slot *s = new (std::nothrow) Slot();
+    if (!s) return fail(ctx, HPGV_ERR_NOMEM, "out of host memory");
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete s; return fail(ctx, HPGV_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    s->busy = true;
+    ctx->slots.push_back(s);
+    *out = s;
+    return HPGV_OK;
+}
+void release_slot(hpgv_ctx *ctx, Slot *s) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    s->busy = false;
+}
+struct SlotLease {
+    hpgv_ctx *ctx; Slot *s = nullptr;
+    explicit SlotLease(hpgv_ctx *c) : ctx(c) {}
+    ~SlotLease() { if (s) release_slot(ctx, s); }
+};
+
+template <typename F>
+int launch_profiled(hpgv_ctx *ctx, hipStream_t st, int which /*0 scan,1 stats*/, F &&launch) {
+    if (ctx->profile) HIPCHK(ctx, hipEventRecord(ctx->ev[2 * which], st));
+    launch();
+    HIPCHK(ctx, hipGetLastError());
+    if (ctx->profile) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev[2 * which + 1], st));
+        (which == 0 ? ctx->have_scan_ev : ctx->have_stats_ev) = true;
+    }
+    return HPGV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *hpgv_version(void) { return "hpgv-mi355x 0.1 (gfx950)"; }
+
+int hpgv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+const char *hpgv_last_error(const hpgv_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int hpgv_create(int device_id, hpgv_ctx **out) {
+    if (!out) return fail(nullptr, HPGV_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, HPGV_ERR_NO_DEVICE,
+                    "no usable HIP device (%s); this engine has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device_id < 0 || device_id >= n)
+        return fail(nullptr, HPGV_ERR_INVALID, "device_id %d out of range [0,%d)", device_id, n);
+    hpgv_ctx *ctx = new (std::nothrow) hpgv_ctx();
+    if (!ctx) return fail(nullptr, HPGV_ERR_NOMEM, "out of host memory");
+    ctx->device = device_id;
+    DeviceGuard g(device_id);
+    for (int i = 0; i < 4; ++i) {
+        e = hipEventCreate(&ctx->ev[i]);
+        if (e != hipSuccess) {
+            int rc = fail(nullptr, HPGV_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+            delete ctx;
+            return rc;
+        }
+    }
+    e = hipMalloc(&ctx->d_sink, 256);
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, HPGV_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return HPGV_OK;
+}
+
+void hpgv_destroy(hpgv_ctx *ctx) {
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (Layout *L : {&ctx->assoc, &ctx->tdt, &ctx->stats})
+        if (L->d_col_of_pos) (void)hipFree(L->d_col_of_pos);
+    ctx->tdt_plan.release();
+    if (ctx->d_lf) (void)hipFree(ctx->d_lf);
+    if (ctx->d_thr) (void)hipFree(ctx->d_thr);
+    if (ctx->d_sink) (void)hipFree(ctx->d_sink);
+    for (Slot *s : ctx->slots) {
+        for (int i = 0; i < 8; ++i) if (s->buf[i]) (void)hipFree(s->buf[i]);
+        if (s->stream) (void)hipStreamDestroy(s->stream);
+        delete s;
+    }
+    for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    delete ctx;
+}
+
+int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
+    if (!ctx || !key) return HPGV_ERR_INVALID;
+    if (!strcmp(key, "row_align")) {
+        if (value < 16 || (value & (value - 1))) return fail(ctx, HPGV_ERR_INVALID, "row_align must be a power of two >= 16");
+        if (ctx->assoc.set || ctx->tdt.set || ctx->stats.set)
+            return fail(ctx, HPGV_ERR_STATE, "row_align must be set before the cohort");
+        ctx->row_align = value;
+    } else if (!strcmp(key, "variants_per_wave")) {
+        if (value < 1 || value > 1024) return fail(ctx, HPGV_ERR_INVALID, "variants_per_wave out of range");
+        ctx->vpw = value;
+    } else if (!strcmp(key, "nontemporal")) {
+        ctx->nontemporal = value ? 1 : 0;
+    } else if (!strcmp(key, "profile")) {
+        ctx->profile = value ? 1 : 0;
+    } else {
+        return fail(ctx, HPGV_ERR_INVALID, "unknown option '%s'", key);
+    }
+    return HPGV_OK;
+}
+
+/* ---- cohort ---------------------------------------------------------------- */
+
+int hpgv_set_cohort(hpgv_ctx *ctx, const uint8_t *condition, int n_samples) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!condition || n_samples < 0) return fail(ctx, HPGV_ERR_INVALID, "bad cohort arguments");
+    DeviceGuard g(ctx->device);
+    int nA = 0, nU = 0;
+    for (int j = 0; j < n_samples; ++j) {
+        if (condition[j] == HPGV_COND_AFFECTED) nA++;
+        else if (condition[j] == HPGV_COND_UNAFFECTED) nU++;
+    }
+    size_t segA = round_up((size_t)nA, 16), segU = round_up((size_t)nU, 16);
+    size_t pitch = round_up(segA + segU, (size_t)ctx->row_align);
+    if (pitch == 0) pitch = (size_t)ctx->row_align;
+    if (!pitch_supported(pitch)) return fail(ctx, HPGV_ERR_UNSUPPORTED, "cohort of %d samples exceeds the row-length limit", n_samples);
+    Layout &L = ctx->assoc;
+    L.n_samples = n_samples;
+    L.pitch = pitch;
+    L.col_of_pos.assign(pitch, -1);
+    size_t a = 0, u = segA;
+    for (int j = 0; j < n_samples; ++j) {
+        if (condition[j] == HPGV_COND_AFFECTED) L.col_of_pos[a++] = j;
+        else if (condition[j] == HPGV_COND_UNAFFECTED) L.col_of_pos[u++] = j;
+    }
+    ctx->nA = nA; ctx->nU = nU; ctx->chunksA = (int)(segA / 16);
+    return upload_layout(ctx, L);
+}
+
+int hpgv_assoc_layout(const hpgv_ctx *ctx, int *n_affected, int *n_unaffected, size_t *pitch) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->assoc.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_cohort has not been called");
+    if (n_affected) *n_affected = ctx->nA;
+    if (n_unaffected) *n_unaffected = ctx->nU;
+    if (pitch) *pitch = ctx->assoc.pitch;
+    return HPGV_OK;
+}
+
+int hpgv_set_logfact(hpgv_ctx *ctx, const double *table, size_t n) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!table || n == 0) return fail(ctx, HPGV_ERR_INVALID, "empty log-factorial table");
+    DeviceGuard g(ctx->device);
+    if (ctx->d_lf) { (void)hipFree(ctx->d_lf); ctx->d_lf = nullptr; ctx->n_lf = 0; }
+    HIPCHK(ctx, hipMalloc(&ctx->d_lf, n * sizeof(double)));
+    HIPCHK(ctx, hipMemcpy(ctx->d_lf, table, n * sizeof(double), hipMemcpyHostToDevice));
+    ctx->n_lf = n;
+    return HPGV_OK;
+}
+
+int hpgv_set_stats_cohort(hpgv_ctx *ctx, int n_samples) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (n_samples < 0) return fail(ctx, HPGV_ERR_INVALID, "negative n_samples");
+    DeviceGuard g(ctx->device);
+    size_t pitch = round_up(round_up((size_t)n_samples, 16), (size_t)ctx->row_align);
+    if (pitch == 0) pitch = (size_t)ctx->row_align;
+    if (!pitch_supported(pitch)) return fail(ctx, HPGV_ERR_UNSUPPORTED, "cohort of %d samples exceeds the row-length limit", n_samples);
+    Layout &L = ctx->stats;
+    L.n_samples = n_samples;
+    L.pitch = pitch;
+    L.col_of_pos.assign(pitch, -1);
+    for (int j = 0; j < n_samples; ++j) L.col_of_pos[j] = j;
+    return upload_layout(ctx, L);
+}
+
+int hpgv_stats_layout(const hpgv_ctx *ctx, size_t *pitch) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->stats.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");
+    if (pitch) *pitch = ctx->stats.pitch;
+    return HPGV_OK;
+}
+
+int hpgv_set_families(hpgv_ctx *ctx, int n_samples, int n_families, const int32_t *father_col,
+                      const int32_t *mother_col, const int32_t *child_off, const int32_t *child_col,
+                      const uint8_t *child_sex) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (n_samples < 0 || n_families < 0 || (n_families > 0 && (!father_col || !mother_col || !child_off)))
+        return fail(ctx, HPGV_ERR_INVALID, "bad family arguments");
+    DeviceGuard g(ctx->device);
+    Layout &L = ctx->tdt;
+    std::string why;
+    int rc = ctx->tdt_plan.build(n_samples, n_families, father_col, mother_col, child_off, child_col,
+                                 child_sex, (size_t)ctx->row_align, L.col_of_pos, L.pitch, why);
+    if (rc != HPGV_OK) return fail(ctx, rc, "%s", why.c_str());
+    if (!pitch_supported(L.pitch)) return fail(ctx, HPGV_ERR_UNSUPPORTED, "pedigree exceeds the row-length limit");
+    L.n_samples = n_samples;
+    return upload_layout(ctx, L);
+}
+
+int hpgv_tdt_layout(const hpgv_ctx *ctx, int *n_trios_fast, int *n_families_slow, size_t *pitch) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->tdt.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_families has not been called");
+    if (n_trios_fast) *n_trios_fast = ctx->tdt_plan.n_fast;
+    if (n_families_slow) *n_families_slow = ctx->tdt_plan.n_slow_families;
+    if (pitch) *pitch = ctx->tdt.pitch;
+    return HPGV_OK;
+}
+
+/* ---- memory ---------------------------------------------------------------- */
+
+int hpgv_dev_alloc(hpgv_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) return HPGV_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    HIPCHK(ctx, hipMalloc(dptr, bytes ? bytes : 16));
+    return HPGV_OK;
+}
+int hpgv_dev_free(hpgv_ctx *ctx, void *dptr) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    if (dptr) HIPCHK(ctx, hipFree(dptr));
+    return HPGV_OK;
+}
+int hpgv_memcpy_h2d(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIPCHK(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return HPGV_OK;
+}
+int hpgv_memcpy_d2h(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return HPGV_OK;
+}
+int hpgv_stream_sync(hpgv_ctx *ctx, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return HPGV_OK;
+}
+
+/* ---- layout + synth ------------------------------------------------------- */
+
+static Layout *pick_layout(hpgv_ctx *ctx, int which) {
+    switch (which) {
+        case HPGV_LAYOUT_ASSOC: return &ctx->assoc;
+        case HPGV_LAYOUT_TDT: return &ctx->tdt;
+        case HPGV_LAYOUT_STATS: return &ctx->stats;
+        default: return nullptr;
+    }
+}
+
+int hpgv_layout_dev(hpgv_ctx *ctx, int which, const uint8_t *d_src, size_t src_pitch, int n_variants,
+                    uint8_t *d_dst, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    Layout *L = pick_layout(ctx, which);
+    if (!L) return fail(ctx, HPGV_ERR_INVALID, "unknown layout %d", which);
+    if (!L->set) return fail(ctx, HPGV_ERR_STATE, "layout %d has no cohort yet", which);
+    if (n_variants < 0 || (n_variants > 0 && (!d_src || !d_dst))) return fail(ctx, HPGV_ERR_INVALID, "bad layout arguments");
+    if (src_pitch < (size_t)L->n_samples) return fail(ctx, HPGV_ERR_INVALID, "src_pitch %zu < n_samples %d", src_pitch, L->n_samples);
+    if (n_variants == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    const long total = (long)n_variants * L->chunks;
+    const int strict = (which == HPGV_LAYOUT_STATS) ? 0 : 1;
+    hipLaunchKernelGGL(hpgv::k_layout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       d_src, src_pitch, n_variants, L->pitch, L->chunks, L->d_col_of_pos, strict, d_dst);
+    HIPCHK(ctx, hipGetLastError());
+    return HPGV_OK;
+}
+
+static int ensure_thr(hpgv_ctx *ctx, int n_variants) {
+    size_t need = (size_t)n_variants * 3 * sizeof(uint32_t);
+    if (ctx->thr_cap >= need) return HPGV_OK;
+    if (ctx->d_thr) { (void)hipFree(ctx->d_thr); ctx->d_thr = nullptr; ctx->thr_cap = 0; }
+    HIPCHK(ctx, hipMalloc(&ctx->d_thr, need));
+    ctx->thr_cap = need;
+    return HPGV_OK;
+}
+
+static int synth_common(hpgv_ctx *ctx, uint64_t v0, int n_variants, size_t pitch, int chunks,
+                        const int32_t *d_col, uint8_t *d_dst, hipStream_t st) {
+    // generated in slabs so the threshold scratch stays small
+    const int slab = 1 << 20;
+    int rc = ensure_thr(ctx, n_variants < slab ? n_variants : slab);
+    if (rc) return rc;
+    for (int off = 0; off < n_variants; off += slab) {
+        const int n = (n_variants - off) < slab ? (n_variants - off) : slab;
+        hipLaunchKernelGGL(hpgv::k_synth_thresholds, dim3((n + 255) / 256), dim3(256), 0, st,
+                           v0 + (uint64_t)off, n, ctx->d_thr);
+        const long total = (long)n * chunks;
+        hipLaunchKernelGGL(hpgv::k_synth_layout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           v0 + (uint64_t)off, n, pitch, chunks, d_col, ctx->d_thr,
+                           d_dst + (size_t)off * pitch);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return HPGV_OK;
+}
+
+int hpgv_synth_dev(hpgv_ctx *ctx, int which, uint64_t v0, int n_variants, uint8_t *d_dst, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    Layout *L = pick_layout(ctx, which);
+    if (!L) return fail(ctx, HPGV_ERR_INVALID, "unknown layout %d", which);
+    if (!L->set) return fail(ctx, HPGV_ERR_STATE, "layout %d has no cohort yet", which);
+    if (n_variants < 0 || (n_variants > 0 && !d_dst)) return fail(ctx, HPGV_ERR_INVALID, "bad synth arguments");
+    if (n_variants == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    std::lock_guard<std::mutex> lk(ctx->mu);   // shares ctx->d_thr
+    return synth_common(ctx, v0, n_variants, L->pitch, L->chunks, L->d_col_of_pos, d_dst, (hipStream_t)stream);
+}
+
+int hpgv_synth_raw_dev(hpgv_ctx *ctx, uint64_t v0, int n_variants, int n_samples, size_t pitch,
+                       uint8_t *d_dst, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (n_variants < 0 || n_samples < 0 || pitch % 16 || pitch < (size_t)n_samples || (n_variants > 0 && !d_dst))
+        return fail(ctx, HPGV_ERR_INVALID, "bad synth_raw arguments (pitch must be a multiple of 16 >= n_samples)");
+    if (n_variants == 0 || pitch == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    std::vector<int32_t> col(pitch, -1);
+    for (int j = 0; j < n_samples; ++j) col[j] = j;
+    int32_t *d_col = nullptr;
+    HIPCHK(ctx, hipMalloc(&d_col, pitch * sizeof(int32_t)));
+    hipError_t e = hipMemcpy(d_col, col.data(), pitch * sizeof(int32_t), hipMemcpyHostToDevice);
+    int rc = HPGV_OK;
+    if (e != hipSuccess) rc = fail(ctx, HPGV_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
+    if (!rc) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        rc = synth_common(ctx, v0, n_variants, pitch, (int)(pitch / 16), d_col, d_dst, (hipStream_t)stream);
+    }
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(d_col);
+    return rc;
+}
+
+/* ---- assoc ------------------------------------------------------------------ */
+
+int hpgv_assoc_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, const uint8_t *d_is_x,
+                        int32_t *d_counts, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->assoc.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_cohort has not been called");
+    if (n_variants < 0 || (n_variants > 0 && (!d_gt || !d_counts))) return fail(ctx, HPGV_ERR_INVALID, "bad scan arguments");
+    if (n_variants == 0) return HPGV_OK;
+    if (((uintptr_t)d_gt & 15) || ((uintptr_t)d_counts & 15)) return fail(ctx, HPGV_ERR_INVALID, "device buffers must be 16-byte aligned");
+    DeviceGuard g(ctx->device);
+    const Layout &L = ctx->assoc;
+    const int vpw = (int)ctx->vpw;
+    const long waves = ((long)n_variants + vpw - 1) / vpw;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    return launch_profiled(ctx, st, 0, [&] {
+        if (ctx->nontemporal)
+            hipLaunchKernelGGL((hpgv::k_assoc_scan<true, kScanUnroll>), dim3(blocks), dim3(256), 0, st, d_gt, L.pitch,
+                               n_variants, ctx->chunksA, L.chunks, d_is_x, (int4 *)d_counts, vpw);
+        else
+            hipLaunchKernelGGL((hpgv::k_assoc_scan<false, kScanUnroll>), dim3(blocks), dim3(256), 0, st, d_gt, L.pitch,
+                               n_variants, ctx->chunksA, L.chunks, d_is_x, (int4 *)d_counts, vpw);
+    });
+}
+
+int hpgv_assoc_chisq_dev(hpgv_ctx *ctx, const int32_t *d_counts, int n_variants, double *d_odds,
+                         double *d_chisq, double *d_p, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (n_variants < 0 || (n_variants > 0 && (!d_counts || !d_odds || !d_chisq || !d_p)))
+        return fail(ctx, HPGV_ERR_INVALID, "bad chisq arguments");
+    if (n_variants == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    return launch_profiled(ctx, st, 1, [&] {
+        hipLaunchKernelGGL(hpgv::k_assoc_chisq, dim3((n_variants + 255) / 256), dim3(256), 0, st,
+                           (const int4 *)d_counts, n_variants, d_odds, d_chisq, d_p);
+    });
+}
+
+int hpgv_assoc_fisher_dev(hpgv_ctx *ctx, const int32_t *d_counts, int n_variants, double *d_odds,
+                          double *d_p, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (n_variants < 0 || (n_variants > 0 && (!d_counts || !d_odds || !d_p)))
+        return fail(ctx, HPGV_ERR_INVALID, "bad fisher arguments");
+    if (!ctx->d_lf) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_logfact has not been called");
+    if (ctx->assoc.set && ctx->n_lf < (size_t)2 * (ctx->nA + ctx->nU) + 1)
+        return fail(ctx, HPGV_ERR_STATE, "log-factorial table has %zu entries, need %d", ctx->n_lf, 2 * (ctx->nA + ctx->nU) + 1);
+    if (n_variants == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    return launch_profiled(ctx, st, 1, [&] {
+        hipLaunchKernelGGL(hpgv::k_assoc_fisher, dim3((n_variants + 3) / 4), dim3(256), 0, st,
+                           (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p);
+    });
+}
+
+/* ---- tdt ------------------------------------------------------------------- */
+
+int hpgv_tdt_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, const uint8_t *d_is_x,
+                      int32_t *d_tu, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->tdt.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_families has not been called");
+    if (n_variants < 0 || (n_variants > 0 && (!d_gt || !d_tu))) return fail(ctx, HPGV_ERR_INVALID, "bad scan arguments");
+    if (n_variants == 0) return HPGV_OK;
+    if (((uintptr_t)d_gt & 15) || ((uintptr_t)d_tu & 7)) return fail(ctx, HPGV_ERR_INVALID, "device buffers must be aligned");
+    DeviceGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    return launch_profiled(ctx, st, 0, [&] {
+        ctx->tdt_plan.launch_scan(d_gt, ctx->tdt.pitch, n_variants, d_is_x, (int2 *)d_tu,
+                                  (int)ctx->vpw, ctx->nontemporal != 0, st);
+    });
+}
+
+int hpgv_tdt_stats_dev(hpgv_ctx *ctx, const int32_t *d_tu, int n_variants, double *d_odds,
+                       double *d_chisq, double *d_p, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (n_variants < 0 || (n_variants > 0 && (!d_tu || !d_odds || !d_chisq || !d_p)))
+        return fail(ctx, HPGV_ERR_INVALID, "bad tdt stats arguments");
+    if (n_variants == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    return launch_profiled(ctx, st, 1, [&] {
+        hipLaunchKernelGGL(hpgv::k_tdt_stats, dim3((n_variants + 255) / 256), dim3(256), 0, st,
+                           (const int2 *)d_tu, n_variants, d_odds, d_chisq, d_p);
+    });
+}
+
+/* ---- stats ----------------------------------------------------------------- */
+
+int hpgv_stats_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, int32_t *d_counts8, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->stats.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");
+    if (n_variants < 0 || (n_variants > 0 && (!d_gt || !d_counts8))) return fail(ctx, HPGV_ERR_INVALID, "bad scan arguments");
+    if (n_variants == 0) return HPGV_OK;
+    if (((uintptr_t)d_gt & 15) || ((uintptr_t)d_counts8 & 15)) return fail(ctx, HPGV_ERR_INVALID, "device buffers must be 16-byte aligned");
+    DeviceGuard g(ctx->device);
+    const Layout &L = ctx->stats;
+    const int vpw = (int)ctx->vpw;
+    const long waves = ((long)n_variants + vpw - 1) / vpw;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    return launch_profiled(ctx, st, 0, [&] {
+        if (ctx->nontemporal)
+            hipLaunchKernelGGL((hpgv::k_stats_scan<true, kScanUnroll>), dim3(blocks), dim3(256), 0, st, d_gt, L.pitch,
+                               n_variants, L.chunks, L.n_samples, (int4 *)d_counts8, vpw);
+        else
+            hipLaunchKernelGGL((hpgv::k_stats_scan<false, kScanUnroll>), dim3(blocks), dim3(256), 0, st, d_gt, L.pitch,
+                               n_variants, L.chunks, L.n_samples, (int4 *)d_counts8, vpw);
+    });
+}
+
+int hpgv_stats_hwe_dev(hpgv_ctx *ctx, const int32_t *d_counts8, int n_variants, double *d_chi2,
+                       double *d_p, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (n_variants < 0 || (n_variants > 0 && (!d_counts8 || !d_chi2 || !d_p)))
+        return fail(ctx, HPGV_ERR_INVALID, "bad hwe arguments");
+    if (n_variants == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    return launch_profiled(ctx, st, 1, [&] {
+        hipLaunchKernelGGL(hpgv::k_stats_hwe, dim3((n_variants + 255) / 256), dim3(256), 0, st,
+                           (const int4 *)d_counts8, n_variants, d_chi2, d_p);
+    });
+}
+
+int hpgv_last_kernel_ms(hpgv_ctx *ctx, float *scan_ms, float *stats_ms) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    if (scan_ms) {
+        *scan_ms = -1.f;
+        if (ctx->have_scan_ev) {
+            HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
+            HIPCHK(ctx, hipEventElapsedTime(scan_ms, ctx->ev[0], ctx->ev[1]));
+        }
+    }
+    if (stats_ms) {
+        *stats_ms = -1.f;
+        if (ctx->have_stats_ev) {
+            HIPCHK(ctx, hipEventSynchronize(ctx->ev[3]));
+            HIPCHK(ctx, hipEventElapsedTime(stats_ms, ctx->ev[2], ctx->ev[3]));
+        }
+    }
+    return HPGV_OK;
+}
+
+/* ---- synchronous per-batch host entry points ------------------------------ */
+
+// slot buffers: 0 raw gt, 1 laid-out gt, 2 is_x, 3 counts, 4 doubles (3n), 5 int SoA
+static int stage_batch(hpgv_ctx *ctx, Slot *s, int which, const Layout &L, const uint8_t *gt, size_t pitch,
+                       int n_variants, const uint8_t *is_x, const uint8_t **d_isx_out) {
+    int rc;
+    if ((rc = ensure(ctx, s, 0, (size_t)n_variants * pitch))) return rc;
+    if ((rc = ensure(ctx, s, 1, (size_t)n_variants * L.pitch))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(s->buf[0], gt, (size_t)n_variants * pitch, hipMemcpyHostToDevice, s->stream));
+    *d_isx_out = nullptr;
+    if (is_x) {
+        if ((rc = ensure(ctx, s, 2, (size_t)n_variants))) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(s->buf[2], is_x, (size_t)n_variants, hipMemcpyHostToDevice, s->stream));
+        *d_isx_out = (const uint8_t *)s->buf[2];
+    }
+    return hpgv_layout_dev(ctx, which, (const uint8_t *)s->buf[0], pitch, n_variants, (uint8_t *)s->buf[1], s->stream);
+}
+
+int hpgv_assoc(hpgv_ctx *ctx, int task, const uint8_t *gt, size_t pitch, int n_variants, const uint8_t *is_x,
+               int32_t *A1, int32_t *A2, int32_t *U1, int32_t *U2, double *odds, double *chisq, double *p) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (task != HPGV_TASK_CHISQ && task != HPGV_TASK_FISHER) return fail(ctx, HPGV_ERR_INVALID, "task must be CHISQ or FISHER");
+    if (!ctx->assoc.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_cohort has not been called");
+    if (n_variants < 0 || (n_variants > 0 && (!gt || !A1 || !A2 || !U1 || !U2 || !odds || !p)))
+        return fail(ctx, HPGV_ERR_INVALID, "bad assoc arguments");
+    if (task == HPGV_TASK_CHISQ && n_variants > 0 && !chisq) return fail(ctx, HPGV_ERR_INVALID, "chisq output is NULL");
+    if (pitch < (size_t)ctx->assoc.n_samples) return fail(ctx, HPGV_ERR_INVALID, "pitch %zu < n_samples %d", pitch, ctx->assoc.n_samples);
+    if (n_variants == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    SlotLease lease(ctx);
+    int rc = acquire_slot(ctx, &lease.s);
+    if (rc) return rc;
+    Slot *s = lease.s;
+    const uint8_t *d_isx = nullptr;
+    if ((rc = stage_batch(ctx, s, HPGV_LAYOUT_ASSOC, ctx->assoc, gt, pitch, n_variants, is_x, &d_isx))) return rc;
+    const size_t n = (size_t)n_variants;
+    if ((rc = ensure(ctx, s, 3, n * 16))) return rc;
+    if ((rc = ensure(ctx, s, 4, n * 3 * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, s, 5, n * 4 * sizeof(int32_t)))) return rc;
+    int32_t *d_counts = (int32_t *)s->buf[3];
+    double *d_odds = (double *)s->buf[4], *d_chisq = d_odds + n, *d_p = d_odds + 2 * n;
+    int32_t *d_soa = (int32_t *)s->buf[5];
+    if ((rc = hpgv_assoc_scan_dev(ctx, (const uint8_t *)s->buf[1], n_variants, d_isx, d_counts, s->stream))) return rc;
+    if (task == HPGV_TASK_CHISQ) rc = hpgv_assoc_chisq_dev(ctx, d_counts, n_variants, d_odds, d_chisq, d_p, s->stream);
+    else rc = hpgv_assoc_fisher_dev(ctx, d_counts, n_variants, d_odds, d_p, s->stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(hpgv::k_counts_to_soa, dim3((n_variants + 255) / 256), dim3(256), 0, s->stream,
+                       (const int4 *)d_counts, n_variants, d_soa, d_soa + n, d_soa + 2 * n, d_soa + 3 * n);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(A1, d_soa, n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(A2, d_soa + n, n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(U1, d_soa + 2 * n, n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(U2, d_soa + 3 * n, n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(odds, d_odds, n * 8, hipMemcpyDeviceToHost, s->stream));
+    if (task == HPGV_TASK_CHISQ) HIPCHK(ctx, hipMemcpyAsync(chisq, d_chisq, n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(p, d_p, n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    return HPGV_OK;
+}
+
+int hpgv_tdt(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, const uint8_t *is_x,
+             int32_t *t1, int32_t *t2, double *odds, double *chisq, double *p) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->tdt.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_families has not been called");
+    if (n_variants < 0 || (n_variants > 0 && (!gt || !t1 || !t2 || !odds || !chisq || !p)))
+        return fail(ctx, HPGV_ERR_INVALID, "bad tdt arguments");
+    if (pitch < (size_t)ctx->tdt.n_samples) return fail(ctx, HPGV_ERR_INVALID, "pitch %zu < n_samples %d", pitch, ctx->tdt.n_samples);
+    if (n_variants == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    SlotLease lease(ctx);
+    int rc = acquire_slot(ctx, &lease.s);
+    if (rc) return rc;
+    Slot *s = lease.s;
+    const uint8_t *d_isx = nullptr;
+    if ((rc = stage_batch(ctx, s, HPGV_LAYOUT_TDT, ctx->tdt, gt, pitch, n_variants, is_x, &d_isx))) return rc;
+    const size_t n = (size_t)n_variants;
+    if ((rc = ensure(ctx, s, 3, n * 8))) return rc;
+    if ((rc = ensure(ctx, s, 4, n * 3 * sizeof(double)))) return rc;
+    int32_t *d_tu = (int32_t *)s->buf[3];
+    double *d_odds = (double *)s->buf[4], *d_chisq = d_odds + n, *d_p = d_odds + 2 * n;
+    if ((rc = hpgv_tdt_scan_dev(ctx, (const uint8_t *)s->buf[1], n_variants, d_isx, d_tu, s->stream))) return rc;
+    if ((rc = hpgv_tdt_stats_dev(ctx, d_tu, n_variants, d_odds, d_chisq, d_p, s->stream))) return rc;
+    std::vector<int32_t> tu(2 * n);
+    HIPCHK(ctx, hipMemcpyAsync(tu.data(), d_tu, n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(odds, d_odds, n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(chisq, d_chisq, n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(p, d_p, n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    for (size_t i = 0; i < n; ++i) { t1[i] = tu[2 * i]; t2[i] = tu[2 * i + 1]; }
+    return HPGV_OK;
+}
+
+int hpgv_stats(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, int32_t *counts8,
+               double *hwe_chi2, double *hwe_p) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->stats.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");
+    if (n_variants < 0 || (n_variants > 0 && (!gt || !counts8 || !hwe_chi2 || !hwe_p)))
+        return fail(ctx, HPGV_ERR_INVALID, "bad stats arguments");
+    if (pitch < (size_t)ctx->stats.n_samples) return fail(ctx, HPGV_ERR_INVALID, "pitch %zu < n_samples %d", pitch, ctx->stats.n_samples);
+    if (n_variants == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    SlotLease lease(ctx);
+    int rc = acquire_slot(ctx, &lease.s);
+    if (rc) return rc;
+    Slot *s = lease.s;
+    const uint8_t *d_isx = nullptr;
+    if ((rc = stage_batch(ctx, s, HPGV_LAYOUT_STATS, ctx->stats, gt, pitch, n_variants, nullptr, &d_isx))) return rc;
+    const size_t n = (size_t)n_variants;
+    if ((rc = ensure(ctx, s, 3, n * 32))) return rc;
+    if ((rc = ensure(ctx, s, 4, n * 2 * sizeof(double)))) return rc;
+    int32_t *d_c8 = (int32_t *)s->buf[3];
+    double *d_chi2 = (double *)s->buf[4], *d_p = d_chi2 + n;
+    if ((rc = hpgv_stats_scan_dev(ctx, (const uint8_t *)s->buf[1], n_variants, d_c8, s->stream))) return rc;
+    if ((rc = hpgv_stats_hwe_dev(ctx, d_c8, n_variants, d_chi2, d_p, s->stream))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(counts8, d_c8, n * 32, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hwe_chi2, d_chi2, n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hwe_p, d_p, n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    return HPGV_OK;
+}
+
+int hpgv_read_probe(hpgv_ctx *ctx, const uint8_t *d_buf, size_t bytes, int iters, float *ms) {
+    if (!ctx || !d_buf || !ms || iters <= 0 || ((uintptr_t)d_buf & 15)) return HPGV_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    const size_t n16 = bytes / 16;
+    hipEvent_t a, b;
+    HIPCHK(ctx, hipEventCreate(&a));
+    HIPCHK(ctx, hipEventCreate(&b));
+    const unsigned blocks = 256 * 8;
+    auto go = [&] {
+        if (ctx->nontemporal)
+            hipLaunchKernelGGL((hpgv::k_read_probe<true>), dim3(blocks), dim3(256), 0, nullptr, (const uint4 *)d_buf, n16, ctx->d_sink);
+        else
+            hipLaunchKernelGGL((hpgv::k_read_probe<false>), dim3(blocks), dim3(256), 0, nullptr, (const uint4 *)d_buf, n16, ctx->d_sink);
+    };
+    go();
+    HIPCHK(ctx, hipEventRecord(a, nullptr));
+    for (int i = 0; i < iters; ++i) go();
+    HIPCHK(ctx, hipEventRecord(b, nullptr));
+    HIPCHK(ctx, hipEventSynchronize(b));
+    float t = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&t, a, b));
+    *ms = t / iters;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return HPGV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,339 @@
+// hpgv_kernels.h -- CDNA4 (gfx950) kernels of the per-variant statistics path.
+//
+// All scans are HBM-read bound integer/byte work: one variant row per
+// wavefront, 16 B per lane per load (1 KiB per wave instruction), several loads
+// in flight, SWAR nibble counting in VGPRs, DPP + readlane wave reduction, one
+// small store per variant.  No LDS, no MFMA: there is no reuse and no dense
+// contraction on this path (DESIGN.md "Kernels").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hpgv {
+
+// ---------------------------------------------------------------------------
+// SWAR helpers on 4 packed genotype bytes (8 nibbles)
+// ---------------------------------------------------------------------------
+// bit 3 of every nibble set <=> that nibble is non-zero (2 x v_lshl_or_b32 + and)
+__device__ __forceinline__ uint32_t nib_nonzero(uint32_t x) {
+    uint32_t y = x | (x << 1);
+    y = y | (y << 2);
+    return y & 0x88888888u;
+}
+// bit 3 of every nibble set <=> that nibble is not 0xF
+__device__ __forceinline__ uint32_t nib_not_f(uint32_t x) { return nib_nonzero(~x); }
+
+// ---------------------------------------------------------------------------
+// wave-wide integer sum -> wave-uniform value (SGPR).  4 DPP adds reduce each
+// row of 16 lanes, 4 readlanes + scalar adds combine the 4 rows.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int wave_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
+template <bool NT>
+__device__ __forceinline__ uint4 load16(const uint4 *p) {
+    if constexpr (NT) {
+        // streamed once: keep it out of the way of the small cached vectors
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+        return make_uint4(t.x, t.y, t.z, t.w);
+    } else {
+        return *p;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// assoc scan.  Row layout: [affected | pad16 | unaffected | pad .. pitch), pad
+// bytes = 0xFF.  chunks = pitch/16 counted chunks, chunksA = affected chunks.
+//
+// Per 16-byte chunk two counts are taken:
+//   NZ  = nibbles != 0        (0xFF bytes give 2)
+//   NNF = nibbles != 0xF      (0xFF bytes give 0; strict rows have no half-missing)
+// and, for chromosome "X" rows only, BNZ = bytes whose two nibbles are both != 0.
+// With T = 2 * (bytes looked at, real or virtual 0xFF):
+//   autosome (assoc.c:108-125): allele1 count = zero nibbles of valid bytes = T - NZ
+//                               allele2 count = NZ + NNF - T
+//   chr X    (assoc.c:94-107) : n_valid = NNF/2, n_missing = T/2 - n_valid,
+//                               n_xx = BNZ - n_missing, n_00 = (T - NZ) - n_valid + n_xx
+// Per-lane partial sums of the two phenotype groups share one register
+// (affected in bits 0..15, unaffected in bits 16..31).
+// ---------------------------------------------------------------------------
+// one row, all lanes of the wave; X selects the chromosome-"X" extra count
+template <bool NT, int U, bool X>
+__device__ __forceinline__ void assoc_row(const uint4 *__restrict__ row, int lane, int chunksA,
+                                          int chunks, uint32_t &pnz, uint32_t &pnnf, uint32_t &pbnz) {
+    for (int base = 0; base < chunks; base += 64 * U) {
+        uint4 q[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = base + u * 64 + lane;
+            q[u] = make_uint4(~0u, ~0u, ~0u, ~0u);     // virtual chunk = all missing
+            if (c < chunks) q[u] = load16<NT>(row + c);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = base + u * 64 + lane;
+            const uint32_t sh = (c < chunksA) ? 0u : 16u;
+            const uint32_t w[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+            uint32_t nz = 0, nnf = 0, bnz = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t ind = nib_nonzero(w[k]);
+                nz += __builtin_popcount(ind);
+                nnf += __builtin_popcount(nib_not_f(w[k]));
+                if constexpr (X) bnz += __builtin_popcount(ind & (ind >> 4) & 0x08080808u);
+            }
+            pnz += nz << sh;
+            pnnf += nnf << sh;
+            if constexpr (X) pbnz += bnz << sh;
+        }
+    }
+}
+
+template <bool NT, int U>
+__global__ __launch_bounds__(256) void k_assoc_scan(const uint8_t *__restrict__ gt, size_t pitch,
+                                                    int n_variants, int chunksA, int chunks,
+                                                    const uint8_t *__restrict__ is_x,
+                                                    int4 *__restrict__ counts, int vpw) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long v_begin = wave * vpw;
+    // every wave looks at `slots` chunk slots per row; slots past `chunks` are
+    // virtual all-0xFF chunks booked on the unaffected group
+    const int slots = ((chunks + 64 * U - 1) / (64 * U)) * (64 * U);
+    const int TA = 32 * chunksA;
+    const int TU = 32 * (slots - chunksA);
+
+    for (int i = 0; i < vpw; ++i) {
+        const long v = v_begin + i;
+        if (v >= n_variants) break;                      // wave-uniform
+        const uint4 *row = reinterpret_cast<const uint4 *>(gt + (size_t)v * pitch);
+        const bool x_row = (is_x != nullptr) && (__builtin_amdgcn_readfirstlane((int)is_x[v]) != 0);
+        uint32_t pnz = 0, pnnf = 0, pbnz = 0;
+        if (x_row) assoc_row<NT, U, true>(row, lane, chunksA, chunks, pnz, pnnf, pbnz);
+        else       assoc_row<NT, U, false>(row, lane, chunksA, chunks, pnz, pnnf, pbnz);
+
+        const int nzA = wave_sum((int)(pnz & 0xFFFFu)), nzU = wave_sum((int)(pnz >> 16));
+        const int nfA = wave_sum((int)(pnnf & 0xFFFFu)), nfU = wave_sum((int)(pnnf >> 16));
+        int4 out;
+        if (!x_row) {
+            out.x = TA - nzA;            // A1
+            out.y = nzA + nfA - TA;      // A2
+            out.z = TU - nzU;            // U1
+            out.w = nzU + nfU - TU;      // U2
+        } else {
+            const int bA = wave_sum((int)(pbnz & 0xFFFFu)), bU = wave_sum((int)(pbnz >> 16));
+            const int validA = nfA >> 1, validU = nfU >> 1;
+            const int xxA = bA - (TA / 2 - validA), xxU = bU - (TU / 2 - validU);
+            out.x = (TA - nzA) - validA + xxA;
+            out.y = xxA;
+            out.z = (TU - nzU) - validU + xxU;
+            out.w = xxU;
+        }
+        if (lane == 0) counts[v] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// chi-square statistics from the counts (assoc_basic_test.c:23-41,58-61).
+// One thread per variant; same operation order as the reference (the file is
+// built with -ffp-contract=off so no FMA is formed).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double chisq_p_value(double x) {
+    // 1 - gsl_cdf_chisq_P(x, 1): see oracle/hpgv_oracle.c orc_chisq_p_value
+    if (x != x) return x;
+    if (x <= 0.0) return 1.0;
+    const double y = x / 2.0;
+    double P;
+    if (y > 0.5) P = 1.0 - erfc(sqrt(y));
+    else         P = erf(sqrt(y));
+    return 1.0 - P;
+}
+
+__device__ __forceinline__ double assoc_odds(int A1, int A2, int U1, int U2) {
+    return (A2 == 0 || U1 == 0) ? __builtin_nan("") : ((double)A1 / A2) * ((double)U2 / U1);
+}
+
+__global__ __launch_bounds__(256) void k_assoc_chisq(const int4 *__restrict__ counts, int n,
+                                                     double *__restrict__ odds,
+                                                     double *__restrict__ chisq,
+                                                     double *__restrict__ pval) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c4 = counts[i];
+    const int a = c4.x, c = c4.y, b = c4.z, d = c4.w;   // assoc.c:61: (A1, U1, A2, U2)
+    const double total = a + c + b + d;
+    const double t_aff = a + c, t_un = b + d, t_1 = a + b, t_2 = c + d;
+    const double e_a1 = (t_aff * t_1) / total;
+    const double e_a2 = (t_aff * t_2) / total;
+    const double e_u1 = (t_un * t_1) / total;
+    const double e_u2 = (t_un * t_2) / total;
+    const double x = ((a - e_a1) * (a - e_a1)) / e_a1 + ((c - e_a2) * (c - e_a2)) / e_a2 +
+                     ((b - e_u1) * (b - e_u1)) / e_u1 + ((d - e_u2) * (d - e_u2)) / e_u2;
+    odds[i] = assoc_odds(a, c, b, d);
+    chisq[i] = x;
+    pval[i] = chisq_p_value(x);
+}
+
+// ---------------------------------------------------------------------------
+// Fisher's exact test, two-sided (assoc_fisher_test.c:24-26; definition in
+// oracle/hpgv_oracle.c orc_fisher_two_sided).  One wave per variant; lanes
+// stride over the admissible tables; the log-factorial table (<= a few MB)
+// is L2 / Infinity-Cache resident.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assoc_fisher(const int4 *__restrict__ counts, int n,
+                                                      const double *__restrict__ lf,
+                                                      double *__restrict__ odds,
+                                                      double *__restrict__ pval) {
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (v >= n) return;
+    const int4 c4 = counts[v];
+    const int a = c4.x, b = c4.y, c = c4.z, d = c4.w;   // assoc.c:70: (A1, A2, U1, U2)
+    const int r1 = a + b, r2 = c + d, c1 = a + c, nn = r1 + r2;
+    const int lo = (c1 - r2) > 0 ? (c1 - r2) : 0;
+    const int hi = r1 < c1 ? r1 : c1;
+    const double konst = lf[r1] + lf[r2] + lf[c1] + lf[nn - c1] - lf[nn];
+    const double p_obs = exp(konst - lf[a] - lf[r1 - a] - lf[c1 - a] - lf[r2 - c1 + a]);
+    const double thr = p_obs * (1.0 + 1e-7);
+    double sum = 0.0;
+    for (int x = lo + lane; x <= hi; x += 64) {
+        const double p = exp(konst - lf[x] - lf[r1 - x] - lf[c1 - x] - lf[r2 - c1 + x]);
+        if (p <= thr) sum += p;
+    }
+    // wave reduction in a fixed order (deterministic run to run)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) {
+        odds[v] = assoc_odds(a, b, c, d);
+        pval[v] = sum > 1.0 ? 1.0 : sum;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// synthetic cohort: bit-reproducible with oracle/hpgv_oracle.c
+// ---------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+#define HPGV_SYNTH_SEED 0x4850475631ULL
+
+__global__ void k_synth_thresholds(uint64_t v0, int n, uint32_t *__restrict__ thr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t v = v0 + (uint64_t)i;
+    const uint64_t h = splitmix64(HPGV_SYNTH_SEED ^ 0xA11E1EULL ^ v);
+    const double u = (double)(h >> 11) * (1.0 / 9007199254740992.0);
+    const double q = 0.05 + 0.45 * u;
+    const uint32_t t_miss = 167772u;
+    const double rest = (double)(16777216u - t_miss);
+    const double omq = 1.0 - q;
+    const double p00 = omq * omq;
+    const double p01 = 2.0 * q * omq;
+    const uint32_t t00 = t_miss + (uint32_t)floor(p00 * rest);
+    const uint32_t t01 = t00 + (uint32_t)floor(p01 * rest);
+    thr[3 * i + 0] = t_miss; thr[3 * i + 1] = t00; thr[3 * i + 2] = t01;
+}
+
+__device__ __forceinline__ uint32_t synth_gt(uint64_t vterm, uint64_t s, uint32_t tm, uint32_t t0,
+                                             uint32_t t1) {
+    const uint32_t r = (uint32_t)(splitmix64(vterm + s) >> 40);
+    return (r < tm) ? 0xFFu : (r < t0) ? 0x00u : (r < t1) ? 0x01u : 0x11u;
+}
+
+// one thread per 16-byte chunk of the destination row; col_of_pos[p] = VCF column
+// stored at row position p, or -1 for padding (0xFF).
+__global__ __launch_bounds__(256) void k_synth_layout(uint64_t v0, int n_variants, size_t pitch,
+                                                      int chunks, const int32_t *__restrict__ col_of_pos,
+                                                      const uint32_t *__restrict__ thr,
+                                                      uint8_t *__restrict__ dst) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n_variants * chunks;
+    if (t >= total) return;
+    const int i = (int)(t / chunks), c = (int)(t % chunks);
+    const uint64_t v = v0 + (uint64_t)i;
+    const uint64_t vterm = HPGV_SYNTH_SEED + v * 0x9E3779B97F4A7C15ULL;
+    const uint32_t tm = thr[3 * i], t0 = thr[3 * i + 1], t1 = thr[3 * i + 2];
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = col_of_pos[c * 16 + k * 4 + j];
+            const uint32_t g = (col < 0) ? 0xFFu : synth_gt(vterm, (uint64_t)col, tm, t0, t1);
+            acc |= g << (8 * j);
+        }
+        w[k] = acc;
+    }
+    *reinterpret_cast<uint4 *>(dst + (size_t)i * pitch + (size_t)c * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ---------------------------------------------------------------------------
+// layout (column gather) kernel: dst[v][p] = src[v][col_of_pos[p]], pads 0xFF.
+// strict != 0 turns any byte with a missing allele into 0xFF (assoc / tdt drop
+// such genotypes: assoc.c:53, tdt.c:103-108,154).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_layout(const uint8_t *__restrict__ src, size_t src_pitch,
+                                                int n_variants, size_t pitch, int chunks,
+                                                const int32_t *__restrict__ col_of_pos, int strict,
+                                                uint8_t *__restrict__ dst) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n_variants * chunks;
+    if (t >= total) return;
+    const int i = (int)(t / chunks), c = (int)(t % chunks);
+    const uint8_t *row = src + (size_t)i * src_pitch;
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = col_of_pos[c * 16 + k * 4 + j];
+            uint32_t g = (col < 0) ? 0xFFu : (uint32_t)row[col];
+            if (strict && (((g & 0xF) == 0xF) || ((g >> 4) == 0xF))) g = 0xFFu;
+            acc |= g << (8 * j);
+        }
+        w[k] = acc;
+    }
+    *reinterpret_cast<uint4 *>(dst + (size_t)i * pitch + (size_t)c * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// de-interleave helpers for the host entry points
+__global__ void k_counts_to_soa(const int4 *__restrict__ counts, int n, int32_t *A1, int32_t *A2,
+                                int32_t *U1, int32_t *U2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = counts[i];
+    A1[i] = c.x; A2[i] = c.y; U1[i] = c.z; U2[i] = c.w;
+}
+
+// ---------------------------------------------------------------------------
+// streaming-read probe: the scan's load shape with one OR per dword, so the
+// measured time is the memory system's, not the ALU's.
+// ---------------------------------------------------------------------------
+template <bool NT>
+__global__ __launch_bounds__(256) void k_read_probe(const uint4 *__restrict__ buf, size_t n16,
+                                                    uint32_t *__restrict__ sink) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = load16<NT>(buf + i), b = load16<NT>(buf + i + stride);
+        const uint4 c = load16<NT>(buf + i + 2 * stride), d = load16<NT>(buf + i + 3 * stride);
+        acc |= a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w | c.x | c.y | c.z | c.w | d.x | d.y | d.z | d.w;
+    }
+    for (; i < n16; i += stride) { const uint4 a = load16<NT>(buf + i); acc |= a.x | a.y | a.z | a.w; }
+    if (acc == 0x12345678u) sink[0] = acc;   // practically never; keeps the loads alive
+}
+
+}  // namespace hpgv

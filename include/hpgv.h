@@ -1,0 +1,175 @@
+/*
+ * hpgv.h -- C ABI of the MI355X-native per-variant statistics engine.
+ *
+ * This is the drop-in boundary for opencb/hpg-variant's per-batch hot path.
+ * Each entry point names the reference interface it stands behind (paths are
+ * relative to the reference tree):
+ *
+ *   hpgv_assoc*      <- assoc_test()            src/gwas/assoc/assoc.h:137-138, assoc.c:23-84
+ *                       assoc_count_individual  src/gwas/assoc/assoc.c:87-134
+ *                       assoc_basic_test/result src/gwas/assoc/assoc_basic_test.c:23-64
+ *                       assoc_fisher_test       src/gwas/assoc/assoc_fisher_test.c:24-26
+ *   hpgv_set_logfact <- init_logarithm_array()  call site src/gwas/assoc/assoc_runner.c:164-166
+ *   hpgv_tdt*        <- tdt_test()              src/gwas/tdt/tdt.h:119, tdt.c:23-276
+ *                       tdt_result_new          src/gwas/tdt/tdt.c:279-295
+ *   hpgv_stats*      <- get_variants_stats()    call site src/vcf-tools/stats/stats_runner.c:194-195
+ *   hpgv_set_cohort  <- sort_individuals() + individual->condition
+ *                                               src/gwas/assoc/assoc_runner.c:138-140, assoc.c:95,101
+ *   hpgv_set_families<- ped_flatten_families() + family->founders/members walk
+ *                                               src/gwas/tdt/tdt_runner.c:87, tdt.c:56-95,135-148
+ *
+ * Plain C: opaque context, plain pointers and sizes, int status codes, caller
+ * allocated outputs.  No function aborts; hpgv_last_error() gives the text.
+ * The library has NO CPU fallback: without a usable HIP device hpgv_create()
+ * fails with HPGV_ERR_NO_DEVICE.
+ *
+ * Genotype code (one byte per call, "HPGV8"):
+ *      byte = (allele1 << 4) | allele2      allele index 0..14 (clamped),
+ *      nibble 0xF = missing allele, 0xFF = missing / unusable genotype.
+ *   Biallelic data uses 0x00 0x01 0x10 0x11 0xFF.  The ORDER of the alleles is
+ *   kept because tdt.c:119,176-213 tests them in order.
+ */
+#ifndef HPGV_H
+#define HPGV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPGV_GT_MISSING 0xFF
+
+/* status codes */
+enum {
+    HPGV_OK = 0,
+    HPGV_ERR_INVALID = 1,      /* bad argument */
+    HPGV_ERR_NO_DEVICE = 2,    /* no usable HIP device */
+    HPGV_ERR_HIP = 3,          /* a HIP runtime call failed */
+    HPGV_ERR_NOMEM = 4,
+    HPGV_ERR_STATE = 5,        /* e.g. scan before the cohort was set */
+    HPGV_ERR_UNSUPPORTED = 6   /* shape outside the engine's limits */
+};
+
+/* enum ASSOC_task of assoc.h:55 */
+enum { HPGV_TASK_NONE = 0, HPGV_TASK_CHISQ = 1, HPGV_TASK_FISHER = 2 };
+/* individual->condition / ->sex by meaning (hpg-libs enums are not in the tree) */
+enum { HPGV_COND_UNAFFECTED = 0, HPGV_COND_AFFECTED = 1, HPGV_COND_OTHER = 2 };
+enum { HPGV_SEX_MALE = 0, HPGV_SEX_FEMALE = 1, HPGV_SEX_UNKNOWN = 2 };
+
+typedef struct hpgv_ctx hpgv_ctx;
+
+/* ---- lifetime ------------------------------------------------------------ */
+const char *hpgv_version(void);
+int  hpgv_device_count(void);                       /* <0 on HIP failure */
+int  hpgv_create(int device_id, hpgv_ctx **out);
+void hpgv_destroy(hpgv_ctx *ctx);
+/* text of the last failure on this ctx (ctx == NULL: last hpgv_create failure
+ * of the calling thread) */
+const char *hpgv_last_error(const hpgv_ctx *ctx);
+/* tuning knobs: "row_align" (bytes, power of two >= 16, default 128),
+ * "variants_per_wave", "nontemporal" (0/1), "profile" (0/1) */
+int  hpgv_set_option(hpgv_ctx *ctx, const char *key, long value);
+
+/* ---- cohort description (replicated per device; tiny) --------------------- */
+/* condition[j] for VCF column j (HPGV_COND_*).  Builds the assoc layout:
+ * [affected columns | pad to 16 B | unaffected columns | pad], others dropped. */
+int  hpgv_set_cohort(hpgv_ctx *ctx, const uint8_t *condition, int n_samples);
+int  hpgv_assoc_layout(const hpgv_ctx *ctx, int *n_affected, int *n_unaffected, size_t *pitch);
+
+/* Families in CSR form, already filtered the way tdt.c does: family f has VCF
+ * columns father_col[f] / mother_col[f] (<0: founder missing or not in the VCF,
+ * family skipped, tdt.c:77-95) and its counted children
+ * child_off[f]..child_off[f+1]-1 = members with both parents set, AFFECTED and
+ * present in the VCF (tdt.c:139-148), in family->members iteration order. */
+int  hpgv_set_families(hpgv_ctx *ctx, int n_samples, int n_families,
+                       const int32_t *father_col, const int32_t *mother_col,
+                       const int32_t *child_off, const int32_t *child_col,
+                       const uint8_t *child_sex);
+int  hpgv_tdt_layout(const hpgv_ctx *ctx, int *n_trios_fast, int *n_families_slow, size_t *pitch);
+
+/* table[i] = ln(i!) for i < n, as init_logarithm_array(num_samples*10) builds it.
+ * Must cover 2*n_samples+1 entries for the Fisher pass. */
+int  hpgv_set_logfact(hpgv_ctx *ctx, const double *table, size_t n);
+
+/* stats layout: all n_samples columns in VCF order, pad to 16 B */
+int  hpgv_set_stats_cohort(hpgv_ctx *ctx, int n_samples);
+int  hpgv_stats_layout(const hpgv_ctx *ctx, size_t *pitch);
+
+/* ---- device memory + streams (thin; callers may also pass memory owned by
+ *      another runtime, e.g. a torch tensor's data_ptr) ---------------------- */
+int  hpgv_dev_alloc(hpgv_ctx *ctx, size_t bytes, void **dptr);
+int  hpgv_dev_free(hpgv_ctx *ctx, void *dptr);
+int  hpgv_memcpy_h2d(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream);
+int  hpgv_memcpy_d2h(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream);
+int  hpgv_stream_sync(hpgv_ctx *ctx, void *stream);   /* stream NULL = default stream */
+
+/* ---- layout kernels: VCF-order code matrix (device) -> engine layout ------ */
+/* which: 0 assoc, 1 tdt, 2 stats.  d_src rows are src_pitch bytes apart and hold
+ * n_samples codes in VCF column order; d_dst rows use the layout's pitch. */
+enum { HPGV_LAYOUT_ASSOC = 0, HPGV_LAYOUT_TDT = 1, HPGV_LAYOUT_STATS = 2 };
+int  hpgv_layout_dev(hpgv_ctx *ctx, int which, const uint8_t *d_src, size_t src_pitch,
+                     int n_variants, uint8_t *d_dst, void *stream);
+
+/* ---- synthetic cohort generator, written directly in the
+ *      engine layout `which`; variant ids v0..v0+n_variants-1 ------------------ */
+int  hpgv_synth_dev(hpgv_ctx *ctx, int which, uint64_t v0, int n_variants,
+                    uint8_t *d_dst, void *stream);
+/* same genotypes in plain VCF column order (for staging tests) */
+int  hpgv_synth_raw_dev(hpgv_ctx *ctx, uint64_t v0, int n_variants, int n_samples,
+                        size_t pitch, uint8_t *d_dst, void *stream);
+
+/* ---- the hot path on device-resident data (asynchronous on `stream`) ------ */
+/* scan: d_gt in assoc layout -> d_counts[v] = {A1, A2, U1, U2} (int32 x4).
+ * d_is_x: per-variant flag "chromosome is exactly X" (assoc.c:94) or NULL. */
+int  hpgv_assoc_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants,
+                         const uint8_t *d_is_x, int32_t *d_counts, void *stream);
+/* statistics from the counts; SoA outputs of n_variants doubles each */
+int  hpgv_assoc_chisq_dev(hpgv_ctx *ctx, const int32_t *d_counts, int n_variants,
+                          double *d_odds, double *d_chisq, double *d_p, void *stream);
+int  hpgv_assoc_fisher_dev(hpgv_ctx *ctx, const int32_t *d_counts, int n_variants,
+                           double *d_odds, double *d_p, void *stream);
+
+/* d_gt in tdt layout -> d_tu[v] = {t1, t2} (int32 x2) */
+int  hpgv_tdt_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants,
+                       const uint8_t *d_is_x, int32_t *d_tu, void *stream);
+int  hpgv_tdt_stats_dev(hpgv_ctx *ctx, const int32_t *d_tu, int n_variants,
+                        double *d_odds, double *d_chisq, double *d_p, void *stream);
+
+/* d_gt in stats layout -> per variant 8 x int32:
+ *   {n_00, n_01, n_10, n_11, missing_genotypes, missing_alleles, n_other, 0}
+ * (biallelic cells of genotypes_count[a1*2+a2]; n_other = genotypes touching an
+ * allele index >= 2) and Hardy-Weinberg chi2 / p on (n_00, n_01+n_10, n_11). */
+int  hpgv_stats_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants,
+                         int32_t *d_counts8, void *stream);
+int  hpgv_stats_hwe_dev(hpgv_ctx *ctx, const int32_t *d_counts8, int n_variants,
+                        double *d_chi2, double *d_p, void *stream);
+
+/* duration (ms) of the last scan / statistics kernel launched through this ctx
+ * when option "profile" = 1 (HIP events on the launch stream; synchronises) */
+int  hpgv_last_kernel_ms(hpgv_ctx *ctx, float *scan_ms, float *stats_ms);
+
+/* ---- per-batch host entry points (synchronous; what assoc_test / tdt_test /
+ *      get_variants_stats adapters call).  gt: host, variant-major, VCF column
+ *      order, rows `pitch` bytes apart.  Outputs: caller-allocated arrays of
+ *      n_variants elements; chisq may be NULL for Fisher.  Thread-safe: may be
+ *      called concurrently from the runner's worker threads. ---------------- */
+int  hpgv_assoc(hpgv_ctx *ctx, int task, const uint8_t *gt, size_t pitch, int n_variants,
+                const uint8_t *is_x,
+                int32_t *A1, int32_t *A2, int32_t *U1, int32_t *U2,
+                double *odds, double *chisq, double *p);
+int  hpgv_tdt(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants,
+              const uint8_t *is_x, int32_t *t1, int32_t *t2,
+              double *odds, double *chisq, double *p);
+int  hpgv_stats(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants,
+                int32_t *counts8 /* n_variants x 8 */, double *hwe_chi2, double *hwe_p);
+
+/* streaming-read ceiling probe: reads `bytes` from d_buf with the scan's load
+ * shape and no arithmetic; returns the kernel time in ms (diagnostic) */
+int  hpgv_read_probe(hpgv_ctx *ctx, const uint8_t *d_buf, size_t bytes, int iters, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

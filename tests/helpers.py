@@ -1,0 +1,89 @@
+"""Shared helpers for the parity tests (HIP path through the C ABI vs the oracle)."""
+import importlib
+
+import numpy as np
+
+from oracle import pyoracle as orc
+
+hpgv = importlib.import_module("hpg-variant_amd")
+
+TOL = 1e-10   # north_star: chi2 / Fisher / HWE p-values within 1e-10 of the reference path
+
+
+def close(got, exp, tol=TOL):
+    """|d| <= tol * max(1, |exp|), NaN == NaN, inf == inf."""
+    got = np.asarray(got, dtype=np.float64)
+    exp = np.asarray(exp, dtype=np.float64)
+    both_nan = np.isnan(got) & np.isnan(exp)
+    same_inf = np.isinf(got) & np.isinf(exp) & (np.sign(got) == np.sign(exp))
+    with np.errstate(invalid="ignore"):
+        ok = np.abs(got - exp) <= tol * np.maximum(1.0, np.abs(exp))
+    return bool(np.all(ok | both_nan | same_inf))
+
+
+def assert_close(got, exp, what="", tol=TOL):
+    if not close(got, exp, tol):
+        got = np.asarray(got); exp = np.asarray(exp)
+        with np.errstate(invalid="ignore"):
+            bad = ~((np.abs(got - exp) <= tol * np.maximum(1.0, np.abs(exp))) |
+                    (np.isnan(got) & np.isnan(exp)) | (np.isinf(got) & np.isinf(exp)))
+        idx = np.flatnonzero(bad)[:5]
+        raise AssertionError("%s: %d mismatches, first at %s: got %s expected %s" %
+                             (what, bad.sum(), idx, got[idx], exp[idx]))
+
+
+# genotype strings covering every branch of assoc.c:94-125 and tdt.c:103-213
+QUIRK_GTS = ["0/0", "0/1", "1/0", "1/1", "1/2", "2/1", "0/2", "2/0", "./.", "./1", "0/.", "1|0", "0|1",
+             "1", ".", "3/3", "14/0", "20/20"]
+
+
+def random_codes(rng, n_variants, n_samples, quirks=True, strict=True, p_missing=0.05):
+    """Random HPGV8 matrix in VCF column order."""
+    if quirks:
+        table = np.array([orc.encode_sample(s, 0, strict) for s in QUIRK_GTS], dtype=np.uint8)
+        w = np.ones(len(table)); w[:4] = 6.0
+        idx = rng.choice(len(table), size=(n_variants, n_samples), p=w / w.sum())
+        return table[idx]
+    base = np.array([0x00, 0x01, 0x11, 0xFF], dtype=np.uint8)
+    p = np.array([0.45, 0.35, 0.2 - p_missing, p_missing])
+    return base[rng.choice(4, size=(n_variants, n_samples), p=p)]
+
+
+def oracle_assoc(task, gt, condition, is_x=None, lf=None):
+    A1, A2, U1, U2 = orc.assoc_counts(gt, condition, is_x)
+    odds, chisq, p = orc.assoc_stats(task, A1, A2, U1, U2, lf)
+    return dict(A1=A1, A2=A2, U1=U1, U2=U2, odds=odds, chisq=chisq, p=p)
+
+
+def check_assoc(res, exp, task):
+    for k in ("A1", "A2", "U1", "U2"):
+        assert np.array_equal(res[k], exp[k]), "%s differs (bit-exact required)" % k
+    assert_close(res["odds"], exp["odds"], "odds")
+    if task == hpgv.TASK_CHISQ:
+        assert_close(res["chisq"], exp["chisq"], "chisq")
+    assert_close(res["p"], exp["p"], "p")
+
+
+def make_families(rng, n_samples, n_families, max_children=1, p_absent=0.0):
+    """Random pedigree over distinct VCF columns -> CSR arrays of hpgv_set_families."""
+    cols = rng.permutation(n_samples)
+    pos = 0
+    fcol, mcol, coff, ccol, csex = [], [], [0], [], []
+    for _ in range(n_families):
+        nc = int(rng.integers(1, max_children + 1)) if max_children > 1 else 1
+        if rng.random() < 0.1 and max_children > 1:
+            nc = 0
+        need = 2 + nc
+        if pos + need > n_samples:
+            break
+        f, m = int(cols[pos]), int(cols[pos + 1])
+        if rng.random() < p_absent:
+            f = -1
+        fcol.append(f); mcol.append(m)
+        for k in range(nc):
+            ccol.append(int(cols[pos + 2 + k]))
+            csex.append(int(rng.integers(0, 2)))
+        coff.append(len(ccol))
+        pos += need
+    return (np.array(fcol, np.int32), np.array(mcol, np.int32), np.array(coff, np.int32),
+            np.array(ccol, np.int32), np.array(csex, np.uint8))

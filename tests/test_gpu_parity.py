@@ -1,0 +1,333 @@
+"""GPU parity tests: the HIP path, called through the C ABI (include/hpgv.h),
+against the CPU oracle on the same inputs.  Integer tallies bit-exact, FP64
+statistics within 1e-10 (NaN == NaN).  Run with -m gpu on an MI355X."""
+import numpy as np
+import pytest
+
+from helpers import (QUIRK_GTS, assert_close, check_assoc, hpgv, make_families, oracle_assoc,
+                     random_codes)
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = hpgv.Engine(0)      # raises when libhpgv.so or the device is missing: no fallback
+    yield e
+    e.close()
+
+
+def fresh():
+    return hpgv.Engine(0)
+
+
+# ---------------------------------------------------------------- assoc ----
+
+@pytest.mark.parametrize("n_samples", [1, 2, 15, 16, 17, 31, 33, 100, 1000, 4099, 10007])
+def test_assoc_chisq_ragged_shapes(n_samples):
+    rng = np.random.default_rng(n_samples)
+    e = fresh()
+    cond = rng.choice([0, 1, 2], size=n_samples, p=[0.45, 0.45, 0.1]).astype(np.uint8)
+    e.set_cohort(cond)
+    for nv in (1, 3, 64, 257):
+        gt = random_codes(rng, nv, n_samples)
+        is_x = (rng.random(nv) < 0.3).astype(np.uint8)
+        res = e.assoc(hpgv.TASK_CHISQ, gt, is_x)
+        check_assoc(res, oracle_assoc(orc.TASK_CHISQ, gt, cond, is_x), hpgv.TASK_CHISQ)
+        res = e.assoc(hpgv.TASK_CHISQ, gt, None)
+        check_assoc(res, oracle_assoc(orc.TASK_CHISQ, gt, cond, None), hpgv.TASK_CHISQ)
+    e.close()
+
+
+def test_assoc_degenerate_cohorts():
+    rng = np.random.default_rng(7)
+    for cond in ([1] * 40, [0] * 40, [2] * 40, [1] + [0] * 39, []):
+        e = fresh()
+        cond = np.array(cond, dtype=np.uint8)
+        e.set_cohort(cond)
+        gt = random_codes(rng, 10, len(cond)) if len(cond) else np.zeros((10, 0), np.uint8)
+        if len(cond) == 0:
+            gt = np.zeros((10, 16), np.uint8)[:, :0]
+            gt = np.ascontiguousarray(np.zeros((10, 1), np.uint8))   # pitch 1 >= n_samples 0
+            exp = oracle_assoc(orc.TASK_CHISQ, np.zeros((10, 0), np.uint8), cond)
+        else:
+            exp = oracle_assoc(orc.TASK_CHISQ, gt, cond)
+        res = e.assoc(hpgv.TASK_CHISQ, gt)
+        check_assoc(res, exp, hpgv.TASK_CHISQ)   # zero margins: chi2 NaN, p NaN, OR NaN
+        e.close()
+
+
+def test_assoc_empty_batch(eng):
+    eng.set_cohort(np.array([0, 1] * 8, dtype=np.uint8))
+    res = eng.assoc(hpgv.TASK_CHISQ, np.zeros((0, 16), np.uint8))
+    assert len(res["A1"]) == 0
+
+
+def test_assoc_all_missing_and_all_one_class():
+    e = fresh()
+    cond = np.array([0, 1] * 500, dtype=np.uint8)
+    e.set_cohort(cond)
+    for code in (0xFF, 0x00, 0x11, 0x01, 0x10, 0xEE):
+        gt = np.full((5, 1000), code, dtype=np.uint8)
+        for is_x in (None, np.ones(5, np.uint8)):
+            check_assoc(e.assoc(hpgv.TASK_CHISQ, gt, is_x), oracle_assoc(orc.TASK_CHISQ, gt, cond, is_x),
+                        hpgv.TASK_CHISQ)
+    e.close()
+
+
+def test_assoc_half_missing_is_dropped():
+    # staging must canonicalise "./1"-style bytes (0xF1, 0x1F) to missing: assoc.c:53
+    e = fresh()
+    cond = np.array([0, 1] * 50, dtype=np.uint8)
+    e.set_cohort(cond)
+    rng = np.random.default_rng(3)
+    gt = random_codes(rng, 20, 100, strict=False)
+    assert ((gt & 0xF) == 0xF).any()
+    strict = gt.copy()
+    strict[((gt & 0xF) == 0xF) | ((gt >> 4) == 0xF)] = 0xFF
+    check_assoc(e.assoc(hpgv.TASK_CHISQ, gt), oracle_assoc(orc.TASK_CHISQ, strict, cond), hpgv.TASK_CHISQ)
+    e.close()
+
+
+@pytest.mark.parametrize("n_samples,nv", [(40, 50), (600, 200), (3001, 64)])
+def test_assoc_fisher(n_samples, nv):
+    rng = np.random.default_rng(100 + n_samples)
+    e = fresh()
+    cond = rng.choice([0, 1], size=n_samples).astype(np.uint8)
+    e.set_cohort(cond)
+    lf = orc.logfact(n_samples * 10)          # assoc_runner.c:164-166
+    e.set_logfact(lf)
+    gt = random_codes(rng, nv, n_samples, quirks=False)
+    # push some variants towards strong association so tiny p-values are covered
+    gt[: nv // 4, cond == 1] = 0x11
+    res = e.assoc(hpgv.TASK_FISHER, gt)
+    check_assoc(res, oracle_assoc(orc.TASK_FISHER, gt, cond, None, lf), hpgv.TASK_FISHER)
+    e.close()
+
+
+def test_fisher_needs_table():
+    e = fresh()
+    e.set_cohort(np.array([0, 1] * 8, dtype=np.uint8))
+    with pytest.raises(hpgv.HpgvError):
+        e.assoc(hpgv.TASK_FISHER, np.zeros((2, 16), np.uint8))
+    e.set_logfact(orc.logfact(8))              # too short for 32 alleles
+    with pytest.raises(hpgv.HpgvError):
+        e.assoc(hpgv.TASK_FISHER, np.zeros((2, 16), np.uint8))
+    e.close()
+
+
+def test_concurrent_batches_like_the_runner():
+    # assoc_runner.c:106-207: num_threads workers call assoc_test concurrently
+    import threading
+    e = fresh()
+    n = 2000
+    cond = (np.arange(n) % 2).astype(np.uint8)
+    e.set_cohort(cond)
+    out, errs = {}, []
+
+    def work(t):
+        try:
+            rng = np.random.default_rng(t)
+            for _ in range(5):
+                gt = random_codes(rng, 200, n)
+                check_assoc(e.assoc(hpgv.TASK_CHISQ, gt), oracle_assoc(orc.TASK_CHISQ, gt, cond), hpgv.TASK_CHISQ)
+            out[t] = True
+        except Exception as ex:       # pragma: no cover
+            errs.append(ex)
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    assert len(out) == 4
+    e.close()
+
+
+# ------------------------------------------------------------- synthetic ----
+
+def test_synth_matches_oracle_bit_for_bit(eng):
+    nv, ns, pitch = 300, 1234, 1248
+    d = eng.alloc(nv * pitch)
+    eng.synth_raw(5000, nv, ns, pitch, d)
+    got = eng.d2h(d, (nv, pitch), np.uint8)
+    exp = orc.synth_matrix(5000, nv, ns, pitch)
+    assert np.array_equal(got, exp)
+    eng.free(d)
+
+
+def test_device_resident_assoc_on_synthetic_cohort():
+    e = fresh()
+    ns, nv = 10000, 4096
+    cond = (np.arange(ns) % 2).astype(np.uint8)     # odd samples are cases
+    nA, nU, pitch = e.set_cohort(cond)
+    assert (nA, nU) == (5000, 5000) and pitch % 128 == 0
+    d_gt = e.alloc(nv * pitch)
+    d_counts = e.alloc(nv * 16)
+    d_out = e.alloc(nv * 24)
+    e.synth(hpgv.LAYOUT_ASSOC, 77, nv, d_gt)
+    e.assoc_scan(d_gt, nv, d_counts)
+    base = d_out.value
+    e.assoc_chisq(d_counts, nv, base, base + 8 * nv, base + 16 * nv)
+    e.sync()
+    counts = e.d2h(d_counts, (nv, 4), np.int32)
+    stats = e.d2h(d_out, (3, nv), np.float64)
+    gt = orc.synth_matrix(77, nv, ns, ns)
+    exp = oracle_assoc(orc.TASK_CHISQ, gt, cond)
+    res = dict(A1=counts[:, 0], A2=counts[:, 1], U1=counts[:, 2], U2=counts[:, 3],
+               odds=stats[0], chisq=stats[1], p=stats[2])
+    check_assoc(res, exp, hpgv.TASK_CHISQ)
+    # the layout kernel from VCF order gives the same matrix as the direct generator
+    d_raw = e.alloc(nv * 10000)
+    e.synth_raw(77, nv, ns, 10000, d_raw)
+    d_lay = e.alloc(nv * pitch)
+    e.layout(hpgv.LAYOUT_ASSOC, d_raw, 10000, nv, d_lay)
+    e.sync()
+    assert np.array_equal(e.d2h(d_lay, (nv, pitch), np.uint8), e.d2h(d_gt, (nv, pitch), np.uint8))
+    e.close()
+
+
+@pytest.mark.parametrize("opt", [("nontemporal", 0), ("variants_per_wave", 1), ("variants_per_wave", 7),
+                                 ("row_align", 16), ("row_align", 256)])
+def test_options_do_not_change_results(opt):
+    e = fresh()
+    e.set_option(*opt)
+    rng = np.random.default_rng(11)
+    cond = rng.choice([0, 1, 2], size=3000).astype(np.uint8)
+    e.set_cohort(cond)
+    gt = random_codes(rng, 333, 3000)
+    check_assoc(e.assoc(hpgv.TASK_CHISQ, gt), oracle_assoc(orc.TASK_CHISQ, gt, cond), hpgv.TASK_CHISQ)
+    e.close()
+
+
+# ------------------------------------------------------------------ TDT ----
+
+def _tdt_check(e, gt, fam, is_x=None):
+    res = e.tdt(gt, is_x)
+    t1, t2 = orc.tdt_counts(gt, *fam, chrom_is_x=is_x)
+    assert np.array_equal(res["t1"], t1) and np.array_equal(res["t2"], t2), "TDT tallies differ"
+    odds, chisq, p = orc.tdt_stats(t1, t2)
+    assert_close(res["odds"], odds, "tdt odds")
+    assert_close(res["chisq"], chisq, "tdt chisq")
+    assert_close(res["p"], p, "tdt p")
+
+
+def test_tdt_reference_kats(goldens):
+    # test/test_tdt_runner.c:93-433 through the HIP path
+    for case in goldens["kats"]["tdt"]:
+        samples, fcol, mcol, coff, ccol, csex = [], [], [], [0], [], []
+        for fam in case["families"]:
+            b = len(samples)
+            samples += [fam["father"], fam["mother"], fam["child"]]
+            fcol.append(b); mcol.append(b + 1)
+            if fam["child_affected"]:
+                ccol.append(b + 2); csex.append(hpgv.SEX_MALE)
+            coff.append(len(ccol))
+        gt = orc.encode_matrix([samples])
+        e = fresh()
+        e.set_families(len(samples), fcol, mcol, coff, ccol, csex)
+        res = e.tdt(gt)
+        assert (res["t1"][0], res["t2"][0]) == (case["t1"], case["t2"]), case["name"]
+        e.close()
+
+
+def test_tdt_all_genotype_triples_exhaustive():
+    # every (father, mother, child) combination of the quirk genotypes, as trios
+    codes = sorted(set(orc.encode_sample(s) for s in QUIRK_GTS))
+    trip = [(f, m, c) for f in codes for m in codes for c in codes]
+    n = len(trip)
+    gt = np.zeros((1, 3 * n), np.uint8)
+    gt[0, 0::3] = [t[0] for t in trip]
+    gt[0, 1::3] = [t[1] for t in trip]
+    gt[0, 2::3] = [t[2] for t in trip]
+    # one variant per trio so that every combination is checked on its own
+    gts = np.full((n, 3 * n), 0xFF, np.uint8)
+    for i in range(n):
+        gts[i, 3 * i: 3 * i + 3] = gt[0, 3 * i: 3 * i + 3]
+    fam = (np.arange(n) * 3, np.arange(n) * 3 + 1, np.arange(n + 1), np.arange(n) * 3 + 2,
+           (np.arange(n) % 2).astype(np.uint8))
+    fam = tuple(np.asarray(a) for a in fam)
+    e = fresh()
+    e.set_families(3 * n, *fam)
+    for is_x in (None, np.ones(n, np.uint8)):
+        _tdt_check(e, gts, fam, is_x)
+    e.close()
+
+
+@pytest.mark.parametrize("n_fam,max_children", [(1, 1), (17, 1), (700, 1), (300, 4), (5000, 1), (40, 30)])
+def test_tdt_random_pedigrees(n_fam, max_children):
+    rng = np.random.default_rng(n_fam * 31 + max_children)
+    n_samples = n_fam * (2 + max_children) + 5
+    fam = make_families(rng, n_samples, n_fam, max_children, p_absent=0.05 if n_fam > 10 else 0.0)
+    e = fresh()
+    n_fast, n_slow, pitch = e.set_families(n_samples, *fam)
+    if max_children > 1 and n_fam >= 40:
+        assert n_slow > 0
+    nv = 97
+    gt = random_codes(rng, nv, n_samples)
+    is_x = (rng.random(nv) < 0.4).astype(np.uint8)
+    _tdt_check(e, gt, fam, None)
+    _tdt_check(e, gt, fam, is_x)
+    gt2 = random_codes(rng, nv, n_samples, quirks=False)   # realistic mix: many counted trios
+    _tdt_check(e, gt2, fam, is_x)
+    e.close()
+
+
+def test_tdt_synthetic_trio_cohort():
+    # trio k = columns (3k, 3k+1, 3k+2), child sex alternating
+    e = fresh()
+    n_tr, nv = 5000, 512
+    k = np.arange(n_tr)
+    fam = (3 * k, 3 * k + 1, np.arange(n_tr + 1), 3 * k + 2, (k % 2).astype(np.uint8))
+    n_fast, n_slow, pitch = e.set_families(3 * n_tr, *fam)
+    assert (n_fast, n_slow) == (n_tr, 0)
+    d_gt, d_tu = e.alloc(nv * pitch), e.alloc(nv * 8)
+    e.synth(hpgv.LAYOUT_TDT, 1000, nv, d_gt)
+    e.tdt_scan(d_gt, nv, d_tu)
+    e.sync()
+    tu = e.d2h(d_tu, (nv, 2), np.int32)
+    gt = orc.synth_matrix(1000, nv, 3 * n_tr, 3 * n_tr)
+    t1, t2 = orc.tdt_counts(gt, *fam)
+    assert np.array_equal(tu[:, 0], t1) and np.array_equal(tu[:, 1], t2)
+    assert t1.sum() > 0 and t2.sum() > 0
+    e.close()
+
+
+# ---------------------------------------------------------------- stats ----
+
+@pytest.mark.parametrize("n_samples", [1, 16, 100, 2504, 10001])
+def test_variant_stats_and_hwe(n_samples):
+    rng = np.random.default_rng(n_samples + 5)
+    e = fresh()
+    e.set_stats_cohort(n_samples)
+    nv = 130
+    gt = random_codes(rng, nv, n_samples, quirks=True, strict=False)
+    gt[: nv // 2] = random_codes(rng, nv // 2, n_samples, quirks=False)
+    res = e.stats(gt)
+    for i in range(nv):
+        vs = orc.variant_stats(gt[i], 2)
+        g = list(vs.genotypes_count)[:4]
+        c8 = res["counts8"][i]
+        assert list(c8[:4]) == g, (i, list(c8), g)
+        assert c8[4] == vs.missing_genotypes and c8[5] == vs.missing_alleles
+        assert c8[6] == n_samples - vs.missing_genotypes - sum(g)
+        assert_close([res["hwe_chi2"][i]], [vs.hw_chi2], "hwe chi2")
+        assert_close([res["hwe_p"][i]], [vs.hw_p], "hwe p")
+    e.close()
+
+
+# ------------------------------------------------------- error behaviour ----
+
+def test_state_and_argument_errors():
+    e = fresh()
+    with pytest.raises(hpgv.HpgvError):
+        e.assoc(hpgv.TASK_CHISQ, np.zeros((1, 16), np.uint8))     # no cohort yet
+    e.set_cohort(np.array([0, 1] * 50, dtype=np.uint8))
+    with pytest.raises(hpgv.HpgvError):
+        e.assoc(hpgv.TASK_CHISQ, np.zeros((1, 16), np.uint8))     # pitch < n_samples
+    with pytest.raises(hpgv.HpgvError):
+        e.assoc(3, np.zeros((1, 100), np.uint8))                   # bad task
+    with pytest.raises(hpgv.HpgvError):
+        e.tdt(np.zeros((1, 100), np.uint8))                        # no families
+    with pytest.raises(hpgv.HpgvError):
+        e.set_families(10, [11], [1], [0, 1], [2], [0])            # column out of range
+    e.close()
