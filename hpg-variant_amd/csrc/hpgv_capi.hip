@@ -44,10 +44,14 @@ struct hpgv_ctx {
     mutable std::string err;
     std::mutex mu;
     // options
-    long row_align = 128;
-    long vpw = 4;
+    long row_align = 16;
+    long vpw = 2;
     long nontemporal = 1;
     long profile = 0;
+    long scan_unroll = 8;
+    long persistent = 0;       // 0: one wave per vpw consecutive rows; 1: persistent strided grid
+    long blocks_per_cu = 8;
+    int n_cus = 256;
     // assoc
     Layout assoc;
     int nA = 0, nU = 0, chunksA = 0;
@@ -114,8 +118,9 @@ int upload_layout(hpgv_ctx *ctx, Layout &L) {
 }
 
 // packed per-lane 16-bit partial sums bound the row length (hpgv_kernels.h)
-constexpr int kScanUnroll = 8;
-bool pitch_supported(size_t pitch) { return pitch / 16 / 64 + kScanUnroll + 1 <= 2047; }
+constexpr int kScanUnroll = 8;       // unroll of the tdt/stats scans
+constexpr int kMaxUnroll = 16;       // largest assoc unroll option
+bool pitch_supported(size_t pitch) { return pitch / 16 / 64 + kMaxUnroll + 1 <= 2047; }
 
 int ensure(hpgv_ctx *ctx, Slot *s, int idx, size_t bytes) {
     if (s->cap[idx] >= bytes) return HPGV_OK;
@@ -198,6 +203,9 @@ int hpgv_create(int device_id, hpgv_ctx **out) {
             return rc;
         }
     }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->n_cus = prop.multiProcessorCount;
     e = hipMalloc(&ctx->d_sink, 256);
     if (e != hipSuccess) {
         int rc = fail(nullptr, HPGV_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
@@ -241,6 +249,15 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
         ctx->nontemporal = value ? 1 : 0;
     } else if (!strcmp(key, "profile")) {
         ctx->profile = value ? 1 : 0;
+    } else if (!strcmp(key, "scan_unroll")) {
+        if (value != 4 && value != 8 && value != 10 && value != 12 && value != 16)
+            return fail(ctx, HPGV_ERR_INVALID, "scan_unroll must be one of 4, 8, 10, 12, 16");
+        ctx->scan_unroll = value;
+    } else if (!strcmp(key, "persistent")) {
+        ctx->persistent = value ? 1 : 0;
+    } else if (!strcmp(key, "blocks_per_cu")) {
+        if (value < 1 || value > 8) return fail(ctx, HPGV_ERR_INVALID, "blocks_per_cu must be in 1..8");
+        ctx->blocks_per_cu = value;
     } else {
         return fail(ctx, HPGV_ERR_INVALID, "unknown option '%s'", key);
     }
@@ -483,16 +500,37 @@ int hpgv_assoc_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, cons
     const Layout &L = ctx->assoc;
     const int vpw = (int)ctx->vpw;
     const long waves = ((long)n_variants + vpw - 1) / vpw;
-    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    unsigned blocks = (unsigned)((waves + 3) / 4);
+    if (ctx->persistent) {
+        const unsigned cap = (unsigned)(ctx->n_cus * ctx->blocks_per_cu);
+        const unsigned need = (unsigned)(((long)n_variants + 3) / 4);
+        blocks = need < cap ? need : cap;
+    }
     hipStream_t st = (hipStream_t)stream;
+    const uint8_t *gt = d_gt;
+    int4 *out = (int4 *)d_counts;
+    const int cA = ctx->chunksA, ch = L.chunks;
+    const size_t pitch = L.pitch;
+#define HPGV_LAUNCH_ASSOC(NT, U, S)                                                              \
+    hipLaunchKernelGGL((hpgv::k_assoc_scan<NT, U, S>), dim3(blocks), dim3(256), 0, st, gt, pitch, \
+                       n_variants, cA, ch, d_is_x, out, vpw)
+#define HPGV_DISPATCH_U(NT, S)                                                                   \
+    switch (ctx->scan_unroll) {                                                                  \
+        case 4: HPGV_LAUNCH_ASSOC(NT, 4, S); break;                                              \
+        case 10: HPGV_LAUNCH_ASSOC(NT, 10, S); break;                                            \
+        case 12: HPGV_LAUNCH_ASSOC(NT, 12, S); break;                                            \
+        case 16: HPGV_LAUNCH_ASSOC(NT, 16, S); break;                                            \
+        default: HPGV_LAUNCH_ASSOC(NT, 8, S); break;                                             \
+    }
     return launch_profiled(ctx, st, 0, [&] {
-        if (ctx->nontemporal)
-            hipLaunchKernelGGL((hpgv::k_assoc_scan<true, kScanUnroll>), dim3(blocks), dim3(256), 0, st, d_gt, L.pitch,
-                               n_variants, ctx->chunksA, L.chunks, d_is_x, (int4 *)d_counts, vpw);
-        else
-            hipLaunchKernelGGL((hpgv::k_assoc_scan<false, kScanUnroll>), dim3(blocks), dim3(256), 0, st, d_gt, L.pitch,
-                               n_variants, ctx->chunksA, L.chunks, d_is_x, (int4 *)d_counts, vpw);
+        if (ctx->nontemporal) {
+            if (ctx->persistent) { HPGV_DISPATCH_U(true, true) } else { HPGV_DISPATCH_U(true, false) }
+        } else {
+            if (ctx->persistent) { HPGV_DISPATCH_U(false, true) } else { HPGV_DISPATCH_U(false, false) }
+        }
     });
+#undef HPGV_DISPATCH_U
+#undef HPGV_LAUNCH_ASSOC
 }
 
 int hpgv_assoc_chisq_dev(hpgv_ctx *ctx, const int32_t *d_counts, int n_variants, double *d_odds,

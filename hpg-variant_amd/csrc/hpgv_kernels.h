@@ -96,47 +96,56 @@ __device__ __forceinline__ void assoc_row(const uint4 *__restrict__ row, int lan
     }
 }
 
-template <bool NT, int U>
+// reduce one row's packed partial sums and store {A1, A2, U1, U2}
+__device__ __forceinline__ void assoc_row_finish(bool x_row, int lane, int TA, int TU, uint32_t pnz,
+                                                 uint32_t pnnf, uint32_t pbnz, int4 *__restrict__ dst) {
+    const int nzA = wave_sum((int)(pnz & 0xFFFFu)), nzU = wave_sum((int)(pnz >> 16));
+    const int nfA = wave_sum((int)(pnnf & 0xFFFFu)), nfU = wave_sum((int)(pnnf >> 16));
+    int4 out;
+    if (!x_row) {
+        out.x = TA - nzA;            // A1
+        out.y = nzA + nfA - TA;      // A2
+        out.z = TU - nzU;            // U1
+        out.w = nzU + nfU - TU;      // U2
+    } else {
+        const int bA = wave_sum((int)(pbnz & 0xFFFFu)), bU = wave_sum((int)(pbnz >> 16));
+        const int validA = nfA >> 1, validU = nfU >> 1;
+        const int xxA = bA - (TA / 2 - validA), xxU = bU - (TU / 2 - validU);
+        out.x = (TA - nzA) - validA + xxA;
+        out.y = xxA;
+        out.z = (TU - nzU) - validU + xxU;
+        out.w = xxU;
+    }
+    if (lane == 0) *dst = out;
+}
+
+// STRIDED = false: wave w owns the vpw consecutive rows [w*vpw, (w+1)*vpw) and the
+//                  grid covers all rows (the hardware dispatcher balances the load);
+// STRIDED = true : persistent grid, wave w takes rows w, w+W, w+2W, ... (W = waves in
+//                  the grid), so at any moment the chip streams one contiguous window.
+template <bool NT, int U, bool STRIDED>
 __global__ __launch_bounds__(256) void k_assoc_scan(const uint8_t *__restrict__ gt, size_t pitch,
                                                     int n_variants, int chunksA, int chunks,
                                                     const uint8_t *__restrict__ is_x,
                                                     int4 *__restrict__ counts, int vpw) {
     const int lane = threadIdx.x & 63;
     const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long v_begin = wave * vpw;
     // every wave looks at `slots` chunk slots per row; slots past `chunks` are
     // virtual all-0xFF chunks booked on the unaffected group
     const int slots = ((chunks + 64 * U - 1) / (64 * U)) * (64 * U);
     const int TA = 32 * chunksA;
     const int TU = 32 * (slots - chunksA);
+    long v, v_end, v_step;
+    if constexpr (STRIDED) { v = wave; v_end = n_variants; v_step = (long)gridDim.x * (blockDim.x >> 6); }
+    else { v = wave * vpw; v_end = v + vpw < n_variants ? v + vpw : n_variants; v_step = 1; }
 
-    for (int i = 0; i < vpw; ++i) {
-        const long v = v_begin + i;
-        if (v >= n_variants) break;                      // wave-uniform
+    for (; v < v_end; v += v_step) {                       // wave-uniform
         const uint4 *row = reinterpret_cast<const uint4 *>(gt + (size_t)v * pitch);
         const bool x_row = (is_x != nullptr) && (__builtin_amdgcn_readfirstlane((int)is_x[v]) != 0);
         uint32_t pnz = 0, pnnf = 0, pbnz = 0;
         if (x_row) assoc_row<NT, U, true>(row, lane, chunksA, chunks, pnz, pnnf, pbnz);
         else       assoc_row<NT, U, false>(row, lane, chunksA, chunks, pnz, pnnf, pbnz);
-
-        const int nzA = wave_sum((int)(pnz & 0xFFFFu)), nzU = wave_sum((int)(pnz >> 16));
-        const int nfA = wave_sum((int)(pnnf & 0xFFFFu)), nfU = wave_sum((int)(pnnf >> 16));
-        int4 out;
-        if (!x_row) {
-            out.x = TA - nzA;            // A1
-            out.y = nzA + nfA - TA;      // A2
-            out.z = TU - nzU;            // U1
-            out.w = nzU + nfU - TU;      // U2
-        } else {
-            const int bA = wave_sum((int)(pbnz & 0xFFFFu)), bU = wave_sum((int)(pbnz >> 16));
-            const int validA = nfA >> 1, validU = nfU >> 1;
-            const int xxA = bA - (TA / 2 - validA), xxU = bU - (TU / 2 - validU);
-            out.x = (TA - nzA) - validA + xxA;
-            out.y = xxA;
-            out.z = (TU - nzU) - validU + xxU;
-            out.w = xxU;
-        }
-        if (lane == 0) counts[v] = out;
+        assoc_row_finish(x_row, lane, TA, TU, pnz, pnnf, pbnz, counts + v);
     }
 }
 

@@ -68,7 +68,7 @@ void hpgv_destroy(hpgv_ctx *ctx);
 /* text of the last failure on this ctx (ctx == NULL: last hpgv_create failure
  * of the calling thread) */
 const char *hpgv_last_error(const hpgv_ctx *ctx);
-/* tuning knobs: "row_align" (bytes, power of two >= 16, default 128),
+/* tuning knobs: "row_align" (bytes, power of two >= 16, default 16),
  * "variants_per_wave", "nontemporal" (0/1), "profile" (0/1) */
 int  hpgv_set_option(hpgv_ctx *ctx, const char *key, long value);
 

@@ -160,7 +160,7 @@ def test_device_resident_assoc_on_synthetic_cohort():
     ns, nv = 10000, 4096
     cond = (np.arange(ns) % 2).astype(np.uint8)     # odd samples are cases
     nA, nU, pitch = e.set_cohort(cond)
-    assert (nA, nU) == (5000, 5000) and pitch % 128 == 0
+    assert (nA, nU) == (5000, 5000) and pitch == 10016
     d_gt = e.alloc(nv * pitch)
     d_counts = e.alloc(nv * 16)
     d_out = e.alloc(nv * 24)
