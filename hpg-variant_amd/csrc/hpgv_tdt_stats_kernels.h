@@ -275,7 +275,8 @@ struct TdtPlan {
 // ---------------------------------------------------------------------------
 // variant stats scan (hpg-libs get_variants_stats, call site stats_runner.c:194;
 // counting rules: oracle/hpgv_oracle.c orc_variant_stats).  Output per variant,
-// 8 x int32: n_00 n_01 n_10 n_11 missing_genotypes missing_alleles n_other 0.
+// 8 x int32: n_00 n_01 n_10 n_11 missing_genotypes missing_alleles allele0 allele1
+// (allele counts include the called allele of half-missing genotypes).
 // Pad / virtual bytes are 0xFF and are subtracted using the known slot count.
 // ---------------------------------------------------------------------------
 template <bool NT, int U>
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void k_stats_scan(const uint8_t *__restrict__ 
         const long v = v_begin + i;
         if (v >= n_variants) break;
         const uint4 *row = reinterpret_cast<const uint4 *>(gt + (size_t)v * pitch);
-        int n00 = 0, n01 = 0, n10 = 0, n11 = 0, mg = 0, nnf = 0;
+        int n00 = 0, n01 = 0, n10 = 0, n11 = 0, mg = 0, nnf = 0, a0 = 0, a1 = 0;
         for (int base = 0; base < chunks; base += 64 * U) {
             uint4 q[U];
 #pragma unroll
@@ -308,6 +309,8 @@ __global__ __launch_bounds__(256) void k_stats_scan(const uint8_t *__restrict__ 
                     const uint32_t z = ~nib_nonzero(x);                 // bit3/bit7: nibble == 0
                     const uint32_t e = ~nib_nonzero(x ^ 0x11111111u);   // bit3/bit7: nibble == 1
                     const uint32_t zl = z & K8, zh = (z >> 4) & K8, el = e & K8, eh = (e >> 4) & K8;
+                    a0 += __builtin_popcount(z & 0x88888888u);
+                    a1 += __builtin_popcount(e & 0x88888888u);
                     n00 += __builtin_popcount(zl & zh);
                     n01 += __builtin_popcount(zh & el);
                     n10 += __builtin_popcount(eh & zl);
@@ -321,9 +324,10 @@ __global__ __launch_bounds__(256) void k_stats_scan(const uint8_t *__restrict__ 
         const int s00 = wave_sum(n00), s01 = wave_sum(n01), s10 = wave_sum(n10), s11 = wave_sum(n11);
         const int smg = wave_sum(mg) - fake;
         const int sma = (slots * 32 - wave_sum(nnf)) - 2 * fake;
+        const int sa0 = wave_sum(a0), sa1 = wave_sum(a1);
         if (lane == 0) {
             out8[2 * v] = make_int4(s00, s01, s10, s11);
-            out8[2 * v + 1] = make_int4(smg, sma, n_samples - smg - s00 - s01 - s10 - s11, 0);
+            out8[2 * v + 1] = make_int4(smg, sma, sa0, sa1);
         }
     }
 }

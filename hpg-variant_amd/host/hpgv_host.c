@@ -1,0 +1,748 @@
+/*
+ * hpgv_host.c -- the reference's per-batch functions (assoc_test, tdt_test,
+ * get_variants_stats) re-hosted on the MI355X engine.  See include/hpgv_host.h.
+ *
+ * Host work per call is only what the reference does around the arithmetic:
+ * locate GT, turn sample strings into bytes, build result records.  Every
+ * count and statistic comes from the HIP kernels through include/hpgv.h.
+ */
+#define _GNU_SOURCE
+#include "hpgv_host.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* small containers                                                           */
+/* ------------------------------------------------------------------------ */
+
+array_list_t *array_list_new(size_t initial_capacity) {
+    array_list_t *l = (array_list_t *)calloc(1, sizeof *l);
+    if (!l) return NULL;
+    l->capacity = initial_capacity ? initial_capacity : 8;
+    l->items = (void **)malloc(l->capacity * sizeof(void *));
+    if (!l->items) { free(l); return NULL; }
+    return l;
+}
+
+int array_list_insert(void *item, array_list_t *list) {
+    if (list->size == list->capacity) {
+        size_t cap = list->capacity * 2;
+        void **p = (void **)realloc(list->items, cap * sizeof(void *));
+        if (!p) return 0;
+        list->items = p; list->capacity = cap;
+    }
+    list->items[list->size++] = item;
+    return 1;
+}
+
+void *array_list_get(size_t index, const array_list_t *list) {
+    return index < list->size ? list->items[index] : NULL;
+}
+
+void array_list_free(array_list_t *list, void (*item_free)(void *)) {
+    if (!list) return;
+    if (item_free) for (size_t i = 0; i < list->size; i++) item_free(list->items[i]);
+    free(list->items);
+    free(list);
+}
+
+vcf_record_t *vcf_record_new(void) {
+    vcf_record_t *r = (vcf_record_t *)calloc(1, sizeof *r);
+    if (r) r->samples = array_list_new(16);
+    return r;
+}
+void vcf_record_free(vcf_record_t *r) { if (r) { array_list_free(r->samples, NULL); free(r); } }
+void set_vcf_record_chromosome(char *s, int n, vcf_record_t *r) { r->chromosome = s; r->chromosome_len = n; }
+void set_vcf_record_position(long p, vcf_record_t *r) { r->position = (unsigned long)p; }
+void set_vcf_record_id(char *s, int n, vcf_record_t *r) { r->id = s; r->id_len = n; }
+void set_vcf_record_reference(char *s, int n, vcf_record_t *r) { r->reference = s; r->reference_len = n; }
+void set_vcf_record_alternate(char *s, int n, vcf_record_t *r) { r->alternate = s; r->alternate_len = n; }
+void set_vcf_record_format(char *s, int n, vcf_record_t *r) { r->format = s; r->format_len = n; }
+
+individual_t *individual_new(char *id, float variable, enum Sex sex, enum Condition condition,
+                             individual_t *father, individual_t *mother, struct family *family) {
+    individual_t *i = (individual_t *)calloc(1, sizeof *i);
+    if (!i) return NULL;
+    i->id = id; i->variable = variable; i->sex = sex; i->condition = condition;
+    i->father = father; i->mother = mother; i->family = family;
+    return i;
+}
+void individual_free(individual_t *i) { free(i); }
+
+family_t *family_new(char *id) {
+    family_t *f = (family_t *)calloc(1, sizeof *f);
+    if (!f) return NULL;
+    f->id = id;
+    f->founders = array_list_new(2);
+    f->members = array_list_new(4);
+    return f;
+}
+int family_set_parent(individual_t *p, family_t *f) { return array_list_insert(p, f->founders) ? 0 : 1; }
+int family_add_child(individual_t *c, family_t *f) { return array_list_insert(c, f->members) ? 0 : 1; }
+void family_free(family_t *f) {
+    if (!f) return;
+    array_list_free(f->founders, NULL);
+    array_list_free(f->members, NULL);
+    free(f);
+}
+
+static size_t str_hash(const char *s) {
+    size_t h = 1469598103934665603ULL;
+    for (; *s; s++) { h ^= (unsigned char)*s; h *= 1099511628211ULL; }
+    return h;
+}
+
+sample_ids_t *sample_ids_new(size_t expected) {
+    sample_ids_t *t = (sample_ids_t *)calloc(1, sizeof *t);
+    if (!t) return NULL;
+    size_t nb = 16;
+    while (nb < expected * 2 + 1) nb <<= 1;
+    t->n_buckets = nb;
+    t->keys = (const char **)calloc(nb, sizeof(char *));
+    t->vals = (int *)calloc(nb, sizeof(int));
+    if (!t->keys || !t->vals) { free(t->keys); free(t->vals); free(t); return NULL; }
+    return t;
+}
+
+static int sample_ids_grow(sample_ids_t *t) {
+    sample_ids_t *n = sample_ids_new(t->n_buckets);
+    if (!n) return 0;
+    for (size_t i = 0; i < t->n_buckets; i++)
+        if (t->keys[i]) sample_ids_put(n, t->keys[i], t->vals[i]);
+    free(t->keys); free(t->vals);
+    *t = *n;
+    free(n);
+    return 1;
+}
+
+int sample_ids_put(sample_ids_t *t, const char *name, int position) {
+    if ((t->size + 1) * 2 > t->n_buckets && !sample_ids_grow(t)) return 0;
+    size_t m = t->n_buckets - 1, i = str_hash(name) & m;
+    while (t->keys[i] && strcmp(t->keys[i], name)) i = (i + 1) & m;
+    if (!t->keys[i]) { t->keys[i] = name; t->size++; }
+    t->vals[i] = position;
+    return 1;
+}
+
+int sample_ids_get(const sample_ids_t *t, const char *name) {
+    size_t m = t->n_buckets - 1, i = str_hash(name) & m;
+    while (t->keys[i]) {
+        if (!strcmp(t->keys[i], name)) return t->vals[i];
+        i = (i + 1) & m;
+    }
+    return -1;
+}
+
+void sample_ids_free(sample_ids_t *t) { if (t) { free(t->keys); free(t->vals); free(t); } }
+
+void list_init(const char *name, int writers, size_t max_length, list_t *list) {
+    memset(list, 0, sizeof *list);
+    list->name = name ? strdup(name) : NULL;
+    list->writers = writers;
+    list->max_length = max_length;
+    pthread_mutex_init(&list->lock, NULL);
+    pthread_cond_init(&list->condition, NULL);
+}
+
+list_item_t *list_item_new(int id, int type, void *data_p) {
+    list_item_t *it = (list_item_t *)calloc(1, sizeof *it);
+    if (it) { it->id = id; it->type = type; it->data_p = data_p; }
+    return it;
+}
+void list_item_free(list_item_t *item) { free(item); }
+
+int list_insert_item(list_item_t *item, list_t *list) {
+    if (!item || !list) return 0;
+    pthread_mutex_lock(&list->lock);
+    item->next_p = NULL;
+    if (list->last_p) list->last_p->next_p = item; else list->first_p = item;
+    list->last_p = item;
+    list->length++;
+    pthread_cond_broadcast(&list->condition);
+    pthread_mutex_unlock(&list->lock);
+    return 1;
+}
+
+list_item_t *list_remove_item(list_t *list) {
+    pthread_mutex_lock(&list->lock);
+    while (!list->first_p && list->writers > 0) pthread_cond_wait(&list->condition, &list->lock);
+    list_item_t *it = list->first_p;
+    if (it) {
+        list->first_p = it->next_p;
+        if (!list->first_p) list->last_p = NULL;
+        list->length--;
+        it->next_p = NULL;
+    }
+    pthread_mutex_unlock(&list->lock);
+    return it;
+}
+
+int list_decr_writers(list_t *list) {
+    pthread_mutex_lock(&list->lock);
+    if (list->writers > 0) list->writers--;
+    pthread_cond_broadcast(&list->condition);
+    int w = list->writers;
+    pthread_mutex_unlock(&list->lock);
+    return w;
+}
+
+void list_free_deep(list_t *list, void (*data_free)(void *)) {
+    list_item_t *it = list->first_p;
+    while (it) {
+        list_item_t *n = it->next_p;
+        if (data_free && it->data_p) data_free(it->data_p);
+        free(it);
+        it = n;
+    }
+    free(list->name);
+    pthread_mutex_destroy(&list->lock);
+    pthread_cond_destroy(&list->condition);
+    memset(list, 0, sizeof *list);
+}
+
+void assoc_basic_result_free(assoc_basic_result_t *r) {
+    if (!r) return;
+    free(r->chromosome); free(r->id); free(r->reference); free(r->alternate); free(r);
+}
+void assoc_fisher_result_free(assoc_fisher_result_t *r) {
+    if (!r) return;
+    free(r->chromosome); free(r->id); free(r->reference); free(r->alternate); free(r);
+}
+void tdt_result_free(tdt_result_t *r) {
+    if (!r) return;
+    free(r->chromosome); free(r->id); free(r->reference); free(r->alternate); free(r);
+}
+void variant_stats_free(variant_stats_t *s) {
+    if (!s) return;
+    free(s->chromosome); free(s->ref_allele); free(s->alt_alleles); free(s);
+}
+file_stats_t *file_stats_new(void) {
+    file_stats_t *f = (file_stats_t *)calloc(1, sizeof *f);
+    if (f) pthread_mutex_init(&f->lock, NULL);
+    return f;
+}
+void file_stats_free(file_stats_t *f) { if (f) { pthread_mutex_destroy(&f->lock); free(f); } }
+
+/* ------------------------------------------------------------------------ */
+/* text -> HPGV8                                                              */
+/* ------------------------------------------------------------------------ */
+
+/* position of `field` among the ':'-separated FORMAT keys (assoc.c:46, tdt.c:47) */
+int get_field_position_in_format(const char *field, char *format) {
+    size_t flen = strlen(field);
+    int pos = 0;
+    const char *p = format;
+    for (;;) {
+        const char *e = strchr(p, ':');
+        size_t len = e ? (size_t)(e - p) : strlen(p);
+        if (len == flen && !memcmp(p, field, flen)) return pos;
+        if (!e) return -1;
+        p = e + 1; pos++;
+    }
+}
+
+/* the reference calls this on a strdup'ed sample (assoc.c:52-53); here the
+ * string is only read.  Return codes: 0 ok, 1 first allele missing, 2 second,
+ * 3 both, 4 haploid (DESIGN.md "Genotype text"). */
+int get_alleles(char *sample, int genotype_position, int *allele1, int *allele2) {
+    const char *p = sample;
+    for (int i = 0; i < genotype_position; i++) {
+        p = strchr(p, ':');
+        if (!p) { *allele1 = *allele2 = -1; return 3; }
+        p++;
+    }
+    const char *end = p;
+    while (*end && *end != ':') end++;
+    const char *sep = p;
+    while (sep < end && *sep != '/' && *sep != '|') sep++;
+    int ret = 0;
+    if (sep == p || (sep - p == 1 && *p == '.')) { *allele1 = -1; ret += 1; }
+    else *allele1 = atoi(p);
+    if (sep == end) { *allele2 = -1; return ret == 0 ? 4 : 3; }
+    const char *q = sep + 1;
+    if (q == end || (end - q == 1 && *q == '.')) { *allele2 = -1; ret += 2; }
+    else *allele2 = atoi(q);
+    return ret;
+}
+
+static inline uint8_t encode_gt(const char *s, int gt_position, int strict) {
+    /* fast path: "a/b" or "a|b" with one-digit alleles in the first field */
+    if (gt_position == 0) {
+        unsigned char c0 = (unsigned char)s[0];
+        if (c0 && (s[1] == '/' || s[1] == '|')) {
+            unsigned char c2 = (unsigned char)s[2];
+            if (c2 && (s[3] == 0 || s[3] == ':')) {
+                int d0 = c0 - '0', d2 = c2 - '0';
+                int ok0 = (d0 >= 0 && d0 <= 9), ok2 = (d2 >= 0 && d2 <= 9);
+                if (ok0 && ok2) return (uint8_t)((d0 << 4) | d2);
+                if ((ok0 || c0 == '.') && (ok2 || c2 == '.')) {
+                    if (strict) return 0xFF;
+                    return (uint8_t)(((ok0 ? d0 : 0xF) << 4) | (ok2 ? d2 : 0xF));
+                }
+            }
+        }
+    }
+    int a1, a2;
+    int st = get_alleles((char *)s, gt_position, &a1, &a2);
+    if (strict && st != 0) return 0xFF;
+    int n1 = (a1 < 0) ? 0xF : (a1 > 14 ? 14 : a1);
+    int n2 = (a2 < 0) ? 0xF : (a2 > 14 ? 14 : a2);
+    return (uint8_t)((n1 << 4) | n2);
+}
+
+int hpgv_host_stage_records(vcf_record_t **variants, int num_variants, int num_samples, int strict,
+                            uint8_t *out, uint8_t *is_x) {
+    for (int i = 0; i < num_variants; i++) {
+        vcf_record_t *record = variants[i];
+        char fmt[256];
+        int fl = record->format_len < 255 ? record->format_len : 255;
+        memcpy(fmt, record->format, (size_t)fl);
+        fmt[fl] = 0;
+        int gt_position = get_field_position_in_format("GT", fmt);        /* assoc.c:45-47 */
+        uint8_t *row = out + (size_t)i * (size_t)num_samples;
+        if (gt_position < 0 || (int)record->samples->size < num_samples) {
+            memset(row, 0xFF, (size_t)num_samples);
+        } else {
+            char **samples = (char **)record->samples->items;
+            for (int j = 0; j < num_samples; j++) row[j] = encode_gt(samples[j], gt_position, strict);
+        }
+        /* assoc.c:94: !strncmp("X", record->chromosome, record->chromosome_len) */
+        if (is_x) is_x[i] = !strncmp("X", record->chromosome, (size_t)record->chromosome_len);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* engine binding                                                             */
+/* ------------------------------------------------------------------------ */
+
+static hpgv_ctx *g_ctx = NULL;
+static int g_device = 0;
+static pthread_mutex_t g_init_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_rwlock_t g_cohort_lock = PTHREAD_RWLOCK_INITIALIZER;
+static char g_err[512];
+
+/* what the current device-side cohort descriptions were built from */
+static struct {
+    const void *samples; int num_samples; uint64_t cond_hash; int set;
+} g_assoc_key;
+static struct { int num_families; int num_columns; uint64_t hash; int set; } g_tdt_key;
+static struct { int num_samples; int set; } g_stats_key;
+static struct { const void *table; int n; } g_lf_key;
+
+const char *hpgv_host_last_error(void) { return g_err; }
+
+static int host_fail(const char *what, int rc) {
+    snprintf(g_err, sizeof g_err, "%s: hpgv status %d: %s", what, rc,
+             g_ctx ? hpgv_last_error(g_ctx) : hpgv_last_error(NULL));
+    return rc;
+}
+
+int hpgv_host_init(int device_id) {
+    pthread_mutex_lock(&g_init_mu);
+    int rc = HPGV_OK;
+    if (!g_ctx) {
+        g_device = device_id;
+        rc = hpgv_create(device_id, &g_ctx);
+        if (rc != HPGV_OK) host_fail("hpgv_create", rc);
+    }
+    pthread_mutex_unlock(&g_init_mu);
+    return rc;
+}
+
+void hpgv_host_shutdown(void) {
+    pthread_mutex_lock(&g_init_mu);
+    if (g_ctx) { hpgv_destroy(g_ctx); g_ctx = NULL; }
+    memset(&g_assoc_key, 0, sizeof g_assoc_key);
+    memset(&g_tdt_key, 0, sizeof g_tdt_key);
+    memset(&g_stats_key, 0, sizeof g_stats_key);
+    memset(&g_lf_key, 0, sizeof g_lf_key);
+    pthread_mutex_unlock(&g_init_mu);
+}
+
+static int ensure_engine(void) { return g_ctx ? HPGV_OK : hpgv_host_init(g_device); }
+
+static char *dupn(const char *s, int n) { return strndup(s ? s : "", (size_t)(n > 0 ? n : 0)); }
+
+static int thread_id(void) {
+#ifdef _OPENMP
+    return omp_get_thread_num();
+#else
+    return 0;
+#endif
+}
+
+/* hpg-libs init_logarithm_array: table[i] = ln(i!) */
+double *init_logarithm_array(int n) {
+    if (n <= 0) return NULL;
+    double *t = (double *)malloc((size_t)n * sizeof(double));
+    if (!t) return NULL;
+    t[0] = 0.0;
+    for (int i = 1; i < n; i++) t[i] = t[i - 1] + log((double)i);
+    return t;
+}
+
+/* ------------------------------------------------------------------------ */
+/* assoc_test                                                                 */
+/* ------------------------------------------------------------------------ */
+
+static int assoc_prepare(enum ASSOC_task task, individual_t **samples, int num_samples, const void *opt_input) {
+    uint64_t h = 1469598103934665603ULL;
+    for (int j = 0; j < num_samples; j++) {
+        /* assert(individual) of assoc.c:92: a VCF sample absent from the PED is fatal there */
+        if (!samples[j]) { snprintf(g_err, sizeof g_err, "sample %d has no individual (assoc.c:92)", j); return HPGV_ERR_INVALID; }
+        h = (h ^ (uint64_t)samples[j]->condition) * 1099511628211ULL;
+    }
+    int need_cohort = !(g_assoc_key.set && g_assoc_key.num_samples == num_samples && g_assoc_key.cond_hash == h);
+    int need_lf = (task == FISHER) && !(g_lf_key.table == opt_input && g_lf_key.n == num_samples * 10);
+    if (!need_cohort && !need_lf) return HPGV_OK;
+    /* upgrade: drop the read lock, take the write lock, re-check */
+    pthread_rwlock_unlock(&g_cohort_lock);
+    pthread_rwlock_wrlock(&g_cohort_lock);
+    int rc = HPGV_OK;
+    if (!(g_assoc_key.set && g_assoc_key.num_samples == num_samples && g_assoc_key.cond_hash == h)) {
+        uint8_t *cond = (uint8_t *)malloc((size_t)(num_samples > 0 ? num_samples : 1));
+        if (!cond) rc = HPGV_ERR_NOMEM;
+        else {
+            for (int j = 0; j < num_samples; j++) {
+                enum Condition c = samples[j]->condition;                 /* assoc.c:95,101 */
+                cond[j] = (c == AFFECTED) ? HPGV_COND_AFFECTED : (c == UNAFFECTED) ? HPGV_COND_UNAFFECTED : HPGV_COND_OTHER;
+            }
+            rc = hpgv_set_cohort(g_ctx, cond, num_samples);
+            free(cond);
+            if (rc == HPGV_OK) {
+                g_assoc_key.samples = samples; g_assoc_key.num_samples = num_samples;
+                g_assoc_key.cond_hash = h; g_assoc_key.set = 1;
+            } else host_fail("hpgv_set_cohort", rc);
+        }
+    }
+    if (rc == HPGV_OK && task == FISHER && !(g_lf_key.table == opt_input && g_lf_key.n == num_samples * 10)) {
+        if (!opt_input) { snprintf(g_err, sizeof g_err, "FISHER needs the log-factorial table (opt_input)"); rc = HPGV_ERR_INVALID; }
+        else {
+            /* assoc_runner.c:164-166: the table has num_samples * 10 entries */
+            rc = hpgv_set_logfact(g_ctx, (const double *)opt_input, (size_t)num_samples * 10);
+            if (rc == HPGV_OK) { g_lf_key.table = opt_input; g_lf_key.n = num_samples * 10; }
+            else host_fail("hpgv_set_logfact", rc);
+        }
+    }
+    pthread_rwlock_unlock(&g_cohort_lock);
+    pthread_rwlock_rdlock(&g_cohort_lock);
+    return rc;
+}
+
+static int assoc_test_impl(enum ASSOC_task test_type, vcf_record_t **variants, int num_variants,
+                           individual_t **samples, int num_samples, const void *opt_input,
+                           list_t *output_list) {
+    if (test_type != CHI_SQUARE && test_type != FISHER) return HPGV_OK;      /* assoc.c:60,69: NONE emits nothing */
+    if (num_variants <= 0) return HPGV_OK;
+    int rc = ensure_engine();
+    if (rc) return rc;
+    int tid = thread_id();                                                   /* assoc.c:25 */
+    size_t n = (size_t)num_variants, ns = (size_t)(num_samples > 0 ? num_samples : 0);
+    size_t pitch = ns ? ns : 1;
+    uint8_t *gt = (uint8_t *)malloc(n * pitch + n);
+    int32_t *cnt = (int32_t *)malloc(n * 4 * sizeof(int32_t));
+    double *st = (double *)malloc(n * 3 * sizeof(double));
+    if (!gt || !cnt || !st) { free(gt); free(cnt); free(st); snprintf(g_err, sizeof g_err, "out of memory"); return HPGV_ERR_NOMEM; }
+    uint8_t *is_x = gt + n * pitch;
+    hpgv_host_stage_records(variants, num_variants, num_samples, 1, gt, is_x);   /* assoc.c:45-57 */
+
+    pthread_rwlock_rdlock(&g_cohort_lock);
+    rc = assoc_prepare(test_type, samples, num_samples, opt_input);
+    if (rc == HPGV_OK) {
+        rc = hpgv_assoc(g_ctx, (int)test_type, gt, pitch, num_variants, is_x, cnt, cnt + n, cnt + 2 * n, cnt + 3 * n,
+                        st, test_type == CHI_SQUARE ? st + n : NULL, st + 2 * n);
+        if (rc != HPGV_OK) host_fail("hpgv_assoc", rc);
+    }
+    pthread_rwlock_unlock(&g_cohort_lock);
+
+    if (rc == HPGV_OK) {
+        for (size_t i = 0; i < n; i++) {
+            vcf_record_t *record = variants[i];
+            void *result;
+            if (test_type == CHI_SQUARE) {                                   /* assoc.c:61-66 */
+                assoc_basic_result_t *r = (assoc_basic_result_t *)malloc(sizeof *r);
+                r->chromosome = dupn(record->chromosome, record->chromosome_len);
+                r->position = record->position;
+                r->id = dupn(record->id, record->id_len);
+                r->reference = dupn(record->reference, record->reference_len);
+                r->alternate = dupn(record->alternate, record->alternate_len);
+                r->affected1 = cnt[i]; r->affected2 = cnt[n + i];
+                r->unaffected1 = cnt[2 * n + i]; r->unaffected2 = cnt[3 * n + i];
+                r->odds_ratio = st[i]; r->chi_square = st[n + i]; r->p_value = st[2 * n + i];
+                result = r;
+            } else {                                                         /* assoc.c:70-75 */
+                assoc_fisher_result_t *r = (assoc_fisher_result_t *)malloc(sizeof *r);
+                r->chromosome = dupn(record->chromosome, record->chromosome_len);
+                r->position = record->position;
+                r->id = dupn(record->id, record->id_len);
+                r->reference = dupn(record->reference, record->reference_len);
+                r->alternate = dupn(record->alternate, record->alternate_len);
+                r->affected1 = cnt[i]; r->affected2 = cnt[n + i];
+                r->unaffected1 = cnt[2 * n + i]; r->unaffected2 = cnt[3 * n + i];
+                r->odds_ratio = st[i]; r->p_value = st[2 * n + i];
+                result = r;
+            }
+            list_insert_item(list_item_new(tid, 0, result), output_list);   /* assoc.c:67-68,76-77 */
+        }
+    }
+    free(gt); free(cnt); free(st);
+    return rc;
+}
+
+void assoc_test(enum ASSOC_task test_type, vcf_record_t **variants, int num_variants,
+                individual_t **samples, int num_samples, const void *opt_input, list_t *output_list) {
+    int rc = assoc_test_impl(test_type, variants, num_variants, samples, num_samples, opt_input, output_list);
+    if (rc != HPGV_OK) {
+        /* the reference function is void; its failures are LOG_FATAL (process exit) */
+        fprintf(stderr, "FATAL: assoc_test: %s\n", g_err);
+        exit(1);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* tdt_test                                                                   */
+/* ------------------------------------------------------------------------ */
+
+/* Builds the CSR pedigree description exactly the way tdt.c walks the families
+ * (father/mother choice tdt.c:62-73, sample lookup :83-95, counted children
+ * :135-148) and installs it when it differs from what the engine holds. */
+static int tdt_prepare(family_t **families, int num_families, sample_ids_t *sample_ids, int num_columns) {
+    size_t total_children = 0;
+    for (int f = 0; f < num_families; f++) total_children += families[f]->members->size;
+    size_t nf = (size_t)(num_families > 0 ? num_families : 1);
+    int32_t *fcol = (int32_t *)malloc(nf * sizeof(int32_t)), *mcol = (int32_t *)malloc(nf * sizeof(int32_t));
+    int32_t *coff = (int32_t *)malloc((nf + 1) * sizeof(int32_t));
+    int32_t *ccol = (int32_t *)malloc((total_children + 1) * sizeof(int32_t));
+    uint8_t *csex = (uint8_t *)malloc(total_children + 1);
+    int rc = HPGV_OK;
+    if (!fcol || !mcol || !coff || !ccol || !csex) {
+        snprintf(g_err, sizeof g_err, "out of memory");
+        rc = HPGV_ERR_NOMEM;
+    } else {
+        int nchild = 0;
+        uint64_t h = 1469598103934665603ULL;
+        coff[0] = 0;
+        for (int f = 0; f < num_families; f++) {
+            family_t *family = families[f];
+            individual_t *father = NULL, *mother = NULL;
+            for (size_t i = 0; i < family->founders->size; i++) {          /* tdt.c:62-73 */
+                if (father && mother) break;
+                individual_t *indiv = (individual_t *)family->founders->items[i];
+                if (indiv->sex == MALE) father = indiv;
+                else if (indiv->sex == FEMALE) mother = indiv;
+            }
+            fcol[f] = mcol[f] = -1;
+            if (father && mother) {                                        /* tdt.c:77-95 */
+                int fp = sample_ids_get(sample_ids, father->id), mp = sample_ids_get(sample_ids, mother->id);
+                if (fp >= 0 && mp >= 0 && fp < num_columns && mp < num_columns) { fcol[f] = fp; mcol[f] = mp; }
+            }
+            if (fcol[f] >= 0) {
+                for (size_t i = 0; i < family->members->size; i++) {       /* tdt.c:135-148 */
+                    individual_t *child = (individual_t *)family->members->items[i];
+                    if (!child->father || !child->mother) continue;
+                    if (child->condition != AFFECTED) continue;
+                    int cp = sample_ids_get(sample_ids, child->id);
+                    if (cp < 0 || cp >= num_columns) continue;
+                    ccol[nchild] = cp;
+                    csex[nchild] = (child->sex == MALE) ? HPGV_SEX_MALE : (child->sex == FEMALE) ? HPGV_SEX_FEMALE : HPGV_SEX_UNKNOWN;
+                    h = (h ^ (uint64_t)(uint32_t)cp ^ ((uint64_t)csex[nchild] << 40)) * 1099511628211ULL;
+                    nchild++;
+                }
+            }
+            coff[f + 1] = nchild;
+            h = (h ^ (uint64_t)(uint32_t)fcol[f]) * 1099511628211ULL;
+            h = (h ^ (uint64_t)(uint32_t)mcol[f]) * 1099511628211ULL;
+            h = (h ^ (uint64_t)(uint32_t)nchild) * 1099511628211ULL;
+        }
+        if (!(g_tdt_key.set && g_tdt_key.num_families == num_families && g_tdt_key.num_columns == num_columns &&
+              g_tdt_key.hash == h)) {
+            pthread_rwlock_unlock(&g_cohort_lock);
+            pthread_rwlock_wrlock(&g_cohort_lock);
+            if (!(g_tdt_key.set && g_tdt_key.num_families == num_families && g_tdt_key.num_columns == num_columns &&
+                  g_tdt_key.hash == h)) {
+                rc = hpgv_set_families(g_ctx, num_columns, num_families, fcol, mcol, coff, ccol, csex);
+                if (rc == HPGV_OK) {
+                    g_tdt_key.num_families = num_families; g_tdt_key.num_columns = num_columns;
+                    g_tdt_key.hash = h; g_tdt_key.set = 1;
+                } else host_fail("hpgv_set_families", rc);
+            }
+            pthread_rwlock_unlock(&g_cohort_lock);
+            pthread_rwlock_rdlock(&g_cohort_lock);
+        }
+    }
+    free(fcol); free(mcol); free(coff); free(ccol); free(csex);
+    return rc;
+}
+
+int tdt_test(vcf_record_t **variants, int num_variants, family_t **families, int num_families,
+             sample_ids_t *sample_ids, list_t *output_list) {
+    if (num_variants <= 0) return 0;
+    int rc = ensure_engine();
+    if (rc) return rc;
+    int tid = thread_id();                                                     /* tdt.c:27 */
+    int num_columns = (int)variants[0]->samples->size;
+    size_t n = (size_t)num_variants, pitch = (size_t)(num_columns > 0 ? num_columns : 1);
+    uint8_t *gt = (uint8_t *)malloc(n * pitch + n);
+    int32_t *tu = (int32_t *)malloc(n * 2 * sizeof(int32_t));
+    double *st = (double *)malloc(n * 3 * sizeof(double));
+    if (!gt || !tu || !st) { free(gt); free(tu); free(st); snprintf(g_err, sizeof g_err, "out of memory"); return HPGV_ERR_NOMEM; }
+    uint8_t *is_x = gt + n * pitch;
+    hpgv_host_stage_records(variants, num_variants, num_columns, 1, gt, is_x);
+
+    pthread_rwlock_rdlock(&g_cohort_lock);
+    rc = tdt_prepare(families, num_families, sample_ids, num_columns);
+    if (rc == HPGV_OK) {
+        rc = hpgv_tdt(g_ctx, gt, pitch, num_variants, is_x, tu, tu + n, st, st + n, st + 2 * n);
+        if (rc != HPGV_OK) host_fail("hpgv_tdt", rc);
+    }
+    pthread_rwlock_unlock(&g_cohort_lock);
+
+    if (rc == HPGV_OK) {
+        for (size_t i = 0; i < n; i++) {                                       /* tdt.c:262-268 */
+            vcf_record_t *record = variants[i];
+            tdt_result_t *r = (tdt_result_t *)malloc(sizeof *r);
+            r->chromosome = dupn(record->chromosome, record->chromosome_len);
+            r->position = record->position;
+            r->id = dupn(record->id, record->id_len);
+            r->reference = dupn(record->reference, record->reference_len);
+            r->alternate = dupn(record->alternate, record->alternate_len);
+            r->t1 = tu[i]; r->t2 = tu[n + i];
+            r->odds_ratio = st[i]; r->chi_square = st[n + i]; r->p_value = st[2 * n + i];
+            list_insert_item(list_item_new(tid, 0, r), output_list);
+        }
+    }
+    free(gt); free(tu); free(st);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* get_variants_stats                                                         */
+/* ------------------------------------------------------------------------ */
+
+int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t **individuals,
+                       sample_ids_t *sample_ids, int num_variables, list_t *output_list,
+                       file_stats_t *file_stats) {
+    (void)individuals; (void)sample_ids; (void)num_variables;   /* per-phenotype grouping: DESIGN.md "Not yet" */
+    if (num_variants <= 0) return 0;
+    int rc = ensure_engine();
+    if (rc) return rc;
+    int tid = thread_id();
+    int num_samples = (int)variants[0]->samples->size;
+    size_t n = (size_t)num_variants, pitch = (size_t)(num_samples > 0 ? num_samples : 1);
+    uint8_t *gt = (uint8_t *)malloc(n * pitch);
+    int32_t *c8 = (int32_t *)malloc(n * 8 * sizeof(int32_t));
+    double *hw = (double *)malloc(n * 2 * sizeof(double));
+    if (!gt || !c8 || !hw) { free(gt); free(c8); free(hw); snprintf(g_err, sizeof g_err, "out of memory"); return HPGV_ERR_NOMEM; }
+    hpgv_host_stage_records(variants, num_variants, num_samples, 0, gt, NULL);
+
+    pthread_rwlock_rdlock(&g_cohort_lock);
+    if (!(g_stats_key.set && g_stats_key.num_samples == num_samples)) {
+        pthread_rwlock_unlock(&g_cohort_lock);
+        pthread_rwlock_wrlock(&g_cohort_lock);
+        if (!(g_stats_key.set && g_stats_key.num_samples == num_samples)) {
+            rc = hpgv_set_stats_cohort(g_ctx, num_samples);
+            if (rc == HPGV_OK) { g_stats_key.set = 1; g_stats_key.num_samples = num_samples; }
+            else host_fail("hpgv_set_stats_cohort", rc);
+        }
+        pthread_rwlock_unlock(&g_cohort_lock);
+        pthread_rwlock_rdlock(&g_cohort_lock);
+    }
+    if (rc == HPGV_OK) {
+        rc = hpgv_stats(g_ctx, gt, pitch, num_variants, c8, hw, hw + n);
+        if (rc != HPGV_OK) host_fail("hpgv_stats", rc);
+    }
+    pthread_rwlock_unlock(&g_cohort_lock);
+
+    if (rc == HPGV_OK) {
+        int multi = 0;
+        for (size_t i = 0; i < n; i++) {
+            vcf_record_t *record = variants[i];
+            const int32_t *c = c8 + 8 * i;
+            variant_stats_t *s = (variant_stats_t *)calloc(1, sizeof *s);
+            s->chromosome = dupn(record->chromosome, record->chromosome_len);
+            s->position = record->position;
+            s->ref_allele = dupn(record->reference, record->reference_len);
+            s->alt_alleles = dupn(record->alternate, record->alternate_len);
+            s->num_alleles = 2;
+            for (int k = 0; k < 4; k++) s->genotypes_count[k] = c[k];
+            s->missing_genotypes = c[4]; s->missing_alleles = c[5];
+            s->other_genotypes = num_samples - c[4] - (c[0] + c[1] + c[2] + c[3]);
+            s->alleles_count[0] = c[6];
+            s->alleles_count[1] = c[7];
+            int ta = s->alleles_count[0] + s->alleles_count[1];
+            int tg = c[0] + c[1] + c[2] + c[3];
+            for (int k = 0; k < 2; k++) s->alleles_freq[k] = ta ? (float)s->alleles_count[k] / ta : 0.0f;
+            for (int k = 0; k < 4; k++) s->genotypes_freq[k] = tg ? (float)c[k] / tg : 0.0f;
+            s->maf = s->alleles_freq[0] < s->alleles_freq[1] ? s->alleles_freq[0] : s->alleles_freq[1];
+            s->hw_chi2 = hw[i]; s->hw_p_value = hw[n + i];
+            if (s->other_genotypes > 0) multi++;
+            list_insert_item(list_item_new(tid, 0, s), output_list);
+        }
+        if (file_stats) {
+            pthread_mutex_lock(&file_stats->lock);
+            file_stats->variants_count += num_variants;
+            file_stats->samples_count = num_samples;
+            file_stats->multiallelics_count += multi;
+            file_stats->biallelics_count += num_variants - multi;
+            pthread_mutex_unlock(&file_stats->lock);
+        }
+    }
+    free(gt); free(c8); free(hw);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* writers: the reference's exact formats                                     */
+/* ------------------------------------------------------------------------ */
+
+void assoc_write_output_header(enum ASSOC_task task, FILE *fd) {
+    if (task == CHI_SQUARE)
+        fprintf(fd, "#CHR\tPOS\tID\tA1\tC_A1\tC_U1\tF_A1\tF_U1\tA2\tC_A2\tC_U2\tF_A2\tF_U2\tOR\tCHISQ\tP-VALUE\n");
+    else if (task == FISHER)
+        fprintf(fd, "#CHR\tPOS\tID\tA1\tC_A1\tC_U1\tF_A1\tF_U1\tA2\tC_A2\tC_U2\tF_A2\tF_U2\tOR\tP-VALUE\n");
+}
+
+void assoc_write_output_body(enum ASSOC_task task, list_t *output_list, FILE *fd) {
+    list_item_t *item;
+    while ((item = list_remove_item(output_list))) {
+        if (task == CHI_SQUARE) {
+            assoc_basic_result_t *r = (assoc_basic_result_t *)item->data_p;
+            int na = r->affected1 + r->affected2, nu = r->unaffected1 + r->unaffected2;   /* assoc_runner.c:309-312 */
+            double fa1 = na > 0 ? (double)r->affected1 / na : 0.0f, fu1 = nu > 0 ? (double)r->unaffected1 / nu : 0.0f;
+            double fa2 = na > 0 ? (double)r->affected2 / na : 0.0f, fu2 = nu > 0 ? (double)r->unaffected2 / nu : 0.0f;
+            fprintf(fd, "%s\t%ld\t%s\t%s\t%d\t%d\t%6f\t%6f\t%s\t%d\t%d\t%6f\t%6f\t%6f\t%6f\t%6f\n",
+                    r->chromosome, (long)r->position, r->id, r->reference, r->affected1, r->unaffected1, fa1, fu1,
+                    r->alternate, r->affected2, r->unaffected2, fa2, fu2, r->odds_ratio, r->chi_square, r->p_value);
+            assoc_basic_result_free(r);
+        } else {
+            assoc_fisher_result_t *r = (assoc_fisher_result_t *)item->data_p;
+            int na = r->affected1 + r->affected2, nu = r->unaffected1 + r->unaffected2;
+            double fa1 = na > 0 ? (double)r->affected1 / na : 0.0f, fu1 = nu > 0 ? (double)r->unaffected1 / nu : 0.0f;
+            double fa2 = na > 0 ? (double)r->affected2 / na : 0.0f, fu2 = nu > 0 ? (double)r->unaffected2 / nu : 0.0f;
+            fprintf(fd, "%s\t%ld\t%s\t%s\t%d\t%d\t%6f\t%6f\t%s\t%d\t%d\t%6f\t%6f\t%6f\t%6f\n",
+                    r->chromosome, (long)r->position, r->id, r->reference, r->affected1, r->unaffected1, fa1, fu1,
+                    r->alternate, r->affected2, r->unaffected2, fa2, fu2, r->odds_ratio, r->p_value);
+            assoc_fisher_result_free(r);
+        }
+        list_item_free(item);
+    }
+}
+
+void tdt_write_output_header(FILE *fd) { fprintf(fd, "#CHR\tPOS\tID\tA1\tA2\tT\tU\tOR\tCHISQ\tP-VALUE\n"); }
+
+void tdt_write_output_body(list_t *output_list, FILE *fd) {
+    list_item_t *item;
+    while ((item = list_remove_item(output_list))) {
+        tdt_result_t *r = (tdt_result_t *)item->data_p;
+        fprintf(fd, "%s\t%ld\t%s\t%s\t%s\t%d\t%d\t%6f\t%6f\t%6f\n", r->chromosome, (long)r->position, r->id,
+                r->reference, r->alternate, r->t1, r->t2, r->odds_ratio, r->chi_square, r->p_value);
+        tdt_result_free(r);
+        list_item_free(item);
+    }
+}

@@ -138,9 +138,11 @@ int  hpgv_tdt_stats_dev(hpgv_ctx *ctx, const int32_t *d_tu, int n_variants,
                         double *d_odds, double *d_chisq, double *d_p, void *stream);
 
 /* d_gt in stats layout -> per variant 8 x int32:
- *   {n_00, n_01, n_10, n_11, missing_genotypes, missing_alleles, n_other, 0}
- * (biallelic cells of genotypes_count[a1*2+a2]; n_other = genotypes touching an
- * allele index >= 2) and Hardy-Weinberg chi2 / p on (n_00, n_01+n_10, n_11). */
+ *   {n_00, n_01, n_10, n_11, missing_genotypes, missing_alleles, allele0, allele1}
+ * (biallelic cells of genotypes_count[a1*2+a2]; allele counts include the called
+ * allele of half-missing genotypes; genotypes touching an allele index >= 2 are
+ * n_samples - missing_genotypes - the four cells) and Hardy-Weinberg chi2 / p on
+ * (n_00, n_01+n_10, n_11). */
 int  hpgv_stats_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants,
                          int32_t *d_counts8, void *stream);
 int  hpgv_stats_hwe_dev(hpgv_ctx *ctx, const int32_t *d_counts8, int n_variants,

@@ -1,0 +1,241 @@
+/*
+ * hpgv_host.h -- host-side mirror of the reference's per-batch runner API.
+ *
+ * hpg-variant's runners call three C functions once per parsed VCF batch
+ * (SURVEY.md 8b).  This header gives those functions with the reference's own
+ * names, argument order, ownership and error behaviour, re-hosted on the
+ * MI355X engine (include/hpgv.h).  The hpg-libs types they take are not in the
+ * reference tree (lib/ is an empty submodule), so the few fields the hot path
+ * touches are defined here with the reference's field names:
+ *
+ *   assoc_test          src/gwas/assoc/assoc.h:137-138   (body assoc.c:23-84)
+ *   tdt_test            src/gwas/tdt/tdt.h:119           (body tdt.c:23-276)
+ *   get_variants_stats  call site src/vcf-tools/stats/stats_runner.c:194-195
+ *   result records      assoc_basic_test.h:30-46, assoc_fisher_test.h:29-44, tdt.h:104-117
+ *   writers             assoc_runner.c:292-342, tdt_runner.c:286-304
+ *
+ * What the adapters do per call: find GT in FORMAT, turn every sample string
+ * into one HPGV8 byte (the reference's strdup + get_alleles per genotype,
+ * assoc.c:45-56), hand the batch to the engine, and build one result record
+ * per variant on the caller's list_t, stamped with the OpenMP thread id
+ * (assoc.c:25,67-68).  No statistics are computed on the host.
+ */
+#ifndef HPGV_HOST_H
+#define HPGV_HOST_H
+
+#include <pthread.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "hpgv.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- hpg-libs stand-in types (only what the hot path reads) ---------------- */
+
+typedef struct array_list {            /* containers/array_list.h: items, size */
+    size_t capacity;
+    size_t size;
+    void **items;
+} array_list_t;
+
+array_list_t *array_list_new(size_t initial_capacity);
+int   array_list_insert(void *item, array_list_t *list);
+void *array_list_get(size_t index, const array_list_t *list);
+void  array_list_free(array_list_t *list, void (*item_free)(void *));
+
+typedef struct vcf_record {            /* bioformats/vcf/vcf_file_structure.h; fields as used in
+                                          assoc.c:40-65, tdt.c:43-48,262-266 */
+    char *chromosome;  int chromosome_len;
+    unsigned long position;
+    char *id;          int id_len;
+    char *reference;   int reference_len;
+    char *alternate;   int alternate_len;
+    char *format;      int format_len;
+    array_list_t *samples;             /* NUL-terminated per-sample strings "0/1:..." */
+} vcf_record_t;
+
+vcf_record_t *vcf_record_new(void);
+void vcf_record_free(vcf_record_t *record);          /* frees the record and its samples list, not the strings */
+void set_vcf_record_chromosome(char *chromosome, int length, vcf_record_t *record);
+void set_vcf_record_position(long position, vcf_record_t *record);
+void set_vcf_record_id(char *id, int length, vcf_record_t *record);
+void set_vcf_record_reference(char *reference, int length, vcf_record_t *record);
+void set_vcf_record_alternate(char *alternate, int length, vcf_record_t *record);
+void set_vcf_record_format(char *format, int length, vcf_record_t *record);
+
+enum Sex { MALE = HPGV_SEX_MALE, FEMALE = HPGV_SEX_FEMALE, UNKNOWN_SEX = HPGV_SEX_UNKNOWN };
+enum Condition { UNAFFECTED = HPGV_COND_UNAFFECTED, AFFECTED = HPGV_COND_AFFECTED,
+                 MISSING_CONDITION = HPGV_COND_OTHER };
+
+struct family;
+typedef struct individual {            /* bioformats/family/family.h; ctor shape from
+                                          test/test_tdt_runner.c:95-97 */
+    char *id;
+    float variable;
+    enum Sex sex;
+    enum Condition condition;
+    struct individual *father;
+    struct individual *mother;
+    struct family *family;
+} individual_t;
+
+individual_t *individual_new(char *id, float variable, enum Sex sex, enum Condition condition,
+                             individual_t *father, individual_t *mother, struct family *family);
+void individual_free(individual_t *individual);
+
+/* family->founders / family->members are khashes in the reference (tdt.c:62-66,
+ * 135-137); here they are ordered lists, iterated in insertion order. */
+typedef struct family {
+    char *id;
+    array_list_t *founders;            /* individual_t*, parents without parents */
+    array_list_t *members;             /* individual_t*, everybody else */
+} family_t;
+
+family_t *family_new(char *id);
+int  family_set_parent(individual_t *parent, family_t *family);
+int  family_add_child(individual_t *child, family_t *family);
+void family_free(family_t *family);    /* frees the lists, not the individuals */
+
+/* khash_t(ids): sample name -> VCF column (tdt.c:83-95); open addressing, strings borrowed */
+typedef struct sample_ids {
+    size_t n_buckets;
+    size_t size;
+    const char **keys;
+    int *vals;
+} sample_ids_t;
+
+sample_ids_t *sample_ids_new(size_t expected);
+int  sample_ids_put(sample_ids_t *ids, const char *name, int position);
+int  sample_ids_get(const sample_ids_t *ids, const char *name);   /* -1 when absent */
+void sample_ids_free(sample_ids_t *ids);
+
+/* containers/list.h: thread-safe producer/consumer list (assoc_runner.c:25,306; assoc.c:67-68) */
+typedef struct list_item {
+    int id;
+    int type;
+    void *data_p;
+    struct list_item *next_p;
+} list_item_t;
+
+typedef struct list {
+    char *name;
+    int writers;
+    size_t max_length;
+    size_t length;
+    list_item_t *first_p, *last_p;
+    pthread_mutex_t lock;
+    pthread_cond_t condition;
+} list_t;
+
+void list_init(const char *name, int writers, size_t max_length, list_t *list);
+list_item_t *list_item_new(int id, int type, void *data_p);
+void list_item_free(list_item_t *item);
+int  list_insert_item(list_item_t *item, list_t *list);
+list_item_t *list_remove_item(list_t *list);   /* blocks while empty and writers > 0; NULL at the end */
+int  list_decr_writers(list_t *list);
+void list_free_deep(list_t *list, void (*data_free)(void *));
+
+/* ---- result records: field for field the reference's ----------------------- */
+
+enum ASSOC_task { NONE = HPGV_TASK_NONE, CHI_SQUARE = HPGV_TASK_CHISQ, FISHER = HPGV_TASK_FISHER };
+
+typedef struct {                       /* assoc_basic_test.h:30-46 */
+    char *chromosome; char *id; char *reference; char *alternate;
+    unsigned long int position;
+    int affected1, affected2, unaffected1, unaffected2;
+    double odds_ratio, chi_square, p_value;
+} assoc_basic_result_t;
+
+typedef struct {                       /* assoc_fisher_test.h:29-44 */
+    char *chromosome; char *id; char *reference; char *alternate;
+    unsigned long int position;
+    int affected1, affected2, unaffected1, unaffected2;
+    double odds_ratio, p_value;
+} assoc_fisher_result_t;
+
+typedef struct {                       /* tdt.h:104-117 */
+    char *chromosome; char *id; char *reference; char *alternate;
+    unsigned long int position;
+    int t1, t2;
+    double odds_ratio, chi_square, p_value;
+} tdt_result_t;
+
+void assoc_basic_result_free(assoc_basic_result_t *result);
+void assoc_fisher_result_free(assoc_fisher_result_t *result);
+void tdt_result_free(tdt_result_t *result);
+
+/* variant_stats_t: the fields visible in the reference tree
+ * (aggregate_runner.c:187-191,288-312,379-400) for the biallelic case, plus the
+ * Hardy-Weinberg record the stats tool reports. */
+typedef struct {
+    char *chromosome; unsigned long position;
+    char *ref_allele; char *alt_alleles;
+    int num_alleles;
+    int alleles_count[2];
+    int genotypes_count[4];            /* [a1 * num_alleles + a2] */
+    float alleles_freq[2];
+    float genotypes_freq[4];
+    int missing_alleles, missing_genotypes;
+    int other_genotypes;               /* calls touching an allele index >= 2 */
+    float maf;
+    double hw_chi2, hw_p_value;
+} variant_stats_t;
+
+void variant_stats_free(variant_stats_t *stats);
+
+typedef struct {                       /* file_stats_t: summary counters (simple sums) */
+    int variants_count, samples_count, biallelics_count, multiallelics_count;
+    pthread_mutex_t lock;
+} file_stats_t;
+
+file_stats_t *file_stats_new(void);
+void file_stats_free(file_stats_t *stats);
+
+/* ---- engine binding ---------------------------------------------------------- */
+/* Chooses the device the adapters run on (default 0).  Called lazily by the
+ * adapters; returns HPGV_OK or an hpgv status.  There is no CPU fallback. */
+int  hpgv_host_init(int device_id);
+void hpgv_host_shutdown(void);
+const char *hpgv_host_last_error(void);
+
+/* ---- the reference's per-batch functions ------------------------------------- */
+
+/* assoc.h:137-138.  void like the reference: an engine failure is logged to
+ * stderr and exits the process with 1, which is what LOG_FATAL does there. */
+void assoc_test(enum ASSOC_task test_type, vcf_record_t **variants, int num_variants,
+                individual_t **samples, int num_samples,
+                const void *opt_input, list_t *output_list);
+
+/* assoc_runner.c:164-166 builds opt_input with init_logarithm_array(num_samples * 10) */
+double *init_logarithm_array(int n);
+
+/* tdt.h:119.  0 = OK (tdt_runner.c:186-188 treats non-zero as fatal). */
+int  tdt_test(vcf_record_t **variants, int num_variants, family_t **families, int num_families,
+              sample_ids_t *sample_ids, list_t *output_list);
+
+/* call shape of stats_runner.c:194-195; returns 0 on success */
+int  get_variants_stats(vcf_record_t **variants, int num_variants, individual_t **individuals,
+                        sample_ids_t *sample_ids, int num_variables, list_t *output_list,
+                        file_stats_t *file_stats);
+
+/* ---- writers with the reference's exact formats ------------------------------ */
+void assoc_write_output_header(enum ASSOC_task task, FILE *fd);             /* assoc_runner.c:292-299 */
+void assoc_write_output_body(enum ASSOC_task task, list_t *output_list, FILE *fd);   /* :301-342 */
+void tdt_write_output_header(FILE *fd);                                     /* tdt_runner.c:286-289 */
+void tdt_write_output_body(list_t *output_list, FILE *fd);                  /* tdt_runner.c:291-304 */
+
+/* ---- staging (GT text -> HPGV8), exposed for tests ---------------------------- */
+int  get_field_position_in_format(const char *field, char *format);
+int  get_alleles(char *sample, int genotype_position, int *allele1, int *allele2);
+/* out: num_variants x num_samples bytes, row-major; is_x: num_variants flags */
+int  hpgv_host_stage_records(vcf_record_t **variants, int num_variants, int num_samples,
+                             int strict, uint8_t *out, uint8_t *is_x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

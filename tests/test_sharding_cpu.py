@@ -1,0 +1,87 @@
+"""CPU suite: the multi-GPU path's variant sharding and result gather, run with
+world_size 2 and 3 over gloo (the GPU box uses the same code over nccl = RCCL).
+The per-shard compute stand-in here is the oracle (test infrastructure)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, V, N, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from importlib import import_module
+    sh = import_module("hpg-variant_amd.sharding")
+    from oracle import pyoracle as orc
+    lo, hi = sh.variant_range(rank, world, V)
+    n = hi - lo
+    cond = (np.arange(N) % 2).astype(np.uint8)
+    gt = orc.synth_matrix(lo, n, N, N)                    # this rank's global variant ids
+    A1, A2, U1, U2 = orc.assoc_counts(gt, cond)
+    odds, chisq, p = orc.assoc_stats(orc.TASK_CHISQ, A1, A2, U1, U2)
+    lay = sh.result_block_layout(n)
+    block = np.zeros(lay["bytes"], dtype=np.uint8)
+    block[: 16 * n] = np.stack([A1, A2, U1, U2], 1).astype(np.int32).reshape(-1).view(np.uint8)
+    for key, arr in (("odds", odds), ("chisq", chisq), ("p", p)):
+        block[lay[key]: lay[key] + 8 * n] = arr.view(np.uint8)
+    sizes = [40 * (sh.variant_range(r, world, V)[1] - sh.variant_range(r, world, V)[0]) for r in range(world)]
+    blocks, work = sh.gather_blocks(torch.from_numpy(block), sizes, dst=0, async_op=True)
+    if work is not None:
+        work.wait()
+    if rank == 0:
+        counts, stats = [], []
+        for r, b in enumerate(blocks):
+            nr = sizes[r] // 40
+            b = b.numpy()
+            counts.append(b[: 16 * nr].view(np.int32).reshape(nr, 4))
+            stats.append(b[16 * nr:].view(np.float64).reshape(3, nr))
+        np.save(os.path.join(out_dir, "counts.npy"), np.concatenate(counts, 0))
+        np.save(os.path.join(out_dir, "stats.npy"), np.concatenate(stats, 1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,V", [(2, 1000), (3, 1001), (2, 1)])
+def test_sharded_scan_and_gather_equals_single_process(tmp_path, world, V):
+    from oracle import pyoracle as orc
+    N = 64
+    mp.spawn(_worker, args=(world, _free_port(), V, N, str(tmp_path)), nprocs=world, join=True)
+    counts = np.load(tmp_path / "counts.npy")
+    stats = np.load(tmp_path / "stats.npy")
+    cond = (np.arange(N) % 2).astype(np.uint8)
+    gt = orc.synth_matrix(0, V, N, N)
+    A1, A2, U1, U2 = orc.assoc_counts(gt, cond)
+    odds, chisq, p = orc.assoc_stats(orc.TASK_CHISQ, A1, A2, U1, U2)
+    assert np.array_equal(counts, np.stack([A1, A2, U1, U2], 1))
+    for got, exp in ((stats[0], odds), (stats[1], chisq), (stats[2], p)):
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        assert np.allclose(got[~np.isnan(got)], exp[~np.isnan(exp)], rtol=0, atol=0)
+
+
+def test_variant_ranges_partition_everything():
+    from importlib import import_module
+    sh = import_module("hpg-variant_amd.sharding")
+    for V in (0, 1, 7, 1000, 10_000_000):
+        for G in (1, 2, 4, 8):
+            r = [sh.variant_range(g, G, V) for g in range(G)]
+            assert r[0][0] == 0 and r[-1][1] == V
+            assert all(r[i][1] == r[i + 1][0] for i in range(G - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
