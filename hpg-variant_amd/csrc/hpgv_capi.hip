@@ -406,6 +406,13 @@ static Layout *pick_layout(hpgv_ctx *ctx, int which) {
     }
 }
 
+// per-layout recoding of the stored byte (hpgv_kernels.h "Per-tool recoding")
+static void recode_of(const hpgv_ctx *ctx, int which, int *mode, int *p16) {
+    *mode = hpgv::RECODE_NONE; *p16 = 0;
+    if (which == HPGV_LAYOUT_TDT) { *mode = hpgv::RECODE_TDT; *p16 = ctx->tdt_plan.p16; }
+    else if (which == HPGV_LAYOUT_STATS) { *mode = hpgv::RECODE_STATS; }
+}
+
 int hpgv_layout_dev(hpgv_ctx *ctx, int which, const uint8_t *d_src, size_t src_pitch, int n_variants,
                     uint8_t *d_dst, void *stream) {
     if (!ctx) return HPGV_ERR_INVALID;
@@ -418,8 +425,10 @@ int hpgv_layout_dev(hpgv_ctx *ctx, int which, const uint8_t *d_src, size_t src_p
     DeviceGuard g(ctx->device);
     const long total = (long)n_variants * L->chunks;
     const int strict = (which == HPGV_LAYOUT_STATS) ? 0 : 1;
+    int mode, p16;
+    recode_of(ctx, which, &mode, &p16);
     hipLaunchKernelGGL(hpgv::k_layout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       d_src, src_pitch, n_variants, L->pitch, L->chunks, L->d_col_of_pos, strict, d_dst);
+                       d_src, src_pitch, n_variants, L->pitch, L->chunks, L->d_col_of_pos, strict, mode, p16, d_dst);
     HIPCHK(ctx, hipGetLastError());
     return HPGV_OK;
 }
@@ -434,7 +443,7 @@ static int ensure_thr(hpgv_ctx *ctx, int n_variants) {
 }
 
 static int synth_common(hpgv_ctx *ctx, uint64_t v0, int n_variants, size_t pitch, int chunks,
-                        const int32_t *d_col, uint8_t *d_dst, hipStream_t st) {
+                        const int32_t *d_col, int mode, int p16, uint8_t *d_dst, hipStream_t st) {
     // generated in slabs so the threshold scratch stays small
     const int slab = 1 << 20;
     int rc = ensure_thr(ctx, n_variants < slab ? n_variants : slab);
@@ -445,7 +454,7 @@ static int synth_common(hpgv_ctx *ctx, uint64_t v0, int n_variants, size_t pitch
                            v0 + (uint64_t)off, n, ctx->d_thr);
         const long total = (long)n * chunks;
         hipLaunchKernelGGL(hpgv::k_synth_layout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                           v0 + (uint64_t)off, n, pitch, chunks, d_col, ctx->d_thr,
+                           v0 + (uint64_t)off, n, pitch, chunks, d_col, ctx->d_thr, mode, p16,
                            d_dst + (size_t)off * pitch);
         HIPCHK(ctx, hipGetLastError());
     }
@@ -460,8 +469,10 @@ int hpgv_synth_dev(hpgv_ctx *ctx, int which, uint64_t v0, int n_variants, uint8_
     if (n_variants < 0 || (n_variants > 0 && !d_dst)) return fail(ctx, HPGV_ERR_INVALID, "bad synth arguments");
     if (n_variants == 0) return HPGV_OK;
     DeviceGuard g(ctx->device);
+    int mode, p16;
+    recode_of(ctx, which, &mode, &p16);
     std::lock_guard<std::mutex> lk(ctx->mu);   // shares ctx->d_thr
-    return synth_common(ctx, v0, n_variants, L->pitch, L->chunks, L->d_col_of_pos, d_dst, (hipStream_t)stream);
+    return synth_common(ctx, v0, n_variants, L->pitch, L->chunks, L->d_col_of_pos, mode, p16, d_dst, (hipStream_t)stream);
 }
 
 int hpgv_synth_raw_dev(hpgv_ctx *ctx, uint64_t v0, int n_variants, int n_samples, size_t pitch,
@@ -480,7 +491,7 @@ int hpgv_synth_raw_dev(hpgv_ctx *ctx, uint64_t v0, int n_variants, int n_samples
     if (e != hipSuccess) rc = fail(ctx, HPGV_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
     if (!rc) {
         std::lock_guard<std::mutex> lk(ctx->mu);
-        rc = synth_common(ctx, v0, n_variants, pitch, (int)(pitch / 16), d_col, d_dst, (hipStream_t)stream);
+        rc = synth_common(ctx, v0, n_variants, pitch, (int)(pitch / 16), d_col, hpgv::RECODE_NONE, 0, d_dst, (hipStream_t)stream);
     }
     (void)hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(d_col);
@@ -612,10 +623,10 @@ int hpgv_stats_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, int3
     return launch_profiled(ctx, st, 0, [&] {
         if (ctx->nontemporal)
             hipLaunchKernelGGL((hpgv::k_stats_scan<true, kScanUnroll>), dim3(blocks), dim3(256), 0, st, d_gt, L.pitch,
-                               n_variants, L.chunks, L.n_samples, (int4 *)d_counts8, vpw);
+                               n_variants, L.chunks, (int4 *)d_counts8, vpw);
         else
             hipLaunchKernelGGL((hpgv::k_stats_scan<false, kScanUnroll>), dim3(blocks), dim3(256), 0, st, d_gt, L.pitch,
-                               n_variants, L.chunks, L.n_samples, (int4 *)d_counts8, vpw);
+                               n_variants, L.chunks, (int4 *)d_counts8, vpw);
     });
 }
 

@@ -259,11 +259,72 @@ __device__ __forceinline__ uint32_t synth_gt(uint64_t vterm, uint64_t s, uint32_
     return (r < tm) ? 0xFFu : (r < t0) ? 0x00u : (r < t1) ? 0x01u : 0x11u;
 }
 
+// ---------------------------------------------------------------------------
+// Per-tool recoding applied when a row is written in an engine layout.  The
+// canonical exchange format stays HPGV8 (one byte per genotype); a layout may
+// store, still one byte per genotype, the CLASS of that genotype for its scan:
+//   RECODE_NONE  : HPGV8 as is (assoc; slow-family groups of the tdt layout)
+//   RECODE_TDT   : positions [0,p16) father / [p16,2p16) mother planes hold the
+//                  parent class, [2p16,3p16) the child class (tdt classes below)
+//   RECODE_STATS : one-hot genotype cell / missing / extra-allele flags
+// Every class is a function of that ONE genotype and of the column's fixed role.
+// ---------------------------------------------------------------------------
+enum { RECODE_NONE = 0, RECODE_TDT = 1, RECODE_STATS = 2 };
+
+// parent classes (tdt.c:113-123 tests): 0 "0/0", 1 "0/x", 2 "x/x" (equal, non-zero),
+// 3 "x/y" (both non-zero, different); unusable = missing or "x/0" (tdt.c:103-108,119)
+constexpr uint32_t TDT_F_UNUSABLE = 0x80u, TDT_M_UNUSABLE = 0x20u;
+// child classes (tdt.c:175,182,203): 0 "0/0", 1 "0/x", 2 "x/0", 3 both non-zero, 4 missing
+constexpr uint32_t TDT_C_INVALID = 4u;
+
+__host__ __device__ __forceinline__ uint32_t tdt_parent_class(uint32_t g, uint32_t unusable) {
+    const uint32_t a1 = g >> 4, a2 = g & 0xFu;
+    if (a1 == 0xFu || a2 == 0xFu) return unusable;
+    if (a1 && !a2) return unusable;
+    if (!a1 && !a2) return 0u;
+    if (!a1) return 1u;
+    return (a1 == a2) ? 2u : 3u;
+}
+__host__ __device__ __forceinline__ uint32_t tdt_child_class(uint32_t g) {
+    const uint32_t a1 = g >> 4, a2 = g & 0xFu;
+    if (a1 == 0xFu || a2 == 0xFu) return TDT_C_INVALID;
+    if (!a1 && !a2) return 0u;
+    if (!a1) return 1u;
+    if (!a2) return 2u;
+    return 3u;
+}
+// stats flags: bit0..3 genotype is 0/0, 0/1, 1/0, 1/1; bit4 some allele missing; bit5 both
+// missing; bit6 / bit7: a called allele 0 / 1 outside those four cells (e.g. "0/2", "./1")
+__host__ __device__ __forceinline__ uint32_t stats_flags(uint32_t g) {
+    const uint32_t a1 = g >> 4, a2 = g & 0xFu;
+    uint32_t f = 0;
+    if (g == 0x00u) f |= 1u; else if (g == 0x01u) f |= 2u; else if (g == 0x10u) f |= 4u; else if (g == 0x11u) f |= 8u;
+    if (a1 == 0xFu || a2 == 0xFu) f |= 0x10u;
+    if (a1 == 0xFu && a2 == 0xFu) f |= 0x20u;
+    if (!(f & 0xFu)) {
+        if (a1 == 0u || a2 == 0u) f |= 0x40u;
+        if (a1 == 1u || a2 == 1u) f |= 0x80u;
+    }
+    return f;
+}
+
+// g: HPGV8 byte (0xFF for padding), pos: byte position in the row
+__device__ __forceinline__ uint32_t recode_byte(uint32_t g, int mode, int p16, int pos, bool is_pad) {
+    if (mode == RECODE_TDT) {
+        if (p16 <= 0 || pos >= 3 * p16) return g;
+        if (pos < p16) return tdt_parent_class(g, TDT_F_UNUSABLE);
+        if (pos < 2 * p16) return tdt_parent_class(g, TDT_M_UNUSABLE);
+        return tdt_child_class(g);
+    }
+    if (mode == RECODE_STATS) return is_pad ? 0u : stats_flags(g);
+    return g;
+}
+
 // one thread per 16-byte chunk of the destination row; col_of_pos[p] = VCF column
-// stored at row position p, or -1 for padding (0xFF).
+// stored at row position p, or -1 for padding (0xFF before recoding).
 __global__ __launch_bounds__(256) void k_synth_layout(uint64_t v0, int n_variants, size_t pitch,
                                                       int chunks, const int32_t *__restrict__ col_of_pos,
-                                                      const uint32_t *__restrict__ thr,
+                                                      const uint32_t *__restrict__ thr, int mode, int p16,
                                                       uint8_t *__restrict__ dst) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)n_variants * chunks;
@@ -278,8 +339,10 @@ __global__ __launch_bounds__(256) void k_synth_layout(uint64_t v0, int n_variant
         uint32_t acc = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int col = col_of_pos[c * 16 + k * 4 + j];
-            const uint32_t g = (col < 0) ? 0xFFu : synth_gt(vterm, (uint64_t)col, tm, t0, t1);
+            const int pos = c * 16 + k * 4 + j;
+            const int col = col_of_pos[pos];
+            uint32_t g = (col < 0) ? 0xFFu : synth_gt(vterm, (uint64_t)col, tm, t0, t1);
+            g = recode_byte(g, mode, p16, pos, col < 0);
             acc |= g << (8 * j);
         }
         w[k] = acc;
@@ -288,14 +351,14 @@ __global__ __launch_bounds__(256) void k_synth_layout(uint64_t v0, int n_variant
 }
 
 // ---------------------------------------------------------------------------
-// layout (column gather) kernel: dst[v][p] = src[v][col_of_pos[p]], pads 0xFF.
-// strict != 0 turns any byte with a missing allele into 0xFF (assoc / tdt drop
-// such genotypes: assoc.c:53, tdt.c:103-108,154).
+// layout (column gather + recode) kernel: dst[v][p] = recode(src[v][col_of_pos[p]]).
+// strict != 0 turns any byte with a missing allele into 0xFF first (assoc / tdt
+// drop such genotypes: assoc.c:53, tdt.c:103-108,154).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_layout(const uint8_t *__restrict__ src, size_t src_pitch,
                                                 int n_variants, size_t pitch, int chunks,
                                                 const int32_t *__restrict__ col_of_pos, int strict,
-                                                uint8_t *__restrict__ dst) {
+                                                int mode, int p16, uint8_t *__restrict__ dst) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)n_variants * chunks;
     if (t >= total) return;
@@ -307,9 +370,11 @@ __global__ __launch_bounds__(256) void k_layout(const uint8_t *__restrict__ src,
         uint32_t acc = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int col = col_of_pos[c * 16 + k * 4 + j];
+            const int pos = c * 16 + k * 4 + j;
+            const int col = col_of_pos[pos];
             uint32_t g = (col < 0) ? 0xFFu : (uint32_t)row[col];
             if (strict && (((g & 0xF) == 0xF) || ((g >> 4) == 0xF))) g = 0xFFu;
+            g = recode_byte(g, mode, p16, pos, col < 0);
             acc |= g << (8 * j);
         }
         w[k] = acc;

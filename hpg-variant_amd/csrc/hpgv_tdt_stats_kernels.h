@@ -1,73 +1,27 @@
 // hpgv_tdt_stats_kernels.h -- TDT trio scan, variant-stats scan and their
 // FP64 statistics kernels (gfx950).  Same machine model as hpgv_kernels.h:
-// one variant row per wavefront, 16-byte lane loads, bit-sliced SWAR logic.
+// one variant row per wavefront, 16-byte lane loads, a handful of VALU ops per
+// dword, DPP + readlane reduction, one small store per variant.
 #pragma once
 #include "hpgv_kernels.h"
 
+#include <cstring>
 #include <string>
 #include <vector>
 
 namespace hpgv {
 
-constexpr uint32_t K8 = 0x08080808u;   // "flag" bit of every byte in the SWAR masks
-
-// per-byte flags (bit 3 of each byte) derived from 4 packed genotype bytes
-struct GtFlags {
-    uint32_t a1nz, a2nz;   // allele1 / allele2 non-zero (missing counts as non-zero)
-    uint32_t ne;           // allele1 != allele2
-    uint32_t valid;        // neither nibble is 0xF
-};
-__device__ __forceinline__ GtFlags gt_flags(uint32_t x) {
-    GtFlags g;
-    const uint32_t ind = nib_nonzero(x);
-    g.a2nz = ind & K8;
-    g.a1nz = (ind >> 4) & K8;
-    g.ne = nib_nonzero((x ^ (x >> 4)) & 0x0F0F0F0Fu) & K8;
-    const uint32_t nf = nib_not_f(x);
-    g.valid = nf & (nf >> 4) & K8;
-    return g;
-}
-
 // ---------------------------------------------------------------------------
-// TDT on 4 trios at once (bytes of f, m, c at the same position form a trio).
-// Bit-sliced statement of tdt.c:103-123 (family filters), the Mendel check
-// (hpg-libs check_mendel as pinned by test/test_checks_family.c, classes by
-// zero-ness) and the transmission table tdt.c:175-213 for families with ONE
-// counted child (so trA/trB start at 0; multi-child families take the slow
-// path below).  male: bit 3 set for male children, used on chr "X" rows only.
+// The TDT rule for one counted child, scalar, on allele values.  This is the
+// product's statement of tdt.c:103-123 (family filters), the Mendel check
+// (hpg-libs check_mendel as pinned by test/test_checks_family.c:16-111; classes
+// by zero-ness) and the transmission table tdt.c:175-213.  It runs
+//   - on the device for families with several counted children (slow groups),
+//     where trA / trB live at family scope (tdt.c:128-132), and
+//   - on the host, once per pedigree, over class representatives, to BUILD the
+//     byte look-up tables the fast path evaluates with v_perm_b32.
 // ---------------------------------------------------------------------------
-template <bool X>
-__device__ __forceinline__ void tdt4(uint32_t f, uint32_t m, uint32_t c, uint32_t male, int &t1, int &t2) {
-    const GtFlags F = gt_flags(f), M = gt_flags(m), C = gt_flags(c);
-    // tdt.c:103-108 parents genotyped; :113 at least one het (a1 != a2); :119 no "x/0" parent
-    uint32_t ok = F.valid & M.valid & C.valid & (F.ne | M.ne);
-    ok &= ~(F.a1nz & ~F.a2nz) & ~(M.a1nz & ~M.a2nz);
-    const uint32_t f_ref = ~(F.a1nz | F.a2nz) & K8, f_alt = F.a1nz & F.a2nz;
-    const uint32_t m_ref = ~(M.a1nz | M.a2nz) & K8, m_alt = M.a1nz & M.a2nz;
-    const uint32_t c_ref = ~(C.a1nz | C.a2nz) & K8, c_alt = C.a1nz & C.a2nz;
-    const uint32_t c_het = ~(c_ref | c_alt) & K8;
-    uint32_t err = (c_het & ((f_ref & m_ref) | (f_alt & m_alt))) | (c_ref & (f_alt | m_alt)) |
-                   (c_alt & (f_ref | m_ref));
-    if constexpr (X) {
-        const uint32_t err_x = (c_alt & m_ref) | (c_ref & m_alt);
-        err = (male & err_x) | (~male & err);
-    }
-    ok &= ~err;
-    const uint32_t fh = ~F.a1nz & F.a2nz, mh = ~M.a1nz & M.a2nz;    // parent is "0/x"
-    const uint32_t c0x = ~C.a1nz & C.a2nz;
-    const uint32_t both_h = fh & mh;
-    // trA == 1  (tdt.c:175-181 kid 00; :182-202 kid 0x)
-    const uint32_t a1 = c_ref | (c0x & ((F.ne & (M.ne | M.a1nz)) | (~F.ne & F.a1nz)));
-    const uint32_t A1 = ok & a1, A2 = ok & ~a1;
-    const uint32_t B1 = ok & c_ref & both_h;
-    const uint32_t B2 = ok & ((c0x & F.ne & M.ne) | (~(c_ref | c0x) & both_h));
-    t1 += __builtin_popcount(A1) + __builtin_popcount(B1);
-    t2 += __builtin_popcount(A2) + __builtin_popcount(B2);
-}
-
-// scalar statement of the same rules for one family with several counted
-// children, keeping trA/trB at family scope (tdt.c:128-132)
-__device__ __forceinline__ int mendel_code(bool is_x_male, int f1, int f2, int m1, int m2, int c1, int c2) {
+__host__ __device__ __forceinline__ int mendel_code(bool is_x_male, int f1, int f2, int m1, int m2, int c1, int c2) {
     const bool f_ref = !f1 && !f2, f_alt = f1 && f2, m_ref = !m1 && !m2, m_alt = m1 && m2;
     const bool c_ref = !c1 && !c2, c_alt = c1 && c2;
     if (is_x_male) return (c_alt && m_ref) ? 9 : (c_ref && m_alt) ? 10 : 0;
@@ -76,42 +30,112 @@ __device__ __forceinline__ int mendel_code(bool is_x_male, int f1, int f2, int m
     return (f_ref && m_ref) ? 8 : f_ref ? 6 : m_ref ? 7 : 0;
 }
 
+// parents usable? (tdt.c:103-123); alleles 0..14, 15 = missing
+__host__ __device__ __forceinline__ bool tdt_parents_usable(int f1, int f2, int m1, int m2) {
+    if (f1 == 0xF || f2 == 0xF || m1 == 0xF || m2 == 0xF) return false;   // tdt.c:103-108
+    if (f1 == f2 && m1 == m2) return false;                                // tdt.c:113-117
+    if ((f1 && !f2) || (m1 && !m2)) return false;                          // tdt.c:119-123
+    return true;
+}
+
+// one child against usable parents; updates the family-scope trA / trB and the tallies
+__host__ __device__ __forceinline__ void tdt_child(int f1, int f2, int m1, int m2, int c1, int c2, bool x_male,
+                                                   int &trA, int &trB, int &t1, int &t2) {
+    if (c1 == 0xF || c2 == 0xF) return;                                    // tdt.c:154
+    if (mendel_code(x_male, f1, f2, m1, m2, c1, c2)) return;               // tdt.c:161-166
+    const bool fh = !f1 && f2, mh = !m1 && m2;
+    if (!c1 && !c2) {                                                      // tdt.c:175-181
+        if (fh && mh) { trA = 1; trB = 1; } else { trA = 1; }
+    } else if (!c1 && c2) {                                                // tdt.c:182-202
+        if (f1 != f2) {
+            if (m1 != m2) { trA = 1; trB = 2; }
+            else if (!m1) { trA = 2; }
+            else { trA = 1; }
+        } else if (!f1) { trA = 2; }
+        else { trA = 1; }
+    } else {                                                               // tdt.c:203-213
+        if (fh && mh) { trA = 2; trB = 2; } else { trA = 2; }
+    }
+    if (trA == 1) t1++; else if (trA == 2) t2++;                           // tdt.c:235-239
+    if (trB == 1) t1++; else if (trB == 2) t2++;
+}
+
 __device__ __forceinline__ void tdt_family_slow(const uint8_t *__restrict__ grp, int n_children,
                                                 const uint8_t *__restrict__ male, bool x_row,
                                                 int &t1, int &t2) {
     const uint32_t fb = grp[0], mb = grp[1];
     const int f1 = fb >> 4, f2 = fb & 0xF, m1 = mb >> 4, m2 = mb & 0xF;
-    if (f1 == 0xF || f2 == 0xF || m1 == 0xF || m2 == 0xF) return;       // tdt.c:103-108
-    if (f1 == f2 && m1 == m2) return;                                    // tdt.c:113-117
-    if ((f1 && !f2) || (m1 && !m2)) return;                              // tdt.c:119-123
-    int trA = 0, trB = 0;                                                // tdt.c:128-132
+    if (!tdt_parents_usable(f1, f2, m1, m2)) return;
+    int trA = 0, trB = 0;                                                  // tdt.c:128-132
     for (int k = 0; k < n_children; ++k) {
         const uint32_t cb = grp[2 + k];
-        const int c1 = cb >> 4, c2 = cb & 0xF;
-        if (c1 == 0xF || c2 == 0xF) continue;                            // tdt.c:154
-        if (mendel_code(x_row && male[2 + k], f1, f2, m1, m2, c1, c2)) continue;   // tdt.c:161-166
-        const bool fh = !f1 && f2, mh = !m1 && m2;
-        if (!c1 && !c2) {
-            if (fh && mh) { trA = 1; trB = 1; } else { trA = 1; }
-        } else if (!c1 && c2) {
-            if (f1 != f2) {
-                if (m1 != m2) { trA = 1; trB = 2; }
-                else if (!m1) { trA = 2; }
-                else { trA = 1; }
-            } else if (!f1) { trA = 2; }
-            else { trA = 1; }
-        } else {
-            if (fh && mh) { trA = 2; trB = 2; } else { trA = 2; }
-        }
-        if (trA == 1) t1++; else if (trA == 2) t2++;                     // tdt.c:235-239
-        if (trB == 1) t1++; else if (trB == 2) t2++;
+        tdt_child(f1, f2, m1, m2, (int)(cb >> 4), (int)(cb & 0xF), x_row && male[2 + k], trA, trB, t1, t2);
     }
 }
 
-// Row layout: [F plane P16 | M plane P16 | C plane P16 | slow groups | pad].
+// ---------------------------------------------------------------------------
+// Fast path: byte look-up tables evaluated 4 trios at a time with v_perm_b32.
+//
+// The father / mother / child planes hold CLASS bytes (hpgv_kernels.h
+// tdt_parent_class / tdt_child_class).  For a single counted child the tallies
+// depend only on (father class, mother class, child class):
+//   pair  = PAIR[m*4 + f]      one-hot "pair class" byte (16-entry table = two
+//                              8-byte v_perm tables + one v_perm to pick by bit 3)
+//   t1   += popcount(pair & C1[child]),  t2 += popcount(pair & C2[child])
+// where C1/C2 are 8-entry tables of the pair classes that add to t1 / t2 for that
+// child class; a pair class that adds 2 owns a second ("dup") bit.  Unusable
+// parents carry a code >= 0x20, which (a) is killed by K = v_perm(0, 0, f|m):
+// selector bytes >= 13 give 0xFF, selectors 0..3 give the 0x00 table bytes.
+// ---------------------------------------------------------------------------
+struct TdtLut {
+    uint32_t pair_lo[2];   // PAIR[0..7]   (idx = mother*4 + father)
+    uint32_t pair_hi[2];   // PAIR[8..15]
+    uint32_t c1[2];        // child class -> pair-class mask counted into t1
+    uint32_t c2[2];        // child class -> pair-class mask counted into t2
+};
+struct TdtLuts {
+    TdtLut autosome;       // joint encoding: one pair byte serves t1 and t2
+    TdtLut xmale_t1;       // chr "X", male child: separate encodings for t1 ...
+    TdtLut xmale_t2;       // ... and t2 (8 pair classes + a dup bit do not fit one byte)
+};
+
+__device__ __forceinline__ uint32_t lut8(uint32_t t0, uint32_t t1, uint32_t sel) {
+    return __builtin_amdgcn_perm(t1, t0, sel);              // selector 0..3 -> t0 bytes, 4..7 -> t1 bytes
+}
+__device__ __forceinline__ uint32_t tdt_pair(const TdtLut &L, uint32_t idx) {
+    const uint32_t sel = idx & 0x07070707u;
+    const uint32_t lo = lut8(L.pair_lo[0], L.pair_lo[1], sel), hi = lut8(L.pair_hi[0], L.pair_hi[1], sel);
+    const uint32_t pick = ((idx >> 1) & 0x04040404u) | 0x03020100u;   // byte i: i (lo) or i + 4 (hi)
+    return __builtin_amdgcn_perm(hi, lo, pick);
+}
+
+template <bool X>
+__device__ __forceinline__ void tdt4(const TdtLuts &L, uint32_t f, uint32_t m, uint32_t c, uint32_t male,
+                                     int &t1, int &t2) {
+    const uint32_t idx = (m << 2) | f;
+    const uint32_t kill = __builtin_amdgcn_perm(0u, 0u, f | m);       // 0xFF where a parent is unusable
+    uint32_t w1, w2;
+    if constexpr (!X) {
+        const uint32_t pair = tdt_pair(L.autosome, idx) & ~kill;
+        w1 = pair & lut8(L.autosome.c1[0], L.autosome.c1[1], c);
+        w2 = pair & lut8(L.autosome.c2[0], L.autosome.c2[1], c);
+    } else {
+        const uint32_t pa = tdt_pair(L.autosome, idx);
+        const uint32_t a1 = pa & lut8(L.autosome.c1[0], L.autosome.c1[1], c), a2 = pa & lut8(L.autosome.c2[0], L.autosome.c2[1], c);
+        const uint32_t x1 = tdt_pair(L.xmale_t1, idx) & lut8(L.xmale_t1.c1[0], L.xmale_t1.c1[1], c);
+        const uint32_t x2 = tdt_pair(L.xmale_t2, idx) & lut8(L.xmale_t2.c2[0], L.xmale_t2.c2[1], c);
+        w1 = ((male & x1) | (~male & a1)) & ~kill;                    // male: 0xFF per male child
+        w2 = ((male & x2) | (~male & a2)) & ~kill;
+    }
+    t1 += __builtin_popcount(w1);
+    t2 += __builtin_popcount(w2);
+}
+
+// Row layout: [F plane P16 | M plane P16 | C plane P16 | slow groups (HPGV8) | pad].
 template <bool NT, int U>
 __global__ __launch_bounds__(256) void k_tdt_scan(const uint8_t *__restrict__ gt, size_t pitch, int n_variants,
-                                                  int pchunks /* P16/16 */, const uint8_t *__restrict__ male_plane,
+                                                  int pchunks /* P16/16 */, TdtLuts luts,
+                                                  const uint8_t *__restrict__ male_plane,
                                                   int n_slow, const int32_t *__restrict__ slow_off,
                                                   const uint8_t *__restrict__ slow_male, int slow_base,
                                                   const uint8_t *__restrict__ is_x, int2 *__restrict__ tu, int vpw) {
@@ -131,28 +155,34 @@ __global__ __launch_bounds__(256) void k_tdt_scan(const uint8_t *__restrict__ gt
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int c = base + u * 64 + lane;
-                qf[u] = qm[u] = qc[u] = make_uint4(~0u, ~0u, ~0u, ~0u);
+                // virtual trio: unusable parents, missing child
+                qf[u] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+                qm[u] = make_uint4(0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u);
+                qc[u] = make_uint4(0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u);
                 if (c < pchunks) {
                     qf[u] = load16<NT>(rowF + c);
                     qm[u] = load16<NT>(rowM + c);
                     qc[u] = load16<NT>(rowC + c);
                 }
             }
+            if (!x_row) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int c = base + u * 64 + lane;
-                if (!x_row) {
-                    tdt4<false>(qf[u].x, qm[u].x, qc[u].x, 0, t1, t2);
-                    tdt4<false>(qf[u].y, qm[u].y, qc[u].y, 0, t1, t2);
-                    tdt4<false>(qf[u].z, qm[u].z, qc[u].z, 0, t1, t2);
-                    tdt4<false>(qf[u].w, qm[u].w, qc[u].w, 0, t1, t2);
-                } else {
+                for (int u = 0; u < U; ++u) {
+                    tdt4<false>(luts, qf[u].x, qm[u].x, qc[u].x, 0, t1, t2);
+                    tdt4<false>(luts, qf[u].y, qm[u].y, qc[u].y, 0, t1, t2);
+                    tdt4<false>(luts, qf[u].z, qm[u].z, qc[u].z, 0, t1, t2);
+                    tdt4<false>(luts, qf[u].w, qm[u].w, qc[u].w, 0, t1, t2);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int c = base + u * 64 + lane;
                     uint4 ml = make_uint4(0, 0, 0, 0);
                     if (c < pchunks) ml = reinterpret_cast<const uint4 *>(male_plane)[c];
-                    tdt4<true>(qf[u].x, qm[u].x, qc[u].x, ml.x, t1, t2);
-                    tdt4<true>(qf[u].y, qm[u].y, qc[u].y, ml.y, t1, t2);
-                    tdt4<true>(qf[u].z, qm[u].z, qc[u].z, ml.z, t1, t2);
-                    tdt4<true>(qf[u].w, qm[u].w, qc[u].w, ml.w, t1, t2);
+                    tdt4<true>(luts, qf[u].x, qm[u].x, qc[u].x, ml.x, t1, t2);
+                    tdt4<true>(luts, qf[u].y, qm[u].y, qc[u].y, ml.y, t1, t2);
+                    tdt4<true>(luts, qf[u].z, qm[u].z, qc[u].z, ml.z, t1, t2);
+                    tdt4<true>(luts, qf[u].w, qm[u].w, qc[u].w, ml.w, t1, t2);
                 }
             }
         }
@@ -180,12 +210,95 @@ __global__ __launch_bounds__(256) void k_tdt_stats(const int2 *__restrict__ tu, 
 }
 
 // ---------------------------------------------------------------------------
-// host-side plan of the TDT row layout
+// host side: pedigree -> row layout + look-up tables
 // ---------------------------------------------------------------------------
+namespace tdt_host {
+
+// weights[f][m][c] in {0,1,2} -> one-hot pair bytes (idx = m*4+f) and child masks.
+// Pair classes = distinct non-zero weight vectors over the 4 child classes; a class
+// with a weight 2 somewhere owns a second bit.  Returns false if 8 bits do not suffice.
+inline bool encode(const int w1[4][4][4], const int w2[4][4][4], bool use1, bool use2,
+                   uint8_t pair[16], uint8_t c1[8], uint8_t c2[8]) {
+    struct Cls { int v1[4], v2[4]; int bit, dup; };
+    std::vector<Cls> cls;
+    int next_bit = 0;
+    memset(pair, 0, 16); memset(c1, 0, 8); memset(c2, 0, 8);
+    for (int m = 0; m < 4; ++m)
+        for (int f = 0; f < 4; ++f) {
+            Cls k{};
+            bool zero = true, has2 = false;
+            for (int c = 0; c < 4; ++c) {
+                k.v1[c] = use1 ? w1[f][m][c] : 0;
+                k.v2[c] = use2 ? w2[f][m][c] : 0;
+                if (k.v1[c] || k.v2[c]) zero = false;
+                if (k.v1[c] == 2 || k.v2[c] == 2) has2 = true;
+                if (k.v1[c] > 2 || k.v2[c] > 2) return false;
+            }
+            if (zero) continue;
+            int found = -1;
+            for (size_t i = 0; i < cls.size(); ++i)
+                if (!memcmp(cls[i].v1, k.v1, sizeof k.v1) && !memcmp(cls[i].v2, k.v2, sizeof k.v2)) { found = (int)i; break; }
+            if (found < 0) {
+                k.bit = next_bit++;
+                k.dup = has2 ? next_bit++ : -1;
+                if (next_bit > 8) return false;
+                cls.push_back(k);
+                found = (int)cls.size() - 1;
+            }
+            const Cls &q = cls[found];
+            pair[m * 4 + f] = (uint8_t)((1u << q.bit) | (q.dup >= 0 ? (1u << q.dup) : 0u));
+        }
+    for (const Cls &q : cls)
+        for (int c = 0; c < 4; ++c) {
+            if (q.v1[c] >= 1) c1[c] |= (uint8_t)(1u << q.bit);
+            if (q.v1[c] == 2) c1[c] |= (uint8_t)(1u << q.dup);
+            if (q.v2[c] >= 1) c2[c] |= (uint8_t)(1u << q.bit);
+            if (q.v2[c] == 2) c2[c] |= (uint8_t)(1u << q.dup);
+        }
+    return true;
+}
+
+inline void pack(const uint8_t pair[16], const uint8_t c1[8], const uint8_t c2[8], TdtLut &L) {
+    auto dw = [](const uint8_t *b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); };
+    L.pair_lo[0] = dw(pair); L.pair_lo[1] = dw(pair + 4);
+    L.pair_hi[0] = dw(pair + 8); L.pair_hi[1] = dw(pair + 12);
+    L.c1[0] = dw(c1); L.c1[1] = dw(c1 + 4);
+    L.c2[0] = dw(c2); L.c2[1] = dw(c2 + 4);
+}
+
+// Runs the scalar rule over class representatives and builds the three tables.
+inline bool build_luts(TdtLuts &out) {
+    // representatives: parent classes 0 "0/0", 1 "0/1", 2 "1/1", 3 "1/2"; child 0 "0/0", 1 "0/1", 2 "1/0", 3 "1/1"
+    static const int P[4][2] = {{0, 0}, {0, 1}, {1, 1}, {1, 2}};
+    static const int C[4][2] = {{0, 0}, {0, 1}, {1, 0}, {1, 1}};
+    int w1[2][4][4][4], w2[2][4][4][4];
+    for (int x = 0; x < 2; ++x)
+        for (int f = 0; f < 4; ++f)
+            for (int m = 0; m < 4; ++m)
+                for (int c = 0; c < 4; ++c) {
+                    int t1 = 0, t2 = 0, trA = 0, trB = 0;
+                    if (tdt_parents_usable(P[f][0], P[f][1], P[m][0], P[m][1]))
+                        tdt_child(P[f][0], P[f][1], P[m][0], P[m][1], C[c][0], C[c][1], x == 1, trA, trB, t1, t2);
+                    w1[x][f][m][c] = t1; w2[x][f][m][c] = t2;
+                }
+    uint8_t pair[16], c1[8], c2[8];
+    if (!encode(w1[0], w2[0], true, true, pair, c1, c2)) return false;
+    pack(pair, c1, c2, out.autosome);
+    if (!encode(w1[1], w2[1], true, false, pair, c1, c2)) return false;
+    pack(pair, c1, c2, out.xmale_t1);
+    if (!encode(w1[1], w2[1], false, true, pair, c1, c2)) return false;
+    pack(pair, c1, c2, out.xmale_t2);
+    return true;
+}
+
+}  // namespace tdt_host
+
 struct TdtPlan {
     int n_fast = 0, n_slow_families = 0;
     int pchunks = 0;
+    int p16 = 0;
     int slow_base = 0;
+    TdtLuts luts{};
     uint8_t *d_male_plane = nullptr;
     int32_t *d_slow_off = nullptr;
     uint8_t *d_slow_male = nullptr;
@@ -195,13 +308,15 @@ struct TdtPlan {
         if (d_slow_off) (void)hipFree(d_slow_off);
         if (d_slow_male) (void)hipFree(d_slow_male);
         d_male_plane = nullptr; d_slow_off = nullptr; d_slow_male = nullptr;
-        n_fast = n_slow_families = pchunks = slow_base = 0;
+        n_fast = n_slow_families = pchunks = p16 = slow_base = 0;
     }
 
+    // return codes are hpgv status values (1 invalid, 3 hip, 6 unsupported)
     int build(int n_samples, int n_families, const int32_t *father_col, const int32_t *mother_col,
               const int32_t *child_off, const int32_t *child_col, const uint8_t *child_sex,
               size_t row_align, std::vector<int32_t> &col_of_pos, size_t &pitch, std::string &why) {
         release();
+        if (!tdt_host::build_luts(luts)) { why = "TDT look-up tables do not fit one byte"; return 6; }
         std::vector<int> fast, slow;
         for (int f = 0; f < n_families; ++f) {
             const int nc = child_off[f + 1] - child_off[f];
@@ -216,13 +331,14 @@ struct TdtPlan {
         n_slow_families = (int)slow.size();
         const size_t P16 = ((size_t)n_fast + 15) / 16 * 16;
         pchunks = (int)(P16 / 16);
+        p16 = (int)P16;
         std::vector<int32_t> slow_off(1, 0);
         size_t slow_bytes = 0;
         for (int f : slow) { slow_bytes += 2 + (size_t)(child_off[f + 1] - child_off[f]); slow_off.push_back((int32_t)slow_bytes); }
         size_t used = 3 * P16 + slow_bytes;
         pitch = (used + row_align - 1) / row_align * row_align;
         if (pitch == 0) pitch = row_align;
-        if (pitch > 0x7FFFFFFFu) { why = "row too long"; return 6; }
+        if (pitch > 0x3FFFFFFFu) { why = "row too long"; return 6; }
         slow_base = (int)(3 * P16);
         col_of_pos.assign(pitch, -1);
         std::vector<uint8_t> male_plane(P16 ? P16 : 16, 0), slow_male(slow_bytes ? slow_bytes : 16, 0);
@@ -231,7 +347,7 @@ struct TdtPlan {
             col_of_pos[t] = father_col[f];
             col_of_pos[P16 + t] = mother_col[f];
             col_of_pos[2 * P16 + t] = child_col[k];
-            male_plane[t] = (child_sex[k] == 0 /* HPGV_SEX_MALE */) ? 0x08 : 0x00;
+            male_plane[t] = (child_sex[k] == 0 /* HPGV_SEX_MALE */) ? 0xFF : 0x00;
         }
         for (size_t s = 0; s < slow.size(); ++s) {
             const int f = slow[s];
@@ -264,70 +380,56 @@ struct TdtPlan {
         const unsigned blocks = (unsigned)((waves + 3) / 4);
         constexpr int U = 4;
         if (nt)
-            hipLaunchKernelGGL((k_tdt_scan<true, U>), dim3(blocks), dim3(256), 0, st, d_gt, pitch, n_variants, pchunks,
+            hipLaunchKernelGGL((k_tdt_scan<true, U>), dim3(blocks), dim3(256), 0, st, d_gt, pitch, n_variants, pchunks, luts,
                                d_male_plane, n_slow_families, d_slow_off, d_slow_male, slow_base, d_is_x, d_tu, vpw);
         else
-            hipLaunchKernelGGL((k_tdt_scan<false, U>), dim3(blocks), dim3(256), 0, st, d_gt, pitch, n_variants, pchunks,
+            hipLaunchKernelGGL((k_tdt_scan<false, U>), dim3(blocks), dim3(256), 0, st, d_gt, pitch, n_variants, pchunks, luts,
                                d_male_plane, n_slow_families, d_slow_off, d_slow_male, slow_base, d_is_x, d_tu, vpw);
     }
 };
 
 // ---------------------------------------------------------------------------
 // variant stats scan (hpg-libs get_variants_stats, call site stats_runner.c:194;
-// counting rules: oracle/hpgv_oracle.c orc_variant_stats).  Output per variant,
-// 8 x int32: n_00 n_01 n_10 n_11 missing_genotypes missing_alleles allele0 allele1
+// counting rules: oracle/hpgv_oracle.c orc_variant_stats).  Rows hold the
+// one-hot flag bytes of hpgv_kernels.h stats_flags (pad bytes are 0), so every
+// counter is a masked popcount.  Output per variant, 8 x int32:
+//   n_00 n_01 n_10 n_11 missing_genotypes missing_alleles allele0 allele1
 // (allele counts include the called allele of half-missing genotypes).
-// Pad / virtual bytes are 0xFF and are subtracted using the known slot count.
 // ---------------------------------------------------------------------------
 template <bool NT, int U>
 __global__ __launch_bounds__(256) void k_stats_scan(const uint8_t *__restrict__ gt, size_t pitch, int n_variants,
-                                                    int chunks, int n_samples, int4 *__restrict__ out8, int vpw) {
+                                                    int chunks, int4 *__restrict__ out8, int vpw) {
     const int lane = threadIdx.x & 63;
     const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long v_begin = wave * vpw;
-    const int slots = ((chunks + 64 * U - 1) / (64 * U)) * (64 * U);
-    const int fake = slots * 16 - n_samples;          // 0xFF bytes that are not samples
     for (int i = 0; i < vpw; ++i) {
         const long v = v_begin + i;
         if (v >= n_variants) break;
         const uint4 *row = reinterpret_cast<const uint4 *>(gt + (size_t)v * pitch);
-        int n00 = 0, n01 = 0, n10 = 0, n11 = 0, mg = 0, nnf = 0, a0 = 0, a1 = 0;
+        int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int base = 0; base < chunks; base += 64 * U) {
             uint4 q[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int c = base + u * 64 + lane;
-                q[u] = make_uint4(~0u, ~0u, ~0u, ~0u);
+                q[u] = make_uint4(0u, 0u, 0u, 0u);
                 if (c < chunks) q[u] = load16<NT>(row + c);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t w[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t x = w[k];
-                    const uint32_t z = ~nib_nonzero(x);                 // bit3/bit7: nibble == 0
-                    const uint32_t e = ~nib_nonzero(x ^ 0x11111111u);   // bit3/bit7: nibble == 1
-                    const uint32_t zl = z & K8, zh = (z >> 4) & K8, el = e & K8, eh = (e >> 4) & K8;
-                    a0 += __builtin_popcount(z & 0x88888888u);
-                    a1 += __builtin_popcount(e & 0x88888888u);
-                    n00 += __builtin_popcount(zl & zh);
-                    n01 += __builtin_popcount(zh & el);
-                    n10 += __builtin_popcount(eh & zl);
-                    n11 += __builtin_popcount(eh & el);
-                    const uint32_t nf = nib_not_f(x);
-                    nnf += __builtin_popcount(nf);
-                    mg += __builtin_popcount(~(nf & (nf >> 4)) & K8);
-                }
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) cnt[b] += __builtin_popcount(w[k] & (0x01010101u << b));
             }
         }
-        const int s00 = wave_sum(n00), s01 = wave_sum(n01), s10 = wave_sum(n10), s11 = wave_sum(n11);
-        const int smg = wave_sum(mg) - fake;
-        const int sma = (slots * 32 - wave_sum(nnf)) - 2 * fake;
-        const int sa0 = wave_sum(a0), sa1 = wave_sum(a1);
+        int s[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) s[b] = wave_sum(cnt[b]);
         if (lane == 0) {
-            out8[2 * v] = make_int4(s00, s01, s10, s11);
-            out8[2 * v + 1] = make_int4(smg, sma, sa0, sa1);
+            out8[2 * v] = make_int4(s[0], s[1], s[2], s[3]);
+            out8[2 * v + 1] = make_int4(s[4], s[4] + s[5], 2 * s[0] + s[1] + s[2] + s[6], 2 * s[3] + s[1] + s[2] + s[7]);
         }
     }
 }
