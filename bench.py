@@ -32,6 +32,9 @@ WORKLOADS = {
     "c2": (1_000_000, 10_000, "assoc --chisq, synthetic 1M biallelic SNP x 10k case/control (BASELINE configs[1])"),
     "m8": (1_250_000, 50_000, "assoc --chisq, per-GPU shard (1/8) of the 10M SNP x 50k metric cohort"),
     "smoke": (20_000, 2_000, "assoc --chisq, tiny smoke cohort"),
+    # secondary configs (not the headline metric; run with --workload):
+    "c3": (1_000_000, 10_000, "assoc --fisher on the 1M x 10k cohort (BASELINE configs[2]): scan + Fisher p-pass"),
+    "c4": (2_000_000, 15_000, "tdt, 2M SNP x 5k trios (BASELINE configs[3]): trio scan + TDT statistics"),
 }
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -47,10 +50,29 @@ def parse_args():
     ap.add_argument("--gather-chunks", type=int, default=8,
                     help="N>1: the shard is scanned in this many variant blocks so that the result "
                          "gather of block i overlaps the scan of block i+1")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="bracket the scan kernel with HIP events on every n-th timed step (an event pair costs "
+                         "tens of microseconds of queue bubbles, so not every step carries one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target wall time of each CPU baseline leg")
     ap.add_argument("--option", action="append", default=[], help="engine option key=value")
     return ap.parse_args()
+
+
+def pmc_traffic(workload, variants, samples, pitch, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/*_pmc_traffic_<workload>.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    in separate runs, gfx950 correction applied).  None when no matching profile."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_%s.json" % workload))):
+        try:
+            d = json.load(open(f))
+            if d["variants"] == variants and d["samples"] == samples and d["row_pitch_bytes"] == pitch:
+                best = d["kernels"][kernel]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+    return best
 
 
 def cpu_baseline(n_samples, cond, target_s):
@@ -126,54 +148,75 @@ def main():
     for kv in args.option:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
+    kind = {"c3": "fisher", "c4": "tdt"}.get(args.workload, "chisq")
     cond = (np.arange(N) % 2).astype(np.uint8)          # odd samples are cases
-    nA, nU, pitch = eng.set_cohort(cond)
+    fam = None
+    if kind == "tdt":
+        n_tr = N // 3                                   # trio k = columns (3k, 3k+1, 3k+2), child sex alternating
+        kk = np.arange(n_tr)
+        fam = (3 * kk, 3 * kk + 1, np.arange(n_tr + 1), 3 * kk + 2, (kk % 2).astype(np.uint8))
+        nA, nU, pitch = eng.set_families(3 * n_tr, *fam)      # (fast trios, slow families, pitch)
+        which, res_bytes, payload, scan_name = hpgv.LAYOUT_TDT, 32, 32, "k_tdt_scan"
+    else:
+        nA, nU, pitch = eng.set_cohort(cond)
+        which, scan_name = hpgv.LAYOUT_ASSOC, "k_assoc_scan"
+        res_bytes, payload = (40, 40) if kind == "chisq" else (32, 32)
+        if kind == "fisher":
+            # ln(i!) table with num_samples * 10 entries, as assoc_runner.c:164-166 builds it (an INPUT of the pass)
+            lf_table = np.concatenate([[0.0], np.cumsum(np.log(np.arange(1, N * 10, dtype=np.float64)))])
+            eng.set_logfact(lf_table)
+    head = 16 if kind != "tdt" else 8                   # integer tallies at the front of a result block
 
     # device memory owned by torch (plumbing); raw pointers cross the C ABI
     gt = torch.empty(V * pitch, dtype=torch.uint8, device=dev)
-    lay = sharding.result_block_layout(V)
-    res = torch.empty(lay["bytes"], dtype=torch.uint8, device=dev)
+    res = torch.empty(res_bytes * V, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream()
     sp = stream.cuda_stream
     v0 = rank * V                                       # global variant ids of this shard
-    eng.synth(hpgv.LAYOUT_ASSOC, v0, V, gt.data_ptr(), sp)
+    eng.synth(which, v0, V, gt.data_ptr(), sp)
     torch.cuda.synchronize()
 
-    base = res.data_ptr()
     chunks = max(1, args.gather_chunks) if world > 1 else 1
     bounds = [sharding.variant_range(c, chunks, V) for c in range(chunks)]
-    # per-chunk result blocks are contiguous sub-blocks, so a chunk's gather needs no repacking:
-    # block c = counts[lo:hi] | odds[lo:hi] | chisq[lo:hi] | p[lo:hi] lives in its own tensor
-    chunk_res = [torch.empty(40 * (hi - lo), dtype=torch.uint8, device=dev) for lo, hi in bounds] if world > 1 else None
+    # a block's result = tallies[n] | f64 arrays[n] ...: each block lives in its own tensor, so the
+    # gather of block i (overlapping the scan of block i+1) needs no repacking
+    chunk_res = [res] if world == 1 else [torch.empty(res_bytes * (hi - lo), dtype=torch.uint8, device=dev) for lo, hi in bounds]
     recv = None
     if world > 1 and rank == 0:
-        recv = [[torch.empty(40 * (hi - lo), dtype=torch.uint8, device=dev) for _ in range(world)] for lo, hi in bounds]
+        recv = [[torch.empty(res_bytes * (hi - lo), dtype=torch.uint8, device=dev) for _ in range(world)] for lo, hi in bounds]
+
+    def scan_block(lo, n, b):
+        g = gt.data_ptr() + lo * pitch
+        if kind == "tdt":
+            eng.tdt_scan(g, n, b, None, sp)
+        else:
+            eng.assoc_scan(g, n, b, None, sp)
+
+    def stats_block(n, b):
+        if kind == "chisq":
+            eng.assoc_chisq(b, n, b + 16 * n, b + 24 * n, b + 32 * n, sp)
+        elif kind == "fisher":
+            eng.assoc_fisher(b, n, b + 16 * n, b + 24 * n, sp)
+        else:
+            eng.tdt_stats(b, n, b + 8 * n, b + 16 * n, b + 24 * n, sp)
 
     def step(ev=None):
-        if world == 1:
-            if ev:
-                ev[0].record(stream)
-            eng.assoc_scan(gt.data_ptr(), V, base + lay["counts"], None, sp)
-            if ev:
-                ev[1].record(stream)
-            eng.assoc_chisq(base + lay["counts"], V, base + lay["odds"], base + lay["chisq"], base + lay["p"], sp)
-            return None
         works = []
         for c, (lo, hi) in enumerate(bounds):
             n = hi - lo
             b = chunk_res[c].data_ptr()
             if ev and c == 0:
                 ev[0].record(stream)
-            eng.assoc_scan(gt.data_ptr() + lo * pitch, n, b, None, sp)
+            scan_block(lo, n, b)
             if ev and c == 0:
                 ev[1].record(stream)
-            eng.assoc_chisq(b, n, b + 16 * n, b + 24 * n, b + 32 * n, sp)
-            _, w = sharding.gather_blocks(chunk_res[c], [40 * n] * world, dst=0, async_op=True,
-                                           out_bufs=recv[c] if recv else None)
-            works.append(w)
+            stats_block(n, b)
+            if world > 1:
+                _, w = sharding.gather_blocks(chunk_res[c], [res_bytes * n] * world, dst=0, async_op=True,
+                                              out_bufs=recv[c] if recv else None)
+                works.append(w)
         for w in works:
             w.wait()
-        return None
 
     def barrier():
         torch.cuda.synchronize()
@@ -184,10 +227,12 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    every = max(1, args.event_every)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range((args.steps + every - 1) // every)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(evs[k])
+        step(evs[k // every] if k % every == 0 else None)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -196,41 +241,50 @@ def main():
         elapsed = float(t.item())
 
     scan_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    scan_variants = V if world == 1 else (bounds[0][1] - bounds[0][0])
-    bytes_per_variant = N + 40                          # N x 1 B + 40 B result payload
+    scan_variants = bounds[0][1] - bounds[0][0]
+    bytes_per_variant = N + payload                     # N x 1 B + result payload
     achieved = scan_variants * bytes_per_variant / (scan_ms * 1e-3) / 1e9
 
-    # ---- parity spot check against the oracle (not timed) -----------------------
+    # ---- parity spot check: the oracle as CHECKER of the timed run's outputs (not timed, not on the product path)
     parity = None
     if rank == 0:
         from oracle import pyoracle as orc
-        if world == 1:
-            counts = res[: 16 * V].view(torch.int32).view(V, 4).cpu().numpy()
-            stats = res[16 * V:].view(torch.float64).view(3, V).cpu().numpy()
-        else:
-            n0 = bounds[0][1] - bounds[0][0]
-            counts = chunk_res[0][: 16 * n0].view(torch.int32).view(n0, 4).cpu().numpy()
-            stats = chunk_res[0][16 * n0:].view(torch.float64).view(3, n0).cpu().numpy()
-        nchk = counts.shape[0]
-        idx = np.unique(np.concatenate([np.arange(min(256, nchk)), np.arange(0, nchk, 1000),
-                                        np.arange(max(0, nchk - 256), nchk)]))
+        n0 = bounds[0][1] - bounds[0][0]
+        blk = chunk_res[0]
+        ints = blk[: head * n0].view(torch.int32).view(n0, head // 4).cpu().numpy()
+        stats = blk[head * n0:].view(torch.float64).view(-1, n0).cpu().numpy()
+        idx = np.unique(np.concatenate([np.arange(min(256, n0)), np.arange(0, n0, 1000), np.arange(max(0, n0 - 256), n0)]))
+        if kind == "fisher":
+            idx = idx[:: max(1, len(idx) // 400)]
         ok = True
+
+        def same(got, exp):
+            with np.errstate(invalid="ignore"):
+                return bool(np.all((np.abs(got - exp) <= 1e-10 * np.maximum(1, np.abs(exp))) | (np.isnan(got) & np.isnan(exp))))
+        ncol = N if kind != "tdt" else 3 * (N // 3)
         for lo in range(0, len(idx), 512):
             sel = idx[lo: lo + 512]
-            rows = np.stack([orc.synth_matrix(v0 + int(v), 1, N, N)[0] for v in sel])
-            A1, A2, U1, U2 = orc.assoc_counts(rows, cond)
-            odds, chisq, p = orc.assoc_stats(orc.TASK_CHISQ, A1, A2, U1, U2)
-            ok &= bool(np.array_equal(counts[sel], np.stack([A1, A2, U1, U2], 1)))
-            for got, exp in ((stats[0][sel], odds), (stats[1][sel], chisq), (stats[2][sel], p)):
-                with np.errstate(invalid="ignore"):
-                    ok &= bool(np.all((np.abs(got - exp) <= 1e-10 * np.maximum(1, np.abs(exp))) |
-                                      (np.isnan(got) & np.isnan(exp))))
-        parity = {"checked_variants": int(len(idx)), "ok": ok}
+            rows = np.stack([orc.synth_matrix(v0 + int(v), 1, ncol, ncol)[0] for v in sel])
+            if kind == "tdt":
+                t1, t2 = orc.tdt_counts(rows, *fam)
+                ok &= bool(np.array_equal(ints[sel], np.stack([t1, t2], 1)))
+                exp = orc.tdt_stats(t1, t2)
+                ok &= all(same(stats[j][sel], exp[j]) for j in range(3))
+            else:
+                A1, A2, U1, U2 = orc.assoc_counts(rows, cond)
+                ok &= bool(np.array_equal(ints[sel], np.stack([A1, A2, U1, U2], 1)))
+                if kind == "chisq":
+                    exp = orc.assoc_stats(orc.TASK_CHISQ, A1, A2, U1, U2)
+                    ok &= all(same(stats[j][sel], exp[j]) for j in range(3))
+                else:
+                    odds, _, p = orc.assoc_stats(orc.TASK_FISHER, A1, A2, U1, U2, lf_table)
+                    ok &= same(stats[0][sel], odds) and same(stats[1][sel], p)
+        parity = {"checked_variants": int(len(idx)), "ok": bool(ok)}
 
     if rank == 0:
         total_variants = V * world * args.steps
         out = {
-            "metric": "variants/s chi2 assoc",
+            "metric": {"chisq": "variants/s chi2 assoc", "fisher": "variants/s fisher assoc", "tdt": "variants/s tdt"}[kind],
             "value": total_variants / elapsed,
             "unit": "variants/s",
             "n_gpus": world,
@@ -243,16 +297,18 @@ def main():
             "dtype": "u8",
             "data": "synthetic (on-device splitmix64 cohort, HWE genotypes, 1% missing, odd samples are cases)",
             "config": {"workload": "%s: %s" % (args.workload, desc), "variants_per_gpu": V, "samples": N,
-                       "affected": nA, "unaffected": nU, "row_pitch_bytes": pitch,
+                       ("affected" if kind != "tdt" else "trios"): nA, ("unaffected" if kind != "tdt" else "multi_child_families"): nU,
+                       "row_pitch_bytes": pitch,
                        "parallelism": "variant-sharded x%d%s" % (world, ", result gather to rank 0 in %d overlapped blocks" % chunks if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "k_assoc_scan", "kernel_ms": scan_ms,
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": pmc_traffic(args.workload, scan_variants, N, pitch, scan_name) if world == 1 else None,
+                         "kernel": scan_name, "kernel_ms": scan_ms, "kernel_samples": len(evs),
                          "algorithmic_bytes_per_variant": bytes_per_variant,
                          "variants_per_launch": scan_variants},
             "parity": parity,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and kind == "chisq":
             out["cpu_baseline"] = cpu_baseline(N, cond, args.cpu_seconds)
         print(json.dumps(out))
         sys.stdout.flush()

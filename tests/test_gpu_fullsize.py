@@ -1,0 +1,126 @@
+"""GPU parity at BASELINE.json's full single-GPU sizes.  The oracle cannot scan
+1e10 genotypes in seconds, so every variant is covered by size-independent
+properties (determinism, shard linearity, parity of allele totals, bounds) and
+a sample (every 1000th variant plus the first / last 256 of the cohort) is
+compared with the oracle bit for bit (counts) / within 1e-10 (statistics)."""
+import numpy as np
+import pytest
+
+from helpers import assert_close, hpgv
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _sample_idx(n):
+    return np.unique(np.concatenate([np.arange(min(256, n)), np.arange(0, n, 1000), np.arange(max(0, n - 256), n)]))
+
+
+def _rows(v0, idx, n_samples):
+    return np.stack([orc.synth_matrix(v0 + int(v), 1, n_samples, n_samples)[0] for v in idx])
+
+
+@pytest.mark.parametrize("V,N", [(1_000_000, 10_000), (1_250_000, 50_000)])
+def test_assoc_chisq_and_fisher_full_size(V, N):
+    e = hpgv.Engine(0)
+    cond = (np.arange(N) % 2).astype(np.uint8)
+    nA, nU, pitch = e.set_cohort(cond)
+    d_gt, d_counts, d_counts2 = e.alloc(V * pitch), e.alloc(V * 16), e.alloc(V * 16)
+    d_st = e.alloc(V * 24)
+    e.synth(hpgv.LAYOUT_ASSOC, 0, V, d_gt)
+    e.assoc_scan(d_gt, V, d_counts)
+    b = d_st.value
+    e.assoc_chisq(d_counts, V, b, b + 8 * V, b + 16 * V)
+    e.sync()
+    counts = e.d2h(d_counts, (V, 4), np.int32)
+    st = e.d2h(d_st, (3, V), np.float64)
+    # properties over ALL variants
+    assert ((counts[:, 0] + counts[:, 1]) % 2 == 0).all() and ((counts[:, 2] + counts[:, 3]) % 2 == 0).all()
+    assert (counts >= 0).all()
+    assert (counts[:, 0] + counts[:, 1] <= 2 * nA).all() and (counts[:, 2] + counts[:, 3] <= 2 * nU).all()
+    miss = 1 - (counts.sum(1) / (2.0 * (nA + nU))).mean()
+    assert 0.009 < miss < 0.011                                 # generator: 1 % missing
+    p = st[2]
+    assert ((p >= 0) & (p <= 1)).all() and np.isfinite(st[1]).all()
+    # determinism + shard linearity: two halves scanned separately give the same table
+    half = V // 2 + 7
+    e.assoc_scan(d_gt, half, d_counts2)
+    e.assoc_scan(d_gt.value + half * pitch, V - half, d_counts2.value + half * 16)
+    e.sync()
+    assert np.array_equal(e.d2h(d_counts2, (V, 4), np.int32), counts)
+    # sampled oracle comparison
+    idx = _sample_idx(V)
+    for lo in range(0, len(idx), 256):
+        sel = idx[lo: lo + 256]
+        A1, A2, U1, U2 = orc.assoc_counts(_rows(0, sel, N), cond)
+        assert np.array_equal(counts[sel], np.stack([A1, A2, U1, U2], 1))
+        odds, chisq, pv = orc.assoc_stats(orc.TASK_CHISQ, A1, A2, U1, U2)
+        assert_close(st[0][sel], odds, "odds"); assert_close(st[1][sel], chisq, "chisq"); assert_close(st[2][sel], pv, "p")
+    # Fisher p-pass on the same counts (BASELINE configs[2])
+    lf = orc.logfact(N * 10)
+    e.set_logfact(lf)
+    e.assoc_fisher(d_counts, V, b, b + 8 * V)
+    e.sync()
+    fp = e.d2h(d_st.value + 8 * V, (V,), np.float64)
+    assert ((fp >= 0) & (fp <= 1)).all()
+    sel = idx[:: max(1, len(idx) // 300)]
+    _, _, pv = orc.assoc_stats(orc.TASK_FISHER, counts[sel, 0], counts[sel, 1], counts[sel, 2], counts[sel, 3], lf)
+    assert_close(fp[sel], pv, "fisher p")
+    e.close()
+
+
+def test_tdt_full_size():
+    # BASELINE configs[3]: 2M SNP x 5k trios
+    V, n_tr = 2_000_000, 5000
+    e = hpgv.Engine(0)
+    k = np.arange(n_tr)
+    fam = (3 * k, 3 * k + 1, np.arange(n_tr + 1), 3 * k + 2, (k % 2).astype(np.uint8))
+    n_fast, n_slow, pitch = e.set_families(3 * n_tr, *fam)
+    d_gt, d_tu, d_tu2, d_st = e.alloc(V * pitch), e.alloc(V * 8), e.alloc(V * 8), e.alloc(V * 24)
+    e.synth(hpgv.LAYOUT_TDT, 0, V, d_gt)
+    e.tdt_scan(d_gt, V, d_tu)
+    b = d_st.value
+    e.tdt_stats(d_tu, V, b, b + 8 * V, b + 16 * V)
+    e.sync()
+    tu = e.d2h(d_tu, (V, 2), np.int32)
+    st = e.d2h(d_st, (3, V), np.float64)
+    assert (tu >= 0).all() and (tu.sum(1) <= 2 * n_tr).all() and tu.sum() > 0
+    assert ((st[2] >= 0) & (st[2] <= 1)).all()
+    half = V // 3
+    e.tdt_scan(d_gt, half, d_tu2)
+    e.tdt_scan(d_gt.value + half * pitch, V - half, d_tu2.value + half * 8)
+    e.sync()
+    assert np.array_equal(e.d2h(d_tu2, (V, 2), np.int32), tu)
+    idx = _sample_idx(V)
+    for lo in range(0, len(idx), 256):
+        sel = idx[lo: lo + 256]
+        t1, t2 = orc.tdt_counts(_rows(0, sel, 3 * n_tr), *fam)
+        assert np.array_equal(tu[sel, 0], t1) and np.array_equal(tu[sel, 1], t2)
+        odds, chisq, p = orc.tdt_stats(t1, t2)
+        assert_close(st[0][sel], odds, "odds"); assert_close(st[1][sel], chisq, "chisq"); assert_close(st[2][sel], p, "p")
+    e.close()
+
+
+def test_stats_full_size():
+    V, N = 1_000_000, 10_000
+    e = hpgv.Engine(0)
+    pitch = e.set_stats_cohort(N)
+    d_gt, d_c8, d_hw = e.alloc(V * pitch), e.alloc(V * 32), e.alloc(V * 16)
+    e.synth(hpgv.LAYOUT_STATS, 0, V, d_gt)
+    e.stats_scan(d_gt, V, d_c8)
+    e.stats_hwe(d_c8, V, d_hw, d_hw.value + 8 * V)
+    e.sync()
+    c8 = e.d2h(d_c8, (V, 8), np.int32)
+    hw = e.d2h(d_hw, (2, V), np.float64)
+    assert (c8[:, :4].sum(1) + c8[:, 4] == N).all()             # biallelic cohort: cells + missing = samples
+    assert (c8[:, 6] + c8[:, 7] + c8[:, 5] == 2 * N).all()      # allele counts + missing alleles = 2N
+    assert ((hw[1] >= 0) & (hw[1] <= 1)).all()
+    idx = _sample_idx(V)[::4]
+    rows = _rows(0, idx, N)
+    for j, v in enumerate(idx):
+        vs = orc.variant_stats(rows[j], 2)
+        assert list(c8[v, :4]) == list(vs.genotypes_count)[:4]
+        assert (c8[v, 4], c8[v, 5], c8[v, 6], c8[v, 7]) == (vs.missing_genotypes, vs.missing_alleles,
+                                                              vs.alleles_count[0], vs.alleles_count[1])
+        assert_close([hw[0][v]], [vs.hw_chi2], "hwe chi2"); assert_close([hw[1][v]], [vs.hw_p], "hwe p")
+    e.close()
