@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the scan kernel with HIP events on every n-th timed step (an event pair costs "
                          "tens of microseconds of queue bubbles, so not every step carries one)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N>1; gloo is a rehearsal mode (blocks are staged through host "
+                         "memory and several ranks may share one GPU), never a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target wall time of each CPU baseline leg")
     ap.add_argument("--option", action="append", default=[], help="engine option key=value")
@@ -128,11 +131,15 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; this engine has no CPU path", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     hpgv = importlib.import_module("hpg-variant_amd")
     from importlib import import_module
@@ -144,7 +151,7 @@ def main():
     if args.samples:
         N = args.samples
 
-    eng = hpgv.Engine(local_rank)
+    eng = hpgv.Engine(dev_index)
     for kv in args.option:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
@@ -180,10 +187,17 @@ def main():
     bounds = [sharding.variant_range(c, chunks, V) for c in range(chunks)]
     # a block's result = tallies[n] | f64 arrays[n] ...: each block lives in its own tensor, so the
     # gather of block i (overlapping the scan of block i+1) needs no repacking
-    chunk_res = [res] if world == 1 else [torch.empty(res_bytes * (hi - lo), dtype=torch.uint8, device=dev) for lo, hi in bounds]
+    # two generations of result blocks: the gathers of step k are only waited for at the end of step k+1
+    # (they overlap that step's scans), so the blocks of step k+1 must not reuse step k's buffers
+    gens = 1 if world == 1 else 2
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
+    chunk_res = [[res] if world == 1 else [torch.empty(res_bytes * (hi - lo), dtype=torch.uint8, device=dev) for lo, hi in bounds]
+                 for _ in range(gens)]
     recv = None
     if world > 1 and rank == 0:
-        recv = [[torch.empty(res_bytes * (hi - lo), dtype=torch.uint8, device=dev) for _ in range(world)] for lo, hi in bounds]
+        recv = [[[torch.empty(res_bytes * (hi - lo), dtype=torch.uint8, device=comm_dev) for _ in range(world)]
+                 for lo, hi in bounds] for _ in range(gens)]
+    pending = []                                       # works of the previous step
 
     def scan_block(lo, n, b):
         g = gt.data_ptr() + lo * pitch
@@ -200,11 +214,16 @@ def main():
         else:
             eng.tdt_stats(b, n, b + 8 * n, b + 16 * n, b + 24 * n, sp)
 
+    step_no = [0]
+
     def step(ev=None):
+        g = step_no[0] % gens
+        step_no[0] += 1
         works = []
         for c, (lo, hi) in enumerate(bounds):
             n = hi - lo
-            b = chunk_res[c].data_ptr()
+            blk = chunk_res[g][c]
+            b = blk.data_ptr()
             if ev and c == 0:
                 ev[0].record(stream)
             scan_block(lo, n, b)
@@ -212,13 +231,22 @@ def main():
                 ev[1].record(stream)
             stats_block(n, b)
             if world > 1:
-                _, w = sharding.gather_blocks(chunk_res[c], [res_bytes * n] * world, dst=0, async_op=True,
-                                              out_bufs=recv[c] if recv else None)
+                send = blk if args.backend == "nccl" else blk.cpu()      # gloo rehearsal: through host memory
+                _, w = sharding.gather_blocks(send, [res_bytes * n] * world, dst=0, async_op=True,
+                                              out_bufs=recv[g][c] if recv else None)
                 works.append(w)
-        for w in works:
+        # the previous step's gathers have had this whole step to finish
+        for w in pending:
             w.wait()
+        pending[:] = works
+
+    def drain():
+        for w in pending:
+            w.wait()
+        pending[:] = []
 
     def barrier():
+        drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -236,7 +264,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -250,9 +278,11 @@ def main():
     if rank == 0:
         from oracle import pyoracle as orc
         n0 = bounds[0][1] - bounds[0][0]
-        blk = chunk_res[0]
-        ints = blk[: head * n0].view(torch.int32).view(n0, head // 4).cpu().numpy()
-        stats = blk[head * n0:].view(torch.float64).view(-1, n0).cpu().numpy()
+        g_last = (step_no[0] - 1) % gens
+        # blocks to check: this rank's first block and, for N > 1, the first block GATHERED from the last rank
+        sources = [(chunk_res[g_last][0], v0)]
+        if world > 1:
+            sources.append((recv[g_last][0][world - 1], (world - 1) * V))
         idx = np.unique(np.concatenate([np.arange(min(256, n0)), np.arange(0, n0, 1000), np.arange(max(0, n0 - 256), n0)]))
         if kind == "fisher":
             idx = idx[:: max(1, len(idx) // 400)]
@@ -262,24 +292,27 @@ def main():
             with np.errstate(invalid="ignore"):
                 return bool(np.all((np.abs(got - exp) <= 1e-10 * np.maximum(1, np.abs(exp))) | (np.isnan(got) & np.isnan(exp))))
         ncol = N if kind != "tdt" else 3 * (N // 3)
-        for lo in range(0, len(idx), 512):
-            sel = idx[lo: lo + 512]
-            rows = np.stack([orc.synth_matrix(v0 + int(v), 1, ncol, ncol)[0] for v in sel])
-            if kind == "tdt":
-                t1, t2 = orc.tdt_counts(rows, *fam)
-                ok &= bool(np.array_equal(ints[sel], np.stack([t1, t2], 1)))
-                exp = orc.tdt_stats(t1, t2)
-                ok &= all(same(stats[j][sel], exp[j]) for j in range(3))
-            else:
-                A1, A2, U1, U2 = orc.assoc_counts(rows, cond)
-                ok &= bool(np.array_equal(ints[sel], np.stack([A1, A2, U1, U2], 1)))
-                if kind == "chisq":
-                    exp = orc.assoc_stats(orc.TASK_CHISQ, A1, A2, U1, U2)
+        for blk, vbase in sources:
+            ints = blk[: head * n0].view(torch.int32).view(n0, head // 4).cpu().numpy()
+            stats = blk[head * n0:].view(torch.float64).view(-1, n0).cpu().numpy()
+            for lo in range(0, len(idx), 512):
+                sel = idx[lo: lo + 512]
+                rows = np.stack([orc.synth_matrix(vbase + int(v), 1, ncol, ncol)[0] for v in sel])
+                if kind == "tdt":
+                    t1, t2 = orc.tdt_counts(rows, *fam)
+                    ok &= bool(np.array_equal(ints[sel], np.stack([t1, t2], 1)))
+                    exp = orc.tdt_stats(t1, t2)
                     ok &= all(same(stats[j][sel], exp[j]) for j in range(3))
                 else:
-                    odds, _, p = orc.assoc_stats(orc.TASK_FISHER, A1, A2, U1, U2, lf_table)
-                    ok &= same(stats[0][sel], odds) and same(stats[1][sel], p)
-        parity = {"checked_variants": int(len(idx)), "ok": bool(ok)}
+                    A1, A2, U1, U2 = orc.assoc_counts(rows, cond)
+                    ok &= bool(np.array_equal(ints[sel], np.stack([A1, A2, U1, U2], 1)))
+                    if kind == "chisq":
+                        exp = orc.assoc_stats(orc.TASK_CHISQ, A1, A2, U1, U2)
+                        ok &= all(same(stats[j][sel], exp[j]) for j in range(3))
+                    else:
+                        odds, _, p = orc.assoc_stats(orc.TASK_FISHER, A1, A2, U1, U2, lf_table)
+                        ok &= same(stats[0][sel], odds) and same(stats[1][sel], p)
+        parity = {"checked_variants": int(len(idx)) * len(sources), "blocks": len(sources), "ok": bool(ok)}
 
     if rank == 0:
         total_variants = V * world * args.steps
@@ -299,7 +332,7 @@ def main():
             "config": {"workload": "%s: %s" % (args.workload, desc), "variants_per_gpu": V, "samples": N,
                        ("affected" if kind != "tdt" else "trios"): nA, ("unaffected" if kind != "tdt" else "multi_child_families"): nU,
                        "row_pitch_bytes": pitch,
-                       "parallelism": "variant-sharded x%d%s" % (world, ", result gather to rank 0 in %d overlapped blocks" % chunks if world > 1 else "")},
+                       "parallelism": "variant-sharded x%d%s" % (world, ", result gather to rank 0 (%s) in %d blocks overlapped with the scans" % (args.backend, chunks) if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": pmc_traffic(args.workload, scan_variants, N, pitch, scan_name) if world == 1 else None,

@@ -48,9 +48,11 @@ struct hpgv_ctx {
     long vpw = 2;
     long nontemporal = 1;
     long profile = 0;
-    long scan_unroll = 8;
+    long scan_unroll = 4;
     long persistent = 0;       // 0: one wave per vpw consecutive rows; 1: persistent strided grid
     long blocks_per_cu = 8;
+    long pipeline = 1;         // 1: software-pipelined scan (loads of the next tile before counting this one)
+    long pipe_waves = 4;       // register budget of the pipelined scan, as waves per SIMD (4, 6 or 8)
     int n_cus = 256;
     // assoc
     Layout assoc;
@@ -253,6 +255,11 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
         if (value != 4 && value != 8 && value != 10 && value != 12 && value != 16)
             return fail(ctx, HPGV_ERR_INVALID, "scan_unroll must be one of 4, 8, 10, 12, 16");
         ctx->scan_unroll = value;
+    } else if (!strcmp(key, "pipeline")) {
+        ctx->pipeline = value ? 1 : 0;
+    } else if (!strcmp(key, "pipe_waves")) {
+        if (value != 4 && value != 6 && value != 8) return fail(ctx, HPGV_ERR_INVALID, "pipe_waves must be 4, 6 or 8");
+        ctx->pipe_waves = value;
     } else if (!strcmp(key, "persistent")) {
         ctx->persistent = value ? 1 : 0;
     } else if (!strcmp(key, "blocks_per_cu")) {
@@ -533,6 +540,23 @@ int hpgv_assoc_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, cons
         case 16: HPGV_LAUNCH_ASSOC(NT, 16, S); break;                                            \
         default: HPGV_LAUNCH_ASSOC(NT, 8, S); break;                                             \
     }
+#define HPGV_LAUNCH_PIPE(NT, U, W)                                                                \
+    hipLaunchKernelGGL((hpgv::k_assoc_scan_pipe<NT, U, W>), dim3(blocks), dim3(256), 0, st, gt, pitch, \
+                       n_variants, cA, ch, d_is_x, out, vpw)
+#define HPGV_PIPE_W(NT, U)                                                                       \
+    do {                                                                                         \
+        if (ctx->pipe_waves == 8) { HPGV_LAUNCH_PIPE(NT, U, 8); }                                \
+        else if (ctx->pipe_waves == 6) { HPGV_LAUNCH_PIPE(NT, U, 6); }                           \
+        else { HPGV_LAUNCH_PIPE(NT, U, 4); }                                                     \
+    } while (0)
+    if (ctx->pipeline && !ctx->persistent)
+        return launch_profiled(ctx, st, 0, [&] {
+            if (ctx->nontemporal) {
+                if (ctx->scan_unroll <= 4) HPGV_PIPE_W(true, 4); else HPGV_PIPE_W(true, 5);
+            } else {
+                if (ctx->scan_unroll <= 4) HPGV_PIPE_W(false, 4); else HPGV_PIPE_W(false, 5);
+            }
+        });
     return launch_profiled(ctx, st, 0, [&] {
         if (ctx->nontemporal) {
             if (ctx->persistent) { HPGV_DISPATCH_U(true, true) } else { HPGV_DISPATCH_U(true, false) }
@@ -541,6 +565,8 @@ int hpgv_assoc_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, cons
         }
     });
 #undef HPGV_DISPATCH_U
+#undef HPGV_LAUNCH_PIPE
+#undef HPGV_PIPE_W
 #undef HPGV_LAUNCH_ASSOC
 }
 

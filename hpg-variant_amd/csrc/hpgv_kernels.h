@@ -36,6 +36,14 @@ __device__ __forceinline__ int wave_sum(int v) {
            __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
+// 16-byte load from a wave-uniform base + 32-bit byte offset: this form lets the compiler keep
+// the base in SGPRs (global_load ... saddr) instead of a 64-bit VGPR address per load
+template <bool NT>
+__device__ __forceinline__ uint4 load16(const uint4 *p);
+template <bool NT>
+__device__ __forceinline__ uint4 load16o(const uint8_t *__restrict__ base, uint32_t byte_off) {
+    return load16<NT>(reinterpret_cast<const uint4 *>(base + byte_off));
+}
 template <bool NT>
 __device__ __forceinline__ uint4 load16(const uint4 *p) {
     if constexpr (NT) {
@@ -66,7 +74,7 @@ __device__ __forceinline__ uint4 load16(const uint4 *p) {
 // ---------------------------------------------------------------------------
 // one row, all lanes of the wave; X selects the chromosome-"X" extra count
 template <bool NT, int U, bool X>
-__device__ __forceinline__ void assoc_row(const uint4 *__restrict__ row, int lane, int chunksA,
+__device__ __forceinline__ void assoc_row(const uint8_t *__restrict__ row, int lane, int chunksA,
                                           int chunks, uint32_t &pnz, uint32_t &pnnf, uint32_t &pbnz) {
     for (int base = 0; base < chunks; base += 64 * U) {
         uint4 q[U];
@@ -74,7 +82,7 @@ __device__ __forceinline__ void assoc_row(const uint4 *__restrict__ row, int lan
         for (int u = 0; u < U; ++u) {
             const int c = base + u * 64 + lane;
             q[u] = make_uint4(~0u, ~0u, ~0u, ~0u);     // virtual chunk = all missing
-            if (c < chunks) q[u] = load16<NT>(row + c);
+            if (c < chunks) q[u] = load16o<NT>(row, (uint32_t)c * 16u);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -140,12 +148,97 @@ __global__ __launch_bounds__(256) void k_assoc_scan(const uint8_t *__restrict__ 
     else { v = wave * vpw; v_end = v + vpw < n_variants ? v + vpw : n_variants; v_step = 1; }
 
     for (; v < v_end; v += v_step) {                       // wave-uniform
-        const uint4 *row = reinterpret_cast<const uint4 *>(gt + (size_t)v * pitch);
+        const uint8_t *row = gt + (size_t)v * pitch;
         const bool x_row = (is_x != nullptr) && (__builtin_amdgcn_readfirstlane((int)is_x[v]) != 0);
         uint32_t pnz = 0, pnnf = 0, pbnz = 0;
         if (x_row) assoc_row<NT, U, true>(row, lane, chunksA, chunks, pnz, pnnf, pbnz);
         else       assoc_row<NT, U, false>(row, lane, chunksA, chunks, pnz, pnnf, pbnz);
         assoc_row_finish(x_row, lane, TA, TU, pnz, pnnf, pbnz, counts + v);
+    }
+}
+
+// Software-pipelined variant: the wave's rows are cut into tiles of 64*U chunks and
+// the loads of tile t+1 (which may belong to the NEXT row) are issued before tile t
+// is counted and, at a row end, reduced and stored.  Two register sets.
+struct AssocAcc { uint32_t pnz, pnnf, pbnz; };
+
+template <int U, bool X>
+__device__ __forceinline__ AssocAcc assoc_count_tile(const uint4 (&q)[U], int base, int lane, int chunksA,
+                                                     AssocAcc a) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = base + u * 64 + lane;
+        const uint32_t sh = (c < chunksA) ? 0u : 16u;
+        const uint32_t w[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+        uint32_t nz = 0, nnf = 0, bnz = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t ind = nib_nonzero(w[k]);
+            nz += __builtin_popcount(ind);
+            nnf += __builtin_popcount(nib_not_f(w[k]));
+            if constexpr (X) bnz += __builtin_popcount(ind & (ind >> 4) & 0x08080808u);
+        }
+        a.pnz += nz << sh;
+        a.pnnf += nnf << sh;
+        if constexpr (X) a.pbnz += bnz << sh;
+    }
+    return a;
+}
+
+template <bool NT, int U>
+__device__ __forceinline__ void assoc_issue_tile(uint4 (&q)[U], const uint8_t *__restrict__ g0, size_t pitch,
+                                                 int t, int ipr, int chunks, int lane) {
+    const int r = t / ipr, base = (t - r * ipr) * 64 * U;
+    const uint8_t *row = g0 + (size_t)r * pitch;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = base + u * 64 + lane;
+        q[u] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if (c < chunks) q[u] = load16o<NT>(row, (uint32_t)c * 16u);
+    }
+}
+
+template <int U>
+__device__ __forceinline__ AssocAcc assoc_consume_tile(const uint4 (&q)[U], AssocAcc a, int t, int ipr, long v_begin,
+                                                       int lane, int chunksA, int TA, int TU,
+                                                       const uint8_t *__restrict__ is_x, int4 *__restrict__ counts) {
+    const int r = t / ipr, it = t - r * ipr;
+    const long v = v_begin + r;
+    const bool x_row = (is_x != nullptr) && (__builtin_amdgcn_readfirstlane((int)is_x[v]) != 0);
+    if (x_row) a = assoc_count_tile<U, true>(q, it * 64 * U, lane, chunksA, a);
+    else       a = assoc_count_tile<U, false>(q, it * 64 * U, lane, chunksA, a);
+    if (it == ipr - 1) {
+        assoc_row_finish(x_row, lane, TA, TU, a.pnz, a.pnnf, a.pbnz, counts + v);
+        a.pnz = a.pnnf = a.pbnz = 0;
+    }
+    return a;
+}
+
+template <bool NT, int U, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_assoc_scan_pipe(const uint8_t *__restrict__ gt, size_t pitch,
+                                                         int n_variants, int chunksA, int chunks,
+                                                         const uint8_t *__restrict__ is_x,
+                                                         int4 *__restrict__ counts, int vpw) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long v_begin = wave * vpw;
+    if (v_begin >= n_variants) return;
+    const int rows = (int)((v_begin + vpw <= n_variants) ? vpw : (n_variants - v_begin));
+    const int ipr = (chunks + 64 * U - 1) / (64 * U);       // tiles per row
+    const int slots = ipr * 64 * U;
+    const int TA = 32 * chunksA, TU = 32 * (slots - chunksA);
+    const int n_tiles = rows * ipr;
+    const uint8_t *g0 = gt + (size_t)v_begin * pitch;
+    AssocAcc acc = {0u, 0u, 0u};
+    uint4 qa[U], qb[U];
+    assoc_issue_tile<NT, U>(qa, g0, pitch, 0, ipr, chunks, lane);
+    for (int t = 0; t < n_tiles; t += 2) {
+        if (t + 1 < n_tiles) assoc_issue_tile<NT, U>(qb, g0, pitch, t + 1, ipr, chunks, lane);
+        acc = assoc_consume_tile<U>(qa, acc, t, ipr, v_begin, lane, chunksA, TA, TU, is_x, counts);
+        if (t + 1 < n_tiles) {
+            if (t + 2 < n_tiles) assoc_issue_tile<NT, U>(qa, g0, pitch, t + 2, ipr, chunks, lane);
+            acc = assoc_consume_tile<U>(qb, acc, t + 1, ipr, v_begin, lane, chunksA, TA, TU, is_x, counts);
+        }
     }
 }
 
@@ -192,10 +285,74 @@ __global__ __launch_bounds__(256) void k_assoc_chisq(const int4 *__restrict__ co
 
 // ---------------------------------------------------------------------------
 // Fisher's exact test, two-sided (assoc_fisher_test.c:24-26; definition in
-// oracle/hpgv_oracle.c orc_fisher_two_sided).  One wave per variant; lanes
-// stride over the admissible tables; the log-factorial table (<= a few MB)
-// is L2 / Infinity-Cache resident.
+// oracle/hpgv_oracle.c orc_fisher_two_sided: sum of P(x) over all admissible
+// tables x with P(x) <= P_obs * (1 + 1e-7), P through the log-factorial table).
+// One wave per variant.  The hypergeometric pmf is unimodal, so the summed set is
+// a left tail [lo, xL] and a right tail [xR, hi].  Short ranges are scanned whole;
+// for long ranges the wave finds xL and xR by a 64-ary search (64 probes per
+// round) and sums each tail outwards, 64 terms per round, until a whole round
+// is below 1e-22 of the sum so far (the terms dropped are further out and decay
+// faster than geometrically, i.e. far below one ulp of the result).
+// The table (a few MB at most) stays L2 / Infinity-Cache resident.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);   // fixed order: deterministic
+    return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off); v = o > v ? o : v; }
+    return v;
+}
+
+struct FisherTab {
+    const double *lf; double konst; int r1, c1, d0;    // d0 = r2 - c1
+    __device__ __forceinline__ double p(int x) const {
+        return exp(konst - lf[x] - lf[r1 - x] - lf[c1 - x] - lf[d0 + x]);
+    }
+};
+
+// first x in [L, R) where pred(x) is false, for a predicate that is true on a prefix
+// of [L, R); returns R if it is true everywhere.  UP: pred(x) = p(x) <= thr (left of the mode,
+// p increasing); !UP: pred(x) = p(x) > thr (right of the mode, p decreasing).
+template <bool UP>
+__device__ __forceinline__ int fisher_boundary(const FisherTab &T, double thr, int L, int R, int lane) {
+    while (R - L > 64) {
+        const int step = (R - L + 63) / 64;
+        const int x = L + lane * step;
+        bool pr = false;
+        if (x < R) { const double v = T.p(x); pr = UP ? (v <= thr) : (v > thr); }
+        const int j = __builtin_popcountll(__ballot(pr));       // leading true probes (prefix-true)
+        const int newL = (j == 0) ? L : L + (j - 1) * step + 1;
+        const int xj = L + j * step;
+        const int newR = (j == 64 || xj >= R) ? R : xj;
+        L = newL; R = newR;
+    }
+    const int x = L + lane;
+    bool pr = false;
+    if (x < R) { const double v = T.p(x); pr = UP ? (v <= thr) : (v > thr); }
+    return L + __builtin_popcountll(__ballot(pr));
+}
+
+// sum of p(x) for x = start, start+dir, ... while inside [lo, hi].  Lanes keep private partial
+// sums (one wave reduction at the end); the walk stops after a round in which no term exceeds
+// 1e-22 of (base + the first round's total), a lower bound of the final sum.
+__device__ __forceinline__ double fisher_tail(const FisherTab &T, int start, int dir, int lo, int hi,
+                                              double base, int lane) {
+    double part = 0.0, cut = 0.0;
+    for (int k = 0;; ++k) {
+        const int first = start + dir * 64 * k;
+        if (first < lo || first > hi) break;                    // wave-uniform
+        const int x = first + dir * lane;
+        const double v = (x >= lo && x <= hi) ? T.p(x) : 0.0;
+        part += v;
+        if (k == 0) cut = 1e-22 * (base + wave_sum_f64(v));
+        if (__ballot(v > cut) == 0ull) break;                   // wave-uniform
+    }
+    return wave_sum_f64(part);
+}
+
 __global__ __launch_bounds__(256) void k_assoc_fisher(const int4 *__restrict__ counts, int n,
                                                       const double *__restrict__ lf,
                                                       double *__restrict__ odds,
@@ -208,17 +365,32 @@ __global__ __launch_bounds__(256) void k_assoc_fisher(const int4 *__restrict__ c
     const int r1 = a + b, r2 = c + d, c1 = a + c, nn = r1 + r2;
     const int lo = (c1 - r2) > 0 ? (c1 - r2) : 0;
     const int hi = r1 < c1 ? r1 : c1;
-    const double konst = lf[r1] + lf[r2] + lf[c1] + lf[nn - c1] - lf[nn];
-    const double p_obs = exp(konst - lf[a] - lf[r1 - a] - lf[c1 - a] - lf[r2 - c1 + a]);
+    FisherTab T;
+    T.lf = lf; T.r1 = r1; T.c1 = c1; T.d0 = r2 - c1;
+    T.konst = lf[r1] + lf[r2] + lf[c1] + lf[nn - c1] - lf[nn];
+    const double p_obs = T.p(a);
     const double thr = p_obs * (1.0 + 1e-7);
-    double sum = 0.0;
-    for (int x = lo + lane; x <= hi; x += 64) {
-        const double p = exp(konst - lf[x] - lf[r1 - x] - lf[c1 - x] - lf[r2 - c1 + x]);
-        if (p <= thr) sum += p;
+    double sum;
+    if (hi - lo < 512) {
+        double part = 0.0;
+        for (int x = lo + lane; x <= hi; x += 64) {
+            const double p = T.p(x);
+            if (p <= thr) part += p;
+        }
+        sum = wave_sum_f64(part);
+    } else {
+        // mode of the hypergeometric distribution, clamped to the support
+        long md = ((long)(r1 + 1) * (long)(c1 + 1)) / ((long)nn + 2);
+        int mode = (int)md;
+        mode = mode < lo ? lo : (mode > hi ? hi : mode);
+        // left of (and including) the mode p grows with x: included x are a prefix [lo, xL)
+        const int xL = fisher_boundary<true>(T, thr, lo, mode + 1, lane);
+        // right of the mode p falls: p > thr on a prefix [mode+1, xR), included x are [xR, hi]
+        const int xR = fisher_boundary<false>(T, thr, mode + 1, hi + 1, lane);
+        const double left = fisher_tail(T, xL - 1, -1, lo, hi, 0.0, lane);
+        const double right = fisher_tail(T, xR, +1, lo, hi, left, lane);
+        sum = left + right;
     }
-    // wave reduction in a fixed order (deterministic run to run)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
     if (lane == 0) {
         odds[v] = assoc_odds(a, b, c, d);
         pval[v] = sum > 1.0 ? 1.0 : sum;

@@ -38,11 +38,15 @@ __host__ __device__ __forceinline__ bool tdt_parents_usable(int f1, int f2, int 
     return true;
 }
 
+// family-scope state of tdt.c:51-52,128-132 (values, not references: keeps it in registers)
+struct TdtState { int trA, trB, t1, t2; };
+
 // one child against usable parents; updates the family-scope trA / trB and the tallies
-__host__ __device__ __forceinline__ void tdt_child(int f1, int f2, int m1, int m2, int c1, int c2, bool x_male,
-                                                   int &trA, int &trB, int &t1, int &t2) {
-    if (c1 == 0xF || c2 == 0xF) return;                                    // tdt.c:154
-    if (mendel_code(x_male, f1, f2, m1, m2, c1, c2)) return;               // tdt.c:161-166
+__host__ __device__ __forceinline__ TdtState tdt_child(int f1, int f2, int m1, int m2, int c1, int c2, bool x_male,
+                                                       TdtState st) {
+    int trA = st.trA, trB = st.trB, t1 = st.t1, t2 = st.t2;
+    if (c1 == 0xF || c2 == 0xF) return st;                                 // tdt.c:154
+    if (mendel_code(x_male, f1, f2, m1, m2, c1, c2)) return st;            // tdt.c:161-166
     const bool fh = !f1 && f2, mh = !m1 && m2;
     if (!c1 && !c2) {                                                      // tdt.c:175-181
         if (fh && mh) { trA = 1; trB = 1; } else { trA = 1; }
@@ -58,19 +62,21 @@ __host__ __device__ __forceinline__ void tdt_child(int f1, int f2, int m1, int m
     }
     if (trA == 1) t1++; else if (trA == 2) t2++;                           // tdt.c:235-239
     if (trB == 1) t1++; else if (trB == 2) t2++;
+    return TdtState{trA, trB, t1, t2};
 }
 
-__device__ __forceinline__ void tdt_family_slow(const uint8_t *__restrict__ grp, int n_children,
-                                                const uint8_t *__restrict__ male, bool x_row,
-                                                int &t1, int &t2) {
+// returns the family's (t1, t2) contribution
+__device__ __forceinline__ int2 tdt_family_slow(const uint8_t *__restrict__ grp, int n_children,
+                                                const uint8_t *__restrict__ male, bool x_row) {
     const uint32_t fb = grp[0], mb = grp[1];
     const int f1 = fb >> 4, f2 = fb & 0xF, m1 = mb >> 4, m2 = mb & 0xF;
-    if (!tdt_parents_usable(f1, f2, m1, m2)) return;
-    int trA = 0, trB = 0;                                                  // tdt.c:128-132
+    if (!tdt_parents_usable(f1, f2, m1, m2)) return make_int2(0, 0);
+    TdtState st = {0, 0, 0, 0};                                            // tdt.c:128-132
     for (int k = 0; k < n_children; ++k) {
         const uint32_t cb = grp[2 + k];
-        tdt_child(f1, f2, m1, m2, (int)(cb >> 4), (int)(cb & 0xF), x_row && male[2 + k], trA, trB, t1, t2);
+        st = tdt_child(f1, f2, m1, m2, (int)(cb >> 4), (int)(cb & 0xF), x_row && male[2 + k], st);
     }
+    return make_int2(st.t1, st.t2);
 }
 
 // ---------------------------------------------------------------------------
@@ -110,8 +116,7 @@ __device__ __forceinline__ uint32_t tdt_pair(const TdtLut &L, uint32_t idx) {
 }
 
 template <bool X>
-__device__ __forceinline__ void tdt4(const TdtLuts &L, uint32_t f, uint32_t m, uint32_t c, uint32_t male,
-                                     int &t1, int &t2) {
+__device__ __forceinline__ int2 tdt4(const TdtLuts &L, uint32_t f, uint32_t m, uint32_t c, uint32_t male) {
     const uint32_t idx = (m << 2) | f;
     const uint32_t kill = __builtin_amdgcn_perm(0u, 0u, f | m);       // 0xFF where a parent is unusable
     uint32_t w1, w2;
@@ -127,8 +132,7 @@ __device__ __forceinline__ void tdt4(const TdtLuts &L, uint32_t f, uint32_t m, u
         w1 = ((male & x1) | (~male & a1)) & ~kill;                    // male: 0xFF per male child
         w2 = ((male & x2) | (~male & a2)) & ~kill;
     }
-    t1 += __builtin_popcount(w1);
-    t2 += __builtin_popcount(w2);
+    return make_int2(__builtin_popcount(w1), __builtin_popcount(w2));
 }
 
 // Row layout: [F plane P16 | M plane P16 | C plane P16 | slow groups (HPGV8) | pad].
@@ -146,8 +150,7 @@ __global__ __launch_bounds__(256) void k_tdt_scan(const uint8_t *__restrict__ gt
         const long v = v_begin + i;
         if (v >= n_variants) break;
         const uint8_t *rowb = gt + (size_t)v * pitch;
-        const uint4 *rowF = reinterpret_cast<const uint4 *>(rowb);
-        const uint4 *rowM = rowF + pchunks, *rowC = rowF + 2 * pchunks;
+        const uint32_t plane = (uint32_t)pchunks * 16u;
         const bool x_row = (is_x != nullptr) && (__builtin_amdgcn_readfirstlane((int)is_x[v]) != 0);
         int t1 = 0, t2 = 0;
         for (int base = 0; base < pchunks; base += 64 * U) {
@@ -160,18 +163,18 @@ __global__ __launch_bounds__(256) void k_tdt_scan(const uint8_t *__restrict__ gt
                 qm[u] = make_uint4(0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u);
                 qc[u] = make_uint4(0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u);
                 if (c < pchunks) {
-                    qf[u] = load16<NT>(rowF + c);
-                    qm[u] = load16<NT>(rowM + c);
-                    qc[u] = load16<NT>(rowC + c);
+                    qf[u] = load16o<NT>(rowb, (uint32_t)c * 16u);
+                    qm[u] = load16o<NT>(rowb, (uint32_t)c * 16u + plane);
+                    qc[u] = load16o<NT>(rowb, (uint32_t)c * 16u + 2u * plane);
                 }
             }
             if (!x_row) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    tdt4<false>(luts, qf[u].x, qm[u].x, qc[u].x, 0, t1, t2);
-                    tdt4<false>(luts, qf[u].y, qm[u].y, qc[u].y, 0, t1, t2);
-                    tdt4<false>(luts, qf[u].z, qm[u].z, qc[u].z, 0, t1, t2);
-                    tdt4<false>(luts, qf[u].w, qm[u].w, qc[u].w, 0, t1, t2);
+                    { const int2 d = tdt4<false>(luts, qf[u].x, qm[u].x, qc[u].x, 0); t1 += d.x; t2 += d.y; }
+                    { const int2 d = tdt4<false>(luts, qf[u].y, qm[u].y, qc[u].y, 0); t1 += d.x; t2 += d.y; }
+                    { const int2 d = tdt4<false>(luts, qf[u].z, qm[u].z, qc[u].z, 0); t1 += d.x; t2 += d.y; }
+                    { const int2 d = tdt4<false>(luts, qf[u].w, qm[u].w, qc[u].w, 0); t1 += d.x; t2 += d.y; }
                 }
             } else {
 #pragma unroll
@@ -179,16 +182,17 @@ __global__ __launch_bounds__(256) void k_tdt_scan(const uint8_t *__restrict__ gt
                     const int c = base + u * 64 + lane;
                     uint4 ml = make_uint4(0, 0, 0, 0);
                     if (c < pchunks) ml = reinterpret_cast<const uint4 *>(male_plane)[c];
-                    tdt4<true>(luts, qf[u].x, qm[u].x, qc[u].x, ml.x, t1, t2);
-                    tdt4<true>(luts, qf[u].y, qm[u].y, qc[u].y, ml.y, t1, t2);
-                    tdt4<true>(luts, qf[u].z, qm[u].z, qc[u].z, ml.z, t1, t2);
-                    tdt4<true>(luts, qf[u].w, qm[u].w, qc[u].w, ml.w, t1, t2);
+                    { const int2 d = tdt4<true>(luts, qf[u].x, qm[u].x, qc[u].x, ml.x); t1 += d.x; t2 += d.y; }
+                    { const int2 d = tdt4<true>(luts, qf[u].y, qm[u].y, qc[u].y, ml.y); t1 += d.x; t2 += d.y; }
+                    { const int2 d = tdt4<true>(luts, qf[u].z, qm[u].z, qc[u].z, ml.z); t1 += d.x; t2 += d.y; }
+                    { const int2 d = tdt4<true>(luts, qf[u].w, qm[u].w, qc[u].w, ml.w); t1 += d.x; t2 += d.y; }
                 }
             }
         }
         for (int k = lane; k < n_slow; k += 64) {
             const int off = slow_off[k], n_children = slow_off[k + 1] - off - 2;
-            tdt_family_slow(rowb + slow_base + off, n_children, slow_male + off, x_row, t1, t2);
+            const int2 d = tdt_family_slow(rowb + slow_base + off, n_children, slow_male + off, x_row);
+            t1 += d.x; t2 += d.y;
         }
         const int s1 = wave_sum(t1), s2 = wave_sum(t2);
         if (lane == 0) tu[v] = make_int2(s1, s2);
@@ -276,10 +280,10 @@ inline bool build_luts(TdtLuts &out) {
         for (int f = 0; f < 4; ++f)
             for (int m = 0; m < 4; ++m)
                 for (int c = 0; c < 4; ++c) {
-                    int t1 = 0, t2 = 0, trA = 0, trB = 0;
+                    TdtState st = {0, 0, 0, 0};
                     if (tdt_parents_usable(P[f][0], P[f][1], P[m][0], P[m][1]))
-                        tdt_child(P[f][0], P[f][1], P[m][0], P[m][1], C[c][0], C[c][1], x == 1, trA, trB, t1, t2);
-                    w1[x][f][m][c] = t1; w2[x][f][m][c] = t2;
+                        st = tdt_child(P[f][0], P[f][1], P[m][0], P[m][1], C[c][0], C[c][1], x == 1, st);
+                    w1[x][f][m][c] = st.t1; w2[x][f][m][c] = st.t2;
                 }
     uint8_t pair[16], c1[8], c2[8];
     if (!encode(w1[0], w2[0], true, true, pair, c1, c2)) return false;
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(256) void k_stats_scan(const uint8_t *__restrict__ 
     for (int i = 0; i < vpw; ++i) {
         const long v = v_begin + i;
         if (v >= n_variants) break;
-        const uint4 *row = reinterpret_cast<const uint4 *>(gt + (size_t)v * pitch);
+        const uint8_t *row = gt + (size_t)v * pitch;
         int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int base = 0; base < chunks; base += 64 * U) {
             uint4 q[U];
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(256) void k_stats_scan(const uint8_t *__restrict__ 
             for (int u = 0; u < U; ++u) {
                 const int c = base + u * 64 + lane;
                 q[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (c < chunks) q[u] = load16<NT>(row + c);
+                if (c < chunks) q[u] = load16o<NT>(row, (uint32_t)c * 16u);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {

@@ -187,15 +187,23 @@ def test_device_resident_assoc_on_synthetic_cohort():
 
 
 @pytest.mark.parametrize("opt", [("nontemporal", 0), ("variants_per_wave", 1), ("variants_per_wave", 7),
-                                 ("row_align", 16), ("row_align", 256)])
+                                 ("row_align", 128), ("row_align", 256), ("pipeline", 0), ("scan_unroll", 8),
+                                 ("scan_unroll", 10), ("scan_unroll", 16), ("persistent", 1), ("pipe_waves", 6)])
 def test_options_do_not_change_results(opt):
     e = fresh()
     e.set_option(*opt)
+    if opt[0] in ("scan_unroll", "persistent"):
+        e.set_option("pipeline", 0)        # these knobs belong to the non-pipelined kernel
     rng = np.random.default_rng(11)
     cond = rng.choice([0, 1, 2], size=3000).astype(np.uint8)
     e.set_cohort(cond)
     gt = random_codes(rng, 333, 3000)
-    check_assoc(e.assoc(hpgv.TASK_CHISQ, gt), oracle_assoc(orc.TASK_CHISQ, gt, cond), hpgv.TASK_CHISQ)
+    is_x = (rng.random(333) < 0.3).astype(np.uint8)
+    check_assoc(e.assoc(hpgv.TASK_CHISQ, gt, is_x), oracle_assoc(orc.TASK_CHISQ, gt, cond, is_x), hpgv.TASK_CHISQ)
+    if opt[0] == "pipeline":                 # also with the other tile shapes of the pipelined kernel
+        for u in (8, 10):
+            e.set_option("pipeline", 1); e.set_option("scan_unroll", u)
+            check_assoc(e.assoc(hpgv.TASK_CHISQ, gt, is_x), oracle_assoc(orc.TASK_CHISQ, gt, cond, is_x), hpgv.TASK_CHISQ)
     e.close()
 
 
