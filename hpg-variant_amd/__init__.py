@@ -31,7 +31,8 @@ SYMBOLS = [
     "hpgv_layout_dev", "hpgv_synth_dev", "hpgv_synth_raw_dev",
     "hpgv_assoc_scan_dev", "hpgv_assoc_chisq_dev", "hpgv_assoc_fisher_dev",
     "hpgv_tdt_scan_dev", "hpgv_tdt_stats_dev", "hpgv_stats_scan_dev", "hpgv_stats_hwe_dev",
-    "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_read_probe",
+    "hpgv_sample_missing_dev", "hpgv_genotype_table_dev",
+    "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_read_probe",
 ]
 
 
@@ -93,6 +94,9 @@ def load():
     L.hpgv_assoc.argtypes = [vp, i32, vp, sz, i32, vp] + [vp] * 7
     L.hpgv_tdt.argtypes = [vp, vp, sz, i32, vp] + [vp] * 5
     L.hpgv_stats.argtypes = [vp, vp, sz, i32, vp, vp, vp]
+    L.hpgv_stats_ex.argtypes = [vp, vp, sz, i32, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
+    L.hpgv_sample_missing_dev.argtypes = [vp, vp, i32, vp, vp]
+    L.hpgv_genotype_table_dev.argtypes = [vp, vp, sz, i32, vp, i32, vp, vp]
     L.hpgv_read_probe.argtypes = [vp, vp, sz, i32, C.POINTER(C.c_float)]
     _lib = L
     return L
@@ -228,6 +232,21 @@ class Engine:
         self._chk(self.L.hpgv_stats(self.h, _ptr(gt), pitch, nv, _ptr(c8), _ptr(chi2), _ptr(p)))
         return dict(counts8=c8, hwe_chi2=chi2, hwe_p=p)
 
+    def stats_ex(self, gt, sample_missing=None, multi_cap=0):
+        """hpgv_stats_ex: counters + HWE, per-sample missing counts accumulated into
+        `sample_missing`, and the 256-bin genotype tables of multi-allelic variants."""
+        gt = _np(gt, np.uint8)
+        nv, pitch = gt.shape
+        c8 = np.zeros((nv, 8), np.int32)
+        chi2, p = np.zeros(nv, np.float64), np.zeros(nv, np.float64)
+        midx = np.zeros(max(multi_cap, 1), np.int32)
+        mtab = np.zeros((max(multi_cap, 1), 256), np.int32)
+        nm = C.c_int(multi_cap)
+        self._chk(self.L.hpgv_stats_ex(self.h, _ptr(gt), pitch, nv, _ptr(c8), _ptr(chi2), _ptr(p),
+                                       _ptr(sample_missing), _ptr(midx), _ptr(mtab), C.byref(nm)))
+        k = min(nm.value, multi_cap)
+        return dict(counts8=c8, hwe_chi2=chi2, hwe_p=p, n_multi=nm.value, multi_idx=midx[:k], multi_table=mtab[:k])
+
     # ---- device-resident path (raw pointers; ints or c_void_p) ---------------
     def synth(self, which, v0, n_variants, d_dst, stream=None):
         self._chk(self.L.hpgv_synth_dev(self.h, which, v0, n_variants, d_dst, stream))
@@ -258,6 +277,12 @@ class Engine:
 
     def stats_hwe(self, d_counts8, n_variants, d_chi2, d_p, stream=None):
         self._chk(self.L.hpgv_stats_hwe_dev(self.h, d_counts8, n_variants, d_chi2, d_p, stream))
+
+    def sample_missing(self, d_gt, n_variants, d_missing, stream=None):
+        self._chk(self.L.hpgv_sample_missing_dev(self.h, d_gt, n_variants, d_missing, stream))
+
+    def genotype_table(self, d_raw, src_pitch, n_samples, d_idx, n_idx, d_table, stream=None):
+        self._chk(self.L.hpgv_genotype_table_dev(self.h, d_raw, src_pitch, n_samples, d_idx, n_idx, d_table, stream))
 
     def last_kernel_ms(self):
         a, b = C.c_float(), C.c_float()

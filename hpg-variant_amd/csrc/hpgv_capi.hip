@@ -670,6 +670,35 @@ int hpgv_stats_hwe_dev(hpgv_ctx *ctx, const int32_t *d_counts8, int n_variants, 
     });
 }
 
+int hpgv_sample_missing_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, int32_t *d_missing, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->stats.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");
+    if (n_variants < 0 || (n_variants > 0 && (!d_gt || !d_missing))) return fail(ctx, HPGV_ERR_INVALID, "bad sample stats arguments");
+    if (n_variants == 0 || ctx->stats.n_samples == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    const Layout &L = ctx->stats;
+    const unsigned tiles = (unsigned)((L.chunks + 63) / 64);
+    dim3 grid((tiles + 3) / 4, (unsigned)((n_variants + hpgv::SAMPLE_STATS_ROWS - 1) / hpgv::SAMPLE_STATS_ROWS));
+    if (grid.y > 65535u) return fail(ctx, HPGV_ERR_UNSUPPORTED, "more than %d variants per sample-stats call", 65535 * hpgv::SAMPLE_STATS_ROWS);
+    hipLaunchKernelGGL(hpgv::k_sample_missing, grid, dim3(256), 0, (hipStream_t)stream, d_gt, L.pitch, n_variants,
+                       L.chunks, L.n_samples, d_missing);
+    HIPCHK(ctx, hipGetLastError());
+    return HPGV_OK;
+}
+
+int hpgv_genotype_table_dev(hpgv_ctx *ctx, const uint8_t *d_raw, size_t src_pitch, int n_samples,
+                            const int32_t *d_variant_idx, int n_idx, int32_t *d_table, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (n_idx < 0 || n_samples < 0 || (n_idx > 0 && (!d_raw || !d_table)) || src_pitch < (size_t)n_samples)
+        return fail(ctx, HPGV_ERR_INVALID, "bad genotype table arguments");
+    if (n_idx == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    hipLaunchKernelGGL(hpgv::k_genotype_table, dim3((unsigned)n_idx), dim3(256), 0, (hipStream_t)stream, d_raw, src_pitch,
+                       n_samples, d_variant_idx, n_idx, d_table);
+    HIPCHK(ctx, hipGetLastError());
+    return HPGV_OK;
+}
+
 int hpgv_last_kernel_ms(hpgv_ctx *ctx, float *scan_ms, float *stats_ms) {
     if (!ctx) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);
@@ -782,13 +811,17 @@ int hpgv_tdt(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, con
     return HPGV_OK;
 }
 
-int hpgv_stats(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, int32_t *counts8,
-               double *hwe_chi2, double *hwe_p) {
+int hpgv_stats_ex(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, int32_t *counts8,
+                  double *hwe_chi2, double *hwe_p, int32_t *sample_missing, int32_t *multi_idx,
+                  int32_t *multi_table, int *n_multi) {
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->stats.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");
     if (n_variants < 0 || (n_variants > 0 && (!gt || !counts8 || !hwe_chi2 || !hwe_p)))
         return fail(ctx, HPGV_ERR_INVALID, "bad stats arguments");
+    if (n_multi && *n_multi > 0 && (!multi_idx || !multi_table)) return fail(ctx, HPGV_ERR_INVALID, "multi-allelic outputs are NULL");
     if (pitch < (size_t)ctx->stats.n_samples) return fail(ctx, HPGV_ERR_INVALID, "pitch %zu < n_samples %d", pitch, ctx->stats.n_samples);
+    const int cap = n_multi ? *n_multi : 0;
+    if (n_multi) *n_multi = 0;
     if (n_variants == 0) return HPGV_OK;
     DeviceGuard g(ctx->device);
     SlotLease lease(ctx);
@@ -798,17 +831,54 @@ int hpgv_stats(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, i
     const uint8_t *d_isx = nullptr;
     if ((rc = stage_batch(ctx, s, HPGV_LAYOUT_STATS, ctx->stats, gt, pitch, n_variants, nullptr, &d_isx))) return rc;
     const size_t n = (size_t)n_variants;
+    const int ns = ctx->stats.n_samples;
     if ((rc = ensure(ctx, s, 3, n * 32))) return rc;
     if ((rc = ensure(ctx, s, 4, n * 2 * sizeof(double)))) return rc;
     int32_t *d_c8 = (int32_t *)s->buf[3];
     double *d_chi2 = (double *)s->buf[4], *d_p = d_chi2 + n;
     if ((rc = hpgv_stats_scan_dev(ctx, (const uint8_t *)s->buf[1], n_variants, d_c8, s->stream))) return rc;
     if ((rc = hpgv_stats_hwe_dev(ctx, d_c8, n_variants, d_chi2, d_p, s->stream))) return rc;
+    if (sample_missing && ns > 0) {
+        if ((rc = ensure(ctx, s, 5, (size_t)ns * sizeof(int32_t)))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(s->buf[5], 0, (size_t)ns * sizeof(int32_t), s->stream));
+        if ((rc = hpgv_sample_missing_dev(ctx, (const uint8_t *)s->buf[1], n_variants, (int32_t *)s->buf[5], s->stream))) return rc;
+    }
     HIPCHK(ctx, hipMemcpyAsync(counts8, d_c8, n * 32, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(ctx, hipMemcpyAsync(hwe_chi2, d_chi2, n * 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(ctx, hipMemcpyAsync(hwe_p, d_p, n * 8, hipMemcpyDeviceToHost, s->stream));
+    std::vector<int32_t> sm;
+    if (sample_missing && ns > 0) {
+        sm.resize((size_t)ns);
+        HIPCHK(ctx, hipMemcpyAsync(sm.data(), s->buf[5], (size_t)ns * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    }
     HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    for (size_t j = 0; j < sm.size(); ++j) sample_missing[j] += sm[j];
+    if (n_multi) {
+        // variants whose biallelic cells do not cover every called genotype get their full table
+        std::vector<int32_t> idx;
+        for (size_t i = 0; i < n; ++i) {
+            const int32_t *c = counts8 + 8 * i;
+            if (ns - c[4] - (c[0] + c[1] + c[2] + c[3]) > 0) idx.push_back((int32_t)i);
+        }
+        *n_multi = (int)idx.size();
+        const int m = (int)idx.size() < cap ? (int)idx.size() : cap;
+        if (m > 0) {
+            if ((rc = ensure(ctx, s, 6, (size_t)m * sizeof(int32_t)))) return rc;
+            if ((rc = ensure(ctx, s, 7, (size_t)m * 256 * sizeof(int32_t)))) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(s->buf[6], idx.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+            if ((rc = hpgv_genotype_table_dev(ctx, (const uint8_t *)s->buf[0], pitch, ns, (const int32_t *)s->buf[6], m,
+                                              (int32_t *)s->buf[7], s->stream))) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(multi_table, s->buf[7], (size_t)m * 256 * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(ctx, hipStreamSynchronize(s->stream));
+            memcpy(multi_idx, idx.data(), (size_t)m * sizeof(int32_t));
+        }
+    }
     return HPGV_OK;
+}
+
+int hpgv_stats(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, int32_t *counts8,
+               double *hwe_chi2, double *hwe_p) {
+    return hpgv_stats_ex(ctx, gt, pitch, n_variants, counts8, hwe_chi2, hwe_p, nullptr, nullptr, nullptr, nullptr);
 }
 
 int hpgv_read_probe(hpgv_ctx *ctx, const uint8_t *d_buf, size_t bytes, int iters, float *ms) {

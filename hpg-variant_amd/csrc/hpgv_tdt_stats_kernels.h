@@ -438,6 +438,63 @@ __global__ __launch_bounds__(256) void k_stats_scan(const uint8_t *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------
+// per-sample missing-genotype counts (hpg-libs get_sample_stats, call site
+// stats_runner.c:197-198) over the same flag rows: a column-wise sum.  Wave =
+// one tile of 1024 samples (64 lanes x 16 B) x SB variants; bytes accumulate in
+// SWAR lanes (SB <= 255 so no byte overflows), then 16 atomics per lane.
+// ---------------------------------------------------------------------------
+constexpr int SAMPLE_STATS_ROWS = 128;
+__global__ __launch_bounds__(256) void k_sample_missing(const uint8_t *__restrict__ gt, size_t pitch, int n_variants,
+                                                        int chunks, int n_samples, int32_t *__restrict__ missing) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);     // column tile
+    const int c = tile * 64 + lane;                                            // 16-byte chunk in the row
+    const long v0 = (long)blockIdx.y * SAMPLE_STATS_ROWS;
+    if (tile * 64 >= chunks) return;
+    uint32_t acc[4] = {0, 0, 0, 0};
+    const int rows = (int)((v0 + SAMPLE_STATS_ROWS <= n_variants) ? SAMPLE_STATS_ROWS : (n_variants - v0));
+    if (c < chunks) {
+#pragma unroll 4
+        for (int r = 0; r < rows; ++r) {
+            const uint4 q = load16o<true>(gt + (size_t)(v0 + r) * pitch, (uint32_t)c * 16u);
+            acc[0] += (q.x >> 4) & 0x01010101u;      // flag bit 4: some allele missing
+            acc[1] += (q.y >> 4) & 0x01010101u;
+            acc[2] += (q.z >> 4) & 0x01010101u;
+            acc[3] += (q.w >> 4) & 0x01010101u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = c * 16 + k * 4 + j;
+                const int n = (int)((acc[k] >> (8 * j)) & 0xFFu);
+                if (n && col < n_samples) atomicAdd(missing + col, n);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// full genotype table of one variant from a RAW HPGV8 row (any alleles 0..14):
+// 256-bin histogram of the code byte, one workgroup per listed variant, LDS
+// atomics.  Meant for the few multi-allelic variants the flag scan reports
+// (cells 0/0..1/1 do not add up), not for the bulk.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_genotype_table(const uint8_t *__restrict__ raw, size_t src_pitch,
+                                                        int n_samples, const int32_t *__restrict__ variant_idx,
+                                                        int n_idx, int32_t *__restrict__ table) {
+    __shared__ int hist[256];
+    const int i = blockIdx.x;
+    if (i >= n_idx) return;
+    const long v = variant_idx ? (long)variant_idx[i] : (long)i;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint8_t *row = raw + (size_t)v * src_pitch;
+    for (int j = threadIdx.x; j < n_samples; j += blockDim.x) atomicAdd(&hist[row[j]], 1);
+    __syncthreads();
+    table[(size_t)i * 256 + threadIdx.x] = hist[threadIdx.x];
+}
+
 // Hardy-Weinberg chi-square on (n_AA, n_Aa, n_aa) = (n_00, n_01 + n_10, n_11);
 // definition: oracle/hpgv_oracle.c orc_hwe (hpg-libs body absent: unpinned)
 __global__ __launch_bounds__(256) void k_stats_hwe(const int4 *__restrict__ in8, int n, double *__restrict__ chi2,

@@ -219,8 +219,16 @@ void tdt_result_free(tdt_result_t *r) {
 }
 void variant_stats_free(variant_stats_t *s) {
     if (!s) return;
-    free(s->chromosome); free(s->ref_allele); free(s->alt_alleles); free(s);
+    free(s->chromosome); free(s->ref_allele); free(s->alt_alleles);
+    free(s->alleles_count); free(s->genotypes_count); free(s->alleles_freq); free(s->genotypes_freq);
+    free(s);
 }
+sample_stats_t *sample_stats_new(char *name) {
+    sample_stats_t *s = (sample_stats_t *)calloc(1, sizeof *s);
+    if (s) s->name = name;
+    return s;
+}
+void sample_stats_free(sample_stats_t *s) { free(s); }
 file_stats_t *file_stats_new(void) {
     file_stats_t *f = (file_stats_t *)calloc(1, sizeof *f);
     if (f) pthread_mutex_init(&f->lock, NULL);
@@ -625,6 +633,30 @@ int tdt_test(vcf_record_t **variants, int num_variants, family_t **families, int
 /* get_variants_stats                                                         */
 /* ------------------------------------------------------------------------ */
 
+static int stats_prepare(int num_samples) {
+    int rc = HPGV_OK;
+    if (!(g_stats_key.set && g_stats_key.num_samples == num_samples)) {
+        pthread_rwlock_unlock(&g_cohort_lock);
+        pthread_rwlock_wrlock(&g_cohort_lock);
+        if (!(g_stats_key.set && g_stats_key.num_samples == num_samples)) {
+            rc = hpgv_set_stats_cohort(g_ctx, num_samples);
+            if (rc == HPGV_OK) { g_stats_key.set = 1; g_stats_key.num_samples = num_samples; }
+            else host_fail("hpgv_set_stats_cohort", rc);
+        }
+        pthread_rwlock_unlock(&g_cohort_lock);
+        pthread_rwlock_rdlock(&g_cohort_lock);
+    }
+    return rc;
+}
+
+/* 1 + number of comma-separated ALT alleles ("." = none) */
+static int count_alleles(const char *alt, int len) {
+    if (len <= 0 || (len == 1 && alt[0] == '.')) return 1;
+    int n = 2;
+    for (int i = 0; i < len; i++) if (alt[i] == ',') n++;
+    return n;
+}
+
 int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t **individuals,
                        sample_ids_t *sample_ids, int num_variables, list_t *output_list,
                        file_stats_t *file_stats) {
@@ -638,29 +670,26 @@ int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t *
     uint8_t *gt = (uint8_t *)malloc(n * pitch);
     int32_t *c8 = (int32_t *)malloc(n * 8 * sizeof(int32_t));
     double *hw = (double *)malloc(n * 2 * sizeof(double));
-    if (!gt || !c8 || !hw) { free(gt); free(c8); free(hw); snprintf(g_err, sizeof g_err, "out of memory"); return HPGV_ERR_NOMEM; }
+    int32_t *midx = (int32_t *)malloc(n * sizeof(int32_t));
+    int32_t *mtab = (int32_t *)malloc(n * 256 * sizeof(int32_t));
+    if (!gt || !c8 || !hw || !midx || !mtab) {
+        free(gt); free(c8); free(hw); free(midx); free(mtab);
+        snprintf(g_err, sizeof g_err, "out of memory");
+        return HPGV_ERR_NOMEM;
+    }
     hpgv_host_stage_records(variants, num_variants, num_samples, 0, gt, NULL);
+    int n_multi = num_variants;
 
     pthread_rwlock_rdlock(&g_cohort_lock);
-    if (!(g_stats_key.set && g_stats_key.num_samples == num_samples)) {
-        pthread_rwlock_unlock(&g_cohort_lock);
-        pthread_rwlock_wrlock(&g_cohort_lock);
-        if (!(g_stats_key.set && g_stats_key.num_samples == num_samples)) {
-            rc = hpgv_set_stats_cohort(g_ctx, num_samples);
-            if (rc == HPGV_OK) { g_stats_key.set = 1; g_stats_key.num_samples = num_samples; }
-            else host_fail("hpgv_set_stats_cohort", rc);
-        }
-        pthread_rwlock_unlock(&g_cohort_lock);
-        pthread_rwlock_rdlock(&g_cohort_lock);
-    }
+    rc = stats_prepare(num_samples);
     if (rc == HPGV_OK) {
-        rc = hpgv_stats(g_ctx, gt, pitch, num_variants, c8, hw, hw + n);
-        if (rc != HPGV_OK) host_fail("hpgv_stats", rc);
+        rc = hpgv_stats_ex(g_ctx, gt, pitch, num_variants, c8, hw, hw + n, NULL, midx, mtab, &n_multi);
+        if (rc != HPGV_OK) host_fail("hpgv_stats_ex", rc);
     }
     pthread_rwlock_unlock(&g_cohort_lock);
 
     if (rc == HPGV_OK) {
-        int multi = 0;
+        int next_multi = 0;
         for (size_t i = 0; i < n; i++) {
             vcf_record_t *record = variants[i];
             const int32_t *c = c8 + 8 * i;
@@ -669,31 +698,92 @@ int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t *
             s->position = record->position;
             s->ref_allele = dupn(record->reference, record->reference_len);
             s->alt_alleles = dupn(record->alternate, record->alternate_len);
-            s->num_alleles = 2;
-            for (int k = 0; k < 4; k++) s->genotypes_count[k] = c[k];
+            int na = count_alleles(record->alternate, record->alternate_len);
+            const int32_t *tab = NULL;
+            if (next_multi < n_multi && midx[next_multi] == (int32_t)i) {   /* multi-allelic: full 256-bin table */
+                tab = mtab + (size_t)next_multi * 256;
+                next_multi++;
+                for (int code = 0; code < 256; code++) {                    /* alleles the calls actually use */
+                    if (!tab[code]) continue;
+                    int a1 = code >> 4, a2 = code & 0xF;
+                    if (a1 != 0xF && a1 + 1 > na) na = a1 + 1;
+                    if (a2 != 0xF && a2 + 1 > na) na = a2 + 1;
+                }
+            }
+            if (na < 2) na = 2;
+            s->num_alleles = na;
+            s->alleles_count = (int *)calloc((size_t)na, sizeof(int));
+            s->genotypes_count = (int *)calloc((size_t)na * na, sizeof(int));
+            s->alleles_freq = (float *)calloc((size_t)na, sizeof(float));
+            s->genotypes_freq = (float *)calloc((size_t)na * na, sizeof(float));
             s->missing_genotypes = c[4]; s->missing_alleles = c[5];
-            s->other_genotypes = num_samples - c[4] - (c[0] + c[1] + c[2] + c[3]);
-            s->alleles_count[0] = c[6];
-            s->alleles_count[1] = c[7];
-            int ta = s->alleles_count[0] + s->alleles_count[1];
-            int tg = c[0] + c[1] + c[2] + c[3];
-            for (int k = 0; k < 2; k++) s->alleles_freq[k] = ta ? (float)s->alleles_count[k] / ta : 0.0f;
-            for (int k = 0; k < 4; k++) s->genotypes_freq[k] = tg ? (float)c[k] / tg : 0.0f;
-            s->maf = s->alleles_freq[0] < s->alleles_freq[1] ? s->alleles_freq[0] : s->alleles_freq[1];
+            if (tab) {
+                for (int code = 0; code < 256; code++) {
+                    int k = tab[code], a1 = code >> 4, a2 = code & 0xF;
+                    if (!k) continue;
+                    if (a1 != 0xF) s->alleles_count[a1] += k;
+                    if (a2 != 0xF) s->alleles_count[a2] += k;
+                    if (a1 != 0xF && a2 != 0xF) s->genotypes_count[a1 * na + a2] += k;
+                }
+            } else {
+                s->alleles_count[0] = c[6]; s->alleles_count[1] = c[7];
+                s->genotypes_count[0] = c[0]; s->genotypes_count[1] = c[1];
+                s->genotypes_count[na] = c[2]; s->genotypes_count[na + 1] = c[3];
+            }
+            int ta = 0, tg = 0;
+            for (int k = 0; k < na; k++) ta += s->alleles_count[k];
+            for (int k = 0; k < na * na; k++) tg += s->genotypes_count[k];
+            s->maf = 1.0f;
+            for (int k = 0; k < na; k++) {
+                s->alleles_freq[k] = ta ? (float)s->alleles_count[k] / ta : 0.0f;
+                if (s->alleles_freq[k] < s->maf) s->maf = s->alleles_freq[k];
+            }
+            for (int k = 0; k < na * na; k++) s->genotypes_freq[k] = tg ? (float)s->genotypes_count[k] / tg : 0.0f;
             s->hw_chi2 = hw[i]; s->hw_p_value = hw[n + i];
-            if (s->other_genotypes > 0) multi++;
             list_insert_item(list_item_new(tid, 0, s), output_list);
         }
         if (file_stats) {
             pthread_mutex_lock(&file_stats->lock);
             file_stats->variants_count += num_variants;
             file_stats->samples_count = num_samples;
-            file_stats->multiallelics_count += multi;
-            file_stats->biallelics_count += num_variants - multi;
+            file_stats->multiallelics_count += n_multi;
+            file_stats->biallelics_count += num_variants - n_multi;
             pthread_mutex_unlock(&file_stats->lock);
         }
     }
-    free(gt); free(c8); free(hw);
+    free(gt); free(c8); free(hw); free(midx); free(mtab);
+    return rc;
+}
+
+int get_sample_stats(vcf_record_t **variants, int num_variants, individual_t **individuals,
+                     sample_ids_t *sample_ids, sample_stats_t **sample_stats, file_stats_t *file_stats) {
+    (void)individuals; (void)sample_ids; (void)file_stats;   /* Mendelian errors per sample: DESIGN.md "Not yet" */
+    if (num_variants <= 0) return 0;
+    int rc = ensure_engine();
+    if (rc) return rc;
+    int num_samples = (int)variants[0]->samples->size;
+    size_t n = (size_t)num_variants, pitch = (size_t)(num_samples > 0 ? num_samples : 1);
+    uint8_t *gt = (uint8_t *)malloc(n * pitch);
+    int32_t *c8 = (int32_t *)malloc(n * 8 * sizeof(int32_t));
+    double *hw = (double *)malloc(n * 2 * sizeof(double));
+    int32_t *miss = (int32_t *)calloc((size_t)(num_samples > 0 ? num_samples : 1), sizeof(int32_t));
+    if (!gt || !c8 || !hw || !miss) { free(gt); free(c8); free(hw); free(miss); snprintf(g_err, sizeof g_err, "out of memory"); return HPGV_ERR_NOMEM; }
+    hpgv_host_stage_records(variants, num_variants, num_samples, 0, gt, NULL);
+    pthread_rwlock_rdlock(&g_cohort_lock);
+    rc = stats_prepare(num_samples);
+    if (rc == HPGV_OK) {
+        rc = hpgv_stats_ex(g_ctx, gt, pitch, num_variants, c8, hw, hw + n, miss, NULL, NULL, NULL);
+        if (rc != HPGV_OK) host_fail("hpgv_stats_ex", rc);
+    }
+    pthread_rwlock_unlock(&g_cohort_lock);
+    if (rc == HPGV_OK) {
+        /* several workers may update the same sample_stats (stats_runner.c:189-198) */
+        static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+        pthread_mutex_lock(&mu);
+        for (int j = 0; j < num_samples; j++) sample_stats[j]->missing_genotypes += miss[j];
+        pthread_mutex_unlock(&mu);
+    }
+    free(gt); free(c8); free(hw); free(miss);
     return rc;
 }
 

@@ -148,6 +148,18 @@ int  hpgv_stats_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants,
 int  hpgv_stats_hwe_dev(hpgv_ctx *ctx, const int32_t *d_counts8, int n_variants,
                         double *d_chi2, double *d_p, void *stream);
 
+/* per-sample missing-genotype counts (get_sample_stats, call site stats_runner.c:197-198) over a
+ * stats-layout matrix: d_missing[j] += number of listed variants in which sample j has a missing
+ * allele.  The caller zeroes d_missing (n_samples ints) before the first batch. */
+int  hpgv_sample_missing_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants,
+                             int32_t *d_missing, void *stream);
+
+/* full genotype table of (multi-allelic) variants from a RAW HPGV8 matrix in VCF column order:
+ * d_table[i*256 + code] = samples of variant d_variant_idx[i] (or variant i when NULL) whose
+ * code byte is `code`; genotypes_count[a1*num_alleles + a2] is d_table[i*256 + (a1<<4|a2)]. */
+int  hpgv_genotype_table_dev(hpgv_ctx *ctx, const uint8_t *d_raw, size_t src_pitch, int n_samples,
+                             const int32_t *d_variant_idx, int n_idx, int32_t *d_table, void *stream);
+
 /* duration (ms) of the last scan / statistics kernel launched through this ctx
  * when option "profile" = 1 (HIP events on the launch stream; synchronises) */
 int  hpgv_last_kernel_ms(hpgv_ctx *ctx, float *scan_ms, float *stats_ms);
@@ -166,6 +178,13 @@ int  hpgv_tdt(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants,
               double *odds, double *chisq, double *p);
 int  hpgv_stats(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants,
                 int32_t *counts8 /* n_variants x 8 */, double *hwe_chi2, double *hwe_p);
+/* same batch, additionally: sample_missing (n_samples ints, ACCUMULATED into; may be NULL) and, for
+ * every variant whose four biallelic cells do not cover all called genotypes, its 256-bin genotype
+ * table: multi_idx[k] = variant index, multi_table[k*256 + code]; *n_multi in = capacity of both
+ * arrays (in variants), out = number of such variants (filled up to the capacity). */
+int  hpgv_stats_ex(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants,
+                   int32_t *counts8, double *hwe_chi2, double *hwe_p, int32_t *sample_missing,
+                   int32_t *multi_idx, int32_t *multi_table, int *n_multi);
 
 /* streaming-read ceiling probe: reads `bytes` from d_buf with the scan's load
  * shape and no arithmetic; returns the kernel time in ms (diagnostic) */

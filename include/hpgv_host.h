@@ -169,23 +169,31 @@ void assoc_fisher_result_free(assoc_fisher_result_t *result);
 void tdt_result_free(tdt_result_t *result);
 
 /* variant_stats_t: the fields visible in the reference tree
- * (aggregate_runner.c:187-191,288-312,379-400) for the biallelic case, plus the
- * Hardy-Weinberg record the stats tool reports. */
+ * (aggregate_runner.c:187-191,288-312,379-400), plus the Hardy-Weinberg record the
+ * stats tool reports.  Arrays are sized by num_alleles (1 + number of ALT alleles). */
 typedef struct {
     char *chromosome; unsigned long position;
     char *ref_allele; char *alt_alleles;
     int num_alleles;
-    int alleles_count[2];
-    int genotypes_count[4];            /* [a1 * num_alleles + a2] */
-    float alleles_freq[2];
-    float genotypes_freq[4];
+    int *alleles_count;                /* [num_alleles] */
+    int *genotypes_count;              /* [a1 * num_alleles + a2] */
+    float *alleles_freq;
+    float *genotypes_freq;
     int missing_alleles, missing_genotypes;
-    int other_genotypes;               /* calls touching an allele index >= 2 */
     float maf;
-    double hw_chi2, hw_p_value;
+    double hw_chi2, hw_p_value;        /* on the first two alleles */
 } variant_stats_t;
 
 void variant_stats_free(variant_stats_t *stats);
+
+typedef struct {                       /* sample_stats_t (stats_runner.c:158-160): per-sample counters */
+    char *name;
+    int missing_genotypes;
+    int mendelian_errors;              /* not computed yet (DESIGN.md "Not yet") */
+} sample_stats_t;
+
+sample_stats_t *sample_stats_new(char *name);
+void sample_stats_free(sample_stats_t *stats);
 
 typedef struct {                       /* file_stats_t: summary counters (simple sums) */
     int variants_count, samples_count, biallelics_count, multiallelics_count;
@@ -221,6 +229,10 @@ int  tdt_test(vcf_record_t **variants, int num_variants, family_t **families, in
 int  get_variants_stats(vcf_record_t **variants, int num_variants, individual_t **individuals,
                         sample_ids_t *sample_ids, int num_variables, list_t *output_list,
                         file_stats_t *file_stats);
+
+/* call shape of stats_runner.c:197-198; accumulates into sample_stats[j] for VCF column j */
+int  get_sample_stats(vcf_record_t **variants, int num_variants, individual_t **individuals,
+                      sample_ids_t *sample_ids, sample_stats_t **sample_stats, file_stats_t *file_stats);
 
 /* ---- writers with the reference's exact formats ------------------------------ */
 void assoc_write_output_header(enum ASSOC_task task, FILE *fd);             /* assoc_runner.c:292-299 */

@@ -428,6 +428,14 @@ void orc_variant_stats(const uint8_t *row, int n_samples, int num_alleles,
     orc_hwe(out->hw_n_AA, out->hw_n_Aa, out->hw_n_aa, &out->hw_chi2, &out->hw_p);
 }
 
+void orc_sample_missing(const uint8_t *gt, size_t pitch, int n_variants, int n_samples, int32_t *missing) {
+    for (int i = 0; i < n_variants; i++) {
+        const uint8_t *row = gt + (size_t)i * pitch;
+        for (int j = 0; j < n_samples; j++)
+            if ((row[j] >> 4) == 0xF || (row[j] & 0xF) == 0xF) missing[j]++;
+    }
+}
+
 /* ------------------------------------------------------------------------
  * Synthetic cohort.  Integer-only per genotype so the device
  * generator reproduces it bit for bit.

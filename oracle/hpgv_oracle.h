@@ -119,6 +119,9 @@ typedef struct {
 void orc_variant_stats(const uint8_t *row, int n_samples, int num_alleles,
                        orc_variant_stats_t *out);
 void orc_hwe(int n_AA, int n_Aa, int n_aa, double *chi2, double *p);
+/* hpg-libs get_sample_stats (call site stats_runner.c:197-198): per sample, the number of
+ * variants in which the genotype has a missing allele; accumulated into missing[] */
+void orc_sample_missing(const uint8_t *gt, size_t pitch, int n_variants, int n_samples, int32_t *missing);
 
 /* ---- synthetic cohort (bit-reproducible on device) */
 #define ORC_SYNTH_SEED 0x4850475631ULL

@@ -88,6 +88,8 @@ def lib():
     L.orc_tdt_stats.argtypes = [C.c_int, p_i32, p_i32, p_f64, p_f64, p_f64]
     L.orc_variant_stats.restype = None
     L.orc_variant_stats.argtypes = [p_u8, C.c_int, C.c_int, C.POINTER(VariantStats)]
+    L.orc_sample_missing.restype = None
+    L.orc_sample_missing.argtypes = [p_u8, C.c_size_t, C.c_int, C.c_int, p_i32]
     L.orc_hwe.restype = None
     L.orc_hwe.argtypes = [C.c_int] * 3 + [p_f64, p_f64]
     L.orc_splitmix64.restype = C.c_uint64
@@ -195,6 +197,13 @@ def variant_stats(row, num_alleles=2):
     vs = VariantStats()
     lib().orc_variant_stats(_p(row, C.c_uint8), row.shape[0], num_alleles, C.byref(vs))
     return vs
+
+
+def sample_missing(gt):
+    gt = np.ascontiguousarray(gt, dtype=np.uint8)
+    out = np.zeros(gt.shape[1], dtype=np.int32)
+    lib().orc_sample_missing(_p(gt, C.c_uint8), gt.shape[1], gt.shape[0], gt.shape[1], _p(out, C.c_int32))
+    return out
 
 
 def hwe(n_AA, n_Aa, n_aa):

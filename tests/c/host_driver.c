@@ -311,19 +311,32 @@ static int cmd_stats(const char *batch_path, const char *out_path) {
     list_t out;
     list_init("output", 1, 0, &out);
     file_stats_t *fs = file_stats_new();
-    int rc = get_variants_stats(b.records, b.n_variants, NULL, NULL, 0, &out, fs);
-    if (rc) { fprintf(stderr, "get_variants_stats failed: %s\n", hpgv_host_last_error()); return 1; }
+    sample_stats_t **ss = (sample_stats_t **)malloc(sizeof(void *) * (size_t)(b.n_samples + 1));
+    for (int j = 0; j < b.n_samples; j++) ss[j] = sample_stats_new(b.sample_names[j]);
+    /* stats_runner.c:184-199: the batch is cut into chunks, both functions run on every chunk */
+    int chunk = 64, rc = 0;
+    for (int start = 0; start < b.n_variants && !rc; start += chunk) {
+        int n = start + chunk <= b.n_variants ? chunk : b.n_variants - start;
+        rc = get_variants_stats(b.records + start, n, NULL, NULL, 0, &out, fs);
+        rc |= get_sample_stats(b.records + start, n, NULL, NULL, ss, fs);
+    }
+    if (rc) { fprintf(stderr, "stats failed: %s\n", hpgv_host_last_error()); return 1; }
     list_decr_writers(&out);
     FILE *fd = fopen(out_path, "w");
     list_item_t *it;
     while ((it = list_remove_item(&out))) {
         variant_stats_t *s = (variant_stats_t *)it->data_p;
-        fprintf(fd, "%s\t%lu\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%.17g\t%.17g\n", s->chromosome, s->position,
-                s->alleles_count[0], s->alleles_count[1], s->genotypes_count[0], s->genotypes_count[1],
-                s->genotypes_count[2], s->genotypes_count[3], s->missing_alleles, s->missing_genotypes,
-                s->other_genotypes, s->hw_chi2, s->hw_p_value);
+        fprintf(fd, "V\t%s\t%lu\t%d\t%d\t%d\t%.17g\t%.17g", s->chromosome, s->position, s->num_alleles,
+                s->missing_alleles, s->missing_genotypes, s->hw_chi2, s->hw_p_value);
+        for (int k = 0; k < s->num_alleles; k++) fprintf(fd, "\t%d", s->alleles_count[k]);
+        for (int k = 0; k < s->num_alleles * s->num_alleles; k++) fprintf(fd, "\t%d", s->genotypes_count[k]);
+        fprintf(fd, "\n");
         variant_stats_free(s);
         list_item_free(it);
+    }
+    for (int j = 0; j < b.n_samples; j++) {
+        fprintf(fd, "S\t%s\t%d\n", ss[j]->name, ss[j]->missing_genotypes);
+        sample_stats_free(ss[j]);
     }
     fclose(fd);
     printf("STATS OK variants=%d multiallelic=%d\n", fs->variants_count, fs->multiallelics_count);

@@ -323,6 +323,27 @@ def test_variant_stats_and_hwe(n_samples):
     e.close()
 
 
+def test_sample_missing_and_multiallelic_tables():
+    rng = np.random.default_rng(77)
+    for n_samples, nv in ((1, 5), (1000, 300), (2049, 129), (5000, 400)):
+        e = fresh()
+        e.set_stats_cohort(n_samples)
+        gt = random_codes(rng, nv, n_samples, quirks=True, strict=False)
+        gt[::3] = random_codes(rng, len(gt[::3]), n_samples, quirks=False)      # biallelic rows in between
+        acc = np.full(n_samples, 7, np.int32)                                    # accumulates INTO the array
+        res = e.stats_ex(gt, sample_missing=acc, multi_cap=nv)
+        assert np.array_equal(acc - 7, orc.sample_missing(gt))
+        multi = [i for i in range(nv) if ((gt[i] != 0x00) & (gt[i] != 0x01) & (gt[i] != 0x10) & (gt[i] != 0x11) &
+                                          ((gt[i] >> 4) != 0xF) & ((gt[i] & 0xF) != 0xF)).any()]
+        assert res["n_multi"] == len(multi) and list(res["multi_idx"]) == multi
+        for k, i in enumerate(multi):
+            assert np.array_equal(res["multi_table"][k], np.bincount(gt[i], minlength=256))
+        # a too small capacity reports the true count and fills what fits
+        small = e.stats_ex(gt, multi_cap=1)
+        assert small["n_multi"] == len(multi) and len(small["multi_idx"]) == min(1, len(multi))
+        e.close()
+
+
 # ------------------------------------------------------- error behaviour ----
 
 def test_state_and_argument_errors():

@@ -174,7 +174,7 @@ def test_tdt_test_runner_shape(driver, tmp_path):
             assert (np.isnan(g) and np.isnan(e)) or (np.isinf(g) and np.isinf(e)) or abs(g - e) <= 6e-7 * max(1.0, abs(e))
 
 
-def test_get_variants_stats(driver, tmp_path):
+def test_get_variants_stats_and_sample_stats(driver, tmp_path):
     rng = np.random.default_rng(13)
     people, names, rows = _write_inputs(tmp_path, rng, 20, 30, 200)
     r = subprocess.run([driver, "stats", str(tmp_path / "batch.txt"), str(tmp_path / "stats.tsv")],
@@ -182,16 +182,25 @@ def test_get_variants_stats(driver, tmp_path):
     assert r.returncode == 0 and "STATS OK variants=200" in r.stdout, r.stdout + r.stderr
     gt = _codes(rows, False)
     lines = [l.rstrip("\n").split("\t") for l in open(tmp_path / "stats.tsv")]
-    assert len(lines) == len(rows)
-    for v, t in enumerate(lines):                          # one worker: order preserved
-        vs = orc.variant_stats(gt[v], 2)
-        g = list(vs.genotypes_count)[:4]
-        assert [int(x) for x in t[2:4]] == list(vs.alleles_count)[:2]
-        assert [int(x) for x in t[4:8]] == g
-        assert int(t[8]) == vs.missing_alleles and int(t[9]) == vs.missing_genotypes
-        assert int(t[10]) == len(names) - vs.missing_genotypes - sum(g)
-        assert_close([_fl(t[11])], [vs.hw_chi2], "hwe chi2")
-        assert_close([_fl(t[12])], [vs.hw_p], "hwe p")
+    vlines = [t for t in lines if t[0] == "V"]
+    slines = [t for t in lines if t[0] == "S"]
+    assert len(vlines) == len(rows) and len(slines) == len(names)
+    n_multi = 0
+    for v, t in enumerate(vlines):                         # one worker: order preserved
+        na = int(t[3])
+        used = [n for code in gt[v] for n in (code >> 4, code & 0xF) if n != 0xF]
+        assert na == max(2, max(used) + 1 if used else 2)  # quirk genotypes reach allele 14 ("20/20" clamps)
+        n_multi += na > 2
+        vs = orc.variant_stats(gt[v], na)
+        assert int(t[4]) == vs.missing_alleles and int(t[5]) == vs.missing_genotypes
+        assert_close([_fl(t[6])], [vs.hw_chi2], "hwe chi2")
+        assert_close([_fl(t[7])], [vs.hw_p], "hwe p")
+        assert [int(x) for x in t[8: 8 + na]] == list(vs.alleles_count)[:na], v
+        assert [int(x) for x in t[8 + na: 8 + na + na * na]] == list(vs.genotypes_count)[: na * na], v
+    assert n_multi > 0 and ("multiallelic=%d" % n_multi) in r.stdout
+    miss = orc.sample_missing(gt)                          # get_sample_stats: per-sample missing genotypes
+    for j, t in enumerate(slines):
+        assert t[1] == names[j] and int(t[2]) == miss[j]
 
 
 def test_staging_matches_the_oracle_encoder():
