@@ -72,7 +72,9 @@ def pmc_traffic(workload, variants, samples, pitch, kernel):
         try:
             d = json.load(open(f))
             if d["variants"] == variants and d["samples"] == samples and d["row_pitch_bytes"] == pitch:
-                best = d["kernels"][kernel]["hbm_bytes_per_launch"]
+                for k, v in d["kernels"].items():
+                    if kernel.startswith(k):
+                        best = v["hbm_bytes_per_launch"]
         except Exception:
             pass
     return best
@@ -166,7 +168,8 @@ def main():
         which, res_bytes, payload, scan_name = hpgv.LAYOUT_TDT, 32, 32, "k_tdt_scan"
     else:
         nA, nU, pitch = eng.set_cohort(cond)
-        which, scan_name = hpgv.LAYOUT_ASSOC, "k_assoc_scan"
+        which = hpgv.LAYOUT_ASSOC
+        scan_name = "k_assoc_scan" if "pipeline=0" in args.option else "k_assoc_scan_pipe"
         res_bytes, payload = (40, 40) if kind == "chisq" else (32, 32)
         if kind == "fisher":
             # ln(i!) table with num_samples * 10 entries, as assoc_runner.c:164-166 builds it (an INPUT of the pass)
