@@ -32,6 +32,7 @@ SYMBOLS = [
     "hpgv_assoc_scan_dev", "hpgv_assoc_chisq_dev", "hpgv_assoc_fisher_dev",
     "hpgv_tdt_scan_dev", "hpgv_tdt_stats_dev", "hpgv_stats_scan_dev", "hpgv_stats_hwe_dev",
     "hpgv_sample_missing_dev", "hpgv_genotype_table_dev",
+    "hpgv_tokenize_dev", "hpgv_tokenize",
     "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_read_probe",
 ]
 
@@ -97,6 +98,8 @@ def load():
     L.hpgv_stats_ex.argtypes = [vp, vp, sz, i32, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
     L.hpgv_sample_missing_dev.argtypes = [vp, vp, i32, vp, vp]
     L.hpgv_genotype_table_dev.argtypes = [vp, vp, sz, i32, vp, i32, vp, vp]
+    L.hpgv_tokenize_dev.argtypes = [vp, vp, sz, i32, i32, i32, vp, vp, vp, vp, sz, vp, vp, vp]
+    L.hpgv_tokenize.argtypes = [vp, C.c_char_p, sz, i32, i32, i32, C.POINTER(i32), vp, vp, vp, sz, vp, vp]
     L.hpgv_read_probe.argtypes = [vp, vp, sz, i32, C.POINTER(C.c_float)]
     _lib = L
     return L
@@ -246,6 +249,25 @@ class Engine:
                                        _ptr(sample_missing), _ptr(midx), _ptr(mtab), C.byref(nm)))
         k = min(nm.value, multi_cap)
         return dict(counts8=c8, hwe_chi2=chi2, hwe_p=p, n_multi=nm.value, multi_idx=midx[:k], multi_table=mtab[:k])
+
+    def tokenize(self, text, n_samples, strict=True, max_lines=None):
+        """VCF data lines (bytes) -> dict(gt [n_lines, n_samples], is_x, status, line_off, field_off, n_lines)."""
+        if isinstance(text, str):
+            text = text.encode()
+        if max_lines is None:
+            max_lines = text.count(b"\n") + 1
+        pitch = max(n_samples, 1)
+        gt = np.zeros((max_lines, pitch), np.uint8)
+        is_x = np.zeros(max_lines, np.uint8)
+        status = np.zeros(max_lines, np.int32)
+        line_off = np.zeros(max_lines + 1, np.uint64)
+        field_off = np.zeros((max_lines, 10), np.uint32)
+        nl = C.c_int(0)
+        self._chk(self.L.hpgv_tokenize(self.h, text, len(text), n_samples, 1 if strict else 0, max_lines, C.byref(nl),
+                                       _ptr(line_off), _ptr(field_off), _ptr(gt), pitch, _ptr(is_x), _ptr(status)))
+        k = min(nl.value, max_lines)
+        return dict(n_lines=nl.value, gt=gt[:k, :n_samples], is_x=is_x[:k], status=status[:k], line_off=line_off[:k + 1],
+                    field_off=field_off[:k])
 
     # ---- device-resident path (raw pointers; ints or c_void_p) ---------------
     def synth(self, which, v0, n_variants, d_dst, stream=None):

@@ -5,6 +5,7 @@
 #include "../../include/hpgv.h"
 #include "hpgv_kernels.h"
 #include "hpgv_tdt_stats_kernels.h"
+#include "hpgv_text_kernels.h"
 
 #include <hip/hip_runtime.h>
 
@@ -73,6 +74,12 @@ struct hpgv_ctx {
     bool have_scan_ev = false, have_stats_ev = false;
     std::vector<Slot *> slots;
     uint32_t *d_sink = nullptr;
+    // tokenizer scratch (newline counts per 4 KiB tile); calls are serialised by tok_mu
+    std::mutex tok_mu;
+    int *d_tok_blocks = nullptr;
+    size_t tok_blocks_cap = 0;
+    unsigned long long *d_tok_line_off = nullptr;
+    size_t tok_line_cap = 0;
 };
 
 namespace {
@@ -228,6 +235,8 @@ void hpgv_destroy(hpgv_ctx *ctx) {
     if (ctx->d_lf) (void)hipFree(ctx->d_lf);
     if (ctx->d_thr) (void)hipFree(ctx->d_thr);
     if (ctx->d_sink) (void)hipFree(ctx->d_sink);
+    if (ctx->d_tok_blocks) (void)hipFree(ctx->d_tok_blocks);
+    if (ctx->d_tok_line_off) (void)hipFree(ctx->d_tok_line_off);
     for (Slot *s : ctx->slots) {
         for (int i = 0; i < 8; ++i) if (s->buf[i]) (void)hipFree(s->buf[i]);
         if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -879,6 +888,89 @@ int hpgv_stats_ex(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants
 int hpgv_stats(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, int32_t *counts8,
                double *hwe_chi2, double *hwe_p) {
     return hpgv_stats_ex(ctx, gt, pitch, n_variants, counts8, hwe_chi2, hwe_p, nullptr, nullptr, nullptr, nullptr);
+}
+
+/* ---- text staging ------------------------------------------------------------ */
+
+int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int n_samples, int strict,
+                      int max_lines, int *d_n_lines, uint64_t *d_line_off, uint32_t *d_field_off,
+                      uint8_t *d_gt, size_t pitch, uint8_t *d_is_x, int32_t *d_status, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (n_samples < 0 || max_lines < 0 || !d_n_lines || (text_bytes > 0 && !d_text) ||
+        (max_lines > 0 && !d_gt) || pitch < (size_t)n_samples)
+        return fail(ctx, HPGV_ERR_INVALID, "bad tokenize arguments");
+    if (text_bytes > ((size_t)1 << 40)) return fail(ctx, HPGV_ERR_UNSUPPORTED, "text buffer too large for one call");
+    DeviceGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(ctx->tok_mu);
+    const size_t n_blocks = (text_bytes + hpgv::TOK_TILE - 1) / hpgv::TOK_TILE;
+    if (n_blocks > 0x7FFFFFFFu) return fail(ctx, HPGV_ERR_UNSUPPORTED, "text buffer too large for one call");
+    if (ctx->tok_blocks_cap < n_blocks + 1) {
+        if (ctx->d_tok_blocks) { HIPCHK(ctx, hipStreamSynchronize(st)); (void)hipFree(ctx->d_tok_blocks); ctx->d_tok_blocks = nullptr; }
+        HIPCHK(ctx, hipMalloc(&ctx->d_tok_blocks, (n_blocks + 1) * sizeof(int)));
+        ctx->tok_blocks_cap = n_blocks + 1;
+    }
+    unsigned long long *line_off = (unsigned long long *)d_line_off;
+    if (!line_off) {                                   // caller does not want the offsets: use scratch
+        if (ctx->tok_line_cap < (size_t)max_lines + 2) {
+            if (ctx->d_tok_line_off) { HIPCHK(ctx, hipStreamSynchronize(st)); (void)hipFree(ctx->d_tok_line_off); ctx->d_tok_line_off = nullptr; }
+            HIPCHK(ctx, hipMalloc(&ctx->d_tok_line_off, ((size_t)max_lines + 2) * sizeof(unsigned long long)));
+            ctx->tok_line_cap = (size_t)max_lines + 2;
+        }
+        line_off = ctx->d_tok_line_off;
+    }
+    if (n_blocks > 0)
+        hipLaunchKernelGGL(hpgv::k_tok_count, dim3((unsigned)n_blocks), dim3(256), 0, st, d_text, text_bytes, ctx->d_tok_blocks);
+    hipLaunchKernelGGL(hpgv::k_tok_scan, dim3(1), dim3(256), 0, st, ctx->d_tok_blocks, (int)n_blocks, d_text, text_bytes,
+                       d_n_lines, line_off, max_lines);
+    if (n_blocks > 0)
+        hipLaunchKernelGGL(hpgv::k_tok_mark, dim3((unsigned)n_blocks), dim3(256), 0, st, d_text, text_bytes,
+                           (const int *)ctx->d_tok_blocks, line_off, max_lines);
+    else
+        HIPCHK(ctx, hipMemsetAsync(line_off, 0, sizeof(unsigned long long), st));
+    if (max_lines > 0)
+        hipLaunchKernelGGL(hpgv::k_tok_parse, dim3((unsigned)max_lines), dim3(256), 0, st, d_text, line_off,
+                           (const int *)d_n_lines, max_lines, n_samples, strict, d_gt, pitch, d_is_x, d_field_off, d_status);
+    HIPCHK(ctx, hipGetLastError());
+    return HPGV_OK;
+}
+
+int hpgv_tokenize(hpgv_ctx *ctx, const char *text, size_t text_bytes, int n_samples, int strict, int max_lines,
+                  int *n_lines, uint64_t *line_off, uint32_t *field_off, uint8_t *gt, size_t pitch,
+                  uint8_t *is_x, int32_t *status) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!n_lines || n_samples < 0 || max_lines < 0 || (text_bytes > 0 && !text) || (max_lines > 0 && !gt) ||
+        pitch < (size_t)n_samples)
+        return fail(ctx, HPGV_ERR_INVALID, "bad tokenize arguments");
+    DeviceGuard g(ctx->device);
+    SlotLease lease(ctx);
+    int rc = acquire_slot(ctx, &lease.s);
+    if (rc) return rc;
+    Slot *s = lease.s;
+    const size_t ml = (size_t)max_lines;
+    if ((rc = ensure(ctx, s, 0, text_bytes + 16))) return rc;
+    if ((rc = ensure(ctx, s, 1, ml * pitch + 16))) return rc;
+    if ((rc = ensure(ctx, s, 2, ml + 16))) return rc;
+    if ((rc = ensure(ctx, s, 3, (ml + 2) * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, s, 4, ml * 10 * sizeof(uint32_t) + 16))) return rc;
+    if ((rc = ensure(ctx, s, 5, ml * sizeof(int32_t) + 16))) return rc;
+    if ((rc = ensure(ctx, s, 6, 16))) return rc;
+    if (text_bytes) HIPCHK(ctx, hipMemcpyAsync(s->buf[0], text, text_bytes, hipMemcpyHostToDevice, s->stream));
+    if ((rc = hpgv_tokenize_dev(ctx, (const char *)s->buf[0], text_bytes, n_samples, strict, max_lines, (int *)s->buf[6],
+                                (uint64_t *)s->buf[3], (uint32_t *)s->buf[4], (uint8_t *)s->buf[1], pitch,
+                                (uint8_t *)s->buf[2], (int32_t *)s->buf[5], s->stream))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(n_lines, s->buf[6], sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    const size_t nl = (size_t)(*n_lines < max_lines ? *n_lines : max_lines);
+    if (nl) {
+        HIPCHK(ctx, hipMemcpyAsync(gt, s->buf[1], nl * pitch, hipMemcpyDeviceToHost, s->stream));
+        if (is_x) HIPCHK(ctx, hipMemcpyAsync(is_x, s->buf[2], nl, hipMemcpyDeviceToHost, s->stream));
+        if (field_off) HIPCHK(ctx, hipMemcpyAsync(field_off, s->buf[4], nl * 10 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        if (status) HIPCHK(ctx, hipMemcpyAsync(status, s->buf[5], nl * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    }
+    if (line_off) HIPCHK(ctx, hipMemcpyAsync(line_off, s->buf[3], (nl + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    return HPGV_OK;
 }
 
 int hpgv_read_probe(hpgv_ctx *ctx, const uint8_t *d_buf, size_t bytes, int iters, float *ms) {

@@ -1,0 +1,222 @@
+// hpgv_text_kernels.h -- VCF data lines (text) -> HPGV8 genotype matrix on the GPU
+// (the step right before the scan; the reference does it
+// per genotype with strdup + get_alleles, assoc.c:45-56).
+//
+//   k_tok_count / k_tok_scan / k_tok_mark : line starts (newline compaction)
+//   k_tok_parse                           : one workgroup per line
+// Text arrives over PCIe at ~55 GB/s, far below what these kernels sustain, so
+// they are written for clarity: 16 bytes per thread per tile, block-wide prefix
+// count of TABs gives every TAB its field index, the thread owning a TAB parses
+// the genotype that follows it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hpgv {
+
+constexpr int TOK_TILE = 4096;          // bytes per workgroup tile (256 threads x 16 B)
+
+__global__ __launch_bounds__(256) void k_tok_count(const char *__restrict__ text, size_t n, int *__restrict__ block_counts) {
+    __shared__ int s[4];
+    const size_t base = (size_t)blockIdx.x * TOK_TILE + (size_t)threadIdx.x * 16;
+    int c = 0;
+    for (int j = 0; j < 16; ++j) if (base + j < n && text[base + j] == '\n') c++;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+// single workgroup: exclusive scan of block_counts in place; n_lines = newlines (+1 for an unterminated tail)
+__global__ __launch_bounds__(256) void k_tok_scan(int *__restrict__ block_counts, int n_blocks, const char *__restrict__ text,
+                                                  size_t n, int *__restrict__ n_lines,
+                                                  unsigned long long *__restrict__ line_off, int max_lines) {
+    __shared__ int s[256];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_blocks; base += 256) {
+        const int i = base + threadIdx.x;
+        const int v = i < n_blocks ? block_counts[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int t = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n_blocks) block_counts[i] = carry + s[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += s[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int tail = (n > 0 && text[n - 1] != '\n') ? 1 : 0;     // unterminated last line
+        *n_lines = carry + tail;
+        if (tail && carry + 1 <= max_lines) line_off[carry + 1] = n;
+    }
+}
+
+// line_off[k] = start of line k; line_off[n_lines] = end of text (one past the last newline or n)
+__global__ __launch_bounds__(256) void k_tok_mark(const char *__restrict__ text, size_t n, const int *__restrict__ block_offsets,
+                                                  unsigned long long *__restrict__ line_off, int max_lines) {
+    __shared__ int s[4];
+    const size_t base = (size_t)blockIdx.x * TOK_TILE + (size_t)threadIdx.x * 16;
+    int c = 0;
+    for (int j = 0; j < 16; ++j) if (base + j < n && text[base + j] == '\n') c++;
+    int x = c;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
+    if (lane == 63) s[w] = x;
+    __syncthreads();
+    int before = block_offsets[blockIdx.x] + x - c;
+    for (int k = 0; k < w; ++k) before += s[k];
+    for (int j = 0; j < 16; ++j)
+        if (base + j < n && text[base + j] == '\n') {
+            before++;
+            if (before <= max_lines) line_off[before] = base + j + 1;
+        }
+    if (blockIdx.x == 0 && threadIdx.x == 0) line_off[0] = 0;
+}
+
+// atoi() on [p, e): optional blanks, sign, digits (what get_alleles applies to an allele token)
+__device__ __forceinline__ int tok_atoi(const char *__restrict__ t, size_t p, size_t e) {
+    while (p < e && (t[p] == ' ' || (t[p] >= '\t' && t[p] <= '\r'))) p++;
+    bool neg = false;
+    if (p < e && (t[p] == '+' || t[p] == '-')) { neg = t[p] == '-'; p++; }
+    int v = 0;
+    while (p < e && t[p] >= '0' && t[p] <= '9') { v = v < 100000 ? v * 10 + (t[p] - '0') : v; p++; }
+    return neg ? -v : v;
+}
+
+// one sample field starting at p (line ends at e, exclusive): the product's statement of
+// get_alleles + the HPGV8 encoding (host twin: hpgv_host.c encode_gt)
+__device__ __forceinline__ uint32_t tok_encode(const char *__restrict__ t, size_t p, size_t e, int gt_position, int strict) {
+    size_t fe = p;                                      // end of this sample field
+    while (fe < e && t[fe] != '\t') fe++;
+    for (int i = 0; i < gt_position; ++i) {             // skip to the GT sub-field
+        while (p < fe && t[p] != ':') p++;
+        if (p >= fe) return 0xFFu;                      // sub-field absent: all alleles missing
+        p++;
+    }
+    size_t ge = p;
+    while (ge < fe && t[ge] != ':') ge++;
+    size_t sep = p;
+    while (sep < ge && t[sep] != '/' && t[sep] != '|') sep++;
+    int status = 0, a1 = -1, a2 = -1;
+    if (sep == p || (sep - p == 1 && t[p] == '.')) status += 1; else a1 = tok_atoi(t, p, sep);
+    if (sep == ge) { status = (status == 0) ? 4 : 3; }
+    else {
+        const size_t q = sep + 1;
+        if (q == ge || (ge - q == 1 && t[q] == '.')) status += 2; else a2 = tok_atoi(t, q, ge);
+    }
+    if (strict && status != 0) return 0xFFu;
+    const uint32_t n1 = (a1 < 0) ? 0xFu : (a1 > 14 ? 14u : (uint32_t)a1);
+    const uint32_t n2 = (a2 < 0) ? 0xFu : (a2 > 14 ? 14u : (uint32_t)a2);
+    return (n1 << 4) | n2;
+}
+
+// block-wide exclusive prefix of v; *total = block sum.  s4: 4 ints of LDS.
+__device__ __forceinline__ int block_excl_scan(int v, int *s4, int *total) {
+    int x = v;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
+    __syncthreads();
+    if (lane == 63) s4[w] = x;
+    __syncthreads();
+    int before = x - v;
+    for (int k = 0; k < w; ++k) before += s4[k];
+    *total = s4[0] + s4[1] + s4[2] + s4[3];
+    return before;
+}
+
+// status per line: 0 ok, 1 fewer than 9 TABs (no sample columns), 2 FORMAT has no GT,
+// 3 fewer sample fields than n_samples (the missing ones are 0xFF)
+__global__ __launch_bounds__(256) void k_tok_parse(const char *__restrict__ text, const unsigned long long *__restrict__ line_off,
+                                                   const int *__restrict__ n_lines_p, int max_lines, int n_samples, int strict,
+                                                   uint8_t *__restrict__ gt, size_t pitch, uint8_t *__restrict__ is_x,
+                                                   uint32_t *__restrict__ field_off /* n_lines x 10 */, int *__restrict__ status) {
+    __shared__ int s4[4];
+    __shared__ unsigned int s_field[10];
+    __shared__ int s_gtpos;
+    const int line = blockIdx.x;
+    const int n_lines = *n_lines_p < max_lines ? *n_lines_p : max_lines;
+    if (line >= n_lines) return;
+    const size_t ls = line_off[line];
+    size_t le = line_off[line + 1];
+    if (le > ls && text[le - 1] == '\n') le--;              // exclusive end, newline dropped
+    const char *t = text;
+    if (threadIdx.x < 10) s_field[threadIdx.x] = 0xFFFFFFFFu;
+    __syncthreads();
+
+    // ---- phase 1: the first nine TABs -> starts of CHROM..FORMAT and of the sample columns
+    int carry = 0;
+    for (size_t base = ls; base < le && carry < 9; base += TOK_TILE) {
+        const size_t p0 = base + (size_t)threadIdx.x * 16;
+        int c = 0;
+        for (int j = 0; j < 16; ++j) if (p0 + j < le && t[p0 + j] == '\t') c++;
+        int total;
+        int idx = carry + block_excl_scan(c, s4, &total);
+        for (int j = 0; j < 16; ++j)
+            if (p0 + j < le && t[p0 + j] == '\t') {
+                idx++;
+                if (idx <= 9) s_field[idx] = (unsigned int)(p0 + j + 1 - ls);
+            }
+        carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        s_field[0] = 0;
+        int gtpos = -1;
+        if (s_field[9] != 0xFFFFFFFFu) {                   // FORMAT = [s_field[8], s_field[9] - 1)
+            size_t p = ls + s_field[8];
+            const size_t fe = ls + s_field[9] - 1;
+            int pos = 0;
+            while (p <= fe) {
+                size_t q = p;
+                while (q < fe && t[q] != ':') q++;
+                if (q - p == 2 && t[p] == 'G' && t[p + 1] == 'T') { gtpos = pos; break; }
+                if (q >= fe) break;
+                p = q + 1; pos++;
+            }
+        }
+        s_gtpos = gtpos;
+        const size_t clen = (s_field[1] != 0xFFFFFFFFu) ? (size_t)s_field[1] - 1 : (le - ls);
+        // assoc.c:94: !strncmp("X", chromosome, chromosome_len)
+        if (is_x) is_x[line] = (clen == 0 || (clen == 1 && t[ls] == 'X')) ? 1 : 0;
+        if (field_off) for (int k = 0; k < 10; ++k) field_off[(size_t)line * 10 + k] = s_field[k];
+    }
+    __syncthreads();
+    uint8_t *row = gt + (size_t)line * pitch;
+    const int gtpos = s_gtpos;
+    if (s_field[9] == 0xFFFFFFFFu || gtpos < 0) {
+        for (int j = threadIdx.x; j < n_samples; j += 256) row[j] = 0xFF;
+        if (threadIdx.x == 0 && status) status[line] = (s_field[9] == 0xFFFFFFFFu) ? 1 : 2;
+        return;
+    }
+
+    // ---- phase 2: every TAB from the ninth on starts a sample field
+    const size_t r0 = ls + s_field[9] - 1;                  // position of the ninth TAB
+    int before = 8;                                         // TABs in front of r0
+    for (size_t base = r0; base < le; base += TOK_TILE) {
+        const size_t p0 = base + (size_t)threadIdx.x * 16;
+        int c = 0;
+        for (int j = 0; j < 16; ++j) if (p0 + j < le && t[p0 + j] == '\t') c++;
+        int total;
+        int idx = before + block_excl_scan(c, s4, &total);  // TABs before this thread's bytes
+        for (int j = 0; j < 16; ++j)
+            if (p0 + j < le && t[p0 + j] == '\t') {
+                const int sample = idx - 8;                 // field index idx+1, samples start at field 9
+                idx++;
+                if (sample < n_samples) row[sample] = (uint8_t)tok_encode(t, p0 + j + 1, le, gtpos, strict);
+            }
+        before += total;
+        __syncthreads();
+    }
+    const int found = before - 8;                           // sample fields present on the line
+    for (int j = (found < 0 ? 0 : found) + threadIdx.x; j < n_samples; j += 256) row[j] = 0xFF;
+    if (threadIdx.x == 0 && status) status[line] = found < n_samples ? 3 : 0;
+}
+
+}  // namespace hpgv

@@ -186,6 +186,25 @@ int  hpgv_stats_ex(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variant
                    int32_t *counts8, double *hwe_chi2, double *hwe_p, int32_t *sample_missing,
                    int32_t *multi_idx, int32_t *multi_table, int *n_multi);
 
+/* ---- VCF text -> HPGV8 on the GPU (replaces the per-genotype
+ *      strdup + get_alleles of assoc.c:45-56 / tdt.c:97-108,150-157) ------------------
+ * text: whole VCF DATA lines (no '#' header lines), TAB separated, '\n' terminated (the last
+ * line may lack it), CHROM..FORMAT then n_samples sample columns.  Outputs, all optional
+ * except gt:  line_off[max_lines+1] byte offset of each line start (line_off[n_lines] = end);
+ * field_off[line*10 + k] offset, relative to the line start, of field k = CHROM..FORMAT (0..8)
+ * and of the first sample column (9) so the host can build result records without re-scanning;
+ * gt rows in VCF column order (strict != 0: genotypes get_alleles() would not report as
+ * ALLELES_OK become 0xFF); is_x per line (assoc.c:94 rule); status per line: 0 ok, 1 fewer
+ * than 10 columns, 2 FORMAT has no GT (row all missing), 3 fewer sample columns than n_samples.
+ * More than max_lines lines: the first max_lines are parsed and *n_lines reports the true count. */
+int  hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int n_samples, int strict,
+                       int max_lines, int *d_n_lines, uint64_t *d_line_off, uint32_t *d_field_off,
+                       uint8_t *d_gt, size_t pitch, uint8_t *d_is_x, int32_t *d_status, void *stream);
+/* host buffers in and out (synchronous) */
+int  hpgv_tokenize(hpgv_ctx *ctx, const char *text, size_t text_bytes, int n_samples, int strict,
+                   int max_lines, int *n_lines, uint64_t *line_off, uint32_t *field_off,
+                   uint8_t *gt, size_t pitch, uint8_t *is_x, int32_t *status);
+
 /* streaming-read ceiling probe: reads `bytes` from d_buf with the scan's load
  * shape and no arithmetic; returns the kernel time in ms (diagnostic) */
 int  hpgv_read_probe(hpgv_ctx *ctx, const uint8_t *d_buf, size_t bytes, int iters, float *ms);

@@ -437,6 +437,50 @@ void orc_sample_missing(const uint8_t *gt, size_t pitch, int n_variants, int n_s
 }
 
 /* ------------------------------------------------------------------------
+ * Text staging oracle
+ * ---------------------------------------------------------------------- */
+int orc_tokenize(const char *text, size_t bytes, int n_samples, int strict, int max_lines,
+                 uint8_t *gt, size_t pitch, uint8_t *is_x, int32_t *status) {
+    int line = 0;
+    size_t ls = 0;
+    while (ls < bytes) {
+        const char *nl = (const char *)memchr(text + ls, '\n', bytes - ls);
+        size_t le = nl ? (size_t)(nl - text) : bytes;
+        if (line < max_lines) {
+            /* split the line on TABs */
+            char *buf = (char *)malloc(le - ls + 1);
+            memcpy(buf, text + ls, le - ls);
+            buf[le - ls] = 0;
+            int nf = 1;
+            for (size_t i = 0; i < le - ls; i++) if (buf[i] == '\t') nf++;
+            char **f = (char **)malloc(sizeof(char *) * (size_t)nf);
+            int k = 0;
+            f[k++] = buf;
+            for (size_t i = 0; i < le - ls; i++) if (buf[i] == '\t') { buf[i] = 0; f[k++] = buf + i + 1; }
+            uint8_t *row = gt + (size_t)line * pitch;
+            int st = 0;
+            if (is_x) is_x[line] = (uint8_t)orc_chrom_is_x(f[0], (int)strlen(f[0]));
+            if (nf < 10) { st = 1; for (int j = 0; j < n_samples; j++) row[j] = 0xFF; }
+            else {
+                int gtpos = orc_get_field_position_in_format("GT", f[8]);
+                if (gtpos < 0) { st = 2; for (int j = 0; j < n_samples; j++) row[j] = 0xFF; }
+                else {
+                    int have = nf - 9;
+                    for (int j = 0; j < n_samples; j++)
+                        row[j] = j < have ? orc_encode_sample(f[9 + j], gtpos, strict) : 0xFF;
+                    if (have < n_samples) st = 3;
+                }
+            }
+            if (status) status[line] = st;
+            free(f); free(buf);
+        }
+        line++;
+        ls = le + 1;
+    }
+    return line;
+}
+
+/* ------------------------------------------------------------------------
  * Synthetic cohort.  Integer-only per genotype so the device
  * generator reproduces it bit for bit.
  * ---------------------------------------------------------------------- */

@@ -123,6 +123,12 @@ void orc_hwe(int n_AA, int n_Aa, int n_aa, double *chi2, double *p);
  * variants in which the genotype has a missing allele; accumulated into missing[] */
 void orc_sample_missing(const uint8_t *gt, size_t pitch, int n_variants, int n_samples, int32_t *missing);
 
+/* ---- text staging: VCF data lines -> HPGV8, the way the reference's parser + assoc.c:45-56
+ *      would see them (TAB split, GT located in FORMAT, get_alleles per sample).  Returns the
+ *      number of lines; rows beyond max_lines are not written.  status as include/hpgv.h. */
+int orc_tokenize(const char *text, size_t bytes, int n_samples, int strict, int max_lines,
+                 uint8_t *gt, size_t pitch, uint8_t *is_x, int32_t *status);
+
 /* ---- synthetic cohort (bit-reproducible on device) */
 #define ORC_SYNTH_SEED 0x4850475631ULL
 uint64_t orc_splitmix64(uint64_t x);

@@ -90,6 +90,8 @@ def lib():
     L.orc_variant_stats.argtypes = [p_u8, C.c_int, C.c_int, C.POINTER(VariantStats)]
     L.orc_sample_missing.restype = None
     L.orc_sample_missing.argtypes = [p_u8, C.c_size_t, C.c_int, C.c_int, p_i32]
+    L.orc_tokenize.restype = C.c_int
+    L.orc_tokenize.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, p_u8, C.c_size_t, p_u8, p_i32]
     L.orc_hwe.restype = None
     L.orc_hwe.argtypes = [C.c_int] * 3 + [p_f64, p_f64]
     L.orc_splitmix64.restype = C.c_uint64
@@ -204,6 +206,21 @@ def sample_missing(gt):
     out = np.zeros(gt.shape[1], dtype=np.int32)
     lib().orc_sample_missing(_p(gt, C.c_uint8), gt.shape[1], gt.shape[0], gt.shape[1], _p(out, C.c_int32))
     return out
+
+
+def tokenize(text, n_samples, strict=True, max_lines=None):
+    if isinstance(text, str):
+        text = text.encode()
+    if max_lines is None:
+        max_lines = text.count(b"\n") + 1
+    pitch = max(n_samples, 1)
+    gt = np.zeros((max_lines, pitch), np.uint8)
+    is_x = np.zeros(max_lines, np.uint8)
+    status = np.zeros(max_lines, np.int32)
+    n = lib().orc_tokenize(text, len(text), n_samples, 1 if strict else 0, max_lines, _p(gt, C.c_uint8), pitch,
+                           _p(is_x, C.c_uint8), _p(status, C.c_int32))
+    k = min(n, max_lines)
+    return dict(n_lines=n, gt=gt[:k, :n_samples], is_x=is_x[:k], status=status[:k])
 
 
 def hwe(n_AA, n_Aa, n_aa):

@@ -1,0 +1,95 @@
+"""GPU text staging (VCF data lines -> HPGV8 on the device)
+against the oracle's TAB-split + get_alleles tokenizer."""
+import numpy as np
+import pytest
+
+from helpers import QUIRK_GTS, hpgv
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+WEIRD = QUIRK_GTS + ["", "0/1:12:99", ".:3", "1/", "/1", "0|0:.", "10/2", "a/1", "-1/0", "+1/1", " 1/0", "0/1/2", "2",
+                     "./.:0,0", "0/0:1,2:3"]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = hpgv.Engine(0)
+    yield e
+    e.close()
+
+
+def _line(rng, n_samples, fmt, chrom, info_len=8, gts=None, n_cols=None):
+    k = fmt.split(":").index("GT") if "GT" in fmt.split(":") else 0
+    n_cols = n_samples if n_cols is None else n_cols
+    cols = []
+    for j in range(n_cols):
+        g = gts[j] if gts is not None else (WEIRD[int(rng.integers(0, len(WEIRD)))] if rng.random() < 0.3
+                                            else ["0/0", "0/1", "1/1", "1|0"][int(rng.integers(0, 4))])
+        parts = ["7"] * k + [g]
+        cols.append(":".join(parts))
+    info = "I=" + "x" * info_len
+    return "\t".join([chrom, "12345", "rs1", "A", "C,T", "50", "PASS", info, fmt] + cols)
+
+
+def _check(eng, text, n_samples, strict, max_lines=None):
+    got = eng.tokenize(text, n_samples, strict, max_lines)
+    exp = orc.tokenize(text, n_samples, strict, max_lines)
+    assert got["n_lines"] == exp["n_lines"]
+    assert np.array_equal(got["status"], exp["status"]), (got["status"], exp["status"])
+    assert np.array_equal(got["is_x"], exp["is_x"])
+    assert np.array_equal(got["gt"], exp["gt"]), np.argwhere(got["gt"] != exp["gt"])[:5]
+    return got
+
+
+@pytest.mark.parametrize("n_samples", [0, 1, 3, 64, 257, 1500])
+def test_random_lines_all_shapes(eng, n_samples):
+    rng = np.random.default_rng(n_samples + 1)
+    lines = []
+    for i in range(40):
+        fmt = ["GT", "GT:DP", "DP:GT", "DP:GQ:GT:PL", "DP:GQ"][i % 5]
+        chrom = ["1", "X", "22", "XY", "chrX", "Y"][i % 6]
+        info_len = [3, 100, 5000, 9000][i % 4]                  # INFO longer than one 4 KiB tile
+        n_cols = n_samples if i % 7 else max(0, n_samples - 2)    # some lines lack trailing samples
+        if i % 11 == 0:
+            n_cols = n_samples + 3                                # some have extra columns
+        lines.append(_line(rng, n_samples, fmt, chrom, info_len, n_cols=n_cols))
+    lines.insert(5, "")                                           # an empty line
+    lines.insert(9, "1\t5\trs\tA\tC")                            # a truncated line
+    for strict in (True, False):
+        _check(eng, "\n".join(lines) + "\n", n_samples, strict)
+        _check(eng, "\n".join(lines), n_samples, strict)          # last line without newline
+        _check(eng, "\r\n".join(lines) + "\r\n", n_samples, strict)   # CRLF files
+
+
+def test_empty_and_capacity(eng):
+    assert eng.tokenize(b"", 5)["n_lines"] == 0
+    rng = np.random.default_rng(3)
+    text = "\n".join(_line(rng, 10, "GT", "1") for _ in range(20)) + "\n"
+    got = _check(eng, text, 10, True, max_lines=7)               # capacity smaller than the text
+    assert got["n_lines"] == 20 and got["gt"].shape[0] == 7
+    # offsets let the host cut the fixed columns without re-scanning
+    full = eng.tokenize(text, 10)
+    for i in range(20):
+        ls = int(full["line_off"][i]); fo = full["field_off"][i]
+        assert text[ls + fo[0]: ls + fo[1] - 1] == "1" and text[ls + fo[8]: ls + fo[9] - 1] == "GT"
+        assert text[ls + fo[2]: ls + fo[3] - 1] == "rs1"
+
+
+def test_large_batch_feeds_the_assoc_path(eng):
+    # 1500 lines x 4000 samples of plain diploid calls: text -> HPGV8 on the GPU -> assoc vs oracle on the
+    # oracle-tokenized matrix (the whole "text batch in, statistics out" chain)
+    rng = np.random.default_rng(8)
+    n_samples, n_lines = 4000, 1500
+    codes = np.array(["0/0", "0/1", "1/0", "1/1", "./."])
+    idx = rng.choice(5, size=(n_lines, n_samples), p=[0.5, 0.2, 0.1, 0.15, 0.05])
+    body = ["\t".join(codes[r]) for r in idx]
+    text = "\n".join("%s\t%d\trs%d\tA\tG\t.\tPASS\t.\tGT\t%s" % (["1", "X"][i % 2], i, i, body[i]) for i in range(n_lines)) + "\n"
+    got = _check(eng, text, n_samples, True)
+    cond = (np.arange(n_samples) % 2).astype(np.uint8)
+    e = hpgv.Engine(0)
+    e.set_cohort(cond)
+    res = e.assoc(hpgv.TASK_CHISQ, got["gt"], got["is_x"])
+    A1, A2, U1, U2 = orc.assoc_counts(orc.tokenize(text, n_samples)["gt"], cond, got["is_x"])
+    assert np.array_equal(res["A1"], A1) and np.array_equal(res["U2"], U2)
+    e.close()
