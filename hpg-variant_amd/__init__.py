@@ -32,7 +32,7 @@ SYMBOLS = [
     "hpgv_assoc_scan_dev", "hpgv_assoc_chisq_dev", "hpgv_assoc_fisher_dev",
     "hpgv_tdt_scan_dev", "hpgv_tdt_stats_dev", "hpgv_stats_scan_dev", "hpgv_stats_hwe_dev",
     "hpgv_sample_missing_dev", "hpgv_genotype_table_dev",
-    "hpgv_tokenize_dev", "hpgv_tokenize",
+    "hpgv_tokenize_dev", "hpgv_tokenize", "hpgv_assoc_text", "hpgv_tdt_text",
     "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_read_probe",
 ]
 
@@ -100,6 +100,8 @@ def load():
     L.hpgv_genotype_table_dev.argtypes = [vp, vp, sz, i32, vp, i32, vp, vp]
     L.hpgv_tokenize_dev.argtypes = [vp, vp, sz, i32, i32, i32, vp, vp, vp, vp, sz, vp, vp, vp]
     L.hpgv_tokenize.argtypes = [vp, C.c_char_p, sz, i32, i32, i32, C.POINTER(i32), vp, vp, vp, sz, vp, vp]
+    L.hpgv_assoc_text.argtypes = [vp, i32, C.c_char_p, sz, i32, C.POINTER(i32), vp, vp, vp] + [vp] * 7
+    L.hpgv_tdt_text.argtypes = [vp, C.c_char_p, sz, i32, C.POINTER(i32), vp, vp, vp] + [vp] * 5
     L.hpgv_read_probe.argtypes = [vp, vp, sz, i32, C.POINTER(C.c_float)]
     _lib = L
     return L
@@ -268,6 +270,38 @@ class Engine:
         k = min(nl.value, max_lines)
         return dict(n_lines=nl.value, gt=gt[:k, :n_samples], is_x=is_x[:k], status=status[:k], line_off=line_off[:k + 1],
                     field_off=field_off[:k])
+
+    def assoc_text(self, task, text, max_lines=None):
+        if isinstance(text, str):
+            text = text.encode()
+        if max_lines is None:
+            max_lines = text.count(b"\n") + 1
+        m = max(max_lines, 1)
+        A1, A2, U1, U2 = (np.zeros(m, np.int32) for _ in range(4))
+        odds, chisq, p = (np.zeros(m, np.float64) for _ in range(3))
+        status = np.zeros(m, np.int32)
+        nl = C.c_int(0)
+        self._chk(self.L.hpgv_assoc_text(self.h, task, text, len(text), max_lines, C.byref(nl), None, None, _ptr(status),
+                                         _ptr(A1), _ptr(A2), _ptr(U1), _ptr(U2), _ptr(odds),
+                                         _ptr(chisq) if task == TASK_CHISQ else None, _ptr(p)))
+        k = min(nl.value, max_lines)
+        return dict(n_lines=nl.value, status=status[:k], A1=A1[:k], A2=A2[:k], U1=U1[:k], U2=U2[:k], odds=odds[:k],
+                    chisq=chisq[:k] if task == TASK_CHISQ else None, p=p[:k])
+
+    def tdt_text(self, text, max_lines=None):
+        if isinstance(text, str):
+            text = text.encode()
+        if max_lines is None:
+            max_lines = text.count(b"\n") + 1
+        m = max(max_lines, 1)
+        t1, t2 = np.zeros(m, np.int32), np.zeros(m, np.int32)
+        odds, chisq, p = (np.zeros(m, np.float64) for _ in range(3))
+        status = np.zeros(m, np.int32)
+        nl = C.c_int(0)
+        self._chk(self.L.hpgv_tdt_text(self.h, text, len(text), max_lines, C.byref(nl), None, None, _ptr(status),
+                                       _ptr(t1), _ptr(t2), _ptr(odds), _ptr(chisq), _ptr(p)))
+        k = min(nl.value, max_lines)
+        return dict(n_lines=nl.value, status=status[:k], t1=t1[:k], t2=t2[:k], odds=odds[:k], chisq=chisq[:k], p=p[:k])
 
     # ---- device-resident path (raw pointers; ints or c_void_p) ---------------
     def synth(self, which, v0, n_variants, d_dst, stream=None):

@@ -973,6 +973,115 @@ int hpgv_tokenize(hpgv_ctx *ctx, const char *text, size_t text_bytes, int n_samp
     return HPGV_OK;
 }
 
+// shared front half of the *_text entry points: text -> device, tokenize, lay out.
+// slot buffers: 0 text, 1 laid-out gt, 2 is_x, 3 tallies, 4 doubles, 5 SoA ints / status,
+// 6 {n_lines, line_off..., field_off...}, 7 raw gt (VCF order)
+static int text_front(hpgv_ctx *ctx, Slot *s, int which, const Layout &L, const char *text, size_t text_bytes,
+                      int max_lines, int *n_lines, uint64_t *line_off, uint32_t *field_off, int32_t *status,
+                      int *nl_out) {
+    int rc;
+    const size_t ml = (size_t)max_lines;
+    const size_t raw_pitch = (size_t)(L.n_samples > 0 ? (L.n_samples + 15) / 16 * 16 : 16);
+    const size_t off_lines = 16, off_fields = off_lines + (ml + 2) * sizeof(uint64_t);
+    if ((rc = ensure(ctx, s, 0, text_bytes + 16))) return rc;
+    if ((rc = ensure(ctx, s, 7, ml * raw_pitch + 16))) return rc;
+    if ((rc = ensure(ctx, s, 1, ml * L.pitch + 16))) return rc;
+    if ((rc = ensure(ctx, s, 2, ml + 16))) return rc;
+    if ((rc = ensure(ctx, s, 5, ml * 4 * sizeof(int32_t) + 16))) return rc;
+    if ((rc = ensure(ctx, s, 6, off_fields + ml * 10 * sizeof(uint32_t) + 16))) return rc;
+    char *meta = (char *)s->buf[6];
+    if (text_bytes) HIPCHK(ctx, hipMemcpyAsync(s->buf[0], text, text_bytes, hipMemcpyHostToDevice, s->stream));
+    if ((rc = hpgv_tokenize_dev(ctx, (const char *)s->buf[0], text_bytes, L.n_samples, which == HPGV_LAYOUT_STATS ? 0 : 1,
+                                max_lines, (int *)meta, (uint64_t *)(meta + off_lines), (uint32_t *)(meta + off_fields),
+                                (uint8_t *)s->buf[7], raw_pitch, (uint8_t *)s->buf[2], (int32_t *)s->buf[5], s->stream))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(n_lines, meta, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    const int nl = *n_lines < max_lines ? *n_lines : max_lines;
+    *nl_out = nl;
+    if (nl == 0) return HPGV_OK;
+    if (status) HIPCHK(ctx, hipMemcpyAsync(status, s->buf[5], (size_t)nl * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    if (line_off) HIPCHK(ctx, hipMemcpyAsync(line_off, meta + off_lines, ((size_t)nl + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
+    if (field_off) HIPCHK(ctx, hipMemcpyAsync(field_off, meta + off_fields, (size_t)nl * 10 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    return hpgv_layout_dev(ctx, which, (const uint8_t *)s->buf[7], raw_pitch, nl, (uint8_t *)s->buf[1], s->stream);
+}
+
+int hpgv_assoc_text(hpgv_ctx *ctx, int task, const char *text, size_t text_bytes, int max_lines, int *n_lines,
+                    uint64_t *line_off, uint32_t *field_off, int32_t *status, int32_t *A1, int32_t *A2,
+                    int32_t *U1, int32_t *U2, double *odds, double *chisq, double *p) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (task != HPGV_TASK_CHISQ && task != HPGV_TASK_FISHER) return fail(ctx, HPGV_ERR_INVALID, "task must be CHISQ or FISHER");
+    if (!ctx->assoc.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_cohort has not been called");
+    if (!n_lines || max_lines < 0 || (text_bytes > 0 && !text) ||
+        (max_lines > 0 && (!A1 || !A2 || !U1 || !U2 || !odds || !p || (task == HPGV_TASK_CHISQ && !chisq))))
+        return fail(ctx, HPGV_ERR_INVALID, "bad assoc_text arguments");
+    *n_lines = 0;
+    if (max_lines == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    SlotLease lease(ctx);
+    int rc = acquire_slot(ctx, &lease.s);
+    if (rc) return rc;
+    Slot *s = lease.s;
+    int nl = 0;
+    if ((rc = text_front(ctx, s, HPGV_LAYOUT_ASSOC, ctx->assoc, text, text_bytes, max_lines, n_lines, line_off, field_off, status, &nl))) return rc;
+    if (nl == 0) { HIPCHK(ctx, hipStreamSynchronize(s->stream)); return HPGV_OK; }
+    const size_t n = (size_t)nl;
+    if ((rc = ensure(ctx, s, 3, n * 16))) return rc;
+    if ((rc = ensure(ctx, s, 4, n * 3 * sizeof(double)))) return rc;
+    int32_t *d_counts = (int32_t *)s->buf[3];
+    double *d_odds = (double *)s->buf[4], *d_chisq = d_odds + n, *d_p = d_odds + 2 * n;
+    int32_t *d_soa = (int32_t *)s->buf[5];        // status has been copied out (same stream, ordered)
+    if ((rc = hpgv_assoc_scan_dev(ctx, (const uint8_t *)s->buf[1], nl, (const uint8_t *)s->buf[2], d_counts, s->stream))) return rc;
+    if (task == HPGV_TASK_CHISQ) rc = hpgv_assoc_chisq_dev(ctx, d_counts, nl, d_odds, d_chisq, d_p, s->stream);
+    else rc = hpgv_assoc_fisher_dev(ctx, d_counts, nl, d_odds, d_p, s->stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(hpgv::k_counts_to_soa, dim3((nl + 255) / 256), dim3(256), 0, s->stream,
+                       (const int4 *)d_counts, nl, d_soa, d_soa + n, d_soa + 2 * n, d_soa + 3 * n);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(A1, d_soa, n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(A2, d_soa + n, n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(U1, d_soa + 2 * n, n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(U2, d_soa + 3 * n, n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(odds, d_odds, n * 8, hipMemcpyDeviceToHost, s->stream));
+    if (task == HPGV_TASK_CHISQ) HIPCHK(ctx, hipMemcpyAsync(chisq, d_chisq, n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(p, d_p, n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    return HPGV_OK;
+}
+
+int hpgv_tdt_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_lines, int *n_lines,
+                  uint64_t *line_off, uint32_t *field_off, int32_t *status, int32_t *t1, int32_t *t2,
+                  double *odds, double *chisq, double *p) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->tdt.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_families has not been called");
+    if (!n_lines || max_lines < 0 || (text_bytes > 0 && !text) || (max_lines > 0 && (!t1 || !t2 || !odds || !chisq || !p)))
+        return fail(ctx, HPGV_ERR_INVALID, "bad tdt_text arguments");
+    *n_lines = 0;
+    if (max_lines == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    SlotLease lease(ctx);
+    int rc = acquire_slot(ctx, &lease.s);
+    if (rc) return rc;
+    Slot *s = lease.s;
+    int nl = 0;
+    if ((rc = text_front(ctx, s, HPGV_LAYOUT_TDT, ctx->tdt, text, text_bytes, max_lines, n_lines, line_off, field_off, status, &nl))) return rc;
+    if (nl == 0) { HIPCHK(ctx, hipStreamSynchronize(s->stream)); return HPGV_OK; }
+    const size_t n = (size_t)nl;
+    if ((rc = ensure(ctx, s, 3, n * 8))) return rc;
+    if ((rc = ensure(ctx, s, 4, n * 3 * sizeof(double)))) return rc;
+    int32_t *d_tu = (int32_t *)s->buf[3];
+    double *d_odds = (double *)s->buf[4], *d_chisq = d_odds + n, *d_p = d_odds + 2 * n;
+    if ((rc = hpgv_tdt_scan_dev(ctx, (const uint8_t *)s->buf[1], nl, (const uint8_t *)s->buf[2], d_tu, s->stream))) return rc;
+    if ((rc = hpgv_tdt_stats_dev(ctx, d_tu, nl, d_odds, d_chisq, d_p, s->stream))) return rc;
+    std::vector<int32_t> tu(2 * n);
+    HIPCHK(ctx, hipMemcpyAsync(tu.data(), d_tu, n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(odds, d_odds, n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(chisq, d_chisq, n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(p, d_p, n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    for (size_t i = 0; i < n; ++i) { t1[i] = tu[2 * i]; t2[i] = tu[2 * i + 1]; }
+    return HPGV_OK;
+}
+
 int hpgv_read_probe(hpgv_ctx *ctx, const uint8_t *d_buf, size_t bytes, int iters, float *ms) {
     if (!ctx || !d_buf || !ms || iters <= 0 || ((uintptr_t)d_buf & 15)) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);

@@ -205,6 +205,18 @@ int  hpgv_tokenize(hpgv_ctx *ctx, const char *text, size_t text_bytes, int n_sam
                    int max_lines, int *n_lines, uint64_t *line_off, uint32_t *field_off,
                    uint8_t *gt, size_t pitch, uint8_t *is_x, int32_t *status);
 
+/* text batch in, statistics out: tokenize + layout + scan + statistics without the genotype
+ * matrix ever crossing PCIe.  task as hpgv_assoc; outputs sized max_lines; *n_lines = lines in
+ * the text (results are filled for min(*n_lines, max_lines)); line_off / field_off / status as
+ * hpgv_tokenize (may be NULL).  The cohort (hpgv_set_cohort / hpgv_set_families) fixes n_samples. */
+int  hpgv_assoc_text(hpgv_ctx *ctx, int task, const char *text, size_t text_bytes, int max_lines, int *n_lines,
+                     uint64_t *line_off, uint32_t *field_off, int32_t *status,
+                     int32_t *A1, int32_t *A2, int32_t *U1, int32_t *U2,
+                     double *odds, double *chisq, double *p);
+int  hpgv_tdt_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_lines, int *n_lines,
+                   uint64_t *line_off, uint32_t *field_off, int32_t *status,
+                   int32_t *t1, int32_t *t2, double *odds, double *chisq, double *p);
+
 /* streaming-read ceiling probe: reads `bytes` from d_buf with the scan's load
  * shape and no arithmetic; returns the kernel time in ms (diagnostic) */
 int  hpgv_read_probe(hpgv_ctx *ctx, const uint8_t *d_buf, size_t bytes, int iters, float *ms);

@@ -93,3 +93,33 @@ def test_large_batch_feeds_the_assoc_path(eng):
     A1, A2, U1, U2 = orc.assoc_counts(orc.tokenize(text, n_samples)["gt"], cond, got["is_x"])
     assert np.array_equal(res["A1"], A1) and np.array_equal(res["U2"], U2)
     e.close()
+
+
+def test_text_in_statistics_out(eng):
+    # hpgv_assoc_text / hpgv_tdt_text: tokenize + layout + scan + statistics in one call
+    from helpers import check_assoc, oracle_assoc, assert_close, make_families
+    rng = np.random.default_rng(21)
+    n_samples = 900
+    lines = [_line(rng, n_samples, ["GT", "GT:DP", "DP:GT"][i % 3], ["1", "X", "7"][i % 3], [5, 4500][i % 2]) for i in range(120)]
+    text = "\n".join(lines) + "\n"
+    tok = orc.tokenize(text, n_samples, True)
+    cond = rng.choice([0, 1, 2], size=n_samples).astype(np.uint8)
+    e = hpgv.Engine(0)
+    e.set_cohort(cond)
+    lf = orc.logfact(n_samples * 10)
+    e.set_logfact(lf)
+    for task, otask in ((hpgv.TASK_CHISQ, orc.TASK_CHISQ), (hpgv.TASK_FISHER, orc.TASK_FISHER)):
+        res = e.assoc_text(task, text)
+        assert res["n_lines"] == 120 and np.array_equal(res["status"], tok["status"])
+        check_assoc(res, oracle_assoc(otask, tok["gt"], cond, tok["is_x"], lf), task)
+    short = e.assoc_text(hpgv.TASK_CHISQ, text, max_lines=50)
+    assert short["n_lines"] == 120 and len(short["A1"]) == 50
+    fam = make_families(rng, n_samples, 200, 3)
+    e.set_families(n_samples, *fam)
+    res = e.tdt_text(text)
+    t1, t2 = orc.tdt_counts(tok["gt"], *fam, chrom_is_x=tok["is_x"])
+    assert np.array_equal(res["t1"], t1) and np.array_equal(res["t2"], t2)
+    odds, chisq, p = orc.tdt_stats(t1, t2)
+    assert_close(res["p"], p, "tdt p"); assert_close(res["chisq"], chisq, "tdt chisq")
+    assert e.assoc_text(hpgv.TASK_CHISQ, b"")["n_lines"] == 0
+    e.close()
