@@ -46,6 +46,7 @@ struct hpgv_ctx {
     std::mutex mu;
     // options
     long row_align = 16;
+    long row_pad = 0;          // extra bytes (multiple of 16) appended to every row; pitch exploration knob
     long vpw = 2;
     long nontemporal = 1;
     long profile = 0;
@@ -253,6 +254,11 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
         if (ctx->assoc.set || ctx->tdt.set || ctx->stats.set)
             return fail(ctx, HPGV_ERR_STATE, "row_align must be set before the cohort");
         ctx->row_align = value;
+    } else if (!strcmp(key, "row_pad")) {
+        if (value < 0 || value % 16 || value > 65536) return fail(ctx, HPGV_ERR_INVALID, "row_pad must be a multiple of 16 in [0, 65536]");
+        if (ctx->assoc.set || ctx->tdt.set || ctx->stats.set)
+            return fail(ctx, HPGV_ERR_STATE, "row_pad must be set before the cohort");
+        ctx->row_pad = value;
     } else if (!strcmp(key, "variants_per_wave")) {
         if (value < 1 || value > 1024) return fail(ctx, HPGV_ERR_INVALID, "variants_per_wave out of range");
         ctx->vpw = value;
@@ -292,7 +298,7 @@ int hpgv_set_cohort(hpgv_ctx *ctx, const uint8_t *condition, int n_samples) {
         else if (condition[j] == HPGV_COND_UNAFFECTED) nU++;
     }
     size_t segA = round_up((size_t)nA, 16), segU = round_up((size_t)nU, 16);
-    size_t pitch = round_up(segA + segU, (size_t)ctx->row_align);
+    size_t pitch = round_up(segA + segU, (size_t)ctx->row_align) + (size_t)ctx->row_pad;
     if (pitch == 0) pitch = (size_t)ctx->row_align;
     if (!pitch_supported(pitch)) return fail(ctx, HPGV_ERR_UNSUPPORTED, "cohort of %d samples exceeds the row-length limit", n_samples);
     Layout &L = ctx->assoc;

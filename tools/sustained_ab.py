@@ -21,6 +21,7 @@ ap.add_argument("--samples", type=int, default=10_000)
 ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--k", type=int, default=20)
 ap.add_argument("--aligns", type=str, default="16,128")
+ap.add_argument("--pads", type=str, default="0")
 ap.add_argument("--grid", type=str, default='{"scan_unroll":[4,8],"variants_per_wave":[2,4]}')
 ap.add_argument("--with-chisq", action="store_true")
 a = ap.parse_args()
@@ -32,9 +33,10 @@ dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream()
 sp = stream.cuda_stream
 arms = []
-for al in [int(x) for x in a.aligns.split(",")]:
+for al, pad in [(int(x), int(y)) for x in a.aligns.split(",") for y in a.pads.split(",")]:
     e = hpgv.Engine(0)
     e.set_option("row_align", al)
+    e.set_option("row_pad", pad)
     cond = (np.arange(N) % 2).astype(np.uint8)
     _, _, pitch = e.set_cohort(cond)
     gt = torch.empty(V * pitch, dtype=torch.uint8, device=dev)
