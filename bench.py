@@ -47,9 +47,10 @@ def parse_args():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--variants", type=int, default=0, help="override variants per GPU")
     ap.add_argument("--samples", type=int, default=0, help="override samples")
-    ap.add_argument("--gather-chunks", type=int, default=8,
-                    help="N>1: the shard is scanned in this many variant blocks so that the result "
-                         "gather of block i overlaps the scan of block i+1")
+    ap.add_argument("--gather-chunks", type=int, default=1,
+                    help="N>1: the shard is scanned in this many variant blocks, each followed by its own "
+                         "asynchronous result gather; with the default 1 the whole step's gather overlaps "
+                         "the next step's scan (result blocks are double-buffered)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the scan kernel with HIP events on every n-th timed step (an event pair costs "
                          "tens of microseconds of queue bubbles, so not every step carries one)")
