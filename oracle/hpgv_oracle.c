@@ -220,6 +220,9 @@ double orc_fisher_two_sided(int a, int b, int c, int d, const double *lf) {
 void orc_assoc_packed(const uint8_t *gt, size_t pitch, int n_variants, int n_samples,
                       const uint8_t *condition, const uint8_t *chrom_is_x,
                       int32_t *A1, int32_t *A2, int32_t *U1, int32_t *U2) {
+    /* variants are independent (assoc.c:42-43 resets the counters per variant); OpenMP only
+     * spreads them over cores when called from serial code (the baseline driver is already parallel) */
+    #pragma omp parallel for schedule(static) if (n_variants > 4096 && !omp_in_parallel())
     for (int i = 0; i < n_variants; i++) {               /* assoc.c:38 */
         const uint8_t *row = gt + (size_t)i * pitch;
         int a1c = 0, a2c = 0, u1c = 0, u2c = 0;           /* assoc.c:42-43 */
@@ -319,6 +322,7 @@ void orc_tdt_packed(const uint8_t *gt, size_t pitch, int n_variants,
                     int n_families, const int32_t *father_col, const int32_t *mother_col,
                     const int32_t *child_off, const int32_t *child_col, const uint8_t *child_sex,
                     int32_t *t1_out, int32_t *t2_out) {
+    #pragma omp parallel for schedule(static) if (n_variants > 1024 && !omp_in_parallel())
     for (int v = 0; v < n_variants; v++) {                          /* tdt.c:41 */
         const uint8_t *row = gt + (size_t)v * pitch;
         const char *chrom = (chrom_is_x && chrom_is_x[v]) ? "X" : "1";

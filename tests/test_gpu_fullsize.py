@@ -124,3 +124,74 @@ def test_stats_full_size():
                                                               vs.alleles_count[0], vs.alleles_count[1])
         assert_close([hw[0][v]], [vs.hw_chi2], "hwe chi2"); assert_close([hw[1][v]], [vs.hw_p], "hwe p")
     e.close()
+
+
+def _layout_conditions(e, cond, n_samples):
+    """condition vector per ROW POSITION of the assoc layout (pads are 'other')."""
+    nA, nU, pitch = e.assoc_layout()
+    segA = (nA + 15) // 16 * 16
+    pos = np.full(pitch, orc.COND_OTHER, np.uint8)
+    pos[:nA] = orc.AFFECTED
+    pos[segA: segA + nU] = orc.UNAFFECTED
+    return pos, pitch
+
+
+def test_assoc_every_variant_against_the_oracle_c2():
+    """SURVEY 8d parity protocol for C2: EVERY variant of the 1M x 10k cohort.  The device matrix is
+    copied back in slabs and scanned by the (OpenMP) oracle, so the comparison also covers the
+    on-device generator at full size."""
+    V, N = 1_000_000, 10_000
+    e = hpgv.Engine(0)
+    cond = (np.arange(N) % 2).astype(np.uint8)
+    e.set_cohort(cond)
+    pos_cond, pitch = _layout_conditions(e, cond, N)
+    d_gt, d_counts, d_st = e.alloc(V * pitch), e.alloc(V * 16), e.alloc(V * 24)
+    e.synth(hpgv.LAYOUT_ASSOC, 0, V, d_gt)
+    e.assoc_scan(d_gt, V, d_counts)
+    b = d_st.value
+    e.assoc_chisq(d_counts, V, b, b + 8 * V, b + 16 * V)
+    e.sync()
+    counts = e.d2h(d_counts, (V, 4), np.int32)
+    st = e.d2h(d_st, (3, V), np.float64)
+    slab = 50_000
+    for lo in range(0, V, slab):
+        n = min(slab, V - lo)
+        rows = e.d2h(d_gt.value + lo * pitch, (n, pitch), np.uint8)
+        A1, A2, U1, U2 = orc.assoc_counts(rows, pos_cond)
+        assert np.array_equal(counts[lo: lo + n], np.stack([A1, A2, U1, U2], 1)), lo
+        odds, chisq, p = orc.assoc_stats(orc.TASK_CHISQ, A1, A2, U1, U2)
+        assert_close(st[0][lo: lo + n], odds, "odds")
+        assert_close(st[1][lo: lo + n], chisq, "chisq")
+        assert_close(st[2][lo: lo + n], p, "p")
+    # the slab copied back is what the oracle generator produces (first and last slab, column order undone)
+    nA, nU, _ = e.assoc_layout()
+    segA = (nA + 15) // 16 * 16
+    for lo in (0, V - 2000):
+        rows = e.d2h(d_gt.value + lo * pitch, (2000, pitch), np.uint8)
+        ref = orc.synth_matrix(lo, 2000, N, N)
+        assert np.array_equal(rows[:, :nA], ref[:, cond == 1]) and np.array_equal(rows[:, segA: segA + nU], ref[:, cond == 0])
+    e.close()
+
+
+def test_tdt_every_variant_against_the_oracle_c4():
+    """C4 (2M SNP x 5k trios), every variant: raw HPGV8 slabs are generated on the device in VCF column
+    order, laid out (recoded) and scanned there, and the same raw slabs go through the oracle."""
+    V, n_tr = 2_000_000, 5000
+    N = 3 * n_tr
+    e = hpgv.Engine(0)
+    k = np.arange(n_tr)
+    fam = (3 * k, 3 * k + 1, np.arange(n_tr + 1), 3 * k + 2, (k % 2).astype(np.uint8))
+    _, _, pitch = e.set_families(N, *fam)
+    slab = 100_000
+    raw_pitch = (N + 15) // 16 * 16
+    d_raw, d_lay, d_tu = e.alloc(slab * raw_pitch), e.alloc(slab * pitch), e.alloc(slab * 8)
+    for lo in range(0, V, slab):
+        e.synth_raw(lo, slab, N, raw_pitch, d_raw)
+        e.layout(hpgv.LAYOUT_TDT, d_raw, raw_pitch, slab, d_lay)
+        e.tdt_scan(d_lay, slab, d_tu)
+        e.sync()
+        tu = e.d2h(d_tu, (slab, 2), np.int32)
+        raw = e.d2h(d_raw, (slab, raw_pitch), np.uint8)
+        t1, t2 = orc.tdt_counts(raw, *fam)
+        assert np.array_equal(tu[:, 0], t1) and np.array_equal(tu[:, 1], t2), lo
+    e.close()
