@@ -1,0 +1,135 @@
+/*
+ * host_cpu_check.c -- CPU-only checks of the host mirror's own logic (no engine
+ * call): containers, the thread-safe result list, and GT-text staging.  Built
+ * with -fsanitize=address,undefined by tests/test_host_logic_cpu.py.
+ *
+ *   host_cpu_check containers         self-checking, prints PASS/FAIL lines
+ *   host_cpu_check stage <file>       file: "N V" then V lines "chrom format s1..sN";
+ *                                     prints per line: is_x then the N code bytes (hex), strict and lax
+ */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "hpgv_host.h"
+
+static int failures = 0;
+#define CHECK(c, m) do { if (!(c)) { printf("FAIL %s\n", m); failures++; } else printf("PASS %s\n", m); } while (0)
+
+static void *producer(void *arg) {
+    list_t *l = (list_t *)arg;
+    for (int i = 0; i < 5000; i++) {
+        int *v = (int *)malloc(sizeof(int));
+        *v = i;
+        list_insert_item(list_item_new(i & 3, 0, v), l);
+    }
+    list_decr_writers(l);
+    return NULL;
+}
+
+static int cmd_containers(void) {
+    /* array_list grows past its initial capacity */
+    array_list_t *al = array_list_new(2);
+    for (long i = 0; i < 1000; i++) array_list_insert((void *)(i + 1), al);
+    int ok = al->size == 1000;
+    for (long i = 0; i < 1000; i++) ok &= ((long)array_list_get((size_t)i, al) == i + 1);
+    CHECK(ok && array_list_get(1000, al) == NULL, "array_list: 1000 inserts, bounds-checked get");
+    array_list_free(al, NULL);
+
+    /* sample_ids: many names, rehashing, absent keys */
+    sample_ids_t *ids = sample_ids_new(4);
+    char (*names)[16] = malloc(20000 * 16);
+    for (int i = 0; i < 20000; i++) { snprintf(names[i], 16, "NA%05d", i); sample_ids_put(ids, names[i], i); }
+    ok = ids->size == 20000;
+    for (int i = 0; i < 20000; i += 7) ok &= sample_ids_get(ids, names[i]) == i;
+    ok &= sample_ids_get(ids, "absent") == -1;
+    sample_ids_put(ids, names[5], 99);
+    ok &= sample_ids_get(ids, names[5]) == 99 && ids->size == 20000;
+    CHECK(ok, "sample_ids: 20000 names, lookups, overwrite, absent key");
+    sample_ids_free(ids);
+    free(names);
+
+    /* list_t: 4 producers, 1 consumer, consumer ends when the writers are gone (assoc_runner.c:306) */
+    list_t l;
+    list_init("output", 4, 0, &l);
+    pthread_t th[4];
+    for (int t = 0; t < 4; t++) pthread_create(&th[t], NULL, producer, &l);
+    long got = 0, sum = 0;
+    list_item_t *it;
+    while ((it = list_remove_item(&l))) { got++; sum += *(int *)it->data_p; free(it->data_p); list_item_free(it); }
+    for (int t = 0; t < 4; t++) pthread_join(th[t], NULL);
+    CHECK(got == 20000 && sum == 4L * (4999L * 5000L / 2), "list_t: 4 writers x 5000 items drained, then NULL");
+    list_free_deep(&l, NULL);
+
+    /* families / individuals */
+    family_t *f = family_new("F1");
+    individual_t *fa = individual_new("fa", -1, MALE, UNAFFECTED, NULL, NULL, f);
+    individual_t *mo = individual_new("mo", -1, FEMALE, UNAFFECTED, NULL, NULL, f);
+    individual_t *ch = individual_new("ch", -1, MALE, AFFECTED, fa, mo, f);
+    family_set_parent(fa, f); family_set_parent(mo, f); family_add_child(ch, f);
+    CHECK(f->founders->size == 2 && f->members->size == 1 && ch->father == fa && ch->mother == mo, "family construction");
+    individual_free(fa); individual_free(mo); individual_free(ch); family_free(f);
+
+    double *lf = init_logarithm_array(100);
+    CHECK(lf && lf[0] == 0.0 && lf[1] == 0.0 && lf[5] > 4.787 && lf[5] < 4.788, "init_logarithm_array: ln(5!) = 4.7875");
+    free(lf);
+    printf("%s\n", failures ? "CONTAINERS FAILED" : "CONTAINERS OK");
+    return failures ? 1 : 0;
+}
+
+static char *next_tok(char **p) {
+    char *s = *p;
+    while (*s == ' ' || *s == '\n' || *s == '\r') s++;
+    if (!*s) return NULL;
+    char *e = s;
+    while (*e && *e != ' ' && *e != '\n' && *e != '\r') e++;
+    if (*e) { *e = 0; e++; }
+    *p = e;
+    return s;
+}
+
+static int cmd_stage(const char *path) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return 2;
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    char *blob = (char *)malloc((size_t)sz + 1);
+    if (fread(blob, 1, (size_t)sz, f) != (size_t)sz) return 2;
+    blob[sz] = 0;
+    fclose(f);
+    char *p = blob;
+    int n = atoi(next_tok(&p)), v = atoi(next_tok(&p));
+    vcf_record_t **recs = (vcf_record_t **)malloc(sizeof(void *) * (size_t)(v + 1));
+    for (int i = 0; i < v; i++) {
+        recs[i] = vcf_record_new();
+        char *chrom = next_tok(&p), *fmt = next_tok(&p);
+        set_vcf_record_chromosome(chrom, (int)strlen(chrom), recs[i]);
+        set_vcf_record_format(fmt, (int)strlen(fmt), recs[i]);
+        for (int j = 0; j < n; j++) {
+            char *s = next_tok(&p);
+            if (!strcmp(s, "<empty>")) s[0] = 0;
+            array_list_insert(s, recs[i]->samples);
+        }
+    }
+    uint8_t *gt = (uint8_t *)malloc((size_t)v * (size_t)(n > 0 ? n : 1)), *isx = (uint8_t *)malloc((size_t)v + 1);
+    for (int strict = 1; strict >= 0; strict--) {
+        hpgv_host_stage_records(recs, v, n, strict, gt, isx);
+        for (int i = 0; i < v; i++) {
+            printf("%d %d", strict, isx[i]);
+            for (int j = 0; j < n; j++) printf(" %02x", gt[(size_t)i * n + j]);
+            printf("\n");
+        }
+    }
+    for (int i = 0; i < v; i++) vcf_record_free(recs[i]);
+    free(recs); free(gt); free(isx); free(blob);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc >= 2 && !strcmp(argv[1], "containers")) return cmd_containers();
+    if (argc >= 3 && !strcmp(argv[1], "stage")) return cmd_stage(argv[2]);
+    return 2;
+}

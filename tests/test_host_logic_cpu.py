@@ -1,0 +1,71 @@
+"""CPU suite: the host mirror's own logic (containers, thread-safe result list,
+GT-text staging) built with AddressSanitizer + UBSan and run without a GPU."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import QUIRK_GTS, hpgv
+from oracle import pyoracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    hpgv.build()
+    from importlib import import_module
+    b = import_module("hpg-variant_amd._build")
+    out = str(tmp_path_factory.mktemp("hostcpu") / "host_cpu_check")
+    # the adapters' source is compiled in directly so that it is instrumented too
+    subprocess.check_call(["gcc", "-O1", "-g", "-std=gnu99", "-fopenmp", "-fsanitize=address,undefined",
+                           "-fno-omit-frame-pointer", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "host_cpu_check.c"),
+                           os.path.join(ROOT, "hpg-variant_amd", "host", "hpgv_host.c"),
+                           "-o", out, "-L", b.LIBDIR, "-lhpgv", "-Wl,-rpath," + b.LIBDIR, "-lm", "-lpthread"])
+    return out
+
+
+def _run(exe, *args):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    return subprocess.run([exe] + list(args), capture_output=True, text=True, env=env)
+
+
+def test_containers_and_result_list_under_sanitizers(exe):
+    r = _run(exe, "containers")
+    assert r.returncode == 0 and "CONTAINERS OK" in r.stdout and "FAIL" not in r.stdout, r.stdout + r.stderr
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
+
+
+def test_staging_matches_the_oracle_encoder(exe, tmp_path):
+    rng = np.random.default_rng(4)
+    pool = QUIRK_GTS + ["0/1:12:99", ".:3", "1/", "/1", "0|0:.", "10/2", "a/1", "-1/0", "+1/1", "0/1/2", "2", "<empty>",
+                        "./.:0,0", "0/0:1,2:3", "7:1/0", "7:./1:5", "7", "7:"]
+    fmts = ["GT", "GT:DP", "DP:GT", "DP:GQ:GT", "DP:GQ"]
+    chroms = ["1", "X", "XY", "x", "23"]
+    n, v = 37, 60
+    rows = []
+    with open(tmp_path / "in.txt", "w") as f:
+        f.write("%d %d\n" % (n, v))
+        for i in range(v):
+            fmt, chrom = fmts[i % len(fmts)], chroms[i % len(chroms)]
+            ss = [pool[int(k)] for k in rng.integers(0, len(pool), size=n)]
+            f.write("%s %s %s\n" % (chrom, fmt, " ".join(ss)))
+            rows.append((chrom, fmt, ss))
+    r = _run(exe, "stage", str(tmp_path / "in.txt"))
+    assert r.returncode == 0, r.stderr
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
+    lines = [l.split() for l in r.stdout.strip().splitlines()]
+    assert len(lines) == 2 * v
+    for k, t in enumerate(lines):
+        strict, i = int(t[0]) == 1, k % v
+        chrom, fmt, ss = rows[i]
+        assert int(t[1]) == orc.lib().orc_chrom_is_x(chrom.encode(), len(chrom))
+        keys = fmt.split(":")
+        if "GT" not in keys:
+            assert all(x == "ff" for x in t[2:])                     # no GT in FORMAT: nothing usable
+            continue
+        pos = keys.index("GT")
+        exp = ["%02x" % orc.encode_sample("" if s == "<empty>" else s, pos, strict) for s in ss]
+        assert t[2:] == exp, (i, strict, list(zip(ss, t[2:], exp)))
