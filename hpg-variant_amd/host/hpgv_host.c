@@ -836,3 +836,107 @@ void tdt_write_output_body(list_t *output_list, FILE *fd) {
         list_item_free(item);
     }
 }
+
+/* ------------------------------------------------------------------------ */
+/* result ordering: `sort -k1,1h -k2,2n` in process                          */
+/* ------------------------------------------------------------------------ */
+
+typedef struct { const char *line; int neg1, order1; long double v1; int neg2; long double v2; } sort_key_t;
+
+static int is_blank(char c) { return c == ' ' || c == '\t'; }
+
+/* GNU sort numeric token at p: optional blanks, '-', digits, optional fraction.  Text that is
+ * not a number counts as 0.  Returns the position after the token in *end. */
+static long double parse_number(const char *p, int *neg, const char **end, int *digits) {
+    while (is_blank(*p)) p++;
+    *neg = 0;
+    if (*p == '-') { *neg = 1; p++; }
+    long double v = 0.0L;
+    *digits = (*p >= '0' && *p <= '9');
+    while (*p >= '0' && *p <= '9') { v = v * 10.0L + (*p - '0'); p++; }
+    if (*p == '.') {
+        long double scale = 0.1L;
+        p++;
+        while (*p >= '0' && *p <= '9') { v += scale * (*p - '0'); scale *= 0.1L; p++; }
+    }
+    if (v == 0.0L) *neg = 0;
+    *end = p;
+    return v;
+}
+
+static void make_key(const char *line, sort_key_t *k) {
+    k->line = line;
+    const char *e;
+    int digits;
+    k->v1 = parse_number(line, &k->neg1, &e, &digits);         /* -k1,1h */
+    static const char units[] = "KMGTPEZY";
+    k->order1 = 0;
+    if (digits) {                                              /* a unit suffix only counts after digits */
+        if (*e == 'k') k->order1 = 1;
+        else { const char *u = *e ? strchr(units, *e) : NULL; if (u) k->order1 = (int)(u - units) + 1; }
+    }
+    /* field 2 = after the first field (non-blanks) of the line; sort's fields carry their leading blanks */
+    const char *p = line;
+    while (is_blank(*p)) p++;
+    while (*p && !is_blank(*p)) p++;
+    k->v2 = parse_number(p, &k->neg2, &e, &digits);            /* -k2,2n */
+}
+
+static int cmp_signed(int na, long double a, int nb, long double b) {
+    if (na != nb) return na ? -1 : 1;
+    if (a == b) return 0;
+    int r = a < b ? -1 : 1;
+    return na ? -r : r;
+}
+
+static int cmp_keys(const void *pa, const void *pb) {
+    const sort_key_t *a = (const sort_key_t *)pa, *b = (const sort_key_t *)pb;
+    /* human numeric: sign, then unit magnitude, then value */
+    if (a->neg1 != b->neg1) return a->neg1 ? -1 : 1;
+    if (a->order1 != b->order1) { int r = a->order1 < b->order1 ? -1 : 1; return a->neg1 ? -r : r; }
+    int r = cmp_signed(a->neg1, a->v1, b->neg1, b->v1);
+    if (r) return r;
+    r = cmp_signed(a->neg2, a->v2, b->neg2, b->v2);
+    if (r) return r;
+    return strcmp(a->line, b->line);                            /* last resort: whole line, bytewise */
+}
+
+int hpgv_host_sort_output_file(const char *path) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return 1;
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    char *blob = (char *)malloc((size_t)sz + 2);
+    if (!blob || fread(blob, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); free(blob); return 1; }
+    fclose(f);
+    blob[sz] = 0;
+    size_t n = 0;
+    for (long i = 0; i < sz; i++) if (blob[i] == '\n') n++;
+    if (sz > 0 && blob[sz - 1] != '\n') n++;
+    sort_key_t *keys = (sort_key_t *)malloc((n + 1) * sizeof *keys);
+    if (!keys) { free(blob); return 1; }
+    size_t k = 0;
+    char *p = blob;
+    while (k < n) {
+        char *e = strchr(p, '\n');
+        if (e) *e = 0;
+        make_key(p, &keys[k++]);
+        if (!e) break;
+        p = e + 1;
+    }
+    qsort(keys, k, sizeof *keys, cmp_keys);
+    size_t len = strlen(path);
+    char *tmp = (char *)malloc(len + 5);
+    if (!tmp) { free(keys); free(blob); return 1; }
+    memcpy(tmp, path, len);
+    memcpy(tmp + len, ".tmp", 5);
+    FILE *o = fopen(tmp, "wb");
+    int rc = o ? 0 : 1;
+    if (o) {
+        for (size_t i = 0; i < k; i++) { fputs(keys[i].line, o); fputc('\n', o); }
+        if (fclose(o) != 0 || rename(tmp, path) != 0) rc = 1;
+    }
+    free(tmp); free(keys); free(blob);
+    return rc;
+}

@@ -240,6 +240,13 @@ void assoc_write_output_body(enum ASSOC_task task, list_t *output_list, FILE *fd
 void tdt_write_output_header(FILE *fd);                                     /* tdt_runner.c:286-289 */
 void tdt_write_output_body(list_t *output_list, FILE *fd);                  /* tdt_runner.c:291-304 */
 
+/* In-process replacement of the runners' `system("sort -k1,1h -k2,2n FILE > FILE.tmp && mv ...")`
+ * (assoc_runner.c:255-258, tdt_runner.c:255-261): sorts the lines of `path` (header included, as
+ * the reference does) by column 1 "human numeric", then column 2 numeric, then the whole line
+ * bytewise -- the order GNU sort gives under LC_ALL=C.  Returns 0, or non-zero when the file
+ * cannot be read / rewritten (the reference only warns in that case). */
+int  hpgv_host_sort_output_file(const char *path);
+
 /* ---- staging (GT text -> HPGV8), exposed for tests ---------------------------- */
 int  get_field_position_in_format(const char *field, char *format);
 int  get_alleles(char *sample, int genotype_position, int *allele1, int *allele2);

@@ -131,5 +131,6 @@ static int cmd_stage(const char *path) {
 int main(int argc, char **argv) {
     if (argc >= 2 && !strcmp(argv[1], "containers")) return cmd_containers();
     if (argc >= 3 && !strcmp(argv[1], "stage")) return cmd_stage(argv[2]);
+    if (argc >= 3 && !strcmp(argv[1], "sort")) return hpgv_host_sort_output_file(argv[2]);
     return 2;
 }

@@ -265,6 +265,7 @@ static int cmd_assoc(const char *batch_path, const char *ped_path, const char *p
         assoc_write_output_header(tasks[t], fd);
         assoc_write_output_body(tasks[t], &out, fd);
         fclose(fd);
+        if (hpgv_host_sort_output_file(path)) fprintf(stderr, "results could not be sorted\n");   /* assoc_runner.c:255-261 */
         list_free_deep(&out, NULL);
     }
     printf("ASSOC OK\n");
@@ -299,6 +300,7 @@ static int cmd_tdt(const char *batch_path, const char *ped_path, const char *pre
     tdt_write_output_header(fd);
     tdt_write_output_body(&out, fd);
     fclose(fd);
+    if (hpgv_host_sort_output_file(path)) fprintf(stderr, "results could not be sorted\n");       /* tdt_runner.c:255-261 */
     list_free_deep(&out, NULL);
     printf("TDT OK\n");
     hpgv_host_shutdown();

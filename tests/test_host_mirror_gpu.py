@@ -102,7 +102,11 @@ def test_assoc_test_runner_shape(driver, tmp_path):
     lf = orc.logfact(len(names) * 10)
     for task, ext in ((orc.TASK_CHISQ, "chisq"), (orc.TASK_FISHER, "fisher")):
         odds, chisq, p = orc.assoc_stats(task, A1, A2, U1, U2, lf)
-        header, table = _parse_table(str(tmp_path / "out") + "." + ext)
+        path = str(tmp_path / "out") + "." + ext
+        gnu = subprocess.run(["sort", "-k1,1h", "-k2,2n", path], capture_output=True, text=True,
+                             env=dict(os.environ, LC_ALL="C"), check=True).stdout
+        assert open(path).read() == gnu                    # already in the order the reference's `sort` call gives
+        header, table = _parse_table(path)
         exp_header = "#CHR POS ID A1 C_A1 C_U1 F_A1 F_U1 A2 C_A2 C_U2 F_A2 F_U2 OR".split() + \
             (["CHISQ", "P-VALUE"] if task == orc.TASK_CHISQ else ["P-VALUE"])
         assert header == exp_header                        # assoc_runner.c:295,297
