@@ -31,7 +31,7 @@ SYMBOLS = [
     "hpgv_layout_dev", "hpgv_synth_dev", "hpgv_synth_raw_dev",
     "hpgv_assoc_scan_dev", "hpgv_assoc_chisq_dev", "hpgv_assoc_fisher_dev",
     "hpgv_tdt_scan_dev", "hpgv_tdt_stats_dev", "hpgv_stats_scan_dev", "hpgv_stats_hwe_dev",
-    "hpgv_sample_missing_dev", "hpgv_genotype_table_dev",
+    "hpgv_sample_missing_dev", "hpgv_genotype_table_dev", "hpgv_stats_filter_dev",
     "hpgv_tokenize_dev", "hpgv_tokenize", "hpgv_assoc_text", "hpgv_tdt_text",
     "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_read_probe",
 ]
@@ -102,6 +102,7 @@ def load():
     L.hpgv_tokenize.argtypes = [vp, C.c_char_p, sz, i32, i32, i32, C.POINTER(i32), vp, vp, vp, sz, vp, vp]
     L.hpgv_assoc_text.argtypes = [vp, i32, C.c_char_p, sz, i32, C.POINTER(i32), vp, vp, vp] + [vp] * 7
     L.hpgv_tdt_text.argtypes = [vp, C.c_char_p, sz, i32, C.POINTER(i32), vp, vp, vp] + [vp] * 5
+    L.hpgv_stats_filter_dev.argtypes = [vp, vp, i32, C.c_double, C.c_double, C.c_double, vp, vp]
     L.hpgv_read_probe.argtypes = [vp, vp, sz, i32, C.POINTER(C.c_float)]
     _lib = L
     return L
@@ -339,6 +340,9 @@ class Engine:
 
     def genotype_table(self, d_raw, src_pitch, n_samples, d_idx, n_idx, d_table, stream=None):
         self._chk(self.L.hpgv_genotype_table_dev(self.h, d_raw, src_pitch, n_samples, d_idx, n_idx, d_table, stream))
+
+    def stats_filter(self, d_counts8, n_variants, d_keep, min_maf=-1.0, max_maf=-1.0, max_missing=-1.0, stream=None):
+        self._chk(self.L.hpgv_stats_filter_dev(self.h, d_counts8, n_variants, min_maf, max_maf, max_missing, d_keep, stream))
 
     def last_kernel_ms(self):
         a, b = C.c_float(), C.c_float()

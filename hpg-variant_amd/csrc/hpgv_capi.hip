@@ -685,6 +685,19 @@ int hpgv_stats_hwe_dev(hpgv_ctx *ctx, const int32_t *d_counts8, int n_variants, 
     });
 }
 
+int hpgv_stats_filter_dev(hpgv_ctx *ctx, const int32_t *d_counts8, int n_variants, double min_maf, double max_maf,
+                          double max_missing, uint8_t *d_keep, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->stats.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");
+    if (n_variants < 0 || (n_variants > 0 && (!d_counts8 || !d_keep))) return fail(ctx, HPGV_ERR_INVALID, "bad filter arguments");
+    if (n_variants == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    hipLaunchKernelGGL(hpgv::k_stats_filter, dim3((n_variants + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const int4 *)d_counts8, n_variants, ctx->stats.n_samples, min_maf, max_maf, max_missing, d_keep);
+    HIPCHK(ctx, hipGetLastError());
+    return HPGV_OK;
+}
+
 int hpgv_sample_missing_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, int32_t *d_missing, void *stream) {
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->stats.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");

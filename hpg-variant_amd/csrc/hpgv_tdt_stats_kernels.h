@@ -495,6 +495,29 @@ __global__ __launch_bounds__(256) void k_genotype_table(const uint8_t *__restric
     table[(size_t)i * 256 + threadIdx.x] = hist[threadIdx.x];
 }
 
+// ---------------------------------------------------------------------------
+// count-derived variant filters (shared_options.c:42-47,86-115: --maf, --missing;
+// predicates live in hpg-libs, absent: directions are explicit parameters here).
+// keep[i] = 1 iff every enabled test passes; a negative threshold disables a test.
+//   maf        = min(allele0, allele1) / (allele0 + allele1)      (0 when no allele is called)
+//   missing    = missing_genotypes / n_samples
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stats_filter(const int4 *__restrict__ in8, int n, int n_samples,
+                                                      double min_maf, double max_maf, double max_missing,
+                                                      uint8_t *__restrict__ keep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 hi = in8[2 * i + 1];                       // missing_gt, missing_alleles, allele0, allele1
+    const int a0 = hi.z, a1 = hi.w, tot = a0 + a1;
+    const double maf = tot > 0 ? (double)(a0 < a1 ? a0 : a1) / (double)tot : 0.0;
+    const double miss = n_samples > 0 ? (double)hi.x / (double)n_samples : 0.0;
+    bool ok = true;
+    if (min_maf >= 0.0) ok = ok && (maf >= min_maf);
+    if (max_maf >= 0.0) ok = ok && (maf <= max_maf);
+    if (max_missing >= 0.0) ok = ok && (miss <= max_missing);
+    keep[i] = ok ? 1 : 0;
+}
+
 // Hardy-Weinberg chi-square on (n_AA, n_Aa, n_aa) = (n_00, n_01 + n_10, n_11);
 // definition: oracle/hpgv_oracle.c orc_hwe (hpg-libs body absent: unpinned)
 __global__ __launch_bounds__(256) void k_stats_hwe(const int4 *__restrict__ in8, int n, double *__restrict__ chi2,

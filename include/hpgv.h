@@ -160,6 +160,14 @@ int  hpgv_sample_missing_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants,
 int  hpgv_genotype_table_dev(hpgv_ctx *ctx, const uint8_t *d_raw, size_t src_pitch, int n_samples,
                              const int32_t *d_variant_idx, int n_idx, int32_t *d_table, void *stream);
 
+/* count-derived variant filters (--maf, --missing of shared_options.c:42-47,86-115) from the stats
+ * counters: d_keep[i] = 1 iff maf >= min_maf, maf <= max_maf and missing rate <= max_missing, where a
+ * negative threshold switches that test off; maf = min(allele0, allele1) / (allele0 + allele1),
+ * missing rate = missing_genotypes / n_samples of the stats cohort. */
+int  hpgv_stats_filter_dev(hpgv_ctx *ctx, const int32_t *d_counts8, int n_variants,
+                           double min_maf, double max_maf, double max_missing,
+                           uint8_t *d_keep, void *stream);
+
 /* duration (ms) of the last scan / statistics kernel launched through this ctx
  * when option "profile" = 1 (HIP events on the launch stream; synchronises) */
 int  hpgv_last_kernel_ms(hpgv_ctx *ctx, float *scan_ms, float *stats_ms);

@@ -344,6 +344,37 @@ def test_sample_missing_and_multiallelic_tables():
         e.close()
 
 
+def test_count_derived_filters():
+    rng = np.random.default_rng(31)
+    n_samples, nv = 800, 500
+    e = fresh()
+    pitch = e.set_stats_cohort(n_samples)
+    gt = random_codes(rng, nv, n_samples, quirks=False, strict=False, p_missing=0.05)
+    gt[::5, : n_samples // 3] = 0xFF                         # some variants with a lot of missing calls
+    gt[1::7] = 0x00                                          # monomorphic variants (maf 0)
+    d_raw, d_lay, d_c8, d_keep = e.alloc(nv * n_samples), e.alloc(nv * pitch), e.alloc(nv * 32), e.alloc(nv)
+    e.h2d(d_raw, gt)
+    e.layout(hpgv.LAYOUT_STATS, d_raw, n_samples, nv, d_lay)
+    e.stats_scan(d_lay, nv, d_c8)
+    maf = np.zeros(nv); miss = np.zeros(nv)
+    for i in range(nv):
+        vs = orc.variant_stats(gt[i], 2)
+        a0, a1 = vs.alleles_count[0], vs.alleles_count[1]
+        maf[i] = min(a0, a1) / (a0 + a1) if a0 + a1 else 0.0
+        miss[i] = vs.missing_genotypes / n_samples
+    for min_maf, max_maf, max_missing in ((0.05, -1, -1), (-1, 0.2, -1), (-1, -1, 0.1), (0.01, 0.45, 0.3), (-1, -1, -1)):
+        e.stats_filter(d_c8, nv, d_keep, min_maf, max_maf, max_missing)
+        e.sync()
+        keep = e.d2h(d_keep, (nv,), np.uint8)
+        exp = np.ones(nv, bool)
+        if min_maf >= 0: exp &= maf >= min_maf
+        if max_maf >= 0: exp &= maf <= max_maf
+        if max_missing >= 0: exp &= miss <= max_missing
+        assert np.array_equal(keep.astype(bool), exp)
+        assert 0 < exp.sum() <= nv
+    e.close()
+
+
 # ------------------------------------------------------- error behaviour ----
 
 def test_state_and_argument_errors():
