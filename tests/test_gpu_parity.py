@@ -391,3 +391,41 @@ def test_state_and_argument_errors():
     with pytest.raises(hpgv.HpgvError):
         e.set_families(10, [11], [1], [0, 1], [2], [0])            # column out of range
     e.close()
+
+
+def test_maximum_row_length():
+    # rows up to ~2M samples are supported (16-bit per-lane partial sums); beyond that the engine refuses
+    rng = np.random.default_rng(5)
+    n_samples = 2_000_000
+    cond = rng.choice([0, 1, 2], size=n_samples, p=[0.5, 0.45, 0.05]).astype(np.uint8)
+    nv = 24
+    gt = random_codes(rng, nv, n_samples, quirks=False)
+    gt[0] = 0x00; gt[1] = 0x11; gt[2] = 0xFF            # extreme tallies: every sample the same
+    is_x = np.zeros(nv, np.uint8); is_x[1::2] = 1
+    for opts in ({}, {"pipeline": 0}, {"pipeline": 0, "scan_unroll": 16}):
+        e = fresh()
+        for k, v in opts.items():
+            e.set_option(k, v)
+        e.set_cohort(cond)
+        check_assoc(e.assoc(hpgv.TASK_CHISQ, gt, is_x), oracle_assoc(orc.TASK_CHISQ, gt, cond, is_x), hpgv.TASK_CHISQ)
+        e.close()
+    e = fresh()
+    e.set_stats_cohort(n_samples)
+    res = e.stats(gt[:6])
+    for i in range(6):
+        vs = orc.variant_stats(gt[i], 2)
+        assert list(res["counts8"][i][:4]) == list(vs.genotypes_count)[:4] and res["counts8"][i][4] == vs.missing_genotypes
+    with pytest.raises(hpgv.HpgvError):
+        e.set_cohort(np.zeros(2_200_000, np.uint8))      # too long a row
+    with pytest.raises(hpgv.HpgvError):
+        e.set_stats_cohort(2_200_000)
+    e.close()
+    # a pedigree as wide as a 600k-sample cohort (200k trios)
+    n_tr = 200_000
+    k = np.arange(n_tr)
+    fam = (3 * k, 3 * k + 1, np.arange(n_tr + 1), 3 * k + 2, (k % 2).astype(np.uint8))
+    e = fresh()
+    e.set_families(3 * n_tr, *fam)
+    gt = random_codes(rng, 8, 3 * n_tr, quirks=False)
+    _tdt_check(e, gt, fam, np.array([0, 1] * 4, np.uint8))
+    e.close()
