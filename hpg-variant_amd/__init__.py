@@ -19,7 +19,7 @@ OK = 0
 TASK_CHISQ, TASK_FISHER = 1, 2
 COND_UNAFFECTED, COND_AFFECTED, COND_OTHER = 0, 1, 2
 SEX_MALE, SEX_FEMALE, SEX_UNKNOWN = 0, 1, 2
-LAYOUT_ASSOC, LAYOUT_TDT, LAYOUT_STATS = 0, 1, 2
+LAYOUT_ASSOC, LAYOUT_TDT, LAYOUT_STATS, LAYOUT_STATS_GROUPS = 0, 1, 2, 3
 GT_MISSING = 0xFF
 
 # every symbol include/hpgv.h declares (checked by the CPU suite)
@@ -27,6 +27,7 @@ SYMBOLS = [
     "hpgv_version", "hpgv_device_count", "hpgv_create", "hpgv_destroy", "hpgv_last_error",
     "hpgv_set_option", "hpgv_set_cohort", "hpgv_assoc_layout", "hpgv_set_families",
     "hpgv_tdt_layout", "hpgv_set_logfact", "hpgv_set_stats_cohort", "hpgv_stats_layout",
+    "hpgv_set_stats_groups", "hpgv_stats_groups_layout", "hpgv_stats_scan_group_dev",
     "hpgv_dev_alloc", "hpgv_dev_free", "hpgv_memcpy_h2d", "hpgv_memcpy_d2h", "hpgv_stream_sync",
     "hpgv_layout_dev", "hpgv_synth_dev", "hpgv_synth_raw_dev",
     "hpgv_assoc_scan_dev", "hpgv_assoc_chisq_dev", "hpgv_assoc_fisher_dev",
@@ -103,6 +104,9 @@ def load():
     L.hpgv_assoc_text.argtypes = [vp, i32, C.c_char_p, sz, i32, C.POINTER(i32), vp, vp, vp] + [vp] * 7
     L.hpgv_tdt_text.argtypes = [vp, C.c_char_p, sz, i32, C.POINTER(i32), vp, vp, vp] + [vp] * 5
     L.hpgv_stats_filter_dev.argtypes = [vp, vp, i32, C.c_double, C.c_double, C.c_double, vp, vp]
+    L.hpgv_set_stats_groups.argtypes = [vp, vp, i32, i32]
+    L.hpgv_stats_groups_layout.argtypes = [vp, C.POINTER(sz), vp]
+    L.hpgv_stats_scan_group_dev.argtypes = [vp, vp, i32, i32, vp, vp]
     L.hpgv_read_probe.argtypes = [vp, vp, sz, i32, C.POINTER(C.c_float)]
     _lib = L
     return L
@@ -183,6 +187,17 @@ class Engine:
         p = C.c_size_t()
         self._chk(self.L.hpgv_stats_layout(self.h, C.byref(p)))
         return p.value
+
+    def set_stats_groups(self, group_of_sample, n_groups):
+        g = _np(group_of_sample, np.int32)
+        self._chk(self.L.hpgv_set_stats_groups(self.h, _ptr(g), len(g), n_groups))
+        p = C.c_size_t()
+        sizes = np.zeros(n_groups, np.int32)
+        self._chk(self.L.hpgv_stats_groups_layout(self.h, C.byref(p), _ptr(sizes)))
+        return p.value, sizes
+
+    def stats_scan_group(self, d_gt, n_variants, group, d_counts8, stream=None):
+        self._chk(self.L.hpgv_stats_scan_group_dev(self.h, d_gt, n_variants, group, d_counts8, stream))
 
     # ---- device memory ------------------------------------------------------
     def alloc(self, nbytes):

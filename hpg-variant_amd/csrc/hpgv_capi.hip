@@ -64,6 +64,9 @@ struct hpgv_ctx {
     hpgv::TdtPlan tdt_plan;
     // stats
     Layout stats;
+    Layout sgroups;                       // [group 0 | pad16 | group 1 | ...]
+    std::vector<uint32_t> sg_off;         // byte offset of every group's segment in the row
+    std::vector<int> sg_size;             // samples per group
     // fisher
     double *d_lf = nullptr;
     size_t n_lf = 0;
@@ -230,7 +233,7 @@ void hpgv_destroy(hpgv_ctx *ctx) {
     if (!ctx) return;
     DeviceGuard g(ctx->device);
     (void)hipDeviceSynchronize();
-    for (Layout *L : {&ctx->assoc, &ctx->tdt, &ctx->stats})
+    for (Layout *L : {&ctx->assoc, &ctx->tdt, &ctx->stats, &ctx->sgroups})
         if (L->d_col_of_pos) (void)hipFree(L->d_col_of_pos);
     ctx->tdt_plan.release();
     if (ctx->d_lf) (void)hipFree(ctx->d_lf);
@@ -349,6 +352,42 @@ int hpgv_set_stats_cohort(hpgv_ctx *ctx, int n_samples) {
     return upload_layout(ctx, L);
 }
 
+int hpgv_set_stats_groups(hpgv_ctx *ctx, const int32_t *group_of_sample, int n_samples, int n_groups) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (n_samples < 0 || n_groups < 1 || n_groups > 4096 || (n_samples > 0 && !group_of_sample))
+        return fail(ctx, HPGV_ERR_INVALID, "bad stats group arguments");
+    DeviceGuard g(ctx->device);
+    std::vector<int> size((size_t)n_groups, 0);
+    for (int j = 0; j < n_samples; ++j) {
+        if (group_of_sample[j] >= n_groups) return fail(ctx, HPGV_ERR_INVALID, "group %d of sample %d out of range", group_of_sample[j], j);
+        if (group_of_sample[j] >= 0) size[(size_t)group_of_sample[j]]++;
+    }
+    std::vector<uint32_t> off((size_t)n_groups, 0);
+    size_t used = 0;
+    for (int k = 0; k < n_groups; ++k) { off[(size_t)k] = (uint32_t)used; used += round_up((size_t)size[(size_t)k], 16); }
+    size_t pitch = round_up(used, (size_t)ctx->row_align) + (size_t)ctx->row_pad;
+    if (pitch == 0) pitch = (size_t)ctx->row_align;
+    if (!pitch_supported(pitch)) return fail(ctx, HPGV_ERR_UNSUPPORTED, "cohort of %d samples exceeds the row-length limit", n_samples);
+    Layout &L = ctx->sgroups;
+    L.n_samples = n_samples;
+    L.pitch = pitch;
+    L.col_of_pos.assign(pitch, -1);
+    std::vector<size_t> fill(off.begin(), off.end());
+    for (int j = 0; j < n_samples; ++j)
+        if (group_of_sample[j] >= 0) L.col_of_pos[fill[(size_t)group_of_sample[j]]++] = j;
+    ctx->sg_off = off;
+    ctx->sg_size = size;
+    return upload_layout(ctx, L);
+}
+
+int hpgv_stats_groups_layout(const hpgv_ctx *ctx, size_t *pitch, int *group_sizes) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->sgroups.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_groups has not been called");
+    if (pitch) *pitch = ctx->sgroups.pitch;
+    if (group_sizes) for (size_t k = 0; k < ctx->sg_size.size(); ++k) group_sizes[k] = ctx->sg_size[k];
+    return HPGV_OK;
+}
+
 int hpgv_stats_layout(const hpgv_ctx *ctx, size_t *pitch) {
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->stats.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");
@@ -424,6 +463,7 @@ static Layout *pick_layout(hpgv_ctx *ctx, int which) {
         case HPGV_LAYOUT_ASSOC: return &ctx->assoc;
         case HPGV_LAYOUT_TDT: return &ctx->tdt;
         case HPGV_LAYOUT_STATS: return &ctx->stats;
+        case HPGV_LAYOUT_STATS_GROUPS: return &ctx->sgroups;
         default: return nullptr;
     }
 }
@@ -432,7 +472,7 @@ static Layout *pick_layout(hpgv_ctx *ctx, int which) {
 static void recode_of(const hpgv_ctx *ctx, int which, int *mode, int *p16) {
     *mode = hpgv::RECODE_NONE; *p16 = 0;
     if (which == HPGV_LAYOUT_TDT) { *mode = hpgv::RECODE_TDT; *p16 = ctx->tdt_plan.p16; }
-    else if (which == HPGV_LAYOUT_STATS) { *mode = hpgv::RECODE_STATS; }
+    else if (which == HPGV_LAYOUT_STATS || which == HPGV_LAYOUT_STATS_GROUPS) { *mode = hpgv::RECODE_STATS; }
 }
 
 int hpgv_layout_dev(hpgv_ctx *ctx, int which, const uint8_t *d_src, size_t src_pitch, int n_variants,
@@ -446,7 +486,7 @@ int hpgv_layout_dev(hpgv_ctx *ctx, int which, const uint8_t *d_src, size_t src_p
     if (n_variants == 0) return HPGV_OK;
     DeviceGuard g(ctx->device);
     const long total = (long)n_variants * L->chunks;
-    const int strict = (which == HPGV_LAYOUT_STATS) ? 0 : 1;
+    const int strict = (which == HPGV_LAYOUT_STATS || which == HPGV_LAYOUT_STATS_GROUPS) ? 0 : 1;
     int mode, p16;
     recode_of(ctx, which, &mode, &p16);
     hipLaunchKernelGGL(hpgv::k_layout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -664,10 +704,35 @@ int hpgv_stats_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, int3
     return launch_profiled(ctx, st, 0, [&] {
         if (ctx->nontemporal)
             hipLaunchKernelGGL((hpgv::k_stats_scan<true, kScanUnroll>), dim3(blocks), dim3(256), 0, st, d_gt, L.pitch,
-                               n_variants, L.chunks, (int4 *)d_counts8, vpw);
+                               n_variants, 0u, L.chunks, (int4 *)d_counts8, vpw);
         else
             hipLaunchKernelGGL((hpgv::k_stats_scan<false, kScanUnroll>), dim3(blocks), dim3(256), 0, st, d_gt, L.pitch,
-                               n_variants, L.chunks, (int4 *)d_counts8, vpw);
+                               n_variants, 0u, L.chunks, (int4 *)d_counts8, vpw);
+    });
+}
+
+int hpgv_stats_scan_group_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, int group, int32_t *d_counts8, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->sgroups.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_groups has not been called");
+    if (group < 0 || (size_t)group >= ctx->sg_off.size()) return fail(ctx, HPGV_ERR_INVALID, "group %d out of range", group);
+    if (n_variants < 0 || (n_variants > 0 && (!d_gt || !d_counts8))) return fail(ctx, HPGV_ERR_INVALID, "bad scan arguments");
+    if (n_variants == 0) return HPGV_OK;
+    if (((uintptr_t)d_gt & 15) || ((uintptr_t)d_counts8 & 15)) return fail(ctx, HPGV_ERR_INVALID, "device buffers must be 16-byte aligned");
+    DeviceGuard g(ctx->device);
+    const Layout &L = ctx->sgroups;
+    const int vpw = (int)ctx->vpw;
+    const long waves = ((long)n_variants + vpw - 1) / vpw;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    const uint32_t off = ctx->sg_off[(size_t)group];
+    const int chunks = (int)(round_up((size_t)ctx->sg_size[(size_t)group], 16) / 16);
+    hipStream_t st = (hipStream_t)stream;
+    return launch_profiled(ctx, st, 0, [&] {
+        if (ctx->nontemporal)
+            hipLaunchKernelGGL((hpgv::k_stats_scan<true, kScanUnroll>), dim3(blocks), dim3(256), 0, st, d_gt, L.pitch,
+                               n_variants, off, chunks, (int4 *)d_counts8, vpw);
+        else
+            hipLaunchKernelGGL((hpgv::k_stats_scan<false, kScanUnroll>), dim3(blocks), dim3(256), 0, st, d_gt, L.pitch,
+                               n_variants, off, chunks, (int4 *)d_counts8, vpw);
     });
 }
 

@@ -402,6 +402,7 @@ struct TdtPlan {
 // ---------------------------------------------------------------------------
 template <bool NT, int U>
 __global__ __launch_bounds__(256) void k_stats_scan(const uint8_t *__restrict__ gt, size_t pitch, int n_variants,
+                                                    uint32_t row_off /* start of the scanned segment */,
                                                     int chunks, int4 *__restrict__ out8, int vpw) {
     const int lane = threadIdx.x & 63;
     const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(256) void k_stats_scan(const uint8_t *__restrict__ 
     for (int i = 0; i < vpw; ++i) {
         const long v = v_begin + i;
         if (v >= n_variants) break;
-        const uint8_t *row = gt + (size_t)v * pitch;
+        const uint8_t *row = gt + (size_t)v * pitch + row_off;
         int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int base = 0; base < chunks; base += 64 * U) {
             uint4 q[U];

@@ -97,6 +97,12 @@ int  hpgv_set_logfact(hpgv_ctx *ctx, const double *table, size_t n);
 int  hpgv_set_stats_cohort(hpgv_ctx *ctx, int n_samples);
 int  hpgv_stats_layout(const hpgv_ctx *ctx, size_t *pitch);
 
+/* per-phenotype statistics (stats_runner.c:47-98,300-303,319-323 write one report per phenotype
+ * group): group_of_sample[j] in [0, n_groups) or < 0 for "in no group".  Builds the layout
+ * HPGV_LAYOUT_STATS_GROUPS = [group 0 columns | pad16 | group 1 columns | pad16 | ...]. */
+int  hpgv_set_stats_groups(hpgv_ctx *ctx, const int32_t *group_of_sample, int n_samples, int n_groups);
+int  hpgv_stats_groups_layout(const hpgv_ctx *ctx, size_t *pitch, int *group_sizes /* n_groups ints, may be NULL */);
+
 /* ---- device memory + streams (thin; callers may also pass memory owned by
  *      another runtime, e.g. a torch tensor's data_ptr) ---------------------- */
 int  hpgv_dev_alloc(hpgv_ctx *ctx, size_t bytes, void **dptr);
@@ -106,9 +112,9 @@ int  hpgv_memcpy_d2h(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, vo
 int  hpgv_stream_sync(hpgv_ctx *ctx, void *stream);   /* stream NULL = default stream */
 
 /* ---- layout kernels: VCF-order code matrix (device) -> engine layout ------ */
-/* which: 0 assoc, 1 tdt, 2 stats.  d_src rows are src_pitch bytes apart and hold
+/* which: 0 assoc, 1 tdt, 2 stats, 3 stats by phenotype group.  d_src rows are src_pitch bytes apart and hold
  * n_samples codes in VCF column order; d_dst rows use the layout's pitch. */
-enum { HPGV_LAYOUT_ASSOC = 0, HPGV_LAYOUT_TDT = 1, HPGV_LAYOUT_STATS = 2 };
+enum { HPGV_LAYOUT_ASSOC = 0, HPGV_LAYOUT_TDT = 1, HPGV_LAYOUT_STATS = 2, HPGV_LAYOUT_STATS_GROUPS = 3 };
 int  hpgv_layout_dev(hpgv_ctx *ctx, int which, const uint8_t *d_src, size_t src_pitch,
                      int n_variants, uint8_t *d_dst, void *stream);
 
@@ -147,6 +153,9 @@ int  hpgv_stats_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants,
                          int32_t *d_counts8, void *stream);
 int  hpgv_stats_hwe_dev(hpgv_ctx *ctx, const int32_t *d_counts8, int n_variants,
                         double *d_chi2, double *d_p, void *stream);
+/* the same counters restricted to one phenotype group; d_gt in the HPGV_LAYOUT_STATS_GROUPS layout */
+int  hpgv_stats_scan_group_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, int group,
+                               int32_t *d_counts8, void *stream);
 
 /* per-sample missing-genotype counts (get_sample_stats, call site stats_runner.c:197-198) over a
  * stats-layout matrix: d_missing[j] += number of listed variants in which sample j has a missing

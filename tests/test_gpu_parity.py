@@ -429,3 +429,32 @@ def test_maximum_row_length():
     gt = random_codes(rng, 8, 3 * n_tr, quirks=False)
     _tdt_check(e, gt, fam, np.array([0, 1] * 4, np.uint8))
     e.close()
+
+
+def test_stats_per_phenotype_group():
+    rng = np.random.default_rng(41)
+    n_samples, nv, n_groups = 1234, 150, 3
+    group = rng.integers(-1, n_groups, size=n_samples).astype(np.int32)     # -1: in no group
+    e = fresh()
+    pitch, sizes = e.set_stats_groups(group, n_groups)
+    assert [int(x) for x in sizes] == [int((group == k).sum()) for k in range(n_groups)]
+    gt = random_codes(rng, nv, n_samples, quirks=True, strict=False)
+    d_raw, d_lay, d_c8, d_hw = e.alloc(nv * n_samples), e.alloc(nv * pitch), e.alloc(nv * 32), e.alloc(nv * 16)
+    e.h2d(d_raw, gt)
+    e.layout(hpgv.LAYOUT_STATS_GROUPS, d_raw, n_samples, nv, d_lay)
+    for k in range(n_groups):
+        e.stats_scan_group(d_lay, nv, k, d_c8)
+        e.stats_hwe(d_c8, nv, d_hw, d_hw.value + 8 * nv)
+        e.sync()
+        c8 = e.d2h(d_c8, (nv, 8), np.int32)
+        hw = e.d2h(d_hw, (2, nv), np.float64)
+        sub = gt[:, group == k]
+        for i in range(nv):
+            vs = orc.variant_stats(np.ascontiguousarray(sub[i]), 2)
+            assert list(c8[i][:4]) == list(vs.genotypes_count)[:4]
+            assert (c8[i][4], c8[i][5], c8[i][6], c8[i][7]) == (vs.missing_genotypes, vs.missing_alleles,
+                                                                 vs.alleles_count[0], vs.alleles_count[1])
+            assert_close([hw[0][i]], [vs.hw_chi2], "hwe chi2"); assert_close([hw[1][i]], [vs.hw_p], "hwe p")
+    with pytest.raises(hpgv.HpgvError):
+        e.stats_scan_group(d_lay, nv, n_groups, d_c8)
+    e.close()
