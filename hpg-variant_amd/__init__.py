@@ -19,7 +19,7 @@ OK = 0
 TASK_CHISQ, TASK_FISHER = 1, 2
 COND_UNAFFECTED, COND_AFFECTED, COND_OTHER = 0, 1, 2
 SEX_MALE, SEX_FEMALE, SEX_UNKNOWN = 0, 1, 2
-LAYOUT_ASSOC, LAYOUT_TDT, LAYOUT_STATS, LAYOUT_STATS_GROUPS = 0, 1, 2, 3
+LAYOUT_ASSOC, LAYOUT_TDT, LAYOUT_STATS, LAYOUT_STATS_GROUPS, LAYOUT_MENDEL = 0, 1, 2, 3, 4
 GT_MISSING = 0xFF
 
 # every symbol include/hpgv.h declares (checked by the CPU suite)
@@ -28,12 +28,13 @@ SYMBOLS = [
     "hpgv_set_option", "hpgv_set_cohort", "hpgv_assoc_layout", "hpgv_set_families",
     "hpgv_tdt_layout", "hpgv_set_logfact", "hpgv_set_stats_cohort", "hpgv_stats_layout",
     "hpgv_set_stats_groups", "hpgv_stats_groups_layout", "hpgv_stats_scan_group_dev",
+    "hpgv_set_pedigree", "hpgv_mendel_layout", "hpgv_mendel_scan_dev", "hpgv_mendel_children_dev",
     "hpgv_dev_alloc", "hpgv_dev_free", "hpgv_memcpy_h2d", "hpgv_memcpy_d2h", "hpgv_stream_sync",
     "hpgv_layout_dev", "hpgv_synth_dev", "hpgv_synth_raw_dev",
     "hpgv_assoc_scan_dev", "hpgv_assoc_chisq_dev", "hpgv_assoc_fisher_dev",
     "hpgv_tdt_scan_dev", "hpgv_tdt_stats_dev", "hpgv_stats_scan_dev", "hpgv_stats_hwe_dev",
     "hpgv_sample_missing_dev", "hpgv_genotype_table_dev", "hpgv_stats_filter_dev",
-    "hpgv_tokenize_dev", "hpgv_tokenize", "hpgv_assoc_text", "hpgv_tdt_text",
+    "hpgv_mendel", "hpgv_tokenize_dev", "hpgv_tokenize", "hpgv_assoc_text", "hpgv_tdt_text",
     "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_read_probe",
 ]
 
@@ -107,6 +108,11 @@ def load():
     L.hpgv_set_stats_groups.argtypes = [vp, vp, i32, i32]
     L.hpgv_stats_groups_layout.argtypes = [vp, C.POINTER(sz), vp]
     L.hpgv_stats_scan_group_dev.argtypes = [vp, vp, i32, i32, vp, vp]
+    L.hpgv_set_pedigree.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+    L.hpgv_mendel_layout.argtypes = [vp, C.POINTER(sz)]
+    L.hpgv_mendel_scan_dev.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.hpgv_mendel_children_dev.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.hpgv_mendel.argtypes = [vp, vp, sz, i32, vp, vp, vp]
     L.hpgv_read_probe.argtypes = [vp, vp, sz, i32, C.POINTER(C.c_float)]
     _lib = L
     return L
@@ -199,6 +205,20 @@ class Engine:
     def stats_scan_group(self, d_gt, n_variants, group, d_counts8, stream=None):
         self._chk(self.L.hpgv_stats_scan_group_dev(self.h, d_gt, n_variants, group, d_counts8, stream))
 
+    def set_pedigree(self, n_samples, father_col, mother_col, child_col, child_sex):
+        f, m, c = _np(father_col, np.int32), _np(mother_col, np.int32), _np(child_col, np.int32)
+        s = _np(child_sex, np.uint8)
+        self._chk(self.L.hpgv_set_pedigree(self.h, n_samples, len(c), _ptr(f), _ptr(m), _ptr(c), _ptr(s)))
+        p = C.c_size_t()
+        self._chk(self.L.hpgv_mendel_layout(self.h, C.byref(p)))
+        return p.value
+
+    def mendel_scan(self, d_gt, n_variants, d_errors, d_is_x=None, stream=None):
+        self._chk(self.L.hpgv_mendel_scan_dev(self.h, d_gt, n_variants, d_is_x, d_errors, stream))
+
+    def mendel_children(self, d_gt, n_variants, d_child_errors, d_is_x=None, stream=None):
+        self._chk(self.L.hpgv_mendel_children_dev(self.h, d_gt, n_variants, d_is_x, d_child_errors, stream))
+
     # ---- device memory ------------------------------------------------------
     def alloc(self, nbytes):
         p = C.c_void_p()
@@ -252,6 +272,14 @@ class Engine:
         chi2, p = np.zeros(nv, np.float64), np.zeros(nv, np.float64)
         self._chk(self.L.hpgv_stats(self.h, _ptr(gt), pitch, nv, _ptr(c8), _ptr(chi2), _ptr(p)))
         return dict(counts8=c8, hwe_chi2=chi2, hwe_p=p)
+
+    def mendel(self, gt, is_x=None, child_errors=None):
+        gt = _np(gt, np.uint8)
+        nv, pitch = gt.shape
+        x = None if is_x is None else _np(is_x, np.uint8)
+        err = np.zeros(nv, np.int32)
+        self._chk(self.L.hpgv_mendel(self.h, _ptr(gt), pitch, nv, _ptr(x), _ptr(err), _ptr(child_errors)))
+        return err
 
     def stats_ex(self, gt, sample_missing=None, multi_cap=0):
         """hpgv_stats_ex: counters + HWE, per-sample missing counts accumulated into

@@ -67,6 +67,11 @@ struct hpgv_ctx {
     Layout sgroups;                       // [group 0 | pad16 | group 1 | ...]
     std::vector<uint32_t> sg_off;         // byte offset of every group's segment in the row
     std::vector<int> sg_size;             // samples per group
+    // mendelian errors
+    Layout mendel;
+    int mendel_trios = 0, mendel_pchunks = 0;
+    hpgv::MendelLuts mendel_luts{};
+    uint8_t *d_mendel_male = nullptr;
     // fisher
     double *d_lf = nullptr;
     size_t n_lf = 0;
@@ -233,7 +238,8 @@ void hpgv_destroy(hpgv_ctx *ctx) {
     if (!ctx) return;
     DeviceGuard g(ctx->device);
     (void)hipDeviceSynchronize();
-    for (Layout *L : {&ctx->assoc, &ctx->tdt, &ctx->stats, &ctx->sgroups})
+    if (ctx->d_mendel_male) (void)hipFree(ctx->d_mendel_male);
+    for (Layout *L : {&ctx->assoc, &ctx->tdt, &ctx->stats, &ctx->sgroups, &ctx->mendel})
         if (L->d_col_of_pos) (void)hipFree(L->d_col_of_pos);
     ctx->tdt_plan.release();
     if (ctx->d_lf) (void)hipFree(ctx->d_lf);
@@ -412,6 +418,47 @@ int hpgv_set_families(hpgv_ctx *ctx, int n_samples, int n_families, const int32_
     return upload_layout(ctx, L);
 }
 
+int hpgv_set_pedigree(hpgv_ctx *ctx, int n_samples, int n_trios, const int32_t *father_col, const int32_t *mother_col,
+                      const int32_t *child_col, const uint8_t *child_sex) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (n_samples < 0 || n_trios < 0 || (n_trios > 0 && (!father_col || !mother_col || !child_col || !child_sex)))
+        return fail(ctx, HPGV_ERR_INVALID, "bad pedigree arguments");
+    for (int t = 0; t < n_trios; ++t)
+        if (father_col[t] < 0 || father_col[t] >= n_samples || mother_col[t] < 0 || mother_col[t] >= n_samples ||
+            child_col[t] < 0 || child_col[t] >= n_samples)
+            return fail(ctx, HPGV_ERR_INVALID, "trio %d has a column out of range", t);
+    DeviceGuard g(ctx->device);
+    const size_t P16 = round_up((size_t)n_trios, 16);
+    size_t pitch = round_up(3 * P16, (size_t)ctx->row_align) + (size_t)ctx->row_pad;
+    if (pitch == 0) pitch = (size_t)ctx->row_align;
+    if (!pitch_supported(pitch)) return fail(ctx, HPGV_ERR_UNSUPPORTED, "pedigree exceeds the row-length limit");
+    Layout &L = ctx->mendel;
+    L.n_samples = n_samples;
+    L.pitch = pitch;
+    L.col_of_pos.assign(pitch, -1);
+    std::vector<uint8_t> male(P16 ? P16 : 16, 0);
+    for (int t = 0; t < n_trios; ++t) {
+        L.col_of_pos[(size_t)t] = father_col[t];
+        L.col_of_pos[P16 + (size_t)t] = mother_col[t];
+        L.col_of_pos[2 * P16 + (size_t)t] = child_col[t];
+        male[(size_t)t] = child_sex[t] == HPGV_SEX_MALE ? 0xFF : 0x00;
+    }
+    if (ctx->d_mendel_male) { (void)hipFree(ctx->d_mendel_male); ctx->d_mendel_male = nullptr; }
+    HIPCHK(ctx, hipMalloc(&ctx->d_mendel_male, male.size()));
+    HIPCHK(ctx, hipMemcpy(ctx->d_mendel_male, male.data(), male.size(), hipMemcpyHostToDevice));
+    hpgv::mendel_host::build_luts(ctx->mendel_luts);
+    ctx->mendel_trios = n_trios;
+    ctx->mendel_pchunks = (int)(P16 / 16);
+    return upload_layout(ctx, L);
+}
+
+int hpgv_mendel_layout(const hpgv_ctx *ctx, size_t *pitch) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->mendel.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_pedigree has not been called");
+    if (pitch) *pitch = ctx->mendel.pitch;
+    return HPGV_OK;
+}
+
 int hpgv_tdt_layout(const hpgv_ctx *ctx, int *n_trios_fast, int *n_families_slow, size_t *pitch) {
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->tdt.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_families has not been called");
@@ -464,6 +511,7 @@ static Layout *pick_layout(hpgv_ctx *ctx, int which) {
         case HPGV_LAYOUT_TDT: return &ctx->tdt;
         case HPGV_LAYOUT_STATS: return &ctx->stats;
         case HPGV_LAYOUT_STATS_GROUPS: return &ctx->sgroups;
+        case HPGV_LAYOUT_MENDEL: return &ctx->mendel;
         default: return nullptr;
     }
 }
@@ -473,6 +521,7 @@ static void recode_of(const hpgv_ctx *ctx, int which, int *mode, int *p16) {
     *mode = hpgv::RECODE_NONE; *p16 = 0;
     if (which == HPGV_LAYOUT_TDT) { *mode = hpgv::RECODE_TDT; *p16 = ctx->tdt_plan.p16; }
     else if (which == HPGV_LAYOUT_STATS || which == HPGV_LAYOUT_STATS_GROUPS) { *mode = hpgv::RECODE_STATS; }
+    else if (which == HPGV_LAYOUT_MENDEL) { *mode = hpgv::RECODE_MENDEL; }
 }
 
 int hpgv_layout_dev(hpgv_ctx *ctx, int which, const uint8_t *d_src, size_t src_pitch, int n_variants,
@@ -750,6 +799,43 @@ int hpgv_stats_hwe_dev(hpgv_ctx *ctx, const int32_t *d_counts8, int n_variants, 
     });
 }
 
+int hpgv_mendel_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, const uint8_t *d_is_x, int32_t *d_errors, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->mendel.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_pedigree has not been called");
+    if (n_variants < 0 || (n_variants > 0 && (!d_gt || !d_errors))) return fail(ctx, HPGV_ERR_INVALID, "bad scan arguments");
+    if (n_variants == 0) return HPGV_OK;
+    if ((uintptr_t)d_gt & 15) return fail(ctx, HPGV_ERR_INVALID, "device buffers must be 16-byte aligned");
+    DeviceGuard g(ctx->device);
+    const int vpw = (int)ctx->vpw;
+    const long waves = ((long)n_variants + vpw - 1) / vpw;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    return launch_profiled(ctx, st, 0, [&] {
+        if (ctx->nontemporal)
+            hipLaunchKernelGGL((hpgv::k_mendel_scan<true, 4>), dim3(blocks), dim3(256), 0, st, d_gt, ctx->mendel.pitch, n_variants,
+                               ctx->mendel_pchunks, ctx->mendel_luts, ctx->d_mendel_male, d_is_x, d_errors, vpw);
+        else
+            hipLaunchKernelGGL((hpgv::k_mendel_scan<false, 4>), dim3(blocks), dim3(256), 0, st, d_gt, ctx->mendel.pitch, n_variants,
+                               ctx->mendel_pchunks, ctx->mendel_luts, ctx->d_mendel_male, d_is_x, d_errors, vpw);
+    });
+}
+
+int hpgv_mendel_children_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, const uint8_t *d_is_x,
+                             int32_t *d_child_errors, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->mendel.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_pedigree has not been called");
+    if (n_variants < 0 || (n_variants > 0 && (!d_gt || !d_child_errors))) return fail(ctx, HPGV_ERR_INVALID, "bad scan arguments");
+    if (n_variants == 0 || ctx->mendel_trios == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    const unsigned tiles = (unsigned)((ctx->mendel_pchunks + 63) / 64);
+    dim3 grid((tiles + 3) / 4, (unsigned)((n_variants + hpgv::SAMPLE_STATS_ROWS - 1) / hpgv::SAMPLE_STATS_ROWS));
+    if (grid.y > 65535u) return fail(ctx, HPGV_ERR_UNSUPPORTED, "more than %d variants per call", 65535 * hpgv::SAMPLE_STATS_ROWS);
+    hipLaunchKernelGGL(hpgv::k_mendel_children, grid, dim3(256), 0, (hipStream_t)stream, d_gt, ctx->mendel.pitch, n_variants,
+                       ctx->mendel_pchunks, ctx->mendel_trios, ctx->mendel_luts, ctx->d_mendel_male, d_is_x, d_child_errors);
+    HIPCHK(ctx, hipGetLastError());
+    return HPGV_OK;
+}
+
 int hpgv_stats_filter_dev(hpgv_ctx *ctx, const int32_t *d_counts8, int n_variants, double min_maf, double max_maf,
                           double max_missing, uint8_t *d_keep, void *stream) {
     if (!ctx) return HPGV_ERR_INVALID;
@@ -972,6 +1058,39 @@ int hpgv_stats_ex(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants
 int hpgv_stats(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, int32_t *counts8,
                double *hwe_chi2, double *hwe_p) {
     return hpgv_stats_ex(ctx, gt, pitch, n_variants, counts8, hwe_chi2, hwe_p, nullptr, nullptr, nullptr, nullptr);
+}
+
+int hpgv_mendel(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, const uint8_t *is_x,
+                int32_t *errors, int32_t *child_errors) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->mendel.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_pedigree has not been called");
+    if (n_variants < 0 || (n_variants > 0 && !gt)) return fail(ctx, HPGV_ERR_INVALID, "bad mendel arguments");
+    if (pitch < (size_t)ctx->mendel.n_samples) return fail(ctx, HPGV_ERR_INVALID, "pitch %zu < n_samples %d", pitch, ctx->mendel.n_samples);
+    if (n_variants == 0 || (!errors && !child_errors)) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    SlotLease lease(ctx);
+    int rc = acquire_slot(ctx, &lease.s);
+    if (rc) return rc;
+    Slot *s = lease.s;
+    const uint8_t *d_isx = nullptr;
+    if ((rc = stage_batch(ctx, s, HPGV_LAYOUT_MENDEL, ctx->mendel, gt, pitch, n_variants, is_x, &d_isx))) return rc;
+    const size_t n = (size_t)n_variants, nt = (size_t)ctx->mendel_trios;
+    if ((rc = ensure(ctx, s, 3, n * sizeof(int32_t) + 16))) return rc;
+    if ((rc = ensure(ctx, s, 5, nt * sizeof(int32_t) + 16))) return rc;
+    std::vector<int32_t> ce;
+    if (errors) {
+        if ((rc = hpgv_mendel_scan_dev(ctx, (const uint8_t *)s->buf[1], n_variants, d_isx, (int32_t *)s->buf[3], s->stream))) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(errors, s->buf[3], n * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    }
+    if (child_errors && nt) {
+        HIPCHK(ctx, hipMemsetAsync(s->buf[5], 0, nt * sizeof(int32_t), s->stream));
+        if ((rc = hpgv_mendel_children_dev(ctx, (const uint8_t *)s->buf[1], n_variants, d_isx, (int32_t *)s->buf[5], s->stream))) return rc;
+        ce.resize(nt);
+        HIPCHK(ctx, hipMemcpyAsync(ce.data(), s->buf[5], nt * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    for (size_t t = 0; t < ce.size(); ++t) child_errors[t] += ce[t];
+    return HPGV_OK;
 }
 
 /* ---- text staging ------------------------------------------------------------ */

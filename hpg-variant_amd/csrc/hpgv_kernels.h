@@ -439,9 +439,11 @@ __device__ __forceinline__ uint32_t synth_gt(uint64_t vterm, uint64_t s, uint32_
 //   RECODE_TDT   : positions [0,p16) father / [p16,2p16) mother planes hold the
 //                  parent class, [2p16,3p16) the child class (tdt classes below)
 //   RECODE_STATS : one-hot genotype cell / missing / extra-allele flags
+//   RECODE_MENDEL: zero-ness class 0 "0/0", 1 one zero allele, 2 no zero allele, 3 not fully called
+//                  (what check_mendel looks at), in father / mother / child planes
 // Every class is a function of that ONE genotype and of the column's fixed role.
 // ---------------------------------------------------------------------------
-enum { RECODE_NONE = 0, RECODE_TDT = 1, RECODE_STATS = 2 };
+enum { RECODE_NONE = 0, RECODE_TDT = 1, RECODE_STATS = 2, RECODE_MENDEL = 3 };
 
 // parent classes (tdt.c:113-123 tests): 0 "0/0", 1 "0/x", 2 "x/x" (equal, non-zero),
 // 3 "x/y" (both non-zero, different); unusable = missing or "x/0" (tdt.c:103-108,119)
@@ -480,6 +482,13 @@ __host__ __device__ __forceinline__ uint32_t stats_flags(uint32_t g) {
     return f;
 }
 
+__host__ __device__ __forceinline__ uint32_t mendel_class(uint32_t g) {
+    const uint32_t a1 = g >> 4, a2 = g & 0xFu;
+    if (a1 == 0xFu || a2 == 0xFu) return 3u;
+    if (!a1 && !a2) return 0u;
+    return (a1 && a2) ? 2u : 1u;
+}
+
 // g: HPGV8 byte (0xFF for padding), pos: byte position in the row
 __device__ __forceinline__ uint32_t recode_byte(uint32_t g, int mode, int p16, int pos, bool is_pad) {
     if (mode == RECODE_TDT) {
@@ -489,6 +498,7 @@ __device__ __forceinline__ uint32_t recode_byte(uint32_t g, int mode, int p16, i
         return tdt_child_class(g);
     }
     if (mode == RECODE_STATS) return is_pad ? 0u : stats_flags(g);
+    if (mode == RECODE_MENDEL) return mendel_class(g);
     return g;
 }
 

@@ -497,6 +497,144 @@ __global__ __launch_bounds__(256) void k_genotype_table(const uint8_t *__restric
 }
 
 // ---------------------------------------------------------------------------
+// Mendelian errors per variant and per child (hpg-libs check_mendel, used by the
+// --mendel filter and by get_sample_stats; rule = mendel_code above).  Rows hold three
+// planes [father | mother | child] of zero-ness classes.  ERR[m*4+f] is a 3-bit mask:
+// bit c set <=> a child of class c is an error for that parent pair; the child byte
+// selects its bit through an 8-entry v_perm table.  Chr "X" male children use the
+// second table (only the mother matters).
+// ---------------------------------------------------------------------------
+struct MendelLut { uint32_t lo[2], hi[2]; };            // ERR[0..7], ERR[8..15]
+struct MendelLuts { MendelLut autosome, xmale; };
+
+__device__ __forceinline__ uint32_t mendel_err4(const MendelLut &L, uint32_t idx, uint32_t c) {
+    const uint32_t sel = idx & 0x07070707u;
+    const uint32_t lo = lut8(L.lo[0], L.lo[1], sel), hi = lut8(L.hi[0], L.hi[1], sel);
+    const uint32_t pair = __builtin_amdgcn_perm(hi, lo, ((idx >> 1) & 0x04040404u) | 0x03020100u);
+    // child class -> its bit (class 3 = not called -> 0)
+    const uint32_t cbit = lut8(0x00040201u, 0u, c);
+    return pair & cbit;
+}
+// 0 / 1 per byte: is one of bits 0..2 set?
+__device__ __forceinline__ uint32_t any3(uint32_t z) { return (z | (z >> 1) | (z >> 2)) & 0x01010101u; }
+
+template <bool X>
+__device__ __forceinline__ uint32_t mendel4(const MendelLuts &L, uint32_t f, uint32_t m, uint32_t c, uint32_t male) {
+    const uint32_t idx = (m << 2) | f;
+    uint32_t z = mendel_err4(L.autosome, idx, c);
+    if constexpr (X) {
+        const uint32_t zx = mendel_err4(L.xmale, idx, c);
+        z = (male & zx) | (~male & z);
+    }
+    return any3(z);
+}
+
+template <bool NT, int U>
+__global__ __launch_bounds__(256) void k_mendel_scan(const uint8_t *__restrict__ gt, size_t pitch, int n_variants,
+                                                     int pchunks, MendelLuts luts, const uint8_t *__restrict__ male_plane,
+                                                     const uint8_t *__restrict__ is_x, int32_t *__restrict__ errors, int vpw) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long v_begin = wave * vpw;
+    const uint32_t plane = (uint32_t)pchunks * 16u;
+    for (int i = 0; i < vpw; ++i) {
+        const long v = v_begin + i;
+        if (v >= n_variants) break;
+        const uint8_t *rowb = gt + (size_t)v * pitch;
+        const bool x_row = (is_x != nullptr) && (__builtin_amdgcn_readfirstlane((int)is_x[v]) != 0);
+        int n = 0;
+        for (int base = 0; base < pchunks; base += 64 * U) {
+            uint4 qf[U], qm[U], qc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = base + u * 64 + lane;
+                qf[u] = qm[u] = qc[u] = make_uint4(0x03030303u, 0x03030303u, 0x03030303u, 0x03030303u);   // not called
+                if (c < pchunks) {
+                    qf[u] = load16o<NT>(rowb, (uint32_t)c * 16u);
+                    qm[u] = load16o<NT>(rowb, (uint32_t)c * 16u + plane);
+                    qc[u] = load16o<NT>(rowb, (uint32_t)c * 16u + 2u * plane);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = base + u * 64 + lane;
+                uint4 ml = make_uint4(0, 0, 0, 0);
+                if (x_row && c < pchunks) ml = reinterpret_cast<const uint4 *>(male_plane)[c];
+                if (!x_row) {
+                    n += __builtin_popcount(mendel4<false>(luts, qf[u].x, qm[u].x, qc[u].x, 0)) +
+                         __builtin_popcount(mendel4<false>(luts, qf[u].y, qm[u].y, qc[u].y, 0)) +
+                         __builtin_popcount(mendel4<false>(luts, qf[u].z, qm[u].z, qc[u].z, 0)) +
+                         __builtin_popcount(mendel4<false>(luts, qf[u].w, qm[u].w, qc[u].w, 0));
+                } else {
+                    n += __builtin_popcount(mendel4<true>(luts, qf[u].x, qm[u].x, qc[u].x, ml.x)) +
+                         __builtin_popcount(mendel4<true>(luts, qf[u].y, qm[u].y, qc[u].y, ml.y)) +
+                         __builtin_popcount(mendel4<true>(luts, qf[u].z, qm[u].z, qc[u].z, ml.z)) +
+                         __builtin_popcount(mendel4<true>(luts, qf[u].w, qm[u].w, qc[u].w, ml.w));
+                }
+            }
+        }
+        const int tot = wave_sum(n);
+        if (lane == 0) errors[v] = tot;
+    }
+}
+
+// per-child error counts: tile of 1024 trios x SAMPLE_STATS_ROWS variants, SWAR byte lanes, atomics at the end
+__global__ __launch_bounds__(256) void k_mendel_children(const uint8_t *__restrict__ gt, size_t pitch, int n_variants,
+                                                         int pchunks, int n_trios, MendelLuts luts,
+                                                         const uint8_t *__restrict__ male_plane,
+                                                         const uint8_t *__restrict__ is_x, int32_t *__restrict__ child_errors) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int c = tile * 64 + lane;
+    const long v0 = (long)blockIdx.y * SAMPLE_STATS_ROWS;
+    if (tile * 64 >= pchunks || c >= pchunks) return;
+    const uint32_t plane = (uint32_t)pchunks * 16u;
+    const int rows = (int)((v0 + SAMPLE_STATS_ROWS <= n_variants) ? SAMPLE_STATS_ROWS : (n_variants - v0));
+    const uint4 ml = reinterpret_cast<const uint4 *>(male_plane)[c];
+    uint32_t acc[4] = {0, 0, 0, 0};
+    for (int r = 0; r < rows; ++r) {
+        const uint8_t *rowb = gt + (size_t)(v0 + r) * pitch;
+        const uint4 f = load16o<true>(rowb, (uint32_t)c * 16u), m = load16o<true>(rowb, (uint32_t)c * 16u + plane);
+        const uint4 k = load16o<true>(rowb, (uint32_t)c * 16u + 2u * plane);
+        if (is_x != nullptr && is_x[v0 + r]) {
+            acc[0] += mendel4<true>(luts, f.x, m.x, k.x, ml.x); acc[1] += mendel4<true>(luts, f.y, m.y, k.y, ml.y);
+            acc[2] += mendel4<true>(luts, f.z, m.z, k.z, ml.z); acc[3] += mendel4<true>(luts, f.w, m.w, k.w, ml.w);
+        } else {
+            acc[0] += mendel4<false>(luts, f.x, m.x, k.x, 0); acc[1] += mendel4<false>(luts, f.y, m.y, k.y, 0);
+            acc[2] += mendel4<false>(luts, f.z, m.z, k.z, 0); acc[3] += mendel4<false>(luts, f.w, m.w, k.w, 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = c * 16 + q * 4 + j;
+            const int n = (int)((acc[q] >> (8 * j)) & 0xFFu);
+            if (n && t < n_trios) atomicAdd(child_errors + t, n);
+        }
+}
+
+namespace mendel_host {
+inline void build_luts(MendelLuts &out) {
+    static const int G[3][2] = {{0, 0}, {0, 1}, {1, 1}};          // class representatives
+    for (int x = 0; x < 2; ++x) {
+        uint8_t err[16];
+        for (int m = 0; m < 4; ++m)
+            for (int f = 0; f < 4; ++f) {
+                uint8_t mask = 0;
+                if (f < 3 && m < 3)
+                    for (int c = 0; c < 3; ++c)
+                        if (mendel_code(x == 1, G[f][0], G[f][1], G[m][0], G[m][1], G[c][0], G[c][1])) mask |= (uint8_t)(1u << c);
+                err[m * 4 + f] = mask;
+            }
+        auto dw = [](const uint8_t *b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); };
+        MendelLut &L = x ? out.xmale : out.autosome;
+        L.lo[0] = dw(err); L.lo[1] = dw(err + 4); L.hi[0] = dw(err + 8); L.hi[1] = dw(err + 12);
+    }
+}
+}  // namespace mendel_host
+
+// ---------------------------------------------------------------------------
 // count-derived variant filters (shared_options.c:42-47,86-115: --maf, --missing;
 // predicates live in hpg-libs, absent: directions are explicit parameters here).
 // keep[i] = 1 iff every enabled test passes; a negative threshold disables a test.

@@ -341,6 +341,7 @@ static struct {
 } g_assoc_key;
 static struct { int num_families; int num_columns; uint64_t hash; int set; } g_tdt_key;
 static struct { int num_samples; int set; } g_stats_key;
+static struct { int num_samples; int n_trios; uint64_t hash; int set; } g_ped_key;
 static struct { const void *table; int n; } g_lf_key;
 
 const char *hpgv_host_last_error(void) { return g_err; }
@@ -369,6 +370,7 @@ void hpgv_host_shutdown(void) {
     memset(&g_assoc_key, 0, sizeof g_assoc_key);
     memset(&g_tdt_key, 0, sizeof g_tdt_key);
     memset(&g_stats_key, 0, sizeof g_stats_key);
+    memset(&g_ped_key, 0, sizeof g_ped_key);
     memset(&g_lf_key, 0, sizeof g_lf_key);
     pthread_mutex_unlock(&g_init_mu);
 }
@@ -757,23 +759,63 @@ int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t *
 
 int get_sample_stats(vcf_record_t **variants, int num_variants, individual_t **individuals,
                      sample_ids_t *sample_ids, sample_stats_t **sample_stats, file_stats_t *file_stats) {
-    (void)individuals; (void)sample_ids; (void)file_stats;   /* Mendelian errors per sample: DESIGN.md "Not yet" */
+    (void)file_stats;
     if (num_variants <= 0) return 0;
     int rc = ensure_engine();
     if (rc) return rc;
     int num_samples = (int)variants[0]->samples->size;
     size_t n = (size_t)num_variants, pitch = (size_t)(num_samples > 0 ? num_samples : 1);
-    uint8_t *gt = (uint8_t *)malloc(n * pitch);
+    uint8_t *gt = (uint8_t *)malloc(n * pitch + n);
     int32_t *c8 = (int32_t *)malloc(n * 8 * sizeof(int32_t));
     double *hw = (double *)malloc(n * 2 * sizeof(double));
     int32_t *miss = (int32_t *)calloc((size_t)(num_samples > 0 ? num_samples : 1), sizeof(int32_t));
-    if (!gt || !c8 || !hw || !miss) { free(gt); free(c8); free(hw); free(miss); snprintf(g_err, sizeof g_err, "out of memory"); return HPGV_ERR_NOMEM; }
-    hpgv_host_stage_records(variants, num_variants, num_samples, 0, gt, NULL);
+    /* trios for the Mendelian check: every individual (VCF column j) whose father and mother are VCF columns too */
+    int n_trios = 0;
+    int32_t *tf = (int32_t *)malloc(pitch * sizeof(int32_t)), *tm = (int32_t *)malloc(pitch * sizeof(int32_t));
+    int32_t *tc = (int32_t *)malloc(pitch * sizeof(int32_t)), *terr = (int32_t *)calloc(pitch, sizeof(int32_t));
+    uint8_t *ts = (uint8_t *)malloc(pitch);
+    if (!gt || !c8 || !hw || !miss || !tf || !tm || !tc || !ts || !terr) {
+        free(gt); free(c8); free(hw); free(miss); free(tf); free(tm); free(tc); free(ts); free(terr);
+        snprintf(g_err, sizeof g_err, "out of memory");
+        return HPGV_ERR_NOMEM;
+    }
+    uint8_t *is_x = gt + n * pitch;
+    uint64_t h = 1469598103934665603ULL;
+    if (individuals && sample_ids) {
+        for (int j = 0; j < num_samples; j++) {
+            individual_t *ind = individuals[j];
+            if (!ind || !ind->father || !ind->mother) continue;
+            int fp = sample_ids_get(sample_ids, ind->father->id), mp = sample_ids_get(sample_ids, ind->mother->id);
+            if (fp < 0 || mp < 0 || fp >= num_samples || mp >= num_samples) continue;
+            tf[n_trios] = fp; tm[n_trios] = mp; tc[n_trios] = j;
+            ts[n_trios] = (ind->sex == MALE) ? HPGV_SEX_MALE : (ind->sex == FEMALE) ? HPGV_SEX_FEMALE : HPGV_SEX_UNKNOWN;
+            h = (h ^ (uint64_t)(uint32_t)fp ^ ((uint64_t)(uint32_t)mp << 20) ^ ((uint64_t)j << 40) ^ ((uint64_t)ts[n_trios] << 62)) * 1099511628211ULL;
+            n_trios++;
+        }
+    }
+    hpgv_host_stage_records(variants, num_variants, num_samples, 0, gt, is_x);
     pthread_rwlock_rdlock(&g_cohort_lock);
     rc = stats_prepare(num_samples);
     if (rc == HPGV_OK) {
         rc = hpgv_stats_ex(g_ctx, gt, pitch, num_variants, c8, hw, hw + n, miss, NULL, NULL, NULL);
         if (rc != HPGV_OK) host_fail("hpgv_stats_ex", rc);
+    }
+    if (rc == HPGV_OK && n_trios > 0) {
+        if (!(g_ped_key.set && g_ped_key.num_samples == num_samples && g_ped_key.n_trios == n_trios && g_ped_key.hash == h)) {
+            pthread_rwlock_unlock(&g_cohort_lock);
+            pthread_rwlock_wrlock(&g_cohort_lock);
+            if (!(g_ped_key.set && g_ped_key.num_samples == num_samples && g_ped_key.n_trios == n_trios && g_ped_key.hash == h)) {
+                rc = hpgv_set_pedigree(g_ctx, num_samples, n_trios, tf, tm, tc, ts);
+                if (rc == HPGV_OK) { g_ped_key.set = 1; g_ped_key.num_samples = num_samples; g_ped_key.n_trios = n_trios; g_ped_key.hash = h; }
+                else host_fail("hpgv_set_pedigree", rc);
+            }
+            pthread_rwlock_unlock(&g_cohort_lock);
+            pthread_rwlock_rdlock(&g_cohort_lock);
+        }
+        if (rc == HPGV_OK) {
+            rc = hpgv_mendel(g_ctx, gt, pitch, num_variants, is_x, NULL, terr);
+            if (rc != HPGV_OK) host_fail("hpgv_mendel", rc);
+        }
     }
     pthread_rwlock_unlock(&g_cohort_lock);
     if (rc == HPGV_OK) {
@@ -781,9 +823,10 @@ int get_sample_stats(vcf_record_t **variants, int num_variants, individual_t **i
         static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
         pthread_mutex_lock(&mu);
         for (int j = 0; j < num_samples; j++) sample_stats[j]->missing_genotypes += miss[j];
+        for (int t = 0; t < n_trios; t++) sample_stats[tc[t]]->mendelian_errors += terr[t];
         pthread_mutex_unlock(&mu);
     }
-    free(gt); free(c8); free(hw); free(miss);
+    free(gt); free(c8); free(hw); free(miss); free(tf); free(tm); free(tc); free(ts); free(terr);
     return rc;
 }
 

@@ -103,6 +103,13 @@ int  hpgv_stats_layout(const hpgv_ctx *ctx, size_t *pitch);
 int  hpgv_set_stats_groups(hpgv_ctx *ctx, const int32_t *group_of_sample, int n_samples, int n_groups);
 int  hpgv_stats_groups_layout(const hpgv_ctx *ctx, size_t *pitch, int *group_sizes /* n_groups ints, may be NULL */);
 
+/* Mendelian errors (hpg-libs check_mendel: the --mendel filter of shared_options.c:45,101-105 and the
+ * per-sample counter of get_sample_stats): every child with both parents among the VCF columns is one
+ * trio, whatever its phenotype.  Layout HPGV_LAYOUT_MENDEL = [father | mother | child] class planes. */
+int  hpgv_set_pedigree(hpgv_ctx *ctx, int n_samples, int n_trios, const int32_t *father_col,
+                       const int32_t *mother_col, const int32_t *child_col, const uint8_t *child_sex);
+int  hpgv_mendel_layout(const hpgv_ctx *ctx, size_t *pitch);
+
 /* ---- device memory + streams (thin; callers may also pass memory owned by
  *      another runtime, e.g. a torch tensor's data_ptr) ---------------------- */
 int  hpgv_dev_alloc(hpgv_ctx *ctx, size_t bytes, void **dptr);
@@ -112,9 +119,10 @@ int  hpgv_memcpy_d2h(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, vo
 int  hpgv_stream_sync(hpgv_ctx *ctx, void *stream);   /* stream NULL = default stream */
 
 /* ---- layout kernels: VCF-order code matrix (device) -> engine layout ------ */
-/* which: 0 assoc, 1 tdt, 2 stats, 3 stats by phenotype group.  d_src rows are src_pitch bytes apart and hold
+/* which: 0 assoc, 1 tdt, 2 stats, 3 stats by phenotype group, 4 Mendelian-error trios.  d_src rows are src_pitch bytes apart and hold
  * n_samples codes in VCF column order; d_dst rows use the layout's pitch. */
-enum { HPGV_LAYOUT_ASSOC = 0, HPGV_LAYOUT_TDT = 1, HPGV_LAYOUT_STATS = 2, HPGV_LAYOUT_STATS_GROUPS = 3 };
+enum { HPGV_LAYOUT_ASSOC = 0, HPGV_LAYOUT_TDT = 1, HPGV_LAYOUT_STATS = 2, HPGV_LAYOUT_STATS_GROUPS = 3,
+       HPGV_LAYOUT_MENDEL = 4 };
 int  hpgv_layout_dev(hpgv_ctx *ctx, int which, const uint8_t *d_src, size_t src_pitch,
                      int n_variants, uint8_t *d_dst, void *stream);
 
@@ -169,6 +177,14 @@ int  hpgv_sample_missing_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants,
 int  hpgv_genotype_table_dev(hpgv_ctx *ctx, const uint8_t *d_raw, size_t src_pitch, int n_samples,
                              const int32_t *d_variant_idx, int n_idx, int32_t *d_table, void *stream);
 
+/* d_gt in the HPGV_LAYOUT_MENDEL layout -> d_errors[v] = trios with a Mendelian error at variant v */
+int  hpgv_mendel_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, const uint8_t *d_is_x,
+                          int32_t *d_errors, void *stream);
+/* d_child_errors[t] += variants at which trio t (order of hpgv_set_pedigree) has a Mendelian error;
+ * the caller zeroes the n_trios counters before the first batch */
+int  hpgv_mendel_children_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, const uint8_t *d_is_x,
+                              int32_t *d_child_errors, void *stream);
+
 /* count-derived variant filters (--maf, --missing of shared_options.c:42-47,86-115) from the stats
  * counters: d_keep[i] = 1 iff maf >= min_maf, maf <= max_maf and missing rate <= max_missing, where a
  * negative threshold switches that test off; maf = min(allele0, allele1) / (allele0 + allele1),
@@ -202,6 +218,11 @@ int  hpgv_stats(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants,
 int  hpgv_stats_ex(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants,
                    int32_t *counts8, double *hwe_chi2, double *hwe_p, int32_t *sample_missing,
                    int32_t *multi_idx, int32_t *multi_table, int *n_multi);
+
+/* Mendelian errors of a host batch: errors[v] per variant (may be NULL) and child_errors[t] per trio of
+ * hpgv_set_pedigree, ACCUMULATED into (may be NULL) */
+int  hpgv_mendel(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, const uint8_t *is_x,
+                 int32_t *errors, int32_t *child_errors);
 
 /* ---- VCF text -> HPGV8 on the GPU (replaces the per-genotype
  *      strdup + get_alleles of assoc.c:45-56 / tdt.c:97-108,150-157) ------------------

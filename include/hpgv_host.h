@@ -189,7 +189,7 @@ void variant_stats_free(variant_stats_t *stats);
 typedef struct {                       /* sample_stats_t (stats_runner.c:158-160): per-sample counters */
     char *name;
     int missing_genotypes;
-    int mendelian_errors;              /* not computed yet (DESIGN.md "Not yet") */
+    int mendelian_errors;              /* variants at which the sample, as a child, contradicts its parents */
 } sample_stats_t;
 
 sample_stats_t *sample_stats_new(char *name);

@@ -365,6 +365,24 @@ void orc_tdt_packed(const uint8_t *gt, size_t pitch, int n_variants,
     }
 }
 
+void orc_mendel_counts(const uint8_t *gt, size_t pitch, int n_variants, const uint8_t *chrom_is_x,
+                       int n_trios, const int32_t *father_col, const int32_t *mother_col,
+                       const int32_t *child_col, const uint8_t *child_sex,
+                       int32_t *errors, int32_t *trio_errors) {
+    for (int v = 0; v < n_variants; v++) {
+        const uint8_t *row = gt + (size_t)v * pitch;
+        const char *chrom = (chrom_is_x && chrom_is_x[v]) ? "X" : "1";
+        int n = 0;
+        for (int t = 0; t < n_trios; t++) {
+            int f1, f2, m1, m2, c1, c2;
+            if (orc_decode(row[father_col[t]], &f1, &f2) || orc_decode(row[mother_col[t]], &m1, &m2) ||
+                orc_decode(row[child_col[t]], &c1, &c2)) continue;
+            if (orc_check_mendel(chrom, f1, f2, m1, m2, c1, c2, child_sex[t])) { n++; if (trio_errors) trio_errors[t]++; }
+        }
+        if (errors) errors[v] = n;
+    }
+}
+
 /* tdt.c:255-260 (chi-square, int arithmetic before the cast) and 279-292 */
 void orc_tdt_stats(int n_variants, const int32_t *t1, const int32_t *t2,
                    double *odds, double *chisq, double *p) {

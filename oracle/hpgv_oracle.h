@@ -99,6 +99,13 @@ void orc_tdt_packed(const uint8_t *gt, size_t pitch, int n_variants,
                     int n_families, const int32_t *father_col, const int32_t *mother_col,
                     const int32_t *child_off, const int32_t *child_col, const uint8_t *child_sex,
                     int32_t *t1, int32_t *t2);
+/* Mendelian errors of trios (father_col, mother_col, child_col, child_sex)[n_trios] through
+ * orc_check_mendel, counted per variant (errors[v]) and per trio (trio_errors[t], accumulated);
+ * a trio with any genotype not ALLELES_OK is not checked */
+void orc_mendel_counts(const uint8_t *gt, size_t pitch, int n_variants, const uint8_t *chrom_is_x,
+                       int n_trios, const int32_t *father_col, const int32_t *mother_col,
+                       const int32_t *child_col, const uint8_t *child_sex,
+                       int32_t *errors, int32_t *trio_errors);
 void orc_tdt_stats(int n_variants, const int32_t *t1, const int32_t *t2,
                    double *odds, double *chisq, double *p);
 

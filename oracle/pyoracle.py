@@ -84,6 +84,8 @@ def lib():
     L.orc_tdt_packed.restype = None
     L.orc_tdt_packed.argtypes = [p_u8, C.c_size_t, C.c_int, p_u8, C.c_int,
                                  p_i32, p_i32, p_i32, p_i32, p_u8, p_i32, p_i32]
+    L.orc_mendel_counts.restype = None
+    L.orc_mendel_counts.argtypes = [p_u8, C.c_size_t, C.c_int, p_u8, C.c_int, p_i32, p_i32, p_i32, p_u8, p_i32, p_i32]
     L.orc_tdt_stats.restype = None
     L.orc_tdt_stats.argtypes = [C.c_int, p_i32, p_i32, p_f64, p_f64, p_f64]
     L.orc_variant_stats.restype = None
@@ -182,6 +184,19 @@ def tdt_counts(gt, father_col, mother_col, child_off, child_col, child_sex, chro
                          _p(fc, C.c_int32), _p(mc, C.c_int32), _p(co, C.c_int32),
                          _p(cc, C.c_int32), _p(cs, C.c_uint8), _p(t1, C.c_int32), _p(t2, C.c_int32))
     return t1, t2
+
+
+def mendel_counts(gt, father_col, mother_col, child_col, child_sex, chrom_is_x=None):
+    gt = np.ascontiguousarray(gt, dtype=np.uint8)
+    nv, pitch = gt.shape
+    fc, mc, cc = (np.ascontiguousarray(a, dtype=np.int32) for a in (father_col, mother_col, child_col))
+    cs = np.ascontiguousarray(child_sex, dtype=np.uint8)
+    x = None if chrom_is_x is None else np.ascontiguousarray(chrom_is_x, dtype=np.uint8)
+    errors = np.zeros(nv, np.int32)
+    trio = np.zeros(len(cc), np.int32)
+    lib().orc_mendel_counts(_p(gt, C.c_uint8), pitch, nv, _p(x, C.c_uint8), len(cc), _p(fc, C.c_int32), _p(mc, C.c_int32),
+                            _p(cc, C.c_int32), _p(cs, C.c_uint8), _p(errors, C.c_int32), _p(trio, C.c_int32))
+    return errors, trio
 
 
 def tdt_stats(t1, t2):

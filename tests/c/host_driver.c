@@ -307,9 +307,18 @@ static int cmd_tdt(const char *batch_path, const char *ped_path, const char *pre
     return 0;
 }
 
-static int cmd_stats(const char *batch_path, const char *out_path) {
+static int cmd_stats(const char *batch_path, const char *out_path, const char *ped_path) {
     batch_file_t b;
     if (load_batch(batch_path, &b)) return 2;
+    individual_t **individuals = NULL;
+    sample_ids_t *ids = NULL;
+    ped_t ped;
+    if (ped_path) {                                       /* stats_runner.c:165-170 */
+        if (load_ped(ped_path, &ped)) return 2;
+        individuals = (individual_t **)calloc((size_t)b.n_samples + 1, sizeof(void *));
+        ids = sample_ids_new((size_t)b.n_samples);
+        for (int j = 0; j < b.n_samples; j++) { individuals[j] = find_person(&ped, b.sample_names[j]); sample_ids_put(ids, b.sample_names[j], j); }
+    }
     list_t out;
     list_init("output", 1, 0, &out);
     file_stats_t *fs = file_stats_new();
@@ -319,8 +328,8 @@ static int cmd_stats(const char *batch_path, const char *out_path) {
     int chunk = 64, rc = 0;
     for (int start = 0; start < b.n_variants && !rc; start += chunk) {
         int n = start + chunk <= b.n_variants ? chunk : b.n_variants - start;
-        rc = get_variants_stats(b.records + start, n, NULL, NULL, 0, &out, fs);
-        rc |= get_sample_stats(b.records + start, n, NULL, NULL, ss, fs);
+        rc = get_variants_stats(b.records + start, n, individuals, ids, 0, &out, fs);
+        rc |= get_sample_stats(b.records + start, n, individuals, ids, ss, fs);
     }
     if (rc) { fprintf(stderr, "stats failed: %s\n", hpgv_host_last_error()); return 1; }
     list_decr_writers(&out);
@@ -337,7 +346,7 @@ static int cmd_stats(const char *batch_path, const char *out_path) {
         list_item_free(it);
     }
     for (int j = 0; j < b.n_samples; j++) {
-        fprintf(fd, "S\t%s\t%d\n", ss[j]->name, ss[j]->missing_genotypes);
+        fprintf(fd, "S\t%s\t%d\t%d\n", ss[j]->name, ss[j]->missing_genotypes, ss[j]->mendelian_errors);
         sample_stats_free(ss[j]);
     }
     fclose(fd);
@@ -351,7 +360,7 @@ int main(int argc, char **argv) {
     if (argc >= 2 && !strcmp(argv[1], "kat")) return cmd_kat();
     if (argc >= 7 && !strcmp(argv[1], "assoc")) return cmd_assoc(argv[2], argv[3], argv[4], atoi(argv[5]), atoi(argv[6]));
     if (argc >= 7 && !strcmp(argv[1], "tdt")) return cmd_tdt(argv[2], argv[3], argv[4], atoi(argv[5]), atoi(argv[6]));
-    if (argc >= 4 && !strcmp(argv[1], "stats")) return cmd_stats(argv[2], argv[3]);
+    if (argc >= 4 && !strcmp(argv[1], "stats")) return cmd_stats(argv[2], argv[3], argc >= 5 ? argv[4] : NULL);
     fprintf(stderr, "usage: host_driver kat | assoc|tdt <batch> <ped> <prefix> <threads> <lines> | stats <batch> <out>\n");
     return 2;
 }

@@ -458,3 +458,32 @@ def test_stats_per_phenotype_group():
     with pytest.raises(hpgv.HpgvError):
         e.stats_scan_group(d_lay, nv, n_groups, d_c8)
     e.close()
+
+
+@pytest.mark.parametrize("n_trios", [1, 17, 1000, 2100])
+def test_mendelian_errors_per_variant_and_per_child(n_trios):
+    rng = np.random.default_rng(n_trios)
+    n_samples = 3 * n_trios + 4
+    cols = rng.permutation(n_samples)
+    f, m, c = cols[:n_trios], cols[n_trios: 2 * n_trios], cols[2 * n_trios: 3 * n_trios]
+    sex = rng.integers(0, 2, size=n_trios).astype(np.uint8)
+    nv = 300
+    gt = random_codes(rng, nv, n_samples, quirks=True, strict=False)
+    gt[::2] = random_codes(rng, len(gt[::2]), n_samples, quirks=False)
+    is_x = (rng.random(nv) < 0.4).astype(np.uint8)
+    e = fresh()
+    pitch = e.set_pedigree(n_samples, f, m, c, sex)
+    d_raw, d_lay = e.alloc(nv * n_samples), e.alloc(nv * pitch)
+    d_err, d_child, d_isx = e.alloc(nv * 4), e.alloc(n_trios * 4), e.alloc(nv)
+    e.h2d(d_raw, gt); e.h2d(d_isx, is_x); e.h2d(d_child, np.zeros(n_trios, np.int32))
+    e.layout(hpgv.LAYOUT_MENDEL, d_raw, n_samples, nv, d_lay)
+    for x, dx in ((is_x, d_isx), (None, None)):
+        e.h2d(d_child, np.zeros(n_trios, np.int32))
+        e.mendel_scan(d_lay, nv, d_err, dx)
+        e.mendel_children(d_lay, nv, d_child, dx)
+        e.sync()
+        exp_err, exp_trio = orc.mendel_counts(gt, f, m, c, sex, x)
+        assert np.array_equal(e.d2h(d_err, (nv,), np.int32), exp_err)
+        assert np.array_equal(e.d2h(d_child, (n_trios,), np.int32), exp_trio)
+        assert exp_err.sum() > 0
+    e.close()

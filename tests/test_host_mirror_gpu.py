@@ -181,7 +181,7 @@ def test_tdt_test_runner_shape(driver, tmp_path):
 def test_get_variants_stats_and_sample_stats(driver, tmp_path):
     rng = np.random.default_rng(13)
     people, names, rows = _write_inputs(tmp_path, rng, 20, 30, 200)
-    r = subprocess.run([driver, "stats", str(tmp_path / "batch.txt"), str(tmp_path / "stats.tsv")],
+    r = subprocess.run([driver, "stats", str(tmp_path / "batch.txt"), str(tmp_path / "stats.tsv"), str(tmp_path / "ped.txt")],
                        capture_output=True, text=True)
     assert r.returncode == 0 and "STATS OK variants=200" in r.stdout, r.stdout + r.stderr
     gt = _codes(rows, False)
@@ -203,8 +203,18 @@ def test_get_variants_stats_and_sample_stats(driver, tmp_path):
         assert [int(x) for x in t[8 + na: 8 + na + na * na]] == list(vs.genotypes_count)[: na * na], v
     assert n_multi > 0 and ("multiallelic=%d" % n_multi) in r.stdout
     miss = orc.sample_missing(gt)                          # get_sample_stats: per-sample missing genotypes
+    # per-sample Mendelian errors: every sample whose two parents are VCF columns, checked on every variant
+    col = {n: i for i, n in enumerate(names)}
+    trios = [(col[p[2]], col[p[3]], col[p[1]], orc.MALE if p[4] == 1 else orc.FEMALE) for p in people if p[2] != "0"]
+    is_x = np.array([1 if c == "X" else 0 for c, _, _ in rows], np.uint8)
+    _, trio_err = orc.mendel_counts(gt, [t[0] for t in trios], [t[1] for t in trios], [t[2] for t in trios],
+                                    [t[3] for t in trios], is_x)
+    exp_mendel = np.zeros(len(names), np.int64)
+    for t, e_ in zip(trios, trio_err):
+        exp_mendel[t[2]] += e_
+    assert exp_mendel.sum() > 0
     for j, t in enumerate(slines):
-        assert t[1] == names[j] and int(t[2]) == miss[j]
+        assert t[1] == names[j] and int(t[2]) == miss[j] and int(t[3]) == exp_mendel[j], (j, t)
 
 
 def test_staging_matches_the_oracle_encoder():
