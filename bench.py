@@ -277,6 +277,15 @@ def main():
     bytes_per_variant = N + payload                     # N x 1 B + result payload
     achieved = scan_variants * bytes_per_variant / (scan_ms * 1e-3) / 1e9
 
+    # ---- measured streaming-read ceiling of the same buffer (report both fractions) -----------
+    probe_gbps = None
+    if rank == 0 and world == 1:
+        try:
+            probe_ms = eng.read_probe(gt.data_ptr(), V * pitch, 5)
+            probe_gbps = V * pitch / (probe_ms * 1e-3) / 1e9
+        except Exception:
+            probe_gbps = None
+
     # ---- parity spot check: the oracle as CHECKER of the timed run's outputs (not timed, not on the product path)
     parity = None
     if rank == 0:
@@ -341,6 +350,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": pmc_traffic(args.workload, scan_variants, N, pitch, scan_name) if world == 1 else None,
                          "kernel": scan_name, "kernel_ms": scan_ms, "kernel_samples": len(evs),
+                         "stream_read_probe_GBps": probe_gbps,
+                         "frac_of_probe": (achieved / probe_gbps) if probe_gbps else None,
                          "algorithmic_bytes_per_variant": bytes_per_variant,
                          "variants_per_launch": scan_variants},
             "parity": parity,

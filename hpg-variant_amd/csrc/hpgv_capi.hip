@@ -1292,7 +1292,7 @@ int hpgv_read_probe(hpgv_ctx *ctx, const uint8_t *d_buf, size_t bytes, int iters
     hipEvent_t a, b;
     HIPCHK(ctx, hipEventCreate(&a));
     HIPCHK(ctx, hipEventCreate(&b));
-    const unsigned blocks = 256 * 8;
+    const unsigned blocks = (unsigned)(ctx->n_cus * 4);      // 4 blocks x 4 waves per CU: the pipelined scan's occupancy
     auto go = [&] {
         if (ctx->nontemporal)
             hipLaunchKernelGGL((hpgv::k_read_probe<true>), dim3(blocks), dim3(256), 0, nullptr, (const uint4 *)d_buf, n16, ctx->d_sink);

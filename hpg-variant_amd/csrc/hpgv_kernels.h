@@ -574,21 +574,45 @@ __global__ void k_counts_to_soa(const int4 *__restrict__ counts, int n, int32_t 
 }
 
 // ---------------------------------------------------------------------------
-// streaming-read probe: the scan's load shape with one OR per dword, so the
-// measured time is the memory system's, not the ALU's.
+// streaming-read probe: a pure read of the buffer with the scan's machine shape
+// (one wave = one contiguous 8 KiB piece per step, 8 x 16 B per lane in flight, two
+// steps of look-ahead, non-temporal) and a single OR per dword, so the measured
+// time is the memory system's, not the ALU's.  This is the ceiling the scans are
+// compared with.
 // ---------------------------------------------------------------------------
 template <bool NT>
 __global__ __launch_bounds__(256) void k_read_probe(const uint4 *__restrict__ buf, size_t n16,
                                                     uint32_t *__restrict__ sink) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const size_t n_waves = (size_t)gridDim.x * (blockDim.x >> 6);
+    const size_t piece = 512;                            // 16-byte chunks per wave step (8 KiB)
     uint32_t acc = 0;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = load16<NT>(buf + i), b = load16<NT>(buf + i + stride);
-        const uint4 c = load16<NT>(buf + i + 2 * stride), d = load16<NT>(buf + i + 3 * stride);
-        acc |= a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w | c.x | c.y | c.z | c.w | d.x | d.y | d.z | d.w;
+    uint4 qa[8], qb[8];
+    size_t p = wave * piece;
+    auto issue = [&](uint4 (&q)[8], size_t base) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const size_t i = base + (size_t)u * 64 + lane;
+            q[u] = make_uint4(0, 0, 0, 0);
+            if (i < n16) q[u] = load16<NT>(buf + i);
+        }
+    };
+    auto eat = [&](const uint4 (&q)[8]) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc |= q[u].x | q[u].y | q[u].z | q[u].w;
+    };
+    if (p < n16) issue(qa, p);
+    while (p < n16) {
+        const size_t p1 = p + n_waves * piece;
+        if (p1 < n16) issue(qb, p1);
+        eat(qa);
+        if (p1 >= n16) break;
+        const size_t p2 = p1 + n_waves * piece;
+        if (p2 < n16) issue(qa, p2);
+        eat(qb);
+        p = p2;
     }
-    for (; i < n16; i += stride) { const uint4 a = load16<NT>(buf + i); acc |= a.x | a.y | a.z | a.w; }
     if (acc == 0x12345678u) sink[0] = acc;   // practically never; keeps the loads alive
 }
 
