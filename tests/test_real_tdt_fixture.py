@@ -87,3 +87,39 @@ def test_hip_path_from_raw_text_on_reference_fixture(fx):
     odds, chisq, p = orc.tdt_stats(res["t1"], res["t2"])
     assert_close(res["chisq"], chisq, "chisq"); assert_close(res["p"], p, "p"); assert_close(res["odds"], odds, "odds")
     e.close()
+
+
+@pytest.mark.gpu
+def test_c_example_from_vcf_text_to_tsv(fx, tmp_path):
+    """examples/assoc_from_text.c: plain C over include/hpgv.h, VCF file in, the reference's .chisq TSV out."""
+    import subprocess
+    from importlib import import_module
+    from helpers import hpgv
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    b = import_module("hpg-variant_amd._build")
+    hpgv.build()
+    exe = str(tmp_path / "assoc_from_text")
+    subprocess.check_call(["gcc", "-O1", "-std=gnu99", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "assoc_from_text.c"), "-o", exe,
+                           "-L", b.LIBDIR, "-lhpgv", "-Wl,-rpath," + b.LIBDIR, "-lm"])
+    vcf = tmp_path / "in.vcf"
+    vcf.write_bytes(b"##fileformat=VCFv4.1\n" + gzip.open(os.path.join(HERE, "tdt_4k_147.vcf.gz")).read())
+    pheno = {p[1]: p[5] for p in fx["people"]}
+    cond = [1 if pheno[n] == 2 else 0 if pheno[n] == 1 else 2 for n in fx["names"]]
+    (tmp_path / "cond.txt").write_text(" ".join(map(str, cond)))
+    out = subprocess.run([exe, str(vcf), str(tmp_path / "cond.txt")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().split("\n")
+    assert lines[0].startswith("#CHR\tPOS\tID\tA1") and len(lines) == 4001
+    tok = orc.tokenize(fx["data"], len(fx["names"]), True)
+    A1, A2, U1, U2 = orc.assoc_counts(tok["gt"], np.array(cond, np.uint8), tok["is_x"])
+    odds, chisq, p = orc.assoc_stats(orc.TASK_CHISQ, A1, A2, U1, U2)
+    data = fx["data"].split("\n")
+    for i in (0, 1, 2, 1999, 3999):
+        t = lines[1 + i].split("\t")
+        ref = data[i].split("\t")
+        assert t[0:3] == ref[0:3] and t[3] == ref[3] and t[8] == ref[4]
+        assert (int(t[4]), int(t[9]), int(t[5]), int(t[10])) == (A1[i], A2[i], U1[i], U2[i])
+        for got, exp in zip(t[13:], (odds[i], chisq[i], p[i])):
+            g = float("nan") if "nan" in got else float(got)
+            assert (np.isnan(g) and np.isnan(exp)) or abs(g - exp) <= 6e-7 * max(1.0, abs(exp))
