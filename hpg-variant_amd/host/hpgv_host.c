@@ -983,3 +983,326 @@ int hpgv_host_sort_output_file(const char *path) {
     free(tmp); free(keys); free(blob);
     return rc;
 }
+
+/* ------------------------------------------------------------------------ */
+/* file-level runners: VCF + PED in, sorted TSV out                           */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+    int n;
+    char **fid, **iid, **pat, **mat;
+    int *sex, *pheno;
+    char *blob;
+} ped_table_t;
+
+static void ped_table_free(ped_table_t *p) {
+    free(p->fid); free(p->iid); free(p->pat); free(p->mat); free(p->sex); free(p->pheno); free(p->blob);
+    memset(p, 0, sizeof *p);
+}
+
+static char *next_ws_token(char **p) {
+    char *s = *p;
+    while (*s == ' ' || *s == '\t' || *s == '\n' || *s == '\r') s++;
+    if (!*s) return NULL;
+    char *e = s;
+    while (*e && *e != ' ' && *e != '\t' && *e != '\n' && *e != '\r') e++;
+    if (*e) { *e = 0; e++; }
+    *p = e;
+    return s;
+}
+
+static int ped_table_read(const char *path, ped_table_t *ped) {
+    memset(ped, 0, sizeof *ped);
+    FILE *f = fopen(path, "rb");
+    if (!f) { snprintf(g_err, sizeof g_err, "cannot open PED file %s", path); return HPGV_ERR_INVALID; }
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    ped->blob = (char *)malloc((size_t)sz + 1);
+    if (!ped->blob || fread(ped->blob, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); ped_table_free(ped); return HPGV_ERR_NOMEM; }
+    fclose(f);
+    ped->blob[sz] = 0;
+    int cap = 0;
+    for (long i = 0; i < sz; i++) if (ped->blob[i] == '\n') cap++;
+    cap += 2;
+    ped->fid = (char **)malloc(sizeof(char *) * (size_t)cap); ped->iid = (char **)malloc(sizeof(char *) * (size_t)cap);
+    ped->pat = (char **)malloc(sizeof(char *) * (size_t)cap); ped->mat = (char **)malloc(sizeof(char *) * (size_t)cap);
+    ped->sex = (int *)malloc(sizeof(int) * (size_t)cap); ped->pheno = (int *)malloc(sizeof(int) * (size_t)cap);
+    char *line = ped->blob;
+    while (line && *line) {
+        char *eol = strchr(line, '\n');
+        if (eol) *eol = 0;
+        if (*line && *line != '#') {
+            char *p = line;
+            char *a = next_ws_token(&p), *b = next_ws_token(&p), *c = next_ws_token(&p), *d = next_ws_token(&p);
+            char *e = next_ws_token(&p), *g = next_ws_token(&p);
+            if (a && b && c && d && e && g && ped->n < cap) {
+                ped->fid[ped->n] = a; ped->iid[ped->n] = b; ped->pat[ped->n] = c; ped->mat[ped->n] = d;
+                ped->sex[ped->n] = !strcmp(e, "1") ? HPGV_SEX_MALE : !strcmp(e, "2") ? HPGV_SEX_FEMALE : HPGV_SEX_UNKNOWN;
+                ped->pheno[ped->n] = !strcmp(g, "2") ? HPGV_COND_AFFECTED : !strcmp(g, "1") ? HPGV_COND_UNAFFECTED : HPGV_COND_OTHER;
+                ped->n++;
+            }
+        }
+        line = eol ? eol + 1 : NULL;
+    }
+    return HPGV_OK;
+}
+
+/* batch reader: whole lines, about batch_bytes per batch */
+typedef struct {
+    FILE *f;
+    char *carry; size_t carry_len, carry_cap;
+    int eof;
+} line_reader_t;
+
+/* fills buf (capacity cap) with whole lines; returns the byte count, 0 at the end */
+static size_t read_lines(line_reader_t *r, char *buf, size_t cap) {
+    size_t n = 0;
+    if (r->carry_len) { memcpy(buf, r->carry, r->carry_len); n = r->carry_len; r->carry_len = 0; }
+    if (!r->eof) {
+        size_t got = fread(buf + n, 1, cap - n, r->f);
+        if (got < cap - n) r->eof = 1;
+        n += got;
+    }
+    if (n == 0) return 0;
+    if (r->eof) return n;                               /* last batch: may end without a newline */
+    size_t end = n;
+    while (end > 0 && buf[end - 1] != '\n') end--;
+    if (end == 0) return (size_t)-1;                    /* a single line longer than the batch */
+    size_t tail = n - end;
+    if (tail > r->carry_cap) { free(r->carry); r->carry = (char *)malloc(tail); r->carry_cap = tail; }
+    memcpy(r->carry, buf + end, tail);
+    r->carry_len = tail;
+    return end;
+}
+
+typedef struct {
+    char *text; size_t bytes; int max_lines, n_lines;
+    uint64_t *line_off; uint32_t *field_off; int32_t *status;
+    int32_t *ints; double *dbl;                          /* 4 (assoc) or 2 (tdt) int arrays, 3 double arrays */
+} run_batch_t;
+
+static int run_batch_alloc(run_batch_t *b, size_t cap_bytes, int n_samples) {
+    memset(b, 0, sizeof *b);
+    size_t min_line = (size_t)(2 * (n_samples > 0 ? n_samples : 1) + 18);
+    b->max_lines = (int)(cap_bytes / min_line) + 2;
+    b->text = (char *)malloc(cap_bytes + 1);
+    b->line_off = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)b->max_lines + 1));
+    b->field_off = (uint32_t *)malloc(sizeof(uint32_t) * 10 * (size_t)b->max_lines);
+    b->status = (int32_t *)malloc(sizeof(int32_t) * (size_t)b->max_lines);
+    b->ints = (int32_t *)malloc(sizeof(int32_t) * 4 * (size_t)b->max_lines);
+    b->dbl = (double *)malloc(sizeof(double) * 3 * (size_t)b->max_lines);
+    return (b->text && b->line_off && b->field_off && b->status && b->ints && b->dbl) ? HPGV_OK : HPGV_ERR_NOMEM;
+}
+/* makes room for `lines` records (short or truncated lines can exceed the estimate) */
+static int run_batch_reserve(run_batch_t *b, int lines) {
+    if (lines <= b->max_lines) return HPGV_OK;
+    free(b->line_off); free(b->field_off); free(b->status); free(b->ints); free(b->dbl);
+    b->max_lines = lines + lines / 8 + 2;
+    b->line_off = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)b->max_lines + 1));
+    b->field_off = (uint32_t *)malloc(sizeof(uint32_t) * 10 * (size_t)b->max_lines);
+    b->status = (int32_t *)malloc(sizeof(int32_t) * (size_t)b->max_lines);
+    b->ints = (int32_t *)malloc(sizeof(int32_t) * 4 * (size_t)b->max_lines);
+    b->dbl = (double *)malloc(sizeof(double) * 3 * (size_t)b->max_lines);
+    return (b->line_off && b->field_off && b->status && b->ints && b->dbl) ? HPGV_OK : HPGV_ERR_NOMEM;
+}
+static void run_batch_free(run_batch_t *b) {
+    free(b->text); free(b->line_off); free(b->field_off); free(b->status); free(b->ints); free(b->dbl);
+}
+
+/* one output line per record, the reference's formats (assoc_runner.c:314-318,332-336; tdt_runner.c:297-299) */
+static void write_batch(FILE *fd, int kind /* CHI_SQUARE, FISHER, 3 = tdt */, const run_batch_t *b) {
+    const int m = b->max_lines;
+    for (int i = 0; i < b->n_lines && i < m; i++) {
+        const uint32_t *fo = b->field_off + 10 * (size_t)i;
+        if (fo[5] == 0xFFFFFFFFu) continue;                          /* fewer than CHROM..ALT: not a record */
+        const char *l = b->text + b->line_off[i];
+        const int lc = (int)(fo[1] - 1 - fo[0]), lp = (int)(fo[2] - 1 - fo[1]), li = (int)(fo[3] - 1 - fo[2]);
+        const int lr = (int)(fo[4] - 1 - fo[3]), la = (int)(fo[5] - 1 - fo[4]);
+        if (kind == 3) {
+            const int t1 = b->ints[i], t2 = b->ints[m + i];
+            fprintf(fd, "%.*s\t%ld\t%.*s\t%.*s\t%.*s\t%d\t%d\t%6f\t%6f\t%6f\n", lc, l + fo[0], atol(l + fo[1]), li, l + fo[2],
+                    lr, l + fo[3], la, l + fo[4], t1, t2, b->dbl[i], b->dbl[m + i], b->dbl[2 * m + i]);
+        } else {
+            const int A1 = b->ints[i], A2 = b->ints[m + i], U1 = b->ints[2 * m + i], U2 = b->ints[3 * m + i];
+            const int na = A1 + A2, nu = U1 + U2;
+            const double fa1 = na > 0 ? (double)A1 / na : 0.0, fu1 = nu > 0 ? (double)U1 / nu : 0.0;
+            const double fa2 = na > 0 ? (double)A2 / na : 0.0, fu2 = nu > 0 ? (double)U2 / nu : 0.0;
+            fprintf(fd, "%.*s\t%ld\t%.*s\t%.*s\t%d\t%d\t%6f\t%6f\t%.*s\t%d\t%d\t%6f\t%6f\t%6f", lc, l + fo[0], atol(l + fo[1]),
+                    li, l + fo[2], lr, l + fo[3], A1, U1, fa1, fu1, la, l + fo[4], A2, U2, fa2, fu2, b->dbl[i]);
+            if (kind == CHI_SQUARE) fprintf(fd, "\t%6f\t%6f\n", b->dbl[m + i], b->dbl[2 * m + i]);
+            else fprintf(fd, "\t%6f\n", b->dbl[2 * m + i]);
+        }
+        (void)lp;
+    }
+}
+
+static int run_file(const char *vcf_path, const char *ped_path, const char *out_path, int kind, size_t batch_bytes,
+                    long *n_variants_out) {
+    int rc = ensure_engine();
+    if (rc) return rc;
+    if (batch_bytes < (1u << 16)) batch_bytes = 1u << 16;
+    ped_table_t ped;
+    if ((rc = ped_table_read(ped_path, &ped))) return rc;
+    FILE *vf = fopen(vcf_path, "rb");
+    if (!vf) { ped_table_free(&ped); snprintf(g_err, sizeof g_err, "cannot open VCF file %s", vcf_path); return HPGV_ERR_INVALID; }
+    /* header: skip '##' lines, take the sample names from the '#CHROM' line */
+    char *hdr = NULL;
+    size_t hcap = 0;
+    ssize_t hl;
+    int n_samples = -1;
+    char **names = NULL;
+    while ((hl = getline(&hdr, &hcap, vf)) > 0) {
+        if (hdr[0] != '#') break;
+        if (!strncmp(hdr, "#CHROM", 6)) {
+            while (hl > 0 && (hdr[hl - 1] == '\n' || hdr[hl - 1] == '\r')) hdr[--hl] = 0;
+            int tabs = 0;
+            for (ssize_t i = 0; i < hl; i++) if (hdr[i] == '\t') tabs++;
+            n_samples = tabs >= 9 ? tabs - 8 : 0;
+            names = (char **)malloc(sizeof(char *) * (size_t)(n_samples + 1));
+            int k = 0, col = 0;
+            for (char *p = hdr; *p; p++)
+                if (*p == '\t') { *p = 0; col++; if (col >= 9 && k < n_samples) names[k++] = p + 1; }
+            break;
+        }
+    }
+    if (n_samples < 0) { fclose(vf); free(hdr); ped_table_free(&ped); snprintf(g_err, sizeof g_err, "no #CHROM header line in %s", vcf_path); return HPGV_ERR_INVALID; }
+
+    /* cohort: PED rows looked up by sample name (associate_samples_and_positions + sort_individuals) */
+    sample_ids_t *ids = sample_ids_new((size_t)n_samples);
+    for (int j = 0; j < n_samples; j++) sample_ids_put(ids, names[j], j);
+    pthread_rwlock_wrlock(&g_cohort_lock);
+    if (kind == 3) {
+        /* families in order of first appearance; father / mother = founders by sex (tdt.c:62-73);
+         * counted children = rows with both parents named, affected, present in the VCF (tdt.c:139-148) */
+        int32_t *fcol = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ped.n + 1)), *mcol = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ped.n + 1));
+        int32_t *coff = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ped.n + 2)), *ccol = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ped.n + 1));
+        uint8_t *csex = (uint8_t *)malloc((size_t)ped.n + 1);
+        char *done = (char *)calloc((size_t)ped.n + 1, 1);
+        int nf = 0, nc = 0;
+        coff[0] = 0;
+        for (int i = 0; i < ped.n; i++) {
+            if (done[i]) continue;
+            int father = -1, mother = -1;
+            for (int k = i; k < ped.n; k++) {
+                if (strcmp(ped.fid[k], ped.fid[i])) continue;
+                done[k] = 1;
+                if (!strcmp(ped.pat[k], "0") && !strcmp(ped.mat[k], "0") && !(father >= 0 && mother >= 0)) {
+                    if (ped.sex[k] == HPGV_SEX_MALE) father = k; else if (ped.sex[k] == HPGV_SEX_FEMALE) mother = k;
+                }
+            }
+            int fp = father >= 0 ? sample_ids_get(ids, ped.iid[father]) : -1, mp = mother >= 0 ? sample_ids_get(ids, ped.iid[mother]) : -1;
+            fcol[nf] = (fp >= 0 && mp >= 0) ? fp : -1;
+            mcol[nf] = (fp >= 0 && mp >= 0) ? mp : -1;
+            if (fcol[nf] >= 0)
+                for (int k = i; k < ped.n; k++) {
+                    if (strcmp(ped.fid[k], ped.fid[i])) continue;
+                    if (!strcmp(ped.pat[k], "0") || !strcmp(ped.mat[k], "0")) continue;       /* child->father && child->mother */
+                    if (ped.pheno[k] != HPGV_COND_AFFECTED) continue;
+                    int cp = sample_ids_get(ids, ped.iid[k]);
+                    if (cp < 0) continue;
+                    ccol[nc] = cp; csex[nc] = (uint8_t)ped.sex[k]; nc++;
+                }
+            coff[++nf] = nc;
+        }
+        rc = hpgv_set_families(g_ctx, n_samples, nf, fcol, mcol, coff, ccol, csex);
+        g_tdt_key.set = 0;
+        if (rc) host_fail("hpgv_set_families", rc);
+        free(fcol); free(mcol); free(coff); free(ccol); free(csex); free(done);
+    } else {
+        uint8_t *cond = (uint8_t *)malloc((size_t)n_samples + 1);
+        for (int j = 0; j < n_samples; j++) cond[j] = HPGV_COND_OTHER;
+        for (int i = 0; i < ped.n; i++) { int j = sample_ids_get(ids, ped.iid[i]); if (j >= 0) cond[j] = (uint8_t)ped.pheno[i]; }
+        rc = hpgv_set_cohort(g_ctx, cond, n_samples);
+        g_assoc_key.set = 0;
+        if (rc) host_fail("hpgv_set_cohort", rc);
+        free(cond);
+        if (!rc && kind == FISHER) {
+            double *lf = init_logarithm_array(n_samples * 10 > 16 ? n_samples * 10 : 16);     /* assoc_runner.c:164-166 */
+            rc = hpgv_set_logfact(g_ctx, lf, (size_t)(n_samples * 10 > 16 ? n_samples * 10 : 16));
+            g_lf_key.table = NULL;
+            if (rc) host_fail("hpgv_set_logfact", rc);
+            free(lf);
+        }
+    }
+    pthread_rwlock_unlock(&g_cohort_lock);
+    sample_ids_free(ids);
+
+    FILE *out = rc ? NULL : fopen(out_path, "wb");
+    if (!rc && !out) { snprintf(g_err, sizeof g_err, "cannot create %s", out_path); rc = HPGV_ERR_INVALID; }
+    long written = 0;
+    run_batch_t bt[2];
+    int have[2] = {0, 0};
+    if (!rc) { rc = run_batch_alloc(&bt[0], batch_bytes, n_samples); have[0] = 1; }
+    if (!rc) { rc = run_batch_alloc(&bt[1], batch_bytes, n_samples); have[1] = 1; }
+    if (!rc) {
+        if (kind == 3) tdt_write_output_header(out); else assoc_write_output_header((enum ASSOC_task)kind, out);
+        line_reader_t rd;
+        memset(&rd, 0, sizeof rd);
+        rd.f = vf;
+        /* the first data line was consumed by getline while looking for the header's end */
+        if (hl > 0 && hdr[0] != '#') { rd.carry = (char *)malloc((size_t)hl); rd.carry_cap = (size_t)hl; memcpy(rd.carry, hdr, (size_t)hl); rd.carry_len = (size_t)hl; }
+        /* software pipeline over batches: while the engine works on batch k (thread A), the same thread of
+         * the previous iteration's results are written and the next batch is read (thread B) */
+        int cur = 0;
+        size_t n0 = read_lines(&rd, bt[0].text, batch_bytes);
+        bt[0].bytes = n0;
+        int prev_ready = 0;
+        while (!rc && bt[cur].bytes != 0) {
+            if (bt[cur].bytes == (size_t)-1) { snprintf(g_err, sizeof g_err, "a VCF line is longer than batch_bytes"); rc = HPGV_ERR_UNSUPPORTED; break; }
+            int rc_engine = HPGV_OK;
+            size_t next_bytes = 0;
+            const int nxt = cur ^ 1;
+            #pragma omp parallel sections num_threads(2)
+            {
+                #pragma omp section
+                {
+                    run_batch_t *b = &bt[cur];
+                    int lines = 1;
+                    for (const char *q = b->text, *e = b->text + b->bytes; (q = (const char *)memchr(q, '\n', (size_t)(e - q))); q++) lines++;
+                    rc_engine = run_batch_reserve(b, lines);
+                    const int m = b->max_lines;
+                    if (rc_engine) { snprintf(g_err, sizeof g_err, "out of memory"); }
+                    else if (kind == 3)
+                        rc_engine = hpgv_tdt_text(g_ctx, b->text, b->bytes, m, &b->n_lines, b->line_off, b->field_off, b->status,
+                                                  b->ints, b->ints + m, b->dbl, b->dbl + m, b->dbl + 2 * m);
+                    else
+                        rc_engine = hpgv_assoc_text(g_ctx, kind, b->text, b->bytes, m, &b->n_lines, b->line_off, b->field_off, b->status,
+                                                    b->ints, b->ints + m, b->ints + 2 * m, b->ints + 3 * m,
+                                                    b->dbl, kind == CHI_SQUARE ? b->dbl + m : NULL, b->dbl + 2 * m);
+                }
+                #pragma omp section
+                {
+                    if (prev_ready) { write_batch(out, kind, &bt[nxt]); }
+                    next_bytes = read_lines(&rd, bt[nxt].text, batch_bytes);
+                }
+            }
+            if (rc_engine) { if (rc_engine != HPGV_ERR_NOMEM) host_fail(kind == 3 ? "hpgv_tdt_text" : "hpgv_assoc_text", rc_engine); rc = rc_engine; break; }
+            if (bt[cur].n_lines > bt[cur].max_lines) { snprintf(g_err, sizeof g_err, "internal: more lines than the batch capacity"); rc = HPGV_ERR_UNSUPPORTED; break; }
+            for (int i = 0; i < bt[cur].n_lines; i++) if (bt[cur].field_off[10 * (size_t)i + 5] != 0xFFFFFFFFu) written++;
+            bt[nxt].bytes = next_bytes;
+            prev_ready = 1;
+            cur = nxt;
+        }
+        if (!rc && prev_ready) write_batch(out, kind, &bt[cur ^ 1]);
+        free(rd.carry);
+    }
+    if (out) fclose(out);
+    if (!rc && hpgv_host_sort_output_file(out_path))                    /* assoc_runner.c:255-261: only a warning there */
+        fprintf(stderr, "WARN: results could not be sorted by chromosome and position\n");
+    if (have[0]) run_batch_free(&bt[0]);
+    if (have[1]) run_batch_free(&bt[1]);
+    fclose(vf); free(hdr); free(names); ped_table_free(&ped);
+    if (n_variants_out) *n_variants_out = written;
+    return rc;
+}
+
+int hpgv_run_assoc(const char *vcf_path, const char *ped_path, const char *out_path, enum ASSOC_task task,
+                   size_t batch_bytes, long *n_variants_out) {
+    if (task != CHI_SQUARE && task != FISHER) { snprintf(g_err, sizeof g_err, "task must be CHI_SQUARE or FISHER"); return HPGV_ERR_INVALID; }
+    return run_file(vcf_path, ped_path, out_path, (int)task, batch_bytes, n_variants_out);
+}
+
+int hpgv_run_tdt(const char *vcf_path, const char *ped_path, const char *out_path, size_t batch_bytes, long *n_variants_out) {
+    return run_file(vcf_path, ped_path, out_path, 3, batch_bytes, n_variants_out);
+}

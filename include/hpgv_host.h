@@ -247,6 +247,19 @@ void tdt_write_output_body(list_t *output_list, FILE *fd);                  /* t
  * cannot be read / rewritten (the reference only warns in that case). */
 int  hpgv_host_sort_output_file(const char *path);
 
+/* ---- file level: what run_association_test (assoc_runner.c:23-276) and run_tdt_test
+ *      (tdt_runner.c:23-279) do, minus options/filters: read the PED, read the (uncompressed) VCF in
+ *      text batches of about batch_bytes, hand every batch to the engine as TEXT (the GPU
+ *      tokenizes it), write the reference's TSV and sort it in process.  Reader, engine and
+ *      writer overlap (one batch in flight each way).  PED columns: FID IID PAT MAT SEX PHENO
+ *      with SEX 1 = male, 2 = female and PHENO 2 = affected, 1 = unaffected
+ *      (stats_runner.c:50,86-87).  Returns 0 or an hpgv / errno-style non-zero code;
+ *      *n_variants_out (may be NULL) receives the number of records written. */
+int  hpgv_run_assoc(const char *vcf_path, const char *ped_path, const char *out_path,
+                    enum ASSOC_task task, size_t batch_bytes, long *n_variants_out);
+int  hpgv_run_tdt(const char *vcf_path, const char *ped_path, const char *out_path,
+                  size_t batch_bytes, long *n_variants_out);
+
 /* ---- staging (GT text -> HPGV8), exposed for tests ---------------------------- */
 int  get_field_position_in_format(const char *field, char *format);
 int  get_alleles(char *sample, int genotype_position, int *allele1, int *allele2);

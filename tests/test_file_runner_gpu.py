@@ -1,0 +1,106 @@
+"""File-level runners (hpgv_run_assoc / hpgv_run_tdt: what run_association_test and
+run_tdt_test do, assoc_runner.c:23-276, tdt_runner.c:23-279): VCF + PED files in, sorted
+TSV out, with the GPU tokenizing the text."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import hpgv
+from oracle import pyoracle as orc
+from test_host_mirror_gpu import _families_csr, _fl, _parse_table, _write_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def host():
+    hpgv.build()
+    from importlib import import_module
+    b = import_module("hpg-variant_amd._build")
+    L = C.CDLL(b.HOSTLIB)
+    L.hpgv_run_assoc.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_size_t, C.POINTER(C.c_long)]
+    L.hpgv_run_tdt.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_long)]
+    L.hpgv_host_last_error.restype = C.c_char_p
+    yield L
+    L.hpgv_host_shutdown()
+
+
+def _vcf_from_batch(tmp, names, rows):
+    with open(tmp / "in.vcf", "w") as f:
+        f.write("##fileformat=VCFv4.1\n##source=test\n")
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n")
+        for v, (chrom, fmt, samples) in enumerate(rows):
+            f.write("%s\t%d\trs%d\tA\tC\t.\tPASS\t.\t%s\t%s\n" % (chrom, 1000 + v, v, fmt, "\t".join(samples)))
+    return str(tmp / "in.vcf")
+
+
+def _codes(rows, strict):
+    return np.array([[orc.encode_sample(s, fmt.split(":").index("GT"), strict) for s in samples]
+                     for _, fmt, samples in rows], dtype=np.uint8)
+
+
+@pytest.mark.parametrize("batch_bytes", [1 << 16, 1 << 22])
+def test_run_assoc_from_files(host, tmp_path, batch_bytes):
+    rng = np.random.default_rng(3)
+    people, names, rows = _write_inputs(tmp_path, rng, 40, 30, 700)
+    vcf = _vcf_from_batch(tmp_path, names, rows)
+    pheno = {p[1]: p[5] for p in people}
+    cond = np.array([{2: orc.AFFECTED, 1: orc.UNAFFECTED}.get(pheno[n], orc.COND_OTHER) for n in names], np.uint8)
+    gt = _codes(rows, True)
+    is_x = np.array([1 if c == "X" else 0 for c, _, _ in rows], np.uint8)
+    A1, A2, U1, U2 = orc.assoc_counts(gt, cond, is_x)
+    lf = orc.logfact(len(names) * 10)
+    for task, ext in ((1, "chisq"), (2, "fisher")):
+        out = str(tmp_path / ("res." + ext))
+        n = C.c_long(0)
+        rc = host.hpgv_run_assoc(vcf.encode(), str(tmp_path / "ped.txt").encode(), out.encode(), task, batch_bytes, C.byref(n))
+        assert rc == 0, host.hpgv_host_last_error()
+        assert n.value == len(rows)
+        gnu = subprocess.run(["sort", "-k1,1h", "-k2,2n", out], capture_output=True, text=True,
+                             env=dict(os.environ, LC_ALL="C"), check=True).stdout
+        assert open(out).read() == gnu                                  # sorted like the reference's file
+        odds, chisq, p = orc.assoc_stats(task, A1, A2, U1, U2, lf)
+        header, table = _parse_table(out)
+        assert header[0] == "#CHR" and len(table) == len(rows)
+        by_pos = {int(t[1]): t for t in table}
+        for v in range(len(rows)):
+            t = by_pos[1000 + v]
+            assert t[0] == rows[v][0] and t[2] == "rs%d" % v
+            assert (int(t[4]), int(t[9]), int(t[5]), int(t[10])) == (A1[v], A2[v], U1[v], U2[v]), v
+            exp = [odds[v]] + ([chisq[v]] if task == 1 else []) + [p[v]]
+            for g, e in zip([_fl(x) for x in t[13:]], exp):
+                assert (np.isnan(g) and np.isnan(e)) or (np.isinf(g) and np.isinf(e)) or abs(g - e) <= 6e-7 * max(1.0, abs(e))
+
+
+def test_run_tdt_from_files(host, tmp_path):
+    rng = np.random.default_rng(4)
+    people, names, rows = _write_inputs(tmp_path, rng, 80, 5, 500)
+    vcf = _vcf_from_batch(tmp_path, names, rows)
+    out = str(tmp_path / "res.tdt")
+    n = C.c_long(0)
+    rc = host.hpgv_run_tdt(vcf.encode(), str(tmp_path / "ped.txt").encode(), out.encode(), 1 << 17, C.byref(n))
+    assert rc == 0 and n.value == len(rows), host.hpgv_host_last_error()
+    gt = _codes(rows, True)
+    is_x = np.array([1 if c == "X" else 0 for c, _, _ in rows], np.uint8)
+    t1, t2 = orc.tdt_counts(gt, *_families_csr(people, names), chrom_is_x=is_x)
+    odds, chisq, p = orc.tdt_stats(t1, t2)
+    header, table = _parse_table(out)
+    assert header == "#CHR POS ID A1 A2 T U OR CHISQ P-VALUE".split() and len(table) == len(rows)
+    by_pos = {int(t[1]): t for t in table}
+    assert t1.sum() + t2.sum() > 0
+    for v in range(len(rows)):
+        t = by_pos[1000 + v]
+        assert (int(t[5]), int(t[6])) == (t1[v], t2[v]), v
+        for g, e in zip([_fl(x) for x in t[7:]], (odds[v], chisq[v], p[v])):
+            assert (np.isnan(g) and np.isnan(e)) or (np.isinf(g) and np.isinf(e)) or abs(g - e) <= 6e-7 * max(1.0, abs(e))
+
+
+def test_run_reports_bad_inputs(host, tmp_path):
+    assert host.hpgv_run_assoc(b"/nonexistent.vcf", b"/nonexistent.ped", str(tmp_path / "o").encode(), 1, 1 << 20, None) != 0
+    (tmp_path / "p.ped").write_text("f a 0 0 1 2\n")
+    (tmp_path / "v.vcf").write_text("1\t5\trs\tA\tC\t.\t.\t.\tGT\t0/1\n")          # no #CHROM line
+    assert host.hpgv_run_assoc(str(tmp_path / "v.vcf").encode(), str(tmp_path / "p.ped").encode(),
+                               str(tmp_path / "o").encode(), 1, 1 << 20, None) != 0

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""End-to-end rate of the file-level runner: synthetic VCF + PED files in, sorted
+.chisq TSV out (file in the page cache -> PCIe -> GPU tokenizer -> scan -> writer ->
+in-process sort).  Diagnostic tool."""
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+hpgv = importlib.import_module("hpg-variant_amd")
+b = importlib.import_module("hpg-variant_amd._build")
+
+n_samples = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000
+n_variants = int(sys.argv[2]) if len(sys.argv) > 2 else 20_000
+rng = np.random.default_rng(0)
+codes = np.array(["0/0", "0/1", "1/1", "./."])
+d = tempfile.mkdtemp()
+vcf, ped, out = os.path.join(d, "in.vcf"), os.path.join(d, "in.ped"), os.path.join(d, "out.chisq")
+bodies = ["\t".join(codes[rng.choice(4, size=n_samples, p=[0.5, 0.3, 0.19, 0.01])]) for _ in range(32)]
+with open(vcf, "w") as f:
+    f.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" +
+            "\t".join("S%d" % j for j in range(n_samples)) + "\n")
+    for i in range(n_variants):
+        f.write("%d\t%d\trs%d\tA\tG\t.\tPASS\t.\tGT\t%s\n" % (1 + i % 22, 1000 + i, i, bodies[i % 32]))
+with open(ped, "w") as f:
+    for j in range(n_samples):
+        f.write("F%d S%d 0 0 %d %d\n" % (j, j, 1 + j % 2, 1 + j % 2))
+size = os.path.getsize(vcf)
+L = C.CDLL(b.HOSTLIB)
+L.hpgv_run_assoc.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_size_t, C.POINTER(C.c_long)]
+L.hpgv_host_last_error.restype = C.c_char_p
+res = []
+for batch in (64 << 20, 256 << 20):
+    n = C.c_long(0)
+    L.hpgv_run_assoc(vcf.encode(), ped.encode(), out.encode(), 1, batch, C.byref(n))      # warm (page cache, engine)
+    t0 = time.perf_counter()
+    rc = L.hpgv_run_assoc(vcf.encode(), ped.encode(), out.encode(), 1, batch, C.byref(n))
+    dt = time.perf_counter() - t0
+    assert rc == 0 and n.value == n_variants, L.hpgv_host_last_error()
+    res.append({"batch_MB": batch >> 20, "seconds": round(dt, 3), "variants_per_s": round(n_variants / dt),
+                "vcf_GBps": round(size / dt / 1e9, 2)})
+print(json.dumps({"n_samples": n_samples, "n_variants": n_variants, "vcf_GB": round(size / 1e9, 2), "runs": res}))
+for p in (vcf, ped, out):
+    os.remove(p)
+os.rmdir(d)
