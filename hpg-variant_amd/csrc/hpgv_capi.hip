@@ -482,6 +482,18 @@ int hpgv_dev_free(hpgv_ctx *ctx, void *dptr) {
     if (dptr) HIPCHK(ctx, hipFree(dptr));
     return HPGV_OK;
 }
+int hpgv_host_alloc(hpgv_ctx *ctx, size_t bytes, void **hptr) {
+    if (!ctx || !hptr) return HPGV_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    HIPCHK(ctx, hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return HPGV_OK;
+}
+int hpgv_host_free(hpgv_ctx *ctx, void *hptr) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    if (hptr) HIPCHK(ctx, hipHostFree(hptr));
+    return HPGV_OK;
+}
 int hpgv_memcpy_h2d(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream) {
     if (!ctx) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);

@@ -9,9 +9,12 @@
 #define _GNU_SOURCE
 #include "hpgv_host.h"
 
+#include <fcntl.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -1048,31 +1051,37 @@ static int ped_table_read(const char *path, ped_table_t *ped) {
     return HPGV_OK;
 }
 
-/* batch reader: whole lines, about batch_bytes per batch */
+/* batch reader: whole lines, about batch_bytes per batch.  The file is read with pread() from a few
+ * threads (one kernel copy out of the page cache per thread) straight into the pinned batch buffer. */
 typedef struct {
-    FILE *f;
-    char *carry; size_t carry_len, carry_cap;
-    int eof;
+    int fd;
+    off_t pos, size;                                    /* next unread byte, file size */
 } line_reader_t;
 
-/* fills buf (capacity cap) with whole lines; returns the byte count, 0 at the end */
+/* fills buf (capacity cap) with whole lines starting at r->pos; returns the byte count, 0 at the end,
+ * (size_t)-1 when a single line does not fit */
 static size_t read_lines(line_reader_t *r, char *buf, size_t cap) {
-    size_t n = 0;
-    if (r->carry_len) { memcpy(buf, r->carry, r->carry_len); n = r->carry_len; r->carry_len = 0; }
-    if (!r->eof) {
-        size_t got = fread(buf + n, 1, cap - n, r->f);
-        if (got < cap - n) r->eof = 1;
-        n += got;
+    if (r->pos >= r->size) return 0;
+    size_t want = (size_t)(r->size - r->pos) < cap ? (size_t)(r->size - r->pos) : cap;
+    const size_t seg = 8u << 20;
+    const int n_seg = (int)((want + seg - 1) / seg);
+    int bad = 0;
+    #pragma omp parallel for num_threads(8) schedule(static) if (n_seg > 1)
+    for (int k = 0; k < n_seg; k++) {
+        size_t off = (size_t)k * seg, len = off + seg <= want ? seg : want - off;
+        while (len > 0) {
+            ssize_t got = pread(r->fd, buf + off, len, r->pos + (off_t)off);
+            if (got <= 0) { bad = 1; break; }
+            off += (size_t)got; len -= (size_t)got;
+        }
     }
-    if (n == 0) return 0;
-    if (r->eof) return n;                               /* last batch: may end without a newline */
-    size_t end = n;
-    while (end > 0 && buf[end - 1] != '\n') end--;
-    if (end == 0) return (size_t)-1;                    /* a single line longer than the batch */
-    size_t tail = n - end;
-    if (tail > r->carry_cap) { free(r->carry); r->carry = (char *)malloc(tail); r->carry_cap = tail; }
-    memcpy(r->carry, buf + end, tail);
-    r->carry_len = tail;
+    if (bad) return 0;
+    size_t end = want;
+    if (r->pos + (off_t)want < r->size) {               /* not the last batch: cut at the last newline */
+        while (end > 0 && buf[end - 1] != '\n') end--;
+        if (end == 0) return (size_t)-1;
+    }
+    r->pos += (off_t)end;
     return end;
 }
 
@@ -1086,7 +1095,7 @@ static int run_batch_alloc(run_batch_t *b, size_t cap_bytes, int n_samples) {
     memset(b, 0, sizeof *b);
     size_t min_line = (size_t)(2 * (n_samples > 0 ? n_samples : 1) + 18);
     b->max_lines = (int)(cap_bytes / min_line) + 2;
-    b->text = (char *)malloc(cap_bytes + 1);
+    if (hpgv_host_alloc(g_ctx, cap_bytes + 1, (void **)&b->text) != HPGV_OK) b->text = NULL;   /* pinned: full-rate H2D */
     b->line_off = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)b->max_lines + 1));
     b->field_off = (uint32_t *)malloc(sizeof(uint32_t) * 10 * (size_t)b->max_lines);
     b->status = (int32_t *)malloc(sizeof(int32_t) * (size_t)b->max_lines);
@@ -1107,7 +1116,8 @@ static int run_batch_reserve(run_batch_t *b, int lines) {
     return (b->line_off && b->field_off && b->status && b->ints && b->dbl) ? HPGV_OK : HPGV_ERR_NOMEM;
 }
 static void run_batch_free(run_batch_t *b) {
-    free(b->text); free(b->line_off); free(b->field_off); free(b->status); free(b->ints); free(b->dbl);
+    if (b->text) (void)hpgv_host_free(g_ctx, b->text);
+    free(b->line_off); free(b->field_off); free(b->status); free(b->ints); free(b->dbl);
 }
 
 /* one output line per record, the reference's formats (assoc_runner.c:314-318,332-336; tdt_runner.c:297-299) */
@@ -1142,31 +1152,58 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     int rc = ensure_engine();
     if (rc) return rc;
     if (batch_bytes < (1u << 16)) batch_bytes = 1u << 16;
+#ifdef _OPENMP
+    omp_set_max_active_levels(2);          /* the reader's pread team runs inside the sections (assoc_runner.c:82 enables nesting too) */
+#endif
     ped_table_t ped;
     if ((rc = ped_table_read(ped_path, &ped))) return rc;
-    FILE *vf = fopen(vcf_path, "rb");
-    if (!vf) { ped_table_free(&ped); snprintf(g_err, sizeof g_err, "cannot open VCF file %s", vcf_path); return HPGV_ERR_INVALID; }
-    /* header: skip '##' lines, take the sample names from the '#CHROM' line */
+    int vfd = open(vcf_path, O_RDONLY);
+    struct stat st;
+    if (vfd < 0 || fstat(vfd, &st) != 0) {
+        if (vfd >= 0) close(vfd);
+        ped_table_free(&ped);
+        snprintf(g_err, sizeof g_err, "cannot open VCF file %s", vcf_path);
+        return HPGV_ERR_INVALID;
+    }
+    /* header: skip '##' lines, take the sample names from the '#CHROM' line; data starts after it */
     char *hdr = NULL;
-    size_t hcap = 0;
-    ssize_t hl;
     int n_samples = -1;
     char **names = NULL;
-    while ((hl = getline(&hdr, &hcap, vf)) > 0) {
-        if (hdr[0] != '#') break;
-        if (!strncmp(hdr, "#CHROM", 6)) {
-            while (hl > 0 && (hdr[hl - 1] == '\n' || hdr[hl - 1] == '\r')) hdr[--hl] = 0;
-            int tabs = 0;
-            for (ssize_t i = 0; i < hl; i++) if (hdr[i] == '\t') tabs++;
-            n_samples = tabs >= 9 ? tabs - 8 : 0;
-            names = (char **)malloc(sizeof(char *) * (size_t)(n_samples + 1));
-            int k = 0, col = 0;
-            for (char *p = hdr; *p; p++)
-                if (*p == '\t') { *p = 0; col++; if (col >= 9 && k < n_samples) names[k++] = p + 1; }
-            break;
+    off_t data_start = 0;
+    {
+        size_t cap = 1u << 20, have = 0;
+        hdr = (char *)malloc(cap + 1);
+        for (;;) {                                       /* grow until the #CHROM line is complete */
+            ssize_t got = hdr ? pread(vfd, hdr + have, cap - have, (off_t)have) : -1;
+            if (got > 0) have += (size_t)got;
+            hdr[have] = 0;
+            char *p = hdr, *chrom = NULL;
+            while (*p == '#') {
+                char *eol = strchr(p, '\n');
+                if (!eol) { p = NULL; break; }
+                if (!strncmp(p, "#CHROM", 6)) { chrom = p; *eol = 0; data_start = (off_t)(eol + 1 - hdr); break; }
+                p = eol + 1;
+            }
+            if (chrom) {
+                size_t len = strlen(chrom);
+                while (len > 0 && chrom[len - 1] == '\r') chrom[--len] = 0;
+                int tabs = 0;
+                for (size_t i = 0; i < len; i++) if (chrom[i] == '\t') tabs++;
+                n_samples = tabs >= 9 ? tabs - 8 : 0;
+                names = (char **)malloc(sizeof(char *) * (size_t)(n_samples + 1));
+                int k = 0, col = 0;
+                for (char *q = chrom; *q; q++)
+                    if (*q == '\t') { *q = 0; col++; if (col >= 9 && k < n_samples) names[k++] = q + 1; }
+                break;
+            }
+            if (p != NULL || got <= 0 || have < cap) break;      /* a data line came first, or end of file */
+            cap *= 2;
+            char *nh = (char *)realloc(hdr, cap + 1);
+            if (!nh) break;
+            hdr = nh;
         }
     }
-    if (n_samples < 0) { fclose(vf); free(hdr); ped_table_free(&ped); snprintf(g_err, sizeof g_err, "no #CHROM header line in %s", vcf_path); return HPGV_ERR_INVALID; }
+    if (n_samples < 0) { close(vfd); free(hdr); ped_table_free(&ped); snprintf(g_err, sizeof g_err, "no #CHROM header line in %s", vcf_path); return HPGV_ERR_INVALID; }
 
     /* cohort: PED rows looked up by sample name (associate_samples_and_positions + sort_individuals) */
     sample_ids_t *ids = sample_ids_new((size_t)n_samples);
@@ -1238,10 +1275,7 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     if (!rc) {
         if (kind == 3) tdt_write_output_header(out); else assoc_write_output_header((enum ASSOC_task)kind, out);
         line_reader_t rd;
-        memset(&rd, 0, sizeof rd);
-        rd.f = vf;
-        /* the first data line was consumed by getline while looking for the header's end */
-        if (hl > 0 && hdr[0] != '#') { rd.carry = (char *)malloc((size_t)hl); rd.carry_cap = (size_t)hl; memcpy(rd.carry, hdr, (size_t)hl); rd.carry_len = (size_t)hl; }
+        rd.fd = vfd; rd.pos = data_start; rd.size = st.st_size;
         /* software pipeline over batches: while the engine works on batch k (thread A), the same thread of
          * the previous iteration's results are written and the next batch is read (thread B) */
         int cur = 0;
@@ -1285,14 +1319,13 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
             cur = nxt;
         }
         if (!rc && prev_ready) write_batch(out, kind, &bt[cur ^ 1]);
-        free(rd.carry);
     }
     if (out) fclose(out);
     if (!rc && hpgv_host_sort_output_file(out_path))                    /* assoc_runner.c:255-261: only a warning there */
         fprintf(stderr, "WARN: results could not be sorted by chromosome and position\n");
     if (have[0]) run_batch_free(&bt[0]);
     if (have[1]) run_batch_free(&bt[1]);
-    fclose(vf); free(hdr); free(names); ped_table_free(&ped);
+    close(vfd); free(hdr); free(names); ped_table_free(&ped);
     if (n_variants_out) *n_variants_out = written;
     return rc;
 }

@@ -117,6 +117,10 @@ int  hpgv_dev_free(hpgv_ctx *ctx, void *dptr);
 int  hpgv_memcpy_h2d(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream);
 int  hpgv_memcpy_d2h(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream);
 int  hpgv_stream_sync(hpgv_ctx *ctx, void *stream);   /* stream NULL = default stream */
+/* page-locked host memory: buffers handed to the host entry points copy to the device at full
+ * PCIe rate when they come from here (pageable memory is staged by the driver, 2-4x slower) */
+int  hpgv_host_alloc(hpgv_ctx *ctx, size_t bytes, void **hptr);
+int  hpgv_host_free(hpgv_ctx *ctx, void *hptr);
 
 /* ---- layout kernels: VCF-order code matrix (device) -> engine layout ------ */
 /* which: 0 assoc, 1 tdt, 2 stats, 3 stats by phenotype group, 4 Mendelian-error trios.  d_src rows are src_pitch bytes apart and hold
