@@ -26,6 +26,17 @@ def pytest_collection_modifyitems(config, items):
     pass
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_libraries():
+    """Builds libhpgv.so / libhpgv_host.so / the oracle when they are missing or stale (no-op otherwise).
+    Building is not a fallback: without a GPU the engine still refuses to run."""
+    import importlib
+    hpgv = importlib.import_module("hpg-variant_amd")
+    hpgv.build()
+    from oracle import pyoracle
+    pyoracle.build()
+
+
 @pytest.fixture(scope="session")
 def goldens():
     import json
