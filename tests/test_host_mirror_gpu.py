@@ -178,12 +178,13 @@ def test_tdt_test_runner_shape(driver, tmp_path):
             assert (np.isnan(g) and np.isnan(e)) or (np.isinf(g) and np.isinf(e)) or abs(g - e) <= 6e-7 * max(1.0, abs(e))
 
 
-def test_get_variants_stats_and_sample_stats(driver, tmp_path):
+@pytest.mark.parametrize("n_fam,n_extra,n_variants", [(20, 30, 200), (0, 100, 1000)])   # second: BASELINE configs[0], 1k x 100
+def test_get_variants_stats_and_sample_stats(driver, tmp_path, n_fam, n_extra, n_variants):
     rng = np.random.default_rng(13)
-    people, names, rows = _write_inputs(tmp_path, rng, 20, 30, 200)
+    people, names, rows = _write_inputs(tmp_path, rng, n_fam, n_extra, n_variants)
     r = subprocess.run([driver, "stats", str(tmp_path / "batch.txt"), str(tmp_path / "stats.tsv"), str(tmp_path / "ped.txt")],
                        capture_output=True, text=True)
-    assert r.returncode == 0 and "STATS OK variants=200" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and ("STATS OK variants=%d" % n_variants) in r.stdout, r.stdout + r.stderr
     gt = _codes(rows, False)
     lines = [l.rstrip("\n").split("\t") for l in open(tmp_path / "stats.tsv")]
     vlines = [t for t in lines if t[0] == "V"]
@@ -212,7 +213,7 @@ def test_get_variants_stats_and_sample_stats(driver, tmp_path):
     exp_mendel = np.zeros(len(names), np.int64)
     for t, e_ in zip(trios, trio_err):
         exp_mendel[t[2]] += e_
-    assert exp_mendel.sum() > 0
+    assert exp_mendel.sum() > 0 or not trios
     for j, t in enumerate(slines):
         assert t[1] == names[j] and int(t[2]) == miss[j] and int(t[3]) == exp_mendel[j], (j, t)
 
