@@ -19,7 +19,7 @@ OK = 0
 TASK_CHISQ, TASK_FISHER = 1, 2
 COND_UNAFFECTED, COND_AFFECTED, COND_OTHER = 0, 1, 2
 SEX_MALE, SEX_FEMALE, SEX_UNKNOWN = 0, 1, 2
-LAYOUT_ASSOC, LAYOUT_TDT, LAYOUT_STATS, LAYOUT_STATS_GROUPS, LAYOUT_MENDEL = 0, 1, 2, 3, 4
+LAYOUT_ASSOC, LAYOUT_TDT, LAYOUT_STATS, LAYOUT_STATS_GROUPS, LAYOUT_MENDEL, LAYOUT_EPI = 0, 1, 2, 3, 4, 5
 GT_MISSING = 0xFF
 
 # every symbol include/hpgv.h declares (checked by the CPU suite)
@@ -35,7 +35,7 @@ SYMBOLS = [
     "hpgv_assoc_scan_dev", "hpgv_assoc_chisq_dev", "hpgv_assoc_fisher_dev",
     "hpgv_tdt_scan_dev", "hpgv_tdt_stats_dev", "hpgv_stats_scan_dev", "hpgv_stats_hwe_dev",
     "hpgv_sample_missing_dev", "hpgv_genotype_table_dev", "hpgv_stats_filter_dev",
-    "hpgv_mendel", "hpgv_tokenize_dev", "hpgv_tokenize", "hpgv_assoc_text", "hpgv_tdt_text",
+    "hpgv_mendel", "hpgv_epi_dataset", "hpgv_tokenize_dev", "hpgv_tokenize", "hpgv_assoc_text", "hpgv_tdt_text",
     "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_read_probe",
 ]
 
@@ -116,6 +116,7 @@ def load():
     L.hpgv_mendel_scan_dev.argtypes = [vp, vp, i32, vp, vp, vp]
     L.hpgv_mendel_children_dev.argtypes = [vp, vp, i32, vp, vp, vp]
     L.hpgv_mendel.argtypes = [vp, vp, sz, i32, vp, vp, vp]
+    L.hpgv_epi_dataset.argtypes = [vp, vp, sz, i32, vp]
     L.hpgv_read_probe.argtypes = [vp, vp, sz, i32, C.POINTER(C.c_float)]
     _lib = L
     return L
@@ -275,6 +276,14 @@ class Engine:
         chi2, p = np.zeros(nv, np.float64), np.zeros(nv, np.float64)
         self._chk(self.L.hpgv_stats(self.h, _ptr(gt), pitch, nv, _ptr(c8), _ptr(chi2), _ptr(p)))
         return dict(counts8=c8, hwe_chi2=chi2, hwe_p=p)
+
+    def epi_dataset(self, gt):
+        gt = _np(gt, np.uint8)
+        nv, pitch = gt.shape
+        nA, nU, _ = self.assoc_layout()
+        out = np.zeros((nv, nA + nU), np.uint8)
+        self._chk(self.L.hpgv_epi_dataset(self.h, _ptr(gt), pitch, nv, _ptr(out)))
+        return out
 
     def mendel(self, gt, is_x=None, child_errors=None):
         gt = _np(gt, np.uint8)

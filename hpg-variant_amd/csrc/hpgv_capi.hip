@@ -524,6 +524,7 @@ static Layout *pick_layout(hpgv_ctx *ctx, int which) {
         case HPGV_LAYOUT_STATS: return &ctx->stats;
         case HPGV_LAYOUT_STATS_GROUPS: return &ctx->sgroups;
         case HPGV_LAYOUT_MENDEL: return &ctx->mendel;
+        case HPGV_LAYOUT_EPI: return &ctx->assoc;
         default: return nullptr;
     }
 }
@@ -534,6 +535,7 @@ static void recode_of(const hpgv_ctx *ctx, int which, int *mode, int *p16) {
     if (which == HPGV_LAYOUT_TDT) { *mode = hpgv::RECODE_TDT; *p16 = ctx->tdt_plan.p16; }
     else if (which == HPGV_LAYOUT_STATS || which == HPGV_LAYOUT_STATS_GROUPS) { *mode = hpgv::RECODE_STATS; }
     else if (which == HPGV_LAYOUT_MENDEL) { *mode = hpgv::RECODE_MENDEL; }
+    else if (which == HPGV_LAYOUT_EPI) { *mode = hpgv::RECODE_EPI; }
 }
 
 int hpgv_layout_dev(hpgv_ctx *ctx, int which, const uint8_t *d_src, size_t src_pitch, int n_variants,
@@ -1070,6 +1072,29 @@ int hpgv_stats_ex(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants
 int hpgv_stats(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, int32_t *counts8,
                double *hwe_chi2, double *hwe_p) {
     return hpgv_stats_ex(ctx, gt, pitch, n_variants, counts8, hwe_chi2, hwe_p, nullptr, nullptr, nullptr, nullptr);
+}
+
+int hpgv_epi_dataset(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, uint8_t *out) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->assoc.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_cohort has not been called");
+    if (n_variants < 0 || (n_variants > 0 && (!gt || !out))) return fail(ctx, HPGV_ERR_INVALID, "bad epi arguments");
+    if (pitch < (size_t)ctx->assoc.n_samples) return fail(ctx, HPGV_ERR_INVALID, "pitch %zu < n_samples %d", pitch, ctx->assoc.n_samples);
+    const size_t nA = (size_t)ctx->nA, nU = (size_t)ctx->nU, width = nA + nU;
+    if (n_variants == 0 || width == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    SlotLease lease(ctx);
+    int rc = acquire_slot(ctx, &lease.s);
+    if (rc) return rc;
+    Slot *s = lease.s;
+    const uint8_t *d_isx = nullptr;
+    if ((rc = stage_batch(ctx, s, HPGV_LAYOUT_EPI, ctx->assoc, gt, pitch, n_variants, nullptr, &d_isx))) return rc;
+    const uint8_t *d = (const uint8_t *)s->buf[1];
+    const size_t segA = (size_t)ctx->chunksA * 16, dp = ctx->assoc.pitch;
+    // drop the 16-byte pads: cases, then controls, straight into the caller's rows
+    if (nA) HIPCHK(ctx, hipMemcpy2DAsync(out, width, d, dp, nA, (size_t)n_variants, hipMemcpyDeviceToHost, s->stream));
+    if (nU) HIPCHK(ctx, hipMemcpy2DAsync(out + nA, width, d + segA, dp, nU, (size_t)n_variants, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    return HPGV_OK;
 }
 
 int hpgv_mendel(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, const uint8_t *is_x,

@@ -439,11 +439,13 @@ __device__ __forceinline__ uint32_t synth_gt(uint64_t vterm, uint64_t s, uint32_
 //   RECODE_TDT   : positions [0,p16) father / [p16,2p16) mother planes hold the
 //                  parent class, [2p16,3p16) the child class (tdt classes below)
 //   RECODE_STATS : one-hot genotype cell / missing / extra-allele flags
+//   RECODE_EPI   : the epistasis dataset code of vcf2epi (dataset_creator.c:255-266):
+//                  0 "0/0", 1 heterozygous (a1 != a2), 2 homozygous non-reference, 255 not ALLELES_OK
 //   RECODE_MENDEL: zero-ness class 0 "0/0", 1 one zero allele, 2 no zero allele, 3 not fully called
 //                  (what check_mendel looks at), in father / mother / child planes
 // Every class is a function of that ONE genotype and of the column's fixed role.
 // ---------------------------------------------------------------------------
-enum { RECODE_NONE = 0, RECODE_TDT = 1, RECODE_STATS = 2, RECODE_MENDEL = 3 };
+enum { RECODE_NONE = 0, RECODE_TDT = 1, RECODE_STATS = 2, RECODE_MENDEL = 3, RECODE_EPI = 4 };
 
 // parent classes (tdt.c:113-123 tests): 0 "0/0", 1 "0/x", 2 "x/x" (equal, non-zero),
 // 3 "x/y" (both non-zero, different); unusable = missing or "x/0" (tdt.c:103-108,119)
@@ -499,6 +501,13 @@ __device__ __forceinline__ uint32_t recode_byte(uint32_t g, int mode, int p16, i
     }
     if (mode == RECODE_STATS) return is_pad ? 0u : stats_flags(g);
     if (mode == RECODE_MENDEL) return mendel_class(g);
+    if (mode == RECODE_EPI) {
+        const uint32_t a1 = g >> 4, a2 = g & 0xFu;
+        if (a1 == 0xFu || a2 == 0xFu) return 255u;          // dataset_creator.c:255-257
+        if (!a1 && !a2) return 0u;                          // :259
+        if (a1 != a2) return 1u;                            // :261
+        return 2u;                                          // :263
+    }
     return g;
 }
 

@@ -123,10 +123,11 @@ int  hpgv_host_alloc(hpgv_ctx *ctx, size_t bytes, void **hptr);
 int  hpgv_host_free(hpgv_ctx *ctx, void *hptr);
 
 /* ---- layout kernels: VCF-order code matrix (device) -> engine layout ------ */
-/* which: 0 assoc, 1 tdt, 2 stats, 3 stats by phenotype group, 4 Mendelian-error trios.  d_src rows are src_pitch bytes apart and hold
+/* which: 0 assoc, 1 tdt, 2 stats, 3 stats by phenotype group, 4 Mendelian-error trios,
+ * 5 epistasis dataset (assoc column order, vcf2epi codes 0/1/2/255; pads 255).  d_src rows are src_pitch bytes apart and hold
  * n_samples codes in VCF column order; d_dst rows use the layout's pitch. */
 enum { HPGV_LAYOUT_ASSOC = 0, HPGV_LAYOUT_TDT = 1, HPGV_LAYOUT_STATS = 2, HPGV_LAYOUT_STATS_GROUPS = 3,
-       HPGV_LAYOUT_MENDEL = 4 };
+       HPGV_LAYOUT_MENDEL = 4, HPGV_LAYOUT_EPI = 5 };
 int  hpgv_layout_dev(hpgv_ctx *ctx, int which, const uint8_t *d_src, size_t src_pitch,
                      int n_variants, uint8_t *d_dst, void *stream);
 
@@ -222,6 +223,12 @@ int  hpgv_stats(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants,
 int  hpgv_stats_ex(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants,
                    int32_t *counts8, double *hwe_chi2, double *hwe_p, int32_t *sample_missing,
                    int32_t *multi_idx, int32_t *multi_table, int *n_multi);
+
+/* epistasis dataset rows of vcf2epi (epistasis_dataset_process_records, dataset_creator.c:241-272):
+ * out[v * (n_affected + n_unaffected) + destination] with cases first then controls, each in VCF column
+ * order (group_individuals_by_phenotype, :302-320), codes 0 "0/0", 1 heterozygous, 2 homozygous
+ * non-reference, 255 missing.  Uses the cohort of hpgv_set_cohort. */
+int  hpgv_epi_dataset(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, uint8_t *out);
 
 /* Mendelian errors of a host batch: errors[v] per variant (may be NULL) and child_errors[t] per trio of
  * hpgv_set_pedigree, ACCUMULATED into (may be NULL) */

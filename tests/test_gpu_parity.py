@@ -487,3 +487,45 @@ def test_mendelian_errors_per_variant_and_per_child(n_trios):
         assert np.array_equal(e.d2h(d_child, (n_trios,), np.int32), exp_trio)
         assert exp_err.sum() > 0
     e.close()
+
+
+def test_epistasis_dataset_reference_kat_and_random(goldens):
+    # test/test_epistasis_dataset.c:87-154 through the HIP layout (cases first, codes 0/1/2/255)
+    k = goldens["kats"]["epistasis_dataset"]
+    n = k["num_samples"]
+    rows = []
+    for r in range(3):
+        row = [k["possible_gts"][(i + r) % 3] for i in range(n)]
+        if r == 0:
+            row[-1] = "./."
+        rows.append(row)
+    gt = orc.encode_matrix(rows, strict=False)
+    pheno = (np.arange(n) % 2).astype(np.uint8)                  # phenotypes[i] = i % 2, 1 = affected
+    e = fresh()
+    e.set_cohort(pheno)
+    out = e.epi_dataset(gt)
+    for r, exp in k["expected"].items():
+        for dest, code in exp.items():
+            assert out[int(r), int(dest)] == code, (r, dest)
+    # destination rule of group_individuals_by_phenotype (test_destination): cases at (i+1)/2-1, controls at nA+(i+1)/2
+    dest = [((i + 1) // 2 - 1) if i % 2 else (10 + (i + 1) // 2) for i in range(n)]
+    full = np.zeros((3, n), np.uint8)
+    for r in range(3):
+        for i in range(n):
+            a = orc.get_alleles(rows[r][i])
+            full[r, dest[i]] = 255 if a[0] != 0 else (0 if (a[1] == 0 and a[2] == 0) else (1 if a[1] != a[2] else 2))
+    assert np.array_equal(out, full)
+    e.close()
+    # random cohort with every genotype spelling
+    rng = np.random.default_rng(2)
+    n = 1037
+    cond = rng.choice([0, 1, 2], size=n).astype(np.uint8)
+    gt = random_codes(rng, 90, n, quirks=True, strict=False)
+    e = fresh()
+    e.set_cohort(cond)
+    out = e.epi_dataset(gt)
+    order = np.concatenate([np.flatnonzero(cond == 1), np.flatnonzero(cond == 0)])
+    a1, a2 = gt[:, order] >> 4, gt[:, order] & 0xF
+    exp = np.where((a1 == 15) | (a2 == 15), 255, np.where((a1 == 0) & (a2 == 0), 0, np.where(a1 != a2, 1, 2))).astype(np.uint8)
+    assert np.array_equal(out, exp)
+    e.close()
