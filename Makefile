@@ -13,7 +13,7 @@ $(LIBDIR)/libhpgv.so: $(CSRC)/hpgv_capi.hip $(wildcard $(CSRC)/*.h) include/hpgv
 
 $(LIBDIR)/libhpgv_host.so: $(HOST)/hpgv_host.c include/hpgv_host.h include/hpgv.h $(LIBDIR)/libhpgv.so
 	$(CC) -O2 -g -std=gnu99 -fPIC -shared -fopenmp -Wall -Wextra -Iinclude -o $@ $(HOST)/hpgv_host.c \
-	    -L$(LIBDIR) -lhpgv -Wl,-rpath,'$$ORIGIN' -lm
+	    -L$(LIBDIR) -lhpgv -Wl,-rpath,'$$ORIGIN' -lm -lz
 
 oracle:
 	$(MAKE) -C oracle

@@ -53,7 +53,7 @@ def build_host_lib(force=False, verbose=False):
     csrcs = [s for s in srcs if s.endswith(".c")]
     cmd = ["gcc", "-O2", "-g", "-std=gnu99", "-fPIC", "-shared", "-fopenmp", "-Wall", "-Wextra",
            "-I", os.path.join(ROOT, "include"), "-I", hdir, "-o", HOSTLIB] + csrcs + \
-          ["-L", LIBDIR, "-lhpgv", "-Wl,-rpath,$ORIGIN", "-lm"]
+          ["-L", LIBDIR, "-lhpgv", "-Wl,-rpath,$ORIGIN", "-lm", "-lz"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -13,8 +13,10 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -1051,37 +1053,180 @@ static int ped_table_read(const char *path, ped_table_t *ped) {
     return HPGV_OK;
 }
 
-/* batch reader: whole lines, about batch_bytes per batch.  The file is read with pread() from a few
- * threads (one kernel copy out of the page cache per thread) straight into the pinned batch buffer. */
+/* ---- byte sources: plain file (pread by a small thread team), BGZF (blocks inflated in parallel),
+ *      generic gzip (one zlib stream) -- shared_options.c:60-61 `--compression gzip|bgzip` ------------ */
+enum { SRC_RAW = 0, SRC_BGZF = 1, SRC_GZIP = 2 };
 typedef struct {
-    int fd;
-    off_t pos, size;                                    /* next unread byte, file size */
+    int kind, fd;
+    off_t pos, size;                                    /* RAW: next unread byte, file size */
+    const unsigned char *map; size_t map_pos;           /* BGZF: the mapped compressed file, next block */
+    unsigned char *pend; size_t pend_len, pend_pos;     /* BGZF: a block inflated aside because the caller's room was short */
+    size_t *blk;                                        /* BGZF: per-call block table (offset, length, destination, size) */
+    gzFile gz;                                          /* GZIP */
+} source_t;
+
+static int bgzf_block(const unsigned char *p, size_t avail, size_t *bsize, size_t *cdata_off, size_t *isize) {
+    if (avail < 18 || p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) return 0;
+    size_t xlen = (size_t)p[10] | ((size_t)p[11] << 8), off = 12, end = 12 + xlen;
+    if (end > avail) return 0;
+    size_t bs = 0;
+    while (off + 4 <= end) {
+        size_t slen = (size_t)p[off + 2] | ((size_t)p[off + 3] << 8);
+        if (p[off] == 'B' && p[off + 1] == 'C' && slen == 2 && off + 6 <= end) bs = ((size_t)p[off + 4] | ((size_t)p[off + 5] << 8)) + 1;
+        off += 4 + slen;
+    }
+    if (bs < end + 8 || bs > avail) return 0;
+    *bsize = bs; *cdata_off = end;
+    *isize = (size_t)p[bs - 4] | ((size_t)p[bs - 3] << 8) | ((size_t)p[bs - 2] << 16) | ((size_t)p[bs - 1] << 24);
+    return 1;
+}
+
+static int source_open(source_t *s, const char *path) {
+    memset(s, 0, sizeof *s);
+    s->fd = open(path, O_RDONLY);
+    struct stat st;
+    if (s->fd < 0 || fstat(s->fd, &st) != 0) { if (s->fd >= 0) close(s->fd); return 1; }
+    s->size = st.st_size;
+    unsigned char head[18];
+    ssize_t got = pread(s->fd, head, sizeof head, 0);
+    if (got >= 2 && head[0] == 31 && head[1] == 139) {
+        size_t bs, co, is;
+        s->map = (const unsigned char *)mmap(NULL, (size_t)s->size, PROT_READ, MAP_PRIVATE, s->fd, 0);
+        if (s->map != MAP_FAILED && bgzf_block(s->map, (size_t)s->size, &bs, &co, &is)) { s->kind = SRC_BGZF; return 0; }
+        if (s->map != MAP_FAILED) munmap((void *)s->map, (size_t)s->size);
+        s->map = NULL;
+        s->gz = gzdopen(dup(s->fd), "rb");
+        if (!s->gz) { close(s->fd); return 1; }
+        gzbuffer(s->gz, 1u << 20);
+        s->kind = SRC_GZIP;
+    }
+    return 0;
+}
+
+static void source_close(source_t *s) {
+    if (s->kind == SRC_BGZF && s->map) munmap((void *)s->map, (size_t)s->size);
+    free(s->pend); free(s->blk);
+    if (s->kind == SRC_GZIP && s->gz) gzclose(s->gz);
+    if (s->fd >= 0) close(s->fd);
+}
+
+static int inflate_block(const unsigned char *in, size_t clen, unsigned char *out, size_t isize) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return 1;
+    zs.next_in = (Bytef *)in; zs.avail_in = (uInt)clen;
+    zs.next_out = (Bytef *)out; zs.avail_out = (uInt)isize;
+    int bad = inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.total_out != isize;
+    inflateEnd(&zs);
+    return bad;
+}
+
+/* appends up to cap bytes of (decompressed) data to buf; 0 = end of data, (size_t)-1 = error.  RAW and GZIP
+ * fill the room unless the data ends; BGZF hands out the whole blocks that fit (inflated in parallel, straight
+ * into buf), or -- when not even the next block fits -- the part of it that does, so callers loop. */
+static size_t source_read(source_t *s, char *buf, size_t cap) {
+    if (s->kind == SRC_RAW) {
+        if (s->pos >= s->size) return 0;
+        size_t want = (size_t)(s->size - s->pos) < cap ? (size_t)(s->size - s->pos) : cap;
+        const size_t seg = 8u << 20;
+        const int n_seg = (int)((want + seg - 1) / seg);
+        int bad = 0;
+        #pragma omp parallel for num_threads(8) schedule(static) if (n_seg > 1)
+        for (int k = 0; k < n_seg; k++) {
+            size_t off = (size_t)k * seg, len = off + seg <= want ? seg : want - off;
+            while (len > 0) {
+                ssize_t got = pread(s->fd, buf + off, len, s->pos + (off_t)off);
+                if (got <= 0) { bad = 1; break; }
+                off += (size_t)got; len -= (size_t)got;
+            }
+        }
+        if (bad) return (size_t)-1;
+        s->pos += (off_t)want;
+        return want;
+    }
+    if (s->kind == SRC_GZIP) {
+        size_t n = 0;
+        while (n < cap) {
+            unsigned chunk = (cap - n) > (1u << 30) ? (1u << 30) : (unsigned)(cap - n);
+            int got = gzread(s->gz, buf + n, chunk);
+            if (got < 0) return (size_t)-1;
+            if (got == 0) break;
+            n += (size_t)got;
+        }
+        return n;
+    }
+    /* BGZF */
+    if (cap == 0) return 0;
+    if (s->pend_pos < s->pend_len) {                                  /* rest of the block set aside last time */
+        size_t n = s->pend_len - s->pend_pos < cap ? s->pend_len - s->pend_pos : cap;
+        memcpy(buf, s->pend + s->pend_pos, n);
+        s->pend_pos += n;
+        return n;
+    }
+    enum { MAXB = 1 << 16 };
+    size_t total = 0;
+    int nb = 0;
+    if (!s->blk && !(s->blk = (size_t *)malloc(sizeof(size_t) * 4 * MAXB))) return (size_t)-1;
+    size_t *const b_in = s->blk, *const b_clen = s->blk + MAXB, *const b_out = s->blk + 2 * MAXB, *const b_isize = s->blk + 3 * MAXB;
+    size_t pos = s->map_pos;
+    while (pos < (size_t)s->size && nb < MAXB) {
+        size_t bs, co, is;
+        if (!bgzf_block(s->map + pos, (size_t)s->size - pos, &bs, &co, &is) || is > 65536) return (size_t)-1;
+        if (total + is > cap) break;
+        b_in[nb] = pos + co; b_clen[nb] = bs - co - 8; b_out[nb] = total; b_isize[nb] = is;
+        total += is; pos += bs; nb++;
+    }
+    if (total == 0) {
+        if (pos >= (size_t)s->size) { s->map_pos = pos; return 0; }   /* only empty blocks (the EOF marker) were left */
+        size_t bs, co, is;                                            /* the next block is larger than the room */
+        if (!bgzf_block(s->map + pos, (size_t)s->size - pos, &bs, &co, &is)) return (size_t)-1;
+        if (!s->pend && !(s->pend = (unsigned char *)malloc(65536))) return (size_t)-1;
+        if (inflate_block(s->map + pos + co, bs - co - 8, s->pend, is)) return (size_t)-1;
+        s->map_pos = pos + bs;
+        s->pend_len = is; s->pend_pos = cap;
+        memcpy(buf, s->pend, cap);
+        return cap;
+    }
+    int bad = 0;
+    #pragma omp parallel for num_threads(16) schedule(dynamic, 8) if (nb > 16)
+    for (int k = 0; k < nb; k++) {
+        if (b_isize[k] == 0) continue;                                /* e.g. the BGZF end-of-file marker */
+        if (inflate_block(s->map + b_in[k], b_clen[k], (unsigned char *)buf + b_out[k], b_isize[k])) bad = 1;
+    }
+    if (bad) return (size_t)-1;
+    s->map_pos = pos;
+    return total;
+}
+
+/* batch reader on top of a source: whole lines, about batch_bytes per batch; the unfinished last line is
+ * carried over to the next batch */
+typedef struct {
+    source_t src;
+    char *carry; size_t carry_len, carry_cap;
+    int eof;
 } line_reader_t;
 
-/* fills buf (capacity cap) with whole lines starting at r->pos; returns the byte count, 0 at the end,
- * (size_t)-1 when a single line does not fit */
+/* fills buf (capacity cap) with whole lines; returns the byte count, 0 at the end, (size_t)-1 when a
+ * single line does not fit or the source fails */
 static size_t read_lines(line_reader_t *r, char *buf, size_t cap) {
-    if (r->pos >= r->size) return 0;
-    size_t want = (size_t)(r->size - r->pos) < cap ? (size_t)(r->size - r->pos) : cap;
-    const size_t seg = 8u << 20;
-    const int n_seg = (int)((want + seg - 1) / seg);
-    int bad = 0;
-    #pragma omp parallel for num_threads(8) schedule(static) if (n_seg > 1)
-    for (int k = 0; k < n_seg; k++) {
-        size_t off = (size_t)k * seg, len = off + seg <= want ? seg : want - off;
-        while (len > 0) {
-            ssize_t got = pread(r->fd, buf + off, len, r->pos + (off_t)off);
-            if (got <= 0) { bad = 1; break; }
-            off += (size_t)got; len -= (size_t)got;
-        }
+    size_t n = 0;
+    if (r->carry_len) { if (r->carry_len > cap) return (size_t)-1; memcpy(buf, r->carry, r->carry_len); n = r->carry_len; r->carry_len = 0; }
+    while (!r->eof && n < cap) {
+        size_t got = source_read(&r->src, buf + n, cap - n);
+        if (got == (size_t)-1) return (size_t)-1;
+        if (got == 0) { r->eof = 1; break; }
+        n += got;
     }
-    if (bad) return 0;
-    size_t end = want;
-    if (r->pos + (off_t)want < r->size) {               /* not the last batch: cut at the last newline */
-        while (end > 0 && buf[end - 1] != '\n') end--;
-        if (end == 0) return (size_t)-1;
-    }
-    r->pos += (off_t)end;
+    if (n == 0) return 0;
+    if (r->eof) return n;                               /* last batch: may end without a newline */
+    size_t end = n;
+    while (end > 0 && buf[end - 1] != '\n') end--;
+    if (end == 0) return (size_t)-1;
+    size_t tail = n - end;
+    if (tail > r->carry_cap) { free(r->carry); r->carry = (char *)malloc(tail); r->carry_cap = r->carry ? tail : 0; }
+    if (tail && !r->carry) return (size_t)-1;
+    memcpy(r->carry, buf + end, tail);
+    r->carry_len = tail;
     return end;
 }
 
@@ -1157,31 +1302,34 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
 #endif
     ped_table_t ped;
     if ((rc = ped_table_read(ped_path, &ped))) return rc;
-    int vfd = open(vcf_path, O_RDONLY);
-    struct stat st;
-    if (vfd < 0 || fstat(vfd, &st) != 0) {
-        if (vfd >= 0) close(vfd);
+    line_reader_t rd;
+    memset(&rd, 0, sizeof rd);
+    if (source_open(&rd.src, vcf_path)) {
         ped_table_free(&ped);
         snprintf(g_err, sizeof g_err, "cannot open VCF file %s", vcf_path);
         return HPGV_ERR_INVALID;
     }
-    /* header: skip '##' lines, take the sample names from the '#CHROM' line; data starts after it */
+    /* header: skip '##' lines, take the sample names from the '#CHROM' line; what follows it in the
+     * bytes already read becomes the reader's carry */
     char *hdr = NULL;
     int n_samples = -1;
     char **names = NULL;
-    off_t data_start = 0;
     {
-        size_t cap = 1u << 20, have = 0;
+        size_t cap = 4u << 20, have = 0;
         hdr = (char *)malloc(cap + 1);
-        for (;;) {                                       /* grow until the #CHROM line is complete */
-            ssize_t got = hdr ? pread(vfd, hdr + have, cap - have, (off_t)have) : -1;
-            if (got > 0) have += (size_t)got;
+        int done = 0;
+        while (hdr && !done) {
+            const int starved = cap == have;             /* header longer than the buffer: grow first */
+            size_t got = starved ? 0 : source_read(&rd.src, hdr + have, cap - have);
+            if (got == (size_t)-1) break;
+            have += got;
             hdr[have] = 0;
             char *p = hdr, *chrom = NULL;
+            size_t data_start = 0;
             while (*p == '#') {
-                char *eol = strchr(p, '\n');
+                char *eol = (char *)memchr(p, '\n', have - (size_t)(p - hdr));
                 if (!eol) { p = NULL; break; }
-                if (!strncmp(p, "#CHROM", 6)) { chrom = p; *eol = 0; data_start = (off_t)(eol + 1 - hdr); break; }
+                if (!strncmp(p, "#CHROM", 6)) { chrom = p; *eol = 0; data_start = (size_t)(eol + 1 - hdr); break; }
                 p = eol + 1;
             }
             if (chrom) {
@@ -1194,16 +1342,20 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
                 int k = 0, col = 0;
                 for (char *q = chrom; *q; q++)
                     if (*q == '\t') { *q = 0; col++; if (col >= 9 && k < n_samples) names[k++] = q + 1; }
-                break;
+                size_t rest = have - data_start;
+                if (rest) { rd.carry = (char *)malloc(rest); rd.carry_cap = rd.carry ? rest : 0; if (rd.carry) { memcpy(rd.carry, hdr + data_start, rest); rd.carry_len = rest; } }
+                done = 1;
+            } else if (p != NULL || (!starved && got == 0)) {
+                break;                                   /* a data line came first, or the file ended */
+            } else if (starved) {                        /* header longer than the buffer: grow */
+                cap *= 2;
+                char *nh = (char *)realloc(hdr, cap + 1);
+                if (!nh) break;
+                hdr = nh;
             }
-            if (p != NULL || got <= 0 || have < cap) break;      /* a data line came first, or end of file */
-            cap *= 2;
-            char *nh = (char *)realloc(hdr, cap + 1);
-            if (!nh) break;
-            hdr = nh;
         }
     }
-    if (n_samples < 0) { close(vfd); free(hdr); ped_table_free(&ped); snprintf(g_err, sizeof g_err, "no #CHROM header line in %s", vcf_path); return HPGV_ERR_INVALID; }
+    if (n_samples < 0) { source_close(&rd.src); free(rd.carry); free(hdr); ped_table_free(&ped); snprintf(g_err, sizeof g_err, "no #CHROM header line in %s", vcf_path); return HPGV_ERR_INVALID; }
 
     /* cohort: PED rows looked up by sample name (associate_samples_and_positions + sort_individuals) */
     sample_ids_t *ids = sample_ids_new((size_t)n_samples);
@@ -1274,8 +1426,6 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     if (!rc) { rc = run_batch_alloc(&bt[1], batch_bytes, n_samples); have[1] = 1; }
     if (!rc) {
         if (kind == 3) tdt_write_output_header(out); else assoc_write_output_header((enum ASSOC_task)kind, out);
-        line_reader_t rd;
-        rd.fd = vfd; rd.pos = data_start; rd.size = st.st_size;
         /* software pipeline over batches: while the engine works on batch k (thread A), the same thread of
          * the previous iteration's results are written and the next batch is read (thread B) */
         int cur = 0;
@@ -1325,8 +1475,33 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
         fprintf(stderr, "WARN: results could not be sorted by chromosome and position\n");
     if (have[0]) run_batch_free(&bt[0]);
     if (have[1]) run_batch_free(&bt[1]);
-    close(vfd); free(hdr); free(names); ped_table_free(&ped);
+    source_close(&rd.src); free(rd.carry); free(hdr); free(names); ped_table_free(&ped);
     if (n_variants_out) *n_variants_out = written;
+    return rc;
+}
+
+/* the runners' reader on its own: copies `in_path` (plain, gzip or BGZF) to `out_path` in whole-line batches
+ * of at most batch_bytes; what the runners feed to the engine, batch by batch */
+int hpgv_host_copy_lines(const char *in_path, const char *out_path, size_t batch_bytes, long *n_batches) {
+    line_reader_t rd;
+    memset(&rd, 0, sizeof rd);
+    if (batch_bytes < (1u << 16)) batch_bytes = 1u << 16;
+    if (source_open(&rd.src, in_path)) { snprintf(g_err, sizeof g_err, "cannot open %s", in_path); return HPGV_ERR_INVALID; }
+    FILE *out = fopen(out_path, "wb");
+    char *buf = (char *)malloc(batch_bytes);
+    int rc = (out && buf) ? HPGV_OK : HPGV_ERR_INVALID;
+    long nb = 0;
+    while (!rc) {
+        size_t n = read_lines(&rd, buf, batch_bytes);
+        if (n == 0) break;
+        if (n == (size_t)-1) { snprintf(g_err, sizeof g_err, "read error, or a line longer than batch_bytes, in %s", in_path); rc = HPGV_ERR_UNSUPPORTED; break; }
+        if (!rd.eof && buf[n - 1] != '\n') { rc = HPGV_ERR_UNSUPPORTED; break; }
+        if (fwrite(buf, 1, n, out) != n) { rc = HPGV_ERR_INVALID; break; }
+        nb++;
+    }
+    if (out) fclose(out);
+    free(buf); free(rd.carry); source_close(&rd.src);
+    if (n_batches) *n_batches = nb;
     return rc;
 }
 

@@ -248,8 +248,9 @@ void tdt_write_output_body(list_t *output_list, FILE *fd);                  /* t
 int  hpgv_host_sort_output_file(const char *path);
 
 /* ---- file level: what run_association_test (assoc_runner.c:23-276) and run_tdt_test
- *      (tdt_runner.c:23-279) do, minus options/filters: read the PED, read the (uncompressed) VCF in
- *      text batches of about batch_bytes, hand every batch to the engine as TEXT (the GPU
+ *      (tdt_runner.c:23-279) do, minus options/filters: read the PED, read the VCF (plain text,
+ *      gzip or bgzip -- `--compression`, shared_options.c:60-61; detected from the file's magic, BGZF
+ *      blocks are inflated in parallel) in text batches of about batch_bytes, hand every batch to the engine as TEXT (the GPU
  *      tokenizes it), write the reference's TSV and sort it in process.  Reader, engine and
  *      writer overlap (one batch in flight each way).  PED columns: FID IID PAT MAT SEX PHENO
  *      with SEX 1 = male, 2 = female and PHENO 2 = affected, 1 = unaffected
@@ -259,6 +260,10 @@ int  hpgv_run_assoc(const char *vcf_path, const char *ped_path, const char *out_
                     enum ASSOC_task task, size_t batch_bytes, long *n_variants_out);
 int  hpgv_run_tdt(const char *vcf_path, const char *ped_path, const char *out_path,
                   size_t batch_bytes, long *n_variants_out);
+
+/* The runners' reader on its own: copies `in_path` (plain / gzip / BGZF) to `out_path` in the whole-line
+ * batches (at most batch_bytes each) the runners hand to the engine; *n_batches may be NULL. */
+int  hpgv_host_copy_lines(const char *in_path, const char *out_path, size_t batch_bytes, long *n_batches);
 
 /* ---- staging (GT text -> HPGV8), exposed for tests ---------------------------- */
 int  get_field_position_in_format(const char *field, char *format);

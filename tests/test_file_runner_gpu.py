@@ -104,3 +104,24 @@ def test_run_reports_bad_inputs(host, tmp_path):
     (tmp_path / "v.vcf").write_text("1\t5\trs\tA\tC\t.\t.\t.\tGT\t0/1\n")          # no #CHROM line
     assert host.hpgv_run_assoc(str(tmp_path / "v.vcf").encode(), str(tmp_path / "p.ped").encode(),
                                str(tmp_path / "o").encode(), 1, 1 << 20, None) != 0
+
+
+@pytest.mark.parametrize("kind", ["gzip", "bgzf"])
+def test_run_assoc_from_compressed_vcf(host, tmp_path, kind):
+    # --compression gzip|bgzip (shared_options.c:60-61): same result file as from the plain text
+    import gzip
+    from test_host_logic_cpu import _bgzf
+    rng = np.random.default_rng(5)
+    people, names, rows = _write_inputs(tmp_path, rng, 60, 25, 1500)
+    vcf = _vcf_from_batch(tmp_path, names, rows)
+    data = open(vcf, "rb").read()
+    packed = str(tmp_path / "in.vcf.gz")
+    open(packed, "wb").write(gzip.compress(data, 1) if kind == "gzip" else _bgzf(data, 0x4000))
+    outs = []
+    for path in (vcf, packed):
+        out = str(tmp_path / ("res_" + os.path.basename(path)))
+        n = C.c_long(0)
+        rc = host.hpgv_run_assoc(path.encode(), str(tmp_path / "ped.txt").encode(), out.encode(), 1, 1 << 16, C.byref(n))
+        assert rc == 0 and n.value == len(rows), host.hpgv_host_last_error()
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] and outs[0].count(b"\n") == len(rows) + 1

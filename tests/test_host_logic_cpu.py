@@ -23,7 +23,7 @@ def exe(tmp_path_factory):
                            "-fno-omit-frame-pointer", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "c", "host_cpu_check.c"),
                            os.path.join(ROOT, "hpg-variant_amd", "host", "hpgv_host.c"),
-                           "-o", out, "-L", b.LIBDIR, "-lhpgv", "-Wl,-rpath," + b.LIBDIR, "-lm", "-lpthread"])
+                           "-o", out, "-L", b.LIBDIR, "-lhpgv", "-Wl,-rpath," + b.LIBDIR, "-lm", "-lz", "-lpthread"])
     return out
 
 
@@ -91,3 +91,49 @@ def test_in_process_sort_equals_gnu_sort(exe, tmp_path):
     gnu = subprocess.run(["sort", "-k1,1h", "-k2,2n", str(b)], capture_output=True, text=True, env=env, check=True).stdout
     assert a.read_text() == gnu
     assert a.read_text().splitlines()[0].startswith("#CHR") or "X" in chroms      # header sorts with the text keys
+
+
+def _bgzf(data, block=0xff00):
+    """BGZF as bgzip writes it: gzip members with a 'BC' extra field holding the block size, then the
+    28-byte end-of-file marker."""
+    import struct
+    import zlib
+    out = bytearray()
+    chunks = [data[i:i + block] for i in range(0, len(data), block)] + [b""]
+    for ch in chunks:
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = co.compress(ch) + co.flush()
+        bsize = 12 + 6 + len(comp) + 8
+        out += b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6)
+        out += b"BC" + struct.pack("<HH", 2, bsize - 1) + comp + struct.pack("<II", zlib.crc32(ch), len(ch))
+    return bytes(out)
+
+
+@pytest.mark.parametrize("kind", ["plain", "gzip", "bgzf"])
+@pytest.mark.parametrize("batch", [1 << 16, 200_000, 1 << 22])
+def test_line_reader_sources(exe, tmp_path, kind, batch):
+    # --compression gzip|bgzip (shared_options.c:60-61): every source hands out the same bytes in whole lines
+    import gzip
+    rng = np.random.default_rng(7)
+    lines = []
+    for i in range(9000):
+        n = int(rng.integers(0, 300)) if i % 50 else int(rng.integers(20_000, 60_000))
+        lines.append(bytes(rng.integers(48, 58, size=n, dtype=np.uint8)) + b"\n")
+    data = b"".join(lines)[:-1]                                      # the last line has no newline
+    src = tmp_path / "in"
+    src.write_bytes({"plain": data, "gzip": gzip.compress(data, 1), "bgzf": _bgzf(data)}[kind])
+    r = _run(exe, "copy", str(src), str(tmp_path / "out"), str(batch))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
+    assert (tmp_path / "out").read_bytes() == data
+    assert int(r.stdout.split()[-1]) >= len(data) // batch
+
+
+def test_line_reader_rejects_damaged_bgzf(exe, tmp_path):
+    data = b"".join(b"%d\n" % i for i in range(200_000))
+    blob = bytearray(_bgzf(data))
+    blob[len(blob) // 2] ^= 0x55
+    (tmp_path / "in").write_bytes(bytes(blob))
+    r = _run(exe, "copy", str(tmp_path / "in"), str(tmp_path / "out"), str(1 << 20))
+    assert r.returncode != 0
+    assert "AddressSanitizer" not in r.stderr, r.stderr
