@@ -1210,7 +1210,23 @@ typedef struct {
  * single line does not fit or the source fails */
 static size_t read_lines(line_reader_t *r, char *buf, size_t cap) {
     size_t n = 0;
-    if (r->carry_len) { if (r->carry_len > cap) return (size_t)-1; memcpy(buf, r->carry, r->carry_len); n = r->carry_len; r->carry_len = 0; }
+    if (r->carry_len) {                                 /* may exceed cap: what followed the header in its read buffer */
+        n = r->carry_len < cap ? r->carry_len : cap;
+        memcpy(buf, r->carry, n);
+        r->carry_len -= n;
+        if (r->carry_len) {
+            memmove(r->carry, r->carry + n, r->carry_len);
+            size_t end = n;
+            while (end > 0 && buf[end - 1] != '\n') end--;
+            if (end == 0) return (size_t)-1;
+            const size_t tail = n - end;                /* put the cut line back in front of the rest */
+            if (r->carry_len + tail > r->carry_cap) return (size_t)-1;     /* cannot happen: n bytes were just taken out */
+            memmove(r->carry + tail, r->carry, r->carry_len);
+            memcpy(r->carry, buf + end, tail);
+            r->carry_len += tail;
+            return end;
+        }
+    }
     while (!r->eof && n < cap) {
         size_t got = source_read(&r->src, buf + n, cap - n);
         if (got == (size_t)-1) return (size_t)-1;
@@ -1228,6 +1244,61 @@ static size_t read_lines(line_reader_t *r, char *buf, size_t cap) {
     memcpy(r->carry, buf + end, tail);
     r->carry_len = tail;
     return end;
+}
+
+/* VCF header: skips the '##' lines and takes the sample names from the '#CHROM' line; what follows that line
+ * in the bytes already read becomes the reader's carry.  Returns the number of samples, -1 without a
+ * '#CHROM' line; *hdr_out owns the text the names point into. */
+static int vcf_header_read(line_reader_t *rd, char **hdr_out, char ***names_out) {
+    char *hdr = NULL;
+    int n_samples = -1;
+    char **names = NULL;
+    size_t cap = 4u << 20, have = 0;
+    hdr = (char *)malloc(cap + 1);
+    int done = 0;
+    while (hdr && !done) {
+        const int starved = cap == have;             /* header longer than the buffer: grow first */
+        size_t got = starved ? 0 : source_read(&rd->src, hdr + have, cap - have);
+        if (got == (size_t)-1) break;
+        have += got;
+        hdr[have] = 0;
+        char *p = hdr, *chrom = NULL;
+        size_t data_start = 0;
+        while (*p == '#') {
+            char *eol = (char *)memchr(p, '\n', have - (size_t)(p - hdr));
+            if (!eol) { p = NULL; break; }
+            if (!strncmp(p, "#CHROM", 6)) { chrom = p; *eol = 0; data_start = (size_t)(eol + 1 - hdr); break; }
+            p = eol + 1;
+        }
+        if (chrom) {
+            size_t len = strlen(chrom);
+            while (len > 0 && chrom[len - 1] == '\r') chrom[--len] = 0;
+            int tabs = 0;
+            for (size_t i = 0; i < len; i++) if (chrom[i] == '\t') tabs++;
+            n_samples = tabs >= 9 ? tabs - 8 : 0;
+            names = (char **)malloc(sizeof(char *) * (size_t)(n_samples + 1));
+            int k = 0, col = 0;
+            for (char *q = chrom; names && *q; q++)
+                if (*q == '\t') { *q = 0; col++; if (col >= 9 && k < n_samples) names[k++] = q + 1; }
+            size_t rest = have - data_start;
+            if (rest) {
+                rd->carry = (char *)malloc(rest);
+                rd->carry_cap = rd->carry ? rest : 0;
+                if (rd->carry) { memcpy(rd->carry, hdr + data_start, rest); rd->carry_len = rest; } else n_samples = -1;
+            }
+            if (!names) n_samples = -1;
+            done = 1;
+        } else if (p != NULL || (!starved && got == 0)) {
+            break;                                   /* a data line came first, or the file ended */
+        } else if (starved) {
+            cap *= 2;
+            char *nh = (char *)realloc(hdr, cap + 1);
+            if (!nh) break;
+            hdr = nh;
+        }
+    }
+    *hdr_out = hdr; *names_out = names;
+    return n_samples;
 }
 
 typedef struct {
@@ -1309,52 +1380,9 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
         snprintf(g_err, sizeof g_err, "cannot open VCF file %s", vcf_path);
         return HPGV_ERR_INVALID;
     }
-    /* header: skip '##' lines, take the sample names from the '#CHROM' line; what follows it in the
-     * bytes already read becomes the reader's carry */
     char *hdr = NULL;
-    int n_samples = -1;
     char **names = NULL;
-    {
-        size_t cap = 4u << 20, have = 0;
-        hdr = (char *)malloc(cap + 1);
-        int done = 0;
-        while (hdr && !done) {
-            const int starved = cap == have;             /* header longer than the buffer: grow first */
-            size_t got = starved ? 0 : source_read(&rd.src, hdr + have, cap - have);
-            if (got == (size_t)-1) break;
-            have += got;
-            hdr[have] = 0;
-            char *p = hdr, *chrom = NULL;
-            size_t data_start = 0;
-            while (*p == '#') {
-                char *eol = (char *)memchr(p, '\n', have - (size_t)(p - hdr));
-                if (!eol) { p = NULL; break; }
-                if (!strncmp(p, "#CHROM", 6)) { chrom = p; *eol = 0; data_start = (size_t)(eol + 1 - hdr); break; }
-                p = eol + 1;
-            }
-            if (chrom) {
-                size_t len = strlen(chrom);
-                while (len > 0 && chrom[len - 1] == '\r') chrom[--len] = 0;
-                int tabs = 0;
-                for (size_t i = 0; i < len; i++) if (chrom[i] == '\t') tabs++;
-                n_samples = tabs >= 9 ? tabs - 8 : 0;
-                names = (char **)malloc(sizeof(char *) * (size_t)(n_samples + 1));
-                int k = 0, col = 0;
-                for (char *q = chrom; *q; q++)
-                    if (*q == '\t') { *q = 0; col++; if (col >= 9 && k < n_samples) names[k++] = q + 1; }
-                size_t rest = have - data_start;
-                if (rest) { rd.carry = (char *)malloc(rest); rd.carry_cap = rd.carry ? rest : 0; if (rd.carry) { memcpy(rd.carry, hdr + data_start, rest); rd.carry_len = rest; } }
-                done = 1;
-            } else if (p != NULL || (!starved && got == 0)) {
-                break;                                   /* a data line came first, or the file ended */
-            } else if (starved) {                        /* header longer than the buffer: grow */
-                cap *= 2;
-                char *nh = (char *)realloc(hdr, cap + 1);
-                if (!nh) break;
-                hdr = nh;
-            }
-        }
-    }
+    const int n_samples = vcf_header_read(&rd, &hdr, &names);
     if (n_samples < 0) { source_close(&rd.src); free(rd.carry); free(hdr); ped_table_free(&ped); snprintf(g_err, sizeof g_err, "no #CHROM header line in %s", vcf_path); return HPGV_ERR_INVALID; }
 
     /* cohort: PED rows looked up by sample name (associate_samples_and_positions + sort_individuals) */
@@ -1482,7 +1510,7 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
 
 /* the runners' reader on its own: copies `in_path` (plain, gzip or BGZF) to `out_path` in whole-line batches
  * of at most batch_bytes; what the runners feed to the engine, batch by batch */
-int hpgv_host_copy_lines(const char *in_path, const char *out_path, size_t batch_bytes, long *n_batches) {
+int hpgv_host_copy_lines(const char *in_path, const char *out_path, size_t batch_bytes, int skip_vcf_header, long *n_batches) {
     line_reader_t rd;
     memset(&rd, 0, sizeof rd);
     if (batch_bytes < (1u << 16)) batch_bytes = 1u << 16;
@@ -1491,6 +1519,11 @@ int hpgv_host_copy_lines(const char *in_path, const char *out_path, size_t batch
     char *buf = (char *)malloc(batch_bytes);
     int rc = (out && buf) ? HPGV_OK : HPGV_ERR_INVALID;
     long nb = 0;
+    if (!rc && skip_vcf_header) {
+        char *hdr = NULL, **names = NULL;
+        if (vcf_header_read(&rd, &hdr, &names) < 0) { snprintf(g_err, sizeof g_err, "no #CHROM header line in %s", in_path); rc = HPGV_ERR_INVALID; }
+        free(hdr); free(names);
+    }
     while (!rc) {
         size_t n = read_lines(&rd, buf, batch_bytes);
         if (n == 0) break;

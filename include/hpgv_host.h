@@ -262,8 +262,10 @@ int  hpgv_run_tdt(const char *vcf_path, const char *ped_path, const char *out_pa
                   size_t batch_bytes, long *n_variants_out);
 
 /* The runners' reader on its own: copies `in_path` (plain / gzip / BGZF) to `out_path` in the whole-line
- * batches (at most batch_bytes each) the runners hand to the engine; *n_batches may be NULL. */
-int  hpgv_host_copy_lines(const char *in_path, const char *out_path, size_t batch_bytes, long *n_batches);
+ * batches (at most batch_bytes each) the runners hand to the engine, optionally after consuming the VCF
+ * header as the runners do; *n_batches may be NULL. */
+int  hpgv_host_copy_lines(const char *in_path, const char *out_path, size_t batch_bytes, int skip_vcf_header,
+                          long *n_batches);
 
 /* ---- staging (GT text -> HPGV8), exposed for tests ---------------------------- */
 int  get_field_position_in_format(const char *field, char *format);

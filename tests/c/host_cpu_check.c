@@ -4,7 +4,7 @@
  * with -fsanitize=address,undefined by tests/test_host_logic_cpu.py.
  *
  *   host_cpu_check containers         self-checking, prints PASS/FAIL lines
- *   host_cpu_check copy <in> <out> <batch_bytes>   the runners' line reader (plain / gzip / BGZF input)
+ *   host_cpu_check copy <in> <out> <batch_bytes> [vcf]   the runners' line reader (plain / gzip / BGZF input)
  *   host_cpu_check stage <file>       file: "N V" then V lines "chrom format s1..sN";
  *                                     prints per line: is_x then the N code bytes (hex), strict and lax
  */
@@ -135,7 +135,7 @@ int main(int argc, char **argv) {
     if (argc >= 3 && !strcmp(argv[1], "sort")) return hpgv_host_sort_output_file(argv[2]);
     if (argc >= 5 && !strcmp(argv[1], "copy")) {
         long nb = 0;
-        int rc = hpgv_host_copy_lines(argv[2], argv[3], (size_t)atol(argv[4]), &nb);
+        int rc = hpgv_host_copy_lines(argv[2], argv[3], (size_t)atol(argv[4]), argc >= 6 && !strcmp(argv[5], "vcf"), &nb);
         printf("%ld\n", nb);
         return rc;
     }

@@ -110,8 +110,9 @@ def _bgzf(data, block=0xff00):
 
 
 @pytest.mark.parametrize("kind", ["plain", "gzip", "bgzf"])
+@pytest.mark.parametrize("header", [False, True])
 @pytest.mark.parametrize("batch", [1 << 16, 200_000, 1 << 22])
-def test_line_reader_sources(exe, tmp_path, kind, batch):
+def test_line_reader_sources(exe, tmp_path, kind, batch, header):
     # --compression gzip|bgzip (shared_options.c:60-61): every source hands out the same bytes in whole lines
     import gzip
     rng = np.random.default_rng(7)
@@ -120,9 +121,14 @@ def test_line_reader_sources(exe, tmp_path, kind, batch):
         n = int(rng.integers(0, 300)) if i % 50 else int(rng.integers(20_000, 60_000))
         lines.append(bytes(rng.integers(48, 58, size=n, dtype=np.uint8)) + b"\n")
     data = b"".join(lines)[:-1]                                      # the last line has no newline
+    head = b""
+    if header:                                                       # the runners take the header off first; what
+        head = b"##fileformat=VCFv4.1\n" + b"##x=" + b"y" * 100_000 + b"\n"          # was read past it is carried over
+        head += b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + b"\t".join(b"s%d" % i for i in range(3000)) + b"\n"
     src = tmp_path / "in"
-    src.write_bytes({"plain": data, "gzip": gzip.compress(data, 1), "bgzf": _bgzf(data)}[kind])
-    r = _run(exe, "copy", str(src), str(tmp_path / "out"), str(batch))
+    full = head + data
+    src.write_bytes({"plain": full, "gzip": gzip.compress(full, 1), "bgzf": _bgzf(full)}[kind])
+    r = _run(exe, "copy", str(src), str(tmp_path / "out"), str(batch), *(["vcf"] if header else []))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
     assert (tmp_path / "out").read_bytes() == data
@@ -137,3 +143,15 @@ def test_line_reader_rejects_damaged_bgzf(exe, tmp_path):
     r = _run(exe, "copy", str(tmp_path / "in"), str(tmp_path / "out"), str(1 << 20))
     assert r.returncode != 0
     assert "AddressSanitizer" not in r.stderr, r.stderr
+
+
+@pytest.mark.parametrize("kind", ["plain", "bgzf"])
+def test_line_reader_header_longer_than_its_buffer(exe, tmp_path, kind):
+    head = b"##big=" + b"z" * (5 << 20) + b"\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ta\tb\n"
+    data = b"".join(b"1\t%d\trs\tA\tC\t.\t.\t.\tGT\t0/1\t1/1\n" % i for i in range(50_000))
+    (tmp_path / "in").write_bytes(head + data if kind == "plain" else _bgzf(head + data))
+    r = _run(exe, "copy", str(tmp_path / "in"), str(tmp_path / "out"), str(1 << 18), "vcf")
+    assert r.returncode == 0 and "AddressSanitizer" not in r.stderr, r.stdout + r.stderr
+    assert (tmp_path / "out").read_bytes() == data
+    (tmp_path / "nohdr").write_bytes(data)
+    assert _run(exe, "copy", str(tmp_path / "nohdr"), str(tmp_path / "out2"), str(1 << 18), "vcf").returncode != 0
