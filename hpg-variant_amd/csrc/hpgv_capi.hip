@@ -83,12 +83,16 @@ struct hpgv_ctx {
     bool have_scan_ev = false, have_stats_ev = false;
     std::vector<Slot *> slots;
     uint32_t *d_sink = nullptr;
-    // tokenizer scratch (newline counts per 4 KiB tile); calls are serialised by tok_mu
+    // tokenizer scratch (newline counts per 4 KiB tile, line offsets), one set per stream that has
+    // tokenized: calls on one stream are ordered by the stream, calls on different streams run
+    // concurrently on the device and must not share it.  The table is guarded by tok_mu.
+    struct TokScratch {
+        hipStream_t stream = nullptr;
+        int *d_blocks = nullptr; size_t blocks_cap = 0;
+        unsigned long long *d_line_off = nullptr; size_t line_cap = 0;
+    };
     std::mutex tok_mu;
-    int *d_tok_blocks = nullptr;
-    size_t tok_blocks_cap = 0;
-    unsigned long long *d_tok_line_off = nullptr;
-    size_t tok_line_cap = 0;
+    std::vector<TokScratch *> tok_scratch;
 };
 
 namespace {
@@ -245,8 +249,12 @@ void hpgv_destroy(hpgv_ctx *ctx) {
     if (ctx->d_lf) (void)hipFree(ctx->d_lf);
     if (ctx->d_thr) (void)hipFree(ctx->d_thr);
     if (ctx->d_sink) (void)hipFree(ctx->d_sink);
-    if (ctx->d_tok_blocks) (void)hipFree(ctx->d_tok_blocks);
-    if (ctx->d_tok_line_off) (void)hipFree(ctx->d_tok_line_off);
+    for (auto *t : ctx->tok_scratch) {
+        if (t->d_blocks) (void)hipFree(t->d_blocks);
+        if (t->d_line_off) (void)hipFree(t->d_line_off);
+        delete t;
+    }
+    ctx->tok_scratch.clear();
     for (Slot *s : ctx->slots) {
         for (int i = 0; i < 8; ++i) if (s->buf[i]) (void)hipFree(s->buf[i]);
         if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -1142,30 +1150,36 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
     if (text_bytes > ((size_t)1 << 40)) return fail(ctx, HPGV_ERR_UNSUPPORTED, "text buffer too large for one call");
     DeviceGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
-    std::lock_guard<std::mutex> lk(ctx->tok_mu);
     const size_t n_blocks = (text_bytes + hpgv::TOK_TILE - 1) / hpgv::TOK_TILE;
     if (n_blocks > 0x7FFFFFFFu) return fail(ctx, HPGV_ERR_UNSUPPORTED, "text buffer too large for one call");
-    if (ctx->tok_blocks_cap < n_blocks + 1) {
-        if (ctx->d_tok_blocks) { HIPCHK(ctx, hipStreamSynchronize(st)); (void)hipFree(ctx->d_tok_blocks); ctx->d_tok_blocks = nullptr; }
-        HIPCHK(ctx, hipMalloc(&ctx->d_tok_blocks, (n_blocks + 1) * sizeof(int)));
-        ctx->tok_blocks_cap = n_blocks + 1;
+    hpgv_ctx::TokScratch *ts = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(ctx->tok_mu);
+        for (auto *t : ctx->tok_scratch) if (t->stream == st) ts = t;
+        if (!ts) { ts = new hpgv_ctx::TokScratch(); ts->stream = st; ctx->tok_scratch.push_back(ts); }
+    }
+    // from here on `ts` is only touched by calls on stream `st`, which the caller does not issue concurrently
+    if (ts->blocks_cap < n_blocks + 1) {
+        if (ts->d_blocks) { HIPCHK(ctx, hipStreamSynchronize(st)); (void)hipFree(ts->d_blocks); ts->d_blocks = nullptr; ts->blocks_cap = 0; }
+        HIPCHK(ctx, hipMalloc(&ts->d_blocks, (n_blocks + 1) * sizeof(int)));
+        ts->blocks_cap = n_blocks + 1;
     }
     unsigned long long *line_off = (unsigned long long *)d_line_off;
     if (!line_off) {                                   // caller does not want the offsets: use scratch
-        if (ctx->tok_line_cap < (size_t)max_lines + 2) {
-            if (ctx->d_tok_line_off) { HIPCHK(ctx, hipStreamSynchronize(st)); (void)hipFree(ctx->d_tok_line_off); ctx->d_tok_line_off = nullptr; }
-            HIPCHK(ctx, hipMalloc(&ctx->d_tok_line_off, ((size_t)max_lines + 2) * sizeof(unsigned long long)));
-            ctx->tok_line_cap = (size_t)max_lines + 2;
+        if (ts->line_cap < (size_t)max_lines + 2) {
+            if (ts->d_line_off) { HIPCHK(ctx, hipStreamSynchronize(st)); (void)hipFree(ts->d_line_off); ts->d_line_off = nullptr; ts->line_cap = 0; }
+            HIPCHK(ctx, hipMalloc(&ts->d_line_off, ((size_t)max_lines + 2) * sizeof(unsigned long long)));
+            ts->line_cap = (size_t)max_lines + 2;
         }
-        line_off = ctx->d_tok_line_off;
+        line_off = ts->d_line_off;
     }
     if (n_blocks > 0)
-        hipLaunchKernelGGL(hpgv::k_tok_count, dim3((unsigned)n_blocks), dim3(256), 0, st, d_text, text_bytes, ctx->d_tok_blocks);
-    hipLaunchKernelGGL(hpgv::k_tok_scan, dim3(1), dim3(256), 0, st, ctx->d_tok_blocks, (int)n_blocks, d_text, text_bytes,
+        hipLaunchKernelGGL(hpgv::k_tok_count, dim3((unsigned)n_blocks), dim3(256), 0, st, d_text, text_bytes, ts->d_blocks);
+    hipLaunchKernelGGL(hpgv::k_tok_scan, dim3(1), dim3(256), 0, st, ts->d_blocks, (int)n_blocks, d_text, text_bytes,
                        d_n_lines, line_off, max_lines);
     if (n_blocks > 0)
         hipLaunchKernelGGL(hpgv::k_tok_mark, dim3((unsigned)n_blocks), dim3(256), 0, st, d_text, text_bytes,
-                           (const int *)ctx->d_tok_blocks, line_off, max_lines);
+                           (const int *)ts->d_blocks, line_off, max_lines);
     else
         HIPCHK(ctx, hipMemsetAsync(line_off, 0, sizeof(unsigned long long), st));
     if (max_lines > 0)

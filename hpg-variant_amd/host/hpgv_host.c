@@ -15,6 +15,7 @@
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 #include <zlib.h>
 #ifdef _OPENMP
@@ -886,6 +887,90 @@ void tdt_write_output_body(list_t *output_list, FILE *fd) {
 }
 
 /* ------------------------------------------------------------------------ */
+/* worker pools of the file-level code: persistent threads, tasks handed out  */
+/* by a counter (a nested OpenMP team is created anew on every entry, which   */
+/* costs milliseconds per batch on a many-core host)                           */
+/* ------------------------------------------------------------------------ */
+
+typedef void (*pool_fn)(void *arg, int task);
+typedef struct {
+    pthread_t *th; int n_threads;
+    pthread_mutex_t mu; pthread_cond_t cv_work, cv_done;
+    pool_fn fn; void *arg; int n_tasks, next, running, gen, stop;
+} io_pool_t;
+
+static void pool_drain(io_pool_t *p) {                  /* called with mu held; returns with mu held */
+    while (p->next < p->n_tasks) {
+        const int t = p->next++;
+        pthread_mutex_unlock(&p->mu);
+        p->fn(p->arg, t);
+        pthread_mutex_lock(&p->mu);
+    }
+}
+
+static void *pool_worker(void *v) {
+    io_pool_t *p = (io_pool_t *)v;
+    int seen = 0;
+    pthread_mutex_lock(&p->mu);
+    for (;;) {
+        while (!p->stop && p->gen == seen) pthread_cond_wait(&p->cv_work, &p->mu);
+        if (p->stop) break;
+        seen = p->gen;
+        p->running++;
+        pool_drain(p);
+        if (--p->running == 0) pthread_cond_broadcast(&p->cv_done);
+    }
+    pthread_mutex_unlock(&p->mu);
+    return NULL;
+}
+
+/* n_threads counts the caller, which works too: n_threads - 1 threads are created */
+static void pool_init(io_pool_t *p, int n_threads) {
+    memset(p, 0, sizeof *p);
+    pthread_mutex_init(&p->mu, NULL);
+    pthread_cond_init(&p->cv_work, NULL);
+    pthread_cond_init(&p->cv_done, NULL);
+    if (n_threads > 1) p->th = (pthread_t *)calloc((size_t)n_threads - 1, sizeof(pthread_t));
+    for (int i = 0; p->th && i < n_threads - 1; i++) {
+        if (pthread_create(&p->th[p->n_threads], NULL, pool_worker, p) == 0) p->n_threads++;
+    }
+}
+
+static void pool_destroy(io_pool_t *p) {
+    pthread_mutex_lock(&p->mu);
+    p->stop = 1;
+    pthread_cond_broadcast(&p->cv_work);
+    pthread_mutex_unlock(&p->mu);
+    for (int i = 0; i < p->n_threads; i++) pthread_join(p->th[i], NULL);
+    free(p->th);
+    pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_work); pthread_cond_destroy(&p->cv_done);
+    memset(p, 0, sizeof *p);
+}
+
+/* runs fn(arg, 0 .. n_tasks-1), each task once, on the pool's threads and the caller; one job at a time per
+ * pool.  p == NULL, or a pool without threads, runs the tasks inline. */
+static void pool_run(io_pool_t *p, pool_fn fn, void *arg, int n_tasks) {
+    if (!p || p->n_threads == 0 || n_tasks <= 1) { for (int t = 0; t < n_tasks; t++) fn(arg, t); return; }
+    pthread_mutex_lock(&p->mu);
+    p->fn = fn; p->arg = arg; p->n_tasks = n_tasks; p->next = 0; p->gen++;
+    pthread_cond_broadcast(&p->cv_work);
+    p->running++;
+    pool_drain(p);
+    p->running--;
+    while (p->running > 0) pthread_cond_wait(&p->cv_done, &p->mu);
+    p->n_tasks = 0;
+    pthread_mutex_unlock(&p->mu);
+}
+
+static int default_io_threads(void) {
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    int t = n >= 32 ? 16 : n >= 4 ? (int)(n / 2) : 1;
+    const char *e = getenv("HPGV_IO_THREADS");
+    if (e && atoi(e) > 0) t = atoi(e) < 64 ? atoi(e) : 64;
+    return t;
+}
+
+/* ------------------------------------------------------------------------ */
 /* result ordering: `sort -k1,1h -k2,2n` in process                          */
 /* ------------------------------------------------------------------------ */
 
@@ -949,6 +1034,43 @@ static int cmp_keys(const void *pa, const void *pb) {
     return strcmp(a->line, b->line);                            /* last resort: whole line, bytewise */
 }
 
+typedef struct {
+    sort_key_t *keys, *src, *dst; size_t k; int parts, width;
+    int unsorted[64];
+} sort_job_t;
+
+static void sort_task_keys(void *v, int t) {           /* keys of one range, and whether the range (and its seam) is in order */
+    sort_job_t *j = (sort_job_t *)v;
+    const size_t lo = j->k * (size_t)t / (size_t)j->parts, hi = j->k * (size_t)(t + 1) / (size_t)j->parts;
+    for (size_t i = lo; i < hi; i++) make_key(j->keys[i].line, &j->keys[i]);
+    int bad = 0;
+    for (size_t i = lo + 1; i < hi && !bad; i++) bad = cmp_keys(&j->keys[i - 1], &j->keys[i]) > 0;
+    if (!bad && hi < j->k && hi > lo) {                 /* seam with the next range: its first key is made here too */
+        sort_key_t nxt;
+        make_key(j->keys[hi].line, &nxt);
+        bad = cmp_keys(&j->keys[hi - 1], &nxt) > 0;
+    }
+    j->unsorted[t] = bad;
+}
+static void sort_task_runs(void *v, int t) {
+    sort_job_t *j = (sort_job_t *)v;
+    const size_t lo = j->k * (size_t)t / (size_t)j->parts, hi = j->k * (size_t)(t + 1) / (size_t)j->parts;
+    qsort(j->keys + lo, hi - lo, sizeof *j->keys, cmp_keys);
+}
+static void sort_task_merge(void *v, int task) {
+    sort_job_t *j = (sort_job_t *)v;
+    const int t = task * 2 * j->width, parts = j->parts, width = j->width;
+    const sort_key_t *src = j->src;
+    sort_key_t *dst = j->dst;
+    const size_t lo = j->k * (size_t)t / (size_t)parts;
+    const size_t mid = j->k * (size_t)(t + width < parts ? t + width : parts) / (size_t)parts;
+    const size_t hi = j->k * (size_t)(t + 2 * width < parts ? t + 2 * width : parts) / (size_t)parts;
+    size_t a = lo, b = mid, o = lo;
+    while (a < mid && b < hi) dst[o++] = cmp_keys(&src[b], &src[a]) < 0 ? src[b++] : src[a++];
+    while (a < mid) dst[o++] = src[a++];
+    while (b < hi) dst[o++] = src[b++];
+}
+
 int hpgv_host_sort_output_file(const char *path) {
     FILE *f = fopen(path, "rb");
     if (!f) return 1;
@@ -966,14 +1088,36 @@ int hpgv_host_sort_output_file(const char *path) {
     if (!keys) { free(blob); return 1; }
     size_t k = 0;
     char *p = blob;
-    while (k < n) {
-        char *e = strchr(p, '\n');
-        if (e) *e = 0;
-        make_key(p, &keys[k++]);
+    while (k < n) {                                    /* line starts (memchr runs at memory speed) */
+        keys[k++].line = p;
+        char *e = (char *)memchr(p, '\n', (size_t)(blob + sz - p));
         if (!e) break;
+        *e = 0;
         p = e + 1;
     }
-    qsort(keys, k, sizeof *keys, cmp_keys);
+    sort_job_t job;
+    memset(&job, 0, sizeof job);
+    job.keys = keys; job.k = k;
+    io_pool_t pool;
+    const int parts = k > 65536 ? default_io_threads() : 1;
+    pool_init(&pool, parts);
+    job.parts = parts;
+    pool_run(&pool, sort_task_keys, &job, parts);
+    int sorted = 1;
+    for (int t = 0; t < parts; t++) sorted = sorted && !job.unsorted[t];
+    if (sorted) { pool_destroy(&pool); free(keys); free(blob); return 0; }   /* a position-sorted VCF gives a sorted result file: leave it */
+    /* sorted runs by the team, then pairwise merges */
+    sort_key_t *tmpk = parts > 1 ? (sort_key_t *)malloc((k + 1) * sizeof *keys) : NULL;
+    if (!tmpk && parts > 1) { job.parts = 1; }
+    pool_run(&pool, sort_task_runs, &job, job.parts);
+    job.src = keys; job.dst = tmpk;
+    for (job.width = 1; job.width < job.parts; job.width *= 2) {
+        pool_run(&pool, sort_task_merge, &job, (job.parts + 2 * job.width - 1) / (2 * job.width));
+        sort_key_t *sw = job.src; job.src = job.dst; job.dst = sw;
+    }
+    if (job.src != keys) memcpy(keys, job.src, k * sizeof *keys);
+    free(tmpk);
+    pool_destroy(&pool);
     size_t len = strlen(path);
     char *tmp = (char *)malloc(len + 5);
     if (!tmp) { free(keys); free(blob); return 1; }
@@ -982,6 +1126,7 @@ int hpgv_host_sort_output_file(const char *path) {
     FILE *o = fopen(tmp, "wb");
     int rc = o ? 0 : 1;
     if (o) {
+        setvbuf(o, NULL, _IOFBF, 1u << 20);
         for (size_t i = 0; i < k; i++) { fputs(keys[i].line, o); fputc('\n', o); }
         if (fclose(o) != 0 || rename(tmp, path) != 0) rc = 1;
     }
@@ -1056,12 +1201,16 @@ static int ped_table_read(const char *path, ped_table_t *ped) {
 /* ---- byte sources: plain file (pread by a small thread team), BGZF (blocks inflated in parallel),
  *      generic gzip (one zlib stream) -- shared_options.c:60-61 `--compression gzip|bgzip` ------------ */
 enum { SRC_RAW = 0, SRC_BGZF = 1, SRC_GZIP = 2 };
+static double g_run_times[6];                           /* last run: read, engine, write, sort, total seconds, batches */
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 typedef struct {
     int kind, fd;
     off_t pos, size;                                    /* RAW: next unread byte, file size */
     const unsigned char *map; size_t map_pos;           /* BGZF: the mapped compressed file, next block */
     unsigned char *pend; size_t pend_len, pend_pos;     /* BGZF: a block inflated aside because the caller's room was short */
     size_t *blk;                                        /* BGZF: per-call block table (offset, length, destination, size) */
+    io_pool_t *pool;                                    /* team for the pread segments / the block inflation (may be NULL) */
+    char *job_buf; size_t job_want; int job_bad;        /* the job the team is working on */
     gzFile gz;                                          /* GZIP */
 } source_t;
 
@@ -1121,6 +1270,27 @@ static int inflate_block(const unsigned char *in, size_t clen, unsigned char *ou
     return bad;
 }
 
+enum { PREAD_SEG = 4 << 20, INFLATE_GROUP = 8, MAXB = 1 << 16 };
+static void source_task_pread(void *v, int k) {
+    source_t *s = (source_t *)v;
+    size_t off = (size_t)k * PREAD_SEG, len = off + PREAD_SEG <= s->job_want ? (size_t)PREAD_SEG : s->job_want - off;
+    while (len > 0) {
+        ssize_t got = pread(s->fd, s->job_buf + off, len, s->pos + (off_t)off);
+        if (got <= 0) { __atomic_store_n(&s->job_bad, 1, __ATOMIC_RELAXED); return; }
+        off += (size_t)got; len -= (size_t)got;
+    }
+}
+static void source_task_inflate(void *v, int g) {
+    source_t *s = (source_t *)v;
+    const size_t *b_in = s->blk, *b_clen = s->blk + MAXB, *b_out = s->blk + 2 * MAXB, *b_isize = s->blk + 3 * MAXB;
+    const int nb = (int)s->job_want;
+    for (int k = g * INFLATE_GROUP; k < nb && k < (g + 1) * INFLATE_GROUP; k++) {
+        if (b_isize[k] == 0) continue;                                /* e.g. the BGZF end-of-file marker */
+        if (inflate_block(s->map + b_in[k], b_clen[k], (unsigned char *)s->job_buf + b_out[k], b_isize[k]))
+            __atomic_store_n(&s->job_bad, 1, __ATOMIC_RELAXED);
+    }
+}
+
 /* appends up to cap bytes of (decompressed) data to buf; 0 = end of data, (size_t)-1 = error.  RAW and GZIP
  * fill the room unless the data ends; BGZF hands out the whole blocks that fit (inflated in parallel, straight
  * into buf), or -- when not even the next block fits -- the part of it that does, so callers loop. */
@@ -1128,18 +1298,9 @@ static size_t source_read(source_t *s, char *buf, size_t cap) {
     if (s->kind == SRC_RAW) {
         if (s->pos >= s->size) return 0;
         size_t want = (size_t)(s->size - s->pos) < cap ? (size_t)(s->size - s->pos) : cap;
-        const size_t seg = 8u << 20;
-        const int n_seg = (int)((want + seg - 1) / seg);
-        int bad = 0;
-        #pragma omp parallel for num_threads(8) schedule(static) if (n_seg > 1)
-        for (int k = 0; k < n_seg; k++) {
-            size_t off = (size_t)k * seg, len = off + seg <= want ? seg : want - off;
-            while (len > 0) {
-                ssize_t got = pread(s->fd, buf + off, len, s->pos + (off_t)off);
-                if (got <= 0) { bad = 1; break; }
-                off += (size_t)got; len -= (size_t)got;
-            }
-        }
+        s->job_buf = buf; s->job_want = want; s->job_bad = 0;
+        pool_run(s->pool, source_task_pread, s, (int)((want + PREAD_SEG - 1) / PREAD_SEG));
+        const int bad = s->job_bad;
         if (bad) return (size_t)-1;
         s->pos += (off_t)want;
         return want;
@@ -1163,7 +1324,6 @@ static size_t source_read(source_t *s, char *buf, size_t cap) {
         s->pend_pos += n;
         return n;
     }
-    enum { MAXB = 1 << 16 };
     size_t total = 0;
     int nb = 0;
     if (!s->blk && !(s->blk = (size_t *)malloc(sizeof(size_t) * 4 * MAXB))) return (size_t)-1;
@@ -1187,12 +1347,9 @@ static size_t source_read(source_t *s, char *buf, size_t cap) {
         memcpy(buf, s->pend, cap);
         return cap;
     }
-    int bad = 0;
-    #pragma omp parallel for num_threads(16) schedule(dynamic, 8) if (nb > 16)
-    for (int k = 0; k < nb; k++) {
-        if (b_isize[k] == 0) continue;                                /* e.g. the BGZF end-of-file marker */
-        if (inflate_block(s->map + b_in[k], b_clen[k], (unsigned char *)buf + b_out[k], b_isize[k])) bad = 1;
-    }
+    s->job_buf = buf; s->job_want = (size_t)nb; s->job_bad = 0;
+    pool_run(s->pool, source_task_inflate, s, (nb + INFLATE_GROUP - 1) / INFLATE_GROUP);
+    const int bad = s->job_bad;
     if (bad) return (size_t)-1;
     s->map_pos = pos;
     return total;
@@ -1336,30 +1493,157 @@ static void run_batch_free(run_batch_t *b) {
     free(b->line_off); free(b->field_off); free(b->status); free(b->ints); free(b->dbl);
 }
 
-/* one output line per record, the reference's formats (assoc_runner.c:314-318,332-336; tdt_runner.c:297-299) */
-static void write_batch(FILE *fd, int kind /* CHI_SQUARE, FISHER, 3 = tdt */, const run_batch_t *b) {
+/* one output line per record, the reference's formats (assoc_runner.c:314-318,332-336; tdt_runner.c:297-299).
+ * Returns the number of characters (as snprintf: what the whole line needs). */
+static int format_record(char *dst, size_t room, int kind /* CHI_SQUARE, FISHER, 3 = tdt */, const run_batch_t *b, int i) {
     const int m = b->max_lines;
-    for (int i = 0; i < b->n_lines && i < m; i++) {
-        const uint32_t *fo = b->field_off + 10 * (size_t)i;
-        if (fo[5] == 0xFFFFFFFFu) continue;                          /* fewer than CHROM..ALT: not a record */
-        const char *l = b->text + b->line_off[i];
-        const int lc = (int)(fo[1] - 1 - fo[0]), lp = (int)(fo[2] - 1 - fo[1]), li = (int)(fo[3] - 1 - fo[2]);
-        const int lr = (int)(fo[4] - 1 - fo[3]), la = (int)(fo[5] - 1 - fo[4]);
-        if (kind == 3) {
-            const int t1 = b->ints[i], t2 = b->ints[m + i];
-            fprintf(fd, "%.*s\t%ld\t%.*s\t%.*s\t%.*s\t%d\t%d\t%6f\t%6f\t%6f\n", lc, l + fo[0], atol(l + fo[1]), li, l + fo[2],
-                    lr, l + fo[3], la, l + fo[4], t1, t2, b->dbl[i], b->dbl[m + i], b->dbl[2 * m + i]);
-        } else {
-            const int A1 = b->ints[i], A2 = b->ints[m + i], U1 = b->ints[2 * m + i], U2 = b->ints[3 * m + i];
-            const int na = A1 + A2, nu = U1 + U2;
-            const double fa1 = na > 0 ? (double)A1 / na : 0.0, fu1 = nu > 0 ? (double)U1 / nu : 0.0;
-            const double fa2 = na > 0 ? (double)A2 / na : 0.0, fu2 = nu > 0 ? (double)U2 / nu : 0.0;
-            fprintf(fd, "%.*s\t%ld\t%.*s\t%.*s\t%d\t%d\t%6f\t%6f\t%.*s\t%d\t%d\t%6f\t%6f\t%6f", lc, l + fo[0], atol(l + fo[1]),
-                    li, l + fo[2], lr, l + fo[3], A1, U1, fa1, fu1, la, l + fo[4], A2, U2, fa2, fu2, b->dbl[i]);
-            if (kind == CHI_SQUARE) fprintf(fd, "\t%6f\t%6f\n", b->dbl[m + i], b->dbl[2 * m + i]);
-            else fprintf(fd, "\t%6f\n", b->dbl[2 * m + i]);
+    const uint32_t *fo = b->field_off + 10 * (size_t)i;
+    const char *l = b->text + b->line_off[i];
+    const int lc = (int)(fo[1] - 1 - fo[0]), li = (int)(fo[3] - 1 - fo[2]);
+    const int lr = (int)(fo[4] - 1 - fo[3]), la = (int)(fo[5] - 1 - fo[4]);
+    if (kind == 3) {
+        const int t1 = b->ints[i], t2 = b->ints[m + i];
+        return snprintf(dst, room, "%.*s\t%ld\t%.*s\t%.*s\t%.*s\t%d\t%d\t%6f\t%6f\t%6f\n", lc, l + fo[0], atol(l + fo[1]), li, l + fo[2],
+                        lr, l + fo[3], la, l + fo[4], t1, t2, b->dbl[i], b->dbl[m + i], b->dbl[2 * m + i]);
+    }
+    const int A1 = b->ints[i], A2 = b->ints[m + i], U1 = b->ints[2 * m + i], U2 = b->ints[3 * m + i];
+    const int na = A1 + A2, nu = U1 + U2;
+    const double fa1 = na > 0 ? (double)A1 / na : 0.0, fu1 = nu > 0 ? (double)U1 / nu : 0.0;
+    const double fa2 = na > 0 ? (double)A2 / na : 0.0, fu2 = nu > 0 ? (double)U2 / nu : 0.0;
+    if (kind == CHI_SQUARE)
+        return snprintf(dst, room, "%.*s\t%ld\t%.*s\t%.*s\t%d\t%d\t%6f\t%6f\t%.*s\t%d\t%d\t%6f\t%6f\t%6f\t%6f\t%6f\n", lc, l + fo[0], atol(l + fo[1]),
+                        li, l + fo[2], lr, l + fo[3], A1, U1, fa1, fu1, la, l + fo[4], A2, U2, fa2, fu2, b->dbl[i], b->dbl[m + i], b->dbl[2 * m + i]);
+    return snprintf(dst, room, "%.*s\t%ld\t%.*s\t%.*s\t%d\t%d\t%6f\t%6f\t%.*s\t%d\t%d\t%6f\t%6f\t%6f\t%6f\n", lc, l + fo[0], atol(l + fo[1]),
+                    li, l + fo[2], lr, l + fo[3], A1, U1, fa1, fu1, la, l + fo[4], A2, U2, fa2, fu2, b->dbl[i], b->dbl[2 * m + i]);
+}
+
+/* formats the records of a batch by a thread team (one contiguous range of lines and one growing buffer per
+ * task), then writes the buffers in line order */
+typedef struct { char *p; size_t len, cap; } out_buf_t;
+typedef struct { const run_batch_t *b; out_buf_t *bufs; int kind, n, parts, bad; } fmt_job_t;
+
+static void fmt_task(void *v, int t) {
+    fmt_job_t *j = (fmt_job_t *)v;
+    const run_batch_t *b = j->b;
+    out_buf_t *o = &j->bufs[t];
+    o->len = 0;
+    const int lo = (int)((long)j->n * t / j->parts), hi = (int)((long)j->n * (t + 1) / j->parts);
+    for (int i = lo; i < hi; i++) {
+        if (b->field_off[10 * (size_t)i + 5] == 0xFFFFFFFFu) continue;              /* fewer than CHROM..ALT: not a record */
+        for (;;) {
+            int need = o->cap > o->len ? format_record(o->p + o->len, o->cap - o->len, j->kind, b, i) : -2;
+            if (need >= 0 && (size_t)need < o->cap - o->len) { o->len += (size_t)need; break; }
+            size_t nc = o->cap ? o->cap * 2 : (size_t)1 << 16;
+            if (need > 0 && nc < o->len + (size_t)need + 1) nc = o->len + (size_t)need + 1;
+            char *np = need == -1 ? NULL : (char *)realloc(o->p, nc);
+            if (!np) { __atomic_store_n(&j->bad, 1, __ATOMIC_RELAXED); return; }
+            o->p = np; o->cap = nc;
         }
-        (void)lp;
+    }
+}
+
+static int write_batch(FILE *fd, int kind, const run_batch_t *b, out_buf_t *bufs, int n_bufs, io_pool_t *pool) {
+    fmt_job_t j;
+    j.b = b; j.bufs = bufs; j.kind = kind; j.bad = 0;
+    j.n = b->n_lines < b->max_lines ? b->n_lines : b->max_lines;
+    j.parts = j.n >= 2048 ? n_bufs : 1;
+    pool_run(pool, fmt_task, &j, j.parts);
+    if (j.bad) return 1;
+    for (int t = 0; t < j.parts; t++)
+        if (bufs[t].len && fwrite(bufs[t].p, 1, bufs[t].len, fd) != bufs[t].len) return 1;
+    return 0;
+}
+
+/* ---- the runners' pipeline: reader -> engine threads -> writer, batches in rotation ------------------ */
+enum { RUN_NB = 5, RUN_ENGINES = 2, RUN_FMT_BUFS = 64 };
+enum { B_FREE = 0, B_FILLED = 1, B_BUSY = 2, B_DONE = 3 };
+typedef struct {
+    pthread_mutex_t mu; pthread_cond_t cv;
+    run_batch_t bt[RUN_NB]; int state[RUN_NB]; long seq[RUN_NB];
+    long n_filled, n_taken, n_written;                  /* sequence numbers handed out so far per stage */
+    int eof, rc, kind;
+    size_t batch_bytes;
+    line_reader_t *rd;
+    double t_read, t_engine, t_write;
+    char err[256];
+} run_pipe_t;
+
+static void pipe_fail(run_pipe_t *P, int rc, const char *msg) {      /* mu held */
+    if (!P->rc) { P->rc = rc; snprintf(P->err, sizeof P->err, "%s", msg); }
+    pthread_cond_broadcast(&P->cv);
+}
+
+static void *pipe_reader(void *v) {
+    run_pipe_t *P = (run_pipe_t *)v;
+    for (;;) {
+        pthread_mutex_lock(&P->mu);
+        int k = -1;
+        while (!P->rc) {
+            for (int i = 0; i < RUN_NB && k < 0; i++) if (P->state[i] == B_FREE) k = i;
+            if (k >= 0) break;
+            pthread_cond_wait(&P->cv, &P->mu);
+        }
+        if (P->rc) { pthread_mutex_unlock(&P->mu); return NULL; }
+        P->state[k] = B_BUSY;
+        pthread_mutex_unlock(&P->mu);
+        const double t0 = now_s();
+        const size_t n = read_lines(P->rd, P->bt[k].text, P->batch_bytes);
+        const double dt = now_s() - t0;
+        pthread_mutex_lock(&P->mu);
+        P->t_read += dt;
+        if (n == (size_t)-1) { P->state[k] = B_FREE; pipe_fail(P, HPGV_ERR_UNSUPPORTED, "read error, or a VCF line is longer than batch_bytes"); pthread_mutex_unlock(&P->mu); return NULL; }
+        if (n == 0) { P->state[k] = B_FREE; P->eof = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu); return NULL; }
+        P->bt[k].bytes = n; P->seq[k] = P->n_filled++; P->state[k] = B_FILLED;
+        pthread_cond_broadcast(&P->cv);
+        pthread_mutex_unlock(&P->mu);
+    }
+}
+
+static void *pipe_engine(void *v) {
+    run_pipe_t *P = (run_pipe_t *)v;
+    const int kind = P->kind;
+    for (;;) {
+        pthread_mutex_lock(&P->mu);
+        int k = -1;
+        while (!P->rc) {
+            for (int i = 0; i < RUN_NB && k < 0; i++) if (P->state[i] == B_FILLED && P->seq[i] == P->n_taken) k = i;
+            if (k >= 0 || (P->eof && P->n_taken == P->n_filled)) break;
+            pthread_cond_wait(&P->cv, &P->mu);
+        }
+        if (P->rc || k < 0) { pthread_mutex_unlock(&P->mu); return NULL; }
+        P->state[k] = B_BUSY; P->n_taken++;
+        pthread_mutex_unlock(&P->mu);
+        const double t0 = now_s();
+        run_batch_t *b = &P->bt[k];
+        int rc = HPGV_OK;
+        /* max_lines is sized for complete records; a batch of short (damaged) lines can hold more: the
+         * engine reports the true count, the arrays grow and the batch is done again */
+        for (int attempt = 0; attempt < 2; attempt++) {
+            const int m = b->max_lines;
+            if (kind == 3)
+                rc = hpgv_tdt_text(g_ctx, b->text, b->bytes, m, &b->n_lines, b->line_off, b->field_off, b->status,
+                                   b->ints, b->ints + m, b->dbl, b->dbl + m, b->dbl + 2 * m);
+            else
+                rc = hpgv_assoc_text(g_ctx, kind, b->text, b->bytes, m, &b->n_lines, b->line_off, b->field_off, b->status,
+                                     b->ints, b->ints + m, b->ints + 2 * m, b->ints + 3 * m,
+                                     b->dbl, kind == CHI_SQUARE ? b->dbl + m : NULL, b->dbl + 2 * m);
+            if (rc || b->n_lines <= b->max_lines) break;
+            if (run_batch_reserve(b, b->n_lines)) { rc = HPGV_ERR_NOMEM; break; }
+        }
+        const double dt = now_s() - t0;
+        pthread_mutex_lock(&P->mu);
+        P->t_engine += dt;
+        if (rc) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "%s failed (%d): %s", kind == 3 ? "hpgv_tdt_text" : "hpgv_assoc_text", rc,
+                     rc == HPGV_ERR_NOMEM ? "out of memory" : hpgv_last_error(g_ctx));
+            pipe_fail(P, rc, msg);
+            pthread_mutex_unlock(&P->mu);
+            return NULL;
+        }
+        P->state[k] = B_DONE;
+        pthread_cond_broadcast(&P->cv);
+        pthread_mutex_unlock(&P->mu);
     }
 }
 
@@ -1368,9 +1652,7 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     int rc = ensure_engine();
     if (rc) return rc;
     if (batch_bytes < (1u << 16)) batch_bytes = 1u << 16;
-#ifdef _OPENMP
-    omp_set_max_active_levels(2);          /* the reader's pread team runs inside the sections (assoc_runner.c:82 enables nesting too) */
-#endif
+    const int io_threads = default_io_threads();
     ped_table_t ped;
     if ((rc = ped_table_read(ped_path, &ped))) return rc;
     line_reader_t rd;
@@ -1447,62 +1729,79 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
 
     FILE *out = rc ? NULL : fopen(out_path, "wb");
     if (!rc && !out) { snprintf(g_err, sizeof g_err, "cannot create %s", out_path); rc = HPGV_ERR_INVALID; }
+    if (out) setvbuf(out, NULL, _IOFBF, 1u << 20);
     long written = 0;
-    run_batch_t bt[2];
-    int have[2] = {0, 0};
-    if (!rc) { rc = run_batch_alloc(&bt[0], batch_bytes, n_samples); have[0] = 1; }
-    if (!rc) { rc = run_batch_alloc(&bt[1], batch_bytes, n_samples); have[1] = 1; }
+    double t_sort = 0;
+    const double t_start = now_s();
+    run_pipe_t *P = (run_pipe_t *)calloc(1, sizeof *P);
+    out_buf_t *fmt = (out_buf_t *)calloc(RUN_FMT_BUFS, sizeof *fmt);
+    int have = 0;
+    if (!P || !fmt) rc = rc ? rc : HPGV_ERR_NOMEM;
+    for (; !rc && have < RUN_NB; have++) rc = run_batch_alloc(&P->bt[have], batch_bytes, n_samples);
+    if (rc == HPGV_ERR_NOMEM) snprintf(g_err, sizeof g_err, "out of memory for the batch buffers");
     if (!rc) {
         if (kind == 3) tdt_write_output_header(out); else assoc_write_output_header((enum ASSOC_task)kind, out);
-        /* software pipeline over batches: while the engine works on batch k (thread A), the same thread of
-         * the previous iteration's results are written and the next batch is read (thread B) */
-        int cur = 0;
-        size_t n0 = read_lines(&rd, bt[0].text, batch_bytes);
-        bt[0].bytes = n0;
-        int prev_ready = 0;
-        while (!rc && bt[cur].bytes != 0) {
-            if (bt[cur].bytes == (size_t)-1) { snprintf(g_err, sizeof g_err, "a VCF line is longer than batch_bytes"); rc = HPGV_ERR_UNSUPPORTED; break; }
-            int rc_engine = HPGV_OK;
-            size_t next_bytes = 0;
-            const int nxt = cur ^ 1;
-            #pragma omp parallel sections num_threads(2)
-            {
-                #pragma omp section
-                {
-                    run_batch_t *b = &bt[cur];
-                    int lines = 1;
-                    for (const char *q = b->text, *e = b->text + b->bytes; (q = (const char *)memchr(q, '\n', (size_t)(e - q))); q++) lines++;
-                    rc_engine = run_batch_reserve(b, lines);
-                    const int m = b->max_lines;
-                    if (rc_engine) { snprintf(g_err, sizeof g_err, "out of memory"); }
-                    else if (kind == 3)
-                        rc_engine = hpgv_tdt_text(g_ctx, b->text, b->bytes, m, &b->n_lines, b->line_off, b->field_off, b->status,
-                                                  b->ints, b->ints + m, b->dbl, b->dbl + m, b->dbl + 2 * m);
-                    else
-                        rc_engine = hpgv_assoc_text(g_ctx, kind, b->text, b->bytes, m, &b->n_lines, b->line_off, b->field_off, b->status,
-                                                    b->ints, b->ints + m, b->ints + 2 * m, b->ints + 3 * m,
-                                                    b->dbl, kind == CHI_SQUARE ? b->dbl + m : NULL, b->dbl + 2 * m);
-                }
-                #pragma omp section
-                {
-                    if (prev_ready) { write_batch(out, kind, &bt[nxt]); }
-                    next_bytes = read_lines(&rd, bt[nxt].text, batch_bytes);
-                }
+        /* one reader thread (with its team of pread / inflate threads), RUN_ENGINES engine threads (each call
+         * is H2D, tokenize, scan, statistics, D2H on its own stream, so two in flight overlap the copies of one
+         * batch with the kernels of the other) and this thread as the writer (with its team of formatters);
+         * batches are written in file order */
+        pthread_mutex_init(&P->mu, NULL);
+        pthread_cond_init(&P->cv, NULL);
+        P->kind = kind; P->batch_bytes = batch_bytes; P->rd = &rd;
+        io_pool_t rpool, wpool;
+        pool_init(&rpool, io_threads);
+        pool_init(&wpool, io_threads);
+        rd.src.pool = &rpool;
+        const int n_fmt = io_threads < RUN_FMT_BUFS ? io_threads : RUN_FMT_BUFS;
+        pthread_t th[1 + RUN_ENGINES];
+        int n_th = 0;
+        if (pthread_create(&th[n_th], NULL, pipe_reader, P) == 0) n_th++;
+        for (int e = 0; e < RUN_ENGINES; e++) if (pthread_create(&th[n_th], NULL, pipe_engine, P) == 0) n_th++;
+        pthread_mutex_lock(&P->mu);
+        if (n_th < 2) pipe_fail(P, HPGV_ERR_NOMEM, "cannot start the pipeline threads");
+        for (;;) {
+            int k = -1;
+            while (!P->rc) {
+                for (int i = 0; i < RUN_NB && k < 0; i++) if (P->state[i] == B_DONE && P->seq[i] == P->n_written) k = i;
+                if (k >= 0 || (P->eof && P->n_written == P->n_filled)) break;
+                pthread_cond_wait(&P->cv, &P->mu);
             }
-            if (rc_engine) { if (rc_engine != HPGV_ERR_NOMEM) host_fail(kind == 3 ? "hpgv_tdt_text" : "hpgv_assoc_text", rc_engine); rc = rc_engine; break; }
-            if (bt[cur].n_lines > bt[cur].max_lines) { snprintf(g_err, sizeof g_err, "internal: more lines than the batch capacity"); rc = HPGV_ERR_UNSUPPORTED; break; }
-            for (int i = 0; i < bt[cur].n_lines; i++) if (bt[cur].field_off[10 * (size_t)i + 5] != 0xFFFFFFFFu) written++;
-            bt[nxt].bytes = next_bytes;
-            prev_ready = 1;
-            cur = nxt;
+            if (P->rc || k < 0) break;
+            P->state[k] = B_BUSY;
+            pthread_mutex_unlock(&P->mu);
+            const double t0 = now_s();
+            const run_batch_t *b = &P->bt[k];
+            const int bad = write_batch(out, kind, b, fmt, n_fmt, &wpool);
+            for (int i = 0; i < b->n_lines; i++) if (b->field_off[10 * (size_t)i + 5] != 0xFFFFFFFFu) written++;
+            const double dt = now_s() - t0;
+            pthread_mutex_lock(&P->mu);
+            P->t_write += dt;
+            if (bad) { pipe_fail(P, HPGV_ERR_INVALID, "cannot write the result file"); break; }
+            P->state[k] = B_FREE; P->n_written++;
+            pthread_cond_broadcast(&P->cv);
         }
-        if (!rc && prev_ready) write_batch(out, kind, &bt[cur ^ 1]);
+        pthread_mutex_unlock(&P->mu);
+        for (int i = 0; i < n_th; i++) pthread_join(th[i], NULL);
+        rd.src.pool = NULL;
+        pool_destroy(&rpool); pool_destroy(&wpool);
+        if (P->rc) { rc = P->rc; snprintf(g_err, sizeof g_err, "%s", P->err); }
+        g_run_times[0] = P->t_read; g_run_times[1] = P->t_engine; g_run_times[2] = P->t_write; g_run_times[5] = (double)P->n_filled;
+        pthread_mutex_destroy(&P->mu); pthread_cond_destroy(&P->cv);
     }
-    if (out) fclose(out);
-    if (!rc && hpgv_host_sort_output_file(out_path))                    /* assoc_runner.c:255-261: only a warning there */
-        fprintf(stderr, "WARN: results could not be sorted by chromosome and position\n");
-    if (have[0]) run_batch_free(&bt[0]);
-    if (have[1]) run_batch_free(&bt[1]);
+    if (out && fclose(out) != 0 && !rc) { snprintf(g_err, sizeof g_err, "cannot write %s", out_path); rc = HPGV_ERR_INVALID; }
+    {
+        const double t0 = now_s();
+        if (!rc && hpgv_host_sort_output_file(out_path))                /* assoc_runner.c:255-261: only a warning there */
+            fprintf(stderr, "WARN: results could not be sorted by chromosome and position\n");
+        t_sort = now_s() - t0;
+    }
+    for (int k = 0; P && k < have; k++) run_batch_free(&P->bt[k]);
+    for (int k = 0; fmt && k < RUN_FMT_BUFS; k++) free(fmt[k].p);
+    free(fmt); free(P);
+    g_run_times[3] = t_sort; g_run_times[4] = now_s() - t_start;
+    if (getenv("HPGV_RUN_TRACE"))
+        fprintf(stderr, "hpgv run: %ld records, %.0f batches, %d io threads: read %.3f s, engine %.3f s (%d threads), write %.3f s (stages overlap), sort %.3f s, total %.3f s\n",
+                written, g_run_times[5], io_threads, g_run_times[0], g_run_times[1], RUN_ENGINES, g_run_times[2], t_sort, g_run_times[4]);
     source_close(&rd.src); free(rd.carry); free(hdr); free(names); ped_table_free(&ped);
     if (n_variants_out) *n_variants_out = written;
     return rc;
@@ -1519,6 +1818,9 @@ int hpgv_host_copy_lines(const char *in_path, const char *out_path, size_t batch
     char *buf = (char *)malloc(batch_bytes);
     int rc = (out && buf) ? HPGV_OK : HPGV_ERR_INVALID;
     long nb = 0;
+    io_pool_t pool;
+    pool_init(&pool, default_io_threads());
+    rd.src.pool = &pool;
     if (!rc && skip_vcf_header) {
         char *hdr = NULL, **names = NULL;
         if (vcf_header_read(&rd, &hdr, &names) < 0) { snprintf(g_err, sizeof g_err, "no #CHROM header line in %s", in_path); rc = HPGV_ERR_INVALID; }
@@ -1533,10 +1835,13 @@ int hpgv_host_copy_lines(const char *in_path, const char *out_path, size_t batch
         nb++;
     }
     if (out) fclose(out);
+    pool_destroy(&pool);
     free(buf); free(rd.carry); source_close(&rd.src);
     if (n_batches) *n_batches = nb;
     return rc;
 }
+
+void hpgv_host_last_run_times(double *seconds6) { memcpy(seconds6, g_run_times, sizeof g_run_times); }
 
 int hpgv_run_assoc(const char *vcf_path, const char *ped_path, const char *out_path, enum ASSOC_task task,
                    size_t batch_bytes, long *n_variants_out) {

@@ -260,6 +260,11 @@ int  hpgv_run_assoc(const char *vcf_path, const char *ped_path, const char *out_
                     enum ASSOC_task task, size_t batch_bytes, long *n_variants_out);
 int  hpgv_run_tdt(const char *vcf_path, const char *ped_path, const char *out_path,
                   size_t batch_bytes, long *n_variants_out);
+/* stage times of the last run on this process: {read, engine, write, sort, total} seconds and the number of
+ * batches; read / engine / write overlap (three threads, three batch buffers in rotation).  The reader and
+ * formatter teams use HPGV_IO_THREADS threads (environment; default half the cores, at most 16);
+ * HPGV_RUN_TRACE=1 prints the same numbers to stderr. */
+void hpgv_host_last_run_times(double *seconds6);
 
 /* The runners' reader on its own: copies `in_path` (plain / gzip / BGZF) to `out_path` in the whole-line
  * batches (at most batch_bytes each) the runners hand to the engine, optionally after consuming the VCF

@@ -125,3 +125,26 @@ def test_run_assoc_from_compressed_vcf(host, tmp_path, kind):
         assert rc == 0 and n.value == len(rows), host.hpgv_host_last_error()
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1] and outs[0].count(b"\n") == len(rows) + 1
+
+
+def test_run_assoc_batches_of_short_lines(host, tmp_path):
+    # lines much shorter than a complete record: more lines per batch than the arrays were sized for
+    names = ["s%d" % j for j in range(50)]
+    with open(tmp_path / "ped.txt", "w") as f:
+        for j, nm in enumerate(names):
+            f.write("F%d %s 0 0 1 %d\n" % (j, nm, 1 + j % 2))
+    with open(tmp_path / "in.vcf", "w") as f:
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n")
+        for v in range(6000):
+            if v % 1500 == 7:
+                f.write("1\t%d\trs%d\tA\tC\t.\t.\t.\tGT\t%s\n" % (100 + v, v, "\t".join(["0/1"] * 50)))
+            else:
+                f.write("1\t%d\trs%d\tA\tC\t.\t.\t.\tGT\n" % (100 + v, v))
+    out = str(tmp_path / "res.chisq")
+    n = C.c_long(0)
+    rc = host.hpgv_run_assoc(str(tmp_path / "in.vcf").encode(), str(tmp_path / "ped.txt").encode(), out.encode(), 1, 1 << 16, C.byref(n))
+    assert rc == 0 and n.value == 6000, host.hpgv_host_last_error()
+    header, table = _parse_table(out)
+    assert len(table) == 6000
+    full = [t for t in table if int(t[4]) + int(t[9]) > 0]
+    assert len(full) == 4 and all((int(t[4]), int(t[9]), int(t[5]), int(t[10])) == (25, 25, 25, 25) for t in full)

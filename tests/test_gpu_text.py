@@ -123,3 +123,38 @@ def test_text_in_statistics_out(eng):
     assert_close(res["p"], p, "tdt p"); assert_close(res["chisq"], chisq, "tdt chisq")
     assert e.assoc_text(hpgv.TASK_CHISQ, b"")["n_lines"] == 0
     e.close()
+
+
+def test_text_entry_point_from_concurrent_threads(eng):
+    # the file runners keep two text batches in flight (two engine threads): the tokenizer's device
+    # scratch must not be shared between concurrent calls
+    import threading
+    from helpers import check_assoc, oracle_assoc
+    rng = np.random.default_rng(33)
+    n_samples = 700
+    cond = rng.choice([0, 1, 2], size=n_samples).astype(np.uint8)
+    e = hpgv.Engine(0)
+    e.set_cohort(cond)
+    texts, expected = [], []
+    for t in range(4):
+        lines = [_line(rng, n_samples, "GT", "1", 5) for _ in range(300 + 117 * t)]
+        text = "\n".join(lines) + "\n"
+        tok = orc.tokenize(text, n_samples, True)
+        texts.append(text)
+        expected.append(oracle_assoc(orc.TASK_CHISQ, tok["gt"], cond, tok["is_x"], None))
+    errors = []
+
+    def work(t):
+        try:
+            for _ in range(25):
+                res = e.assoc_text(hpgv.TASK_CHISQ, texts[t])
+                assert res["n_lines"] == 300 + 117 * t
+                check_assoc(res, expected[t], hpgv.TASK_CHISQ)
+        except Exception as ex:                                     # noqa: BLE001
+            errors.append((t, repr(ex)))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    e.close()
+    assert not errors, errors

@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
 """End-to-end rate of the file-level runner: synthetic VCF + PED files in, sorted
 .chisq TSV out (file in the page cache -> PCIe -> GPU tokenizer -> scan -> writer ->
-in-process sort).  Diagnostic tool."""
+in-process sort), with the stage times the runner reports.  Diagnostic tool.
+
+  python tools/bench_file_runner.py [n_samples] [n_variants] [plain,bgzf,gzip] [batch_MB,...]
+"""
 import ctypes as C
 import importlib
 import json
 import os
+import struct
 import sys
 import tempfile
 import time
+import zlib
 
 import numpy as np
 
@@ -18,6 +23,8 @@ b = importlib.import_module("hpg-variant_amd._build")
 
 n_samples = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000
 n_variants = int(sys.argv[2]) if len(sys.argv) > 2 else 20_000
+kinds = (sys.argv[3] if len(sys.argv) > 3 else "plain").split(",")
+batches = [int(x) << 20 for x in (sys.argv[4] if len(sys.argv) > 4 else "64,256").split(",")]
 rng = np.random.default_rng(0)
 codes = np.array(["0/0", "0/1", "1/1", "./."])
 d = tempfile.mkdtemp()
@@ -27,25 +34,55 @@ with open(vcf, "w") as f:
     f.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" +
             "\t".join("S%d" % j for j in range(n_samples)) + "\n")
     for i in range(n_variants):
-        f.write("%d\t%d\trs%d\tA\tG\t.\tPASS\t.\tGT\t%s\n" % (1 + i % 22, 1000 + i, i, bodies[i % 32]))
+        # position-sorted like a real VCF (chromosomes in blocks), so the result file needs no re-ordering
+        f.write("%d\t%d\trs%d\tA\tG\t.\tPASS\t.\tGT\t%s\n" % (1 + i * 22 // n_variants, 1000 + i, i, bodies[i % 32]))
 with open(ped, "w") as f:
     for j in range(n_samples):
         f.write("F%d S%d 0 0 %d %d\n" % (j, j, 1 + j % 2, 1 + j % 2))
 size = os.path.getsize(vcf)
+
+
+def bgzf_file(src, dst, block=0xff00):
+    with open(src, "rb") as fi, open(dst, "wb") as fo:
+        while True:
+            ch = fi.read(block)
+            co = zlib.compressobj(1, zlib.DEFLATED, -15)
+            comp = co.compress(ch) + co.flush()
+            fo.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(comp) + 8 - 1)
+                     + comp + struct.pack("<II", zlib.crc32(ch), len(ch)))
+            if not ch:
+                break
+
+
 L = C.CDLL(b.HOSTLIB)
 L.hpgv_run_assoc.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_size_t, C.POINTER(C.c_long)]
 L.hpgv_host_last_error.restype = C.c_char_p
+L.hpgv_host_last_run_times.argtypes = [C.POINTER(C.c_double)]
 res = []
-for batch in (64 << 20, 256 << 20):
-    n = C.c_long(0)
-    L.hpgv_run_assoc(vcf.encode(), ped.encode(), out.encode(), 1, batch, C.byref(n))      # warm (page cache, engine)
-    t0 = time.perf_counter()
-    rc = L.hpgv_run_assoc(vcf.encode(), ped.encode(), out.encode(), 1, batch, C.byref(n))
-    dt = time.perf_counter() - t0
-    assert rc == 0 and n.value == n_variants, L.hpgv_host_last_error()
-    res.append({"batch_MB": batch >> 20, "seconds": round(dt, 3), "variants_per_s": round(n_variants / dt),
-                "vcf_GBps": round(size / dt / 1e9, 2)})
-print(json.dumps({"n_samples": n_samples, "n_variants": n_variants, "vcf_GB": round(size / 1e9, 2), "runs": res}))
+for kind in kinds:
+    path = vcf
+    if kind == "bgzf":
+        path = vcf + ".bgz"
+        bgzf_file(vcf, path)
+    elif kind == "gzip":
+        path = vcf + ".gz"
+        os.system("gzip -1 -c %s > %s" % (vcf, path))
+    for batch in batches:
+        n = C.c_long(0)
+        L.hpgv_run_assoc(path.encode(), ped.encode(), out.encode(), 1, batch, C.byref(n))      # warm (page cache, engine)
+        t0 = time.perf_counter()
+        rc = L.hpgv_run_assoc(path.encode(), ped.encode(), out.encode(), 1, batch, C.byref(n))
+        dt = time.perf_counter() - t0
+        assert rc == 0 and n.value == n_variants, L.hpgv_host_last_error()
+        tm = (C.c_double * 6)()
+        L.hpgv_host_last_run_times(tm)
+        res.append({"input": kind, "file_GB": round(os.path.getsize(path) / 1e9, 3), "batch_MB": batch >> 20, "seconds": round(dt, 3),
+                    "variants_per_s": round(n_variants / dt), "vcf_text_GBps": round(size / dt / 1e9, 2),
+                    "stages_s": {k: round(v, 3) for k, v in zip(("read", "engine", "write", "sort", "total"), tm)}, "batches": int(tm[5])})
+    if path != vcf:
+        os.remove(path)
+print(json.dumps({"n_samples": n_samples, "n_variants": n_variants, "vcf_GB": round(size / 1e9, 2),
+                  "io_threads": os.environ.get("HPGV_IO_THREADS", "default"), "runs": res}))
 for p in (vcf, ped, out):
     os.remove(p)
 os.rmdir(d)
