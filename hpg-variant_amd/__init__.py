@@ -36,7 +36,7 @@ SYMBOLS = [
     "hpgv_tdt_scan_dev", "hpgv_tdt_stats_dev", "hpgv_stats_scan_dev", "hpgv_stats_hwe_dev",
     "hpgv_sample_missing_dev", "hpgv_genotype_table_dev", "hpgv_stats_filter_dev",
     "hpgv_mendel", "hpgv_epi_dataset", "hpgv_tokenize_dev", "hpgv_tokenize", "hpgv_assoc_text", "hpgv_tdt_text",
-    "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_read_probe",
+    "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_stats_groups", "hpgv_read_probe",
 ]
 
 
@@ -101,6 +101,7 @@ def load():
     L.hpgv_tdt.argtypes = [vp, vp, sz, i32, vp] + [vp] * 5
     L.hpgv_stats.argtypes = [vp, vp, sz, i32, vp, vp, vp]
     L.hpgv_stats_ex.argtypes = [vp, vp, sz, i32, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
+    L.hpgv_stats_groups.argtypes = [vp, vp, sz, i32, vp, vp, vp]
     L.hpgv_sample_missing_dev.argtypes = [vp, vp, i32, vp, vp]
     L.hpgv_genotype_table_dev.argtypes = [vp, vp, sz, i32, vp, i32, vp, vp]
     L.hpgv_tokenize_dev.argtypes = [vp, vp, sz, i32, i32, i32, vp, vp, vp, vp, sz, vp, vp, vp]
@@ -275,6 +276,14 @@ class Engine:
         c8 = np.zeros((nv, 8), np.int32)
         chi2, p = np.zeros(nv, np.float64), np.zeros(nv, np.float64)
         self._chk(self.L.hpgv_stats(self.h, _ptr(gt), pitch, nv, _ptr(c8), _ptr(chi2), _ptr(p)))
+        return dict(counts8=c8, hwe_chi2=chi2, hwe_p=p)
+
+    def stats_groups(self, gt, n_groups):
+        gt = _np(gt, np.uint8)
+        nv, pitch = gt.shape
+        c8 = np.zeros((n_groups, nv, 8), np.int32)
+        chi2, p = np.zeros((n_groups, nv), np.float64), np.zeros((n_groups, nv), np.float64)
+        self._chk(self.L.hpgv_stats_groups(self.h, _ptr(gt), pitch, nv, _ptr(c8), _ptr(chi2), _ptr(p)))
         return dict(counts8=c8, hwe_chi2=chi2, hwe_p=p)
 
     def epi_dataset(self, gt):

@@ -1082,6 +1082,39 @@ int hpgv_stats(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, i
     return hpgv_stats_ex(ctx, gt, pitch, n_variants, counts8, hwe_chi2, hwe_p, nullptr, nullptr, nullptr, nullptr);
 }
 
+int hpgv_stats_groups(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, int32_t *counts8,
+                      double *hwe_chi2, double *hwe_p) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->sgroups.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_groups has not been called");
+    if (n_variants < 0 || (n_variants > 0 && (!gt || !counts8))) return fail(ctx, HPGV_ERR_INVALID, "bad stats group arguments");
+    if ((hwe_chi2 == nullptr) != (hwe_p == nullptr)) return fail(ctx, HPGV_ERR_INVALID, "hwe_chi2 and hwe_p go together");
+    if (pitch < (size_t)ctx->sgroups.n_samples) return fail(ctx, HPGV_ERR_INVALID, "pitch %zu < n_samples %d", pitch, ctx->sgroups.n_samples);
+    if (n_variants == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    SlotLease lease(ctx);
+    int rc = acquire_slot(ctx, &lease.s);
+    if (rc) return rc;
+    Slot *s = lease.s;
+    const uint8_t *d_isx = nullptr;
+    if ((rc = stage_batch(ctx, s, HPGV_LAYOUT_STATS_GROUPS, ctx->sgroups, gt, pitch, n_variants, nullptr, &d_isx))) return rc;
+    const size_t n = (size_t)n_variants, ng = ctx->sg_off.size();
+    if ((rc = ensure(ctx, s, 3, ng * n * 32))) return rc;
+    if ((rc = ensure(ctx, s, 4, ng * n * 2 * sizeof(double)))) return rc;
+    int32_t *d_c8 = (int32_t *)s->buf[3];
+    double *d_hw = (double *)s->buf[4];
+    for (size_t k = 0; k < ng; ++k) {
+        if ((rc = hpgv_stats_scan_group_dev(ctx, (const uint8_t *)s->buf[1], n_variants, (int)k, d_c8 + k * n * 8, s->stream))) return rc;
+        if (hwe_chi2 && (rc = hpgv_stats_hwe_dev(ctx, d_c8 + k * n * 8, n_variants, d_hw + k * n, d_hw + (ng + k) * n, s->stream))) return rc;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(counts8, d_c8, ng * n * 32, hipMemcpyDeviceToHost, s->stream));
+    if (hwe_chi2) {
+        HIPCHK(ctx, hipMemcpyAsync(hwe_chi2, d_hw, ng * n * 8, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(ctx, hipMemcpyAsync(hwe_p, d_hw + ng * n, ng * n * 8, hipMemcpyDeviceToHost, s->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    return HPGV_OK;
+}
+
 int hpgv_epi_dataset(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, uint8_t *out) {
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->assoc.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_cohort has not been called");

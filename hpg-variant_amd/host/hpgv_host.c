@@ -227,6 +227,7 @@ void variant_stats_free(variant_stats_t *s) {
     if (!s) return;
     free(s->chromosome); free(s->ref_allele); free(s->alt_alleles);
     free(s->alleles_count); free(s->genotypes_count); free(s->alleles_freq); free(s->genotypes_freq);
+    free(s->phenotype_stats);
     free(s);
 }
 sample_stats_t *sample_stats_new(char *name) {
@@ -348,6 +349,7 @@ static struct {
 static struct { int num_families; int num_columns; uint64_t hash; int set; } g_tdt_key;
 static struct { int num_samples; int set; } g_stats_key;
 static struct { int num_samples; int n_trios; uint64_t hash; int set; } g_ped_key;
+static struct { int num_samples; int n_groups; uint64_t hash; int set; } g_group_key;
 static struct { const void *table; int n; } g_lf_key;
 
 const char *hpgv_host_last_error(void) { return g_err; }
@@ -377,6 +379,7 @@ void hpgv_host_shutdown(void) {
     memset(&g_tdt_key, 0, sizeof g_tdt_key);
     memset(&g_stats_key, 0, sizeof g_stats_key);
     memset(&g_ped_key, 0, sizeof g_ped_key);
+    memset(&g_group_key, 0, sizeof g_group_key);
     memset(&g_lf_key, 0, sizeof g_lf_key);
     pthread_mutex_unlock(&g_init_mu);
 }
@@ -668,7 +671,7 @@ static int count_alleles(const char *alt, int len) {
 int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t **individuals,
                        sample_ids_t *sample_ids, int num_variables, list_t *output_list,
                        file_stats_t *file_stats) {
-    (void)individuals; (void)sample_ids; (void)num_variables;   /* per-phenotype grouping: DESIGN.md "Not yet" */
+    (void)sample_ids;
     if (num_variants <= 0) return 0;
     int rc = ensure_engine();
     if (rc) return rc;
@@ -688,11 +691,51 @@ int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t *
     hpgv_host_stage_records(variants, num_variants, num_samples, 0, gt, NULL);
     int n_multi = num_variants;
 
+    /* per-phenotype counters (one report per phenotype, stats_runner.c:300-303,319-323): the group of VCF
+     * column j is the id of its individual's PED variable, 0 .. num_variables-1 */
+    const int ng = (individuals && num_variables > 0 && num_samples > 0) ? num_variables : 0;
+    int32_t *group = NULL, *gc8 = NULL;
+    double *ghw = NULL;
+    uint64_t gh = 1469598103934665603ULL;
+    if (ng) {
+        group = (int32_t *)malloc((size_t)num_samples * sizeof(int32_t));
+        gc8 = (int32_t *)malloc((size_t)ng * n * 8 * sizeof(int32_t));
+        ghw = (double *)malloc((size_t)ng * n * 2 * sizeof(double));
+        if (!group || !gc8 || !ghw) {
+            free(group); free(gc8); free(ghw); free(gt); free(c8); free(hw); free(midx); free(mtab);
+            snprintf(g_err, sizeof g_err, "out of memory");
+            return HPGV_ERR_NOMEM;
+        }
+        for (int j = 0; j < num_samples; j++) {
+            const individual_t *ind = individuals[j];
+            const int k = ind ? (int)ind->variable : -1;
+            group[j] = (ind && ind->variable >= 0 && k < ng) ? k : -1;
+            gh = (gh ^ (uint64_t)(uint32_t)group[j]) * 1099511628211ULL;
+        }
+    }
+
     pthread_rwlock_rdlock(&g_cohort_lock);
     rc = stats_prepare(num_samples);
     if (rc == HPGV_OK) {
         rc = hpgv_stats_ex(g_ctx, gt, pitch, num_variants, c8, hw, hw + n, NULL, midx, mtab, &n_multi);
         if (rc != HPGV_OK) host_fail("hpgv_stats_ex", rc);
+    }
+    if (rc == HPGV_OK && ng) {
+        if (!(g_group_key.set && g_group_key.num_samples == num_samples && g_group_key.n_groups == ng && g_group_key.hash == gh)) {
+            pthread_rwlock_unlock(&g_cohort_lock);
+            pthread_rwlock_wrlock(&g_cohort_lock);
+            if (!(g_group_key.set && g_group_key.num_samples == num_samples && g_group_key.n_groups == ng && g_group_key.hash == gh)) {
+                rc = hpgv_set_stats_groups(g_ctx, group, num_samples, ng);
+                if (rc == HPGV_OK) { g_group_key.set = 1; g_group_key.num_samples = num_samples; g_group_key.n_groups = ng; g_group_key.hash = gh; }
+                else host_fail("hpgv_set_stats_groups", rc);
+            }
+            pthread_rwlock_unlock(&g_cohort_lock);
+            pthread_rwlock_rdlock(&g_cohort_lock);
+        }
+        if (rc == HPGV_OK) {
+            rc = hpgv_stats_groups(g_ctx, gt, pitch, num_variants, gc8, ghw, ghw + (size_t)ng * n);
+            if (rc != HPGV_OK) host_fail("hpgv_stats_groups", rc);
+        }
     }
     pthread_rwlock_unlock(&g_cohort_lock);
 
@@ -748,6 +791,22 @@ int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t *
             }
             for (int k = 0; k < na * na; k++) s->genotypes_freq[k] = tg ? (float)s->genotypes_count[k] / tg : 0.0f;
             s->hw_chi2 = hw[i]; s->hw_p_value = hw[n + i];
+            if (ng) {
+                s->num_phenotypes = ng;
+                s->phenotype_stats = (variant_phenotype_stats_t *)calloc((size_t)ng, sizeof *s->phenotype_stats);
+                for (int k = 0; s->phenotype_stats && k < ng; k++) {
+                    const int32_t *g = gc8 + ((size_t)k * n + i) * 8;
+                    variant_phenotype_stats_t *ps = &s->phenotype_stats[k];
+                    ps->genotypes_count[0] = g[0]; ps->genotypes_count[1] = g[1]; ps->genotypes_count[2] = g[2]; ps->genotypes_count[3] = g[3];
+                    ps->missing_genotypes = g[4]; ps->missing_alleles = g[5];
+                    ps->alleles_count[0] = g[6]; ps->alleles_count[1] = g[7];
+                    const int t2 = g[6] + g[7];
+                    ps->alleles_freq[0] = t2 ? (float)g[6] / t2 : 0.0f;
+                    ps->alleles_freq[1] = t2 ? (float)g[7] / t2 : 0.0f;
+                    ps->maf = ps->alleles_freq[0] < ps->alleles_freq[1] ? ps->alleles_freq[0] : ps->alleles_freq[1];
+                    ps->hw_chi2 = ghw[(size_t)k * n + i]; ps->hw_p_value = ghw[((size_t)ng + k) * n + i];
+                }
+            }
             list_insert_item(list_item_new(tid, 0, s), output_list);
         }
         if (file_stats) {
@@ -759,7 +818,7 @@ int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t *
             pthread_mutex_unlock(&file_stats->lock);
         }
     }
-    free(gt); free(c8); free(hw); free(midx); free(mtab);
+    free(gt); free(c8); free(hw); free(midx); free(mtab); free(group); free(gc8); free(ghw);
     return rc;
 }
 

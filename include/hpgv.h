@@ -224,6 +224,12 @@ int  hpgv_stats_ex(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variant
                    int32_t *counts8, double *hwe_chi2, double *hwe_p, int32_t *sample_missing,
                    int32_t *multi_idx, int32_t *multi_table, int *n_multi);
 
+/* the stats counters per phenotype group of hpgv_set_stats_groups (one report per phenotype,
+ * stats_runner.c:300-303,319-323): counts8[(g * n_variants + v) * 8 + k], hwe_*[g * n_variants + v]
+ * (both hwe arrays may be NULL).  Samples in no group are not counted anywhere. */
+int  hpgv_stats_groups(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants,
+                       int32_t *counts8, double *hwe_chi2, double *hwe_p);
+
 /* epistasis dataset rows of vcf2epi (epistasis_dataset_process_records, dataset_creator.c:241-272):
  * out[v * (n_affected + n_unaffected) + destination] with cases first then controls, each in VCF column
  * order (group_individuals_by_phenotype, :302-320), codes 0 "0/0", 1 heterozygous, 2 homozygous

@@ -171,6 +171,15 @@ void tdt_result_free(tdt_result_t *result);
 /* variant_stats_t: the fields visible in the reference tree
  * (aggregate_runner.c:187-191,288-312,379-400), plus the Hardy-Weinberg record the
  * stats tool reports.  Arrays are sized by num_alleles (1 + number of ALT alleles). */
+typedef struct {                       /* the counters of one phenotype group (first two alleles) */
+    int alleles_count[2];
+    int genotypes_count[4];            /* 0/0, 0/1, 1/0, 1/1 */
+    float alleles_freq[2];
+    int missing_alleles, missing_genotypes;
+    float maf;
+    double hw_chi2, hw_p_value;
+} variant_phenotype_stats_t;
+
 typedef struct {
     char *chromosome; unsigned long position;
     char *ref_allele; char *alt_alleles;
@@ -182,6 +191,9 @@ typedef struct {
     int missing_alleles, missing_genotypes;
     float maf;
     double hw_chi2, hw_p_value;        /* on the first two alleles */
+    int num_phenotypes;                /* num_variables of the call (0 without a PED) */
+    variant_phenotype_stats_t *phenotype_stats;   /* [num_phenotypes]: samples whose individual->variable is that id
+                                          (report_vcf_variant_phenotype_stats(fd, n, batch, i), stats_runner.c:319-323) */
 } variant_stats_t;
 
 void variant_stats_free(variant_stats_t *stats);
@@ -225,7 +237,9 @@ double *init_logarithm_array(int n);
 int  tdt_test(vcf_record_t **variants, int num_variants, family_t **families, int num_families,
               sample_ids_t *sample_ids, list_t *output_list);
 
-/* call shape of stats_runner.c:194-195; returns 0 on success */
+/* call shape of stats_runner.c:194-195; returns 0 on success.  With individuals != NULL and
+ * num_variables > 0 every record also carries the counters of each phenotype group: VCF column j
+ * belongs to group (int)individuals[j]->variable when that is in [0, num_variables). */
 int  get_variants_stats(vcf_record_t **variants, int num_variants, individual_t **individuals,
                         sample_ids_t *sample_ids, int num_variables, list_t *output_list,
                         file_stats_t *file_stats);

@@ -200,7 +200,10 @@ static int load_ped(const char *path, ped_t *ped) {
         enum Sex s = !strcmp(sex, "1") ? MALE : !strcmp(sex, "2") ? FEMALE : UNKNOWN_SEX;
         /* stats_runner.c:50,86-87: unaffected label "1", affected "2" */
         enum Condition c = !strcmp(phe, "2") ? AFFECTED : !strcmp(phe, "1") ? UNAFFECTED : MISSING_CONDITION;
-        ped->people[ped->n] = individual_new(iid, -1.0f, s, c, NULL, NULL, NULL);
+        /* variable = id of the PED variable's value, in order of first appearance (get_phenotypes / set_variable_field
+         * "PHENO", stats_runner.c:47-50): here the phenotype column itself, "1" -> 0, "2" -> 1, anything else -> 2 */
+        float var = !strcmp(phe, "1") ? 0.0f : !strcmp(phe, "2") ? 1.0f : 2.0f;
+        ped->people[ped->n] = individual_new(iid, var, s, c, NULL, NULL, NULL);
         ped->fid[ped->n] = fid; ped->pat[ped->n] = pat; ped->mat[ped->n] = mat;
         ped->n++;
     }
@@ -328,7 +331,7 @@ static int cmd_stats(const char *batch_path, const char *out_path, const char *p
     int chunk = 64, rc = 0;
     for (int start = 0; start < b.n_variants && !rc; start += chunk) {
         int n = start + chunk <= b.n_variants ? chunk : b.n_variants - start;
-        rc = get_variants_stats(b.records + start, n, individuals, ids, 0, &out, fs);
+        rc = get_variants_stats(b.records + start, n, individuals, ids, individuals ? 3 : 0, &out, fs);
         rc |= get_sample_stats(b.records + start, n, individuals, ids, ss, fs);
     }
     if (rc) { fprintf(stderr, "stats failed: %s\n", hpgv_host_last_error()); return 1; }
@@ -342,6 +345,12 @@ static int cmd_stats(const char *batch_path, const char *out_path, const char *p
         for (int k = 0; k < s->num_alleles; k++) fprintf(fd, "\t%d", s->alleles_count[k]);
         for (int k = 0; k < s->num_alleles * s->num_alleles; k++) fprintf(fd, "\t%d", s->genotypes_count[k]);
         fprintf(fd, "\n");
+        for (int k = 0; k < s->num_phenotypes; k++) {
+            const variant_phenotype_stats_t *ps = &s->phenotype_stats[k];
+            fprintf(fd, "P\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%.17g\t%.17g\t%.9g\n", k, ps->genotypes_count[0], ps->genotypes_count[1],
+                    ps->genotypes_count[2], ps->genotypes_count[3], ps->missing_genotypes, ps->missing_alleles,
+                    ps->alleles_count[0], ps->alleles_count[1], ps->hw_chi2, ps->hw_p_value, (double)ps->maf);
+        }
         variant_stats_free(s);
         list_item_free(it);
     }

@@ -457,6 +457,15 @@ def test_stats_per_phenotype_group():
             assert_close([hw[0][i]], [vs.hw_chi2], "hwe chi2"); assert_close([hw[1][i]], [vs.hw_p], "hwe p")
     with pytest.raises(hpgv.HpgvError):
         e.stats_scan_group(d_lay, nv, n_groups, d_c8)
+    # the host-batch entry point gives the same counters for all groups in one call
+    res = e.stats_groups(gt, n_groups)
+    for k in range(n_groups):
+        sub = gt[:, group == k]
+        for i in range(0, nv, 7):
+            vs = orc.variant_stats(np.ascontiguousarray(sub[i]), 2)
+            c = res["counts8"][k][i]
+            assert list(c[:4]) == list(vs.genotypes_count)[:4] and (c[4], c[5]) == (vs.missing_genotypes, vs.missing_alleles)
+            assert_close([res["hwe_chi2"][k][i]], [vs.hw_chi2], "hwe chi2"); assert_close([res["hwe_p"][k][i]], [vs.hw_p], "hwe p")
     e.close()
 
 

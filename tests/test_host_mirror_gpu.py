@@ -203,6 +203,19 @@ def test_get_variants_stats_and_sample_stats(driver, tmp_path, n_fam, n_extra, n
         assert [int(x) for x in t[8: 8 + na]] == list(vs.alleles_count)[:na], v
         assert [int(x) for x in t[8 + na: 8 + na + na * na]] == list(vs.genotypes_count)[: na * na], v
     assert n_multi > 0 and ("multiallelic=%d" % n_multi) in r.stdout
+    # per-phenotype counters: group = id of the PED variable of the column's individual ("1" -> 0, "2" -> 1, else 2);
+    # a VCF column without a PED row is in no group
+    pheno = {p[1]: p[5] for p in people}
+    group = np.array([{1: 0, 2: 1}.get(pheno[n], 2) if n in pheno else -1 for n in names])
+    plines = [t for t in lines if t[0] == "P"]
+    assert len(plines) == 3 * len(rows)
+    for v in range(len(rows)):
+        for k in range(3):
+            t = plines[3 * v + k]
+            vs = orc.variant_stats(np.ascontiguousarray(gt[v][group == k]), 2)
+            assert int(t[1]) == k and [int(x) for x in t[2:6]] == list(vs.genotypes_count)[:4], (v, k)
+            assert (int(t[6]), int(t[7]), int(t[8]), int(t[9])) == (vs.missing_genotypes, vs.missing_alleles, vs.alleles_count[0], vs.alleles_count[1])
+            assert_close([_fl(t[10])], [vs.hw_chi2], "group hwe chi2"); assert_close([_fl(t[11])], [vs.hw_p], "group hwe p")
     miss = orc.sample_missing(gt)                          # get_sample_stats: per-sample missing genotypes
     # per-sample Mendelian errors: every sample whose two parents are VCF columns, checked on every variant
     col = {n: i for i, n in enumerate(names)}
