@@ -22,6 +22,13 @@
  *                                documented here, cross-checked vs exact
  *                                rational arithmetic / scipy goldens.
  *
+ *   - epistasis / MDR counting : PINNED by the reference's unit tests
+ *                                (test/test_epistasis_model.c:116-520: pair and triple
+ *                                counts, counts per fold, confusion matrices, evaluation
+ *                                formulas; test/test_mdr.c:33-65: high-risk cells);
+ *                                restated from src/gwas/epistasis/model.c, mdr.c
+ *                                (hpgv_epi_oracle.c)
+ *
  * The reference itself cannot be compiled here (needs hpg-libs, GSL,
  * argtable2, libconfig; none present), so there is no oracle/_ref build.
  */
@@ -148,6 +155,27 @@ double orc_baseline_assoc_packed(const uint8_t *gt, size_t pitch, int n_variants
                                  const uint8_t *condition, int n_threads, int *threads_used);
 double orc_baseline_assoc_text(uint64_t v0, int n_variants, int n_samples,
                                const uint8_t *condition, int n_threads, int *threads_used);
+
+/* ---- epistasis / MDR (hpgv_epi_oracle.c; src/gwas/epistasis/model.c, mdr.c, epistasis.c) ---- */
+void orc_epi_counts(int order, const uint8_t *const *rows, int n_affected, int n_unaffected,
+                    int32_t *counts_aff, int32_t *counts_unaff);                         /* model.c:76-124 */
+void orc_epi_counts_all_folds(int order, const uint8_t *const *rows, int n_affected, int n_unaffected,
+                              const uint8_t *fold_masks, int num_folds,
+                              int32_t *counts_aff, int32_t *counts_unaff);               /* model.c:126-206 */
+int  orc_mdr_high_risk(unsigned count_affected, unsigned count_unaffected,
+                       unsigned samples_affected, unsigned samples_unaffected);          /* mdr.c:23-42 */
+int  orc_mdr_high_risk2(int count_affected, int count_unaffected,
+                        unsigned num_affected, unsigned num_unaffected);                 /* mdr.c:45-76 */
+void orc_epi_confusion(int order, const uint8_t *risky, int n_risky, const uint8_t *const *rows,
+                       int n_affected, int n_unaffected, const uint8_t *fold_mask, int subset,
+                       const int32_t size_aff_unaff[2], uint32_t matrix[4]);             /* model.c:337-456 */
+double orc_epi_evaluate(const uint32_t matrix[4], int function);                         /* model.c:458-476 */
+void orc_epi_model(int order, const uint8_t *const *rows, int n_affected, int n_unaffected,
+                   const uint8_t *fold_masks, int num_folds, int subset,
+                   double *accuracy, uint32_t *risky_mask, uint32_t *matrices);          /* epistasis.c:14-95 */
+void orc_epi_scan_pairs(const uint8_t *dataset, int n_variants, int n_affected, int n_unaffected,
+                        const uint8_t *fold_masks, int num_folds, int subset,
+                        double *accuracy, uint32_t *risky_mask);
 
 #ifdef __cplusplus
 }

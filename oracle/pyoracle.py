@@ -19,7 +19,7 @@ MAX_ALLELES = 15
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("hpgv_oracle.c", "hpgv_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("hpgv_oracle.c", "hpgv_epi_oracle.c", "hpgv_oracle.h")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in src)):
         return _SO
@@ -272,3 +272,87 @@ def baseline_assoc_text(v0, n_variants, n_samples, condition, n_threads):
     sec = lib().orc_baseline_assoc_text(v0, n_variants, n_samples, _p(cond, C.c_uint8),
                                         n_threads, C.byref(used))
     return sec, used.value
+
+
+# ---- epistasis / MDR (hpgv_epi_oracle.c) -------------------------------------------------------
+
+def _rows(rows):
+    rows = [np.ascontiguousarray(r, dtype=np.uint8) for r in rows]
+    arr = (C.POINTER(C.c_uint8) * len(rows))(*[_p(r, C.c_uint8) for r in rows])
+    return rows, arr
+
+
+def epi_counts(rows, n_affected, n_unaffected):
+    """combination_counts (model.c:76-124): rows = `order` genotype rows, cases first."""
+    rows, arr = _rows(rows)
+    cells = 3 ** len(rows)
+    aff, unaff = np.zeros(cells, np.int32), np.zeros(cells, np.int32)
+    lib().orc_epi_counts(len(rows), arr, n_affected, n_unaffected, _p(aff, C.c_int32), _p(unaff, C.c_int32))
+    return aff, unaff
+
+
+def epi_counts_all_folds(rows, n_affected, n_unaffected, fold_masks):
+    """combination_counts_all_folds (model.c:126-206): fold_masks k x (nA+nU), 1 = training part."""
+    rows, arr = _rows(rows)
+    fm = np.ascontiguousarray(fold_masks, dtype=np.uint8)
+    k, cells = fm.shape[0], 3 ** len(rows)
+    aff, unaff = np.zeros((k, cells), np.int32), np.zeros((k, cells), np.int32)
+    lib().orc_epi_counts_all_folds(len(rows), arr, n_affected, n_unaffected, _p(fm, C.c_uint8), k,
+                                   _p(aff, C.c_int32), _p(unaff, C.c_int32))
+    return aff, unaff
+
+
+def mdr_high_risk(ca, cu, n_aff, n_unaff):
+    return bool(lib().orc_mdr_high_risk(ca, cu, n_aff, n_unaff))
+
+
+def mdr_high_risk2(ca, cu, n_aff, n_unaff):
+    return bool(lib().orc_mdr_high_risk2(ca, cu, n_aff, n_unaff))
+
+
+def epi_confusion(risky, rows, n_affected, n_unaffected, fold_mask, subset, sizes):
+    """confusion_matrix (model.c:337-456): risky = list of cells (tuples of genotypes); subset 1 TRAINING, 0 TESTING."""
+    rows, arr = _rows(rows)
+    r = np.ascontiguousarray(np.array(risky, dtype=np.uint8).reshape(-1))
+    fm = np.ascontiguousarray(fold_mask, dtype=np.uint8)
+    sz = np.array(sizes, np.int32)
+    m = np.zeros(4, np.uint32)
+    lib().orc_epi_confusion(len(rows), _p(r, C.c_uint8), len(risky), arr, n_affected, n_unaffected, _p(fm, C.c_uint8),
+                            subset, _p(sz, C.c_int32), _p(m, C.c_uint32))
+    return [int(x) for x in m]
+
+
+def epi_evaluate(matrix, function):
+    lib().orc_epi_evaluate.restype = C.c_double
+    m = np.array(matrix, np.uint32)
+    return float(lib().orc_epi_evaluate(_p(m, C.c_uint32), function))
+
+
+def epi_model(rows, n_affected, n_unaffected, fold_masks, subset):
+    rows, arr = _rows(rows)
+    fm = np.ascontiguousarray(fold_masks, dtype=np.uint8)
+    k = fm.shape[0]
+    acc, rm, mat = np.zeros(k, np.float64), np.zeros(k, np.uint32), np.zeros((k, 4), np.uint32)
+    lib().orc_epi_model(len(rows), arr, n_affected, n_unaffected, _p(fm, C.c_uint8), k, subset,
+                        _p(acc, C.c_double), _p(rm, C.c_uint32), _p(mat, C.c_uint32))
+    return acc, rm, mat
+
+
+def epi_scan_pairs(dataset, n_affected, n_unaffected, fold_masks, subset):
+    """Every pair i < j in lexicographic order: accuracy[f][p], risky_mask[f][p]."""
+    d = np.ascontiguousarray(dataset, dtype=np.uint8)
+    fm = np.ascontiguousarray(fold_masks, dtype=np.uint8)
+    v, k = d.shape[0], fm.shape[0]
+    assert k <= 64 and d.shape[1] == n_affected + n_unaffected == fm.shape[1]
+    n_pairs = v * (v - 1) // 2
+    acc, rm = np.zeros((k, n_pairs), np.float64), np.zeros((k, n_pairs), np.uint32)
+    lib().orc_epi_scan_pairs(_p(d, C.c_uint8), v, n_affected, n_unaffected, _p(fm, C.c_uint8), k, subset,
+                             _p(acc, C.c_double), _p(rm, C.c_uint32))
+    return acc, rm
+
+
+def fold_masks_from_assignment(fold_of_sample, num_folds):
+    """get_k_folds_masks (cross_validation.c:247-281) without the SSE padding: mask[f][s] = 0 when sample s
+    is in the testing part of fold f, 1 otherwise."""
+    f = np.asarray(fold_of_sample)
+    return (f[None, :] != np.arange(num_folds)[:, None]).astype(np.uint8)

@@ -87,3 +87,28 @@ def make_families(rng, n_samples, n_families, max_children=1, p_absent=0.0):
         pos += need
     return (np.array(fcol, np.int32), np.array(mcol, np.int32), np.array(coff, np.int32),
             np.array(ccol, np.int32), np.array(csex, np.uint8))
+
+
+# ---- epistasis / MDR ---------------------------------------------------------------------------
+
+def epi_unpad(padded, n_affected, n_unaffected):
+    """The reference's SSE layout [affected | pad to 16 | unaffected | pad to 16] -> [affected | unaffected]."""
+    a = np.asarray(padded, dtype=np.uint8)
+    pa = -(-n_affected // 16) * 16
+    return np.concatenate([a[:n_affected], a[pa: pa + n_unaffected]])
+
+
+def epi_random_dataset(rng, n_variants, n_affected, n_unaffected, p_missing=0.02):
+    """vcf2epi rows: codes 0/1/2, 255 = missing, cases first."""
+    codes = np.array([0, 1, 2, 255], np.uint8)
+    p = np.array([0.5, 0.35, 0.15 - p_missing, p_missing])
+    return codes[rng.choice(4, size=(n_variants, n_affected + n_unaffected), p=p)]
+
+
+def epi_random_folds(rng, n_affected, n_unaffected, num_folds):
+    """Fold of every sample as get_k_folds deals them out (cross_validation.c:16-100): shuffled cases and
+    shuffled controls handed round-robin to the folds."""
+    f = np.empty(n_affected + n_unaffected, np.int32)
+    f[rng.permutation(n_affected)] = np.arange(n_affected) % num_folds
+    f[n_affected + rng.permutation(n_unaffected)] = np.arange(n_unaffected) % num_folds
+    return f

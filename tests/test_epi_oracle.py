@@ -1,0 +1,131 @@
+"""The epistasis / MDR oracle (oracle/hpgv_epi_oracle.c) against the reference's own unit tests
+(tests/golden/reference_kats.json "epistasis_model": test/test_epistasis_model.c, test/test_mdr.c) and
+against an independent numpy statement of the same definitions.  CPU only."""
+import numpy as np
+import pytest
+
+from helpers import epi_random_dataset, epi_random_folds, epi_unpad
+from oracle import pyoracle as orc
+
+
+@pytest.fixture(scope="module")
+def kat(goldens):
+    return goldens["kats"]["epistasis_model"]
+
+
+def test_counts_reference_kat(kat):
+    k = kat["counts"]
+    nA, nU = k["num_affected"], k["num_unaffected"]
+    rows = [epi_unpad(r, nA, nU) for r in k["padded_rows"]]
+    for name in ("order2", "order3"):
+        aff, unaff = orc.epi_counts([rows[i] for i in k[name]["rows"]], nA, nU)
+        assert list(aff) == k[name]["aff"] and list(unaff) == k[name]["unaff"], name
+
+
+def test_counts_all_folds_reference_kat(kat):
+    k = kat["counts_all_folds"]
+    nA, nU = k["num_affected"], k["num_unaffected"]
+    rows = [epi_unpad(r, nA, nU) for r in k["padded_rows"]]
+    masks = np.stack([epi_unpad(m, nA, nU) for m in k["padded_fold_masks"]])
+    assert ((masks == 0).sum(axis=0) == 1).all()                     # the KAT's masks are a partition into testing folds
+    aff, unaff = orc.epi_counts_all_folds([rows[i] for i in k["order2"]["rows"]], nA, nU, masks)
+    assert aff.tolist() == k["order2"]["aff"] and unaff.tolist() == k["order2"]["unaff"]
+    aff, unaff = orc.epi_counts_all_folds(rows, nA, nU, masks)
+    for f, cells in k["order3"]["some_cells"].items():
+        for c, (ea, eu) in cells.items():
+            assert (aff[int(f)][int(c)], unaff[int(f)][int(c)]) == (ea, eu), (f, c)
+
+
+def test_confusion_matrix_reference_kats(kat):
+    for case in kat["confusion"]:
+        nA, nU = case["num_affected"], case["num_unaffected"]
+        rows = [epi_unpad(r, nA, nU) for r in case["padded_rows"]]
+        mask = epi_unpad(case["padded_fold_mask"], nA, nU)
+        training = case["subset"] == "TRAINING"
+        m = orc.epi_confusion(case["risky"], rows, nA, nU, mask, 1 if training else 0,
+                              case["training_size"] if training else case["testing_size"])
+        assert m == case["matrix"], case["line"]
+
+
+def test_evaluation_formulas_reference_kat(kat):
+    for case in kat["evaluate"]:
+        for fn, name in ((0, "CA"), (1, "BA"), (3, "GAMMA"), (4, "TAU_B")):
+            assert abs(orc.epi_evaluate(case["matrix"], fn) - case[name]) <= 1e-6, (case["matrix"], name)
+    assert orc.epi_evaluate([40, 2, 4, 10], 1) == ((40 / 42) + (10 / 14)) / 2
+    assert np.isnan(orc.epi_evaluate([0, 0, 3, 4], 1))                # no affected sample in the subset: 0/0 as in C
+
+
+def test_mdr_high_risk_reference_kats(kat):
+    k = kat["mdr_high_risk"]
+    nA, nU = k["num_affected"], k["num_unaffected"]
+    risky = [i for i, (a, u) in enumerate(k["scalar"]["counts"]) if orc.mdr_high_risk(a, u, nA, nU)]
+    assert risky == k["scalar"]["risky_indices"]
+    got = [orc.mdr_high_risk2(a, u, nA, nU) for a, u in zip(k["vector"]["aff"], k["vector"]["unaff"])]
+    assert got == k["vector"]["risky"]
+    assert not orc.mdr_high_risk2(0, 0, nA, nU) and not orc.mdr_high_risk(0, 0, nA, nU)      # empty cell: 0/0, never risky
+    assert orc.mdr_high_risk2(1, 8, 10, 80)                          # exactly the cohort's ratio: >= holds
+
+
+def _numpy_model(ri, rj, nA, nU, fold, k, subset):
+    """Independent statement: counts by bincount, the MDR rule in float32, confusion from the cell counts."""
+    n = nA + nU
+    valid = (ri < 3) & (rj < 3)
+    cell = np.where(valid, ri.astype(int) * 3 + rj, 9)
+    is_aff = np.arange(n) < nA
+    acc, masks = [], []
+    ratio = np.float32(nA) / np.float32(nU)
+    for f in range(k):
+        train = fold != f
+        ca = np.bincount(cell[train & is_aff], minlength=10)[:9].astype(np.float32)
+        cu = np.bincount(cell[train & ~is_aff], minlength=10)[:9].astype(np.float32)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            total = ca + cu
+            prop = cu * ratio
+            nu_ = prop * (total / (prop + ca))
+            risky = (total - nu_) >= nu_
+        sel = train if subset == 1 else ~train
+        pred = valid & risky[np.minimum(cell, 8)] & sel
+        tp, fp = int((pred & is_aff).sum()), int((pred & ~is_aff).sum())
+        sa, su = int((sel & is_aff).sum()), int((sel & ~is_aff).sum())
+        with np.errstate(invalid="ignore", divide="ignore"):
+            acc.append((np.float64(tp) / np.float64(sa) + np.float64(su - fp) / np.float64(su)) / 2)
+        masks.append(int(sum(1 << c for c in range(9) if risky[c])))
+    return np.array(acc), np.array(masks, np.uint32)
+
+
+@pytest.mark.parametrize("nA,nU,k", [(37, 52, 5), (16, 16, 2), (100, 33, 10), (5, 4, 3)])
+def test_pair_scan_against_numpy(nA, nU, k):
+    rng = np.random.default_rng(nA * 1000 + nU)
+    v = 12
+    data = epi_random_dataset(rng, v, nA, nU, p_missing=0.05)
+    fold = epi_random_folds(rng, nA, nU, k)
+    masks = orc.fold_masks_from_assignment(fold, k)
+    for subset in (0, 1):
+        acc, rm = orc.epi_scan_pairs(data, nA, nU, masks, subset)
+        p = 0
+        for i in range(v):
+            for j in range(i + 1, v):
+                ea, em = _numpy_model(data[i], data[j], nA, nU, fold, k, subset)
+                got = acc[:, p]
+                assert np.array_equal(rm[:, p], em), (i, j)
+                assert np.all((got == ea) | (np.isnan(got) & np.isnan(ea))), (i, j, got, ea)
+                p += 1
+        assert p == acc.shape[1]
+
+
+def test_model_matrices_consistent_with_counts():
+    rng = np.random.default_rng(5)
+    nA, nU, k = 40, 60, 4
+    data = epi_random_dataset(rng, 3, nA, nU)
+    fold = epi_random_folds(rng, nA, nU, k)
+    masks = orc.fold_masks_from_assignment(fold, k)
+    for rows in ([data[0], data[1]], [data[0], data[1], data[2]]):
+        acc, rm, mat = orc.epi_model(rows, nA, nU, masks, 0)
+        aff, unaff = orc.epi_counts_all_folds(rows, nA, nU, masks)
+        tot_a, tot_u = orc.epi_counts(rows, nA, nU)
+        for f in range(k):
+            cells = [c for c in range(3 ** len(rows)) if rm[f] >> c & 1]
+            tp = sum(int(tot_a[c] - aff[f][c]) for c in cells)             # testing part = everybody minus the training part
+            fp = sum(int(tot_u[c] - unaff[f][c]) for c in cells)
+            assert (int(mat[f][0]), int(mat[f][2])) == (tp, fp)
+            assert int(mat[f][0] + mat[f][1]) == int(((fold == f) & (np.arange(nA + nU) < nA)).sum())
