@@ -17,6 +17,7 @@ from . import _build
 
 OK = 0
 TASK_CHISQ, TASK_FISHER = 1, 2
+EPI_TESTING, EPI_TRAINING = 0, 1
 COND_UNAFFECTED, COND_AFFECTED, COND_OTHER = 0, 1, 2
 SEX_MALE, SEX_FEMALE, SEX_UNKNOWN = 0, 1, 2
 LAYOUT_ASSOC, LAYOUT_TDT, LAYOUT_STATS, LAYOUT_STATS_GROUPS, LAYOUT_MENDEL, LAYOUT_EPI = 0, 1, 2, 3, 4, 5
@@ -36,7 +37,9 @@ SYMBOLS = [
     "hpgv_tdt_scan_dev", "hpgv_tdt_stats_dev", "hpgv_stats_scan_dev", "hpgv_stats_hwe_dev",
     "hpgv_sample_missing_dev", "hpgv_genotype_table_dev", "hpgv_stats_filter_dev",
     "hpgv_mendel", "hpgv_epi_dataset", "hpgv_tokenize_dev", "hpgv_tokenize", "hpgv_assoc_text", "hpgv_tdt_text",
-    "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_stats_groups", "hpgv_read_probe",
+    "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_stats_groups",
+    "hpgv_epi_set_dataset", "hpgv_epi_set_folds", "hpgv_epi_set_fold_masks", "hpgv_epi_counts",
+    "hpgv_epi_counts_all_folds", "hpgv_epi_scan_pairs", "hpgv_epi_rank_pairs", "hpgv_read_probe",
 ]
 
 
@@ -118,6 +121,13 @@ def load():
     L.hpgv_mendel_children_dev.argtypes = [vp, vp, i32, vp, vp, vp]
     L.hpgv_mendel.argtypes = [vp, vp, sz, i32, vp, vp, vp]
     L.hpgv_epi_dataset.argtypes = [vp, vp, sz, i32, vp]
+    L.hpgv_epi_set_dataset.argtypes = [vp, vp, i32, i32, i32]
+    L.hpgv_epi_set_folds.argtypes = [vp, vp, i32]
+    L.hpgv_epi_set_fold_masks.argtypes = [vp, vp, i32]
+    L.hpgv_epi_counts.argtypes = [vp, i32, vp, i32, vp, vp]
+    L.hpgv_epi_counts_all_folds.argtypes = [vp, i32, vp, i32, vp, vp]
+    L.hpgv_epi_scan_pairs.argtypes = [vp, i32, i32, i32, vp, vp, C.POINTER(C.c_ulonglong)]
+    L.hpgv_epi_rank_pairs.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
     L.hpgv_read_probe.argtypes = [vp, vp, sz, i32, C.POINTER(C.c_float)]
     _lib = L
     return L
@@ -285,6 +295,51 @@ class Engine:
         chi2, p = np.zeros((n_groups, nv), np.float64), np.zeros((n_groups, nv), np.float64)
         self._chk(self.L.hpgv_stats_groups(self.h, _ptr(gt), pitch, nv, _ptr(c8), _ptr(chi2), _ptr(p)))
         return dict(counts8=c8, hwe_chi2=chi2, hwe_p=p)
+
+    # ---- epistasis / MDR ------------------------------------------------------
+    def epi_set_dataset(self, genotypes, n_affected, n_unaffected):
+        d = _np(genotypes, np.uint8)
+        assert d.ndim == 2 and d.shape[1] == n_affected + n_unaffected
+        self._chk(self.L.hpgv_epi_set_dataset(self.h, _ptr(d), d.shape[0], n_affected, n_unaffected))
+        self._epi = (d.shape[0], n_affected, n_unaffected, 1)
+
+    def epi_set_folds(self, fold_of_sample, num_folds):
+        f = _np(fold_of_sample, np.int32)
+        self._chk(self.L.hpgv_epi_set_folds(self.h, _ptr(f), num_folds))
+        self._epi = self._epi[:3] + (num_folds,)
+
+    def epi_set_fold_masks(self, padded_masks, num_folds):
+        m = _np(padded_masks, np.uint8)
+        self._chk(self.L.hpgv_epi_set_fold_masks(self.h, _ptr(m), num_folds))
+        self._epi = self._epi[:3] + (num_folds,)
+
+    def epi_counts(self, combs, all_folds=False):
+        c = _np(combs, np.int32)
+        n, order = c.shape
+        cells, k = 3 ** order, self._epi[3]
+        shape = (k, n, cells) if all_folds else (n, cells)
+        aff, unaff = np.zeros(shape, np.int32), np.zeros(shape, np.int32)
+        fn = self.L.hpgv_epi_counts_all_folds if all_folds else self.L.hpgv_epi_counts
+        self._chk(fn(self.h, order, _ptr(c), n, _ptr(aff), _ptr(unaff)))
+        return aff, unaff
+
+    def epi_scan_pairs(self, subset, i_begin=0, i_end=None):
+        i_end = self._epi[0] if i_end is None else i_end
+        n = C.c_ulonglong(0)
+        self._chk(self.L.hpgv_epi_scan_pairs(self.h, i_begin, i_end, subset, None, None, C.byref(n)))
+        k = self._epi[3]
+        acc, mask = np.zeros((k, n.value), np.float64), np.zeros((k, n.value), np.uint16)
+        if n.value:
+            self._chk(self.L.hpgv_epi_scan_pairs(self.h, i_begin, i_end, subset, _ptr(acc), _ptr(mask), C.byref(n)))
+        return acc, mask
+
+    def epi_rank_pairs(self, subset, max_ranking_size):
+        k, n = self._epi[3], max_ranking_size
+        ci, cj = np.zeros((k, n), np.int32), np.zeros((k, n), np.int32)
+        acc, mask, cnt = np.zeros((k, n), np.float64), np.zeros((k, n), np.uint32), np.zeros(k, np.int32)
+        ms = C.c_float(0)
+        self._chk(self.L.hpgv_epi_rank_pairs(self.h, subset, n, _ptr(ci), _ptr(cj), _ptr(acc), _ptr(mask), _ptr(cnt), C.byref(ms)))
+        return dict(i=ci, j=cj, accuracy=acc, risky=mask, n=cnt, scan_ms=ms.value)
 
     def epi_dataset(self, gt):
         gt = _np(gt, np.uint8)

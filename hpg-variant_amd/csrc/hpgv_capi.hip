@@ -6,9 +6,12 @@
 #include "hpgv_kernels.h"
 #include "hpgv_tdt_stats_kernels.h"
 #include "hpgv_text_kernels.h"
+#include "hpgv_epi_kernels.h"
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -36,6 +39,22 @@ struct Slot {
     hipStream_t stream = nullptr;
     void *buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+// epistasis / MDR state: the vcf2epi dataset on the device, its bit planes for the current folds
+struct EpiState {
+    bool have_data = false, have_folds = false;
+    int V = 0, nA = 0, nU = 0, num_folds = 0, W = 0, V_alloc = 0, n_chunks = 0;
+    uint8_t *d_data = nullptr;
+    uint32_t *d_planes = nullptr;
+    hpgv::EpiChunk *d_chunks = nullptr;
+    int32_t *d_group_size = nullptr;
+    uint32_t *d_group_w0 = nullptr;
+    std::vector<int32_t> group_size;
+    hpgv::EpiCand *d_cand = nullptr;
+    unsigned *d_cand_count = nullptr;
+    unsigned cand_cap = 0;
+    double *d_thr = nullptr;
 };
 
 }  // namespace
@@ -93,6 +112,9 @@ struct hpgv_ctx {
     };
     std::mutex tok_mu;
     std::vector<TokScratch *> tok_scratch;
+    // epistasis (calls are serialised by epi_mu)
+    std::mutex epi_mu;
+    EpiState epi;
 };
 
 namespace {
@@ -190,6 +212,9 @@ int launch_profiled(hpgv_ctx *ctx, hipStream_t st, int which /*0 scan,1 stats*/,
 
 }  // namespace
 
+// the epistasis / MDR entry points (declared extern "C" in hpgv.h)
+#include "hpgv_epi_capi.inc"
+
 extern "C" {
 
 const char *hpgv_version(void) { return "hpgv-mi355x 0.1 (gfx950)"; }
@@ -255,6 +280,7 @@ void hpgv_destroy(hpgv_ctx *ctx) {
         delete t;
     }
     ctx->tok_scratch.clear();
+    epi_free(ctx->epi);
     for (Slot *s : ctx->slots) {
         for (int i = 0; i < 8; ++i) if (s->buf[i]) (void)hipFree(s->buf[i]);
         if (s->stream) (void)hipStreamDestroy(s->stream);

@@ -1,0 +1,265 @@
+// hpgv_epi_kernels.h -- CDNA4 (gfx950) kernels of the epistasis / MDR counting path
+// (src/gwas/epistasis/model.c:76-206 combination_counts[_all_folds], mdr.c:45-76,
+// model.c:320-476 test_model / confusion_matrix / evaluate_model, driven per combination by
+// epistasis.c:14-95).
+//
+// Data: the vcf2epi dataset (one row per SNP, cases first, codes 0/1/2, anything else =
+// missing) is turned once into three BIT PLANES per SNP ("genotype is 0 / 1 / 2"), with the
+// samples re-ordered so that every (fold, class) group -- the samples of one class whose
+// TESTING fold is f -- is a contiguous run of whole 32-bit words (runs are padded to 4 words
+// with zero bits, which no plane counts).  The cell counts the reference gets from k passes
+// of byte masks ANDed with k fold masks then come from ONE pass: popcount(plane_i[a] &
+// plane_j[b]) over a group's words is that group's count of cell (a, b); the training counts
+// of fold f are the totals minus the fold's own group.
+//
+// This path is a dense binary contraction (V x V pairs x N samples): VALU bound, 18 integer
+// operations (9 v_and + 9 v_bcnt with accumulate) per pair and 32 samples.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hpgv {
+
+constexpr int EPI_CH = 32;            // words of one LDS chunk (1024 samples)
+constexpr int EPI_ROW = 36;           // LDS row pitch in words: 32 + 4 keeps the 16-B reads of 16 lanes on 16 different slots
+constexpr int EPI_TJ = 64;            // tile: 64 columns (one per lane) ...
+constexpr int EPI_TI = 4;             // ... x 4 rows (one per wave)
+constexpr int EPI_MAX_FOLDS = 16;
+
+struct EpiChunk {
+    uint32_t w0;                      // first word
+    uint16_t nw;                      // words (multiple of 4, <= EPI_CH)
+    int16_t flush;                    // group (fold * 2 + class, class 0 = affected) that ends with this chunk, or -1
+};
+
+struct EpiCand {                      // a model that reached a fold's current threshold
+    double accuracy;
+    int32_t i, j;
+    uint32_t risky;                   // bit c = cell c is high risk
+    uint32_t pad;
+};
+
+// ---------------------------------------------------------------------------
+// dataset rows -> bit planes.  planes[(snp * 3 + g) * W + w]; src_of_pos[p] = dataset column of
+// the sample at bit position p, or -1 for a pad bit.  One workgroup per SNP row (rows >= V are zero).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_epi_planes(const uint8_t *__restrict__ data, int n_variants, int n_samples,
+                                                     const int32_t *__restrict__ src_of_pos, int W,
+                                                     uint32_t *__restrict__ planes) {
+    const int snp = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *out = planes + (size_t)snp * 3 * W;
+    const uint8_t *row = data + (size_t)snp * n_samples;
+    for (int w2 = wave; w2 * 2 < W; w2 += 4) {                       // 64 bit positions per wave step
+        const int p = w2 * 64 + lane;
+        uint32_t g = 255;
+        if (snp < n_variants && p < W * 32) {
+            const int s = src_of_pos[p];
+            if (s >= 0) g = row[s];
+        }
+        const unsigned long long b0 = __ballot(g == 0), b1 = __ballot(g == 1), b2 = __ballot(g == 2);
+        if (lane == 0) {
+            out[0 * W + 2 * w2] = (uint32_t)b0; out[1 * W + 2 * w2] = (uint32_t)b1; out[2 * W + 2 * w2] = (uint32_t)b2;
+            if (2 * w2 + 1 < W) {
+                out[0 * W + 2 * w2 + 1] = (uint32_t)(b0 >> 32); out[1 * W + 2 * w2 + 1] = (uint32_t)(b1 >> 32);
+                out[2 * W + 2 * w2 + 1] = (uint32_t)(b2 >> 32);
+            }
+        }
+    }
+}
+
+// the MDR rule of the runner, mdr_high_risk_combinations2 (mdr.c:45-76): single precision, operation by
+// operation (the library is built with -ffp-contract=off; float division is correctly rounded)
+__device__ __forceinline__ bool mdr_high_risk(int count_aff, int count_unaff, float ratio) {
+    const float ca = (float)count_aff, cu = (float)count_unaff;
+    const float total = ca + cu;
+    const float prop = cu * ratio;
+    const float red = total / (prop + ca);
+    const float norm_unaff = prop * red;
+    const float norm_aff = total - norm_unaff;
+    return norm_aff >= norm_unaff;                                   // an empty cell is 0/0 = NaN: false
+}
+
+// ---------------------------------------------------------------------------
+// listed combinations of 2 or 3 SNPs: in-fold cell counts, out[(comb * n_groups + g) * cells + c]
+// (g = fold * 2 + class).  One wave per combination; utility / parity kernel, not the fast path.
+// ---------------------------------------------------------------------------
+template <int ORDER>
+__global__ void __launch_bounds__(256) k_epi_counts(const uint32_t *__restrict__ planes, int W, const int32_t *__restrict__ combs,
+                                                     int n_combs, const uint32_t *__restrict__ group_w0 /* n_groups + 1 */,
+                                                     int n_groups, int32_t *__restrict__ out) {
+    constexpr int CELLS = ORDER == 2 ? 9 : 27;
+    const int lane = threadIdx.x & 63, comb = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (comb >= n_combs) return;
+    const uint32_t *r0 = planes + (size_t)combs[comb * ORDER] * 3 * W;
+    const uint32_t *r1 = planes + (size_t)combs[comb * ORDER + 1] * 3 * W;
+    const uint32_t *r2 = ORDER == 3 ? planes + (size_t)combs[comb * ORDER + 2] * 3 * W : r1;
+    for (int g = 0; g < n_groups; g++) {
+        int cnt[CELLS];
+        #pragma unroll
+        for (int c = 0; c < CELLS; c++) cnt[c] = 0;
+        for (uint32_t w = group_w0[g] + lane; w < group_w0[g + 1]; w += 64) {
+            #pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const uint32_t x = r0[a * W + w];
+                #pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    const uint32_t xy = x & r1[b * W + w];
+                    if constexpr (ORDER == 2) {
+                        cnt[a * 3 + b] += __popc(xy);
+                    } else {
+                        #pragma unroll
+                        for (int c = 0; c < 3; c++) cnt[(a * 3 + b) * 3 + c] += __popc(xy & r2[c * W + w]);
+                    }
+                }
+            }
+        }
+        #pragma unroll
+        for (int c = 0; c < CELLS; c++) {
+            const int s = wave_sum(cnt[c]);
+            if (lane == 0) out[((size_t)comb * n_groups + g) * CELLS + c] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// every pair (i, j), i < j, of a band of rows: cell counts per (fold, class) group, MDR high-risk cells
+// per fold from the training counts, confusion matrix on the training or the testing part, balanced
+// accuracy.  Workgroup = 4 waves = 4 rows x 64 columns; the planes of the 64 + 4 SNPs stream through LDS
+// in chunks of 32 words (double buffered, one barrier per chunk); every lane keeps its pair's counts in
+// registers: 9 running counts of the current group + K x 9 finished groups, two 16-bit counts per register
+// (affected low, unaffected high: a (fold, class) group holds fewer than 65536 samples).
+// ---------------------------------------------------------------------------
+template <int K, bool TRAINING>
+__global__ void __launch_bounds__(256) k_epi_pairs(const uint32_t *__restrict__ planes, int W, int n_variants, int i_begin, int i_end,
+                                                    const EpiChunk *__restrict__ chunks, int n_chunks,
+                                                    const int32_t *__restrict__ group_size /* K x 2 */, int n_affected, int n_unaffected,
+                                                    double *__restrict__ acc_out, uint16_t *__restrict__ mask_out, unsigned long long n_pairs_out,
+                                                    unsigned long long rank_base,
+                                                    const double *__restrict__ thr, EpiCand *__restrict__ cand,
+                                                    unsigned *__restrict__ cand_count, unsigned cand_cap) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2][(EPI_TJ + EPI_TI) * 3 * EPI_ROW];
+    const int j0 = blockIdx.x * EPI_TJ, i0 = i_begin + blockIdx.y * EPI_TI;
+    if (j0 + EPI_TJ - 1 <= i0) return;                               // the whole tile lies on or below the diagonal
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int i = i0 + wave, j = j0 + lane;
+
+    // ---- staging: piece q = one 16-byte piece of one (snp, plane) row of the chunk ----
+    constexpr int ROWS = (EPI_TJ + EPI_TI) * 3, PIECES = ROWS * (EPI_CH / 4), PER_T = (PIECES + 255) / 256;
+    uint4 stage[PER_T];
+    auto load_chunk = [&](int c) {
+        const uint32_t w0 = chunks[c].w0;
+        const int nw = chunks[c].nw;
+        #pragma unroll
+        for (int r = 0; r < PER_T; r++) {
+            const int q = t + 256 * r, row = q >> 3, piece = q & 7;
+            stage[r] = make_uint4(0, 0, 0, 0);
+            if (row < ROWS && piece * 4 < nw) {
+                const int snp = row < EPI_TJ * 3 ? j0 + row / 3 : i0 + (row - EPI_TJ * 3) / 3;
+                stage[r] = *reinterpret_cast<const uint4 *>(planes + ((size_t)snp * 3 + row % 3) * W + w0 + piece * 4);
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        #pragma unroll
+        for (int r = 0; r < PER_T; r++) {
+            const int q = t + 256 * r, row = q >> 3, piece = q & 7;
+            if (row < ROWS) *reinterpret_cast<uint4 *>(&lds[buf][row * EPI_ROW + piece * 4]) = stage[r];
+        }
+    };
+
+    uint32_t packed[K][9];
+    uint32_t run[9];
+    #pragma unroll
+    for (int f = 0; f < K; f++)
+        #pragma unroll
+        for (int c = 0; c < 9; c++) packed[f][c] = 0;
+    #pragma unroll
+    for (int c = 0; c < 9; c++) run[c] = 0;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; c++) {
+        const int cur = c & 1;
+        if (c + 1 < n_chunks) load_chunk(c + 1);                     // global loads of the next chunk fly during the counting
+        const int nw = chunks[c].nw;
+        const uint32_t *jrow = &lds[cur][lane * 3 * EPI_ROW];
+        const uint32_t *irow = &lds[cur][(EPI_TJ + wave) * 3 * EPI_ROW];
+        for (int s = 0; s < nw; s += 4) {
+            uint4 x[3], y[3];
+            #pragma unroll
+            for (int a = 0; a < 3; a++) {
+                x[a] = *reinterpret_cast<const uint4 *>(irow + a * EPI_ROW + s);     // same address in every lane: broadcast
+                y[a] = *reinterpret_cast<const uint4 *>(jrow + a * EPI_ROW + s);
+            }
+            #pragma unroll
+            for (int a = 0; a < 3; a++)
+                #pragma unroll
+                for (int b = 0; b < 3; b++)
+                    run[a * 3 + b] += __popc(x[a].x & y[b].x) + __popc(x[a].y & y[b].y) + __popc(x[a].z & y[b].z) + __popc(x[a].w & y[b].w);
+        }
+        const int g = chunks[c].flush;                               // wave-uniform
+        if (g >= 0) {
+            const int f = g >> 1, sh = (g & 1) * 16;
+            #pragma unroll
+            for (int ff = 0; ff < K; ff++)
+                if (ff == f) {
+                    #pragma unroll
+                    for (int cc = 0; cc < 9; cc++) packed[ff][cc] += run[cc] << sh;
+                }
+            #pragma unroll
+            for (int cc = 0; cc < 9; cc++) run[cc] = 0;
+        }
+        if (c + 1 < n_chunks) store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+
+    if (i >= i_end || i >= n_variants || j >= n_variants || j <= i) return;
+
+    // ---- per fold: training counts, high-risk cells, confusion matrix, balanced accuracy ----
+    int tot_a[9], tot_u[9];
+    #pragma unroll
+    for (int c = 0; c < 9; c++) { tot_a[c] = 0; tot_u[c] = 0; }
+    #pragma unroll
+    for (int f = 0; f < K; f++)
+        #pragma unroll
+        for (int c = 0; c < 9; c++) { tot_a[c] += (int)(packed[f][c] & 0xFFFFu); tot_u[c] += (int)(packed[f][c] >> 16); }
+    const float ratio = (float)(unsigned)n_affected / (float)(unsigned)n_unaffected;
+    const unsigned long long vi = (unsigned long long)i;
+    const unsigned long long p = vi * (2ull * (unsigned long long)n_variants - vi - 1ull) / 2ull + (unsigned long long)(j - i - 1) - rank_base;
+    #pragma unroll
+    for (int f = 0; f < K; f++) {
+        const int test_a = group_size[2 * f], test_u = group_size[2 * f + 1];
+        if (test_a < 0) continue;                                    // fold beyond the run's num_folds
+        int tp = 0, fp = 0;
+        uint32_t mask = 0;
+        #pragma unroll
+        for (int c = 0; c < 9; c++) {
+            const int in_a = (int)(packed[f][c] & 0xFFFFu), in_u = (int)(packed[f][c] >> 16);
+            const int tr_a = tot_a[c] - in_a, tr_u = tot_u[c] - in_u;
+            if (mdr_high_risk(tr_a, tr_u, ratio)) {
+                mask |= 1u << c;
+                tp += TRAINING ? tr_a : in_a;
+                fp += TRAINING ? tr_u : in_u;
+            }
+        }
+        const int size_a = TRAINING ? n_affected - test_a : test_a, size_u = TRAINING ? n_unaffected - test_u : test_u;
+        // evaluate_model BA (model.c:466-467) on {TP, FN, FP, TN} = {tp, size_a - tp, fp, size_u - fp}
+        const double TP = (double)tp, FN = (double)(size_a - tp), FP = (double)fp, TN = (double)(size_u - fp);
+        const double acc = ((TP / (TP + FN)) + (TN / (TN + FP))) / 2;
+        if (acc_out) {
+            acc_out[(unsigned long long)f * n_pairs_out + p] = acc;
+            mask_out[(unsigned long long)f * n_pairs_out + p] = (uint16_t)mask;
+        }
+        if (cand && acc >= thr[f]) {
+            const unsigned slot = atomicAdd(&cand_count[f], 1u);
+            if (slot < cand_cap) {
+                EpiCand e;
+                e.accuracy = acc; e.i = i; e.j = j; e.risky = mask; e.pad = 0;
+                cand[(size_t)f * cand_cap + slot] = e;
+            }
+        }
+    }
+}
+
+}  // namespace hpgv

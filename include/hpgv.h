@@ -236,6 +236,45 @@ int  hpgv_stats_groups(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_var
  * non-reference, 255 missing.  Uses the cohort of hpgv_set_cohort. */
 int  hpgv_epi_dataset(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, uint8_t *out);
 
+/* ---- epistasis / MDR counting (hpg-var-gwas epi: src/gwas/epistasis/model.c, mdr.c, epistasis.c;
+ *      runner src/gwas/epistasis/singlenode/epistasis_runner.c) -------------------------------------
+ * The input is the vcf2epi dataset (dataset.c:63-76; hpgv_epi_dataset makes its rows): one row per SNP,
+ * n_affected + n_unaffected bytes, cases first, 0 / 1 / 2 = genotype, anything else = missing.  The cell
+ * of a combination of `order` SNPs is numbered with the LAST SNP varying fastest
+ * (get_genotype_combinations, dataset.c:170-200): order 2 -> cell = g_i * 3 + g_j. */
+enum { HPGV_EPI_TESTING = 0, HPGV_EPI_TRAINING = 1 };                 /* enum evaluation_subset, model.h:73 */
+
+/* copies the dataset to the device; until folds are given all samples form one fold */
+int  hpgv_epi_set_dataset(hpgv_ctx *ctx, const uint8_t *genotypes, int n_variants, int n_affected, int n_unaffected);
+/* k-fold cross-validation: fold_of_sample[s] in [0, num_folds) = the fold whose TESTING part holds sample s
+ * (get_k_folds, cross_validation.c:16-100); num_folds <= 16, fewer than 65536 samples per class and fold */
+int  hpgv_epi_set_folds(hpgv_ctx *ctx, const int32_t *fold_of_sample, int num_folds);
+/* the same from the reference's own mask array (get_k_folds_masks, cross_validation.c:247-281):
+ * num_folds x num_samples_with_padding bytes, 1 = training part, both classes padded to 16.  Masks that
+ * are not a partition (a sample left out of no fold, or of two) are refused with HPGV_ERR_UNSUPPORTED. */
+int  hpgv_epi_set_fold_masks(hpgv_ctx *ctx, const uint8_t *fold_masks, int num_folds);
+/* combination_counts (model.c:76-124) of listed combinations (order 2 or 3; combs = n_combs x order SNP
+ * indices): counts_*[comb * cells + cell] */
+int  hpgv_epi_counts(hpgv_ctx *ctx, int order, const int32_t *combs, int n_combs,
+                     int32_t *counts_aff, int32_t *counts_unaff);
+/* combination_counts_all_folds (model.c:126-206), the reference's layout for n_combs combinations in a
+ * row: counts_*[(fold * n_combs + comb) * cells + cell] = count over the TRAINING part of the fold */
+int  hpgv_epi_counts_all_folds(hpgv_ctx *ctx, int order, const int32_t *combs, int n_combs,
+                               int32_t *counts_aff, int32_t *counts_unaff);
+/* process_set_of_combinations (epistasis.c:14-95) for every pair (i, j), i_begin <= i < i_end, i < j:
+ * per fold the MDR high-risk cells (mdr_high_risk_combinations2 on the training counts), the confusion
+ * matrix on `subset` and the balanced accuracy (test_model, model.c:320-335).  Outputs, pairs in
+ * lexicographic order: accuracy[fold * *n_pairs + p], risky_mask[...] (bit c = cell c is high risk).
+ * Call with accuracy = risky_mask = NULL to get *n_pairs only. */
+int  hpgv_epi_scan_pairs(hpgv_ctx *ctx, int i_begin, int i_end, int subset, double *accuracy,
+                         uint16_t *risky_mask, unsigned long long *n_pairs);
+/* the whole scan with the per-fold ranking of the runner (add_to_model_ranking, model.c:478-517; ties:
+ * higher accuracy, then smaller (i, j)): for every fold the best max_ranking_size pairs,
+ * out[fold * max_ranking_size + k], n_ranked[fold] of them.  *scan_ms (may be NULL) = device time of
+ * the scan kernels. */
+int  hpgv_epi_rank_pairs(hpgv_ctx *ctx, int subset, int max_ranking_size, int32_t *comb_i, int32_t *comb_j,
+                         double *accuracy, uint32_t *risky_mask, int32_t *n_ranked, float *scan_ms);
+
 /* Mendelian errors of a host batch: errors[v] per variant (may be NULL) and child_errors[t] per trio of
  * hpgv_set_pedigree, ACCUMULATED into (may be NULL) */
 int  hpgv_mendel(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, const uint8_t *is_x,
