@@ -48,13 +48,15 @@ struct EpiState {
     uint8_t *d_data = nullptr;
     uint32_t *d_planes = nullptr;
     hpgv::EpiChunk *d_chunks = nullptr;
-    int32_t *d_group_size = nullptr;
+    hpgv::EpiFold *d_folds = nullptr;
     uint32_t *d_group_w0 = nullptr;
     std::vector<int32_t> group_size;
     hpgv::EpiCand *d_cand = nullptr;
     unsigned *d_cand_count = nullptr;
     unsigned cand_cap = 0;
     double *d_thr = nullptr;
+    unsigned *d_tile_base = nullptr;
+    size_t tile_base_cap = 0;
 };
 
 }  // namespace

@@ -26,10 +26,16 @@ constexpr int EPI_TJ = 64;            // tile: 64 columns (one per lane) ...
 constexpr int EPI_TI = 4;             // ... x 4 rows (one per wave)
 constexpr int EPI_MAX_FOLDS = 16;
 
-struct EpiChunk {
+struct EpiChunk {                     // one staging block: up to EPI_CH consecutive words, possibly of several groups
     uint32_t w0;                      // first word
-    uint16_t nw;                      // words (multiple of 4, <= EPI_CH)
-    int16_t flush;                    // group (fold * 2 + class, class 0 = affected) that ends with this chunk, or -1
+    uint32_t nw;                      // words (multiple of 8, <= EPI_CH)
+    uint64_t flush;                   // byte s = the group (fold * 2 + class, class 0 = affected) that ends with the
+                                      // block's 4-word step s, or 0xFF when no group ends there
+};
+
+struct EpiFold {                      // per fold constants of the evaluation
+    int32_t test_a, test_u;           // samples of the fold's testing part (affected, unaffected); test_a < 0: fold unused
+    double inv_a, inv_u;              // RN(1 / size) of the evaluated part, for the two divisions of the balanced accuracy
 };
 
 struct EpiCand {                      // a model that reached a fold's current threshold
@@ -67,16 +73,42 @@ __global__ void __launch_bounds__(256) k_epi_planes(const uint8_t *__restrict__ 
     }
 }
 
+// acc + popcount(x) in ONE instruction (v_bcnt_u32_b32 has an accumulator operand; written as a sum of four
+// popcounts the compiler emits four v_bcnt + two v_add3 instead)
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
 // the MDR rule of the runner, mdr_high_risk_combinations2 (mdr.c:45-76): single precision, operation by
 // operation (the library is built with -ffp-contract=off; float division is correctly rounded)
-__device__ __forceinline__ bool mdr_high_risk(int count_aff, int count_unaff, float ratio) {
-    const float ca = (float)count_aff, cu = (float)count_unaff;
+__device__ __forceinline__ bool mdr_high_risk_exact(float ca, float cu, float ratio) {
     const float total = ca + cu;
     const float prop = cu * ratio;
     const float red = total / (prop + ca);
     const float norm_unaff = prop * red;
     const float norm_aff = total - norm_unaff;
     return norm_aff >= norm_unaff;                                   // an empty cell is 0/0 = NaN: false
+}
+
+// The same decision without the division wherever it is safe.  In exact arithmetic the rule is
+// count_aff * num_unaffected >= count_unaff * num_affected (norm_aff - norm_unaff = total * d / s with
+// d = ca*nU - cu*nA, s = ca*nU + cu*nA); the six float operations above move norm_aff - norm_unaff by less than
+// 2^-20 * total, so when |d| > 2^-16 * s the sign of d decides.  Cells closer to the boundary (ties included, and
+// the empty cell) take the exact sequence.  With num_affected == num_unaffected the sequence is exact for counts
+// below 2^23 (ratio = 1, red = 1) and reduces to count_aff >= count_unaff on a non-empty cell.
+template <bool BALANCED>
+__device__ __forceinline__ bool mdr_high_risk(int count_aff, int count_unaff, float ratio, float f_na, float f_nu) {
+    if constexpr (BALANCED) {
+        return (count_aff >= count_unaff) & ((count_aff | count_unaff) != 0);
+    } else {
+        const float ca = (float)count_aff, cu = (float)count_unaff;
+        const float p1 = ca * f_nu, p2 = cu * f_na;
+        const float d = p1 - p2, tol = (p1 + p2) * 0x1p-16f;
+        if (__builtin_fabsf(d) > tol) return d > 0.0f;
+        return mdr_high_risk_exact(ca, cu, ratio);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -129,17 +161,24 @@ __global__ void __launch_bounds__(256) k_epi_counts(const uint32_t *__restrict__
 // registers: 9 running counts of the current group + K x 9 finished groups, two 16-bit counts per register
 // (affected low, unaffected high: a (fold, class) group holds fewer than 65536 samples).
 // ---------------------------------------------------------------------------
-template <int K, bool TRAINING>
-__global__ void __launch_bounds__(256) k_epi_pairs(const uint32_t *__restrict__ planes, int W, int n_variants, int i_begin, int i_end,
+template <int K, bool TRAINING, bool BALANCED>
+__global__ void __launch_bounds__(256) k_epi_pairs(const uint32_t *__restrict__ planes, int W, int n_variants, int i_begin, int i_first, int i_end,
+                                                    const unsigned *__restrict__ tile_base, int n_q, int tiles_j,
                                                     const EpiChunk *__restrict__ chunks, int n_chunks,
-                                                    const int32_t *__restrict__ group_size /* K x 2 */, int n_affected, int n_unaffected,
+                                                    const EpiFold *__restrict__ folds /* K */, int n_affected, int n_unaffected,
                                                     double *__restrict__ acc_out, uint16_t *__restrict__ mask_out, unsigned long long n_pairs_out,
                                                     unsigned long long rank_base,
                                                     const double *__restrict__ thr, EpiCand *__restrict__ cand,
                                                     unsigned *__restrict__ cand_count, unsigned cand_cap) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[2][(EPI_TJ + EPI_TI) * 3 * EPI_ROW];
-    const int j0 = blockIdx.x * EPI_TJ, i0 = i_begin + blockIdx.y * EPI_TI;
-    if (j0 + EPI_TJ - 1 <= i0) return;                               // the whole tile lies on or below the diagonal
+    // blockIdx.x numbers the tiles that hold at least one pair: row block ti = blockIdx.x / tiles_j owns the column
+    // tiles from its diagonal tile on; tile_base[q] = tiles before the 16 row blocks whose rows start at 64 * q
+    // relative to i_begin (i_begin is a multiple of 64), found by bisection
+    int q_lo = 0, q_hi = n_q;
+    while (q_hi - q_lo > 1) { const int mid = (q_lo + q_hi) >> 1; if (tile_base[mid] <= blockIdx.x) q_lo = mid; else q_hi = mid; }
+    const int tj_min = (i_begin >> 6) + q_lo, per_row = tiles_j - tj_min;
+    const int rem = (int)(blockIdx.x - tile_base[q_lo]);
+    const int j0 = (tj_min + rem % per_row) * EPI_TJ, i0 = i_begin + (q_lo * 16 + rem / per_row) * EPI_TI;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int i = i0 + wave, j = j0 + lane;
 
@@ -148,7 +187,7 @@ __global__ void __launch_bounds__(256) k_epi_pairs(const uint32_t *__restrict__ 
     uint4 stage[PER_T];
     auto load_chunk = [&](int c) {
         const uint32_t w0 = chunks[c].w0;
-        const int nw = chunks[c].nw;
+        const int nw = (int)chunks[c].nw;
         #pragma unroll
         for (int r = 0; r < PER_T; r++) {
             const int q = t + 256 * r, row = q >> 3, piece = q & 7;
@@ -182,39 +221,49 @@ __global__ void __launch_bounds__(256) k_epi_pairs(const uint32_t *__restrict__ 
     for (int c = 0; c < n_chunks; c++) {
         const int cur = c & 1;
         if (c + 1 < n_chunks) load_chunk(c + 1);                     // global loads of the next chunk fly during the counting
-        const int nw = chunks[c].nw;
+        const int nw = (int)chunks[c].nw;
+        const uint64_t flush = chunks[c].flush;                      // wave-uniform
         const uint32_t *jrow = &lds[cur][lane * 3 * EPI_ROW];
-        const uint32_t *irow = &lds[cur][(EPI_TJ + wave) * 3 * EPI_ROW];
-        for (int s = 0; s < nw; s += 4) {
-            uint4 x[3], y[3];
-            #pragma unroll
-            for (int a = 0; a < 3; a++) {
-                x[a] = *reinterpret_cast<const uint4 *>(irow + a * EPI_ROW + s);     // same address in every lane: broadcast
-                y[a] = *reinterpret_cast<const uint4 *>(jrow + a * EPI_ROW + s);
-            }
-            #pragma unroll
-            for (int a = 0; a < 3; a++)
-                #pragma unroll
-                for (int b = 0; b < 3; b++)
-                    run[a * 3 + b] += __popc(x[a].x & y[b].x) + __popc(x[a].y & y[b].y) + __popc(x[a].z & y[b].z) + __popc(x[a].w & y[b].w);
+        const uint32_t *irow = &lds[cur][(EPI_TJ + wave) * 3 * EPI_ROW];   // the wave's own row: same address in every lane (broadcast)
+        uint4 xa[3], ya[3], xb[3], yb[3];
+#define HPGV_EPI_FETCH(X, Y, S)                                                                          \
+        _Pragma("unroll") for (int a = 0; a < 3; a++) {                                                  \
+            X[a] = *reinterpret_cast<const uint4 *>(irow + a * EPI_ROW + (S));                           \
+            Y[a] = *reinterpret_cast<const uint4 *>(jrow + a * EPI_ROW + (S));                           \
         }
-        const int g = chunks[c].flush;                               // wave-uniform
-        if (g >= 0) {
-            const int f = g >> 1, sh = (g & 1) * 16;
-            #pragma unroll
-            for (int ff = 0; ff < K; ff++)
-                if (ff == f) {
-                    #pragma unroll
-                    for (int cc = 0; cc < 9; cc++) packed[ff][cc] += run[cc] << sh;
-                }
-            #pragma unroll
-            for (int cc = 0; cc < 9; cc++) run[cc] = 0;
+#define HPGV_EPI_COUNT(X, Y, S)                                                                          \
+        _Pragma("unroll") for (int a = 0; a < 3; a++)                                                    \
+            _Pragma("unroll") for (int b = 0; b < 3; b++) {                                              \
+                uint32_t r = run[a * 3 + b];                                                             \
+                r = bcnt_acc(X[a].x & Y[b].x, r); r = bcnt_acc(X[a].y & Y[b].y, r);                      \
+                r = bcnt_acc(X[a].z & Y[b].z, r); r = bcnt_acc(X[a].w & Y[b].w, r);                      \
+                run[a * 3 + b] = r;                                                                      \
+            }                                                                                            \
+        {                                                                                                \
+            const int g = (int)((flush >> (2 * (S))) & 0xFFu);       /* byte S / 4 */                    \
+            if (g != 0xFF) {                 /* a (fold, class) group ends here: bank its nine counts */ \
+                const int f = g >> 1, sh = (g & 1) * 16;                                                 \
+                _Pragma("unroll") for (int ff = 0; ff < K; ff++)                                         \
+                    if (ff == f) {                                                                       \
+                        _Pragma("unroll") for (int cc = 0; cc < 9; cc++) packed[ff][cc] += run[cc] << sh; \
+                    }                                                                                    \
+                _Pragma("unroll") for (int cc = 0; cc < 9; cc++) run[cc] = 0;                            \
+            }                                                                                            \
         }
+        HPGV_EPI_FETCH(xa, ya, 0)
+        for (int s = 0; s < nw; s += 8) {
+            HPGV_EPI_FETCH(xb, yb, s + 4)
+            HPGV_EPI_COUNT(xa, ya, s)
+            if (s + 8 < nw) { HPGV_EPI_FETCH(xa, ya, s + 8) }
+            HPGV_EPI_COUNT(xb, yb, s + 4)
+        }
+#undef HPGV_EPI_FETCH
+#undef HPGV_EPI_COUNT
         if (c + 1 < n_chunks) store_chunk(cur ^ 1);
         __syncthreads();
     }
 
-    if (i >= i_end || i >= n_variants || j >= n_variants || j <= i) return;
+    if (i < i_first || i >= i_end || i >= n_variants || j >= n_variants || j <= i) return;
 
     // ---- per fold: training counts, high-risk cells, confusion matrix, balanced accuracy ----
     int tot_a[9], tot_u[9];
@@ -224,29 +273,36 @@ __global__ void __launch_bounds__(256) k_epi_pairs(const uint32_t *__restrict__ 
     for (int f = 0; f < K; f++)
         #pragma unroll
         for (int c = 0; c < 9; c++) { tot_a[c] += (int)(packed[f][c] & 0xFFFFu); tot_u[c] += (int)(packed[f][c] >> 16); }
-    const float ratio = (float)(unsigned)n_affected / (float)(unsigned)n_unaffected;
+    const float f_na = (float)(unsigned)n_affected, f_nu = (float)(unsigned)n_unaffected;
+    const float ratio = f_na / f_nu;
     const unsigned long long vi = (unsigned long long)i;
     const unsigned long long p = vi * (2ull * (unsigned long long)n_variants - vi - 1ull) / 2ull + (unsigned long long)(j - i - 1) - rank_base;
     #pragma unroll
     for (int f = 0; f < K; f++) {
-        const int test_a = group_size[2 * f], test_u = group_size[2 * f + 1];
-        if (test_a < 0) continue;                                    // fold beyond the run's num_folds
+        const EpiFold fo = folds[f];
+        if (fo.test_a < 0) continue;                                 // fold beyond the run's num_folds
         int tp = 0, fp = 0;
         uint32_t mask = 0;
         #pragma unroll
         for (int c = 0; c < 9; c++) {
             const int in_a = (int)(packed[f][c] & 0xFFFFu), in_u = (int)(packed[f][c] >> 16);
             const int tr_a = tot_a[c] - in_a, tr_u = tot_u[c] - in_u;
-            if (mdr_high_risk(tr_a, tr_u, ratio)) {
+            if (mdr_high_risk<BALANCED>(tr_a, tr_u, ratio, f_na, f_nu)) {
                 mask |= 1u << c;
                 tp += TRAINING ? tr_a : in_a;
                 fp += TRAINING ? tr_u : in_u;
             }
         }
-        const int size_a = TRAINING ? n_affected - test_a : test_a, size_u = TRAINING ? n_unaffected - test_u : test_u;
-        // evaluate_model BA (model.c:466-467) on {TP, FN, FP, TN} = {tp, size_a - tp, fp, size_u - fp}
-        const double TP = (double)tp, FN = (double)(size_a - tp), FP = (double)fp, TN = (double)(size_u - fp);
-        const double acc = ((TP / (TP + FN)) + (TN / (TN + FP))) / 2;
+        const int size_a = TRAINING ? n_affected - fo.test_a : fo.test_a, size_u = TRAINING ? n_unaffected - fo.test_u : fo.test_u;
+        // evaluate_model BA (model.c:466-467) on {TP, FN, FP, TN} = {tp, size_a - tp, fp, size_u - fp}:
+        // ((TP / (TP + FN)) + (TN / (TN + FP))) / 2 with TP + FN = size_a, TN + FP = size_u.  Each quotient x / y is
+        // formed as q = x * r, q' = fma(fma(-q, y, x), r, q) with r = RN(1 / y) from the host: the correctly rounded
+        // quotient (Markstein), i.e. the very double the division gives; y = 0 gives 0 * inf = NaN like 0 / 0.
+        const double TP = (double)tp, TN = (double)(size_u - fp), ya = (double)size_a, yu = (double)size_u;
+        double qa = TP * fo.inv_a, qu = TN * fo.inv_u;
+        qa = __builtin_fma(__builtin_fma(-qa, ya, TP), fo.inv_a, qa);
+        qu = __builtin_fma(__builtin_fma(-qu, yu, TN), fo.inv_u, qu);
+        const double acc = (qa + qu) / 2;
         if (acc_out) {
             acc_out[(unsigned long long)f * n_pairs_out + p] = acc;
             mask_out[(unsigned long long)f * n_pairs_out + p] = (uint16_t)mask;

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Throughput of the epistasis / MDR pair scan (hpgv_epi_rank_pairs): all V(V-1)/2 pairs x N samples x k folds.
+Bound: VALU integer issue -- 18 operations (9 v_and_b32 + 9 v_bcnt_u32_b32) per pair and 32 samples; peak =
+256 CUs x 64 lanes x clock.  Diagnostic tool (not the headline metric).
+
+  python tools/bench_epistasis.py [V] [N] [k] [--cpu]
+"""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+hpgv = importlib.import_module("hpg-variant_amd")
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+V = int(args[0]) if len(args) > 0 else 4096
+N = int(args[1]) if len(args) > 1 else 10000
+K = int(args[2]) if len(args) > 2 else 10
+CLOCK_GHZ = 2.4
+rng = np.random.default_rng(1)
+nA = nU = N // 2
+data = rng.choice(np.array([0, 1, 2, 255], np.uint8), size=(V, nA + nU), p=[0.5, 0.35, 0.14, 0.01])
+fold = np.empty(nA + nU, np.int32)
+fold[rng.permutation(nA)] = np.arange(nA) % K
+fold[nA + rng.permutation(nU)] = np.arange(nU) % K
+e = hpgv.Engine(0)
+t0 = time.perf_counter()
+e.epi_set_dataset(data, nA, nU)
+e.epi_set_folds(fold, K)
+t_setup = time.perf_counter() - t0
+e.epi_rank_pairs(hpgv.EPI_TESTING, 10)                        # warm
+runs = []
+for _ in range(3):
+    t0 = time.perf_counter()
+    res = e.epi_rank_pairs(hpgv.EPI_TESTING, 10)
+    runs.append((time.perf_counter() - t0, res["scan_ms"]))
+wall, scan_ms = min(runs)
+pairs = V * (V - 1) // 2
+words = -(-(N // (2 * K)) // 128) * 4 * 2 * K                 # words per row after padding every (fold, class) run to 4 words
+ops = pairs * words * 18
+out = {"V": V, "samples": N, "folds": K, "pairs": pairs, "setup_s": round(t_setup, 3), "wall_s": round(wall, 4), "scan_ms": round(scan_ms, 3),
+       "pairs_per_s": pairs / (scan_ms * 1e-3), "pair_samples_per_s": pairs * N / (scan_ms * 1e-3),
+       "valu_lane_ops_per_s": ops * 32 / (scan_ms * 1e-3) / 32 * 1.0,
+       "roofline": {"bound": "valu", "achieved_Tops": ops / (scan_ms * 1e-3) / 1e12 * 64 / 64,
+                    "peak_Tops": 256 * 4 * CLOCK_GHZ * 1e9 / 4 / 1e12 * 4, "unit": "T wave-instructions x 64 lanes /s"}}
+# peak: each SIMD issues one wave64 VALU instruction per 4 cycles: 256 CUs x 4 SIMDs x 2.4e9 / 4 = 614 G wave-instr/s
+peak_wave_instr = 256 * 4 * CLOCK_GHZ * 1e9 / 4
+wave_instr = ops / 64
+out["roofline"] = {"bound": "valu", "achieved": wave_instr / (scan_ms * 1e-3) / 1e9, "peak": peak_wave_instr / 1e9,
+                   "unit": "G wave64 VALU instructions/s", "frac": wave_instr / (scan_ms * 1e-3) / peak_wave_instr,
+                   "algorithmic_ops_per_pair_word": 18}
+del out["valu_lane_ops_per_s"]
+if "--cpu" in sys.argv:
+    from oracle import pyoracle as orc
+    vs = 48
+    masks = orc.fold_masks_from_assignment(fold, K)
+    t0 = time.perf_counter()
+    orc.epi_scan_pairs(data[:vs], nA, nU, masks, 0)
+    dt = time.perf_counter() - t0
+    out["cpu_baseline"] = {"value": vs * (vs - 1) // 2 / dt, "unit": "pairs/s", "kind": "port", "cores": os.cpu_count(),
+                           "sample": "oracle scan of the first %d SNPs (%d pairs) x %d samples x %d folds, OpenMP over rows, %.1f s" % (vs, vs * (vs - 1) // 2, N, K, dt)}
+print(json.dumps(out))
+e.close()
