@@ -280,6 +280,18 @@ int  hpgv_run_tdt(const char *vcf_path, const char *ped_path, const char *out_pa
  * HPGV_RUN_TRACE=1 prints the same numbers to stderr. */
 void hpgv_host_last_run_times(double *seconds6);
 
+/* ---- epistasis (hpg-var-gwas epi): k-fold cross-validation helpers and the run over a vcf2epi dataset ------ */
+/* cross_validation.c:16-100 and :247-281, same signatures; the shuffle uses rand() */
+int **get_k_folds(unsigned int num_samples_affected, unsigned int num_samples_unaffected, unsigned int k,
+                  unsigned int **sizes);
+uint8_t *get_k_folds_masks(unsigned int num_samples_affected, unsigned int num_samples_unaffected, unsigned int k,
+                           int **folds, unsigned int *sizes);
+/* run_epistasis (singlenode/epistasis_runner.c:23-330) for pairs of SNPs: dataset file in, one report
+ * <out_prefix>.cv<r>.epi per repetition out (epistasis_report.c:30-81).  eval_subset HPGV_EPI_TESTING /
+ * HPGV_EPI_TRAINING; eval_mode 0 = CV-c (consistency), 1 = CV-a (accuracy). */
+int  hpgv_run_epistasis(const char *dataset_path, int num_folds, int num_cv_repetitions, int max_ranking_size,
+                        int eval_subset, int eval_mode, const char *out_prefix);
+
 /* The runners' reader on its own: copies `in_path` (plain / gzip / BGZF) to `out_path` in the whole-line
  * batches (at most batch_bytes each) the runners hand to the engine, optionally after consuming the VCF
  * header as the runners do; *n_batches may be NULL. */

@@ -12,6 +12,7 @@ tests/helpers strip it with the group sizes.
   test/test_epistasis_model.c:434-519   test_get_confusion_matrix_excluding_samples
   test/test_epistasis_model.c:522-543   test_model_evaluation_formulas
   test/test_mdr.c:33-65                 test_get_high_risk_combinations{,2}
+  test/test_cross_validation.c:36-283   test_get_k_folds (fold sizes; mask layout asserted structurally)
 """
 import json
 import os
@@ -102,6 +103,28 @@ kat["mdr_high_risk"] = {
     # test_get_high_risk_combinations2 (what the runner uses)
     "vector": {"aff": [8, 4, 9, 8, 4], "unaff": [40, 75, 20, 63, 40], "risky": [True, False, True, True, False]},
 }
+
+# ---- get_k_folds: fold sizes (samples, affected, unaffected), test/test_cross_validation.c:36-283 ------
+def _sizes(*runs):
+    out = []
+    for n, triple in runs:
+        out += [list(triple)] * n
+    return out
+
+
+kat["k_folds"] = [
+    {"num_affected": 200, "num_unaffected": 200, "k": 10, "sizes": _sizes((10, (40, 20, 20)))},
+    {"num_affected": 150, "num_unaffected": 250, "k": 4, "sizes": _sizes((2, (101, 38, 63)), (2, (99, 37, 62)))},
+    {"num_affected": 150, "num_unaffected": 250, "k": 10, "sizes": _sizes((10, (40, 15, 25)))},
+    {"num_affected": 50, "num_unaffected": 75, "k": 5, "sizes": _sizes((5, (25, 10, 15)))},
+    {"num_affected": 50, "num_unaffected": 75, "k": 7, "sizes": _sizes((1, (19, 8, 11)), (4, (18, 7, 11)), (2, (17, 7, 10)))},
+    {"num_affected": 50, "num_unaffected": 75, "k": 10, "sizes": _sizes((5, (13, 5, 8)), (5, (12, 5, 7)))},
+    {"num_affected": 8, "num_unaffected": 12, "k": 8, "sizes": _sizes((4, (3, 1, 2)), (4, (2, 1, 1)))},
+    # the test leaves fold 8 of this case unchecked (its loop starts at 9); None = not asserted by the reference
+    {"num_affected": 8, "num_unaffected": 12, "k": 10, "sizes": _sizes((2, (3, 1, 2)), (6, (2, 1, 1))) + [None, [1, 0, 1]]},
+    {"num_affected": 16, "num_unaffected": 4, "k": 5, "sizes": [[5, 4, 1], [4, 3, 1], [4, 3, 1], [4, 3, 1], [3, 3, 0]]},
+    {"num_affected": 16, "num_unaffected": 4, "k": 10, "sizes": _sizes((4, (3, 2, 1)), (2, (2, 2, 0)), (4, (1, 1, 0)))},
+]
 
 path = os.path.join(HERE, "reference_kats.json")
 d = json.load(open(path))

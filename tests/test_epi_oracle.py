@@ -129,3 +129,41 @@ def test_model_matrices_consistent_with_counts():
             fp = sum(int(tot_u[c] - unaff[f][c]) for c in cells)
             assert (int(mat[f][0]), int(mat[f][2])) == (tp, fp)
             assert int(mat[f][0] + mat[f][1]) == int(((fold == f) & (np.arange(nA + nU) < nA)).sum())
+
+
+def test_k_folds_reference_kat_and_mask_layout(kat):
+    """get_k_folds / get_k_folds_masks of the host mirror (cross_validation.c:16-100,247-281): the fold sizes the
+    reference's test pins, cases and controls never mixed, the padded mask layout (test_cross_validation.c:36-283,
+    664-716).  Pure host code: no engine call."""
+    import ctypes as C
+    from importlib import import_module
+    b = import_module("hpg-variant_amd._build")
+    L = C.CDLL(b.HOSTLIB)
+    L.get_k_folds.restype = C.POINTER(C.POINTER(C.c_int))
+    L.get_k_folds.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.POINTER(C.c_uint))]
+    L.get_k_folds_masks.restype = C.POINTER(C.c_uint8)
+    L.get_k_folds_masks.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.POINTER(C.c_int)), C.POINTER(C.c_uint)]
+    libc = C.CDLL(None)
+    libc.srand(12345)
+    for case in kat["k_folds"]:
+        nA, nU, k = case["num_affected"], case["num_unaffected"], case["k"]
+        sizes = C.POINTER(C.c_uint)()
+        folds = L.get_k_folds(nA, nU, k, C.byref(sizes))
+        seen = []
+        for f, exp in enumerate(case["sizes"]):
+            got = [sizes[3 * f], sizes[3 * f + 1], sizes[3 * f + 2]]
+            assert exp is None or got == exp, (nA, nU, k, f, got)
+            members = [folds[f][j] for j in range(got[0])]
+            assert members == sorted(members)
+            assert all(m < nA for m in members[: got[1]]) and all(m >= nA for m in members[got[1]:])
+            seen += members
+        assert sorted(seen) == list(range(nA + nU))                  # a partition of the cohort
+        pa, pu = -(-nA // 16) * 16, -(-nU // 16) * 16
+        m = L.get_k_folds_masks(nA, nU, k, folds, sizes)
+        masks = np.ctypeslib.as_array(m, shape=(k, pa + pu)).copy()
+        assert (masks[:, nA:pa] == 0).all() and (masks[:, pa + nU:] == 0).all()          # both paddings are 0
+        real = np.concatenate([masks[:, :nA], masks[:, pa: pa + nU]], axis=1)
+        assert ((real == 0).sum(axis=0) == 1).all()                  # every sample is left out of exactly one fold
+        for f in range(k):
+            out = set(np.flatnonzero(real[f] == 0).tolist())
+            assert out == set(folds[f][j] for j in range(sizes[3 * f]))

@@ -94,6 +94,29 @@ def test_pair_scan_matches_the_oracle(eng, v, nA, nU, k):
         assert _same(a2, acc[:, lo: lo + a2.shape[1]]) and np.array_equal(m2, rm[:, lo: lo + a2.shape[1]])
 
 
+@pytest.mark.parametrize("nA,nU", [(1000, 3000), (333, 999), (1200, 800), (77, 770)])
+def test_mdr_rule_on_cells_at_the_boundary(eng, nA, nU):
+    # rare genotypes give many small cells whose counts sit exactly on (or one sample off) the cohort's case/control
+    # ratio: the division-free form of the rule must decide them as the reference's float sequence does
+    rng = np.random.default_rng(nA + nU)
+    v, k = 60, 4
+    codes = np.array([0, 1, 2, 255], np.uint8)
+    data = codes[rng.choice(4, size=(v, nA + nU), p=[0.93, 0.05, 0.015, 0.005])]
+    fold = epi_random_folds(rng, nA, nU, k)
+    eng.epi_set_dataset(data, nA, nU)
+    eng.epi_set_folds(fold, k)
+    masks = orc.fold_masks_from_assignment(fold, k)
+    acc, rm = eng.epi_scan_pairs(hpgv.EPI_TESTING)
+    eacc, erm = orc.epi_scan_pairs(data, nA, nU, masks, 0)
+    assert np.array_equal(rm, erm.astype(np.uint16)) and _same(acc, eacc)
+    # the data does hold exact ties: some cell of some pair has count_aff * nU == count_unaff * nA (non-empty)
+    ties = 0
+    for i, j in [(0, 1), (2, 3), (4, 5), (6, 7), (8, 9), (10, 11)]:
+        fa, fu = orc.epi_counts_all_folds([data[i], data[j]], nA, nU, masks)
+        ties += int(((fa * nU == fu * nA) & (fa + fu > 0)).sum())
+    assert ties > 0
+
+
 def test_counts_against_the_oracle_order_2_and_3(eng):
     rng = np.random.default_rng(99)
     v, nA, nU, k = 25, 333, 401, 7
@@ -149,3 +172,63 @@ def test_epistasis_error_paths(eng):
     with pytest.raises(hpgv.HpgvError):
         e.epi_counts(np.array([[0, 4]], np.int32))                   # SNP index outside the dataset
     e.close()
+
+
+def test_run_epistasis_from_a_dataset_file(tmp_path):
+    """hpgv_run_epistasis (run_epistasis, singlenode/epistasis_runner.c): dataset file in, report out; the expected
+    report is rebuilt from the oracle's scan with the same folds (same rand() stream)."""
+    import ctypes as C
+    import struct
+    from importlib import import_module
+    b = import_module("hpg-variant_amd._build")
+    L = C.CDLL(b.HOSTLIB)
+    L.get_k_folds.restype = C.POINTER(C.POINTER(C.c_int))
+    L.get_k_folds.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.POINTER(C.c_uint))]
+    L.hpgv_run_epistasis.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    L.hpgv_host_last_error.restype = C.c_char_p
+    libc = C.CDLL(None)
+    rng = np.random.default_rng(23)
+    v, nA, nU, k, n, reps = 45, 90, 110, 5, 8, 2
+    data = epi_random_dataset(rng, v, nA, nU)
+    data[3, :nA] = rng.choice([1, 2], size=nA); data[30, :nA] = rng.choice([1, 2], size=nA)
+    path = tmp_path / "epi.bin"
+    with open(path, "wb") as f:                                      # dataset.c:63-76
+        f.write(struct.pack("<III", v, nA, nU)); f.write(data.tobytes())
+    # the folds the run will deal: same seed, same calls
+    libc.srand(777)
+    folds_per_rep = []
+    for _ in range(reps):
+        sizes = C.POINTER(C.c_uint)()
+        folds = L.get_k_folds(nA, nU, k, C.byref(sizes))
+        fold_of = np.empty(nA + nU, np.int32)
+        for f in range(k):
+            for j in range(sizes[3 * f]):
+                fold_of[folds[f][j]] = f
+        folds_per_rep.append(fold_of)
+    pairs = [(i, j) for i in range(v) for j in range(i + 1, v)]
+    for mode in (1, 0):
+        libc.srand(777)
+        prefix = str(tmp_path / ("out%d" % mode))
+        rc = L.hpgv_run_epistasis(str(path).encode(), k, reps, n, hpgv.EPI_TESTING, mode, prefix.encode())
+        assert rc == 0, L.hpgv_host_last_error()
+        for r in range(reps):
+            masks = orc.fold_masks_from_assignment(folds_per_rep[r], k)
+            acc, rm = orc.epi_scan_pairs(data, nA, nU, masks, 0)
+            merged = {}
+            for f in range(k):
+                a = np.where(np.isnan(acc[f]), -np.inf, acc[f])
+                for p in sorted(range(len(pairs)), key=lambda q: (-a[q], pairs[q]))[:n]:
+                    e = merged.setdefault(pairs[p], [0.0, 0, int(rm[f][p])])
+                    e[0] += acc[f][p]; e[1] += 1
+            rows = [(pr, s / k, c, m) for pr, (s, c, m) in merged.items()]
+            rows.sort(key=(lambda t: (-t[1], t[0])) if mode == 1 else (lambda t: (-t[2], -t[1], t[0])))
+            lines = open("%s.cv%d.epi" % (prefix, r + 1)).read().splitlines()
+            assert lines[0] == "#CROSS VALIDATION %d" % (r + 1) and lines[1] == "#COMBINATIONS OF: 2 SNPs"
+            assert lines[2] == ("#EVALUATION MODE: Cross-validation accuracy" if mode == 1 else "#EVALUATION MODE: Cross-validation consistency")
+            assert lines[3] == "#EVALUATION PARTITION: Testing" and lines[4] == "#POSITION\tSNPs\tGENOTYPES\tCV-C\tCV-A"
+            body = lines[5:]
+            assert len(body) == min(n, len(rows))
+            for pos, (line, (pr, a, c, m)) in enumerate(zip(body, rows)):
+                gts = "".join("(%d-%d), " % (cell // 3, cell % 3) for cell in range(9) if m >> cell & 1)
+                assert line == "%d\t( %d, %d )\t%s%d\t%.3f" % (pos + 1, pr[0], pr[1], gts, c, a), (mode, r, pos)
+            assert rows[0][0] == (3, 30)                             # the planted interaction wins
