@@ -1397,6 +1397,32 @@ int hpgv_tdt_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_li
     return HPGV_OK;
 }
 
+int hpgv_epi_dataset_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_lines, int *n_lines,
+                          uint64_t *line_off, uint32_t *field_off, int32_t *status, uint8_t *out) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->assoc.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_cohort has not been called");
+    if (!n_lines || max_lines < 0 || (text_bytes > 0 && !text) || (max_lines > 0 && !out))
+        return fail(ctx, HPGV_ERR_INVALID, "bad epi_dataset_text arguments");
+    *n_lines = 0;
+    if (max_lines == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    SlotLease lease(ctx);
+    int rc = acquire_slot(ctx, &lease.s);
+    if (rc) return rc;
+    Slot *s = lease.s;
+    int nl = 0;
+    if ((rc = text_front(ctx, s, HPGV_LAYOUT_EPI, ctx->assoc, text, text_bytes, max_lines, n_lines, line_off, field_off, status, &nl))) return rc;
+    const size_t nA = (size_t)ctx->nA, nU = (size_t)ctx->nU, width = nA + nU;
+    if (nl > 0 && width > 0) {
+        const uint8_t *d = (const uint8_t *)s->buf[1];
+        const size_t segA = (size_t)ctx->chunksA * 16, dp = ctx->assoc.pitch;
+        if (nA) HIPCHK(ctx, hipMemcpy2DAsync(out, width, d, dp, nA, (size_t)nl, hipMemcpyDeviceToHost, s->stream));
+        if (nU) HIPCHK(ctx, hipMemcpy2DAsync(out + nA, width, d + segA, dp, nU, (size_t)nl, hipMemcpyDeviceToHost, s->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    return HPGV_OK;
+}
+
 int hpgv_read_probe(hpgv_ctx *ctx, const uint8_t *d_buf, size_t bytes, int iters, float *ms) {
     if (!ctx || !d_buf || !ms || iters <= 0 || ((uintptr_t)d_buf & 15)) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);

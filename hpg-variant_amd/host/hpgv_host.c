@@ -1671,10 +1671,12 @@ typedef struct {
     char *text; size_t bytes; int max_lines, n_lines;
     uint64_t *line_off; uint32_t *field_off; int32_t *status;
     int32_t *ints; double *dbl;                          /* 4 (assoc) or 2 (tdt) int arrays, 3 double arrays */
+    uint8_t *rows; size_t rows_cap; int row_width;       /* vcf2epi: one dataset row per line */
 } run_batch_t;
 
-static int run_batch_alloc(run_batch_t *b, size_t cap_bytes, int n_samples) {
+static int run_batch_alloc(run_batch_t *b, size_t cap_bytes, int n_samples, int row_width) {
     memset(b, 0, sizeof *b);
+    b->row_width = row_width;
     size_t min_line = (size_t)(2 * (n_samples > 0 ? n_samples : 1) + 18);
     b->max_lines = (int)(cap_bytes / min_line) + 2;
     if (hpgv_host_alloc(g_ctx, cap_bytes + 1, (void **)&b->text) != HPGV_OK) b->text = NULL;   /* pinned: full-rate H2D */
@@ -1683,6 +1685,10 @@ static int run_batch_alloc(run_batch_t *b, size_t cap_bytes, int n_samples) {
     b->status = (int32_t *)malloc(sizeof(int32_t) * (size_t)b->max_lines);
     b->ints = (int32_t *)malloc(sizeof(int32_t) * 4 * (size_t)b->max_lines);
     b->dbl = (double *)malloc(sizeof(double) * 3 * (size_t)b->max_lines);
+    if (b->row_width > 0) {
+        b->rows_cap = (size_t)b->max_lines * (size_t)b->row_width;
+        if (!(b->rows = (uint8_t *)malloc(b->rows_cap + 1))) return HPGV_ERR_NOMEM;
+    }
     return (b->text && b->line_off && b->field_off && b->status && b->ints && b->dbl) ? HPGV_OK : HPGV_ERR_NOMEM;
 }
 /* makes room for `lines` records (short or truncated lines can exceed the estimate) */
@@ -1695,11 +1701,16 @@ static int run_batch_reserve(run_batch_t *b, int lines) {
     b->status = (int32_t *)malloc(sizeof(int32_t) * (size_t)b->max_lines);
     b->ints = (int32_t *)malloc(sizeof(int32_t) * 4 * (size_t)b->max_lines);
     b->dbl = (double *)malloc(sizeof(double) * 3 * (size_t)b->max_lines);
+    if (b->row_width > 0) {
+        free(b->rows);
+        b->rows_cap = (size_t)b->max_lines * (size_t)b->row_width;
+        if (!(b->rows = (uint8_t *)malloc(b->rows_cap + 1))) return HPGV_ERR_NOMEM;
+    }
     return (b->line_off && b->field_off && b->status && b->ints && b->dbl) ? HPGV_OK : HPGV_ERR_NOMEM;
 }
 static void run_batch_free(run_batch_t *b) {
     if (b->text) (void)hpgv_host_free(g_ctx, b->text);
-    free(b->line_off); free(b->field_off); free(b->status); free(b->ints); free(b->dbl);
+    free(b->line_off); free(b->field_off); free(b->status); free(b->ints); free(b->dbl); free(b->rows);
 }
 
 /* one output line per record, the reference's formats (assoc_runner.c:314-318,332-336; tdt_runner.c:297-299).
@@ -1752,6 +1763,19 @@ static void fmt_task(void *v, int t) {
 }
 
 static int write_batch(FILE *fd, int kind, const run_batch_t *b, out_buf_t *bufs, int n_bufs, io_pool_t *pool) {
+    if (kind == 4) {                                     /* vcf2epi: the rows of the records, in line order (dataset_creator.c:196-199) */
+        const int n = b->n_lines < b->max_lines ? b->n_lines : b->max_lines;
+        const size_t w = (size_t)b->row_width;
+        int i = 0;
+        while (i < n) {                                  /* runs of consecutive records go out in one write */
+            while (i < n && b->field_off[10 * (size_t)i + 5] == 0xFFFFFFFFu) i++;
+            int e = i;
+            while (e < n && b->field_off[10 * (size_t)e + 5] != 0xFFFFFFFFu) e++;
+            if (e > i && w && fwrite(b->rows + (size_t)i * w, w, (size_t)(e - i), fd) != (size_t)(e - i)) return 1;
+            i = e;
+        }
+        return 0;
+    }
     fmt_job_t j;
     j.b = b; j.bufs = bufs; j.kind = kind; j.bad = 0;
     j.n = b->n_lines < b->max_lines ? b->n_lines : b->max_lines;
@@ -1829,7 +1853,9 @@ static void *pipe_engine(void *v) {
          * engine reports the true count, the arrays grow and the batch is done again */
         for (int attempt = 0; attempt < 2; attempt++) {
             const int m = b->max_lines;
-            if (kind == 3)
+            if (kind == 4)
+                rc = hpgv_epi_dataset_text(g_ctx, b->text, b->bytes, m, &b->n_lines, b->line_off, b->field_off, b->status, b->rows);
+            else if (kind == 3)
                 rc = hpgv_tdt_text(g_ctx, b->text, b->bytes, m, &b->n_lines, b->line_off, b->field_off, b->status,
                                    b->ints, b->ints + m, b->dbl, b->dbl + m, b->dbl + 2 * m);
             else
@@ -1844,7 +1870,7 @@ static void *pipe_engine(void *v) {
         P->t_engine += dt;
         if (rc) {
             char msg[256];
-            snprintf(msg, sizeof msg, "%s failed (%d): %s", kind == 3 ? "hpgv_tdt_text" : "hpgv_assoc_text", rc,
+            snprintf(msg, sizeof msg, "%s failed (%d): %s", kind == 4 ? "hpgv_epi_dataset_text" : kind == 3 ? "hpgv_tdt_text" : "hpgv_assoc_text", rc,
                      rc == HPGV_ERR_NOMEM ? "out of memory" : hpgv_last_error(g_ctx));
             pipe_fail(P, rc, msg);
             pthread_mutex_unlock(&P->mu);
@@ -1879,6 +1905,7 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     /* cohort: PED rows looked up by sample name (associate_samples_and_positions + sort_individuals) */
     sample_ids_t *ids = sample_ids_new((size_t)n_samples);
     for (int j = 0; j < n_samples; j++) sample_ids_put(ids, names[j], j);
+    uint32_t epi_aff = 0, epi_unaff = 0;
     pthread_rwlock_wrlock(&g_cohort_lock);
     if (kind == 3) {
         /* families in order of first appearance; father / mother = founders by sex (tdt.c:62-73);
@@ -1921,6 +1948,12 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
         uint8_t *cond = (uint8_t *)malloc((size_t)n_samples + 1);
         for (int j = 0; j < n_samples; j++) cond[j] = HPGV_COND_OTHER;
         for (int i = 0; i < ped.n; i++) { int j = sample_ids_get(ids, ped.iid[i]); if (j >= 0) cond[j] = (uint8_t)ped.pheno[i]; }
+        if (kind == 4) {                                 /* get_individual_phenotypes, dataset_creator.c:279-300: affected, or not */
+            for (int j = 0; j < n_samples; j++) {
+                if (cond[j] != HPGV_COND_AFFECTED) cond[j] = HPGV_COND_UNAFFECTED;
+                if (cond[j] == HPGV_COND_AFFECTED) epi_aff++; else epi_unaff++;
+            }
+        }
         rc = hpgv_set_cohort(g_ctx, cond, n_samples);
         g_assoc_key.set = 0;
         if (rc) host_fail("hpgv_set_cohort", rc);
@@ -1946,10 +1979,14 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     out_buf_t *fmt = (out_buf_t *)calloc(RUN_FMT_BUFS, sizeof *fmt);
     int have = 0;
     if (!P || !fmt) rc = rc ? rc : HPGV_ERR_NOMEM;
-    for (; !rc && have < RUN_NB; have++) rc = run_batch_alloc(&P->bt[have], batch_bytes, n_samples);
+    for (; !rc && have < RUN_NB; have++) rc = run_batch_alloc(&P->bt[have], batch_bytes, n_samples, kind == 4 ? n_samples : 0);
     if (rc == HPGV_ERR_NOMEM) snprintf(g_err, sizeof g_err, "out of memory for the batch buffers");
     if (!rc) {
-        if (kind == 3) tdt_write_output_header(out); else assoc_write_output_header((enum ASSOC_task)kind, out);
+        if (kind == 4) {                                 /* room for the number of variants, then the class sizes (dataset_creator.c:186-193) */
+            const uint32_t head[3] = {0, epi_aff, epi_unaff};
+            if (fwrite(head, sizeof(uint32_t), 3, out) != 3) rc = HPGV_ERR_INVALID;
+        } else if (kind == 3) tdt_write_output_header(out);
+        else assoc_write_output_header((enum ASSOC_task)kind, out);
         /* one reader thread (with its team of pread / inflate threads), RUN_ENGINES engine threads (each call
          * is H2D, tokenize, scan, statistics, D2H on its own stream, so two in flight overlap the copies of one
          * batch with the kernels of the other) and this thread as the writer (with its team of formatters);
@@ -1997,10 +2034,14 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
         g_run_times[0] = P->t_read; g_run_times[1] = P->t_engine; g_run_times[2] = P->t_write; g_run_times[5] = (double)P->n_filled;
         pthread_mutex_destroy(&P->mu); pthread_cond_destroy(&P->cv);
     }
+    if (out && kind == 4 && !rc) {                       /* finally the real number of variants (dataset_creator.c:208-212) */
+        const uint32_t nv = (uint32_t)written;
+        if (fseek(out, 0, SEEK_SET) != 0 || fwrite(&nv, sizeof nv, 1, out) != 1) { snprintf(g_err, sizeof g_err, "cannot write %s", out_path); rc = HPGV_ERR_INVALID; }
+    }
     if (out && fclose(out) != 0 && !rc) { snprintf(g_err, sizeof g_err, "cannot write %s", out_path); rc = HPGV_ERR_INVALID; }
     {
         const double t0 = now_s();
-        if (!rc && hpgv_host_sort_output_file(out_path))                /* assoc_runner.c:255-261: only a warning there */
+        if (!rc && kind != 4 && hpgv_host_sort_output_file(out_path))                /* assoc_runner.c:255-261: only a warning there */
             fprintf(stderr, "WARN: results could not be sorted by chromosome and position\n");
         t_sort = now_s() - t0;
     }
@@ -2060,4 +2101,8 @@ int hpgv_run_assoc(const char *vcf_path, const char *ped_path, const char *out_p
 
 int hpgv_run_tdt(const char *vcf_path, const char *ped_path, const char *out_path, size_t batch_bytes, long *n_variants_out) {
     return run_file(vcf_path, ped_path, out_path, 3, batch_bytes, n_variants_out);
+}
+
+int hpgv_run_vcf2epi(const char *vcf_path, const char *ped_path, const char *out_path, size_t batch_bytes, long *n_variants_out) {
+    return run_file(vcf_path, ped_path, out_path, 4, batch_bytes, n_variants_out);
 }

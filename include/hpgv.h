@@ -236,6 +236,11 @@ int  hpgv_stats_groups(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_var
  * non-reference, 255 missing.  Uses the cohort of hpgv_set_cohort. */
 int  hpgv_epi_dataset(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, uint8_t *out);
 
+/* the same rows from a batch of VCF text (tokenized on the device like hpgv_assoc_text): row v of `out` belongs to
+ * line v; lines that are not records (field_off[10 v + 5] == 0xFFFFFFFF) leave their row undefined */
+int  hpgv_epi_dataset_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_lines, int *n_lines,
+                           uint64_t *line_off, uint32_t *field_off, int32_t *status, uint8_t *out);
+
 /* ---- epistasis / MDR counting (hpg-var-gwas epi: src/gwas/epistasis/model.c, mdr.c, epistasis.c;
  *      runner src/gwas/epistasis/singlenode/epistasis_runner.c) -------------------------------------
  * The input is the vcf2epi dataset (dataset.c:63-76; hpgv_epi_dataset makes its rows): one row per SNP,

@@ -274,6 +274,12 @@ int  hpgv_run_assoc(const char *vcf_path, const char *ped_path, const char *out_
                     enum ASSOC_task task, size_t batch_bytes, long *n_variants_out);
 int  hpgv_run_tdt(const char *vcf_path, const char *ped_path, const char *out_path,
                   size_t batch_bytes, long *n_variants_out);
+/* create_dataset_from_vcf (src/vcf-tools/vcf2epi/dataset_creator.c:24-222) without its filters: the binary
+ * dataset hpgv_run_epistasis reads -- uint32 num_variants, num_affected, num_unaffected, then per variant
+ * one byte per sample, cases first (0 "0/0", 1 heterozygous, 2 homozygous non-reference, 255 missing);
+ * every sample that is not AFFECTED counts as unaffected (dataset_creator.c:279-300) */
+int  hpgv_run_vcf2epi(const char *vcf_path, const char *ped_path, const char *out_path,
+                      size_t batch_bytes, long *n_variants_out);
 /* stage times of the last run on this process: {read, engine, write, sort, total} seconds and the number of
  * batches; read / engine / write overlap (three threads, three batch buffers in rotation).  The reader and
  * formatter teams use HPGV_IO_THREADS threads (environment; default half the cores, at most 16);

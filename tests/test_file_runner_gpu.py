@@ -148,3 +148,37 @@ def test_run_assoc_batches_of_short_lines(host, tmp_path):
     assert len(table) == 6000
     full = [t for t in table if int(t[4]) + int(t[9]) > 0]
     assert len(full) == 4 and all((int(t[4]), int(t[9]), int(t[5]), int(t[10])) == (25, 25, 25, 25) for t in full)
+
+
+def test_run_vcf2epi_then_epistasis(host, tmp_path):
+    # create_dataset_from_vcf (dataset_creator.c:24-222): VCF + PED -> binary dataset; then the epistasis run reads it
+    import struct
+    host.hpgv_run_vcf2epi.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_long)]
+    host.hpgv_run_epistasis.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    rng = np.random.default_rng(8)
+    people, names, rows = _write_inputs(tmp_path, rng, 30, 40, 300)
+    vcf = _vcf_from_batch(tmp_path, names, rows)
+    out = str(tmp_path / "epistasis_dataset.bin")
+    n = C.c_long(0)
+    rc = host.hpgv_run_vcf2epi(vcf.encode(), str(tmp_path / "ped.txt").encode(), out.encode(), 1 << 16, C.byref(n))
+    assert rc == 0 and n.value == len(rows), host.hpgv_host_last_error()
+    blob = open(out, "rb").read()
+    nv, nA, nU = struct.unpack("<III", blob[:12])
+    pheno = {p[1]: p[5] for p in people}
+    affected = np.array([pheno.get(nm) == 2 for nm in names])
+    assert (nv, nA, nU) == (len(rows), int(affected.sum()), int((~affected).sum()))
+    data = np.frombuffer(blob[12:], np.uint8).reshape(nv, nA + nU)
+    # destination of VCF column k: cases in column order first, then the others (group_individuals_by_phenotype)
+    dest = np.empty(len(names), np.int64)
+    dest[affected] = np.arange(nA); dest[~affected] = nA + np.arange(nU)
+    exp = np.zeros_like(data)
+    for v, (_, fmt, samples) in enumerate(rows):
+        pos = fmt.split(":").index("GT")
+        for k_, s in enumerate(samples):
+            st, a1, a2 = orc.get_alleles(s, pos)
+            exp[v, dest[k_]] = 255 if st != 0 else (0 if (a1 == 0 and a2 == 0) else (1 if a1 != a2 else 2))
+    assert np.array_equal(data, exp)
+    rc = host.hpgv_run_epistasis(out.encode(), 4, 1, 5, 0, 1, str(tmp_path / "epi").encode())
+    assert rc == 0, host.hpgv_host_last_error()
+    report = open(str(tmp_path / "epi") + ".cv1.epi").read().splitlines()
+    assert report[0] == "#CROSS VALIDATION 1" and len(report) == 5 + 5
