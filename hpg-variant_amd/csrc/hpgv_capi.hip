@@ -114,6 +114,9 @@ struct hpgv_ctx {
     };
     std::mutex tok_mu;
     std::vector<TokScratch *> tok_scratch;
+    // record filters of the text entry points (hpgv_set_text_filters); negative = off
+    double filt_min_maf = -1.0, filt_max_missing = -1.0;
+    long filt_max_mendel = -1;
     // epistasis (calls are serialised by epi_mu)
     std::mutex epi_mu;
     EpiState epi;
@@ -1306,7 +1309,9 @@ static int text_front(hpgv_ctx *ctx, Slot *s, int which, const Layout &L, const 
     if ((rc = ensure(ctx, s, 6, off_fields + ml * 10 * sizeof(uint32_t) + 16))) return rc;
     char *meta = (char *)s->buf[6];
     if (text_bytes) HIPCHK(ctx, hipMemcpyAsync(s->buf[0], text, text_bytes, hipMemcpyHostToDevice, s->stream));
-    if ((rc = hpgv_tokenize_dev(ctx, (const char *)s->buf[0], text_bytes, L.n_samples, which == HPGV_LAYOUT_STATS ? 0 : 1,
+    // the raw matrix keeps half-called genotypes ("./1"): the record filters count alleles as the stats tool does;
+    // the strict layouts (assoc, tdt, epi) turn every not fully called genotype into "missing" on their way in
+    if ((rc = hpgv_tokenize_dev(ctx, (const char *)s->buf[0], text_bytes, L.n_samples, 0,
                                 max_lines, (int *)meta, (uint64_t *)(meta + off_lines), (uint32_t *)(meta + off_fields),
                                 (uint8_t *)s->buf[7], raw_pitch, (uint8_t *)s->buf[2], (int32_t *)s->buf[5], s->stream))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(n_lines, meta, sizeof(int), hipMemcpyDeviceToHost, s->stream));
@@ -1317,7 +1322,48 @@ static int text_front(hpgv_ctx *ctx, Slot *s, int which, const Layout &L, const 
     if (status) HIPCHK(ctx, hipMemcpyAsync(status, s->buf[5], (size_t)nl * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
     if (line_off) HIPCHK(ctx, hipMemcpyAsync(line_off, meta + off_lines, ((size_t)nl + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
     if (field_off) HIPCHK(ctx, hipMemcpyAsync(field_off, meta + off_fields, (size_t)nl * 10 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    // ---- record filters (--maf, --missing, --mendel: shared_options.c:44-46,101-115), from the same matrix ----
+    const bool f_counts = ctx->filt_min_maf >= 0.0 || ctx->filt_max_missing >= 0.0, f_mendel = ctx->filt_max_mendel >= 0;
+    if (status && (f_counts || f_mendel)) {
+        const size_t n = (size_t)nl;
+        std::vector<uint8_t> keep;
+        std::vector<int32_t> merr;
+        if (f_counts) {
+            if (!ctx->stats.set || ctx->stats.n_samples != L.n_samples)
+                return fail(ctx, HPGV_ERR_STATE, "the count filters need hpgv_set_stats_cohort(%d)", L.n_samples);
+            if ((rc = ensure(ctx, s, 1, n * std::max(ctx->stats.pitch, L.pitch) + 16))) return rc;
+            if ((rc = ensure(ctx, s, 3, n * 33 + 64))) return rc;
+            if ((rc = hpgv_layout_dev(ctx, HPGV_LAYOUT_STATS, (const uint8_t *)s->buf[7], raw_pitch, nl, (uint8_t *)s->buf[1], s->stream))) return rc;
+            if ((rc = hpgv_stats_scan_dev(ctx, (const uint8_t *)s->buf[1], nl, (int32_t *)s->buf[3], s->stream))) return rc;
+            uint8_t *d_keep = (uint8_t *)s->buf[3] + n * 32;
+            if ((rc = hpgv_stats_filter_dev(ctx, (const int32_t *)s->buf[3], nl, ctx->filt_min_maf, -1.0, ctx->filt_max_missing, d_keep, s->stream))) return rc;
+            keep.resize(n);
+            HIPCHK(ctx, hipMemcpyAsync(keep.data(), d_keep, n, hipMemcpyDeviceToHost, s->stream));
+        }
+        if (f_mendel) {
+            if (!ctx->mendel.set || ctx->mendel.n_samples != L.n_samples)
+                return fail(ctx, HPGV_ERR_STATE, "the Mendelian error filter needs hpgv_set_pedigree over %d columns", L.n_samples);
+            if ((rc = ensure(ctx, s, 1, n * std::max(ctx->mendel.pitch, L.pitch) + 16))) return rc;
+            if ((rc = ensure(ctx, s, 4, n * sizeof(int32_t) + 64))) return rc;
+            if ((rc = hpgv_layout_dev(ctx, HPGV_LAYOUT_MENDEL, (const uint8_t *)s->buf[7], raw_pitch, nl, (uint8_t *)s->buf[1], s->stream))) return rc;
+            if ((rc = hpgv_mendel_scan_dev(ctx, (const uint8_t *)s->buf[1], nl, (const uint8_t *)s->buf[2], (int32_t *)s->buf[4], s->stream))) return rc;
+            merr.resize(n);
+            HIPCHK(ctx, hipMemcpyAsync(merr.data(), s->buf[4], n * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+        }
+        HIPCHK(ctx, hipStreamSynchronize(s->stream));
+        for (size_t i = 0; i < n; ++i) {
+            const bool out = (f_counts && !keep[i]) || (f_mendel && (long)merr[i] > ctx->filt_max_mendel);
+            if (out) status[i] |= HPGV_LINE_FILTERED;
+        }
+    }
     return hpgv_layout_dev(ctx, which, (const uint8_t *)s->buf[7], raw_pitch, nl, (uint8_t *)s->buf[1], s->stream);
+}
+
+int hpgv_set_text_filters(hpgv_ctx *ctx, double min_maf, double max_missing, long max_mendel_errors) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (min_maf > 0.5 || max_missing > 1.0) return fail(ctx, HPGV_ERR_INVALID, "min_maf is at most 0.5, max_missing at most 1");
+    ctx->filt_min_maf = min_maf; ctx->filt_max_missing = max_missing; ctx->filt_max_mendel = max_mendel_errors;
+    return HPGV_OK;
 }
 
 int hpgv_assoc_text(hpgv_ctx *ctx, int task, const char *text, size_t text_bytes, int max_lines, int *n_lines,

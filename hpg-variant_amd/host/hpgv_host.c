@@ -1410,6 +1410,7 @@ static int ped_table_read(const char *path, ped_table_t *ped) {
 /* ---- byte sources: plain file (pread by a small thread team), BGZF (blocks inflated in parallel),
  *      generic gzip (one zlib stream) -- shared_options.c:60-61 `--compression gzip|bgzip` ------------ */
 enum { SRC_RAW = 0, SRC_BGZF = 1, SRC_GZIP = 2 };
+static hpgv_run_filters_t g_filters = { -1.0, -1.0, -1, -1, -1.0 };     /* hpgv_run_set_filters; negative = off */
 static double g_run_times[6];                           /* last run: read, engine, write, sort, total seconds, batches */
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 typedef struct {
@@ -1737,6 +1738,29 @@ static int format_record(char *dst, size_t room, int kind /* CHI_SQUARE, FISHER,
                     li, l + fo[2], lr, l + fo[3], A1, U1, fa1, fu1, la, l + fo[4], A2, U2, fa2, fu2, b->dbl[i], b->dbl[2 * m + i]);
 }
 
+/* does line i of the batch give an output record?  Not when it has fewer than CHROM..ALT, when a device-side filter
+ * rejected it (--maf / --missing / --mendel), or when it fails --alleles (1 + number of ALT alleles, "." = none) or
+ * --quality (QUAL >= minimum; a missing QUAL fails) */
+static int record_passes(const run_batch_t *b, int i) {
+    const uint32_t *fo = b->field_off + 10 * (size_t)i;
+    if (fo[5] == 0xFFFFFFFFu) return 0;
+    if (b->status[i] & HPGV_LINE_FILTERED) return 0;
+    const char *l = b->text + b->line_off[i];
+    if (g_filters.num_alleles >= 0) {
+        const char *alt = l + fo[4];
+        const int la = (int)(fo[5] - 1 - fo[4]);
+        int n = (la <= 0 || (la == 1 && alt[0] == '.')) ? 1 : 2;
+        for (int k = 0; k < la; k++) if (alt[k] == ',') n++;
+        if (n != g_filters.num_alleles) return 0;
+    }
+    if (g_filters.min_quality >= 0.0) {
+        if (fo[6] == 0xFFFFFFFFu) return 0;
+        const char *q = l + fo[5];
+        if (*q == '.' || *q == '\t' || strtod(q, NULL) < g_filters.min_quality) return 0;
+    }
+    return 1;
+}
+
 /* formats the records of a batch by a thread team (one contiguous range of lines and one growing buffer per
  * task), then writes the buffers in line order */
 typedef struct { char *p; size_t len, cap; } out_buf_t;
@@ -1749,7 +1773,7 @@ static void fmt_task(void *v, int t) {
     o->len = 0;
     const int lo = (int)((long)j->n * t / j->parts), hi = (int)((long)j->n * (t + 1) / j->parts);
     for (int i = lo; i < hi; i++) {
-        if (b->field_off[10 * (size_t)i + 5] == 0xFFFFFFFFu) continue;              /* fewer than CHROM..ALT: not a record */
+        if (!record_passes(b, i)) continue;
         for (;;) {
             int need = o->cap > o->len ? format_record(o->p + o->len, o->cap - o->len, j->kind, b, i) : -2;
             if (need >= 0 && (size_t)need < o->cap - o->len) { o->len += (size_t)need; break; }
@@ -1768,9 +1792,9 @@ static int write_batch(FILE *fd, int kind, const run_batch_t *b, out_buf_t *bufs
         const size_t w = (size_t)b->row_width;
         int i = 0;
         while (i < n) {                                  /* runs of consecutive records go out in one write */
-            while (i < n && b->field_off[10 * (size_t)i + 5] == 0xFFFFFFFFu) i++;
+            while (i < n && !record_passes(b, i)) i++;
             int e = i;
-            while (e < n && b->field_off[10 * (size_t)e + 5] != 0xFFFFFFFFu) e++;
+            while (e < n && record_passes(b, e)) e++;
             if (e > i && w && fwrite(b->rows + (size_t)i * w, w, (size_t)(e - i), fd) != (size_t)(e - i)) return 1;
             i = e;
         }
@@ -1966,6 +1990,31 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
             free(lf);
         }
     }
+    /* device-side record filters: the count filters scan the stats layout of all columns, the Mendelian filter the
+     * trios of the PED whose three members are VCF columns (every child with both parents, whatever its phenotype) */
+    const int dev_filters = g_filters.min_maf >= 0.0 || g_filters.max_missing >= 0.0 || g_filters.max_mendel_errors >= 0;
+    if (!rc && (g_filters.min_maf >= 0.0 || g_filters.max_missing >= 0.0)) {
+        rc = hpgv_set_stats_cohort(g_ctx, n_samples);
+        g_stats_key.set = 0;
+        if (rc) host_fail("hpgv_set_stats_cohort", rc);
+    }
+    if (!rc && g_filters.max_mendel_errors >= 0) {
+        int32_t *tf = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ped.n + 1)), *tm = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ped.n + 1));
+        int32_t *tc = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ped.n + 1));
+        uint8_t *ts = (uint8_t *)malloc((size_t)ped.n + 1);
+        int nt = 0;
+        for (int i = 0; i < ped.n; i++) {
+            if (!strcmp(ped.pat[i], "0") || !strcmp(ped.mat[i], "0")) continue;
+            const int cp = sample_ids_get(ids, ped.iid[i]), fp = sample_ids_get(ids, ped.pat[i]), mp = sample_ids_get(ids, ped.mat[i]);
+            if (cp < 0 || fp < 0 || mp < 0) continue;
+            tf[nt] = fp; tm[nt] = mp; tc[nt] = cp; ts[nt] = (uint8_t)ped.sex[i]; nt++;
+        }
+        rc = hpgv_set_pedigree(g_ctx, n_samples, nt, tf, tm, tc, ts);
+        g_ped_key.set = 0;
+        if (rc) host_fail("hpgv_set_pedigree", rc);
+        free(tf); free(tm); free(tc); free(ts);
+    }
+    if (!rc) (void)hpgv_set_text_filters(g_ctx, g_filters.min_maf, g_filters.max_missing, (long)g_filters.max_mendel_errors);
     pthread_rwlock_unlock(&g_cohort_lock);
     sample_ids_free(ids);
 
@@ -2018,7 +2067,7 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
             const double t0 = now_s();
             const run_batch_t *b = &P->bt[k];
             const int bad = write_batch(out, kind, b, fmt, n_fmt, &wpool);
-            for (int i = 0; i < b->n_lines; i++) if (b->field_off[10 * (size_t)i + 5] != 0xFFFFFFFFu) written++;
+            for (int i = 0; i < b->n_lines; i++) if (record_passes(b, i)) written++;
             const double dt = now_s() - t0;
             pthread_mutex_lock(&P->mu);
             P->t_write += dt;
@@ -2048,6 +2097,7 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     for (int k = 0; P && k < have; k++) run_batch_free(&P->bt[k]);
     for (int k = 0; fmt && k < RUN_FMT_BUFS; k++) free(fmt[k].p);
     free(fmt); free(P);
+    if (dev_filters) (void)hpgv_set_text_filters(g_ctx, -1.0, -1.0, -1);
     g_run_times[3] = t_sort; g_run_times[4] = now_s() - t_start;
     if (getenv("HPGV_RUN_TRACE"))
         fprintf(stderr, "hpgv run: %ld records, %.0f batches, %d io threads: read %.3f s, engine %.3f s (%d threads), write %.3f s (stages overlap), sort %.3f s, total %.3f s\n",
@@ -2089,6 +2139,11 @@ int hpgv_host_copy_lines(const char *in_path, const char *out_path, size_t batch
     free(buf); free(rd.carry); source_close(&rd.src);
     if (n_batches) *n_batches = nb;
     return rc;
+}
+
+void hpgv_run_set_filters(const hpgv_run_filters_t *filters) {
+    const hpgv_run_filters_t off = { -1.0, -1.0, -1, -1, -1.0 };
+    g_filters = filters ? *filters : off;
 }
 
 void hpgv_host_last_run_times(double *seconds6) { memcpy(seconds6, g_run_times, sizeof g_run_times); }

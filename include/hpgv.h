@@ -236,6 +236,15 @@ int  hpgv_stats_groups(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_var
  * non-reference, 255 missing.  Uses the cohort of hpgv_set_cohort. */
 int  hpgv_epi_dataset(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, uint8_t *out);
 
+/* record filters of the text entry points, computed on the device from the tokenized matrix before the tool's own
+ * scan: --maf (keep minor-allele frequency >= min_maf), --missing (keep missing-genotype rate <= max_missing),
+ * --mendel (keep Mendelian errors <= max_mendel_errors) -- shared_options.c:44-46,101-115; the filter bodies live
+ * in hpg-libs (definitions as hpgv_stats_filter_dev / hpgv_mendel_scan_dev).  A negative value switches a filter off.
+ * A rejected line gets HPGV_LINE_FILTERED OR-ed into its status; its statistics are still computed.  The count
+ * filters need hpgv_set_stats_cohort(n_samples), the Mendel filter hpgv_set_pedigree over the same columns. */
+#define HPGV_LINE_FILTERED 0x100
+int  hpgv_set_text_filters(hpgv_ctx *ctx, double min_maf, double max_missing, long max_mendel_errors);
+
 /* the same rows from a batch of VCF text (tokenized on the device like hpgv_assoc_text): row v of `out` belongs to
  * line v; lines that are not records (field_off[10 v + 5] == 0xFFFFFFFF) leave their row undefined */
 int  hpgv_epi_dataset_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_lines, int *n_lines,

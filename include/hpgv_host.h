@@ -274,6 +274,23 @@ int  hpgv_run_assoc(const char *vcf_path, const char *ped_path, const char *out_
                     enum ASSOC_task task, size_t batch_bytes, long *n_variants_out);
 int  hpgv_run_tdt(const char *vcf_path, const char *ped_path, const char *out_path,
                   size_t batch_bytes, long *n_variants_out);
+/* record filters of the file-level runners (filter_records on every batch, assoc_runner.c:191; options
+ * shared_options.c:42-47,86-115).  A negative member switches that filter off; NULL switches all off.  The
+ * count-derived ones run on the GPU from the same tokenized batch:
+ *   min_maf            --maf      keep records whose minor-allele frequency (first two alleles) is >= min_maf
+ *   max_missing        --missing  keep records whose rate of missing genotypes is <= max_missing
+ *   max_mendel_errors  --mendel   keep records with at most this many Mendelian errors over the PED's trios
+ *   num_alleles        --alleles  keep records with exactly this many alleles (1 + ALT alleles)
+ *   min_quality        --quality  keep records with QUAL >= min_quality
+ * The filter bodies live in hpg-libs (absent from the reference tree): these are the definitions used here.
+ * The setting applies to the runs started afterwards on this process. */
+typedef struct {
+    double min_maf, max_missing;
+    int max_mendel_errors, num_alleles;
+    double min_quality;
+} hpgv_run_filters_t;
+void hpgv_run_set_filters(const hpgv_run_filters_t *filters);
+
 /* create_dataset_from_vcf (src/vcf-tools/vcf2epi/dataset_creator.c:24-222) without its filters: the binary
  * dataset hpgv_run_epistasis reads -- uint32 num_variants, num_affected, num_unaffected, then per variant
  * one byte per sample, cases first (0 "0/0", 1 heterozygous, 2 homozygous non-reference, 255 missing);

@@ -182,3 +182,75 @@ def test_run_vcf2epi_then_epistasis(host, tmp_path):
     assert rc == 0, host.hpgv_host_last_error()
     report = open(str(tmp_path / "epi") + ".cv1.epi").read().splitlines()
     assert report[0] == "#CROSS VALIDATION 1" and len(report) == 5 + 5
+
+
+class _Filters(C.Structure):
+    _fields_ = [("min_maf", C.c_double), ("max_missing", C.c_double), ("max_mendel_errors", C.c_int),
+                ("num_alleles", C.c_int), ("min_quality", C.c_double)]
+
+
+@pytest.mark.parametrize("which", ["maf", "missing", "mendel", "alleles", "quality", "all"])
+def test_run_assoc_with_record_filters(host, tmp_path, which):
+    # filter_records on every batch (assoc_runner.c:191): --maf / --missing / --mendel on the GPU, --alleles / --quality
+    # from the record's text; the surviving records carry the same statistics as in an unfiltered run
+    rng = np.random.default_rng(31)
+    people, names, rows = _write_inputs(tmp_path, rng, 25, 20, 400)
+    n = len(names)
+    # make the cohort interesting for the filters: rare variants, missing-heavy variants, multi-allelic ALT, QUAL values
+    alts, quals = [], []
+    for v, (chrom, fmt, samples) in enumerate(rows):
+        pos = fmt.split(":").index("GT")
+        if v % 5 == 0:                                             # rare alternative allele
+            for k_ in range(n):
+                if rng.random() < 0.9:
+                    parts = samples[k_].split(":"); parts[pos] = "0/0"; samples[k_] = ":".join(parts)
+        if v % 7 == 0:                                             # many missing calls
+            for k_ in range(n):
+                if rng.random() < 0.3:
+                    parts = samples[k_].split(":"); parts[pos] = "./."; samples[k_] = ":".join(parts)
+        alts.append(["C", "C,G", ".", "C,G,T"][v % 4]); quals.append([".", "10", "35.5", "90"][v % 4 if v % 3 else 3])
+    with open(tmp_path / "in.vcf", "w") as f:
+        f.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n")
+        for v, (chrom, fmt, samples) in enumerate(rows):
+            f.write("%s\t%d\trs%d\tA\t%s\t%s\tPASS\t.\t%s\t%s\n" % (chrom, 1000 + v, v, alts[v], quals[v], fmt, "\t".join(samples)))
+    vcf = str(tmp_path / "in.vcf")
+    lax = _codes(rows, False)
+    is_x = np.array([1 if c == "X" else 0 for c, _, _ in rows], np.uint8)
+    col = {nm: i for i, nm in enumerate(names)}
+    trios = [(col[p[2]], col[p[3]], col[p[1]], orc.MALE if p[4] == 1 else orc.FEMALE) for p in people
+             if p[2] != "0" and p[3] != "0" and p[1] in col and p[2] in col and p[3] in col]
+    merr, _ = orc.mendel_counts(lax, [t[0] for t in trios], [t[1] for t in trios], [t[2] for t in trios], [t[3] for t in trios], is_x)
+    maf, miss = np.zeros(len(rows)), np.zeros(len(rows))
+    for v in range(len(rows)):
+        vs = orc.variant_stats(lax[v], 2)
+        a0, a1 = vs.alleles_count[0], vs.alleles_count[1]
+        maf[v] = min(a0, a1) / (a0 + a1) if a0 + a1 else 0.0
+        miss[v] = vs.missing_genotypes / n
+    n_alleles = np.array([1 if a == "." else 1 + len(a.split(",")) for a in alts])
+    qual = np.array([-1.0 if q == "." else float(q) for q in quals])
+    F = {"maf": _Filters(0.1, -1, -1, -1, -1), "missing": _Filters(-1, 0.1, -1, -1, -1), "mendel": _Filters(-1, -1, 1, -1, -1),
+         "alleles": _Filters(-1, -1, -1, 2, -1), "quality": _Filters(-1, -1, -1, -1, 30.0), "all": _Filters(0.02, 0.4, 50, 2, 5.0)}[which]
+    keep = np.ones(len(rows), bool)
+    if F.min_maf >= 0: keep &= maf >= F.min_maf
+    if F.max_missing >= 0: keep &= miss <= F.max_missing
+    if F.max_mendel_errors >= 0: keep &= merr <= F.max_mendel_errors
+    if F.num_alleles >= 0: keep &= n_alleles == F.num_alleles
+    if F.min_quality >= 0: keep &= qual >= F.min_quality
+    assert 0 < keep.sum() < len(rows)
+    host.hpgv_run_set_filters.argtypes = [C.POINTER(_Filters)]
+    ped = str(tmp_path / "ped.txt").encode()
+    full, filt = str(tmp_path / "full.chisq"), str(tmp_path / "filt.chisq")
+    cnt = C.c_long(0)
+    host.hpgv_run_set_filters(None)
+    assert host.hpgv_run_assoc(vcf.encode(), ped, full.encode(), 1, 1 << 16, C.byref(cnt)) == 0 and cnt.value == len(rows)
+    host.hpgv_run_set_filters(C.byref(F))
+    try:
+        rc = host.hpgv_run_assoc(vcf.encode(), ped, filt.encode(), 1, 1 << 16, C.byref(cnt))
+    finally:
+        host.hpgv_run_set_filters(None)
+    assert rc == 0, host.hpgv_host_last_error()
+    assert cnt.value == int(keep.sum())
+    all_lines = {int(l.split("\t")[1]): l for l in open(full).read().splitlines()[1:]}
+    got = open(filt).read().splitlines()[1:]
+    assert sorted(int(l.split("\t")[1]) for l in got) == [1000 + v for v in np.flatnonzero(keep)]
+    assert all(l == all_lines[int(l.split("\t")[1])] for l in got)
