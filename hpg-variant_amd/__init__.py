@@ -39,7 +39,7 @@ SYMBOLS = [
     "hpgv_mendel", "hpgv_epi_dataset", "hpgv_tokenize_dev", "hpgv_tokenize", "hpgv_assoc_text", "hpgv_tdt_text",
     "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_stats_groups",
     "hpgv_epi_dataset_text", "hpgv_set_text_filters", "hpgv_epi_set_dataset", "hpgv_epi_set_folds", "hpgv_epi_set_fold_masks", "hpgv_epi_counts",
-    "hpgv_epi_counts_all_folds", "hpgv_epi_scan_pairs", "hpgv_epi_rank_pairs", "hpgv_read_probe",
+    "hpgv_epi_counts_all_folds", "hpgv_epi_scan_pairs", "hpgv_epi_rank_pairs", "hpgv_epi_rank_pairs_rows", "hpgv_read_probe",
 ]
 
 
@@ -130,6 +130,7 @@ def load():
     L.hpgv_epi_counts_all_folds.argtypes = [vp, i32, vp, i32, vp, vp]
     L.hpgv_epi_scan_pairs.argtypes = [vp, i32, i32, i32, vp, vp, C.POINTER(C.c_ulonglong)]
     L.hpgv_epi_rank_pairs.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
+    L.hpgv_epi_rank_pairs_rows.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
     L.hpgv_read_probe.argtypes = [vp, vp, sz, i32, C.POINTER(C.c_float)]
     _lib = L
     return L
@@ -335,12 +336,14 @@ class Engine:
             self._chk(self.L.hpgv_epi_scan_pairs(self.h, i_begin, i_end, subset, _ptr(acc), _ptr(mask), C.byref(n)))
         return acc, mask
 
-    def epi_rank_pairs(self, subset, max_ranking_size):
+    def epi_rank_pairs(self, subset, max_ranking_size, rows=None):
         k, n = self._epi[3], max_ranking_size
         ci, cj = np.zeros((k, n), np.int32), np.zeros((k, n), np.int32)
         acc, mask, cnt = np.zeros((k, n), np.float64), np.zeros((k, n), np.uint32), np.zeros(k, np.int32)
         ms = C.c_float(0)
-        self._chk(self.L.hpgv_epi_rank_pairs(self.h, subset, n, _ptr(ci), _ptr(cj), _ptr(acc), _ptr(mask), _ptr(cnt), C.byref(ms)))
+        lo, hi = (0, self._epi[0]) if rows is None else rows
+        self._chk(self.L.hpgv_epi_rank_pairs_rows(self.h, lo, hi, subset, n, _ptr(ci), _ptr(cj), _ptr(acc), _ptr(mask), _ptr(cnt),
+                                                  C.byref(ms)))
         return dict(i=ci, j=cj, accuracy=acc, risky=mask, n=cnt, scan_ms=ms.value)
 
     def epi_dataset(self, gt):

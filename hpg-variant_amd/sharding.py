@@ -56,3 +56,43 @@ def gather_blocks(block, sizes, dst=0, group=None, async_op=False, out_bufs=None
     if rank != dst:
         return None, work
     return [b[: sizes[r]] for r, b in enumerate(bufs)], work
+
+
+def reduce_sample_counters(counters, dst=0, group=None, async_op=False):
+    """Per-sample counters of get_sample_stats (missing genotypes, Mendelian errors per sample: call site
+    stats_runner.c:197-198) are sums over variants, so with variants sharded across ranks they are the one
+    quantity that needs a reduction: an int32 sum of n_samples values onto `dst`
+    (ncclReduce over xGMI on the GPU box, gloo in the CPU tests).  In place; returns the work handle."""
+    assert counters.dtype == torch.int32 and counters.dim() == 1
+    if dist.get_world_size(group) == 1:
+        return None
+    return dist.reduce(counters, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def pair_row_range(rank, world, n_variants):
+    """Row band [lo, hi) of the epistasis pair scan for rank `rank`: the triangle of V(V-1)/2 pairs is cut into bands
+    of whole 64-row blocks with (nearly) equal numbers of pairs, so every GPU scans the same amount of work; each
+    rank ranks its band (hpgv_epi_rank_pairs over its rows) and the per-fold top lists are merged on rank 0."""
+    blocks = (n_variants + 63) // 64
+    total = n_variants * (n_variants - 1) // 2
+
+    def pairs_before(row):
+        row = min(row, n_variants)
+        return row * (2 * n_variants - row - 1) // 2
+
+    def cut(k):
+        if k <= 0:
+            return 0
+        if k >= world:
+            return n_variants
+        target = total * k // world
+        lo, hi = 0, blocks
+        while lo < hi:                               # first block boundary with at least `target` pairs before it
+            mid = (lo + hi) // 2
+            if pairs_before(mid * 64) >= target:
+                hi = mid
+            else:
+                lo = mid + 1
+        return min(lo * 64, n_variants)
+
+    return cut(rank), cut(rank + 1)

@@ -288,6 +288,11 @@ int  hpgv_epi_scan_pairs(hpgv_ctx *ctx, int i_begin, int i_end, int subset, doub
  * the scan kernels. */
 int  hpgv_epi_rank_pairs(hpgv_ctx *ctx, int subset, int max_ranking_size, int32_t *comb_i, int32_t *comb_j,
                          double *accuracy, uint32_t *risky_mask, int32_t *n_ranked, float *scan_ms);
+/* the same over the pairs (i, j) with i_begin <= i < i_end only (i_begin a multiple of 64): the unit of work of
+ * one GPU when the triangle is cut into row bands; the bands' lists merge into the whole ranking */
+int  hpgv_epi_rank_pairs_rows(hpgv_ctx *ctx, int i_begin, int i_end, int subset, int max_ranking_size,
+                              int32_t *comb_i, int32_t *comb_j, double *accuracy, uint32_t *risky_mask,
+                              int32_t *n_ranked, float *scan_ms);
 
 /* Mendelian errors of a host batch: errors[v] per variant (may be NULL) and child_errors[t] per trio of
  * hpgv_set_pedigree, ACCUMULATED into (may be NULL) */

@@ -156,6 +156,14 @@ def test_ranking_is_the_top_of_the_dense_scan(eng):
         assert [(int(x), int(y)) for x, y in zip(res["i"][f], res["j"][f])] == [pairs[p] for p in order]
         assert np.array_equal(res["accuracy"][f], acc[f][order]) and np.array_equal(res["risky"][f], rm[f][order])
     assert (7, 91) == (int(res["i"][0][0]), int(res["j"][0][0]))
+    # row bands (the multi-GPU unit of work, hpg-variant_amd/sharding.py pair_row_range): the merged band lists are the ranking
+    from importlib import import_module
+    sh = import_module("hpg-variant_amd.sharding")
+    for world in (2, 3):
+        parts = [eng.epi_rank_pairs(hpgv.EPI_TESTING, n, rows=sh.pair_row_range(g, world, v)) for g in range(world)]
+        for f in range(k):
+            merged = sorted(((-float(p["accuracy"][f][e]), int(p["i"][f][e]), int(p["j"][f][e])) for p in parts for e in range(p["n"][f])))[:n]
+            assert [(i_, j_) for _, i_, j_ in merged] == [(int(x), int(y)) for x, y in zip(res["i"][f], res["j"][f])]
 
 
 def test_epistasis_error_paths(eng):

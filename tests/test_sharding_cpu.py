@@ -85,3 +85,43 @@ def test_variant_ranges_partition_everything():
             assert all(r[i][1] == r[i + 1][0] for i in range(G - 1))
             sizes = [b - a for a, b in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _reduce_worker(rank, world, port, V, N, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from importlib import import_module
+    sh = import_module("hpg-variant_amd.sharding")
+    from oracle import pyoracle as orc
+    lo, hi = sh.variant_range(rank, world, V)
+    gt = orc.synth_matrix(lo, hi - lo, N, N)
+    miss = torch.from_numpy(orc.sample_missing(gt).astype(np.int32)) if hi > lo else torch.zeros(N, dtype=torch.int32)
+    sh.reduce_sample_counters(miss, dst=0)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "miss.npy"), miss.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,V", [(2, 500), (3, 301)])
+def test_sample_counters_reduce_over_variant_shards(tmp_path, world, V):
+    from oracle import pyoracle as orc
+    N = 96
+    mp.spawn(_reduce_worker, args=(world, _free_port(), V, N, str(tmp_path)), nprocs=world, join=True)
+    assert np.array_equal(np.load(tmp_path / "miss.npy"), orc.sample_missing(orc.synth_matrix(0, V, N, N)))
+
+
+def test_pair_row_bands_partition_the_triangle_evenly():
+    from importlib import import_module
+    sh = import_module("hpg-variant_amd.sharding")
+    for V in (2, 63, 64, 65, 1000, 16384, 100_000):
+        for G in (1, 2, 4, 8):
+            bands = [sh.pair_row_range(g, G, V) for g in range(G)]
+            assert bands[0][0] == 0 and bands[-1][1] == V
+            assert all(bands[i][1] == bands[i + 1][0] for i in range(G - 1))
+            assert all(lo % 64 == 0 or lo == V for lo, _ in bands)
+            pairs = [sum(V - 1 - r for r in range(lo, hi)) if V <= 1000 else (hi * (2 * V - hi - 1) - lo * (2 * V - lo - 1)) // 2 for lo, hi in bands]
+            assert sum(pairs) == V * (V - 1) // 2
+            if V >= 16384:
+                assert max(pairs) <= 1.05 * (sum(pairs) / G) + 64 * V
