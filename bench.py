@@ -11,7 +11,8 @@ the timed region (SURVEY.md 8d generator), so nothing crosses PCIe while timing.
 N = 1 default workload is BASELINE.json configs[1] ("c2": 1M biallelic SNP x 10k
 case/control): the metric's own 10M x 50k cohort is 500 GB and does not fit one
 GPU.  "m8" is the per-GPU shard of that metric cohort at 8 GPUs (1.25M x 50k,
-62.5 GB).  Scaling is weak: every rank scans one such shard.
+62.5 GB); "c5" one 100 GB tile of a GPU's shard of the 40M x 100k cohort.
+Scaling is weak: every rank scans one such shard.
 
 Prints ONE JSON line on rank 0.
 """
@@ -31,6 +32,7 @@ WORKLOADS = {
     # name: (variants per GPU, samples, description)
     "c2": (1_000_000, 10_000, "assoc --chisq, synthetic 1M biallelic SNP x 10k case/control (BASELINE configs[1])"),
     "m8": (1_250_000, 50_000, "assoc --chisq, per-GPU shard (1/8) of the 10M SNP x 50k metric cohort"),
+    "c5": (1_000_000, 100_000, "assoc --chisq, one 100 GB tile (1 of 5) of a GPU's shard of the 40M SNP x 100k cohort on 8 GPUs (BASELINE configs[4])"),
     "smoke": (20_000, 2_000, "assoc --chisq, tiny smoke cohort"),
     # secondary configs (not the headline metric; run with --workload):
     "c3": (1_000_000, 10_000, "assoc --fisher on the 1M x 10k cohort (BASELINE configs[2]): scan + Fisher p-pass"),

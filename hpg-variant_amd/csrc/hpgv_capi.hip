@@ -1443,6 +1443,93 @@ int hpgv_tdt_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_li
     return HPGV_OK;
 }
 
+int hpgv_stats_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_lines, int *n_lines,
+                    uint64_t *line_off, uint32_t *field_off, int32_t *status, int32_t *counts8, double *hwe_chi2,
+                    double *hwe_p, int32_t *sample_missing, int32_t *multi_idx, int32_t *multi_table, int *n_multi,
+                    int32_t *mendel_errors, int32_t *child_errors) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!ctx->stats.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");
+    if (!n_lines || max_lines < 0 || (text_bytes > 0 && !text) || (max_lines > 0 && (!counts8 || !hwe_chi2 || !hwe_p)))
+        return fail(ctx, HPGV_ERR_INVALID, "bad stats_text arguments");
+    if (n_multi && *n_multi > 0 && (!multi_idx || !multi_table)) return fail(ctx, HPGV_ERR_INVALID, "multi-allelic outputs are NULL");
+    const bool want_mendel = mendel_errors || child_errors;
+    if (want_mendel && (!ctx->mendel.set || ctx->mendel.n_samples != ctx->stats.n_samples))
+        return fail(ctx, HPGV_ERR_STATE, "Mendelian errors need hpgv_set_pedigree over the same %d columns", ctx->stats.n_samples);
+    const int cap = n_multi ? *n_multi : 0;
+    if (n_multi) *n_multi = 0;
+    *n_lines = 0;
+    if (max_lines == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    SlotLease lease(ctx);
+    int rc = acquire_slot(ctx, &lease.s);
+    if (rc) return rc;
+    Slot *s = lease.s;
+    int nl = 0;
+    if ((rc = text_front(ctx, s, HPGV_LAYOUT_STATS, ctx->stats, text, text_bytes, max_lines, n_lines, line_off, field_off, status, &nl))) return rc;
+    if (nl == 0) { HIPCHK(ctx, hipStreamSynchronize(s->stream)); return HPGV_OK; }
+    const size_t n = (size_t)nl;
+    const int ns = ctx->stats.n_samples;
+    const size_t raw_pitch = (size_t)(ns > 0 ? (ns + 15) / 16 * 16 : 16);
+    if ((rc = ensure(ctx, s, 3, n * 32))) return rc;
+    if ((rc = ensure(ctx, s, 4, n * 2 * sizeof(double) + 64))) return rc;
+    int32_t *d_c8 = (int32_t *)s->buf[3];
+    double *d_chi2 = (double *)s->buf[4], *d_p = d_chi2 + n;
+    if ((rc = hpgv_stats_scan_dev(ctx, (const uint8_t *)s->buf[1], nl, d_c8, s->stream))) return rc;
+    if ((rc = hpgv_stats_hwe_dev(ctx, d_c8, nl, d_chi2, d_p, s->stream))) return rc;
+    std::vector<int32_t> sm, ce;
+    int32_t *d_sm = nullptr;
+    if (sample_missing && ns > 0) {                                  // the line status array has been copied out: reuse its buffer
+        if ((rc = ensure(ctx, s, 5, std::max((size_t)ns, n * 4) * sizeof(int32_t)))) return rc;
+        d_sm = (int32_t *)s->buf[5];
+        HIPCHK(ctx, hipMemsetAsync(d_sm, 0, (size_t)ns * sizeof(int32_t), s->stream));
+        if ((rc = hpgv_sample_missing_dev(ctx, (const uint8_t *)s->buf[1], nl, d_sm, s->stream))) return rc;
+        sm.resize((size_t)ns);
+        HIPCHK(ctx, hipMemcpyAsync(sm.data(), d_sm, (size_t)ns * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(counts8, d_c8, n * 32, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hwe_chi2, d_chi2, n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hwe_p, d_p, n * 8, hipMemcpyDeviceToHost, s->stream));
+    if (want_mendel) {                                               // the stats layout in buf[1] has been consumed (same stream)
+        const size_t nt = (size_t)ctx->mendel_trios;
+        if ((rc = ensure(ctx, s, 1, n * std::max(ctx->mendel.pitch, ctx->stats.pitch) + 16))) return rc;
+        if ((rc = hpgv_layout_dev(ctx, HPGV_LAYOUT_MENDEL, (const uint8_t *)s->buf[7], raw_pitch, nl, (uint8_t *)s->buf[1], s->stream))) return rc;
+        if ((rc = ensure(ctx, s, 6, (n + nt) * sizeof(int32_t) + 64))) return rc;   // meta has been copied out
+        int32_t *d_err = (int32_t *)s->buf[6], *d_child = d_err + n;
+        if (mendel_errors) {
+            if ((rc = hpgv_mendel_scan_dev(ctx, (const uint8_t *)s->buf[1], nl, (const uint8_t *)s->buf[2], d_err, s->stream))) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(mendel_errors, d_err, n * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+        }
+        if (child_errors && nt) {
+            HIPCHK(ctx, hipMemsetAsync(d_child, 0, nt * sizeof(int32_t), s->stream));
+            if ((rc = hpgv_mendel_children_dev(ctx, (const uint8_t *)s->buf[1], nl, (const uint8_t *)s->buf[2], d_child, s->stream))) return rc;
+            ce.resize(nt);
+            HIPCHK(ctx, hipMemcpyAsync(ce.data(), d_child, nt * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+        }
+    }
+    HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    for (size_t j = 0; j < sm.size(); ++j) sample_missing[j] += sm[j];
+    for (size_t t = 0; t < ce.size(); ++t) child_errors[t] += ce[t];
+    if (n_multi) {
+        std::vector<int32_t> idx;
+        for (size_t i = 0; i < n; ++i) {
+            const int32_t *c = counts8 + 8 * i;
+            if (ns - c[4] - (c[0] + c[1] + c[2] + c[3]) > 0) idx.push_back((int32_t)i);
+        }
+        *n_multi = (int)idx.size();
+        const int m = (int)idx.size() < cap ? (int)idx.size() : cap;
+        if (m > 0) {
+            if ((rc = ensure(ctx, s, 3, (size_t)m * 257 * sizeof(int32_t)))) return rc;
+            int32_t *d_idx = (int32_t *)s->buf[3], *d_tab = d_idx + m;
+            HIPCHK(ctx, hipMemcpyAsync(d_idx, idx.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+            if ((rc = hpgv_genotype_table_dev(ctx, (const uint8_t *)s->buf[7], raw_pitch, ns, d_idx, m, d_tab, s->stream))) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(multi_table, d_tab, (size_t)m * 256 * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(ctx, hipStreamSynchronize(s->stream));
+            memcpy(multi_idx, idx.data(), (size_t)m * sizeof(int32_t));
+        }
+    }
+    return HPGV_OK;
+}
+
 int hpgv_epi_dataset_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_lines, int *n_lines,
                           uint64_t *line_off, uint32_t *field_off, int32_t *status, uint8_t *out) {
     if (!ctx) return HPGV_ERR_INVALID;

@@ -1616,7 +1616,7 @@ static size_t read_lines(line_reader_t *r, char *buf, size_t cap) {
 /* VCF header: skips the '##' lines and takes the sample names from the '#CHROM' line; what follows that line
  * in the bytes already read becomes the reader's carry.  Returns the number of samples, -1 without a
  * '#CHROM' line; *hdr_out owns the text the names point into. */
-static int vcf_header_read(line_reader_t *rd, char **hdr_out, char ***names_out) {
+static int vcf_header_read(line_reader_t *rd, char **hdr_out, char ***names_out, size_t *chrom_off) {
     char *hdr = NULL;
     int n_samples = -1;
     char **names = NULL;
@@ -1638,6 +1638,7 @@ static int vcf_header_read(line_reader_t *rd, char **hdr_out, char ***names_out)
             p = eol + 1;
         }
         if (chrom) {
+            if (chrom_off) *chrom_off = (size_t)(chrom - hdr);
             size_t len = strlen(chrom);
             while (len > 0 && chrom[len - 1] == '\r') chrom[--len] = 0;
             int tabs = 0;
@@ -1673,11 +1674,27 @@ typedef struct {
     uint64_t *line_off; uint32_t *field_off; int32_t *status;
     int32_t *ints; double *dbl;                          /* 4 (assoc) or 2 (tdt) int arrays, 3 double arrays */
     uint8_t *rows; size_t rows_cap; int row_width;       /* vcf2epi: one dataset row per line */
+    int stats;                                           /* aggregate / stats: the counters of hpgv_stats_text */
+    int32_t *c8, *merr, *midx, *mtab, *smiss, *cerr; double *hw;
+    int n_multi, multi_cap, n_smiss, n_cerr;
 } run_batch_t;
 
-static int run_batch_alloc(run_batch_t *b, size_t cap_bytes, int n_samples, int row_width) {
+static int run_batch_stats_arrays(run_batch_t *b) {
+    if (!b->stats) return HPGV_OK;
+    free(b->c8); free(b->hw); free(b->merr); free(b->midx);
+    b->c8 = (int32_t *)malloc(sizeof(int32_t) * 8 * (size_t)b->max_lines);
+    b->hw = (double *)malloc(sizeof(double) * 2 * (size_t)b->max_lines);
+    b->merr = (int32_t *)calloc((size_t)b->max_lines, sizeof(int32_t));
+    b->midx = (int32_t *)malloc(sizeof(int32_t) * (size_t)b->max_lines);
+    if (!b->smiss) b->smiss = (int32_t *)calloc((size_t)b->n_smiss + 1, sizeof(int32_t));
+    if (!b->cerr) b->cerr = (int32_t *)calloc((size_t)b->n_cerr + 1, sizeof(int32_t));
+    return (b->c8 && b->hw && b->merr && b->midx && b->smiss && b->cerr) ? HPGV_OK : HPGV_ERR_NOMEM;
+}
+
+static int run_batch_alloc(run_batch_t *b, size_t cap_bytes, int n_samples, int row_width, int stats, int n_trios) {
     memset(b, 0, sizeof *b);
     b->row_width = row_width;
+    b->stats = stats; b->n_smiss = n_samples; b->n_cerr = n_trios;
     size_t min_line = (size_t)(2 * (n_samples > 0 ? n_samples : 1) + 18);
     b->max_lines = (int)(cap_bytes / min_line) + 2;
     if (hpgv_host_alloc(g_ctx, cap_bytes + 1, (void **)&b->text) != HPGV_OK) b->text = NULL;   /* pinned: full-rate H2D */
@@ -1690,6 +1707,7 @@ static int run_batch_alloc(run_batch_t *b, size_t cap_bytes, int n_samples, int 
         b->rows_cap = (size_t)b->max_lines * (size_t)b->row_width;
         if (!(b->rows = (uint8_t *)malloc(b->rows_cap + 1))) return HPGV_ERR_NOMEM;
     }
+    if (run_batch_stats_arrays(b)) return HPGV_ERR_NOMEM;
     return (b->text && b->line_off && b->field_off && b->status && b->ints && b->dbl) ? HPGV_OK : HPGV_ERR_NOMEM;
 }
 /* makes room for `lines` records (short or truncated lines can exceed the estimate) */
@@ -1707,16 +1725,23 @@ static int run_batch_reserve(run_batch_t *b, int lines) {
         b->rows_cap = (size_t)b->max_lines * (size_t)b->row_width;
         if (!(b->rows = (uint8_t *)malloc(b->rows_cap + 1))) return HPGV_ERR_NOMEM;
     }
+    if (run_batch_stats_arrays(b)) return HPGV_ERR_NOMEM;
     return (b->line_off && b->field_off && b->status && b->ints && b->dbl) ? HPGV_OK : HPGV_ERR_NOMEM;
 }
 static void run_batch_free(run_batch_t *b) {
     if (b->text) (void)hpgv_host_free(g_ctx, b->text);
     free(b->line_off); free(b->field_off); free(b->status); free(b->ints); free(b->dbl); free(b->rows);
+    free(b->c8); free(b->hw); free(b->merr); free(b->midx); free(b->mtab); free(b->smiss); free(b->cerr);
 }
 
 /* one output line per record, the reference's formats (assoc_runner.c:314-318,332-336; tdt_runner.c:297-299).
  * Returns the number of characters (as snprintf: what the whole line needs). */
-static int format_record(char *dst, size_t room, int kind /* CHI_SQUARE, FISHER, 3 = tdt */, const run_batch_t *b, int i) {
+static int format_aggregate(char *dst, size_t room, const run_batch_t *b, int i);
+static int format_stats_variant(char *dst, size_t room, const run_batch_t *b, int i);
+
+static int format_record(char *dst, size_t room, int kind /* CHI_SQUARE, FISHER, 3 = tdt, 5 = aggregate, 6 = stats */, const run_batch_t *b, int i) {
+    if (kind == 5) return format_aggregate(dst, room, b, i);
+    if (kind == 6) return format_stats_variant(dst, room, b, i);
     const int m = b->max_lines;
     const uint32_t *fo = b->field_off + 10 * (size_t)i;
     const char *l = b->text + b->line_off[i];
@@ -1760,6 +1785,132 @@ static int record_passes(const run_batch_t *b, int i) {
     }
     return 1;
 }
+
+/* ---- aggregate / stats: the counters of one record as variant_stats_t holds them (get_variants_stats above) ---- */
+typedef struct { int na, miss_al, miss_gt, ac[15], gc[225]; } vcounts_t;
+
+static void record_counts(const run_batch_t *b, int i, const char *alt, int la, vcounts_t *v) {
+    const int32_t *c = b->c8 + 8 * (size_t)i;
+    memset(v, 0, sizeof *v);
+    int na = (la <= 0 || (la == 1 && alt[0] == '.')) ? 1 : 2;
+    for (int k = 0; k < la; k++) if (alt[k] == ',') na++;
+    const int32_t *tab = NULL;
+    if (b->n_multi > 0) {                                   /* multi-allelic: its 256-bin table (binary search: midx ascends) */
+        int lo = 0, hi = b->n_multi < b->multi_cap ? b->n_multi : b->multi_cap;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (b->midx[mid] < i) lo = mid + 1; else hi = mid; }
+        if (lo < (b->n_multi < b->multi_cap ? b->n_multi : b->multi_cap) && b->midx[lo] == i) tab = b->mtab + (size_t)lo * 256;
+    }
+    if (tab)
+        for (int code = 0; code < 256; code++) {
+            if (!tab[code]) continue;
+            const int a1 = code >> 4, a2 = code & 0xF;
+            if (a1 != 0xF && a1 + 1 > na) na = a1 + 1;
+            if (a2 != 0xF && a2 + 1 > na) na = a2 + 1;
+        }
+    if (na < 2) na = 2;
+    if (na > 15) na = 15;
+    v->na = na; v->miss_gt = c[4]; v->miss_al = c[5];
+    if (tab) {
+        for (int code = 0; code < 256; code++) {
+            const int k = tab[code], a1 = code >> 4, a2 = code & 0xF;
+            if (!k) continue;
+            if (a1 != 0xF) v->ac[a1] += k;
+            if (a2 != 0xF) v->ac[a2] += k;
+            if (a1 != 0xF && a2 != 0xF) v->gc[a1 * na + a2] += k;
+        }
+    } else {
+        v->ac[0] = c[6]; v->ac[1] = c[7];
+        v->gc[0] = c[0]; v->gc[1] = c[1]; v->gc[na] = c[2]; v->gc[na + 1] = c[3];
+    }
+}
+
+#define APPEND(...) do { int w_ = snprintf(dst + o, o < room ? room - o : 0, __VA_ARGS__); if (w_ < 0) return -1; o += (size_t)w_; } while (0)
+
+/* HPG_GTC / the stats file's genotype column: "i/j:count," for i <= j (both orders of a heterozygote together), then
+ * the missing genotypes -- report_variant_genotypes_stats, aggregate_runner.c:376-403 */
+static int append_gtc(char *dst, size_t room, size_t o0, const vcounts_t *v) {
+    size_t o = o0;
+    for (int i = 0; i < v->na; i++)
+        for (int j = i; j < v->na; j++)
+            APPEND("%d/%d:%d,", i, j, i == j ? v->gc[i * v->na + j] : v->gc[i * v->na + j] + v->gc[j * v->na + i]);
+    APPEND("./.:%d", v->miss_gt);
+    return (int)(o - o0);
+}
+
+static int g_aggregate_overwrite = 0;
+
+/* one line of the aggregated VCF (aggregate_runner.c:176-199): the record without its samples, INFO = the original
+ * fields (AC / AF / AN dropped when overwriting) followed by [HPG_]AC, [HPG_]AF, [HPG_]AN and HPG_GTC
+ * (merge_info_and_stats, :262-365; the reference emits the fields in the order of a hash table) */
+static int format_aggregate(char *dst, size_t room, const run_batch_t *b, int i) {
+    const uint32_t *fo = b->field_off + 10 * (size_t)i;
+    const char *l = b->text + b->line_off[i];
+    const char *eol = b->text + b->line_off[i + 1];
+    while (eol > l && (eol[-1] == '\n' || eol[-1] == '\r')) eol--;
+    size_t o = 0;
+    vcounts_t v;
+    record_counts(b, i, l + fo[4], (int)(fo[5] - 1 - fo[4]), &v);
+    /* CHROM .. ALT as they are; QUAL and FILTER when the line has them */
+    APPEND("%.*s", (int)(fo[5] - 1 - fo[0]), l + fo[0]);
+    const int has_q = fo[6] != 0xFFFFFFFFu || (fo[5] != 0xFFFFFFFFu && l + fo[5] < eol);
+    const char *q = l + fo[5], *qe = fo[6] != 0xFFFFFFFFu ? l + fo[6] - 1 : eol;
+    if (has_q && qe > q) APPEND("\t%.*s", (int)(qe - q), q); else APPEND("\t.");
+    const char *f = fo[6] != 0xFFFFFFFFu ? l + fo[6] : NULL, *fe = fo[7] != 0xFFFFFFFFu ? l + fo[7] - 1 : eol;
+    if (f && fe > f) APPEND("\t%.*s", (int)(fe - f), f); else APPEND("\t.");
+    const char *in = fo[7] != 0xFFFFFFFFu ? l + fo[7] : NULL, *ine = fo[8] != 0xFFFFFFFFu ? l + fo[8] - 1 : eol;
+    APPEND("\t");
+    if (in && ine > in && !(ine - in == 1 && in[0] == '.')) {
+        const char *p = in;
+        while (p < ine) {                                    /* field by field */
+            const char *e = (const char *)memchr(p, ';', (size_t)(ine - p));
+            if (!e) e = ine;
+            const int klen = (int)((const char *)memchr(p, '=', (size_t)(e - p)) ? (const char *)memchr(p, '=', (size_t)(e - p)) - p : e - p);
+            const int drop = g_aggregate_overwrite && klen == 2 && (!strncmp(p, "AC", 2) || !strncmp(p, "AF", 2) || !strncmp(p, "AN", 2));
+            if (!drop && e > p) APPEND("%.*s;", (int)(e - p), p);
+            p = e + 1;
+        }
+    }
+    const char *pre = g_aggregate_overwrite ? "" : "HPG_";
+    int ta = 0;
+    for (int k = 0; k < v.na; k++) ta += v.ac[k];
+    APPEND("%sAC=", pre);
+    for (int k = 1; k < v.na; k++) APPEND(k + 1 < v.na ? "%d," : "%d", v.ac[k]);
+    APPEND(";%sAF=", pre);
+    for (int k = 1; k < v.na; k++) APPEND(k + 1 < v.na ? "%.3f," : "%.3f", ta ? (float)v.ac[k] / ta : 0.0f);
+    APPEND(";%sAN=%d;HPG_GTC=", pre, ta);
+    const int w = append_gtc(dst, room, o, &v);
+    if (w < 0) return -1;
+    o += (size_t)w;
+    APPEND("\n");
+    return (int)o;
+}
+
+/* one line of <prefix>.stats-variants.  The reference's report_vcf_variant_stats lives in hpg-libs (not in the
+ * tree): this is the project's own tab-separated rendering of the same variant_stats_t fields. */
+static int format_stats_variant(char *dst, size_t room, const run_batch_t *b, int i) {
+    const uint32_t *fo = b->field_off + 10 * (size_t)i;
+    const char *l = b->text + b->line_off[i];
+    size_t o = 0;
+    vcounts_t v;
+    record_counts(b, i, l + fo[4], (int)(fo[5] - 1 - fo[4]), &v);
+    int ta = 0;
+    for (int k = 0; k < v.na; k++) ta += v.ac[k];
+    APPEND("%.*s\t%ld\t%.*s\t%.*s\t%d\t", (int)(fo[1] - 1 - fo[0]), l + fo[0], atol(l + fo[1]), (int)(fo[4] - 1 - fo[3]), l + fo[3],
+           (int)(fo[5] - 1 - fo[4]), l + fo[4], v.na);
+    for (int k = 0; k < v.na; k++) APPEND(k + 1 < v.na ? "%d," : "%d\t", v.ac[k]);
+    float maf = 1.0f;
+    for (int k = 0; k < v.na; k++) {
+        const float fr = ta ? (float)v.ac[k] / ta : 0.0f;
+        if (fr < maf) maf = fr;
+        APPEND(k + 1 < v.na ? "%.4f," : "%.4f\t", fr);
+    }
+    const int w = append_gtc(dst, room, o, &v);
+    if (w < 0) return -1;
+    o += (size_t)w;
+    APPEND("\t%d\t%d\t%.4f\t%d\t%.6g\t%.6g\n", v.miss_al, v.miss_gt, maf, b->merr[i], b->hw[i], b->hw[b->max_lines + i]);
+    return (int)o;
+}
+#undef APPEND
 
 /* formats the records of a batch by a thread team (one contiguous range of lines and one growing buffer per
  * task), then writes the buffers in line order */
@@ -1877,7 +2028,15 @@ static void *pipe_engine(void *v) {
          * engine reports the true count, the arrays grow and the batch is done again */
         for (int attempt = 0; attempt < 2; attempt++) {
             const int m = b->max_lines;
-            if (kind == 4)
+            if (kind == 5 || kind == 6) {
+                memset(b->smiss, 0, sizeof(int32_t) * (size_t)b->n_smiss);
+                memset(b->cerr, 0, sizeof(int32_t) * (size_t)b->n_cerr);
+                if (!b->mtab) { b->multi_cap = m; b->mtab = (int32_t *)malloc(sizeof(int32_t) * 256 * (size_t)m); if (!b->mtab) { rc = HPGV_ERR_NOMEM; break; } }
+                b->n_multi = b->multi_cap;
+                const int mend = kind == 6 && b->n_cerr > 0;
+                rc = hpgv_stats_text(g_ctx, b->text, b->bytes, m, &b->n_lines, b->line_off, b->field_off, b->status, b->c8, b->hw, b->hw + m,
+                                     kind == 6 ? b->smiss : NULL, b->midx, b->mtab, &b->n_multi, mend ? b->merr : NULL, mend ? b->cerr : NULL);
+            } else if (kind == 4)
                 rc = hpgv_epi_dataset_text(g_ctx, b->text, b->bytes, m, &b->n_lines, b->line_off, b->field_off, b->status, b->rows);
             else if (kind == 3)
                 rc = hpgv_tdt_text(g_ctx, b->text, b->bytes, m, &b->n_lines, b->line_off, b->field_off, b->status,
@@ -1887,6 +2046,7 @@ static void *pipe_engine(void *v) {
                                      b->ints, b->ints + m, b->ints + 2 * m, b->ints + 3 * m,
                                      b->dbl, kind == CHI_SQUARE ? b->dbl + m : NULL, b->dbl + 2 * m);
             if (rc || b->n_lines <= b->max_lines) break;
+            free(b->mtab); b->mtab = NULL;
             if (run_batch_reserve(b, b->n_lines)) { rc = HPGV_ERR_NOMEM; break; }
         }
         const double dt = now_s() - t0;
@@ -1894,7 +2054,7 @@ static void *pipe_engine(void *v) {
         P->t_engine += dt;
         if (rc) {
             char msg[256];
-            snprintf(msg, sizeof msg, "%s failed (%d): %s", kind == 4 ? "hpgv_epi_dataset_text" : kind == 3 ? "hpgv_tdt_text" : "hpgv_assoc_text", rc,
+            snprintf(msg, sizeof msg, "%s failed (%d): %s", kind >= 5 ? "hpgv_stats_text" : kind == 4 ? "hpgv_epi_dataset_text" : kind == 3 ? "hpgv_tdt_text" : "hpgv_assoc_text", rc,
                      rc == HPGV_ERR_NOMEM ? "out of memory" : hpgv_last_error(g_ctx));
             pipe_fail(P, rc, msg);
             pthread_mutex_unlock(&P->mu);
@@ -1906,6 +2066,75 @@ static void *pipe_engine(void *v) {
     }
 }
 
+/* ---- hpg-var-vcf stats: what the run accumulates besides the per-variant lines (sample_stats_t, file_stats_t;
+ *      the report writers live in hpg-libs, so the two files below are this project's rendering) ---- */
+typedef struct {
+    long *smiss, *serr;                                   /* per VCF column: missing genotypes, Mendelian errors as a child */
+    long variants, biallelic, multiallelic, snps, indels, transitions, transversions, pass, with_quality;
+    double quality_sum;
+} run_stats_t;
+
+static void run_stats_add(run_stats_t *R, const run_batch_t *b, int n_samples, const int32_t *trio_child) {
+    for (int j = 0; j < n_samples; j++) R->smiss[j] += b->smiss[j];      /* counted over every line of the batch, as get_sample_stats does */
+    for (int t = 0; t < b->n_cerr; t++) R->serr[trio_child[t]] += b->cerr[t];
+    const int n = b->n_lines < b->max_lines ? b->n_lines : b->max_lines;
+    for (int i = 0; i < n; i++) {
+        if (!record_passes(b, i)) continue;
+        const uint32_t *fo = b->field_off + 10 * (size_t)i;
+        const char *l = b->text + b->line_off[i];
+        const char *ref = l + fo[3], *alt = l + fo[4];
+        const int lr = (int)(fo[4] - 1 - fo[3]), la = (int)(fo[5] - 1 - fo[4]);
+        vcounts_t v;
+        record_counts(b, i, alt, la, &v);
+        R->variants++;
+        if (v.na > 2) R->multiallelic++; else R->biallelic++;
+        int snp = lr == 1, n_alt = 0;                      /* a SNP: REF and every ALT allele one base long */
+        for (int k = 0; k <= la; k++)
+            if (k == la || alt[k] == ',') { n_alt++; }
+        for (int k = 0, start = 0; k <= la && snp; k++)
+            if (k == la || alt[k] == ',') { if (k - start != 1 || alt[start] == '.') snp = 0; start = k + 1; }
+        if (snp) {
+            R->snps++;
+            if (n_alt == 1) {
+                const char a = (char)(ref[0] & ~0x20), c = (char)(alt[0] & ~0x20);
+                const int purine_a = a == 'A' || a == 'G', purine_c = c == 'A' || c == 'G';
+                if (purine_a == purine_c) R->transitions++; else R->transversions++;
+            }
+        } else if (!(la == 1 && alt[0] == '.')) R->indels++;
+        if (fo[6] != 0xFFFFFFFFu) {
+            const char *q = l + fo[5];
+            if (*q != '.' && *q != '\t') { R->quality_sum += strtod(q, NULL); R->with_quality++; }
+            const char *f = l + fo[6];
+            const int lf = fo[7] != 0xFFFFFFFFu ? (int)(fo[7] - 1 - fo[6]) : 0;
+            if (lf == 4 && !strncmp(f, "PASS", 4)) R->pass++;
+        }
+    }
+}
+
+static int run_stats_write(const run_stats_t *R, const char *prefix, char **names, int n_samples, long written) {
+    char *path = (char *)malloc(strlen(prefix) + 32);
+    if (!path) return HPGV_ERR_NOMEM;
+    sprintf(path, "%s.stats-samples", prefix);
+    FILE *f = fopen(path, "w");
+    if (!f) { snprintf(g_err, sizeof g_err, "cannot create %s", path); free(path); return HPGV_ERR_INVALID; }
+    fprintf(f, "#SAMPLE\tMISS_GT\tMEND_ER\n");
+    for (int j = 0; j < n_samples; j++) fprintf(f, "%s\t%ld\t%ld\n", names[j], R->smiss[j], R->serr[j]);
+    fclose(f);
+    sprintf(path, "%s.stats-summary", prefix);
+    f = fopen(path, "w");
+    if (!f) { snprintf(g_err, sizeof g_err, "cannot create %s", path); free(path); return HPGV_ERR_INVALID; }
+    fprintf(f, "Number of variants = %ld\nNumber of samples = %d\nNumber of biallelic variants = %ld\nNumber of multiallelic variants = %ld\n\n",
+            written, n_samples, R->biallelic, R->multiallelic);
+    fprintf(f, "Number of SNP = %ld\nNumber of indels = %ld\n\n", R->snps, R->indels);
+    fprintf(f, "Number of transitions = %ld\nNumber of transversions = %ld\nTi/TV ratio = %.4f\n\n", R->transitions, R->transversions,
+            R->transversions ? (double)R->transitions / (double)R->transversions : 0.0);
+    fprintf(f, "Percentage of PASS = %.2f%%\nAverage quality = %.2f\n", R->variants ? 100.0 * (double)R->pass / (double)R->variants : 0.0,
+            R->with_quality ? R->quality_sum / (double)R->with_quality : 0.0);
+    fclose(f);
+    free(path);
+    return HPGV_OK;
+}
+
 static int run_file(const char *vcf_path, const char *ped_path, const char *out_path, int kind, size_t batch_bytes,
                     long *n_variants_out) {
     int rc = ensure_engine();
@@ -1913,7 +2142,8 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     if (batch_bytes < (1u << 16)) batch_bytes = 1u << 16;
     const int io_threads = default_io_threads();
     ped_table_t ped;
-    if ((rc = ped_table_read(ped_path, &ped))) return rc;
+    memset(&ped, 0, sizeof ped);
+    if (ped_path || kind < 5) { if ((rc = ped_table_read(ped_path, &ped))) return rc; }      /* aggregate / stats run without a PED too */
     line_reader_t rd;
     memset(&rd, 0, sizeof rd);
     if (source_open(&rd.src, vcf_path)) {
@@ -1923,15 +2153,41 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     }
     char *hdr = NULL;
     char **names = NULL;
-    const int n_samples = vcf_header_read(&rd, &hdr, &names);
+    size_t chrom_off = 0;
+    const int n_samples = vcf_header_read(&rd, &hdr, &names, &chrom_off);
     if (n_samples < 0) { source_close(&rd.src); free(rd.carry); free(hdr); ped_table_free(&ped); snprintf(g_err, sizeof g_err, "no #CHROM header line in %s", vcf_path); return HPGV_ERR_INVALID; }
 
     /* cohort: PED rows looked up by sample name (associate_samples_and_positions + sort_individuals) */
     sample_ids_t *ids = sample_ids_new((size_t)n_samples);
     for (int j = 0; j < n_samples; j++) sample_ids_put(ids, names[j], j);
     uint32_t epi_aff = 0, epi_unaff = 0;
+    int n_trios = 0;
+    int32_t *trio_child = NULL;                          /* stats: VCF column of every trio's child */
     pthread_rwlock_wrlock(&g_cohort_lock);
-    if (kind == 3) {
+    if (kind >= 5) {
+        /* get_variants_stats / get_sample_stats over all columns; with a PED, the trios whose three members are VCF
+         * columns give the Mendelian errors (stats_runner.c:165-170,194-198) */
+        rc = hpgv_set_stats_cohort(g_ctx, n_samples);
+        g_stats_key.set = 0;
+        if (rc) host_fail("hpgv_set_stats_cohort", rc);
+        if (!rc && kind == 6 && ped.n > 0) {
+            int32_t *tf = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ped.n + 1)), *tm = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ped.n + 1));
+            trio_child = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ped.n + 1));
+            uint8_t *ts = (uint8_t *)malloc((size_t)ped.n + 1);
+            for (int i = 0; i < ped.n; i++) {
+                if (!strcmp(ped.pat[i], "0") || !strcmp(ped.mat[i], "0")) continue;
+                const int cp = sample_ids_get(ids, ped.iid[i]), fp = sample_ids_get(ids, ped.pat[i]), mp = sample_ids_get(ids, ped.mat[i]);
+                if (cp < 0 || fp < 0 || mp < 0) continue;
+                tf[n_trios] = fp; tm[n_trios] = mp; trio_child[n_trios] = cp; ts[n_trios] = (uint8_t)ped.sex[i]; n_trios++;
+            }
+            if (n_trios > 0) {
+                rc = hpgv_set_pedigree(g_ctx, n_samples, n_trios, tf, tm, trio_child, ts);
+                g_ped_key.set = 0;
+                if (rc) host_fail("hpgv_set_pedigree", rc);
+            }
+            free(tf); free(tm); free(ts);
+        }
+    } else if (kind == 3) {
         /* families in order of first appearance; father / mother = founders by sex (tdt.c:62-73);
          * counted children = rows with both parents named, affected, present in the VCF (tdt.c:139-148) */
         int32_t *fcol = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ped.n + 1)), *mcol = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ped.n + 1));
@@ -2018,8 +2274,19 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     pthread_rwlock_unlock(&g_cohort_lock);
     sample_ids_free(ids);
 
-    FILE *out = rc ? NULL : fopen(out_path, "wb");
-    if (!rc && !out) { snprintf(g_err, sizeof g_err, "cannot create %s", out_path); rc = HPGV_ERR_INVALID; }
+    char *path6 = NULL;
+    if (kind == 6) {
+        path6 = (char *)malloc(strlen(out_path) + 32);
+        if (path6) sprintf(path6, "%s.stats-variants", out_path); else rc = rc ? rc : HPGV_ERR_NOMEM;
+    }
+    FILE *out = rc ? NULL : fopen(kind == 6 ? path6 : out_path, "wb");
+    if (!rc && !out) { snprintf(g_err, sizeof g_err, "cannot create %s", kind == 6 ? path6 : out_path); rc = HPGV_ERR_INVALID; }
+    run_stats_t *RS = NULL;
+    if (!rc && kind == 6) {
+        RS = (run_stats_t *)calloc(1, sizeof *RS);
+        if (RS) { RS->smiss = (long *)calloc((size_t)n_samples + 1, sizeof(long)); RS->serr = (long *)calloc((size_t)n_samples + 1, sizeof(long)); }
+        if (!RS || !RS->smiss || !RS->serr) rc = HPGV_ERR_NOMEM;
+    }
     if (out) setvbuf(out, NULL, _IOFBF, 1u << 20);
     long written = 0;
     double t_sort = 0;
@@ -2028,10 +2295,23 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     out_buf_t *fmt = (out_buf_t *)calloc(RUN_FMT_BUFS, sizeof *fmt);
     int have = 0;
     if (!P || !fmt) rc = rc ? rc : HPGV_ERR_NOMEM;
-    for (; !rc && have < RUN_NB; have++) rc = run_batch_alloc(&P->bt[have], batch_bytes, n_samples, kind == 4 ? n_samples : 0);
+    for (; !rc && have < RUN_NB; have++) rc = run_batch_alloc(&P->bt[have], batch_bytes, n_samples, kind == 4 ? n_samples : 0, kind >= 5, n_trios);
     if (rc == HPGV_ERR_NOMEM) snprintf(g_err, sizeof g_err, "out of memory for the batch buffers");
     if (!rc) {
-        if (kind == 4) {                                 /* room for the number of variants, then the class sizes (dataset_creator.c:186-193) */
+        if (kind == 5) {
+            /* write_vcf_header_nosamples after add_aggregator_header (aggregate_runner.c:171-173,226-245): the file's
+             * meta lines, the INFO entries of the added fields (texts: etc/hpg-variant/vcf-info-fields.conf), the
+             * delimiter line without FORMAT and samples */
+            if (chrom_off && fwrite(hdr, 1, chrom_off, out) != chrom_off) rc = HPGV_ERR_INVALID;
+            const char *pre = g_aggregate_overwrite ? "" : "HPG_", *by = g_aggregate_overwrite ? "" : "Calculated by HPG Variant: ";
+            fprintf(out, "##INFO=<ID=%sAC,Number=.,Type=Integer,Description=\"%sAllele count in genotypes, for each ALT allele, in the same order as listed\">\n", pre, by);
+            fprintf(out, "##INFO=<ID=%sAF,Number=.,Type=Float,Description=\"%sAllele Frequency, for each ALT allele, in the same order as listed\">\n", pre, by);
+            fprintf(out, "##INFO=<ID=%sAN,Number=1,Type=Integer,Description=\"%sTotal number of alleles in called genotypes\">\n", pre, by);
+            fprintf(out, "##INFO=<ID=HPG_GTC,Number=.,Type=String,Description=\"Calculated by HPG Variant: Genotype counts, in pairs genotype:count\">\n");
+            fprintf(out, "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n");
+        } else if (kind == 6) {
+            fprintf(out, "#CHROM\tPOS\tREF\tALT\tNUM_ALLELES\tALLELES_COUNT\tALLELES_FREQ\tGENOTYPES_COUNT\tMISS_AL\tMISS_GT\tMAF\tMEND_ER\tHWE_CHI2\tHWE_P\n");
+        } else if (kind == 4) {                          /* room for the number of variants, then the class sizes (dataset_creator.c:186-193) */
             const uint32_t head[3] = {0, epi_aff, epi_unaff};
             if (fwrite(head, sizeof(uint32_t), 3, out) != 3) rc = HPGV_ERR_INVALID;
         } else if (kind == 3) tdt_write_output_header(out);
@@ -2068,6 +2348,7 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
             const run_batch_t *b = &P->bt[k];
             const int bad = write_batch(out, kind, b, fmt, n_fmt, &wpool);
             for (int i = 0; i < b->n_lines; i++) if (record_passes(b, i)) written++;
+            if (kind == 6 && !bad) run_stats_add(RS, b, n_samples, trio_child);
             const double dt = now_s() - t0;
             pthread_mutex_lock(&P->mu);
             P->t_write += dt;
@@ -2090,10 +2371,13 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     if (out && fclose(out) != 0 && !rc) { snprintf(g_err, sizeof g_err, "cannot write %s", out_path); rc = HPGV_ERR_INVALID; }
     {
         const double t0 = now_s();
-        if (!rc && kind != 4 && hpgv_host_sort_output_file(out_path))                /* assoc_runner.c:255-261: only a warning there */
+        if (!rc && kind < 4 && hpgv_host_sort_output_file(out_path))                /* assoc_runner.c:255-261: only a warning there */
             fprintf(stderr, "WARN: results could not be sorted by chromosome and position\n");
         t_sort = now_s() - t0;
     }
+    if (!rc && kind == 6) rc = run_stats_write(RS, out_path, names, n_samples, written);
+    if (RS) { free(RS->smiss); free(RS->serr); free(RS); }
+    free(path6); free(trio_child);
     for (int k = 0; P && k < have; k++) run_batch_free(&P->bt[k]);
     for (int k = 0; fmt && k < RUN_FMT_BUFS; k++) free(fmt[k].p);
     free(fmt); free(P);
@@ -2123,7 +2407,7 @@ int hpgv_host_copy_lines(const char *in_path, const char *out_path, size_t batch
     rd.src.pool = &pool;
     if (!rc && skip_vcf_header) {
         char *hdr = NULL, **names = NULL;
-        if (vcf_header_read(&rd, &hdr, &names) < 0) { snprintf(g_err, sizeof g_err, "no #CHROM header line in %s", in_path); rc = HPGV_ERR_INVALID; }
+        if (vcf_header_read(&rd, &hdr, &names, NULL) < 0) { snprintf(g_err, sizeof g_err, "no #CHROM header line in %s", in_path); rc = HPGV_ERR_INVALID; }
         free(hdr); free(names);
     }
     while (!rc) {
@@ -2156,6 +2440,22 @@ int hpgv_run_assoc(const char *vcf_path, const char *ped_path, const char *out_p
 
 int hpgv_run_tdt(const char *vcf_path, const char *ped_path, const char *out_path, size_t batch_bytes, long *n_variants_out) {
     return run_file(vcf_path, ped_path, out_path, 3, batch_bytes, n_variants_out);
+}
+
+/* run_aggregate (src/vcf-tools/aggregate/aggregate_runner.c:23-222) */
+int hpgv_run_aggregate(const char *vcf_path, const char *out_path, int overwrite, size_t batch_bytes, long *n_variants_out) {
+    g_aggregate_overwrite = overwrite ? 1 : 0;
+    return run_file(vcf_path, NULL, out_path, 5, batch_bytes, n_variants_out);
+}
+
+/* run_stats (src/vcf-tools/stats/stats_runner.c:23-420) without the per-phenotype files and the database */
+int hpgv_run_stats(const char *vcf_path, const char *ped_path, const char *out_prefix, size_t batch_bytes, long *n_variants_out) {
+    /* the per-sample counters are sums over every data line of a batch, so the record filters are not applied here */
+    const hpgv_run_filters_t saved = g_filters;
+    hpgv_run_set_filters(NULL);
+    const int rc = run_file(vcf_path, ped_path, out_prefix, 6, batch_bytes, n_variants_out);
+    g_filters = saved;
+    return rc;
 }
 
 int hpgv_run_vcf2epi(const char *vcf_path, const char *ped_path, const char *out_path, size_t batch_bytes, long *n_variants_out) {

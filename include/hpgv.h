@@ -236,6 +236,15 @@ int  hpgv_stats_groups(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_var
  * non-reference, 255 missing.  Uses the cohort of hpgv_set_cohort. */
 int  hpgv_epi_dataset(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, uint8_t *out);
 
+/* hpgv_stats_ex (+ hpgv_mendel) on a batch of VCF text: what get_variants_stats and get_sample_stats need
+ * (stats_runner.c:194-198, aggregate_runner.c:113-114), tokenized on the device.  sample_missing (n_samples ints)
+ * and child_errors (one per trio of hpgv_set_pedigree) are ACCUMULATED into; mendel_errors[v] per line; any of the
+ * three may be NULL.  Multi-allelic lines as in hpgv_stats_ex. */
+int  hpgv_stats_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_lines, int *n_lines,
+                     uint64_t *line_off, uint32_t *field_off, int32_t *status, int32_t *counts8,
+                     double *hwe_chi2, double *hwe_p, int32_t *sample_missing, int32_t *multi_idx,
+                     int32_t *multi_table, int *n_multi, int32_t *mendel_errors, int32_t *child_errors);
+
 /* record filters of the text entry points, computed on the device from the tokenized matrix before the tool's own
  * scan: --maf (keep minor-allele frequency >= min_maf), --missing (keep missing-genotype rate <= max_missing),
  * --mendel (keep Mendelian errors <= max_mendel_errors) -- shared_options.c:44-46,101-115; the filter bodies live

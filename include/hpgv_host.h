@@ -297,6 +297,19 @@ void hpgv_run_set_filters(const hpgv_run_filters_t *filters);
  * every sample that is not AFFECTED counts as unaffected (dataset_creator.c:279-300) */
 int  hpgv_run_vcf2epi(const char *vcf_path, const char *ped_path, const char *out_path,
                       size_t batch_bytes, long *n_variants_out);
+/* run_aggregate (src/vcf-tools/aggregate/aggregate_runner.c:23-222): the VCF without its samples, every record's
+ * INFO extended by HPG_AC, HPG_AF, HPG_AN (AC / AF / AN replacing the record's own with overwrite != 0) and HPG_GTC,
+ * computed by get_variants_stats on the GPU.  Values as merge_info_and_stats (:262-365) and
+ * report_variant_genotypes_stats (:376-403) print them; the order of the INFO fields is original fields first, then
+ * AC, AF, AN, GTC (the reference walks a hash table); QUAL is copied as written. */
+int  hpgv_run_aggregate(const char *vcf_path, const char *out_path, int overwrite, size_t batch_bytes,
+                        long *n_variants_out);
+/* run_stats (src/vcf-tools/stats/stats_runner.c:23-420): <out_prefix>.stats-variants / .stats-samples /
+ * .stats-summary from one pass over the VCF (ped_path may be NULL: no Mendelian errors then).  The report
+ * writers of the reference live in hpg-libs; the three files are tab-separated renderings of the same fields
+ * (header lines name the columns). */
+int  hpgv_run_stats(const char *vcf_path, const char *ped_path, const char *out_prefix, size_t batch_bytes,
+                    long *n_variants_out);
 /* stage times of the last run on this process: {read, engine, write, sort, total} seconds and the number of
  * batches; read / engine / write overlap (three threads, three batch buffers in rotation).  The reader and
  * formatter teams use HPGV_IO_THREADS threads (environment; default half the cores, at most 16);

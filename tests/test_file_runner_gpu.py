@@ -254,3 +254,106 @@ def test_run_assoc_with_record_filters(host, tmp_path, which):
     got = open(filt).read().splitlines()[1:]
     assert sorted(int(l.split("\t")[1]) for l in got) == [1000 + v for v in np.flatnonzero(keep)]
     assert all(l == all_lines[int(l.split("\t")[1])] for l in got)
+
+
+def _stats_inputs(tmp_path, rng, n_fam, n_extra, n_variants):
+    people, names, rows = _write_inputs(tmp_path, rng, n_fam, n_extra, n_variants)
+    alts = [["C", "C,G", "CT", "C,G,T"][v % 4] for v in range(len(rows))]
+    infos = [[".", "DP=10;AC=3;DB=1", "AF=0.5", "NS=3;AN=7"][v % 4] for v in range(len(rows))]
+    quals = [[".", "10", "35.5", "90"][v % 4] for v in range(len(rows))]
+    filts = [["PASS", "q10", ".", "PASS"][(v // 2) % 4] for v in range(len(rows))]
+    with open(tmp_path / "in.vcf", "w") as f:
+        f.write("##fileformat=VCFv4.1\n##source=test\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n")
+        for v, (chrom, fmt, samples) in enumerate(rows):
+            f.write("%s\t%d\trs%d\tA\t%s\t%s\t%s\t%s\t%s\t%s\n" % (chrom, 1000 + v, v, alts[v], quals[v], filts[v], infos[v], fmt, "\t".join(samples)))
+    return people, names, rows, alts, infos, quals, filts
+
+
+def _expected_counts(code_row, alt):
+    """variant_stats_t of one record as get_variants_stats fills it (alleles seen in the calls extend num_alleles)."""
+    na = 1 if alt == "." else 1 + len(alt.split(","))
+    used = [n for code in code_row for n in (code >> 4, code & 0xF) if n != 0xF]
+    na = max(2, na, (max(used) + 1) if used else 2)
+    return na, orc.variant_stats(code_row, na)
+
+
+def _gtc(vs, na):
+    parts = []
+    for i in range(na):
+        for j in range(i, na):
+            c = vs.genotypes_count[i * na + j] if i == j else vs.genotypes_count[i * na + j] + vs.genotypes_count[j * na + i]
+            parts.append("%d/%d:%d" % (i, j, c))
+    return ",".join(parts) + ",./.:%d" % vs.missing_genotypes
+
+
+@pytest.mark.parametrize("overwrite", [0, 1])
+def test_run_aggregate(host, tmp_path, overwrite):
+    # run_aggregate (aggregate_runner.c:23-222): samples dropped, INFO extended by the allele / genotype counts
+    host.hpgv_run_aggregate.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_size_t, C.POINTER(C.c_long)]
+    rng = np.random.default_rng(61)
+    people, names, rows, alts, infos, quals, filts = _stats_inputs(tmp_path, rng, 10, 30, 260)
+    out = str(tmp_path / "in.vcf.aggregated")
+    n = C.c_long(0)
+    rc = host.hpgv_run_aggregate(str(tmp_path / "in.vcf").encode(), out.encode(), overwrite, 1 << 16, C.byref(n))
+    assert rc == 0 and n.value == len(rows), host.hpgv_host_last_error()
+    lines = open(out).read().splitlines()
+    pre = "" if overwrite else "HPG_"
+    assert lines[:2] == ["##fileformat=VCFv4.1", "##source=test"]
+    assert [l.split(",")[0] for l in lines[2:6]] == ["##INFO=<ID=%sAC" % pre, "##INFO=<ID=%sAF" % pre, "##INFO=<ID=%sAN" % pre, "##INFO=<ID=HPG_GTC"]
+    assert lines[6] == "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO" and len(lines) == 7 + len(rows)
+    lax = _codes(rows, False)
+    for v, line in enumerate(lines[7:]):
+        t = line.split("\t")
+        assert t[:7] == [rows[v][0], str(1000 + v), "rs%d" % v, "A", alts[v], quals[v], filts[v]], v
+        na, vs = _expected_counts(lax[v], alts[v])
+        total = sum(vs.alleles_count[:na])
+        kept = [] if infos[v] == "." else [f for f in infos[v].split(";") if not (overwrite and f.split("=")[0] in ("AC", "AF", "AN"))]
+        exp = kept + ["%sAC=%s" % (pre, ",".join(str(vs.alleles_count[k]) for k in range(1, na))),
+                      "%sAF=%s" % (pre, ",".join("%.3f" % (np.float32(vs.alleles_count[k]) / np.float32(total) if total else 0.0) for k in range(1, na))),
+                      "%sAN=%d" % (pre, total), "HPG_GTC=" + _gtc(vs, na)]
+        assert t[7] == ";".join(exp), (v, t[7], ";".join(exp))
+
+
+def test_run_stats_files(host, tmp_path):
+    # run_stats (stats_runner.c:23-420): per-variant counters, per-sample counters, file summary
+    host.hpgv_run_stats.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_long)]
+    rng = np.random.default_rng(62)
+    people, names, rows, alts, infos, quals, filts = _stats_inputs(tmp_path, rng, 20, 15, 330)
+    prefix = str(tmp_path / "in.vcf")
+    n = C.c_long(0)
+    rc = host.hpgv_run_stats(prefix.encode(), str(tmp_path / "ped.txt").encode(), prefix.encode(), 1 << 16, C.byref(n))
+    assert rc == 0 and n.value == len(rows), host.hpgv_host_last_error()
+    lax = _codes(rows, False)
+    is_x = np.array([1 if c == "X" else 0 for c, _, _ in rows], np.uint8)
+    col = {nm: i for i, nm in enumerate(names)}
+    trios = [(col[p[2]], col[p[3]], col[p[1]], orc.MALE if p[4] == 1 else orc.FEMALE) for p in people if p[2] != "0" and p[3] != "0"]
+    merr, trio_err = orc.mendel_counts(lax, [t[0] for t in trios], [t[1] for t in trios], [t[2] for t in trios], [t[3] for t in trios], is_x)
+    vl = open(prefix + ".stats-variants").read().splitlines()
+    assert vl[0].split("\t")[:5] == ["#CHROM", "POS", "REF", "ALT", "NUM_ALLELES"] and len(vl) == 1 + len(rows)
+    for v, line in enumerate(vl[1:]):
+        t = line.split("\t")
+        na, vs = _expected_counts(lax[v], alts[v])
+        total = sum(vs.alleles_count[:na])
+        assert t[:5] == [rows[v][0], str(1000 + v), "A", alts[v], str(na)]
+        assert t[5] == ",".join(str(vs.alleles_count[k]) for k in range(na)) and t[7] == _gtc(vs, na)
+        assert t[6] == ",".join("%.4f" % (np.float32(vs.alleles_count[k]) / np.float32(total) if total else 0.0) for k in range(na))
+        assert (int(t[8]), int(t[9]), int(t[11])) == (vs.missing_alleles, vs.missing_genotypes, merr[v])
+        for g, e in ((_fl(t[12]), vs.hw_chi2), (_fl(t[13]), vs.hw_p)):
+            assert (np.isnan(g) and np.isnan(e)) or abs(g - e) <= 1e-5 * max(1.0, abs(e))
+    sl = open(prefix + ".stats-samples").read().splitlines()
+    miss = orc.sample_missing(lax)
+    exp_err = np.zeros(len(names), np.int64)
+    for t, e in zip(trios, trio_err):
+        exp_err[t[2]] += e
+    assert sl[0] == "#SAMPLE\tMISS_GT\tMEND_ER"
+    assert [l.split("\t") for l in sl[1:]] == [[names[j], str(miss[j]), str(exp_err[j])] for j in range(len(names))]
+    summary = open(prefix + ".stats-summary").read()
+    n_multi = sum(1 for v in range(len(rows)) if _expected_counts(lax[v], alts[v])[0] > 2)
+    assert "Number of variants = %d\nNumber of samples = %d\nNumber of biallelic variants = %d\nNumber of multiallelic variants = %d" % (
+        len(rows), len(names), len(rows) - n_multi, n_multi) in summary
+    snps = sum(1 for a in alts if all(len(x) == 1 for x in a.split(",")))
+    assert "Number of SNP = %d\nNumber of indels = %d" % (snps, len(rows) - snps) in summary
+    assert "Number of transitions = 0\nNumber of transversions = %d" % sum(1 for a in alts if a == "C") in summary      # A>C only
+    assert "Percentage of PASS = %.2f%%" % (100.0 * sum(1 for f in filts if f == "PASS") / len(rows)) in summary
+    qs = [float(q) for q in quals if q != "."]
+    assert "Average quality = %.2f" % (sum(qs) / len(qs)) in summary
