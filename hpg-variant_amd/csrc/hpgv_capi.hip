@@ -76,6 +76,7 @@ struct hpgv_ctx {
     long blocks_per_cu = 8;
     long pipeline = 1;         // 1: software-pipelined scan (loads of the next tile before counting this one)
     long pipe_waves = 4;       // register budget of the pipelined scan, as waves per SIMD (4, 6 or 8)
+    long scan_lds = 0;         // bytes of (unused) LDS per workgroup of the stats / tdt scans: caps the waves in flight per CU
     int n_cus = 256;
     // assoc
     Layout assoc;
@@ -320,6 +321,9 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
         ctx->scan_unroll = value;
     } else if (!strcmp(key, "pipeline")) {
         ctx->pipeline = value ? 1 : 0;
+    } else if (!strcmp(key, "scan_lds")) {
+        if (value < 0 || value > 160 * 1024) return fail(ctx, HPGV_ERR_INVALID, "scan_lds must be in [0, 163840]");
+        ctx->scan_lds = value;
     } else if (!strcmp(key, "pipe_waves")) {
         if (value != 4 && value != 6 && value != 8) return fail(ctx, HPGV_ERR_INVALID, "pipe_waves must be 4, 6 or 8");
         ctx->pipe_waves = value;
@@ -804,7 +808,12 @@ int hpgv_stats_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, int3
     const unsigned blocks = (unsigned)((waves + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
     return launch_profiled(ctx, st, 0, [&] {
-        if (ctx->nontemporal)
+        if (ctx->pipeline) {                              // bit-sliced counting, pipelined tiles (default)
+            if (ctx->nontemporal)
+                hipLaunchKernelGGL((hpgv::k_stats_scan_hs<true>), dim3(blocks), dim3(256), (size_t)ctx->scan_lds, st, d_gt, L.pitch, n_variants, 0u, L.chunks, (int4 *)d_counts8, vpw);
+            else
+                hipLaunchKernelGGL((hpgv::k_stats_scan_hs<false>), dim3(blocks), dim3(256), 0, st, d_gt, L.pitch, n_variants, 0u, L.chunks, (int4 *)d_counts8, vpw);
+        } else if (ctx->nontemporal)
             hipLaunchKernelGGL((hpgv::k_stats_scan<true, kScanUnroll>), dim3(blocks), dim3(256), 0, st, d_gt, L.pitch,
                                n_variants, 0u, L.chunks, (int4 *)d_counts8, vpw);
         else
@@ -829,7 +838,12 @@ int hpgv_stats_scan_group_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants
     const int chunks = (int)(round_up((size_t)ctx->sg_size[(size_t)group], 16) / 16);
     hipStream_t st = (hipStream_t)stream;
     return launch_profiled(ctx, st, 0, [&] {
-        if (ctx->nontemporal)
+        if (ctx->pipeline) {
+            if (ctx->nontemporal)
+                hipLaunchKernelGGL((hpgv::k_stats_scan_hs<true>), dim3(blocks), dim3(256), 0, st, d_gt, L.pitch, n_variants, off, chunks, (int4 *)d_counts8, vpw);
+            else
+                hipLaunchKernelGGL((hpgv::k_stats_scan_hs<false>), dim3(blocks), dim3(256), 0, st, d_gt, L.pitch, n_variants, off, chunks, (int4 *)d_counts8, vpw);
+        } else if (ctx->nontemporal)
             hipLaunchKernelGGL((hpgv::k_stats_scan<true, kScanUnroll>), dim3(blocks), dim3(256), 0, st, d_gt, L.pitch,
                                n_variants, off, chunks, (int4 *)d_counts8, vpw);
         else
