@@ -167,3 +167,22 @@ def test_k_folds_reference_kat_and_mask_layout(kat):
         for f in range(k):
             out = set(np.flatnonzero(real[f] == 0).tolist())
             assert out == set(folds[f][j] for j in range(sizes[3 * f]))
+
+
+def test_count_invariants_of_the_oracle():
+    """Size-independent properties the GPU tests rely on at full size: cells partition the fully called samples;
+    training counts of the folds of a partition add up to (k - 1) x the totals; a pair and its transpose."""
+    rng = np.random.default_rng(77)
+    nA, nU, k = 123, 211, 6
+    data = epi_random_dataset(rng, 5, nA, nU, p_missing=0.1)
+    fold = epi_random_folds(rng, nA, nU, k)
+    masks = orc.fold_masks_from_assignment(fold, k)
+    for rows in ([data[0], data[1]], [data[2], data[3], data[4]]):
+        a, u = orc.epi_counts(rows, nA, nU)
+        called = np.all(np.stack(rows) < 3, axis=0)
+        assert a.sum() == called[:nA].sum() and u.sum() == called[nA:].sum()
+        fa, fu = orc.epi_counts_all_folds(rows, nA, nU, masks)
+        assert np.array_equal(fa.sum(axis=0), (k - 1) * a) and np.array_equal(fu.sum(axis=0), (k - 1) * u)
+    a01, _ = orc.epi_counts([data[0], data[1]], nA, nU)
+    a10, _ = orc.epi_counts([data[1], data[0]], nA, nU)
+    assert np.array_equal(a01.reshape(3, 3), a10.reshape(3, 3).T)

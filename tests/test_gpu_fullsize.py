@@ -195,3 +195,55 @@ def test_tdt_every_variant_against_the_oracle_c4():
         t1, t2 = orc.tdt_counts(raw, *fam)
         assert np.array_equal(tu[:, 0], t1) and np.array_equal(tu[:, 1], t2), lo
     e.close()
+
+
+def test_epistasis_pair_scan_full_size():
+    """4096 SNPs x 10 000 samples x 10 folds (8.4 M pairs): properties over every pair, the ranking against the dense
+    scan, and an oracle sample of pairs bit for bit."""
+    from helpers import epi_random_dataset, epi_random_folds
+    rng = np.random.default_rng(2024)
+    V, nA, nU, K, N = 4096, 5200, 4800, 10, 10
+    data = epi_random_dataset(rng, V, nA, nU, p_missing=0.01)
+    data[100, :nA] = rng.choice([1, 2], size=nA); data[3000, :nA] = rng.choice([1, 2], size=nA)     # a planted interaction
+    fold = epi_random_folds(rng, nA, nU, K)
+    e = hpgv.Engine(0)
+    e.epi_set_dataset(data, nA, nU)
+    e.epi_set_folds(fold, K)
+    res = e.epi_rank_pairs(hpgv.EPI_TESTING, N)
+    assert (int(res["i"][0][0]), int(res["j"][0][0])) == (100, 3000)
+    # dense scan of two row bands: the ranking's entries inside the bands are the bands' best
+    for lo, hi in ((64, 192), (2944, 3072)):
+        acc, rm = e.epi_scan_pairs(hpgv.EPI_TESTING, lo, hi)
+        with np.errstate(invalid="ignore"):
+            assert ((acc >= 0) & (acc <= 1) | np.isnan(acc)).all()
+        assert (rm < 512).all()
+        pairs_i = np.concatenate([np.full(V - 1 - i, i) for i in range(lo, hi)])
+        pairs_j = np.concatenate([np.arange(i + 1, V) for i in range(lo, hi)])
+        for f in range(K):
+            inside = [(int(a), int(b), float(c)) for a, b, c in zip(res["i"][f], res["j"][f], res["accuracy"][f]) if lo <= a < hi]
+            best = np.nanmax(acc[f])
+            assert all(c <= best for _, _, c in inside)
+            for a, b, c in inside:
+                p = np.flatnonzero((pairs_i == a) & (pairs_j == b))[0]
+                assert acc[f][p] == c
+            if res["n"][f] == N:                                     # nothing in the band beats the ranking's last entry unless listed
+                thr = res["accuracy"][f][N - 1]
+                above = np.flatnonzero(acc[f] > thr)
+                assert set(zip(pairs_i[above].tolist(), pairs_j[above].tolist())) <= set(zip(res["i"][f].tolist(), res["j"][f].tolist()))
+    # oracle sample
+    masks = orc.fold_masks_from_assignment(fold, K)
+    sel = [(int(a), int(b)) for a, b in zip(rng.integers(0, V - 1, 60), rng.integers(0, V, 60)) if a < b] + [(100, 3000), (0, 1), (V - 2, V - 1)]
+    for (i, j) in sel:
+        ea, em, _ = orc.epi_model([data[i], data[j]], nA, nU, masks, 0)
+        ib = i // 64 * 64
+        acc, rm = e.epi_scan_pairs(hpgv.EPI_TESTING, i, i + 1)
+        p = j - i - 1
+        assert np.array_equal(rm[:, p], em.astype(np.uint16)), (i, j)
+        assert np.all((acc[:, p] == ea) | (np.isnan(acc[:, p]) & np.isnan(ea))), (i, j)
+    # counts: every sample called at both SNPs falls in exactly one cell
+    combs = np.array(sel[:20], np.int32)
+    aff, unaff = e.epi_counts(combs)
+    for n_, (i, j) in enumerate(sel[:20]):
+        both = (data[i] < 3) & (data[j] < 3)
+        assert aff[n_].sum() == both[:nA].sum() and unaff[n_].sum() == both[nA:].sum()
+    e.close()
