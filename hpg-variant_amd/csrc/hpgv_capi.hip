@@ -76,6 +76,7 @@ struct hpgv_ctx {
     long blocks_per_cu = 8;
     long pipeline = 1;         // 1: software-pipelined scan (loads of the next tile before counting this one)
     long pipe_waves = 4;       // register budget of the pipelined scan, as waves per SIMD (4, 6 or 8)
+    long epi_dma = 1;          // epistasis pair scan: stage the planes with global_load_lds (LDS-DMA) instead of through registers
     long scan_lds = 0;         // bytes of (unused) LDS per workgroup of the stats / tdt scans: caps the waves in flight per CU
     int n_cus = 256;
     // assoc
@@ -321,6 +322,8 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
         ctx->scan_unroll = value;
     } else if (!strcmp(key, "pipeline")) {
         ctx->pipeline = value ? 1 : 0;
+    } else if (!strcmp(key, "epi_dma")) {
+        ctx->epi_dma = value ? 1 : 0;
     } else if (!strcmp(key, "scan_lds")) {
         if (value < 0 || value > 160 * 1024) return fail(ctx, HPGV_ERR_INVALID, "scan_lds must be in [0, 163840]");
         ctx->scan_lds = value;

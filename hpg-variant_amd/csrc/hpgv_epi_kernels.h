@@ -161,8 +161,8 @@ __global__ void __launch_bounds__(256) k_epi_counts(const uint32_t *__restrict__
 // registers: 9 running counts of the current group + K x 9 finished groups, two 16-bit counts per register
 // (affected low, unaffected high: a (fold, class) group holds fewer than 65536 samples).
 // ---------------------------------------------------------------------------
-template <int K, bool TRAINING, bool BALANCED>
-__global__ void __launch_bounds__(256) k_epi_pairs(const uint32_t *__restrict__ planes, int W, int n_variants, int i_begin, int i_first, int i_end,
+template <int K, bool TRAINING, bool BALANCED, bool DMA>
+__global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(const uint32_t *__restrict__ planes, int W, int n_variants, int i_begin, int i_first, int i_end,
                                                     const unsigned *__restrict__ tile_base, int n_q, int tiles_j,
                                                     const EpiChunk *__restrict__ chunks, int n_chunks,
                                                     const EpiFold *__restrict__ folds /* K */, int n_affected, int n_unaffected,
@@ -170,7 +170,11 @@ __global__ void __launch_bounds__(256) k_epi_pairs(const uint32_t *__restrict__ 
                                                     unsigned long long rank_base,
                                                     const double *__restrict__ thr, EpiCand *__restrict__ cand,
                                                     unsigned *__restrict__ cand_count, unsigned cand_cap) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2][(EPI_TJ + EPI_TI) * 3 * EPI_ROW];
+    // register-staged: rows pitched 36 words; LDS-DMA (DMA): 26 x 8 linear rows of 32 words, the 16-byte pieces of a row
+    // swizzled by the column index so that the per-lane reads of 16 lanes fall on 16 different slots
+    constexpr int RP = DMA ? EPI_CH : EPI_ROW;
+    constexpr int LROWS = DMA ? 208 : (EPI_TJ + EPI_TI) * 3;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2][LROWS * RP];
     // blockIdx.x numbers the tiles that hold at least one pair: row block ti = blockIdx.x / tiles_j owns the column
     // tiles from its diagonal tile on; tile_base[q] = tiles before the 16 row blocks whose rows start at 64 * q
     // relative to i_begin (i_begin is a multiple of 64), found by bisection
@@ -184,10 +188,28 @@ __global__ void __launch_bounds__(256) k_epi_pairs(const uint32_t *__restrict__ 
 
     // ---- staging: piece q = one 16-byte piece of one (snp, plane) row of the chunk ----
     constexpr int ROWS = (EPI_TJ + EPI_TI) * 3, PIECES = ROWS * (EPI_CH / 4), PER_T = (PIECES + 255) / 256;
-    uint4 stage[PER_T];
-    auto load_chunk = [&](int c) {
+    uint4 stage[DMA ? 1 : PER_T];
+    auto load_chunk = [&](int c, int buf) {
         const uint32_t w0 = chunks[c].w0;
         const int nw = (int)chunks[c].nw;
+        if constexpr (DMA) {
+            // one global_load_lds_dwordx4 = 64 lanes x 16 B = 8 rows of the image; lane l fetches row 8k + l / 8, physical
+            // piece l % 8, i.e. the logical piece (l % 8) ^ swizzle(row's SNP): the swizzle sits on the source address
+            #pragma unroll
+            for (int r = 0; r < 7; r++) {
+                const int k = wave + 4 * r;
+                if (k < 26) {
+                    const int row = 8 * k + (lane >> 3), snp_idx = row / 3;
+                    const int piece = (lane & 7) ^ ((snp_idx >> 1) & 7);
+                    if (row < ROWS && piece * 4 < nw) {
+                        const int snp = snp_idx < EPI_TJ ? j0 + snp_idx : i0 + (snp_idx - EPI_TJ);
+                        const uint32_t *src = planes + ((size_t)snp * 3 + row % 3) * W + w0 + piece * 4;
+                        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) uint32_t *)&lds[buf][8 * k * EPI_CH], 16, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
         #pragma unroll
         for (int r = 0; r < PER_T; r++) {
             const int q = t + 256 * r, row = q >> 3, piece = q & 7;
@@ -199,6 +221,7 @@ __global__ void __launch_bounds__(256) k_epi_pairs(const uint32_t *__restrict__ 
         }
     };
     auto store_chunk = [&](int buf) {
+        if constexpr (DMA) return;
         #pragma unroll
         for (int r = 0; r < PER_T; r++) {
             const int q = t + 256 * r, row = q >> 3, piece = q & 7;
@@ -215,21 +238,22 @@ __global__ void __launch_bounds__(256) k_epi_pairs(const uint32_t *__restrict__ 
     #pragma unroll
     for (int c = 0; c < 9; c++) run[c] = 0;
 
-    load_chunk(0);
+    load_chunk(0, 0);
     store_chunk(0);
     __syncthreads();
+    const int swz_j = DMA ? ((lane >> 1) & 7) : 0, swz_i = DMA ? (((EPI_TJ + wave) >> 1) & 7) : 0;
     for (int c = 0; c < n_chunks; c++) {
         const int cur = c & 1;
-        if (c + 1 < n_chunks) load_chunk(c + 1);                     // global loads of the next chunk fly during the counting
+        if (c + 1 < n_chunks) load_chunk(c + 1, cur ^ 1);            // the next chunk's loads fly during the counting
         const int nw = (int)chunks[c].nw;
         const uint64_t flush = chunks[c].flush;                      // wave-uniform
-        const uint32_t *jrow = &lds[cur][lane * 3 * EPI_ROW];
-        const uint32_t *irow = &lds[cur][(EPI_TJ + wave) * 3 * EPI_ROW];   // the wave's own row: same address in every lane (broadcast)
+        const uint32_t *jrow = &lds[cur][lane * 3 * RP];
+        const uint32_t *irow = &lds[cur][(EPI_TJ + wave) * 3 * RP];  // the wave's own row: same address in every lane (broadcast)
         uint4 xa[3], ya[3], xb[3], yb[3];
 #define HPGV_EPI_FETCH(X, Y, S)                                                                          \
         _Pragma("unroll") for (int a = 0; a < 3; a++) {                                                  \
-            X[a] = *reinterpret_cast<const uint4 *>(irow + a * EPI_ROW + (S));                           \
-            Y[a] = *reinterpret_cast<const uint4 *>(jrow + a * EPI_ROW + (S));                           \
+            X[a] = *reinterpret_cast<const uint4 *>(irow + a * RP + (((((S) >> 2) ^ swz_i)) << 2));          \
+            Y[a] = *reinterpret_cast<const uint4 *>(jrow + a * RP + (((((S) >> 2) ^ swz_j)) << 2));          \
         }
 #define HPGV_EPI_COUNT(X, Y, S)                                                                          \
         _Pragma("unroll") for (int a = 0; a < 3; a++)                                                    \
@@ -250,12 +274,21 @@ __global__ void __launch_bounds__(256) k_epi_pairs(const uint32_t *__restrict__ 
                 _Pragma("unroll") for (int cc = 0; cc < 9; cc++) run[cc] = 0;                            \
             }                                                                                            \
         }
-        HPGV_EPI_FETCH(xa, ya, 0)
-        for (int s = 0; s < nw; s += 8) {
-            HPGV_EPI_FETCH(xb, yb, s + 4)
-            HPGV_EPI_COUNT(xa, ya, s)
-            if (s + 8 < nw) { HPGV_EPI_FETCH(xa, ya, s + 8) }
-            HPGV_EPI_COUNT(xb, yb, s + 4)
+        if constexpr (DMA && K > 5) {
+            // three waves per SIMD hide the LDS latency; one register set keeps the kernel within their 168 VGPRs
+            for (int s = 0; s < nw; s += 4) {
+                HPGV_EPI_FETCH(xa, ya, s)
+                HPGV_EPI_COUNT(xa, ya, s)
+            }
+            (void)xb; (void)yb;
+        } else {
+            HPGV_EPI_FETCH(xa, ya, 0)
+            for (int s = 0; s < nw; s += 8) {
+                HPGV_EPI_FETCH(xb, yb, s + 4)
+                HPGV_EPI_COUNT(xa, ya, s)
+                if (s + 8 < nw) { HPGV_EPI_FETCH(xa, ya, s + 8) }
+                HPGV_EPI_COUNT(xb, yb, s + 4)
+            }
         }
 #undef HPGV_EPI_FETCH
 #undef HPGV_EPI_COUNT

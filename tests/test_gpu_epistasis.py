@@ -10,9 +10,10 @@ from oracle import pyoracle as orc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=[0, 1], ids=["regstage", "ldsdma"])
+def eng(request):
     e = hpgv.Engine(0)
+    e.set_option("epi_dma", request.param)        # both staging paths of the pair scan
     yield e
     e.close()
 

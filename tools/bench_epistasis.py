@@ -28,6 +28,8 @@ fold = np.empty(nA + nU, np.int32)
 fold[rng.permutation(nA)] = np.arange(nA) % K
 fold[nA + rng.permutation(nU)] = np.arange(nU) % K
 e = hpgv.Engine(0)
+for kv in [a[len('--option='):] for a in sys.argv[1:] if a.startswith('--option=')]:
+    e.set_option(kv.split('=')[0], int(kv.split('=')[1]))
 t0 = time.perf_counter()
 e.epi_set_dataset(data, nA, nU)
 e.epi_set_folds(fold, K)
