@@ -594,12 +594,18 @@ int hpgv_layout_dev(hpgv_ctx *ctx, int which, const uint8_t *d_src, size_t src_p
     if (src_pitch < (size_t)L->n_samples) return fail(ctx, HPGV_ERR_INVALID, "src_pitch %zu < n_samples %d", src_pitch, L->n_samples);
     if (n_variants == 0) return HPGV_OK;
     DeviceGuard g(ctx->device);
-    const long total = (long)n_variants * L->chunks;
     const int strict = (which == HPGV_LAYOUT_STATS || which == HPGV_LAYOUT_STATS_GROUPS) ? 0 : 1;
     int mode, p16;
     recode_of(ctx, which, &mode, &p16);
-    hipLaunchKernelGGL(hpgv::k_layout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       d_src, src_pitch, n_variants, L->pitch, L->chunks, L->d_col_of_pos, strict, mode, p16, d_dst);
+    // one thread per 16-byte chunk; slabs of variants keep a launch below 2^31 threads
+    const long slab = std::max(1L, (1L << 31) / (L->chunks > 0 ? L->chunks : 1));
+    for (long off = 0; off < n_variants; off += slab) {
+        const int n = (int)std::min(slab, (long)n_variants - off);
+        const long total = (long)n * L->chunks;
+        hipLaunchKernelGGL(hpgv::k_layout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           d_src + (size_t)off * src_pitch, src_pitch, n, L->pitch, L->chunks, L->d_col_of_pos, strict, mode, p16,
+                           d_dst + (size_t)off * L->pitch);
+    }
     HIPCHK(ctx, hipGetLastError());
     return HPGV_OK;
 }
@@ -615,8 +621,10 @@ static int ensure_thr(hpgv_ctx *ctx, int n_variants) {
 
 static int synth_common(hpgv_ctx *ctx, uint64_t v0, int n_variants, size_t pitch, int chunks,
                         const int32_t *d_col, int mode, int p16, uint8_t *d_dst, hipStream_t st) {
-    // generated in slabs so the threshold scratch stays small
-    const int slab = 1 << 20;
+    // generated in slabs so the threshold scratch stays small and a launch stays below 2^31 threads (one per 16-byte
+    // chunk; a grid of more than 2^32 threads does not launch whole)
+    const long by_threads = (1L << 31) / (chunks > 0 ? chunks : 1);
+    const int slab = (int)std::max(1L, std::min((long)(1 << 20), by_threads));
     int rc = ensure_thr(ctx, n_variants < slab ? n_variants : slab);
     if (rc) return rc;
     for (int off = 0; off < n_variants; off += slab) {
