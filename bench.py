@@ -290,6 +290,7 @@ def main():
 
     # ---- parity spot check: the oracle as CHECKER of the timed run's outputs (not timed, not on the product path)
     parity = None
+    parity_failed = False
     if rank == 0:
         from oracle import pyoracle as orc
         n0 = bounds[0][1] - bounds[0][0]
@@ -362,10 +363,16 @@ def main():
             out["cpu_baseline"] = cpu_baseline(N, cond, args.cpu_seconds)
         print(json.dumps(out))
         sys.stdout.flush()
+        if parity is not None and not parity["ok"]:
+            print("bench.py: the timed run's outputs DIFFER from the oracle on the sampled variants: the number above is invalid",
+                  file=sys.stderr)
+            parity_failed = True
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    if parity_failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":
