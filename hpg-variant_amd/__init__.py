@@ -38,7 +38,7 @@ SYMBOLS = [
     "hpgv_sample_missing_dev", "hpgv_genotype_table_dev", "hpgv_stats_filter_dev",
     "hpgv_mendel", "hpgv_epi_dataset", "hpgv_tokenize_dev", "hpgv_tokenize", "hpgv_assoc_text", "hpgv_tdt_text",
     "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_stats_groups",
-    "hpgv_epi_dataset_text", "hpgv_set_text_filters", "hpgv_stats_text", "hpgv_epi_set_dataset", "hpgv_epi_set_folds", "hpgv_epi_set_fold_masks", "hpgv_epi_counts",
+    "hpgv_epi_dataset_text", "hpgv_set_text_filters", "hpgv_stats_text", "hpgv_stats_text_groups", "hpgv_epi_set_dataset", "hpgv_epi_set_folds", "hpgv_epi_set_fold_masks", "hpgv_epi_counts",
     "hpgv_epi_counts_all_folds", "hpgv_epi_scan_pairs", "hpgv_epi_rank_pairs", "hpgv_epi_rank_pairs_rows", "hpgv_read_probe",
 ]
 
@@ -122,6 +122,7 @@ def load():
     L.hpgv_mendel.argtypes = [vp, vp, sz, i32, vp, vp, vp]
     L.hpgv_epi_dataset.argtypes = [vp, vp, sz, i32, vp]
     L.hpgv_stats_text.argtypes = [vp, C.c_char_p, sz, i32, C.POINTER(i32), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32), vp, vp]
+    L.hpgv_stats_text_groups.argtypes = [vp, C.c_char_p, sz, i32, C.POINTER(i32), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32), vp, vp, vp, vp, vp]
     L.hpgv_set_text_filters.argtypes = [vp, C.c_double, C.c_double, C.c_long]
     L.hpgv_epi_dataset_text.argtypes = [vp, C.c_char_p, sz, i32, C.POINTER(i32), vp, vp, vp, vp]
     L.hpgv_epi_set_dataset.argtypes = [vp, vp, i32, i32, i32]

@@ -1472,6 +1472,15 @@ int hpgv_stats_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_
                     uint64_t *line_off, uint32_t *field_off, int32_t *status, int32_t *counts8, double *hwe_chi2,
                     double *hwe_p, int32_t *sample_missing, int32_t *multi_idx, int32_t *multi_table, int *n_multi,
                     int32_t *mendel_errors, int32_t *child_errors) {
+    return hpgv_stats_text_groups(ctx, text, text_bytes, max_lines, n_lines, line_off, field_off, status, counts8, hwe_chi2, hwe_p,
+                                  sample_missing, multi_idx, multi_table, n_multi, mendel_errors, child_errors, nullptr, nullptr, nullptr);
+}
+
+int hpgv_stats_text_groups(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_lines, int *n_lines,
+                           uint64_t *line_off, uint32_t *field_off, int32_t *status, int32_t *counts8, double *hwe_chi2,
+                           double *hwe_p, int32_t *sample_missing, int32_t *multi_idx, int32_t *multi_table, int *n_multi,
+                           int32_t *mendel_errors, int32_t *child_errors, int32_t *group_counts8, double *group_hwe_chi2,
+                           double *group_hwe_p) {
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->stats.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");
     if (!n_lines || max_lines < 0 || (text_bytes > 0 && !text) || (max_lines > 0 && (!counts8 || !hwe_chi2 || !hwe_p)))
@@ -1480,6 +1489,10 @@ int hpgv_stats_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_
     const bool want_mendel = mendel_errors || child_errors;
     if (want_mendel && (!ctx->mendel.set || ctx->mendel.n_samples != ctx->stats.n_samples))
         return fail(ctx, HPGV_ERR_STATE, "Mendelian errors need hpgv_set_pedigree over the same %d columns", ctx->stats.n_samples);
+    if (group_counts8 && (!ctx->sgroups.set || ctx->sgroups.n_samples != ctx->stats.n_samples))
+        return fail(ctx, HPGV_ERR_STATE, "per-group counters need hpgv_set_stats_groups over the same %d columns", ctx->stats.n_samples);
+    if ((group_hwe_chi2 == nullptr) != (group_hwe_p == nullptr) || (group_hwe_chi2 && !group_counts8))
+        return fail(ctx, HPGV_ERR_INVALID, "group_hwe_chi2 and group_hwe_p go together, with group_counts8");
     const int cap = n_multi ? *n_multi : 0;
     if (n_multi) *n_multi = 0;
     *n_lines = 0;
@@ -1529,6 +1542,28 @@ int hpgv_stats_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_
             if ((rc = hpgv_mendel_children_dev(ctx, (const uint8_t *)s->buf[1], nl, (const uint8_t *)s->buf[2], d_child, s->stream))) return rc;
             ce.resize(nt);
             HIPCHK(ctx, hipMemcpyAsync(ce.data(), d_child, nt * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+        }
+    }
+    if (group_counts8) {                                             // per phenotype group: the grouped layout of the same raw matrix
+        const size_t ng = ctx->sg_off.size();
+        HIPCHK(ctx, hipStreamSynchronize(s->stream));                // the copies out of buf[3] / buf[4] above are done before their reuse
+        if ((rc = ensure(ctx, s, 1, n * std::max(ctx->sgroups.pitch, ctx->stats.pitch) + 16))) return rc;
+        if ((rc = hpgv_layout_dev(ctx, HPGV_LAYOUT_STATS_GROUPS, (const uint8_t *)s->buf[7], raw_pitch, nl, (uint8_t *)s->buf[1], s->stream))) return rc;
+        if ((rc = ensure(ctx, s, 3, ng * n * 32 + 64))) return rc;
+        if ((rc = ensure(ctx, s, 4, ng * n * 2 * sizeof(double) + 64))) return rc;
+        int32_t *d_g8 = (int32_t *)s->buf[3];
+        double *d_ghw = (double *)s->buf[4];
+        for (size_t k = 0; k < ng; ++k) {
+            if ((rc = hpgv_stats_scan_group_dev(ctx, (const uint8_t *)s->buf[1], nl, (int)k, d_g8 + k * n * 8, s->stream))) return rc;
+            if (group_hwe_chi2 && (rc = hpgv_stats_hwe_dev(ctx, d_g8 + k * n * 8, nl, d_ghw + k * n, d_ghw + (ng + k) * n, s->stream))) return rc;
+        }
+        // outputs are laid out for max_lines lines per group: [g * max_lines + v]
+        for (size_t k = 0; k < ng; ++k) {
+            HIPCHK(ctx, hipMemcpyAsync(group_counts8 + k * (size_t)max_lines * 8, d_g8 + k * n * 8, n * 32, hipMemcpyDeviceToHost, s->stream));
+            if (group_hwe_chi2) {
+                HIPCHK(ctx, hipMemcpyAsync(group_hwe_chi2 + k * (size_t)max_lines, d_ghw + k * n, n * 8, hipMemcpyDeviceToHost, s->stream));
+                HIPCHK(ctx, hipMemcpyAsync(group_hwe_p + k * (size_t)max_lines, d_ghw + (ng + k) * n, n * 8, hipMemcpyDeviceToHost, s->stream));
+            }
         }
     }
     HIPCHK(ctx, hipStreamSynchronize(s->stream));

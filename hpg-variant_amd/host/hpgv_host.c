@@ -1349,13 +1349,13 @@ int hpgv_host_sort_output_file(const char *path) {
 
 typedef struct {
     int n;
-    char **fid, **iid, **pat, **mat;
+    char **fid, **iid, **pat, **mat, **phe;             /* phe: the PHENO column as written (the stats tool's variable) */
     int *sex, *pheno;
     char *blob;
 } ped_table_t;
 
 static void ped_table_free(ped_table_t *p) {
-    free(p->fid); free(p->iid); free(p->pat); free(p->mat); free(p->sex); free(p->pheno); free(p->blob);
+    free(p->fid); free(p->iid); free(p->pat); free(p->mat); free(p->phe); free(p->sex); free(p->pheno); free(p->blob);
     memset(p, 0, sizeof *p);
 }
 
@@ -1386,6 +1386,7 @@ static int ped_table_read(const char *path, ped_table_t *ped) {
     cap += 2;
     ped->fid = (char **)malloc(sizeof(char *) * (size_t)cap); ped->iid = (char **)malloc(sizeof(char *) * (size_t)cap);
     ped->pat = (char **)malloc(sizeof(char *) * (size_t)cap); ped->mat = (char **)malloc(sizeof(char *) * (size_t)cap);
+    ped->phe = (char **)malloc(sizeof(char *) * (size_t)cap);
     ped->sex = (int *)malloc(sizeof(int) * (size_t)cap); ped->pheno = (int *)malloc(sizeof(int) * (size_t)cap);
     char *line = ped->blob;
     while (line && *line) {
@@ -1396,7 +1397,7 @@ static int ped_table_read(const char *path, ped_table_t *ped) {
             char *a = next_ws_token(&p), *b = next_ws_token(&p), *c = next_ws_token(&p), *d = next_ws_token(&p);
             char *e = next_ws_token(&p), *g = next_ws_token(&p);
             if (a && b && c && d && e && g && ped->n < cap) {
-                ped->fid[ped->n] = a; ped->iid[ped->n] = b; ped->pat[ped->n] = c; ped->mat[ped->n] = d;
+                ped->fid[ped->n] = a; ped->iid[ped->n] = b; ped->pat[ped->n] = c; ped->mat[ped->n] = d; ped->phe[ped->n] = g;
                 ped->sex[ped->n] = !strcmp(e, "1") ? HPGV_SEX_MALE : !strcmp(e, "2") ? HPGV_SEX_FEMALE : HPGV_SEX_UNKNOWN;
                 ped->pheno[ped->n] = !strcmp(g, "2") ? HPGV_COND_AFFECTED : !strcmp(g, "1") ? HPGV_COND_UNAFFECTED : HPGV_COND_OTHER;
                 ped->n++;
@@ -1677,6 +1678,7 @@ typedef struct {
     int stats;                                           /* aggregate / stats: the counters of hpgv_stats_text */
     int32_t *c8, *merr, *midx, *mtab, *smiss, *cerr; double *hw;
     int n_multi, multi_cap, n_smiss, n_cerr;
+    int n_groups; int32_t *gc8; double *ghw;              /* stats: per-phenotype counters, [g * max_lines + v] */
 } run_batch_t;
 
 static int run_batch_stats_arrays(run_batch_t *b) {
@@ -1686,15 +1688,21 @@ static int run_batch_stats_arrays(run_batch_t *b) {
     b->hw = (double *)malloc(sizeof(double) * 2 * (size_t)b->max_lines);
     b->merr = (int32_t *)calloc((size_t)b->max_lines, sizeof(int32_t));
     b->midx = (int32_t *)malloc(sizeof(int32_t) * (size_t)b->max_lines);
+    if (b->n_groups > 0) {
+        free(b->gc8); free(b->ghw);
+        b->gc8 = (int32_t *)malloc(sizeof(int32_t) * 8 * (size_t)b->max_lines * (size_t)b->n_groups);
+        b->ghw = (double *)malloc(sizeof(double) * 2 * (size_t)b->max_lines * (size_t)b->n_groups);
+        if (!b->gc8 || !b->ghw) return HPGV_ERR_NOMEM;
+    }
     if (!b->smiss) b->smiss = (int32_t *)calloc((size_t)b->n_smiss + 1, sizeof(int32_t));
     if (!b->cerr) b->cerr = (int32_t *)calloc((size_t)b->n_cerr + 1, sizeof(int32_t));
     return (b->c8 && b->hw && b->merr && b->midx && b->smiss && b->cerr) ? HPGV_OK : HPGV_ERR_NOMEM;
 }
 
-static int run_batch_alloc(run_batch_t *b, size_t cap_bytes, int n_samples, int row_width, int stats, int n_trios) {
+static int run_batch_alloc(run_batch_t *b, size_t cap_bytes, int n_samples, int row_width, int stats, int n_trios, int n_groups) {
     memset(b, 0, sizeof *b);
     b->row_width = row_width;
-    b->stats = stats; b->n_smiss = n_samples; b->n_cerr = n_trios;
+    b->stats = stats; b->n_smiss = n_samples; b->n_cerr = n_trios; b->n_groups = n_groups;
     size_t min_line = (size_t)(2 * (n_samples > 0 ? n_samples : 1) + 18);
     b->max_lines = (int)(cap_bytes / min_line) + 2;
     if (hpgv_host_alloc(g_ctx, cap_bytes + 1, (void **)&b->text) != HPGV_OK) b->text = NULL;   /* pinned: full-rate H2D */
@@ -1731,7 +1739,7 @@ static int run_batch_reserve(run_batch_t *b, int lines) {
 static void run_batch_free(run_batch_t *b) {
     if (b->text) (void)hpgv_host_free(g_ctx, b->text);
     free(b->line_off); free(b->field_off); free(b->status); free(b->ints); free(b->dbl); free(b->rows);
-    free(b->c8); free(b->hw); free(b->merr); free(b->midx); free(b->mtab); free(b->smiss); free(b->cerr);
+    free(b->c8); free(b->hw); free(b->merr); free(b->midx); free(b->mtab); free(b->smiss); free(b->cerr); free(b->gc8); free(b->ghw);
 }
 
 /* one output line per record, the reference's formats (assoc_runner.c:314-318,332-336; tdt_runner.c:297-299).
@@ -2034,8 +2042,10 @@ static void *pipe_engine(void *v) {
                 if (!b->mtab) { b->multi_cap = m; b->mtab = (int32_t *)malloc(sizeof(int32_t) * 256 * (size_t)m); if (!b->mtab) { rc = HPGV_ERR_NOMEM; break; } }
                 b->n_multi = b->multi_cap;
                 const int mend = kind == 6 && b->n_cerr > 0;
-                rc = hpgv_stats_text(g_ctx, b->text, b->bytes, m, &b->n_lines, b->line_off, b->field_off, b->status, b->c8, b->hw, b->hw + m,
-                                     kind == 6 ? b->smiss : NULL, b->midx, b->mtab, &b->n_multi, mend ? b->merr : NULL, mend ? b->cerr : NULL);
+                const size_t gm = (size_t)m * (size_t)b->n_groups;
+                rc = hpgv_stats_text_groups(g_ctx, b->text, b->bytes, m, &b->n_lines, b->line_off, b->field_off, b->status, b->c8, b->hw, b->hw + m,
+                                            kind == 6 ? b->smiss : NULL, b->midx, b->mtab, &b->n_multi, mend ? b->merr : NULL, mend ? b->cerr : NULL,
+                                            b->n_groups ? b->gc8 : NULL, b->n_groups ? b->ghw : NULL, b->n_groups ? b->ghw + gm : NULL);
             } else if (kind == 4)
                 rc = hpgv_epi_dataset_text(g_ctx, b->text, b->bytes, m, &b->n_lines, b->line_off, b->field_off, b->status, b->rows);
             else if (kind == 3)
@@ -2135,6 +2145,25 @@ static int run_stats_write(const run_stats_t *R, const char *prefix, char **name
     return HPGV_OK;
 }
 
+/* the per-phenotype lines of a batch: the counters of the first two alleles within the group (variant_stats_t per
+ * phenotype, stats_runner.c:319-323) */
+static void write_group_lines(FILE **gfd, const run_batch_t *b) {
+    const int n = b->n_lines < b->max_lines ? b->n_lines : b->max_lines, m = b->max_lines;
+    for (int g = 0; g < b->n_groups; g++)
+        for (int i = 0; i < n; i++) {
+            if (!record_passes(b, i)) continue;
+            const uint32_t *fo = b->field_off + 10 * (size_t)i;
+            const char *l = b->text + b->line_off[i];
+            const int32_t *c = b->gc8 + ((size_t)g * m + (size_t)i) * 8;
+            const int ta = c[6] + c[7];
+            const float f0 = ta ? (float)c[6] / ta : 0.0f, f1 = ta ? (float)c[7] / ta : 0.0f;
+            fprintf(gfd[g], "%.*s\t%ld\t%.*s\t%.*s\t%d,%d\t%.4f,%.4f\t0/0:%d,0/1:%d,1/1:%d,./.:%d\t%d\t%d\t%.4f\t%.6g\t%.6g\n",
+                    (int)(fo[1] - 1 - fo[0]), l + fo[0], atol(l + fo[1]), (int)(fo[4] - 1 - fo[3]), l + fo[3], (int)(fo[5] - 1 - fo[4]), l + fo[4],
+                    c[6], c[7], f0, f1, c[0], c[1] + c[2], c[3], c[4], c[5], c[4], f0 < f1 ? f0 : f1,
+                    b->ghw[(size_t)g * m + (size_t)i], b->ghw[((size_t)b->n_groups + (size_t)g) * m + (size_t)i]);
+        }
+}
+
 static int run_file(const char *vcf_path, const char *ped_path, const char *out_path, int kind, size_t batch_bytes,
                     long *n_variants_out) {
     int rc = ensure_engine();
@@ -2161,7 +2190,8 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     sample_ids_t *ids = sample_ids_new((size_t)n_samples);
     for (int j = 0; j < n_samples; j++) sample_ids_put(ids, names[j], j);
     uint32_t epi_aff = 0, epi_unaff = 0;
-    int n_trios = 0;
+    int n_trios = 0, n_groups = 0;
+    char **group_names = NULL;                           /* stats: the phenotype values, pointing into the PED text */
     int32_t *trio_child = NULL;                          /* stats: VCF column of every trio's child */
     pthread_rwlock_wrlock(&g_cohort_lock);
     if (kind >= 5) {
@@ -2170,6 +2200,26 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
         rc = hpgv_set_stats_cohort(g_ctx, n_samples);
         g_stats_key.set = 0;
         if (rc) host_fail("hpgv_set_stats_cohort", rc);
+        if (!rc && kind == 6 && ped.n > 0) {
+            /* phenotype groups (stats_runner.c:47-50,165-170): the distinct values of the PED's PHENO column, numbered in
+             * order of first appearance; a VCF column without a PED row belongs to no group */
+            int32_t *group = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_samples + 1));
+            group_names = (char **)malloc(sizeof(char *) * (size_t)(ped.n + 1));
+            for (int j = 0; j < n_samples; j++) group[j] = -1;
+            for (int i = 0; i < ped.n; i++) {
+                int gidx = -1;
+                for (int k = 0; k < n_groups; k++) if (!strcmp(group_names[k], ped.phe[i])) { gidx = k; break; }
+                if (gidx < 0 && n_groups < 4096) { gidx = n_groups; group_names[n_groups++] = ped.phe[i]; }
+                const int j = sample_ids_get(ids, ped.iid[i]);
+                if (j >= 0) group[j] = gidx;
+            }
+            if (n_groups > 0) {
+                rc = hpgv_set_stats_groups(g_ctx, group, n_samples, n_groups);
+                g_group_key.set = 0;
+                if (rc) host_fail("hpgv_set_stats_groups", rc);
+            }
+            free(group);
+        }
         if (!rc && kind == 6 && ped.n > 0) {
             int32_t *tf = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ped.n + 1)), *tm = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ped.n + 1));
             trio_child = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ped.n + 1));
@@ -2281,6 +2331,18 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     }
     FILE *out = rc ? NULL : fopen(kind == 6 ? path6 : out_path, "wb");
     if (!rc && !out) { snprintf(g_err, sizeof g_err, "cannot create %s", kind == 6 ? path6 : out_path); rc = HPGV_ERR_INVALID; }
+    FILE **gfd = NULL;
+    if (!rc && kind == 6 && n_groups > 0) {               /* one file per phenotype (stats_runner.c:267-297) */
+        gfd = (FILE **)calloc((size_t)n_groups, sizeof(FILE *));
+        char *gp = (char *)malloc(strlen(out_path) + 300);
+        for (int k = 0; gfd && gp && k < n_groups && !rc; k++) {
+            snprintf(gp, strlen(out_path) + 300, "%s.phenotype-%.200s.stats-variants", out_path, group_names[k]);
+            if (!(gfd[k] = fopen(gp, "w"))) { snprintf(g_err, sizeof g_err, "cannot create %s", gp); rc = HPGV_ERR_INVALID; }
+            else fprintf(gfd[k], "#CHROM\tPOS\tREF\tALT\tALLELES_COUNT\tALLELES_FREQ\tGENOTYPES_COUNT\tMISS_AL\tMISS_GT\tMAF\tHWE_CHI2\tHWE_P\n");
+        }
+        free(gp);
+        if (!gfd) rc = HPGV_ERR_NOMEM;
+    }
     run_stats_t *RS = NULL;
     if (!rc && kind == 6) {
         RS = (run_stats_t *)calloc(1, sizeof *RS);
@@ -2295,7 +2357,7 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     out_buf_t *fmt = (out_buf_t *)calloc(RUN_FMT_BUFS, sizeof *fmt);
     int have = 0;
     if (!P || !fmt) rc = rc ? rc : HPGV_ERR_NOMEM;
-    for (; !rc && have < RUN_NB; have++) rc = run_batch_alloc(&P->bt[have], batch_bytes, n_samples, kind == 4 ? n_samples : 0, kind >= 5, n_trios);
+    for (; !rc && have < RUN_NB; have++) rc = run_batch_alloc(&P->bt[have], batch_bytes, n_samples, kind == 4 ? n_samples : 0, kind >= 5, n_trios, n_groups);
     if (rc == HPGV_ERR_NOMEM) snprintf(g_err, sizeof g_err, "out of memory for the batch buffers");
     if (!rc) {
         if (kind == 5) {
@@ -2349,6 +2411,7 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
             const int bad = write_batch(out, kind, b, fmt, n_fmt, &wpool);
             for (int i = 0; i < b->n_lines; i++) if (record_passes(b, i)) written++;
             if (kind == 6 && !bad) run_stats_add(RS, b, n_samples, trio_child);
+            if (kind == 6 && !bad && gfd) write_group_lines(gfd, b);
             const double dt = now_s() - t0;
             pthread_mutex_lock(&P->mu);
             P->t_write += dt;
@@ -2377,6 +2440,8 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     }
     if (!rc && kind == 6) rc = run_stats_write(RS, out_path, names, n_samples, written);
     if (RS) { free(RS->smiss); free(RS->serr); free(RS); }
+    for (int k = 0; gfd && k < n_groups; k++) if (gfd[k]) fclose(gfd[k]);
+    free(gfd); free(group_names);
     free(path6); free(trio_child);
     for (int k = 0; P && k < have; k++) run_batch_free(&P->bt[k]);
     for (int k = 0; fmt && k < RUN_FMT_BUFS; k++) free(fmt[k].p);

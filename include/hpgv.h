@@ -245,6 +245,15 @@ int  hpgv_stats_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max
                      double *hwe_chi2, double *hwe_p, int32_t *sample_missing, int32_t *multi_idx,
                      int32_t *multi_table, int *n_multi, int32_t *mendel_errors, int32_t *child_errors);
 
+/* the same with the counters of every phenotype group of hpgv_set_stats_groups in addition (one report per phenotype,
+ * stats_runner.c:300-303,319-323): group_counts8[(g * max_lines + v) * 8 + k], group_hwe_*[g * max_lines + v]; all three
+ * may be NULL (then this is hpgv_stats_text) */
+int  hpgv_stats_text_groups(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_lines, int *n_lines,
+                            uint64_t *line_off, uint32_t *field_off, int32_t *status, int32_t *counts8,
+                            double *hwe_chi2, double *hwe_p, int32_t *sample_missing, int32_t *multi_idx,
+                            int32_t *multi_table, int *n_multi, int32_t *mendel_errors, int32_t *child_errors,
+                            int32_t *group_counts8, double *group_hwe_chi2, double *group_hwe_p);
+
 /* record filters of the text entry points, computed on the device from the tokenized matrix before the tool's own
  * scan: --maf (keep minor-allele frequency >= min_maf), --missing (keep missing-genotype rate <= max_missing),
  * --mendel (keep Mendelian errors <= max_mendel_errors) -- shared_options.c:44-46,101-115; the filter bodies live

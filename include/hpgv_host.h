@@ -305,7 +305,9 @@ int  hpgv_run_vcf2epi(const char *vcf_path, const char *ped_path, const char *ou
 int  hpgv_run_aggregate(const char *vcf_path, const char *out_path, int overwrite, size_t batch_bytes,
                         long *n_variants_out);
 /* run_stats (src/vcf-tools/stats/stats_runner.c:23-420): <out_prefix>.stats-variants / .stats-samples /
- * .stats-summary from one pass over the VCF (ped_path may be NULL: no Mendelian errors then).  The report
+ * .stats-summary from one pass over the VCF; with a PED also the Mendelian errors and one
+ * <out_prefix>.phenotype-<value>.stats-variants per value of its phenotype column (stats_runner.c:267-297); ped_path
+ * may be NULL.  The report
  * writers of the reference live in hpg-libs; the three files are tab-separated renderings of the same fields
  * (header lines name the columns). */
 int  hpgv_run_stats(const char *vcf_path, const char *ped_path, const char *out_prefix, size_t batch_bytes,

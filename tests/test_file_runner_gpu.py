@@ -357,3 +357,23 @@ def test_run_stats_files(host, tmp_path):
     assert "Percentage of PASS = %.2f%%" % (100.0 * sum(1 for f in filts if f == "PASS") / len(rows)) in summary
     qs = [float(q) for q in quals if q != "."]
     assert "Average quality = %.2f" % (sum(qs) / len(qs)) in summary
+    # one file per phenotype value of the PED (stats_runner.c:267-297,319-323): the counters within the group
+    pheno = {p[1]: str(p[5]) for p in people}
+    values = []
+    for p in people:
+        if str(p[5]) not in values:
+            values.append(str(p[5]))
+    for val in values:
+        cols = np.array([pheno.get(nm) == val for nm in names])
+        gl = open("%s.phenotype-%s.stats-variants" % (prefix, val)).read().splitlines()
+        assert gl[0].startswith("#CHROM\tPOS\tREF\tALT\tALLELES_COUNT") and len(gl) == 1 + len(rows)
+        for v in range(0, len(rows), 3):
+            t = gl[1 + v].split("\t")
+            vs = orc.variant_stats(np.ascontiguousarray(lax[v][cols]), 2)
+            g = vs.genotypes_count
+            assert t[:4] == [rows[v][0], str(1000 + v), "A", alts[v]]
+            assert t[4] == "%d,%d" % (vs.alleles_count[0], vs.alleles_count[1])
+            assert t[6] == "0/0:%d,0/1:%d,1/1:%d,./.:%d" % (g[0], g[1] + g[2], g[3], vs.missing_genotypes), (val, v, t[6])
+            assert (int(t[7]), int(t[8])) == (vs.missing_alleles, vs.missing_genotypes)
+            for got, e in ((_fl(t[10]), vs.hw_chi2), (_fl(t[11]), vs.hw_p)):
+                assert (np.isnan(got) and np.isnan(e)) or abs(got - e) <= 1e-5 * max(1.0, abs(e))
