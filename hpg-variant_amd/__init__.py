@@ -39,7 +39,7 @@ SYMBOLS = [
     "hpgv_mendel", "hpgv_epi_dataset", "hpgv_tokenize_dev", "hpgv_tokenize", "hpgv_assoc_text", "hpgv_tdt_text",
     "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_stats_groups",
     "hpgv_epi_dataset_text", "hpgv_set_text_filters", "hpgv_stats_text", "hpgv_stats_text_groups", "hpgv_epi_set_dataset", "hpgv_epi_set_folds", "hpgv_epi_set_fold_masks", "hpgv_epi_counts",
-    "hpgv_epi_counts_all_folds", "hpgv_epi_scan_pairs", "hpgv_epi_rank_pairs", "hpgv_epi_rank_pairs_rows", "hpgv_read_probe",
+    "hpgv_epi_counts_all_folds", "hpgv_epi_scan_pairs", "hpgv_epi_rank_pairs", "hpgv_epi_rank_pairs_rows", "hpgv_epi_scan_triples", "hpgv_epi_rank_triples", "hpgv_read_probe",
 ]
 
 
@@ -132,6 +132,8 @@ def load():
     L.hpgv_epi_counts_all_folds.argtypes = [vp, i32, vp, i32, vp, vp]
     L.hpgv_epi_scan_pairs.argtypes = [vp, i32, i32, i32, vp, vp, C.POINTER(C.c_ulonglong)]
     L.hpgv_epi_rank_pairs.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
+    L.hpgv_epi_scan_triples.argtypes = [vp, i32, vp, vp]
+    L.hpgv_epi_rank_triples.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
     L.hpgv_epi_rank_pairs_rows.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
     L.hpgv_read_probe.argtypes = [vp, vp, sz, i32, C.POINTER(C.c_float)]
     _lib = L
@@ -347,6 +349,20 @@ class Engine:
         self._chk(self.L.hpgv_epi_rank_pairs_rows(self.h, lo, hi, subset, n, _ptr(ci), _ptr(cj), _ptr(acc), _ptr(mask), _ptr(cnt),
                                                   C.byref(ms)))
         return dict(i=ci, j=cj, accuracy=acc, risky=mask, n=cnt, scan_ms=ms.value)
+
+    def epi_scan_triples(self, subset):
+        v, k = self._epi[0], self._epi[3]
+        acc, mask = np.zeros((k, v, v, v), np.float64), np.zeros((k, v, v, v), np.uint32)
+        self._chk(self.L.hpgv_epi_scan_triples(self.h, subset, _ptr(acc), _ptr(mask)))
+        return acc, mask
+
+    def epi_rank_triples(self, subset, max_ranking_size):
+        k, n = self._epi[3], max_ranking_size
+        ci, cj, ck = (np.zeros((k, n), np.int32) for _ in range(3))
+        acc, mask, cnt = np.zeros((k, n), np.float64), np.zeros((k, n), np.uint32), np.zeros(k, np.int32)
+        ms = C.c_float(0)
+        self._chk(self.L.hpgv_epi_rank_triples(self.h, subset, n, _ptr(ci), _ptr(cj), _ptr(ck), _ptr(acc), _ptr(mask), _ptr(cnt), C.byref(ms)))
+        return dict(i=ci, j=cj, k=ck, accuracy=acc, risky=mask, n=cnt, scan_ms=ms.value)
 
     def epi_dataset(self, gt):
         gt = _np(gt, np.uint8)

@@ -1002,12 +1002,13 @@ uint8_t *get_k_folds_masks(unsigned int num_samples_affected, unsigned int num_s
     return masks;
 }
 
-typedef struct { int i, j, count; unsigned risky; double accuracy; } epi_model_t;
+typedef struct { int i, j, k, count; unsigned risky; double accuracy; } epi_model_t;     /* k = -1 for a pair */
 
 static int cmp_model_comb(const void *a, const void *b) {            /* compare_risky, epistasis.c:162-175 */
     const epi_model_t *x = (const epi_model_t *)a, *y = (const epi_model_t *)b;
     if (x->i != y->i) return x->i < y->i ? -1 : 1;
     if (x->j != y->j) return x->j < y->j ? -1 : 1;
+    if (x->k != y->k) return x->k < y->k ? -1 : 1;
     return 0;
 }
 static int cmp_model_cva(const void *a, const void *b) {             /* CV-a: accuracy, then the combination */
@@ -1029,8 +1030,14 @@ static int cmp_model_cvc(const void *a, const void *b) {             /* CV-c: fo
  * epistasis_report.c:30-81.  eval_mode 0 = CV-c, 1 = CV-a (enum evaluation_mode, model.h:74). */
 int hpgv_run_epistasis(const char *dataset_path, int num_folds, int num_cv_repetitions, int max_ranking_size,
                        int eval_subset, int eval_mode, const char *out_prefix) {
+    return hpgv_run_epistasis_order(dataset_path, 2, num_folds, num_cv_repetitions, max_ranking_size, eval_subset, eval_mode, out_prefix);
+}
+
+int hpgv_run_epistasis_order(const char *dataset_path, int order, int num_folds, int num_cv_repetitions, int max_ranking_size,
+                             int eval_subset, int eval_mode, const char *out_prefix) {
     int rc = ensure_engine();
     if (rc) return rc;
+    if (order != 2 && order != 3) { snprintf(g_err, sizeof g_err, "combinations of %d SNPs are not supported (2 or 3)", order); return HPGV_ERR_UNSUPPORTED; }
     if (num_folds < 1 || num_cv_repetitions < 1 || max_ranking_size < 1 || !dataset_path || !out_prefix) {
         snprintf(g_err, sizeof g_err, "bad epistasis arguments");
         return HPGV_ERR_INVALID;
@@ -1047,25 +1054,27 @@ int hpgv_run_epistasis(const char *dataset_path, int num_folds, int num_cv_repet
     if (rc) return host_fail("hpgv_epi_set_dataset", rc);
     const size_t N = (size_t)max_ranking_size, K = (size_t)num_folds;
     int32_t *ci = (int32_t *)malloc(sizeof(int32_t) * K * N), *cj = (int32_t *)malloc(sizeof(int32_t) * K * N), *cnt = (int32_t *)malloc(sizeof(int32_t) * K);
+    int32_t *ck = (int32_t *)malloc(sizeof(int32_t) * K * N);
     uint32_t *risky = (uint32_t *)malloc(sizeof(uint32_t) * K * N);
     double *acc = (double *)malloc(sizeof(double) * K * N);
     epi_model_t *all = (epi_model_t *)malloc(sizeof(epi_model_t) * (K * N + 1));
     char *path = (char *)malloc(strlen(out_prefix) + 32);
-    if (!ci || !cj || !cnt || !risky || !acc || !all || !path) rc = HPGV_ERR_NOMEM;
+    if (!ci || !cj || !ck || !cnt || !risky || !acc || !all || !path) rc = HPGV_ERR_NOMEM;
     for (int r = 0; r < num_cv_repetitions && !rc; r++) {
         unsigned int *sizes = NULL;
         int **folds = get_k_folds((unsigned)nA, (unsigned)nU, (unsigned)num_folds, &sizes);
         uint8_t *masks = folds ? get_k_folds_masks((unsigned)nA, (unsigned)nU, (unsigned)num_folds, folds, sizes) : NULL;
         if (!masks) rc = HPGV_ERR_NOMEM;
         if (!rc && (rc = hpgv_epi_set_fold_masks(g_ctx, masks, num_folds))) host_fail("hpgv_epi_set_fold_masks", rc);
-        if (!rc && (rc = hpgv_epi_rank_pairs(g_ctx, eval_subset, max_ranking_size, ci, cj, acc, risky, cnt, NULL))) host_fail("hpgv_epi_rank_pairs", rc);
+        if (!rc && order == 2 && (rc = hpgv_epi_rank_pairs(g_ctx, eval_subset, max_ranking_size, ci, cj, acc, risky, cnt, NULL))) host_fail("hpgv_epi_rank_pairs", rc);
+        if (!rc && order == 3 && (rc = hpgv_epi_rank_triples(g_ctx, eval_subset, max_ranking_size, ci, cj, ck, acc, risky, cnt, NULL))) host_fail("hpgv_epi_rank_triples", rc);
         if (folds) { for (int k = 0; k < num_folds; k++) free(folds[k]); free(folds); }
         free(sizes); free(masks);
         if (rc) break;
         size_t n = 0;
         for (size_t k = 0; k < K; k++)
             for (int e = 0; e < cnt[k]; e++) {
-                epi_model_t m = { ci[k * N + (size_t)e], cj[k * N + (size_t)e], 1, risky[k * N + (size_t)e], acc[k * N + (size_t)e] };
+                epi_model_t m = { ci[k * N + (size_t)e], cj[k * N + (size_t)e], order == 3 ? ck[k * N + (size_t)e] : -1, 1, risky[k * N + (size_t)e], acc[k * N + (size_t)e] };
                 all[n++] = m;
             }
         qsort(all, n, sizeof *all, cmp_model_comb);                  /* stable enough: equal pairs differ only by fold */
@@ -1079,18 +1088,24 @@ int hpgv_run_epistasis(const char *dataset_path, int num_folds, int num_cv_repet
         sprintf(path, "%s.cv%d.epi", out_prefix, r + 1);
         FILE *fd = fopen(path, "w");
         if (!fd) { snprintf(g_err, sizeof g_err, "cannot create %s", path); rc = HPGV_ERR_INVALID; break; }
-        fprintf(fd, "#CROSS VALIDATION %d\n#COMBINATIONS OF: %d SNPs\n", r + 1, 2);
+        fprintf(fd, "#CROSS VALIDATION %d\n#COMBINATIONS OF: %d SNPs\n", r + 1, order);
         fprintf(fd, eval_mode == 1 ? "#EVALUATION MODE: Cross-validation accuracy\n" : "#EVALUATION MODE: Cross-validation consistency\n");
         fprintf(fd, eval_subset == HPGV_EPI_TRAINING ? "#EVALUATION PARTITION: Training\n" : "#EVALUATION PARTITION: Testing\n");
         fprintf(fd, "#POSITION\tSNPs\tGENOTYPES\tCV-C\tCV-A\n");
         for (size_t e = 0; e < m && e < N; e++) {
-            fprintf(fd, "%d\t( %d, %d )\t", (int)e + 1, all[e].i, all[e].j);
-            for (int c = 0; c < 9; c++) if (all[e].risky >> c & 1) fprintf(fd, "(%d-%d), ", c / 3, c % 3);
+            /* epistasis_report.c:62-77: "( i, j )" / "( i, j, k )"; genotypes "(a-b), " / "(a-b, c), " */
+            if (order == 2) {
+                fprintf(fd, "%d\t( %d, %d )\t", (int)e + 1, all[e].i, all[e].j);
+                for (int c = 0; c < 9; c++) if (all[e].risky >> c & 1) fprintf(fd, "(%d-%d), ", c / 3, c % 3);
+            } else {
+                fprintf(fd, "%d\t( %d, %d, %d )\t", (int)e + 1, all[e].i, all[e].j, all[e].k);
+                for (int c = 0; c < 27; c++) if (all[e].risky >> c & 1) fprintf(fd, "(%d-%d, %d), ", c / 9, (c / 3) % 3, c % 3);
+            }
             fprintf(fd, "%d\t%.3f\n", all[e].count, all[e].accuracy);
         }
         fclose(fd);
     }
-    free(ci); free(cj); free(cnt); free(risky); free(acc); free(all); free(path);
+    free(ci); free(cj); free(ck); free(cnt); free(risky); free(acc); free(all); free(path);
     if (rc == HPGV_ERR_NOMEM) snprintf(g_err, sizeof g_err, "out of memory");
     return rc;
 }

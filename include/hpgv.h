@@ -312,6 +312,14 @@ int  hpgv_epi_rank_pairs_rows(hpgv_ctx *ctx, int i_begin, int i_end, int subset,
                               int32_t *comb_i, int32_t *comb_j, double *accuracy, uint32_t *risky_mask,
                               int32_t *n_ranked, float *scan_ms);
 
+/* order 3: the same model for every triple i < j < k (27 cells, cell = (g_i * 3 + g_j) * 3 + g_k; at most 65535
+ * samples per class, no empty fold).  hpgv_epi_scan_triples is the dense form for small sets (<= 256 SNPs):
+ * accuracy / risky_mask[((fold * V + i) * V + j) * V + k], NaN / 0 where (i, j, k) is no triple;
+ * hpgv_epi_rank_triples the per-fold ranking as for pairs. */
+int  hpgv_epi_scan_triples(hpgv_ctx *ctx, int subset, double *accuracy, uint32_t *risky_mask);
+int  hpgv_epi_rank_triples(hpgv_ctx *ctx, int subset, int max_ranking_size, int32_t *comb_i, int32_t *comb_j,
+                           int32_t *comb_k, double *accuracy, uint32_t *risky_mask, int32_t *n_ranked, float *scan_ms);
+
 /* Mendelian errors of a host batch: errors[v] per variant (may be NULL) and child_errors[t] per trio of
  * hpgv_set_pedigree, ACCUMULATED into (may be NULL) */
 int  hpgv_mendel(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, const uint8_t *is_x,

@@ -329,6 +329,9 @@ uint8_t *get_k_folds_masks(unsigned int num_samples_affected, unsigned int num_s
  * HPGV_EPI_TRAINING; eval_mode 0 = CV-c (consistency), 1 = CV-a (accuracy). */
 int  hpgv_run_epistasis(const char *dataset_path, int num_folds, int num_cv_repetitions, int max_ranking_size,
                         int eval_subset, int eval_mode, const char *out_prefix);
+/* the same for combinations of `order` = 2 or 3 SNPs (the --order option) */
+int  hpgv_run_epistasis_order(const char *dataset_path, int order, int num_folds, int num_cv_repetitions,
+                              int max_ranking_size, int eval_subset, int eval_mode, const char *out_prefix);
 
 /* The runners' reader on its own: copies `in_path` (plain / gzip / BGZF) to `out_path` in the whole-line
  * batches (at most batch_bytes each) the runners hand to the engine, optionally after consuming the VCF

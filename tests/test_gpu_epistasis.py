@@ -241,3 +241,79 @@ def test_run_epistasis_from_a_dataset_file(tmp_path):
                 gts = "".join("(%d-%d), " % (cell // 3, cell % 3) for cell in range(9) if m >> cell & 1)
                 assert line == "%d\t( %d, %d )\t%s%d\t%.3f" % (pos + 1, pr[0], pr[1], gts, c, a), (mode, r, pos)
             assert rows[0][0] == (3, 30)                             # the planted interaction wins
+
+
+@pytest.mark.parametrize("v,nA,nU,k", [(14, 60, 75, 4), (9, 32, 32, 2), (20, 210, 180, 10), (70, 40, 50, 3)])
+def test_triple_scan_matches_the_oracle(eng, v, nA, nU, k):
+    # order 3 (27 cells): every triple of a small set against the oracle's model, both evaluation subsets
+    rng = np.random.default_rng(v + k)
+    data = epi_random_dataset(rng, v, nA, nU, p_missing=0.04)
+    fold = epi_random_folds(rng, nA, nU, k)
+    eng.epi_set_dataset(data, nA, nU)
+    eng.epi_set_folds(fold, k)
+    masks = orc.fold_masks_from_assignment(fold, k)
+    triples = [(a, b, c) for a in range(v) for b in range(a + 1, v) for c in range(b + 1, v)]
+    if len(triples) > 600:
+        triples = [triples[t] for t in rng.choice(len(triples), 600, replace=False)]
+    for subset in (hpgv.EPI_TESTING, hpgv.EPI_TRAINING):
+        acc, rm = eng.epi_scan_triples(subset)
+        assert np.isnan(acc[:, 3, 2, 5]).all() and np.isnan(acc[:, 1, 1, 2]).all()       # not a triple i < j < k
+        for (a, b, c) in triples:
+            ea, em, _ = orc.epi_model([data[a], data[b], data[c]], nA, nU, masks, subset)
+            assert np.array_equal(rm[:, a, b, c], em), (a, b, c)
+            got = acc[:, a, b, c]
+            assert np.all((got == ea) | (np.isnan(got) & np.isnan(ea))), (a, b, c, got, ea)
+
+
+def test_triple_ranking_is_the_top_of_the_dense_scan(eng):
+    rng = np.random.default_rng(303)
+    v, nA, nU, k, n = 40, 150, 170, 5, 9
+    data = epi_random_dataset(rng, v, nA, nU)
+    for s in (4, 17, 33):                                            # a planted three-way signal
+        data[s, :nA] = rng.choice([1, 2], size=nA)
+    fold = epi_random_folds(rng, nA, nU, k)
+    eng.epi_set_dataset(data, nA, nU)
+    eng.epi_set_folds(fold, k)
+    acc, rm = eng.epi_scan_triples(hpgv.EPI_TESTING)
+    res = eng.epi_rank_triples(hpgv.EPI_TESTING, n)
+    triples = [(a, b, c) for a in range(v) for b in range(a + 1, v) for c in range(b + 1, v)]
+    for f in range(k):
+        vals = np.array([acc[f][t] for t in triples])
+        vals = np.where(np.isnan(vals), -np.inf, vals)
+        order = sorted(range(len(triples)), key=lambda p: (-vals[p], triples[p]))[:n]
+        assert res["n"][f] == n
+        assert [(int(a), int(b), int(c)) for a, b, c in zip(res["i"][f], res["j"][f], res["k"][f])] == [triples[p] for p in order]
+        assert np.array_equal(res["accuracy"][f], np.array([acc[f][triples[p]] for p in order]))
+        assert np.array_equal(res["risky"][f], np.array([rm[f][triples[p]] for p in order], np.uint32))
+    assert (4, 17, 33) == (int(res["i"][0][0]), int(res["j"][0][0]), int(res["k"][0][0]))
+
+
+def test_run_epistasis_order_3_report(tmp_path):
+    import ctypes as C
+    import struct
+    from importlib import import_module
+    b = import_module("hpg-variant_amd._build")
+    L = C.CDLL(b.HOSTLIB)
+    L.hpgv_run_epistasis_order.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    L.hpgv_host_last_error.restype = C.c_char_p
+    rng = np.random.default_rng(41)
+    v, nA, nU = 24, 120, 130
+    data = epi_random_dataset(rng, v, nA, nU)
+    for s_ in (2, 9, 20):
+        data[s_, :nA] = rng.choice([1, 2], size=nA)
+    path = tmp_path / "epi3.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<III", v, nA, nU)); f.write(data.tobytes())
+    prefix = str(tmp_path / "o3")
+    rc = L.hpgv_run_epistasis_order(str(path).encode(), 3, 4, 1, 6, hpgv.EPI_TRAINING, 1, prefix.encode())
+    assert rc == 0, L.hpgv_host_last_error()
+    lines = open(prefix + ".cv1.epi").read().splitlines()
+    assert lines[1] == "#COMBINATIONS OF: 3 SNPs" and lines[3] == "#EVALUATION PARTITION: Training"
+    first = lines[5].split("\t")
+    # epistasis_report.c:62-77: position, "( i, j, k )", then the risky cells "(a-b, c), " run straight into the CV-c count
+    assert first[0] == "1" and first[1] == "( 2, 9, 20 )" and first[2].startswith("(")
+    genos, count = first[2].rsplit("), ", 1)
+    cells = genos.split("), ")
+    assert count == "4" and all(len(c.strip("()").replace("-", ",").replace(" ", "").split(",")) == 3 for c in cells)
+    assert "(1-1, 1)" in first[2] and "(2-2, 2)" in first[2] and "(0-" not in first[2]      # the planted carriers
+    assert L.hpgv_run_epistasis_order(str(path).encode(), 4, 4, 1, 6, 0, 1, prefix.encode()) != 0      # order 4: refused
