@@ -351,4 +351,157 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
     }
 }
 
+// ---------------------------------------------------------------------------
+// every triple (i, j, k), i < j < k, of a band of first SNPs i: the order-3 model of process_set_of_combinations
+// (27 cells, cell = (g_i * 3 + g_j) * 3 + g_k).  Workgroup = 4 waves; a wave owns one (i, j) pair, its lanes 64
+// third SNPs k.  Per 32-bit word a lane forms the nine x_a & y_b words of its pair and 27 x (v_and + v_bcnt) =
+// 63 operations.  With 27 cells the per-fold counts of all K folds do not fit in registers, so the scan makes TWO
+// passes over the samples: the first leaves the 27 totals (cases low, controls high 16 bits), the second visits the
+// groups in (fold, class) order and, each time a fold's two groups are complete, evaluates that fold at once from
+// totals - fold counts.  Classes are limited to 65 535 samples here.
+// ---------------------------------------------------------------------------
+struct EpiCand3 {
+    double accuracy;
+    int32_t i, j, k;
+    uint32_t risky;                   // bit c = cell c of the 27 is high risk
+};
+
+template <bool TRAINING, bool BALANCED>
+__global__ void __launch_bounds__(256, 2) k_epi_triples(const uint32_t *__restrict__ planes, int W, int n_variants, int i_first,
+                                                         const EpiChunk *__restrict__ chunks, int n_chunks, int num_folds,
+                                                         const EpiFold *__restrict__ folds, int n_affected, int n_unaffected,
+                                                         double *__restrict__ acc_out, uint32_t *__restrict__ mask_out,
+                                                         const double *__restrict__ thr, EpiCand3 *__restrict__ cand,
+                                                         unsigned *__restrict__ cand_count, unsigned cand_cap) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2][(EPI_TJ + EPI_TI + 1) * 3 * EPI_ROW];
+    const int i = i_first + blockIdx.z, j0 = blockIdx.y * EPI_TI, k0 = blockIdx.x * EPI_TJ;
+    if (j0 + EPI_TI - 1 <= i || k0 + EPI_TJ - 1 <= j0) return;      // no triple i < j < k in this tile
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int j = j0 + wave, k = k0 + lane;
+    // LDS rows: 0..63 the k columns, 64..67 the four j rows, 68 the i row
+    constexpr int SNPS = EPI_TJ + EPI_TI + 1, ROWS = SNPS * 3, PIECES = ROWS * (EPI_CH / 4), PER_T = (PIECES + 255) / 256;
+    uint4 stage[PER_T];
+    auto load_chunk = [&](int c) {
+        const uint32_t w0 = chunks[c].w0;
+        const int nw = (int)chunks[c].nw;
+        #pragma unroll
+        for (int r = 0; r < PER_T; r++) {
+            const int q = t + 256 * r, row = q >> 3, piece = q & 7;
+            stage[r] = make_uint4(0, 0, 0, 0);
+            if (row < ROWS && piece * 4 < nw) {
+                const int sidx = row / 3;
+                const int snp = sidx < EPI_TJ ? k0 + sidx : sidx < EPI_TJ + EPI_TI ? j0 + (sidx - EPI_TJ) : i;
+                stage[r] = *reinterpret_cast<const uint4 *>(planes + ((size_t)snp * 3 + row % 3) * W + w0 + piece * 4);
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        #pragma unroll
+        for (int r = 0; r < PER_T; r++) {
+            const int q = t + 256 * r, row = q >> 3, piece = q & 7;
+            if (row < ROWS) *reinterpret_cast<uint4 *>(&lds[buf][row * EPI_ROW + piece * 4]) = stage[r];
+        }
+    };
+    const bool live = j > i && k > j && j < n_variants && k < n_variants;
+    const float f_na = (float)(unsigned)n_affected, f_nu = (float)(unsigned)n_unaffected;
+    const float ratio = f_na / f_nu;
+    uint32_t tot[27], cur[27], run[27];
+    #pragma unroll
+    for (int c = 0; c < 27; c++) { tot[c] = 0; cur[c] = 0; run[c] = 0; }
+
+    for (int pass = 0; pass < 2; pass++) {
+        __syncthreads();
+        load_chunk(0);
+        store_chunk(0);
+        __syncthreads();
+        for (int c = 0; c < n_chunks; c++) {
+            const int buf = c & 1;
+            if (c + 1 < n_chunks) load_chunk(c + 1);
+            const int nw = (int)chunks[c].nw;
+            const uint64_t flush = chunks[c].flush;
+            const uint32_t *zrow = &lds[buf][lane * 3 * EPI_ROW];
+            const uint32_t *yrow = &lds[buf][(EPI_TJ + wave) * 3 * EPI_ROW];
+            const uint32_t *xrow = &lds[buf][(EPI_TJ + EPI_TI) * 3 * EPI_ROW];
+            for (int s = 0; s < nw; s += 4) {
+                uint4 x[3], y[3], z[3];
+                #pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    x[a] = *reinterpret_cast<const uint4 *>(xrow + a * EPI_ROW + s);
+                    y[a] = *reinterpret_cast<const uint4 *>(yrow + a * EPI_ROW + s);
+                    z[a] = *reinterpret_cast<const uint4 *>(zrow + a * EPI_ROW + s);
+                }
+                #pragma unroll
+                for (int a = 0; a < 3; a++)
+                    #pragma unroll
+                    for (int b = 0; b < 3; b++) {
+                        const uint4 xy = make_uint4(x[a].x & y[b].x, x[a].y & y[b].y, x[a].z & y[b].z, x[a].w & y[b].w);
+                        #pragma unroll
+                        for (int d = 0; d < 3; d++) {
+                            uint32_t r = run[(a * 3 + b) * 3 + d];
+                            r = bcnt_acc(xy.x & z[d].x, r); r = bcnt_acc(xy.y & z[d].y, r);
+                            r = bcnt_acc(xy.z & z[d].z, r); r = bcnt_acc(xy.w & z[d].w, r);
+                            run[(a * 3 + b) * 3 + d] = r;
+                        }
+                    }
+                const int g = (int)((flush >> (2 * s)) & 0xFFu);
+                if (g != 0xFF) {                                     // a (fold, class) group ends with this step
+                    const int sh = (g & 1) * 16;
+                    if (pass == 0) {
+                        #pragma unroll
+                        for (int cc = 0; cc < 27; cc++) { tot[cc] += run[cc] << sh; run[cc] = 0; }
+                    } else {
+                        #pragma unroll
+                        for (int cc = 0; cc < 27; cc++) { cur[cc] += run[cc] << sh; run[cc] = 0; }
+                        // groups come as (fold 0 cases, fold 0 controls, fold 1 cases, ...); a fold is complete with its
+                        // controls, or with its cases when it has no controls (then no group g | 1 ever ends)
+                        const int f = g >> 1;
+                        const EpiFold fo = folds[f];
+                        const bool fold_done = (g & 1) || fo.test_u == 0;
+                        if (fold_done) {
+                            if (live) {
+                                int tp = 0, fp = 0;
+                                uint32_t mask = 0;
+                                #pragma unroll
+                                for (int cc = 0; cc < 27; cc++) {
+                                    const int in_a = (int)(cur[cc] & 0xFFFFu), in_u = (int)(cur[cc] >> 16);
+                                    const int tr_a = (int)(tot[cc] & 0xFFFFu) - in_a, tr_u = (int)(tot[cc] >> 16) - in_u;
+                                    if (mdr_high_risk<BALANCED>(tr_a, tr_u, ratio, f_na, f_nu)) {
+                                        mask |= 1u << cc;
+                                        tp += TRAINING ? tr_a : in_a;
+                                        fp += TRAINING ? tr_u : in_u;
+                                    }
+                                }
+                                const int size_a = TRAINING ? n_affected - fo.test_a : fo.test_a, size_u = TRAINING ? n_unaffected - fo.test_u : fo.test_u;
+                                const double TP = (double)tp, TN = (double)(size_u - fp), ya = (double)size_a, yu = (double)size_u;
+                                double qa = TP * fo.inv_a, qu = TN * fo.inv_u;
+                                qa = __builtin_fma(__builtin_fma(-qa, ya, TP), fo.inv_a, qa);
+                                qu = __builtin_fma(__builtin_fma(-qu, yu, TN), fo.inv_u, qu);
+                                const double acc = (qa + qu) / 2;
+                                if (acc_out) {
+                                    const size_t V = (size_t)n_variants;
+                                    const size_t o = (((size_t)f * V + (size_t)i) * V + (size_t)j) * V + (size_t)k;
+                                    acc_out[o] = acc; mask_out[o] = mask;
+                                }
+                                if (cand && acc >= thr[f]) {
+                                    const unsigned slot = atomicAdd(&cand_count[f], 1u);
+                                    if (slot < cand_cap) {
+                                        EpiCand3 e;
+                                        e.accuracy = acc; e.i = i; e.j = j; e.k = k; e.risky = mask;
+                                        cand[(size_t)f * cand_cap + slot] = e;
+                                    }
+                                }
+                            }
+                            #pragma unroll
+                            for (int cc = 0; cc < 27; cc++) cur[cc] = 0;
+                        }
+                    }
+                }
+            }
+            if (c + 1 < n_chunks) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    (void)num_folds;
+}
+
 }  // namespace hpgv
