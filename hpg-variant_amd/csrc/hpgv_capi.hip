@@ -76,6 +76,7 @@ struct hpgv_ctx {
     long blocks_per_cu = 8;
     long pipeline = 1;         // 1: software-pipelined scan (loads of the next tile before counting this one)
     long pipe_waves = 4;       // register budget of the pipelined scan, as waves per SIMD (4, 6 or 8)
+    long fisher_cut_exp = 22;  // Fisher tails stop after a round whose terms are all below 10^-this of the sum so far
     long epi_dma = 1;          // epistasis pair scan: stage the planes with global_load_lds (LDS-DMA) instead of through registers
     long scan_lds = 0;         // bytes of (unused) LDS per workgroup of the stats / tdt scans: caps the waves in flight per CU
     int n_cus = 256;
@@ -322,6 +323,9 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
         ctx->scan_unroll = value;
     } else if (!strcmp(key, "pipeline")) {
         ctx->pipeline = value ? 1 : 0;
+    } else if (!strcmp(key, "fisher_cut_exp")) {
+        if (value < 12 || value > 300) return fail(ctx, HPGV_ERR_INVALID, "fisher_cut_exp must be in [12, 300]");
+        ctx->fisher_cut_exp = value;
     } else if (!strcmp(key, "epi_dma")) {
         ctx->epi_dma = value ? 1 : 0;
     } else if (!strcmp(key, "scan_lds")) {
@@ -769,7 +773,7 @@ int hpgv_assoc_fisher_dev(hpgv_ctx *ctx, const int32_t *d_counts, int n_variants
     hipStream_t st = (hipStream_t)stream;
     return launch_profiled(ctx, st, 1, [&] {
         hipLaunchKernelGGL(hpgv::k_assoc_fisher, dim3((n_variants + 3) / 4), dim3(256), 0, st,
-                           (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p);
+                           (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, pow(10.0, -(double)ctx->fisher_cut_exp));
     });
 }
 

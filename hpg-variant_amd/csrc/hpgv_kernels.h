@@ -313,50 +313,63 @@ struct FisherTab {
     }
 };
 
-// first x in [L, R) where pred(x) is false, for a predicate that is true on a prefix
-// of [L, R); returns R if it is true everywhere.  UP: pred(x) = p(x) <= thr (left of the mode,
-// p increasing); !UP: pred(x) = p(x) > thr (right of the mode, p decreasing).
-template <bool UP>
-__device__ __forceinline__ int fisher_boundary(const FisherTab &T, double thr, int L, int R, int lane) {
-    while (R - L > 64) {
-        const int step = (R - L + 63) / 64;
-        const int x = L + lane * step;
-        bool pr = false;
-        if (x < R) { const double v = T.p(x); pr = UP ? (v <= thr) : (v > thr); }
-        const int j = __builtin_popcountll(__ballot(pr));       // leading true probes (prefix-true)
-        const int newL = (j == 0) ? L : L + (j - 1) * step + 1;
-        const int xj = L + j * step;
-        const int newR = (j == 64 || xj >= R) ? R : xj;
-        L = newL; R = newR;
+// Boundary of a prefix-true predicate over [L, R) by 64-ary search: 64 probes per round; UP (left of the mode, p
+// increasing): pred(x) = p(x) <= thr; right of the mode (p decreasing): pred(x) = p(x) > thr.  Returns the first x where
+// the predicate is false (R if none).
+// Both boundary searches in lockstep: the two 64-ary searches are independent, so every round issues the table
+// reads and the exp of BOTH probes before either result is needed -- half as many latency-bound rounds.
+__device__ __forceinline__ void fisher_boundaries(const FisherTab &T, double thr, int L1, int R1, int L2, int R2, int lane,
+                                                  int *xL, int *xR) {
+    while (R1 - L1 > 64 || R2 - L2 > 64) {                          // wave-uniform
+        const bool go1 = R1 - L1 > 64, go2 = R2 - L2 > 64;
+        const int step1 = (R1 - L1 + 63) / 64, step2 = (R2 - L2 + 63) / 64;
+        const int x1 = L1 + lane * step1, x2 = L2 + lane * step2;
+        const double v1 = (go1 && x1 < R1) ? T.p(x1) : 0.0;
+        const double v2 = (go2 && x2 < R2) ? T.p(x2) : 0.0;
+        if (go1) {
+            const int j = __builtin_popcountll(__ballot(x1 < R1 && v1 <= thr));
+            const int xj = L1 + j * step1;
+            const int nL = (j == 0) ? L1 : L1 + (j - 1) * step1 + 1, nR = (j == 64 || xj >= R1) ? R1 : xj;
+            L1 = nL; R1 = nR;
+        }
+        if (go2) {
+            const int j = __builtin_popcountll(__ballot(x2 < R2 && v2 > thr));
+            const int xj = L2 + j * step2;
+            const int nL = (j == 0) ? L2 : L2 + (j - 1) * step2 + 1, nR = (j == 64 || xj >= R2) ? R2 : xj;
+            L2 = nL; R2 = nR;
+        }
     }
-    const int x = L + lane;
-    bool pr = false;
-    if (x < R) { const double v = T.p(x); pr = UP ? (v <= thr) : (v > thr); }
-    return L + __builtin_popcountll(__ballot(pr));
+    const int x1 = L1 + lane, x2 = L2 + lane;
+    const double v1 = x1 < R1 ? T.p(x1) : 0.0, v2 = x2 < R2 ? T.p(x2) : 0.0;
+    *xL = L1 + __builtin_popcountll(__ballot(x1 < R1 && v1 <= thr));
+    *xR = L2 + __builtin_popcountll(__ballot(x2 < R2 && v2 > thr));
 }
 
-// sum of p(x) for x = start, start+dir, ... while inside [lo, hi].  Lanes keep private partial
-// sums (one wave reduction at the end); the walk stops after a round in which no term exceeds
-// 1e-22 of (base + the first round's total), a lower bound of the final sum.
-__device__ __forceinline__ double fisher_tail(const FisherTab &T, int start, int dir, int lo, int hi,
-                                              double base, int lane) {
-    double part = 0.0, cut = 0.0;
-    for (int k = 0;; ++k) {
-        const int first = start + dir * 64 * k;
-        if (first < lo || first > hi) break;                    // wave-uniform
-        const int x = first + dir * lane;
-        const double v = (x >= lo && x <= hi) ? T.p(x) : 0.0;
-        part += v;
-        if (k == 0) cut = 1e-22 * (base + wave_sum_f64(v));
-        if (__ballot(v > cut) == 0ull) break;                   // wave-uniform
+// Both tails in lockstep (left from xL - 1 downwards, right from xR upwards).  Lanes keep private partial sums (one
+// wave reduction at the end); a tail ends after a round in which none of its terms exceeds rel_cut x its own first
+// round's total (the terms dropped are further out and decay faster than geometrically).
+__device__ __forceinline__ double fisher_tails(const FisherTab &T, int xL, int xR, int lo, int hi, int lane, double rel_cut) {
+    double partL = 0.0, partR = 0.0, cutL = 0.0, cutR = 0.0;
+    bool onL = true, onR = true;
+    for (int k = 0; onL || onR; ++k) {                              // wave-uniform
+        const int firstL = xL - 1 - 64 * k, firstR = xR + 64 * k;
+        if (firstL < lo) onL = false;
+        if (firstR > hi) onR = false;
+        const int a = firstL - lane, b = firstR + lane;
+        const double vL = (onL && a >= lo) ? T.p(a) : 0.0;
+        const double vR = (onR && b <= hi) ? T.p(b) : 0.0;
+        partL += vL; partR += vR;
+        if (k == 0) { cutL = rel_cut * wave_sum_f64(vL); cutR = rel_cut * wave_sum_f64(vR); }
+        if (onL && __ballot(vL > cutL) == 0ull) onL = false;
+        if (onR && __ballot(vR > cutR) == 0ull) onR = false;
     }
-    return wave_sum_f64(part);
+    return wave_sum_f64(partL) + wave_sum_f64(partR);
 }
 
 __global__ __launch_bounds__(256) void k_assoc_fisher(const int4 *__restrict__ counts, int n,
                                                       const double *__restrict__ lf,
                                                       double *__restrict__ odds,
-                                                      double *__restrict__ pval) {
+                                                      double *__restrict__ pval, double rel_cut) {
     const int lane = threadIdx.x & 63;
     const int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (v >= n) return;
@@ -384,12 +397,10 @@ __global__ __launch_bounds__(256) void k_assoc_fisher(const int4 *__restrict__ c
         int mode = (int)md;
         mode = mode < lo ? lo : (mode > hi ? hi : mode);
         // left of (and including) the mode p grows with x: included x are a prefix [lo, xL)
-        const int xL = fisher_boundary<true>(T, thr, lo, mode + 1, lane);
         // right of the mode p falls: p > thr on a prefix [mode+1, xR), included x are [xR, hi]
-        const int xR = fisher_boundary<false>(T, thr, mode + 1, hi + 1, lane);
-        const double left = fisher_tail(T, xL - 1, -1, lo, hi, 0.0, lane);
-        const double right = fisher_tail(T, xR, +1, lo, hi, left, lane);
-        sum = left + right;
+        int xL, xR;
+        fisher_boundaries(T, thr, lo, mode + 1, mode + 1, hi + 1, lane, &xL, &xR);
+        sum = fisher_tails(T, xL, xR, lo, hi, lane, rel_cut);
     }
     if (lane == 0) {
         odds[v] = assoc_odds(a, b, c, d);
