@@ -88,11 +88,7 @@ def cpu_baseline(n_samples, cond, target_s):
     reference's worker structure (OpenMP workers pulling 200-variant batches),
     text-faithful scan = per genotype strdup + parse + free as assoc.c:50-57."""
     from oracle import pyoracle as orc
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = orc.effective_cpus()                        # affinity mask capped by the cgroup CPU quota
     # pilot to size the bounded sample
     pilot = 200 * cores
     sec, used = orc.baseline_assoc_text(0, pilot, n_samples, cond, cores)

@@ -308,9 +308,10 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 
 struct FisherTab {
     const double *lf; double konst; int r1, c1, d0;    // d0 = r2 - c1
-    __device__ __forceinline__ double p(int x) const {
-        return exp(konst - lf[x] - lf[r1 - x] - lf[c1 - x] - lf[d0 + x]);
-    }
+    // ln P(x): the exponent of the definition's term; comparisons between terms are made on it (exp is monotone),
+    // so the boundary searches need no exp at all
+    __device__ __forceinline__ double e(int x) const { return konst - lf[x] - lf[r1 - x] - lf[c1 - x] - lf[d0 + x]; }
+    __device__ __forceinline__ double p(int x) const { return exp(e(x)); }
 };
 
 // Boundary of a prefix-true predicate over [L, R) by 64-ary search: 64 probes per round; UP (left of the mode, p
@@ -318,14 +319,14 @@ struct FisherTab {
 // the predicate is false (R if none).
 // Both boundary searches in lockstep: the two 64-ary searches are independent, so every round issues the table
 // reads and the exp of BOTH probes before either result is needed -- half as many latency-bound rounds.
-__device__ __forceinline__ void fisher_boundaries(const FisherTab &T, double thr, int L1, int R1, int L2, int R2, int lane,
+__device__ __forceinline__ void fisher_boundaries(const FisherTab &T, double thr /* ln */, int L1, int R1, int L2, int R2, int lane,
                                                   int *xL, int *xR) {
     while (R1 - L1 > 64 || R2 - L2 > 64) {                          // wave-uniform
         const bool go1 = R1 - L1 > 64, go2 = R2 - L2 > 64;
         const int step1 = (R1 - L1 + 63) / 64, step2 = (R2 - L2 + 63) / 64;
         const int x1 = L1 + lane * step1, x2 = L2 + lane * step2;
-        const double v1 = (go1 && x1 < R1) ? T.p(x1) : 0.0;
-        const double v2 = (go2 && x2 < R2) ? T.p(x2) : 0.0;
+        const double v1 = (go1 && x1 < R1) ? T.e(x1) : 0.0;
+        const double v2 = (go2 && x2 < R2) ? T.e(x2) : 0.0;
         if (go1) {
             const int j = __builtin_popcountll(__ballot(x1 < R1 && v1 <= thr));
             const int xj = L1 + j * step1;
@@ -340,7 +341,7 @@ __device__ __forceinline__ void fisher_boundaries(const FisherTab &T, double thr
         }
     }
     const int x1 = L1 + lane, x2 = L2 + lane;
-    const double v1 = x1 < R1 ? T.p(x1) : 0.0, v2 = x2 < R2 ? T.p(x2) : 0.0;
+    const double v1 = x1 < R1 ? T.e(x1) : 0.0, v2 = x2 < R2 ? T.e(x2) : 0.0;
     *xL = L1 + __builtin_popcountll(__ballot(x1 < R1 && v1 <= thr));
     *xR = L2 + __builtin_popcountll(__ballot(x2 < R2 && v2 > thr));
 }
@@ -381,14 +382,14 @@ __global__ __launch_bounds__(256) void k_assoc_fisher(const int4 *__restrict__ c
     FisherTab T;
     T.lf = lf; T.r1 = r1; T.c1 = c1; T.d0 = r2 - c1;
     T.konst = lf[r1] + lf[r2] + lf[c1] + lf[nn - c1] - lf[nn];
-    const double p_obs = T.p(a);
-    const double thr = p_obs * (1.0 + 1e-7);
+    // included tables: P(x) <= P_obs * (1 + 1e-7), tested as ln P(x) <= ln P_obs + ln(1 + 1e-7)
+    const double thr = T.e(a) + 9.9999995000000333e-08;
     double sum;
     if (hi - lo < 512) {
         double part = 0.0;
         for (int x = lo + lane; x <= hi; x += 64) {
-            const double p = T.p(x);
-            if (p <= thr) part += p;
+            const double ex = T.e(x);
+            if (ex <= thr) part += exp(ex);
         }
         sum = wave_sum_f64(part);
     } else {

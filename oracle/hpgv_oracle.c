@@ -649,3 +649,13 @@ double orc_baseline_assoc_text(uint64_t v0, int n_variants, int n_samples,
     (void)sink;
     return total;   /* max over workers of their scan time = parallel wall time of the scan */
 }
+
+/* OpenMP team size of the oracle's parallel loops (a cgroup CPU quota can be far below the visible CPUs) */
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+

@@ -156,6 +156,8 @@ double orc_baseline_assoc_packed(const uint8_t *gt, size_t pitch, int n_variants
 double orc_baseline_assoc_text(uint64_t v0, int n_variants, int n_samples,
                                const uint8_t *condition, int n_threads, int *threads_used);
 
+void orc_set_threads(int n);           /* team size of the oracle's OpenMP loops */
+
 /* ---- epistasis / MDR (hpgv_epi_oracle.c; src/gwas/epistasis/model.c, mdr.c, epistasis.c) ---- */
 void orc_epi_counts(int order, const uint8_t *const *rows, int n_affected, int n_unaffected,
                     int32_t *counts_aff, int32_t *counts_unaff);                         /* model.c:76-124 */

@@ -44,12 +44,35 @@ class VariantStats(C.Structure):
 _lib = None
 
 
+def effective_cpus():
+    """CPUs this process may really use: its affinity mask capped by the cgroup CPU quota (a container can see 256
+    CPUs and be allowed 16; a team of 256 threads is then throttled to a crawl)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is not None:
         return _lib
     build()
     L = C.CDLL(_SO)
+    L.orc_set_threads(effective_cpus())
     p_u8 = C.POINTER(C.c_uint8)
     p_i32 = C.POINTER(C.c_int32)
     p_f64 = C.POINTER(C.c_double)

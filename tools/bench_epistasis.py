@@ -84,7 +84,7 @@ if "--cpu" in sys.argv:
     t0 = time.perf_counter()
     orc.epi_scan_pairs(data[:vs], nA, nU, masks, 0)
     dt = time.perf_counter() - t0
-    out["cpu_baseline"] = {"value": vs * (vs - 1) // 2 / dt, "unit": "pairs/s", "kind": "port", "cores": os.cpu_count(),
+    out["cpu_baseline"] = {"value": vs * (vs - 1) // 2 / dt, "unit": "pairs/s", "kind": "port", "cores": orc.effective_cpus(),
                            "sample": "oracle scan of the first %d SNPs (%d pairs) x %d samples x %d folds, OpenMP over rows, %.1f s" % (vs, vs * (vs - 1) // 2, N, K, dt)}
 print(json.dumps(out))
 e.close()
