@@ -1188,7 +1188,13 @@ static void pool_run(io_pool_t *p, pool_fn fn, void *arg, int n_tasks) {
 
 static int default_io_threads(void) {
     long n = sysconf(_SC_NPROCESSORS_ONLN);
-    int t = n >= 32 ? 16 : n >= 4 ? (int)(n / 2) : 1;
+    FILE *q = fopen("/sys/fs/cgroup/cpu.max", "r");         /* a container may be allotted far fewer CPUs than it sees */
+    if (q) {
+        long quota = 0, period = 0;
+        if (fscanf(q, "%ld %ld", &quota, &period) == 2 && quota > 0 && period > 0 && quota / period < n) n = quota / period > 0 ? quota / period : 1;
+        fclose(q);
+    }
+    int t = n >= 32 ? 16 : n >= 16 ? (int)n : n >= 4 ? (int)(n / 2) : 1;
     const char *e = getenv("HPGV_IO_THREADS");
     if (e && atoi(e) > 0) t = atoi(e) < 64 ? atoi(e) : 64;
     return t;
