@@ -317,3 +317,26 @@ def test_run_epistasis_order_3_report(tmp_path):
     assert count == "4" and all(len(c.strip("()").replace("-", ",").replace(" ", "").split(",")) == 3 for c in cells)
     assert "(1-1, 1)" in first[2] and "(2-2, 2)" in first[2] and "(0-" not in first[2]      # the planted carriers
     assert L.hpgv_run_epistasis_order(str(path).encode(), 4, 4, 1, 6, 0, 1, prefix.encode()) != 0      # order 4: refused
+
+
+@pytest.mark.parametrize("nA,nU,k", [(20, 2, 4), (2, 21, 4), (3, 3, 3), (1, 40, 2)])
+def test_folds_that_lack_a_class(eng, nA, nU, k):
+    # fewer cases (or controls) than folds: some folds hold one class only; sizes of zero give 0/0 = NaN accuracies exactly
+    # where the reference's division does
+    rng = np.random.default_rng(nA * 31 + nU)
+    v = 12
+    data = epi_random_dataset(rng, v, nA, nU, p_missing=0.05)
+    fold = epi_random_folds(rng, nA, nU, k)
+    eng.epi_set_dataset(data, nA, nU)
+    eng.epi_set_folds(fold, k)
+    masks = orc.fold_masks_from_assignment(fold, k)
+    for subset in (hpgv.EPI_TESTING, hpgv.EPI_TRAINING):
+        acc, rm = eng.epi_scan_pairs(subset)
+        eacc, erm = orc.epi_scan_pairs(data, nA, nU, masks, subset)
+        assert np.array_equal(rm, erm.astype(np.uint16)) and _same(acc, eacc)
+        acc3, rm3 = eng.epi_scan_triples(subset)
+        for (a, b, c) in [(0, 1, 2), (0, 5, 11), (3, 4, 9), (9, 10, 11), (2, 7, 8)]:
+            ea, em, _ = orc.epi_model([data[a], data[b], data[c]], nA, nU, masks, subset)
+            assert np.array_equal(rm3[:, a, b, c], em), (a, b, c)
+            got = acc3[:, a, b, c]
+            assert np.all((got == ea) | (np.isnan(got) & np.isnan(ea))), (a, b, c, got, ea)
