@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) k_epi_counts(const uint32_t *__restrict__
 // ---------------------------------------------------------------------------
 template <int K, bool TRAINING, bool BALANCED, bool DMA>
 __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(const uint32_t *__restrict__ planes, int W, int n_variants, int i_begin, int i_first, int i_end,
-                                                    const unsigned *__restrict__ tile_base, int n_q, int tiles_j,
+                                                    const unsigned *__restrict__ tile_base, int n_cols, unsigned n_tiles,
                                                     const EpiChunk *__restrict__ chunks, int n_chunks,
                                                     const EpiFold *__restrict__ folds /* K */, int n_affected, int n_unaffected,
                                                     double *__restrict__ acc_out, uint16_t *__restrict__ mask_out, unsigned long long n_pairs_out,
@@ -175,14 +175,17 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
     constexpr int RP = DMA ? EPI_CH : EPI_ROW;
     constexpr int LROWS = DMA ? 208 : (EPI_TJ + EPI_TI) * 3;
     __shared__ __attribute__((aligned(16))) uint32_t lds[2][LROWS * RP];
-    // blockIdx.x numbers the tiles that hold at least one pair: row block ti = blockIdx.x / tiles_j owns the column
-    // tiles from its diagonal tile on; tile_base[q] = tiles before the 16 row blocks whose rows start at 64 * q
-    // relative to i_begin (i_begin is a multiple of 64), found by bisection
-    int q_lo = 0, q_hi = n_q;
-    while (q_hi - q_lo > 1) { const int mid = (q_lo + q_hi) >> 1; if (tile_base[mid] <= blockIdx.x) q_lo = mid; else q_hi = mid; }
-    const int tj_min = (i_begin >> 6) + q_lo, per_row = tiles_j - tj_min;
-    const int rem = (int)(blockIdx.x - tile_base[q_lo]);
-    const int j0 = (tj_min + rem % per_row) * EPI_TJ, i0 = i_begin + (q_lo * 16 + rem / per_row) * EPI_TI;
+    // Tiles that hold at least one pair are numbered COLUMN tile by column tile (tile_base[c] = tiles before column tile
+    // tj0 + c; inside a column tile the row blocks 0 .. n - 1 from the band's first row down to the diagonal), and the
+    // numbering is dealt to the XCDs in eight contiguous spans: workgroup b runs on XCD b % 8 (round-robin dispatch) and
+    // takes tile (b % 8) * span + b / 8.  An XCD therefore works through whole column tiles: their 64 x 3 plane rows stay
+    // in its L2 while only the four row-SNPs of each tile stream.
+    const unsigned span = (n_tiles + 7u) / 8u;
+    const unsigned tile = (blockIdx.x & 7u) * span + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    int c_lo = 0, c_hi = n_cols;
+    while (c_hi - c_lo > 1) { const int mid = (c_lo + c_hi) >> 1; if (tile_base[mid] <= tile) c_lo = mid; else c_hi = mid; }
+    const int j0 = ((i_begin >> 6) + c_lo) * EPI_TJ, i0 = i_begin + (int)(tile - tile_base[c_lo]) * EPI_TI;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int i = i0 + wave, j = j0 + lane;
 
