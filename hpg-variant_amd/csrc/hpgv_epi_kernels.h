@@ -369,24 +369,44 @@ struct EpiCand3 {
     uint32_t risky;                   // bit c = cell c of the 27 is high risk
 };
 
-template <bool TRAINING, bool BALANCED>
-__global__ void __launch_bounds__(256, 2) k_epi_triples(const uint32_t *__restrict__ planes, int W, int n_variants, int i_first,
+template <bool TRAINING, bool BALANCED, bool DMA>
+__global__ void __launch_bounds__(256, DMA ? 3 : 2) k_epi_triples(const uint32_t *__restrict__ planes, int W, int n_variants, int i_first,
                                                          const EpiChunk *__restrict__ chunks, int n_chunks, int num_folds,
                                                          const EpiFold *__restrict__ folds, int n_affected, int n_unaffected,
                                                          double *__restrict__ acc_out, uint32_t *__restrict__ mask_out,
                                                          const double *__restrict__ thr, EpiCand3 *__restrict__ cand,
                                                          unsigned *__restrict__ cand_count, unsigned cand_cap) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2][(EPI_TJ + EPI_TI + 1) * 3 * EPI_ROW];
+    // register-staged: rows pitched 36 words; LDS-DMA: 26 x 8 linear rows of 32 words, pieces swizzled by the SNP index on
+    // the source address (as k_epi_pairs)
+    constexpr int RP = DMA ? EPI_CH : EPI_ROW;
+    constexpr int LROWS = DMA ? 208 : (EPI_TJ + EPI_TI + 1) * 3;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2][LROWS * RP];
     const int i = i_first + blockIdx.z, j0 = blockIdx.y * EPI_TI, k0 = blockIdx.x * EPI_TJ;
     if (j0 + EPI_TI - 1 <= i || k0 + EPI_TJ - 1 <= j0) return;      // no triple i < j < k in this tile
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int j = j0 + wave, k = k0 + lane;
     // LDS rows: 0..63 the k columns, 64..67 the four j rows, 68 the i row
     constexpr int SNPS = EPI_TJ + EPI_TI + 1, ROWS = SNPS * 3, PIECES = ROWS * (EPI_CH / 4), PER_T = (PIECES + 255) / 256;
-    uint4 stage[PER_T];
-    auto load_chunk = [&](int c) {
+    uint4 stage[DMA ? 1 : PER_T];
+    auto load_chunk = [&](int c, int buf) {
         const uint32_t w0 = chunks[c].w0;
         const int nw = (int)chunks[c].nw;
+        if constexpr (DMA) {
+            #pragma unroll
+            for (int r = 0; r < 7; r++) {
+                const int kk = wave + 4 * r;
+                if (kk < 26) {
+                    const int row = 8 * kk + (lane >> 3), sidx = row / 3;
+                    const int piece = (lane & 7) ^ ((sidx >> 1) & 7);
+                    if (row < ROWS && piece * 4 < nw) {
+                        const int snp = sidx < EPI_TJ ? k0 + sidx : sidx < EPI_TJ + EPI_TI ? j0 + (sidx - EPI_TJ) : i;
+                        const uint32_t *src = planes + ((size_t)snp * 3 + row % 3) * W + w0 + piece * 4;
+                        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) uint32_t *)&lds[buf][8 * kk * EPI_CH], 16, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
         #pragma unroll
         for (int r = 0; r < PER_T; r++) {
             const int q = t + 256 * r, row = q >> 3, piece = q & 7;
@@ -399,6 +419,7 @@ __global__ void __launch_bounds__(256, 2) k_epi_triples(const uint32_t *__restri
         }
     };
     auto store_chunk = [&](int buf) {
+        if constexpr (DMA) return;
         #pragma unroll
         for (int r = 0; r < PER_T; r++) {
             const int q = t + 256 * r, row = q >> 3, piece = q & 7;
@@ -414,24 +435,25 @@ __global__ void __launch_bounds__(256, 2) k_epi_triples(const uint32_t *__restri
 
     for (int pass = 0; pass < 2; pass++) {
         __syncthreads();
-        load_chunk(0);
+        load_chunk(0, 0);
         store_chunk(0);
         __syncthreads();
         for (int c = 0; c < n_chunks; c++) {
             const int buf = c & 1;
-            if (c + 1 < n_chunks) load_chunk(c + 1);
+            if (c + 1 < n_chunks) load_chunk(c + 1, buf ^ 1);
             const int nw = (int)chunks[c].nw;
             const uint64_t flush = chunks[c].flush;
-            const uint32_t *zrow = &lds[buf][lane * 3 * EPI_ROW];
-            const uint32_t *yrow = &lds[buf][(EPI_TJ + wave) * 3 * EPI_ROW];
-            const uint32_t *xrow = &lds[buf][(EPI_TJ + EPI_TI) * 3 * EPI_ROW];
+            const uint32_t *zrow = &lds[buf][lane * 3 * RP];
+            const uint32_t *yrow = &lds[buf][(EPI_TJ + wave) * 3 * RP];
+            const uint32_t *xrow = &lds[buf][(EPI_TJ + EPI_TI) * 3 * RP];
+            const int swz_z = DMA ? ((lane >> 1) & 7) : 0, swz_y = DMA ? (((EPI_TJ + wave) >> 1) & 7) : 0, swz_x = DMA ? (((EPI_TJ + EPI_TI) >> 1) & 7) : 0;
             for (int s = 0; s < nw; s += 4) {
                 uint4 x[3], y[3], z[3];
                 #pragma unroll
                 for (int a = 0; a < 3; a++) {
-                    x[a] = *reinterpret_cast<const uint4 *>(xrow + a * EPI_ROW + s);
-                    y[a] = *reinterpret_cast<const uint4 *>(yrow + a * EPI_ROW + s);
-                    z[a] = *reinterpret_cast<const uint4 *>(zrow + a * EPI_ROW + s);
+                    x[a] = *reinterpret_cast<const uint4 *>(xrow + a * RP + (((s >> 2) ^ swz_x) << 2));
+                    y[a] = *reinterpret_cast<const uint4 *>(yrow + a * RP + (((s >> 2) ^ swz_y) << 2));
+                    z[a] = *reinterpret_cast<const uint4 *>(zrow + a * RP + (((s >> 2) ^ swz_z) << 2));
                 }
                 #pragma unroll
                 for (int a = 0; a < 3; a++)
