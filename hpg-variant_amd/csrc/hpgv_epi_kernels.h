@@ -371,6 +371,8 @@ struct EpiCand3 {
 
 template <bool TRAINING, bool BALANCED, bool DMA>
 __global__ void __launch_bounds__(256, DMA ? 3 : 2) k_epi_triples(const uint32_t *__restrict__ planes, int W, int n_variants, int i_first,
+                                                         const unsigned *__restrict__ row_base /* n_i + 1 */, int n_i,
+                                                         const unsigned *__restrict__ jb_prefix /* n_jb + 1 */, int n_jb,
                                                          const EpiChunk *__restrict__ chunks, int n_chunks, int num_folds,
                                                          const EpiFold *__restrict__ folds, int n_affected, int n_unaffected,
                                                          double *__restrict__ acc_out, uint32_t *__restrict__ mask_out,
@@ -381,8 +383,17 @@ __global__ void __launch_bounds__(256, DMA ? 3 : 2) k_epi_triples(const uint32_t
     constexpr int RP = DMA ? EPI_CH : EPI_ROW;
     constexpr int LROWS = DMA ? 208 : (EPI_TJ + EPI_TI + 1) * 3;
     __shared__ __attribute__((aligned(16))) uint32_t lds[2][LROWS * RP];
-    const int i = i_first + blockIdx.z, j0 = blockIdx.y * EPI_TI, k0 = blockIdx.x * EPI_TJ;
-    if (j0 + EPI_TI - 1 <= i || k0 + EPI_TJ - 1 <= j0) return;      // no triple i < j < k in this tile
+    // only tiles that hold a triple are launched: blockIdx.x -> first SNP (bisection on row_base), then its j block
+    // (bisection on jb_prefix, the count of k tiles per j block, which does not depend on i), then the k tile
+    int r_lo = 0, r_hi = n_i;
+    while (r_hi - r_lo > 1) { const int mid = (r_lo + r_hi) >> 1; if (row_base[mid] <= blockIdx.x) r_lo = mid; else r_hi = mid; }
+    const int i = i_first + r_lo;
+    const int jb_min = (i + 1) >> 2;                                 // first j block with a row j > i
+    const unsigned want = (blockIdx.x - row_base[r_lo]) + jb_prefix[jb_min];
+    int b_lo = jb_min, b_hi = n_jb;
+    while (b_hi - b_lo > 1) { const int mid = (b_lo + b_hi) >> 1; if (jb_prefix[mid] <= want) b_lo = mid; else b_hi = mid; }
+    const int j0 = b_lo * EPI_TI;
+    const int k0 = (((j0 + 1) >> 6) + (int)(want - jb_prefix[b_lo])) * EPI_TJ;     // k tiles from the one that holds j0 + 1 on
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int j = j0 + wave, k = k0 + lane;
     // LDS rows: 0..63 the k columns, 64..67 the four j rows, 68 the i row
