@@ -174,7 +174,10 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
     // swizzled by the column index so that the per-lane reads of 16 lanes fall on 16 different slots
     constexpr int RP = DMA ? EPI_CH : EPI_ROW;
     constexpr int LROWS = DMA ? 208 : (EPI_TJ + EPI_TI) * 3;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2][LROWS * RP];
+    // two separate arrays, not lds[2][...]: the compiler then sees that the LDS-DMA writes into one buffer cannot touch the
+    // other and does not put an s_waitcnt vmcnt(0) in front of the counting loop's reads
+    __shared__ __attribute__((aligned(16))) uint32_t lds_a[LROWS * RP];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_b[LROWS * RP];
     // Tiles that hold at least one pair are numbered COLUMN tile by column tile (tile_base[c] = tiles before column tile
     // tj0 + c; inside a column tile the row blocks 0 .. n - 1 from the band's first row down to the diagonal), and the
     // numbering is dealt to the XCDs in eight contiguous spans: workgroup b runs on XCD b % 8 (round-robin dispatch) and
@@ -192,7 +195,7 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
     // ---- staging: piece q = one 16-byte piece of one (snp, plane) row of the chunk ----
     constexpr int ROWS = (EPI_TJ + EPI_TI) * 3, PIECES = ROWS * (EPI_CH / 4), PER_T = (PIECES + 255) / 256;
     uint4 stage[DMA ? 1 : PER_T];
-    auto load_chunk = [&](int c, int buf) {
+    auto load_chunk = [&](int c, uint32_t *dst) {
         const uint32_t w0 = chunks[c].w0;
         const int nw = (int)chunks[c].nw;
         if constexpr (DMA) {
@@ -207,7 +210,7 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
                     if (row < ROWS && piece * 4 < nw) {
                         const int snp = snp_idx < EPI_TJ ? j0 + snp_idx : i0 + (snp_idx - EPI_TJ);
                         const uint32_t *src = planes + ((size_t)snp * 3 + row % 3) * W + w0 + piece * 4;
-                        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) uint32_t *)&lds[buf][8 * k * EPI_CH], 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) uint32_t *)(dst + 8 * k * EPI_CH), 16, 0, 0);
                     }
                 }
             }
@@ -223,12 +226,12 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
             }
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](uint32_t *dst) {
         if constexpr (DMA) return;
         #pragma unroll
         for (int r = 0; r < PER_T; r++) {
             const int q = t + 256 * r, row = q >> 3, piece = q & 7;
-            if (row < ROWS) *reinterpret_cast<uint4 *>(&lds[buf][row * EPI_ROW + piece * 4]) = stage[r];
+            if (row < ROWS) *reinterpret_cast<uint4 *>(dst + row * EPI_ROW + piece * 4) = stage[r];
         }
     };
 
@@ -241,18 +244,12 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
     #pragma unroll
     for (int c = 0; c < 9; c++) run[c] = 0;
 
-    load_chunk(0, 0);
-    store_chunk(0);
+    load_chunk(0, lds_a);
+    store_chunk(lds_a);
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int swz_j = DMA ? ((lane >> 1) & 7) : 0, swz_i = DMA ? (((EPI_TJ + wave) >> 1) & 7) : 0;
-    for (int c = 0; c < n_chunks; c++) {
-        const int cur = c & 1;
-        if (c + 1 < n_chunks) load_chunk(c + 1, cur ^ 1);            // the next chunk's loads fly during the counting
-        const int nw = (int)chunks[c].nw;
-        const uint64_t flush = chunks[c].flush;                      // wave-uniform
-        const uint32_t *jrow = &lds[cur][lane * 3 * RP];
-        const uint32_t *irow = &lds[cur][(EPI_TJ + wave) * 3 * RP];  // the wave's own row: same address in every lane (broadcast)
-        uint4 xa[3], ya[3], xb[3], yb[3];
+    uint4 xa[3], ya[3], xb[3], yb[3];
 #define HPGV_EPI_FETCH(X, Y, S)                                                                          \
         _Pragma("unroll") for (int a = 0; a < 3; a++) {                                                  \
             X[a] = *reinterpret_cast<const uint4 *>(irow + a * RP + (((((S) >> 2) ^ swz_i)) << 2));          \
@@ -277,27 +274,42 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
                 _Pragma("unroll") for (int cc = 0; cc < 9; cc++) run[cc] = 0;                            \
             }                                                                                            \
         }
-        if constexpr (DMA && K > 5) {
-            // three waves per SIMD hide the LDS latency; one register set keeps the kernel within their 168 VGPRs
-            for (int s = 0; s < nw; s += 4) {
-                HPGV_EPI_FETCH(xa, ya, s)
-                HPGV_EPI_COUNT(xa, ya, s)
-            }
-            (void)xb; (void)yb;
-        } else {
-            HPGV_EPI_FETCH(xa, ya, 0)
-            for (int s = 0; s < nw; s += 8) {
-                HPGV_EPI_FETCH(xb, yb, s + 4)
-                HPGV_EPI_COUNT(xa, ya, s)
-                if (s + 8 < nw) { HPGV_EPI_FETCH(xa, ya, s + 8) }
-                HPGV_EPI_COUNT(xb, yb, s + 4)
-            }
-        }
+    // one chunk: the next chunk's loads fly into NXT during the counting over CUR
+#define HPGV_EPI_CHUNK(CUR, NXT)                                                                         \
+    {                                                                                                    \
+        if (c + 1 < n_chunks) load_chunk(c + 1, NXT);                                                    \
+        const int nw = (int)chunks[c].nw;                                                                \
+        const uint64_t flush = chunks[c].flush;                      /* wave-uniform */                  \
+        const uint32_t *jrow = &CUR[lane * 3 * RP];                                                      \
+        const uint32_t *irow = &CUR[(EPI_TJ + wave) * 3 * RP];       /* the wave's own row: broadcast */  \
+        if constexpr (DMA && K > 5) {                                                                    \
+            /* three waves per SIMD hide the LDS latency; one register set keeps the kernel within 168 VGPRs */ \
+            for (int s = 0; s < nw; s += 4) {                                                            \
+                HPGV_EPI_FETCH(xa, ya, s)                                                                \
+                HPGV_EPI_COUNT(xa, ya, s)                                                                \
+            }                                                                                            \
+            (void)xb; (void)yb;                                                                          \
+        } else {                                                                                         \
+            HPGV_EPI_FETCH(xa, ya, 0)                                                                    \
+            for (int s = 0; s < nw; s += 8) {                                                            \
+                HPGV_EPI_FETCH(xb, yb, s + 4)                                                            \
+                HPGV_EPI_COUNT(xa, ya, s)                                                                \
+                if (s + 8 < nw) { HPGV_EPI_FETCH(xa, ya, s + 8) }                                        \
+                HPGV_EPI_COUNT(xb, yb, s + 4)                                                            \
+            }                                                                                            \
+        }                                                                                                \
+        if (c + 1 < n_chunks) store_chunk(NXT);                                                          \
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* this wave's part of NXT has landed */ \
+        __syncthreads();                                                                                 \
+    }
+    for (int c = 0; c < n_chunks; c++) {
+        HPGV_EPI_CHUNK(lds_a, lds_b)
+        if (++c >= n_chunks) break;
+        HPGV_EPI_CHUNK(lds_b, lds_a)
+    }
+#undef HPGV_EPI_CHUNK
 #undef HPGV_EPI_FETCH
 #undef HPGV_EPI_COUNT
-        if (c + 1 < n_chunks) store_chunk(cur ^ 1);
-        __syncthreads();
-    }
 
     if (i < i_first || i >= i_end || i >= n_variants || j >= n_variants || j <= i) return;
 
