@@ -76,9 +76,8 @@ __global__ void __launch_bounds__(256) k_epi_planes(const uint8_t *__restrict__ 
 // acc + popcount(x) in ONE instruction (v_bcnt_u32_b32 has an accumulator operand; written as a sum of four
 // popcounts the compiler emits four v_bcnt + two v_add3 instead)
 __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
-    uint32_t r;
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
-    return r;
+    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(x));
+    return acc;
 }
 
 // the MDR rule of the runner, mdr_high_risk_combinations2 (mdr.c:45-76): single precision, operation by
@@ -195,24 +194,32 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
     // ---- staging: piece q = one 16-byte piece of one (snp, plane) row of the chunk ----
     constexpr int ROWS = (EPI_TJ + EPI_TI) * 3, PIECES = ROWS * (EPI_CH / 4), PER_T = (PIECES + 255) / 256;
     uint4 stage[DMA ? 1 : PER_T];
+    // LDS-DMA: one global_load_lds_dwordx4 = 64 lanes x 16 B = 8 rows of the image; lane l fetches row 8k + l / 8, physical
+    // piece l % 8, i.e. the logical piece (l % 8) ^ swizzle(row's SNP): the swizzle sits on the source address.  Kept per
+    // instruction: the word offset of the lane's piece inside the planes (below 2^32 words).  Always whole 32-word rows
+    // (the words past a short last chunk are fetched and never read: the planes carry 32 words of slack); the four rows
+    // of the image past the 204 used ones re-fetch row 0.
+    uint32_t dma_off[7];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);         // the wave index as a scalar
+    if constexpr (DMA) {
+        #pragma unroll
+        for (int r = 0; r < 7; r++) {
+            const int k = wave + 4 * r, row8 = 8 * k + (lane >> 3), row = row8 < ROWS ? row8 : 0, snp_idx = row / 3;
+            const int piece = (lane & 7) ^ ((snp_idx >> 1) & 7);
+            const int snp = snp_idx < EPI_TJ ? j0 + snp_idx : i0 + (snp_idx - EPI_TJ);
+            dma_off[r] = ((uint32_t)snp * 3u + (uint32_t)(row % 3)) * (uint32_t)W + (uint32_t)piece * 4u;
+        }
+    }
     auto load_chunk = [&](int c, uint32_t *dst) {
         const uint32_t w0 = chunks[c].w0;
         const int nw = (int)chunks[c].nw;
         if constexpr (DMA) {
-            // one global_load_lds_dwordx4 = 64 lanes x 16 B = 8 rows of the image; lane l fetches row 8k + l / 8, physical
-            // piece l % 8, i.e. the logical piece (l % 8) ^ swizzle(row's SNP): the swizzle sits on the source address
+            (void)nw;
             #pragma unroll
             for (int r = 0; r < 7; r++) {
-                const int k = wave + 4 * r;
-                if (k < 26) {
-                    const int row = 8 * k + (lane >> 3), snp_idx = row / 3;
-                    const int piece = (lane & 7) ^ ((snp_idx >> 1) & 7);
-                    if (row < ROWS && piece * 4 < nw) {
-                        const int snp = snp_idx < EPI_TJ ? j0 + snp_idx : i0 + (snp_idx - EPI_TJ);
-                        const uint32_t *src = planes + ((size_t)snp * 3 + row % 3) * W + w0 + piece * 4;
-                        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) uint32_t *)(dst + 8 * k * EPI_CH), 16, 0, 0);
-                    }
-                }
+                const int k = wave_u + 4 * r;
+                if (k < 26)
+                    __builtin_amdgcn_global_load_lds(planes + (dma_off[r] + w0), (__attribute__((address_space(3))) uint32_t *)(dst + 8 * k * EPI_CH), 16, 0, 0);
             }
             return;
         }
@@ -241,8 +248,6 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
     for (int f = 0; f < K; f++)
         #pragma unroll
         for (int c = 0; c < 9; c++) packed[f][c] = 0;
-    #pragma unroll
-    for (int c = 0; c < 9; c++) run[c] = 0;
 
     load_chunk(0, lds_a);
     store_chunk(lds_a);
@@ -250,28 +255,32 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
     __syncthreads();
     const int swz_j = DMA ? ((lane >> 1) & 7) : 0, swz_i = DMA ? (((EPI_TJ + wave) >> 1) & 7) : 0;
     uint4 xa[3], ya[3], xb[3], yb[3];
+    bool fresh = true;
 #define HPGV_EPI_FETCH(X, Y, S)                                                                          \
         _Pragma("unroll") for (int a = 0; a < 3; a++) {                                                  \
             X[a] = *reinterpret_cast<const uint4 *>(irow + a * RP + (((((S) >> 2) ^ swz_i)) << 2));          \
             Y[a] = *reinterpret_cast<const uint4 *>(jrow + a * RP + (((((S) >> 2) ^ swz_j)) << 2));          \
         }
-#define HPGV_EPI_COUNT(X, Y, S)                                                                          \
+#define HPGV_EPI_COUNT1(X, Y, FIRST)                                                                     \
         _Pragma("unroll") for (int a = 0; a < 3; a++)                                                    \
             _Pragma("unroll") for (int b = 0; b < 3; b++) {                                              \
-                uint32_t r = run[a * 3 + b];                                                             \
-                r = bcnt_acc(X[a].x & Y[b].x, r); r = bcnt_acc(X[a].y & Y[b].y, r);                      \
+                uint32_t r = (FIRST) ? (uint32_t)__popc(X[a].x & Y[b].x) : bcnt_acc(X[a].x & Y[b].x, run[a * 3 + b]); \
+                r = bcnt_acc(X[a].y & Y[b].y, r);                                                        \
                 r = bcnt_acc(X[a].z & Y[b].z, r); r = bcnt_acc(X[a].w & Y[b].w, r);                      \
                 run[a * 3 + b] = r;                                                                      \
-            }                                                                                            \
+            }
+    // `fresh` (wave-uniform): the step starts a group, its counts start from zero -- the running counts are never cleared
+#define HPGV_EPI_COUNT(X, Y, S)                                                                          \
+        if (fresh) { HPGV_EPI_COUNT1(X, Y, true) } else { HPGV_EPI_COUNT1(X, Y, false) }                 \
         {                                                                                                \
             const int g = (int)((flush >> (2 * (S))) & 0xFFu);       /* byte S / 4 */                    \
-            if (g != 0xFF) {                 /* a (fold, class) group ends here: bank its nine counts */ \
+            fresh = g != 0xFF;                                                                           \
+            if (fresh) {                     /* a (fold, class) group ends here: bank its nine counts */ \
                 const int f = g >> 1, sh = (g & 1) * 16;                                                 \
                 _Pragma("unroll") for (int ff = 0; ff < K; ff++)                                         \
                     if (ff == f) {                                                                       \
                         _Pragma("unroll") for (int cc = 0; cc < 9; cc++) packed[ff][cc] += run[cc] << sh; \
                     }                                                                                    \
-                _Pragma("unroll") for (int cc = 0; cc < 9; cc++) run[cc] = 0;                            \
             }                                                                                            \
         }
     // one chunk: the next chunk's loads fly into NXT during the counting over CUR
@@ -310,10 +319,62 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
 #undef HPGV_EPI_CHUNK
 #undef HPGV_EPI_FETCH
 #undef HPGV_EPI_COUNT
+#undef HPGV_EPI_COUNT1
 
     if (i < i_first || i >= i_end || i >= n_variants || j >= n_variants || j <= i) return;
 
     // ---- per fold: training counts, high-risk cells, confusion matrix, balanced accuracy ----
+    const float f_na = (float)(unsigned)n_affected, f_nu = (float)(unsigned)n_unaffected;
+    const float ratio = f_na / f_nu;
+    if (!acc_out && cand && n_affected < 65536 && n_unaffected < 65536) {
+        // Ranking, classes below 65 536 samples: the whole evaluation stays on the packed pairs (cases low, controls high
+        // half: neither half of a difference or of a sum of selected cells can borrow or carry), and the high-risk mask is
+        // formed only for the rare model that reaches its fold's threshold.
+        uint32_t totp[9];
+        #pragma unroll
+        for (int c = 0; c < 9; c++) {
+            totp[c] = 0;
+            #pragma unroll
+            for (int f = 0; f < K; f++) totp[c] += packed[f][c];
+        }
+        #pragma unroll
+        for (int f = 0; f < K; f++) {
+            const EpiFold fo = folds[f];
+            if (fo.test_a < 0) continue;
+            uint32_t sel = 0;                                            // TP (low half), FP (high half)
+            #pragma unroll
+            for (int c = 0; c < 9; c++) {
+                const uint32_t in = packed[f][c], tr = totp[c] - in;
+                bool high;
+                // balanced: cases >= controls, compared as (cases:controls) >= (controls:cases); an empty cell adds nothing
+                if constexpr (BALANCED) high = __builtin_amdgcn_alignbit(tr, tr, 16) >= tr;
+                else high = mdr_high_risk<false>((int)(tr & 0xFFFFu), (int)(tr >> 16), ratio, f_na, f_nu);
+                sel += high ? (TRAINING ? tr : in) : 0u;
+            }
+            const int tp = (int)(sel & 0xFFFFu), fp = (int)(sel >> 16);
+            const int size_a = TRAINING ? n_affected - fo.test_a : fo.test_a, size_u = TRAINING ? n_unaffected - fo.test_u : fo.test_u;
+            const double TP = (double)tp, TN = (double)(size_u - fp), ya = (double)size_a, yu = (double)size_u;
+            double qa = TP * fo.inv_a, qu = TN * fo.inv_u;               // the two quotients as below (Markstein)
+            qa = __builtin_fma(__builtin_fma(-qa, ya, TP), fo.inv_a, qa);
+            qu = __builtin_fma(__builtin_fma(-qu, yu, TN), fo.inv_u, qu);
+            const double acc = (qa + qu) / 2;
+            if (acc >= thr[f]) {
+                uint32_t mask = 0;
+                #pragma unroll
+                for (int c = 0; c < 9; c++) {
+                    const uint32_t tr = totp[c] - packed[f][c];
+                    if (mdr_high_risk<BALANCED>((int)(tr & 0xFFFFu), (int)(tr >> 16), ratio, f_na, f_nu)) mask |= 1u << c;
+                }
+                const unsigned slot = atomicAdd(&cand_count[f], 1u);
+                if (slot < cand_cap) {
+                    EpiCand e;
+                    e.accuracy = acc; e.i = i; e.j = j; e.risky = mask; e.pad = 0;
+                    cand[(size_t)f * cand_cap + slot] = e;
+                }
+            }
+        }
+        return;
+    }
     int tot_a[9], tot_u[9];
     #pragma unroll
     for (int c = 0; c < 9; c++) { tot_a[c] = 0; tot_u[c] = 0; }
@@ -321,8 +382,6 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
     for (int f = 0; f < K; f++)
         #pragma unroll
         for (int c = 0; c < 9; c++) { tot_a[c] += (int)(packed[f][c] & 0xFFFFu); tot_u[c] += (int)(packed[f][c] >> 16); }
-    const float f_na = (float)(unsigned)n_affected, f_nu = (float)(unsigned)n_unaffected;
-    const float ratio = f_na / f_nu;
     const unsigned long long vi = (unsigned long long)i;
     const unsigned long long p = vi * (2ull * (unsigned long long)n_variants - vi - 1ull) / 2ull + (unsigned long long)(j - i - 1) - rank_base;
     #pragma unroll
