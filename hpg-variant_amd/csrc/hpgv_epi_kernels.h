@@ -253,13 +253,13 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
     store_chunk(lds_a);
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int swz_j = DMA ? ((lane >> 1) & 7) : 0, swz_i = DMA ? (((EPI_TJ + wave) >> 1) & 7) : 0;
+    const int swz_j = DMA ? ((lane >> 1) & 7) : 0, swz_i = DMA ? (((EPI_TJ + wave_u) >> 1) & 7) : 0;
     uint4 xa[3], ya[3], xb[3], yb[3];
     bool fresh = true;
 #define HPGV_EPI_FETCH(X, Y, S)                                                                          \
         _Pragma("unroll") for (int a = 0; a < 3; a++) {                                                  \
-            X[a] = *reinterpret_cast<const uint4 *>(irow + a * RP + (((((S) >> 2) ^ swz_i)) << 2));          \
-            Y[a] = *reinterpret_cast<const uint4 *>(jrow + a * RP + (((((S) >> 2) ^ swz_j)) << 2));          \
+            X[a] = *reinterpret_cast<const uint4 *>(cur_bytes + ((DMA ? ioff ^ ((S) << 2) : ioff + ((S) << 2)) + a * RP * 4)); \
+            Y[a] = *reinterpret_cast<const uint4 *>(cur_bytes + ((DMA ? joff ^ ((S) << 2) : joff + ((S) << 2)) + a * RP * 4)); \
         }
 #define HPGV_EPI_COUNT1(X, Y, FIRST)                                                                     \
         _Pragma("unroll") for (int a = 0; a < 3; a++)                                                    \
@@ -289,8 +289,11 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
         if (c + 1 < n_chunks) load_chunk(c + 1, NXT);                                                    \
         const int nw = (int)chunks[c].nw;                                                                \
         const uint64_t flush = chunks[c].flush;                      /* wave-uniform */                  \
-        const uint32_t *jrow = &CUR[lane * 3 * RP];                                                      \
-        const uint32_t *irow = &CUR[(EPI_TJ + wave) * 3 * RP];       /* the wave's own row: broadcast */  \
+        /* byte offsets of the lane's column and of the wave's own row (the same in every lane: broadcast) in the buffer;     \
+           with the swizzle folded in, the 16-byte piece of step S sits at offset ^ (S * 4): rows are 128-byte aligned */    \
+        const char *cur_bytes = reinterpret_cast<const char *>(CUR);                                                       \
+        int joff = (lane * 3 * RP + (swz_j << 2)) * 4, ioff = ((EPI_TJ + wave_u) * 3 * RP + (swz_i << 2)) * 4;              \
+        asm("" : "+v"(joff)); asm("" : "+s"(ioff));   /* opaque: keeps the compiler from pulling the * 4 out of the ^ */     \
         if constexpr (DMA && K > 5) {                                                                    \
             /* three waves per SIMD hide the LDS latency; one register set keeps the kernel within 168 VGPRs */ \
             for (int s = 0; s < nw; s += 4) {                                                            \
