@@ -349,8 +349,10 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
             for (int c = 0; c < 9; c++) {
                 const uint32_t in = packed[f][c], tr = totp[c] - in;
                 bool high;
-                // balanced: cases >= controls, compared as (cases:controls) >= (controls:cases); an empty cell adds nothing
-                if constexpr (BALANCED) high = __builtin_amdgcn_alignbit(tr, tr, 16) >= tr;
+                // balanced: cases >= controls, compared as (cases:controls) >= (controls:cases).  An empty training cell is not
+                // high risk: on the training part it adds nothing either way; on the testing part its samples must stay out,
+                // so the comparison is made against max(tr, 1), which the swapped halves of tr = 0 cannot reach.
+                if constexpr (BALANCED) high = __builtin_amdgcn_alignbit(tr, tr, 16) >= (TRAINING ? tr : (tr > 1u ? tr : 1u));
                 else high = mdr_high_risk<false>((int)(tr & 0xFFFFu), (int)(tr >> 16), ratio, f_na, f_nu);
                 sel += high ? (TRAINING ? tr : in) : 0u;
             }

@@ -167,6 +167,40 @@ def test_ranking_is_the_top_of_the_dense_scan(eng):
             assert [(i_, j_) for _, i_, j_ in merged] == [(int(x), int(y)) for x, y in zip(res["i"][f], res["j"][f])]
 
 
+@pytest.mark.parametrize("nA,nU,k", [(180, 220, 5), (200, 200, 10), (64, 64, 2), (130, 127, 7)])
+def test_ranking_with_every_model_kept_is_the_dense_scan(eng, nA, nU, k):
+    # the ranking mode evaluates on packed 16-bit pairs and forms the high-risk mask only for kept models: with every
+    # model kept, accuracies and masks of all pairs (and of all triples) must be those of the dense scan, both subsets
+    rng = np.random.default_rng(nA + 7 * k)
+    v = 36
+    data = epi_random_dataset(rng, v, nA, nU, p_missing=0.03)
+    data[5, :nA] = rng.choice([1, 2], size=nA); data[20, :nA] = rng.choice([1, 2], size=nA)
+    fold = epi_random_folds(rng, nA, nU, k)
+    eng.epi_set_dataset(data, nA, nU)
+    eng.epi_set_folds(fold, k)
+    pairs = [(i, j) for i in range(v) for j in range(i + 1, v)]
+    triples = [(a, b, c) for a in range(v) for b in range(a + 1, v) for c in range(b + 1, v)]
+    for subset in (hpgv.EPI_TESTING, hpgv.EPI_TRAINING):
+        acc, rm = eng.epi_scan_pairs(subset)
+        res = eng.epi_rank_pairs(subset, len(pairs))
+        for f in range(k):
+            a = np.where(np.isnan(acc[f]), -np.inf, acc[f])
+            order = [p for p in sorted(range(len(pairs)), key=lambda p: (-a[p], pairs[p])) if a[p] > -np.inf]
+            assert res["n"][f] == len(order)
+            assert [(int(x), int(y)) for x, y in zip(res["i"][f], res["j"][f])] == [pairs[p] for p in order]
+            assert np.array_equal(res["accuracy"][f], acc[f][order]) and np.array_equal(res["risky"][f], rm[f][order])
+        acc3, rm3 = eng.epi_scan_triples(subset)
+        res3 = eng.epi_rank_triples(subset, len(triples))
+        for f in range(k):
+            vals = np.array([acc3[f][t] for t in triples])
+            vals = np.where(np.isnan(vals), -np.inf, vals)
+            order = [p for p in sorted(range(len(triples)), key=lambda p: (-vals[p], triples[p])) if vals[p] > -np.inf]
+            assert res3["n"][f] == len(order)
+            assert [(int(a_), int(b_), int(c_)) for a_, b_, c_ in zip(res3["i"][f], res3["j"][f], res3["k"][f])] == [triples[p] for p in order]
+            assert np.array_equal(res3["accuracy"][f], np.array([acc3[f][triples[p]] for p in order]))
+            assert np.array_equal(res3["risky"][f], np.array([rm3[f][triples[p]] for p in order], np.uint32))
+
+
 def test_epistasis_error_paths(eng):
     e = hpgv.Engine(0)
     with pytest.raises(hpgv.HpgvError):
