@@ -78,6 +78,7 @@ struct hpgv_ctx {
     long pipe_waves = 4;       // register budget of the pipelined scan, as waves per SIMD (4, 6 or 8)
     long fisher_cut_exp = 22;  // Fisher tails stop after a round whose terms are all below 10^-this of the sum so far
     long epi_dma = 1;          // epistasis pair scan: stage the planes with global_load_lds (LDS-DMA) instead of through registers
+    long epi_triples_1pass = 1; // epistasis triple ranking with at most 10 folds: one pass, all folds' counts in registers (one wave per SIMD)
     long scan_lds = 0;         // bytes of (unused) LDS per workgroup of the stats / tdt scans: caps the waves in flight per CU
     int n_cus = 256;
     // assoc
@@ -328,6 +329,8 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
         ctx->fisher_cut_exp = value;
     } else if (!strcmp(key, "epi_dma")) {
         ctx->epi_dma = value ? 1 : 0;
+    } else if (!strcmp(key, "epi_triples_1pass")) {
+        ctx->epi_triples_1pass = value ? 1 : 0;
     } else if (!strcmp(key, "scan_lds")) {
         if (value < 0 || value > 160 * 1024) return fail(ctx, HPGV_ERR_INVALID, "scan_lds must be in [0, 163840]");
         ctx->scan_lds = value;

@@ -616,4 +616,180 @@ __global__ void __launch_bounds__(256, DMA ? 3 : 2) k_epi_triples(const uint32_t
     (void)num_folds;
 }
 
+// ---------------------------------------------------------------------------
+// The triple scan of the ranking in ONE pass over the samples (at most K folds, classes below 65 536 samples): every
+// lane keeps the 27 counts of all K folds, two 16-bit counts per register (cases low, controls high) = 27 K registers
+// besides the 27 running counts and two sets of operands.  That takes the whole register file of a SIMD (one wave per
+// SIMD, up to 512 registers: what does not fit in the 256 architectural VGPRs the compiler parks in the accumulation
+// registers), so latency is hidden inside the wave: the operands of step s + 1 are read while step s counts, the next
+// chunk arrives by LDS-DMA.  Half the counting work of the two-pass form above.  Evaluation as in k_epi_pairs'
+// ranking mode: packed differences and sums, the 27-bit mask only for a model that reaches its fold's threshold.
+// ---------------------------------------------------------------------------
+template <int K, bool TRAINING, bool BALANCED>
+__global__ void __launch_bounds__(256, 1) k_epi_triples1(const uint32_t *__restrict__ planes, int W, int n_variants, int i_first,
+                                                          const unsigned *__restrict__ row_base /* n_i + 1 */, int n_i,
+                                                          const unsigned *__restrict__ jb_prefix /* n_jb + 1 */, int n_jb,
+                                                          const EpiChunk *__restrict__ chunks, int n_chunks,
+                                                          const EpiFold *__restrict__ folds, int n_affected, int n_unaffected,
+                                                          const double *__restrict__ thr, EpiCand3 *__restrict__ cand,
+                                                          unsigned *__restrict__ cand_count, unsigned cand_cap) {
+    constexpr int RP = EPI_CH;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_a[208 * RP];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_b[208 * RP];
+    // tile -> (i, j block, k tile) as in k_epi_triples
+    int r_lo = 0, r_hi = n_i;
+    while (r_hi - r_lo > 1) { const int mid = (r_lo + r_hi) >> 1; if (row_base[mid] <= blockIdx.x) r_lo = mid; else r_hi = mid; }
+    const int i = i_first + r_lo;
+    const int jb_min = (i + 1) >> 2;
+    const unsigned want = (blockIdx.x - row_base[r_lo]) + jb_prefix[jb_min];
+    int b_lo = jb_min, b_hi = n_jb;
+    while (b_hi - b_lo > 1) { const int mid = (b_lo + b_hi) >> 1; if (jb_prefix[mid] <= want) b_lo = mid; else b_hi = mid; }
+    const int j0 = b_lo * EPI_TI;
+    const int k0 = (((j0 + 1) >> 6) + (int)(want - jb_prefix[b_lo])) * EPI_TJ;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int j = j0 + wave, k = k0 + lane;
+    // LDS rows: 0..63 the k columns, 64..67 the four j rows, 68 the i row; staging as in k_epi_pairs
+    constexpr int ROWS = (EPI_TJ + EPI_TI + 1) * 3;
+    uint32_t dma_off[7];
+    #pragma unroll
+    for (int r = 0; r < 7; r++) {
+        const int kk = wave + 4 * r, row8 = 8 * kk + (lane >> 3), row = row8 < ROWS ? row8 : 0, sidx = row / 3;
+        const int piece = (lane & 7) ^ ((sidx >> 1) & 7);
+        const int snp = sidx < EPI_TJ ? k0 + sidx : sidx < EPI_TJ + EPI_TI ? j0 + (sidx - EPI_TJ) : i;
+        dma_off[r] = ((uint32_t)snp * 3u + (uint32_t)(row % 3)) * (uint32_t)W + (uint32_t)piece * 4u;
+    }
+    auto load_chunk = [&](int c, uint32_t *dst) {
+        const uint32_t w0 = chunks[c].w0;
+        #pragma unroll
+        for (int r = 0; r < 7; r++) {
+            const int kk = wave_u + 4 * r;
+            if (kk < 26)
+                __builtin_amdgcn_global_load_lds(planes + (dma_off[r] + w0), (__attribute__((address_space(3))) uint32_t *)(dst + 8 * kk * EPI_CH), 16, 0, 0);
+        }
+    };
+
+    uint32_t packed[K][27];
+    uint32_t run[27];
+    #pragma unroll
+    for (int f = 0; f < K; f++)
+        #pragma unroll
+        for (int c = 0; c < 27; c++) packed[f][c] = 0;
+    bool fresh = true;
+    const int swz_z = (lane >> 1) & 7, swz_y = ((EPI_TJ + wave_u) >> 1) & 7, swz_x = ((EPI_TJ + EPI_TI) >> 1) & 7;
+
+    load_chunk(0, lds_a);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint4 xa[3], ya[3], za[3], xb[3], yb[3], zb[3];
+#define HPGV_EPI3_FETCH(X, Y, Z, S)                                                                      \
+        _Pragma("unroll") for (int a = 0; a < 3; a++) {                                                  \
+            X[a] = *reinterpret_cast<const uint4 *>(cur_bytes + ((xoff ^ ((S) << 2)) + a * RP * 4));     \
+            Y[a] = *reinterpret_cast<const uint4 *>(cur_bytes + ((yoff ^ ((S) << 2)) + a * RP * 4));     \
+            Z[a] = *reinterpret_cast<const uint4 *>(cur_bytes + ((zoff ^ ((S) << 2)) + a * RP * 4));     \
+        }
+    // nine cells at a time: first the nine three-way ANDs, then the nine popcount-accumulates, so that no instruction
+    // waits on the one just before it (with one wave per SIMD a dependent pair issues ~1.7x slower than an independent one).
+#define HPGV_EPI3_W(V, C) ((C) == 0 ? (V).x : (C) == 1 ? (V).y : (C) == 2 ? (V).z : (V).w)
+#define HPGV_EPI3_COUNT1(X, Y, Z, FIRST)                                                 \
+        _Pragma("unroll") for (int a = 0; a < 3; a++) {                                                  \
+            _Pragma("unroll") for (int w = 0; w < 4; w++) {                                              \
+                uint32_t t9[9];                                                                          \
+                _Pragma("unroll") for (int b = 0; b < 3; b++)                                            \
+                    _Pragma("unroll") for (int d = 0; d < 3; d++)                                        \
+                        t9[b * 3 + d] = HPGV_EPI3_W(X[a], w) & HPGV_EPI3_W(Y[b], w) & HPGV_EPI3_W(Z[d], w); \
+                _Pragma("unroll") for (int q = 0; q < 9; q++)                                            \
+                    run[a * 9 + q] = ((FIRST) && w == 0) ? (uint32_t)__popc(t9[q]) : bcnt_acc(t9[q], run[a * 9 + q]); \
+            }                                                                                            \
+        }
+#define HPGV_EPI3_COUNT(X, Y, Z, S)                                                      \
+        if (fresh) { HPGV_EPI3_COUNT1(X, Y, Z, true) } else { HPGV_EPI3_COUNT1(X, Y, Z, false) }         \
+        {                                                                                                \
+            const int g = (int)((flush >> (2 * (S))) & 0xFFu);                                           \
+            fresh = g != 0xFF;                                                                           \
+            if (fresh) {                     /* a (fold, class) group ends here: bank its 27 counts */   \
+                const int f = g >> 1, sh = (g & 1) * 16;                                                 \
+                _Pragma("unroll") for (int ff = 0; ff < K; ff++)                                         \
+                    if (ff == f) {                                                                       \
+                        _Pragma("unroll") for (int cc = 0; cc < 27; cc++) packed[ff][cc] += run[cc] << sh; \
+                    }                                                                                    \
+            }                                                                                            \
+        }
+#define HPGV_EPI3_CHUNK(CUR, NXT)                                                                        \
+    {                                                                                                    \
+        if (c + 1 < n_chunks) load_chunk(c + 1, NXT);                                                    \
+        const int nw = (int)chunks[c].nw;                                                                \
+        const uint64_t flush = chunks[c].flush;                                                          \
+        const char *cur_bytes = reinterpret_cast<const char *>(CUR);                                     \
+        int zoff = (lane * 3 * RP + (swz_z << 2)) * 4, yoff = ((EPI_TJ + wave_u) * 3 * RP + (swz_y << 2)) * 4,  \
+            xoff = ((EPI_TJ + EPI_TI) * 3 * RP + (swz_x << 2)) * 4;                                      \
+        asm("" : "+v"(zoff)); asm("" : "+s"(yoff)); asm("" : "+s"(xoff));                                \
+        HPGV_EPI3_FETCH(xa, ya, za, 0)                                                                   \
+        for (int s = 0; s < nw; s += 8) {        /* reads past the chunk's end: a neighbouring row, never used */ \
+            HPGV_EPI3_FETCH(xb, yb, zb, s + 4)                                                           \
+            HPGV_EPI3_COUNT(xa, ya, za, s)                                                               \
+            HPGV_EPI3_FETCH(xa, ya, za, s + 8)                                                           \
+            HPGV_EPI3_COUNT(xb, yb, zb, s + 4)                                                           \
+        }                                                                                                \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
+        __syncthreads();                                                                                 \
+    }
+    for (int c = 0; c < n_chunks; c++) {
+        HPGV_EPI3_CHUNK(lds_a, lds_b)
+        if (++c >= n_chunks) break;
+        HPGV_EPI3_CHUNK(lds_b, lds_a)
+    }
+#undef HPGV_EPI3_CHUNK
+#undef HPGV_EPI3_COUNT
+#undef HPGV_EPI3_COUNT1
+#undef HPGV_EPI3_W
+#undef HPGV_EPI3_FETCH
+
+    if (!(j > i && k > j && j < n_variants && k < n_variants)) return;
+    const float f_na = (float)(unsigned)n_affected, f_nu = (float)(unsigned)n_unaffected;
+    const float ratio = f_na / f_nu;
+    uint32_t totp[27];
+    #pragma unroll
+    for (int c = 0; c < 27; c++) {
+        totp[c] = 0;
+        #pragma unroll
+        for (int f = 0; f < K; f++) totp[c] += packed[f][c];
+    }
+    #pragma unroll
+    for (int f = 0; f < K; f++) {
+        const EpiFold fo = folds[f];
+        if (fo.test_a < 0) continue;                                 // fold beyond the run's num_folds
+        uint32_t sel = 0;                                            // TP (low half), FP (high half)
+        #pragma unroll
+        for (int c = 0; c < 27; c++) {
+            const uint32_t in = packed[f][c], tr = totp[c] - in;
+            bool high;
+            if constexpr (BALANCED) high = __builtin_amdgcn_alignbit(tr, tr, 16) >= (TRAINING ? tr : (tr > 1u ? tr : 1u));   // as k_epi_pairs
+            else high = mdr_high_risk<false>((int)(tr & 0xFFFFu), (int)(tr >> 16), ratio, f_na, f_nu);
+            sel += high ? (TRAINING ? tr : in) : 0u;
+        }
+        const int tp = (int)(sel & 0xFFFFu), fp = (int)(sel >> 16);
+        const int size_a = TRAINING ? n_affected - fo.test_a : fo.test_a, size_u = TRAINING ? n_unaffected - fo.test_u : fo.test_u;
+        const double TP = (double)tp, TN = (double)(size_u - fp), ya_ = (double)size_a, yu_ = (double)size_u;
+        double qa = TP * fo.inv_a, qu = TN * fo.inv_u;               // the two quotients as in k_epi_pairs (Markstein)
+        qa = __builtin_fma(__builtin_fma(-qa, ya_, TP), fo.inv_a, qa);
+        qu = __builtin_fma(__builtin_fma(-qu, yu_, TN), fo.inv_u, qu);
+        const double acc = (qa + qu) / 2;
+        if (acc >= thr[f]) {
+            uint32_t mask = 0;
+            #pragma unroll
+            for (int c = 0; c < 27; c++) {
+                const uint32_t tr = totp[c] - packed[f][c];
+                if (mdr_high_risk<BALANCED>((int)(tr & 0xFFFFu), (int)(tr >> 16), ratio, f_na, f_nu)) mask |= 1u << c;
+            }
+            const unsigned slot = atomicAdd(&cand_count[f], 1u);
+            if (slot < cand_cap) {
+                EpiCand3 e;
+                e.accuracy = acc; e.i = i; e.j = j; e.k = k; e.risky = mask;
+                cand[(size_t)f * cand_cap + slot] = e;
+            }
+        }
+    }
+}
+
 }  // namespace hpgv
