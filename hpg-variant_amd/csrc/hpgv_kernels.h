@@ -289,11 +289,17 @@ __global__ __launch_bounds__(256) void k_assoc_chisq(const int4 *__restrict__ co
 // tables x with P(x) <= P_obs * (1 + 1e-7), P through the log-factorial table).
 // One wave per variant.  The hypergeometric pmf is unimodal, so the summed set is
 // a left tail [lo, xL] and a right tail [xR, hi].  Short ranges are scanned whole;
-// for long ranges the wave finds xL and xR by a 64-ary search (64 probes per
-// round) and sums each tail outwards, 64 terms per round, until a whole round
-// is below 1e-22 of the sum so far (the terms dropped are further out and decay
-// faster than geometrically, i.e. far below one ulp of the result).
-// The table (a few MB at most) stays L2 / Infinity-Cache resident.
+// for long ranges the wave finds xL and xR -- one round of two 64-wide windows around
+// where they almost always are (next to the observed table; near its mirror image
+// about the mode), a 64-ary search over what is left when a window misses -- and
+// sums each tail outwards, 64 terms per round, until a whole round is below 1e-22 of
+// the tail's largest term (the terms dropped are further out and decay faster than
+// geometrically, i.e. far below one ulp of the result).  Every term is the
+// definition's exp(konst - lf[..] - lf[..] - lf[..] - lf[..]) on the reference's own
+// table: the table's rounding noise (1e-10 relative per term at 100 k alleles) is part
+// of the reference's result, and a sum built from ratios of neighbouring terms --
+// 2x fewer instructions, measured -- drifts from it by more than the 1e-10 bar.
+// The table (a few MB at most) stays L1 / L2 resident (92 % L1 hits measured).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
@@ -306,12 +312,53 @@ __device__ __forceinline__ double wave_max_f64(double v) {
     return v;
 }
 
+// exp for the Fisher terms (arguments are log-probabilities: <= 0 up to rounding, down to underflow): e = (64 m + j) ln2/64 + r,
+// |r| <= ln2/128, exp(e) = 2^m * 2^(j/64) * (1 + r + r^2/2 + ... + r^5/120); the 64 values 2^(j/64) sit in LDS (filled by
+// the kernel).  Relative error below 3e-16 (the truncated r^6/720 is 3.5e-17); about 18 instructions against the ~45 of the
+// library's full-range exp.  Results below the denormal range flush to zero through v_ldexp_f64.
+__device__ const double k_exp2_j64[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0,
+};
+__device__ __forceinline__ double fisher_exp(double e, const double *tab /* LDS */) {
+    const double kf = __builtin_rint(e * 0x1.71547652b82fep+6);
+    double r = __builtin_fma(-kf, 0x1.62e42fe000000p-7, e);
+    r = __builtin_fma(-kf, 0x1.f473de6af278fp-36, r);
+    const int ki = (int)kf;
+    const double tj = tab[ki & 63];
+    double q = __builtin_fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    q = __builtin_fma(r, q, 1.0 / 6.0);
+    q = __builtin_fma(r, q, 0.5);
+    q = __builtin_fma(r * r, q, r);                                  // exp(r) - 1
+    const double y = __builtin_fma(tj, q, tj);
+    return e < -1100.0 ? 0.0 : __builtin_ldexp(y, ki >> 6);
+}
+
 struct FisherTab {
-    const double *lf; double konst; int r1, c1, d0;    // d0 = r2 - c1
+    const double *lf; const double *xt /* 2^(j/64), LDS */; double konst; int r1, c1, d0;    // d0 = r2 - c1
     // ln P(x): the exponent of the definition's term; comparisons between terms are made on it (exp is monotone),
     // so the boundary searches need no exp at all
-    __device__ __forceinline__ double e(int x) const { return konst - lf[x] - lf[r1 - x] - lf[c1 - x] - lf[d0 + x]; }
-    __device__ __forceinline__ double p(int x) const { return exp(e(x)); }
+    // the four table reads address the table by unsigned 32-bit byte offsets off a scalar base (one VALU op per address)
+    __device__ __forceinline__ double at(uint32_t byte_off) const { return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lf) + byte_off); }
+    __device__ __forceinline__ double e(int x) const {
+        const uint32_t x8 = (uint32_t)x << 3;
+        return konst - at(x8) - at(((uint32_t)r1 << 3) - x8) - at(((uint32_t)c1 << 3) - x8) - at(((uint32_t)d0 << 3) + x8);
+    }
+    __device__ __forceinline__ double p(int x) const { return fisher_exp(e(x), xt); }
 };
 
 // Boundary of a prefix-true predicate over [L, R) by 64-ary search: 64 probes per round; UP (left of the mode, p
@@ -346,31 +393,76 @@ __device__ __forceinline__ void fisher_boundaries(const FisherTab &T, double thr
     *xR = L2 + __builtin_popcountll(__ballot(x2 < R2 && v2 > thr));
 }
 
-// Both tails in lockstep (left from xL - 1 downwards, right from xR upwards).  Lanes keep private partial sums (one
-// wave reduction at the end); a tail ends after a round in which none of its terms exceeds rel_cut x its own first
-// round's total (the terms dropped are further out and decay faster than geometrically).
+// Both tails in lockstep (left from xL - 1 downwards, right from xR upwards), 4 x 64 tables per side and turn: the
+// table reads and exps of a turn are independent of each other, so a variant costs two or three memory round trips here
+// instead of one per 64 tables (the kernel is bound by such dependent round trips, not by instructions).  Lanes keep
+// private partial sums (one wave reduction at the end); a tail ends after a turn whose outermost 64 tables are all
+// below rel_cut x its own first (largest) table (the tables dropped are further out and decay faster than geometrically).
 __device__ __forceinline__ double fisher_tails(const FisherTab &T, int xL, int xR, int lo, int hi, int lane, double rel_cut) {
+    constexpr int U = 1;
     double partL = 0.0, partR = 0.0, cutL = 0.0, cutR = 0.0;
     bool onL = true, onR = true;
     for (int k = 0; onL || onR; ++k) {                              // wave-uniform
-        const int firstL = xL - 1 - 64 * k, firstR = xR + 64 * k;
+        const int firstL = xL - 1 - 64 * U * k, firstR = xR + 64 * U * k;
         if (firstL < lo) onL = false;
         if (firstR > hi) onR = false;
-        const int a = firstL - lane, b = firstR + lane;
-        const double vL = (onL && a >= lo) ? T.p(a) : 0.0;
-        const double vR = (onR && b <= hi) ? T.p(b) : 0.0;
-        partL += vL; partR += vR;
-        if (k == 0) { cutL = rel_cut * wave_sum_f64(vL); cutR = rel_cut * wave_sum_f64(vR); }
-        if (onL && __ballot(vL > cutL) == 0ull) onL = false;
-        if (onR && __ballot(vR > cutR) == 0ull) onR = false;
+        double eL[U], eR[U];
+        #pragma unroll
+        for (int u = 0; u < U; u++) {                               // all the table reads first
+            const int a = firstL - lane - 64 * u, b = firstR + lane + 64 * u;
+            eL[u] = (onL && a >= lo) ? T.e(a) : -2000.0;
+            eR[u] = (onR && b <= hi) ? T.e(b) : -2000.0;
+        }
+        double sL = 0.0, sR = 0.0, lastL = 0.0, lastR = 0.0;
+        #pragma unroll
+        for (int u = 0; u < U; u++) {
+            lastL = fisher_exp(eL[u], T.xt); lastR = fisher_exp(eR[u], T.xt);       // exp(-2000) = 0
+            sL += lastL; sR += lastR;
+        }
+        partL += sL; partR += sR;
+        // the reference value of a tail: its first table (lane 0 of the first turn), the largest of the tail
+        if (k == 0) { cutL = rel_cut * __shfl(sL, 0); cutR = rel_cut * __shfl(sR, 0); }
+        if (onL && __ballot(lastL > cutL) == 0ull) onL = false;
+        if (onR && __ballot(lastR > cutR) == 0ull) onR = false;
     }
-    return wave_sum_f64(partL) + wave_sum_f64(partR);
+    return wave_sum_f64(partL + partR);
+}
+
+// The two boundaries are almost always where a guess puts them: on the observed side right after the observed table
+// (further only by the 1e-7 slack, i.e. next to the mode), on the other side near the mirror image of the observed table
+// about the mode (off by the skew: a few tables).  One round probes a 64-wide window around each guess; a window that
+// does not bracket its boundary leaves a one-sided range to the 64-ary search.  Returns true when both were found.
+__device__ __forceinline__ bool fisher_boundary_windows(const FisherTab &T, double thr /* ln */, int lo, int mode, int hi, int obs, int lane,
+                                                        int *L1, int *R1, int *L2, int *R2) {
+    // left: pred(x) = e(x) <= thr is prefix-true over [lo, mode + 1); right: pred(x) = e(x) > thr over [mode + 1, hi + 1)
+    const int g1 = obs <= mode ? obs + 1 : 2 * mode - obs + 1, g2 = obs <= mode ? 2 * mode - obs : obs;
+    int w1 = g1 - 32, w2 = g2 - 32;
+    w1 = w1 > *R1 - 64 ? *R1 - 64 : w1; w1 = w1 < *L1 ? *L1 : w1;
+    w2 = w2 > *R2 - 64 ? *R2 - 64 : w2; w2 = w2 < *L2 ? *L2 : w2;
+    const int x1 = w1 + lane, x2 = w2 + lane;
+    const bool in1 = x1 < *R1, in2 = x2 < *R2;
+    const double v1 = in1 ? T.e(x1) : 0.0, v2 = in2 ? T.e(x2) : 0.0;
+    const int n1 = __builtin_popcountll(__ballot(in1)), n2 = __builtin_popcountll(__ballot(in2));
+    const int c1 = __builtin_popcountll(__ballot(in1 && v1 <= thr)), c2 = __builtin_popcountll(__ballot(in2 && v2 > thr));
+    bool ok = true;
+    // count == 0: the boundary is at or left of the window's start; count == all: at or right of its end
+    if (c1 == 0 && w1 > *L1) { *R1 = w1; ok = false; }
+    else if (c1 == n1 && w1 + n1 < *R1) { *L1 = w1 + n1; ok = false; }
+    else { *L1 = w1 + c1; *R1 = w1 + c1; }
+    if (c2 == 0 && w2 > *L2) { *R2 = w2; ok = false; }
+    else if (c2 == n2 && w2 + n2 < *R2) { *L2 = w2 + n2; ok = false; }
+    else { *L2 = w2 + c2; *R2 = w2 + c2; }
+    (void)lo; (void)hi;
+    return ok;
 }
 
 __global__ __launch_bounds__(256) void k_assoc_fisher(const int4 *__restrict__ counts, int n,
                                                       const double *__restrict__ lf,
                                                       double *__restrict__ odds,
                                                       double *__restrict__ pval, double rel_cut) {
+    __shared__ double exp_tab[64];
+    if (threadIdx.x < 64) exp_tab[threadIdx.x] = k_exp2_j64[threadIdx.x];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (v >= n) return;
@@ -380,7 +472,7 @@ __global__ __launch_bounds__(256) void k_assoc_fisher(const int4 *__restrict__ c
     const int lo = (c1 - r2) > 0 ? (c1 - r2) : 0;
     const int hi = r1 < c1 ? r1 : c1;
     FisherTab T;
-    T.lf = lf; T.r1 = r1; T.c1 = c1; T.d0 = r2 - c1;
+    T.lf = lf; T.xt = exp_tab; T.r1 = r1; T.c1 = c1; T.d0 = r2 - c1;
     T.konst = lf[r1] + lf[r2] + lf[c1] + lf[nn - c1] - lf[nn];
     // included tables: P(x) <= P_obs * (1 + 1e-7), tested as ln P(x) <= ln P_obs + ln(1 + 1e-7)
     const double thr = T.e(a) + 9.9999995000000333e-08;
@@ -389,18 +481,23 @@ __global__ __launch_bounds__(256) void k_assoc_fisher(const int4 *__restrict__ c
         double part = 0.0;
         for (int x = lo + lane; x <= hi; x += 64) {
             const double ex = T.e(x);
-            if (ex <= thr) part += exp(ex);
+            if (ex <= thr) part += fisher_exp(ex, exp_tab);
         }
         sum = wave_sum_f64(part);
     } else {
-        // mode of the hypergeometric distribution, clamped to the support
-        long md = ((long)(r1 + 1) * (long)(c1 + 1)) / ((long)nn + 2);
+        // mode of the hypergeometric distribution, floor((r1 + 1)(c1 + 1) / (n + 2)), clamped to the support: the quotient
+        // in double (the product is below 2^53), put right with the exact remainder
+        const double prod = (double)(r1 + 1) * (double)(c1 + 1), den = (double)(nn + 2);      // exact: below 2^53
+        double md = __builtin_floor(prod / den);
+        const double rem = __builtin_fma(-md, den, prod);           // exact remainder of the candidate
+        md += rem >= den ? 1.0 : (rem < 0.0 ? -1.0 : 0.0);
         int mode = (int)md;
         mode = mode < lo ? lo : (mode > hi ? hi : mode);
         // left of (and including) the mode p grows with x: included x are a prefix [lo, xL)
         // right of the mode p falls: p > thr on a prefix [mode+1, xR), included x are [xR, hi]
-        int xL, xR;
-        fisher_boundaries(T, thr, lo, mode + 1, mode + 1, hi + 1, lane, &xL, &xR);
+        int L1 = lo, R1 = mode + 1, L2 = mode + 1, R2 = hi + 1, xL, xR;
+        if (fisher_boundary_windows(T, thr, lo, mode, hi, a, lane, &L1, &R1, &L2, &R2)) { xL = L1; xR = L2; }
+        else fisher_boundaries(T, thr, L1, R1, L2, R2, lane, &xL, &xR);
         sum = fisher_tails(T, xL, xR, lo, hi, lane, rel_cut);
     }
     if (lane == 0) {

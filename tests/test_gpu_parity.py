@@ -538,3 +538,43 @@ def test_epistasis_dataset_reference_kat_and_random(goldens):
     exp = np.where((a1 == 15) | (a2 == 15), 255, np.where((a1 == 0) & (a2 == 0), 0, np.where(a1 != a2, 1, 2))).astype(np.uint8)
     assert np.array_equal(out, exp)
     e.close()
+
+
+def test_fisher_table_sweep():
+    # 2x2 tables straight into the Fisher p-pass (hpgv_assoc_fisher_dev): margins from balanced to very skewed, 2 k to
+    # 400 k alleles, the observed table from the mode out to 30 sigma on either side and at the ends of the support --
+    # every path of the kernel (whole-support scan, boundary windows that hit / miss, one or several tail rounds)
+    rng = np.random.default_rng(2024)
+    tabs = []
+    for nn in (700, 2000, 20_000, 100_000, 400_000):
+        for fr in (0.5, 0.3, 0.1, 0.02):
+            for fc in (0.5, 0.3, 0.05, 0.9):
+                r1, c1 = max(1, int(nn * fr)), max(1, int(nn * fc))
+                r2 = nn - r1
+                lo, hi = max(0, c1 - r2), min(r1, c1)
+                mode = min(hi, max(lo, (r1 + 1) * (c1 + 1) // (nn + 2)))
+                sigma = max(1.0, (r1 * (c1 / nn) * (1 - c1 / nn) * (nn - r1) / max(1, nn - 1)) ** 0.5)
+                xs = {lo, hi, min(hi, lo + 1), max(lo, hi - 1), mode, min(hi, mode + 1), max(lo, mode - 1)}
+                for t in (0.3, 1, 2, 3, 6, 12, 30):
+                    for sgn in (-1, 1):
+                        xs.add(int(min(hi, max(lo, round(mode + sgn * t * sigma + rng.uniform(-0.5, 0.5))))))
+                for x in sorted(xs):
+                    tabs.append((x, r1 - x, c1 - x, r2 - (c1 - x)))
+    tabs = np.array(tabs, dtype=np.int32)
+    assert (tabs >= 0).all()
+    n = len(tabs)
+    lf = orc.logfact(400_000 + 16)
+    e = fresh()
+    e.set_cohort(np.zeros(4, np.uint8))
+    e.set_logfact(lf)
+    d_counts, d_st = e.alloc(n * 16), e.alloc(n * 16)
+    e.h2d(d_counts, tabs)
+    e.assoc_fisher(d_counts, n, d_st.value, d_st.value + 8 * n)
+    e.sync()
+    got = e.d2h(d_st.value + 8 * n, (n,), np.float64)
+    _, _, exp = orc.assoc_stats(orc.TASK_FISHER, tabs[:, 0], tabs[:, 1], tabs[:, 2], tabs[:, 3], lf)
+    assert_close(got, exp, "fisher p over the table sweep")
+    # relative agreement too, where the p-value is not denormal-small
+    big = exp > 1e-280
+    assert np.all(np.abs(got[big] - exp[big]) <= 1e-11 * exp[big]), np.max(np.abs(got[big] - exp[big]) / exp[big])
+    e.close()
