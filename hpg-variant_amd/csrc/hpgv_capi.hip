@@ -76,7 +76,7 @@ struct hpgv_ctx {
     long blocks_per_cu = 8;
     long pipeline = 1;         // 1: software-pipelined scan (loads of the next tile before counting this one)
     long pipe_waves = 4;       // register budget of the pipelined scan, as waves per SIMD (4, 6 or 8)
-    long fisher_cut_exp = 22;  // Fisher tails stop after a round whose terms are all below 10^-this of the sum so far
+    long fisher_cut_exp = 22;  // Fisher tails stop after a round whose terms are all below 10^-this of the tail's largest term
     long epi_dma = 1;          // epistasis pair scan: stage the planes with global_load_lds (LDS-DMA) instead of through registers
     long epi_triples_1pass = 1; // epistasis triple ranking with at most 10 folds: one pass, all folds' counts in registers (one wave per SIMD)
     long scan_lds = 0;         // bytes of (unused) LDS per workgroup of the stats / tdt scans: caps the waves in flight per CU
