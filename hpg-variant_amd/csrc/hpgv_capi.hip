@@ -47,6 +47,8 @@ struct EpiState {
     int V = 0, nA = 0, nU = 0, num_folds = 0, W = 0, V_alloc = 0, n_chunks = 0;
     uint8_t *d_data = nullptr;
     uint32_t *d_planes = nullptr;
+    uint32_t *d_marg = nullptr;       // per SNP and (fold, class) group: samples with genotype 0 / 1 (16 bits each)
+    bool complete = false;            // the dataset holds no call other than 0 / 1 / 2
     hpgv::EpiChunk *d_chunks = nullptr;
     hpgv::EpiFold *d_folds = nullptr;
     uint32_t *d_group_w0 = nullptr;
@@ -78,6 +80,7 @@ struct hpgv_ctx {
     long pipe_waves = 4;       // register budget of the pipelined scan, as waves per SIMD (4, 6 or 8)
     long fisher_cut_exp = 22;  // Fisher tails stop after a round whose terms are all below 10^-this of the tail's largest term
     long epi_dma = 1;          // epistasis pair scan: stage the planes with global_load_lds (LDS-DMA) instead of through registers
+    long epi_complete = 1;     // epistasis pair scan on a dataset without missing calls: count four cells, derive the other five
     long epi_triples_1pass = 1; // epistasis triple ranking with at most 10 folds: one pass, all folds' counts in registers (one wave per SIMD)
     long scan_lds = 0;         // bytes of (unused) LDS per workgroup of the stats / tdt scans: caps the waves in flight per CU
     int n_cus = 256;
@@ -329,6 +332,8 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
         ctx->fisher_cut_exp = value;
     } else if (!strcmp(key, "epi_dma")) {
         ctx->epi_dma = value ? 1 : 0;
+    } else if (!strcmp(key, "epi_complete")) {
+        ctx->epi_complete = value ? 1 : 0;
     } else if (!strcmp(key, "epi_triples_1pass")) {
         ctx->epi_triples_1pass = value ? 1 : 0;
     } else if (!strcmp(key, "scan_lds")) {

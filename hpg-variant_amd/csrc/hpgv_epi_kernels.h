@@ -51,18 +51,20 @@ struct EpiCand {                      // a model that reached a fold's current t
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_epi_planes(const uint8_t *__restrict__ data, int n_variants, int n_samples,
                                                      const int32_t *__restrict__ src_of_pos, int W,
-                                                     uint32_t *__restrict__ planes) {
+                                                     uint32_t *__restrict__ planes, unsigned *__restrict__ any_missing) {
     const int snp = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t *out = planes + (size_t)snp * 3 * W;
     const uint8_t *row = data + (size_t)snp * n_samples;
     for (int w2 = wave; w2 * 2 < W; w2 += 4) {                       // 64 bit positions per wave step
         const int p = w2 * 64 + lane;
         uint32_t g = 255;
+        bool missing = false;
         if (snp < n_variants && p < W * 32) {
             const int s = src_of_pos[p];
-            if (s >= 0) g = row[s];
+            if (s >= 0) { g = row[s]; missing = g > 2; }
         }
         const unsigned long long b0 = __ballot(g == 0), b1 = __ballot(g == 1), b2 = __ballot(g == 2);
+        if (__ballot(missing) != 0ull && lane == 0) atomicOr(any_missing, 1u);   // a call that is none of 0 / 1 / 2
         if (lane == 0) {
             out[0 * W + 2 * w2] = (uint32_t)b0; out[1 * W + 2 * w2] = (uint32_t)b1; out[2 * W + 2 * w2] = (uint32_t)b2;
             if (2 * w2 + 1 < W) {
@@ -70,6 +72,21 @@ __global__ void __launch_bounds__(256) k_epi_planes(const uint8_t *__restrict__ 
                 out[2 * W + 2 * w2 + 1] = (uint32_t)(b2 >> 32);
             }
         }
+    }
+}
+
+// per SNP and (fold, class) group: how many of the group's samples have genotype 0 and genotype 1 (low / high 16 bits).
+// marg[snp * (2 * EPI_MAX_FOLDS) + g].  One workgroup per SNP row, wave w takes the groups w, w + 4, ...
+__global__ void __launch_bounds__(256) k_epi_marginals(const uint32_t *__restrict__ planes, int W, const uint32_t *__restrict__ group_w0,
+                                                        int n_groups, uint32_t *__restrict__ marg) {
+    const int snp = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t *p0 = planes + (size_t)snp * 3 * W, *p1 = p0 + W;
+    for (int g = wave; g < 2 * EPI_MAX_FOLDS; g += 4) {
+        int c0 = 0, c1 = 0;
+        if (g < n_groups)
+            for (uint32_t w = group_w0[g] + lane; w < group_w0[g + 1]; w += 64) { c0 += __popc(p0[w]); c1 += __popc(p1[w]); }
+        c0 = wave_sum(c0); c1 = wave_sum(c1);
+        if (lane == 0) marg[(size_t)snp * (2 * EPI_MAX_FOLDS) + g] = (uint32_t)c0 | ((uint32_t)c1 << 16);
     }
 }
 
@@ -160,8 +177,12 @@ __global__ void __launch_bounds__(256) k_epi_counts(const uint32_t *__restrict__
 // registers: 9 running counts of the current group + K x 9 finished groups, two 16-bit counts per register
 // (affected low, unaffected high: a (fold, class) group holds fewer than 65536 samples).
 // ---------------------------------------------------------------------------
-template <int K, bool TRAINING, bool BALANCED, bool DMA>
-__global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(const uint32_t *__restrict__ planes, int W, int n_variants, int i_begin, int i_first, int i_end,
+// MODE 0: staging through registers; 1: LDS-DMA; 2: LDS-DMA on a dataset WITHOUT missing calls, where only the four cells
+// of genotypes {0, 1} x {0, 1} are counted (16 instead of 36 AND + popcount pairs per step, two planes per SNP staged)
+// and the other five follow at a group's end from the per-SNP, per-group genotype counts `marg` (k_epi_marginals):
+// n(a, 2) = n_i(a) - n(a, 0) - n(a, 1), n(2, b) = n_j(b) - n(0, b) - n(1, b), n(2, 2) = the rest of the group.
+template <int K, bool TRAINING, bool BALANCED, int MODE>
+__global__ void __launch_bounds__(256, (MODE != 0 && K <= 10) ? 3 : 2) k_epi_pairs(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ marg, int W, int n_variants, int i_begin, int i_first, int i_end,
                                                     const unsigned *__restrict__ tile_base, int n_cols, unsigned n_tiles,
                                                     const EpiChunk *__restrict__ chunks, int n_chunks,
                                                     const EpiFold *__restrict__ folds /* K */, int n_affected, int n_unaffected,
@@ -171,8 +192,11 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
                                                     unsigned *__restrict__ cand_count, unsigned cand_cap) {
     // register-staged: rows pitched 36 words; LDS-DMA (DMA): 26 x 8 linear rows of 32 words, the 16-byte pieces of a row
     // swizzled by the column index so that the per-lane reads of 16 lanes fall on 16 different slots
+    constexpr bool DMA = MODE != 0, COMPLETE = MODE == 2;
+    constexpr int NP = COMPLETE ? 2 : 3, NC = NP * NP;               // planes staged per SNP, cells counted
     constexpr int RP = DMA ? EPI_CH : EPI_ROW;
-    constexpr int LROWS = DMA ? 208 : (EPI_TJ + EPI_TI) * 3;
+    constexpr int LROWS = COMPLETE ? 136 : DMA ? 208 : (EPI_TJ + EPI_TI) * 3;
+    constexpr int NDMA = COMPLETE ? 17 : 26;                         // LDS-DMA instructions per chunk (8 rows each)
     // two separate arrays, not lds[2][...]: the compiler then sees that the LDS-DMA writes into one buffer cannot touch the
     // other and does not put an s_waitcnt vmcnt(0) in front of the counting loop's reads
     __shared__ __attribute__((aligned(16))) uint32_t lds_a[LROWS * RP];
@@ -192,22 +216,24 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
     const int i = i0 + wave, j = j0 + lane;
 
     // ---- staging: piece q = one 16-byte piece of one (snp, plane) row of the chunk ----
-    constexpr int ROWS = (EPI_TJ + EPI_TI) * 3, PIECES = ROWS * (EPI_CH / 4), PER_T = (PIECES + 255) / 256;
+    constexpr int ROWS = (EPI_TJ + EPI_TI) * NP, PIECES = ROWS * (EPI_CH / 4), PER_T = (PIECES + 255) / 256;
     uint4 stage[DMA ? 1 : PER_T];
     // LDS-DMA: one global_load_lds_dwordx4 = 64 lanes x 16 B = 8 rows of the image; lane l fetches row 8k + l / 8, physical
     // piece l % 8, i.e. the logical piece (l % 8) ^ swizzle(row's SNP): the swizzle sits on the source address.  Kept per
     // instruction: the word offset of the lane's piece inside the planes (below 2^32 words).  Always whole 32-word rows
     // (the words past a short last chunk are fetched and never read: the planes carry 32 words of slack); the four rows
-    // of the image past the 204 used ones re-fetch row 0.
+    // of the image past the 204 used ones re-fetch row 0.  The complete-data image is plane-major (row = plane * 68 + SNP,
+    // 136 rows = 17 instructions): with two planes per SNP an SNP-major image would put all 16 lanes of a read on 32 banks.
     uint32_t dma_off[7];
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);         // the wave index as a scalar
     if constexpr (DMA) {
         #pragma unroll
         for (int r = 0; r < 7; r++) {
-            const int k = wave + 4 * r, row8 = 8 * k + (lane >> 3), row = row8 < ROWS ? row8 : 0, snp_idx = row / 3;
+            const int k = wave + 4 * r, row8 = 8 * k + (lane >> 3), row = row8 < ROWS ? row8 : 0;
+            const int snp_idx = COMPLETE ? row % (EPI_TJ + EPI_TI) : row / 3, plane = COMPLETE ? row / (EPI_TJ + EPI_TI) : row % 3;
             const int piece = (lane & 7) ^ ((snp_idx >> 1) & 7);
             const int snp = snp_idx < EPI_TJ ? j0 + snp_idx : i0 + (snp_idx - EPI_TJ);
-            dma_off[r] = ((uint32_t)snp * 3u + (uint32_t)(row % 3)) * (uint32_t)W + (uint32_t)piece * 4u;
+            dma_off[r] = ((uint32_t)snp * 3u + (uint32_t)plane) * (uint32_t)W + (uint32_t)piece * 4u;
         }
     }
     auto load_chunk = [&](int c, uint32_t *dst) {
@@ -218,7 +244,7 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
             #pragma unroll
             for (int r = 0; r < 7; r++) {
                 const int k = wave_u + 4 * r;
-                if (k < 26)
+                if (k < NDMA)
                     __builtin_amdgcn_global_load_lds(planes + (dma_off[r] + w0), (__attribute__((address_space(3))) uint32_t *)(dst + 8 * k * EPI_CH), 16, 0, 0);
             }
             return;
@@ -243,31 +269,43 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
     };
 
     uint32_t packed[K][9];
-    uint32_t run[9];
+    uint32_t run[NC];
     #pragma unroll
     for (int f = 0; f < K; f++)
         #pragma unroll
         for (int c = 0; c < 9; c++) packed[f][c] = 0;
+    // complete data: genotype counts of the tile's 64 + 4 SNPs per group, [g][0..63 columns | 64..67 rows | 68 group size]
+    __shared__ uint32_t lds_marg[COMPLETE ? 2 * K * 69 : 1];
+    if constexpr (COMPLETE) {
+        for (int q = t; q < 2 * K * 69; q += 256) {
+            const int g = q / 69, e = q % 69;
+            uint32_t v;
+            if (e < EPI_TJ + EPI_TI) v = marg[(size_t)(e < EPI_TJ ? j0 + e : i0 + (e - EPI_TJ)) * (2 * EPI_MAX_FOLDS) + g];
+            else { const int n = (g & 1) ? folds[g >> 1].test_u : folds[g >> 1].test_a; v = n > 0 ? (uint32_t)n : 0u; }
+            lds_marg[q] = v;
+        }
+    }
 
     load_chunk(0, lds_a);
     store_chunk(lds_a);
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int swz_j = DMA ? ((lane >> 1) & 7) : 0, swz_i = DMA ? (((EPI_TJ + wave_u) >> 1) & 7) : 0;
-    uint4 xa[3], ya[3], xb[3], yb[3];
+    constexpr int PS = COMPLETE ? (EPI_TJ + EPI_TI) * RP * 4 : RP * 4;      // bytes from one plane of an SNP to the next
+    uint4 xa[NP], ya[NP], xb[NP], yb[NP];
     bool fresh = true;
 #define HPGV_EPI_FETCH(X, Y, S)                                                                          \
-        _Pragma("unroll") for (int a = 0; a < 3; a++) {                                                  \
-            X[a] = *reinterpret_cast<const uint4 *>(cur_bytes + ((DMA ? ioff ^ ((S) << 2) : ioff + ((S) << 2)) + a * RP * 4)); \
-            Y[a] = *reinterpret_cast<const uint4 *>(cur_bytes + ((DMA ? joff ^ ((S) << 2) : joff + ((S) << 2)) + a * RP * 4)); \
+        _Pragma("unroll") for (int a = 0; a < NP; a++) {                                                 \
+            X[a] = *reinterpret_cast<const uint4 *>(cur_bytes + ((DMA ? ioff ^ ((S) << 2) : ioff + ((S) << 2)) + a * PS)); \
+            Y[a] = *reinterpret_cast<const uint4 *>(cur_bytes + ((DMA ? joff ^ ((S) << 2) : joff + ((S) << 2)) + a * PS)); \
         }
 #define HPGV_EPI_COUNT1(X, Y, FIRST)                                                                     \
-        _Pragma("unroll") for (int a = 0; a < 3; a++)                                                    \
-            _Pragma("unroll") for (int b = 0; b < 3; b++) {                                              \
-                uint32_t r = (FIRST) ? (uint32_t)__popc(X[a].x & Y[b].x) : bcnt_acc(X[a].x & Y[b].x, run[a * 3 + b]); \
+        _Pragma("unroll") for (int a = 0; a < NP; a++)                                                   \
+            _Pragma("unroll") for (int b = 0; b < NP; b++) {                                             \
+                uint32_t r = (FIRST) ? (uint32_t)__popc(X[a].x & Y[b].x) : bcnt_acc(X[a].x & Y[b].x, run[a * NP + b]); \
                 r = bcnt_acc(X[a].y & Y[b].y, r);                                                        \
                 r = bcnt_acc(X[a].z & Y[b].z, r); r = bcnt_acc(X[a].w & Y[b].w, r);                      \
-                run[a * 3 + b] = r;                                                                      \
+                run[a * NP + b] = r;                                                                     \
             }
     // `fresh` (wave-uniform): the step starts a group, its counts start from zero -- the running counts are never cleared
 #define HPGV_EPI_COUNT(X, Y, S)                                                                          \
@@ -277,9 +315,20 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
             fresh = g != 0xFF;                                                                           \
             if (fresh) {                     /* a (fold, class) group ends here: bank its nine counts */ \
                 const int f = g >> 1, sh = (g & 1) * 16;                                                 \
+                uint32_t cell[9];                                                                        \
+                if constexpr (COMPLETE) {    /* the five cells with a genotype 2 from the genotype counts */ \
+                    const uint32_t mj = lds_marg[g * 69 + lane], mi = lds_marg[g * 69 + EPI_TJ + wave_u], ng = lds_marg[g * 69 + 68]; \
+                    const uint32_t mj0 = mj & 0xFFFFu, mj1 = mj >> 16, mi0 = mi & 0xFFFFu, mi1 = mi >> 16;  \
+                    cell[0] = run[0]; cell[1] = run[1]; cell[2] = mi0 - run[0] - run[1];                 \
+                    cell[3] = run[2]; cell[4] = run[3]; cell[5] = mi1 - run[2] - run[3];                 \
+                    cell[6] = mj0 - run[0] - run[2]; cell[7] = mj1 - run[1] - run[3];                    \
+                    cell[8] = ng - mi0 - mi1 - cell[6] - cell[7];                                        \
+                } else {                                                                                 \
+                    _Pragma("unroll") for (int cc = 0; cc < 9; cc++) cell[cc] = run[cc < NC ? cc : 0];   \
+                }                                                                                        \
                 _Pragma("unroll") for (int ff = 0; ff < K; ff++)                                         \
                     if (ff == f) {                                                                       \
-                        _Pragma("unroll") for (int cc = 0; cc < 9; cc++) packed[ff][cc] += run[cc] << sh; \
+                        _Pragma("unroll") for (int cc = 0; cc < 9; cc++) packed[ff][cc] += cell[cc] << sh; \
                     }                                                                                    \
             }                                                                                            \
         }
@@ -292,7 +341,8 @@ __global__ void __launch_bounds__(256, (DMA && K <= 10) ? 3 : 2) k_epi_pairs(con
         /* byte offsets of the lane's column and of the wave's own row (the same in every lane: broadcast) in the buffer;     \
            with the swizzle folded in, the 16-byte piece of step S sits at offset ^ (S * 4): rows are 128-byte aligned */    \
         const char *cur_bytes = reinterpret_cast<const char *>(CUR);                                                       \
-        int joff = (lane * 3 * RP + (swz_j << 2)) * 4, ioff = ((EPI_TJ + wave_u) * 3 * RP + (swz_i << 2)) * 4;              \
+        int joff = (lane * (COMPLETE ? 1 : 3) * RP + (swz_j << 2)) * 4,                                                    \
+            ioff = ((EPI_TJ + wave_u) * (COMPLETE ? 1 : 3) * RP + (swz_i << 2)) * 4;                                        \
         asm("" : "+v"(joff)); asm("" : "+s"(ioff));   /* opaque: keeps the compiler from pulling the * 4 out of the ^ */     \
         if constexpr (DMA && K > 5) {                                                                    \
             /* three waves per SIMD hide the LDS latency; one register set keeps the kernel within 168 VGPRs */ \

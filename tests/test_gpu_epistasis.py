@@ -95,6 +95,49 @@ def test_pair_scan_matches_the_oracle(eng, v, nA, nU, k):
         assert _same(a2, acc[:, lo: lo + a2.shape[1]]) and np.array_equal(m2, rm[:, lo: lo + a2.shape[1]])
 
 
+@pytest.mark.parametrize("v,nA,nU,k", [(70, 37, 52, 5), (130, 300, 420, 10), (65, 5, 4, 3), (40, 1100, 1300, 4), (33, 64, 64, 1),
+                                       (50, 256, 256, 8), (90, 100, 100, 10), (12, 2500, 2300, 8), (21, 3, 40, 2)])
+def test_pair_scan_on_a_dataset_without_missing_calls(eng, v, nA, nU, k):
+    # complete data takes its own counting path (four cells counted, five derived from per-SNP genotype counts): every pair
+    # against the oracle, both subsets; the ranking with every model kept; and the same numbers with the path switched off
+    rng = np.random.default_rng(v * 11 + k)
+    data = epi_random_dataset(rng, v, nA, nU, p_missing=0.0)
+    assert data.max() <= 2
+    if v > 40:
+        data[3] = 0; data[17] = 2; data[29, :nA] = 1                # monomorphic SNPs: whole rows / columns of empty cells
+    fold = epi_random_folds(rng, nA, nU, k)
+    eng.epi_set_dataset(data, nA, nU)
+    eng.epi_set_folds(fold, k)
+    masks = orc.fold_masks_from_assignment(fold, k)
+    pairs = [(i, j) for i in range(v) for j in range(i + 1, v)]
+    for subset in (hpgv.EPI_TESTING, hpgv.EPI_TRAINING):
+        acc, rm = eng.epi_scan_pairs(subset)
+        eacc, erm = orc.epi_scan_pairs(data, nA, nU, masks, subset)
+        assert np.array_equal(rm, erm.astype(np.uint16)), "risky cells differ"
+        assert _same(acc, eacc), "accuracy differs"
+        res = eng.epi_rank_pairs(subset, len(pairs))
+        for f in range(k):
+            a = np.where(np.isnan(acc[f]), -np.inf, acc[f])
+            order = [p for p in sorted(range(len(pairs)), key=lambda p: (-a[p], pairs[p])) if a[p] > -np.inf]
+            n = len(order)
+            assert res["n"][f] == n
+            assert [(int(x), int(y)) for x, y in zip(res["i"][f][:n], res["j"][f][:n])] == [pairs[p] for p in order]
+            assert np.array_equal(res["accuracy"][f][:n], acc[f][order]) and np.array_equal(res["risky"][f][:n], rm[f][order])
+    eng.set_option("epi_complete", 0)
+    try:
+        acc0, rm0 = eng.epi_scan_pairs(hpgv.EPI_TRAINING)
+    finally:
+        eng.set_option("epi_complete", 1)
+    assert _same(acc0, acc) and np.array_equal(rm0, rm)
+    # one missing call anywhere switches the path off by itself
+    data[v // 2, (nA + nU) // 2] = 255
+    eng.epi_set_dataset(data, nA, nU)
+    eng.epi_set_folds(fold, k)
+    acc1, rm1 = eng.epi_scan_pairs(hpgv.EPI_TESTING)
+    eacc1, erm1 = orc.epi_scan_pairs(data, nA, nU, masks, hpgv.EPI_TESTING)
+    assert np.array_equal(rm1, erm1.astype(np.uint16)) and _same(acc1, eacc1)
+
+
 @pytest.mark.parametrize("nA,nU", [(1000, 3000), (333, 999), (1200, 800), (77, 770)])
 def test_mdr_rule_on_cells_at_the_boundary(eng, nA, nU):
     # rare genotypes give many small cells whose counts sit exactly on (or one sample off) the cohort's case/control
