@@ -79,7 +79,6 @@ struct hpgv_ctx {
     long pipeline = 1;         // 1: software-pipelined scan (loads of the next tile before counting this one)
     long pipe_waves = 4;       // register budget of the pipelined scan, as waves per SIMD (4, 6 or 8)
     long fisher_cut_exp = 22;  // Fisher tails stop after a round whose terms are all below 10^-this of the tail's largest term
-    long epi_dma = 1;          // epistasis pair scan: stage the planes with global_load_lds (LDS-DMA) instead of through registers
     long epi_complete = 1;     // epistasis pair scan on a dataset without missing calls: count four cells, derive the other five
     long epi_triples_1pass = 1; // epistasis triple ranking with at most 10 folds: one pass, all folds' counts in registers (one wave per SIMD)
     long scan_lds = 0;         // bytes of (unused) LDS per workgroup of the stats / tdt scans: caps the waves in flight per CU
@@ -330,8 +329,6 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
     } else if (!strcmp(key, "fisher_cut_exp")) {
         if (value < 12 || value > 300) return fail(ctx, HPGV_ERR_INVALID, "fisher_cut_exp must be in [12, 300]");
         ctx->fisher_cut_exp = value;
-    } else if (!strcmp(key, "epi_dma")) {
-        ctx->epi_dma = value ? 1 : 0;
     } else if (!strcmp(key, "epi_complete")) {
         ctx->epi_complete = value ? 1 : 0;
     } else if (!strcmp(key, "epi_triples_1pass")) {

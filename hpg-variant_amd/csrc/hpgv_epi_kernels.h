@@ -21,7 +21,6 @@
 namespace hpgv {
 
 constexpr int EPI_CH = 32;            // words of one LDS chunk (1024 samples)
-constexpr int EPI_ROW = 36;           // LDS row pitch in words: 32 + 4 keeps the 16-B reads of 16 lanes on 16 different slots
 constexpr int EPI_TJ = 64;            // tile: 64 columns (one per lane) ...
 constexpr int EPI_TI = 4;             // ... x 4 rows (one per wave)
 constexpr int EPI_MAX_FOLDS = 16;
@@ -177,12 +176,13 @@ __global__ void __launch_bounds__(256) k_epi_counts(const uint32_t *__restrict__
 // registers: 9 running counts of the current group + K x 9 finished groups, two 16-bit counts per register
 // (affected low, unaffected high: a (fold, class) group holds fewer than 65536 samples).
 // ---------------------------------------------------------------------------
-// MODE 0: staging through registers; 1: LDS-DMA; 2: LDS-DMA on a dataset WITHOUT missing calls, where only the four cells
-// of genotypes {0, 1} x {0, 1} are counted (16 instead of 36 AND + popcount pairs per step, two planes per SNP staged)
-// and the other five follow at a group's end from the per-SNP, per-group genotype counts `marg` (k_epi_marginals):
-// n(a, 2) = n_i(a) - n(a, 0) - n(a, 1), n(2, b) = n_j(b) - n(0, b) - n(1, b), n(2, 2) = the rest of the group.
-template <int K, bool TRAINING, bool BALANCED, int MODE>
-__global__ void __launch_bounds__(256, (MODE != 0 && K <= 10) ? 3 : 2) k_epi_pairs(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ marg, int W, int n_variants, int i_begin, int i_first, int i_end,
+// COMPLETE: a dataset WITHOUT missing calls, where only the four cells of genotypes {0, 1} x {0, 1} are counted (16 instead
+// of 36 AND + popcount pairs per step, two planes per SNP staged) and the other five follow at a group's end from the
+// per-SNP, per-group genotype counts `marg` (k_epi_marginals): n(a, 2) = n_i(a) - n(a, 0) - n(a, 1),
+// n(2, b) = n_j(b) - n(0, b) - n(1, b), n(2, 2) = the rest of the group.
+// K <= 10: at most 168 registers, three waves per SIMD; K = 16 (more than 10 folds): two.
+template <int K, bool TRAINING, bool BALANCED, bool COMPLETE>
+__global__ void __launch_bounds__(256, K <= 10 ? 3 : 2) k_epi_pairs(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ marg, int W, int n_variants, int i_begin, int i_first, int i_end,
                                                     const unsigned *__restrict__ tile_base, int n_cols, unsigned n_tiles,
                                                     const EpiChunk *__restrict__ chunks, int n_chunks,
                                                     const EpiFold *__restrict__ folds /* K */, int n_affected, int n_unaffected,
@@ -190,12 +190,11 @@ __global__ void __launch_bounds__(256, (MODE != 0 && K <= 10) ? 3 : 2) k_epi_pai
                                                     unsigned long long rank_base,
                                                     const double *__restrict__ thr, EpiCand *__restrict__ cand,
                                                     unsigned *__restrict__ cand_count, unsigned cand_cap) {
-    // register-staged: rows pitched 36 words; LDS-DMA (DMA): 26 x 8 linear rows of 32 words, the 16-byte pieces of a row
-    // swizzled by the column index so that the per-lane reads of 16 lanes fall on 16 different slots
-    constexpr bool DMA = MODE != 0, COMPLETE = MODE == 2;
+    // staging by LDS-DMA: 26 (17) x 8 linear rows of 32 words, the 16-byte pieces of a row swizzled by the column index so
+    // that the per-lane reads of 16 lanes fall on 16 different slots
     constexpr int NP = COMPLETE ? 2 : 3, NC = NP * NP;               // planes staged per SNP, cells counted
-    constexpr int RP = DMA ? EPI_CH : EPI_ROW;
-    constexpr int LROWS = COMPLETE ? 136 : DMA ? 208 : (EPI_TJ + EPI_TI) * 3;
+    constexpr int RP = EPI_CH;
+    constexpr int LROWS = COMPLETE ? 136 : 208;
     constexpr int NDMA = COMPLETE ? 17 : 26;                         // LDS-DMA instructions per chunk (8 rows each)
     // two separate arrays, not lds[2][...]: the compiler then sees that the LDS-DMA writes into one buffer cannot touch the
     // other and does not put an s_waitcnt vmcnt(0) in front of the counting loop's reads
@@ -216,8 +215,7 @@ __global__ void __launch_bounds__(256, (MODE != 0 && K <= 10) ? 3 : 2) k_epi_pai
     const int i = i0 + wave, j = j0 + lane;
 
     // ---- staging: piece q = one 16-byte piece of one (snp, plane) row of the chunk ----
-    constexpr int ROWS = (EPI_TJ + EPI_TI) * NP, PIECES = ROWS * (EPI_CH / 4), PER_T = (PIECES + 255) / 256;
-    uint4 stage[DMA ? 1 : PER_T];
+    constexpr int ROWS = (EPI_TJ + EPI_TI) * NP;
     // LDS-DMA: one global_load_lds_dwordx4 = 64 lanes x 16 B = 8 rows of the image; lane l fetches row 8k + l / 8, physical
     // piece l % 8, i.e. the logical piece (l % 8) ^ swizzle(row's SNP): the swizzle sits on the source address.  Kept per
     // instruction: the word offset of the lane's piece inside the planes (below 2^32 words).  Always whole 32-word rows
@@ -226,7 +224,7 @@ __global__ void __launch_bounds__(256, (MODE != 0 && K <= 10) ? 3 : 2) k_epi_pai
     // 136 rows = 17 instructions): with two planes per SNP an SNP-major image would put all 16 lanes of a read on 32 banks.
     uint32_t dma_off[7];
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);         // the wave index as a scalar
-    if constexpr (DMA) {
+    {
         #pragma unroll
         for (int r = 0; r < 7; r++) {
             const int k = wave + 4 * r, row8 = 8 * k + (lane >> 3), row = row8 < ROWS ? row8 : 0;
@@ -238,33 +236,11 @@ __global__ void __launch_bounds__(256, (MODE != 0 && K <= 10) ? 3 : 2) k_epi_pai
     }
     auto load_chunk = [&](int c, uint32_t *dst) {
         const uint32_t w0 = chunks[c].w0;
-        const int nw = (int)chunks[c].nw;
-        if constexpr (DMA) {
-            (void)nw;
-            #pragma unroll
-            for (int r = 0; r < 7; r++) {
-                const int k = wave_u + 4 * r;
-                if (k < NDMA)
-                    __builtin_amdgcn_global_load_lds(planes + (dma_off[r] + w0), (__attribute__((address_space(3))) uint32_t *)(dst + 8 * k * EPI_CH), 16, 0, 0);
-            }
-            return;
-        }
         #pragma unroll
-        for (int r = 0; r < PER_T; r++) {
-            const int q = t + 256 * r, row = q >> 3, piece = q & 7;
-            stage[r] = make_uint4(0, 0, 0, 0);
-            if (row < ROWS && piece * 4 < nw) {
-                const int snp = row < EPI_TJ * 3 ? j0 + row / 3 : i0 + (row - EPI_TJ * 3) / 3;
-                stage[r] = *reinterpret_cast<const uint4 *>(planes + ((size_t)snp * 3 + row % 3) * W + w0 + piece * 4);
-            }
-        }
-    };
-    auto store_chunk = [&](uint32_t *dst) {
-        if constexpr (DMA) return;
-        #pragma unroll
-        for (int r = 0; r < PER_T; r++) {
-            const int q = t + 256 * r, row = q >> 3, piece = q & 7;
-            if (row < ROWS) *reinterpret_cast<uint4 *>(dst + row * EPI_ROW + piece * 4) = stage[r];
+        for (int r = 0; r < 7; r++) {
+            const int k = wave_u + 4 * r;
+            if (k < NDMA)
+                __builtin_amdgcn_global_load_lds(planes + (dma_off[r] + w0), (__attribute__((address_space(3))) uint32_t *)(dst + 8 * k * EPI_CH), 16, 0, 0);
         }
     };
 
@@ -287,17 +263,16 @@ __global__ void __launch_bounds__(256, (MODE != 0 && K <= 10) ? 3 : 2) k_epi_pai
     }
 
     load_chunk(0, lds_a);
-    store_chunk(lds_a);
-    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int swz_j = DMA ? ((lane >> 1) & 7) : 0, swz_i = DMA ? (((EPI_TJ + wave_u) >> 1) & 7) : 0;
+    const int swz_j = (lane >> 1) & 7, swz_i = ((EPI_TJ + wave_u) >> 1) & 7;
     constexpr int PS = COMPLETE ? (EPI_TJ + EPI_TI) * RP * 4 : RP * 4;      // bytes from one plane of an SNP to the next
     uint4 xa[NP], ya[NP], xb[NP], yb[NP];
     bool fresh = true;
 #define HPGV_EPI_FETCH(X, Y, S)                                                                          \
         _Pragma("unroll") for (int a = 0; a < NP; a++) {                                                 \
-            X[a] = *reinterpret_cast<const uint4 *>(cur_bytes + ((DMA ? ioff ^ ((S) << 2) : ioff + ((S) << 2)) + a * PS)); \
-            Y[a] = *reinterpret_cast<const uint4 *>(cur_bytes + ((DMA ? joff ^ ((S) << 2) : joff + ((S) << 2)) + a * PS)); \
+            X[a] = *reinterpret_cast<const uint4 *>(cur_bytes + ((ioff ^ ((S) << 2)) + a * PS));         \
+            Y[a] = *reinterpret_cast<const uint4 *>(cur_bytes + ((joff ^ ((S) << 2)) + a * PS));         \
         }
 #define HPGV_EPI_COUNT1(X, Y, FIRST)                                                                     \
         _Pragma("unroll") for (int a = 0; a < NP; a++)                                                   \
@@ -344,7 +319,7 @@ __global__ void __launch_bounds__(256, (MODE != 0 && K <= 10) ? 3 : 2) k_epi_pai
         int joff = (lane * (COMPLETE ? 1 : 3) * RP + (swz_j << 2)) * 4,                                                    \
             ioff = ((EPI_TJ + wave_u) * (COMPLETE ? 1 : 3) * RP + (swz_i << 2)) * 4;                                        \
         asm("" : "+v"(joff)); asm("" : "+s"(ioff));   /* opaque: keeps the compiler from pulling the * 4 out of the ^ */     \
-        if constexpr (DMA && K > 5) {                                                                    \
+        if constexpr (K > 5) {                                                                           \
             /* three waves per SIMD hide the LDS latency; one register set keeps the kernel within 168 VGPRs */ \
             for (int s = 0; s < nw; s += 4) {                                                            \
                 HPGV_EPI_FETCH(xa, ya, s)                                                                \
@@ -360,8 +335,7 @@ __global__ void __launch_bounds__(256, (MODE != 0 && K <= 10) ? 3 : 2) k_epi_pai
                 HPGV_EPI_COUNT(xb, yb, s + 4)                                                            \
             }                                                                                            \
         }                                                                                                \
-        if (c + 1 < n_chunks) store_chunk(NXT);                                                          \
-        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* this wave's part of NXT has landed */ \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             /* this wave's part of NXT has landed */ \
         __syncthreads();                                                                                 \
     }
     for (int c = 0; c < n_chunks; c++) {
@@ -495,8 +469,8 @@ struct EpiCand3 {
     uint32_t risky;                   // bit c = cell c of the 27 is high risk
 };
 
-template <bool TRAINING, bool BALANCED, bool DMA>
-__global__ void __launch_bounds__(256, DMA ? 3 : 2) k_epi_triples(const uint32_t *__restrict__ planes, int W, int n_variants, int i_first,
+template <bool TRAINING, bool BALANCED>
+__global__ void __launch_bounds__(256, 3) k_epi_triples(const uint32_t *__restrict__ planes, int W, int n_variants, int i_first,
                                                          const unsigned *__restrict__ row_base /* n_i + 1 */, int n_i,
                                                          const unsigned *__restrict__ jb_prefix /* n_jb + 1 */, int n_jb,
                                                          const EpiChunk *__restrict__ chunks, int n_chunks, int num_folds,
@@ -504,10 +478,9 @@ __global__ void __launch_bounds__(256, DMA ? 3 : 2) k_epi_triples(const uint32_t
                                                          double *__restrict__ acc_out, uint32_t *__restrict__ mask_out,
                                                          const double *__restrict__ thr, EpiCand3 *__restrict__ cand,
                                                          unsigned *__restrict__ cand_count, unsigned cand_cap) {
-    // register-staged: rows pitched 36 words; LDS-DMA: 26 x 8 linear rows of 32 words, pieces swizzled by the SNP index on
-    // the source address (as k_epi_pairs)
-    constexpr int RP = DMA ? EPI_CH : EPI_ROW;
-    constexpr int LROWS = DMA ? 208 : (EPI_TJ + EPI_TI + 1) * 3;
+    // LDS-DMA staging: 26 x 8 linear rows of 32 words, pieces swizzled by the SNP index on the source address (as k_epi_pairs)
+    constexpr int RP = EPI_CH;
+    constexpr int LROWS = 208;
     __shared__ __attribute__((aligned(16))) uint32_t lds[2][LROWS * RP];
     // only tiles that hold a triple are launched: blockIdx.x -> first SNP (bisection on row_base), then its j block
     // (bisection on jb_prefix, the count of k tiles per j block, which does not depend on i), then the k tile
@@ -523,44 +496,22 @@ __global__ void __launch_bounds__(256, DMA ? 3 : 2) k_epi_triples(const uint32_t
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int j = j0 + wave, k = k0 + lane;
     // LDS rows: 0..63 the k columns, 64..67 the four j rows, 68 the i row
-    constexpr int SNPS = EPI_TJ + EPI_TI + 1, ROWS = SNPS * 3, PIECES = ROWS * (EPI_CH / 4), PER_T = (PIECES + 255) / 256;
-    uint4 stage[DMA ? 1 : PER_T];
+    constexpr int SNPS = EPI_TJ + EPI_TI + 1, ROWS = SNPS * 3;
     auto load_chunk = [&](int c, int buf) {
         const uint32_t w0 = chunks[c].w0;
         const int nw = (int)chunks[c].nw;
-        if constexpr (DMA) {
-            #pragma unroll
-            for (int r = 0; r < 7; r++) {
-                const int kk = wave + 4 * r;
-                if (kk < 26) {
-                    const int row = 8 * kk + (lane >> 3), sidx = row / 3;
-                    const int piece = (lane & 7) ^ ((sidx >> 1) & 7);
-                    if (row < ROWS && piece * 4 < nw) {
-                        const int snp = sidx < EPI_TJ ? k0 + sidx : sidx < EPI_TJ + EPI_TI ? j0 + (sidx - EPI_TJ) : i;
-                        const uint32_t *src = planes + ((size_t)snp * 3 + row % 3) * W + w0 + piece * 4;
-                        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) uint32_t *)&lds[buf][8 * kk * EPI_CH], 16, 0, 0);
-                    }
+        #pragma unroll
+        for (int r = 0; r < 7; r++) {
+            const int kk = wave + 4 * r;
+            if (kk < 26) {
+                const int row = 8 * kk + (lane >> 3), sidx = row / 3;
+                const int piece = (lane & 7) ^ ((sidx >> 1) & 7);
+                if (row < ROWS && piece * 4 < nw) {
+                    const int snp = sidx < EPI_TJ ? k0 + sidx : sidx < EPI_TJ + EPI_TI ? j0 + (sidx - EPI_TJ) : i;
+                    const uint32_t *src = planes + ((size_t)snp * 3 + row % 3) * W + w0 + piece * 4;
+                    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) uint32_t *)&lds[buf][8 * kk * EPI_CH], 16, 0, 0);
                 }
             }
-            return;
-        }
-        #pragma unroll
-        for (int r = 0; r < PER_T; r++) {
-            const int q = t + 256 * r, row = q >> 3, piece = q & 7;
-            stage[r] = make_uint4(0, 0, 0, 0);
-            if (row < ROWS && piece * 4 < nw) {
-                const int sidx = row / 3;
-                const int snp = sidx < EPI_TJ ? k0 + sidx : sidx < EPI_TJ + EPI_TI ? j0 + (sidx - EPI_TJ) : i;
-                stage[r] = *reinterpret_cast<const uint4 *>(planes + ((size_t)snp * 3 + row % 3) * W + w0 + piece * 4);
-            }
-        }
-    };
-    auto store_chunk = [&](int buf) {
-        if constexpr (DMA) return;
-        #pragma unroll
-        for (int r = 0; r < PER_T; r++) {
-            const int q = t + 256 * r, row = q >> 3, piece = q & 7;
-            if (row < ROWS) *reinterpret_cast<uint4 *>(&lds[buf][row * EPI_ROW + piece * 4]) = stage[r];
         }
     };
     const bool live = j > i && k > j && j < n_variants && k < n_variants;
@@ -573,7 +524,6 @@ __global__ void __launch_bounds__(256, DMA ? 3 : 2) k_epi_triples(const uint32_t
     for (int pass = 0; pass < 2; pass++) {
         __syncthreads();
         load_chunk(0, 0);
-        store_chunk(0);
         __syncthreads();
         for (int c = 0; c < n_chunks; c++) {
             const int buf = c & 1;
@@ -583,7 +533,7 @@ __global__ void __launch_bounds__(256, DMA ? 3 : 2) k_epi_triples(const uint32_t
             const uint32_t *zrow = &lds[buf][lane * 3 * RP];
             const uint32_t *yrow = &lds[buf][(EPI_TJ + wave) * 3 * RP];
             const uint32_t *xrow = &lds[buf][(EPI_TJ + EPI_TI) * 3 * RP];
-            const int swz_z = DMA ? ((lane >> 1) & 7) : 0, swz_y = DMA ? (((EPI_TJ + wave) >> 1) & 7) : 0, swz_x = DMA ? (((EPI_TJ + EPI_TI) >> 1) & 7) : 0;
+            const int swz_z = (lane >> 1) & 7, swz_y = ((EPI_TJ + wave) >> 1) & 7, swz_x = ((EPI_TJ + EPI_TI) >> 1) & 7;
             for (int s = 0; s < nw; s += 4) {
                 uint4 x[3], y[3], z[3];
                 #pragma unroll
@@ -659,7 +609,6 @@ __global__ void __launch_bounds__(256, DMA ? 3 : 2) k_epi_triples(const uint32_t
                     }
                 }
             }
-            if (c + 1 < n_chunks) store_chunk(buf ^ 1);
             __syncthreads();
         }
     }

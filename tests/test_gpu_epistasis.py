@@ -10,10 +10,9 @@ from oracle import pyoracle as orc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["regstage", "ldsdma"])
-def eng(request):
+@pytest.fixture(scope="module")
+def eng():
     e = hpgv.Engine(0)
-    e.set_option("epi_dma", request.param)        # both staging paths of the pair scan
     yield e
     e.close()
 
@@ -96,7 +95,7 @@ def test_pair_scan_matches_the_oracle(eng, v, nA, nU, k):
 
 
 @pytest.mark.parametrize("v,nA,nU,k", [(70, 37, 52, 5), (130, 300, 420, 10), (65, 5, 4, 3), (40, 1100, 1300, 4), (33, 64, 64, 1),
-                                       (50, 256, 256, 8), (90, 100, 100, 10), (12, 2500, 2300, 8), (21, 3, 40, 2)])
+                                       (50, 256, 256, 8), (90, 100, 100, 10), (12, 2500, 2300, 8), (21, 3, 40, 2), (24, 300, 280, 12), (18, 160, 160, 16)])
 def test_pair_scan_on_a_dataset_without_missing_calls(eng, v, nA, nU, k):
     # complete data takes its own counting path (four cells counted, five derived from per-SNP genotype counts): every pair
     # against the oracle, both subsets; the ranking with every model kept; and the same numbers with the path switched off
