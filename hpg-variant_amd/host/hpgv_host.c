@@ -1763,6 +1763,54 @@ static void run_batch_free(run_batch_t *b) {
     free(b->c8); free(b->hw); free(b->merr); free(b->midx); free(b->mtab); free(b->smiss); free(b->cerr); free(b->gc8); free(b->ghw);
 }
 
+/* ---- number formatting of the result lines: the characters printf would give, without printf ------------- */
+static char *put_u64(char *p, uint64_t v) {
+    char tmp[24];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+static char *put_i64(char *p, long v) {
+    if (v < 0) { *p++ = '-'; return put_u64(p, (uint64_t)(-(v + 1)) + 1u); }
+    return put_u64(p, (uint64_t)v);
+}
+/* exactly the characters of printf("%6f", x) (the format of assoc_runner.c:314-318 / tdt_runner.c:297-299): the value
+ * x = m * 2^e is scaled by 10^6 in 128-bit integer arithmetic and rounded half-to-even on the EXACT binary value, which
+ * is what glibc does.  Non-finite values and |x| >= 9e12 go through sprintf (dst needs 320 characters in all). */
+int hpgv_host_format_f6(double x, char *dst) {
+    char *p = dst;
+    uint64_t bits;
+    memcpy(&bits, &x, sizeof bits);
+    const int bexp = (int)((bits >> 52) & 0x7FF);
+    const uint64_t frac = bits & 0xFFFFFFFFFFFFFull;
+    if (bexp == 0x7FF || !(fabs(x) < 9e12)) return sprintf(dst, "%6f", x);
+    if (bits >> 63) *p++ = '-';
+    const uint64_t m = bexp ? (frac | (1ull << 52)) : frac;
+    const int e = (bexp ? bexp : 1) - 1075;
+    const unsigned __int128 P = (unsigned __int128)m * 1000000u;     /* below 2^73 */
+    uint64_t N;
+    if (e >= 0) N = (uint64_t)(P << e);                              /* |x| < 9e12: fits */
+    else {
+        const int sh = -e;
+        if (sh >= 75) N = 0;                                         /* P < 2^73 <= half an ulp of the last digit */
+        else {
+            const unsigned __int128 q = P >> sh, rem = P & ((((unsigned __int128)1) << sh) - 1), half = ((unsigned __int128)1) << (sh - 1);
+            N = (uint64_t)q;
+            if (rem > half || (rem == half && (N & 1u))) N++;
+        }
+    }
+    p = put_u64(p, N / 1000000u);
+    *p++ = '.';
+    uint32_t f = (uint32_t)(N % 1000000u);
+    for (int k = 5; k >= 0; k--) { p[k] = (char)('0' + f % 10); f /= 10; }
+    p += 6;
+    *p = 0;
+    return (int)(p - dst);
+}
+#define PUT_F6(p, x) ((p) + hpgv_host_format_f6((x), (p)))
+#define PUT_STR(p, s, n) (memcpy((p), (s), (size_t)(n)), (p) + (n))
+
 /* one output line per record, the reference's formats (assoc_runner.c:314-318,332-336; tdt_runner.c:297-299).
  * Returns the number of characters (as snprintf: what the whole line needs). */
 static int format_aggregate(char *dst, size_t room, const run_batch_t *b, int i);
@@ -1776,20 +1824,39 @@ static int format_record(char *dst, size_t room, int kind /* CHI_SQUARE, FISHER,
     const char *l = b->text + b->line_off[i];
     const int lc = (int)(fo[1] - 1 - fo[0]), li = (int)(fo[3] - 1 - fo[2]);
     const int lr = (int)(fo[4] - 1 - fo[3]), la = (int)(fo[5] - 1 - fo[4]);
+    /* the line is put together by hand (the formats, for reference:
+     *   tdt    "%s\t%ld\t%s\t%s\t%s\t%d\t%d\t%6f\t%6f\t%6f\n"
+     *   chisq  "%s\t%ld\t%s\t%s\t%d\t%d\t%6f\t%6f\t%s\t%d\t%d\t%6f\t%6f\t%6f\t%6f\t%6f\n"     fisher: without the chi-square column);
+     * printf's number parsing and its generic %f were a third of the writer's time */
+    const size_t worst = (size_t)(lc + li + lr + la) + 24 + 4 * 12 + 7 * 320 + 20;      /* %f of the largest double: 316 characters */
+    if (room <= worst) return (int)worst;                            /* the caller grows the buffer and comes again */
+    char *p = dst;
+    p = PUT_STR(p, l + fo[0], lc); *p++ = '\t';
+    p = put_i64(p, atol(l + fo[1])); *p++ = '\t';
+    p = PUT_STR(p, l + fo[2], li); *p++ = '\t';
+    p = PUT_STR(p, l + fo[3], lr); *p++ = '\t';
     if (kind == 3) {
         const int t1 = b->ints[i], t2 = b->ints[m + i];
-        return snprintf(dst, room, "%.*s\t%ld\t%.*s\t%.*s\t%.*s\t%d\t%d\t%6f\t%6f\t%6f\n", lc, l + fo[0], atol(l + fo[1]), li, l + fo[2],
-                        lr, l + fo[3], la, l + fo[4], t1, t2, b->dbl[i], b->dbl[m + i], b->dbl[2 * m + i]);
+        p = PUT_STR(p, l + fo[4], la); *p++ = '\t';
+        p = put_i64(p, t1); *p++ = '\t'; p = put_i64(p, t2); *p++ = '\t';
+        p = PUT_F6(p, b->dbl[i]); *p++ = '\t'; p = PUT_F6(p, b->dbl[m + i]); *p++ = '\t'; p = PUT_F6(p, b->dbl[2 * m + i]);
+        *p++ = '\n'; *p = 0;
+        return (int)(p - dst);
     }
     const int A1 = b->ints[i], A2 = b->ints[m + i], U1 = b->ints[2 * m + i], U2 = b->ints[3 * m + i];
     const int na = A1 + A2, nu = U1 + U2;
     const double fa1 = na > 0 ? (double)A1 / na : 0.0, fu1 = nu > 0 ? (double)U1 / nu : 0.0;
     const double fa2 = na > 0 ? (double)A2 / na : 0.0, fu2 = nu > 0 ? (double)U2 / nu : 0.0;
-    if (kind == CHI_SQUARE)
-        return snprintf(dst, room, "%.*s\t%ld\t%.*s\t%.*s\t%d\t%d\t%6f\t%6f\t%.*s\t%d\t%d\t%6f\t%6f\t%6f\t%6f\t%6f\n", lc, l + fo[0], atol(l + fo[1]),
-                        li, l + fo[2], lr, l + fo[3], A1, U1, fa1, fu1, la, l + fo[4], A2, U2, fa2, fu2, b->dbl[i], b->dbl[m + i], b->dbl[2 * m + i]);
-    return snprintf(dst, room, "%.*s\t%ld\t%.*s\t%.*s\t%d\t%d\t%6f\t%6f\t%.*s\t%d\t%d\t%6f\t%6f\t%6f\t%6f\n", lc, l + fo[0], atol(l + fo[1]),
-                    li, l + fo[2], lr, l + fo[3], A1, U1, fa1, fu1, la, l + fo[4], A2, U2, fa2, fu2, b->dbl[i], b->dbl[2 * m + i]);
+    p = put_i64(p, A1); *p++ = '\t'; p = put_i64(p, U1); *p++ = '\t';
+    p = PUT_F6(p, fa1); *p++ = '\t'; p = PUT_F6(p, fu1); *p++ = '\t';
+    p = PUT_STR(p, l + fo[4], la); *p++ = '\t';
+    p = put_i64(p, A2); *p++ = '\t'; p = put_i64(p, U2); *p++ = '\t';
+    p = PUT_F6(p, fa2); *p++ = '\t'; p = PUT_F6(p, fu2); *p++ = '\t';
+    p = PUT_F6(p, b->dbl[i]); *p++ = '\t';                            /* odds ratio */
+    if (kind == CHI_SQUARE) { p = PUT_F6(p, b->dbl[m + i]); *p++ = '\t'; }
+    p = PUT_F6(p, b->dbl[2 * m + i]);
+    *p++ = '\n'; *p = 0;
+    return (int)(p - dst);
 }
 
 /* does line i of the batch give an output record?  Not when it has fewer than CHROM..ALT, when a device-side filter

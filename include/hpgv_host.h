@@ -261,6 +261,11 @@ void tdt_write_output_body(list_t *output_list, FILE *fd);                  /* t
  * cannot be read / rewritten (the reference only warns in that case). */
 int  hpgv_host_sort_output_file(const char *path);
 
+/* The characters of printf("%6f", x) -- the number format of the result files (assoc_runner.c:314-318,
+ * tdt_runner.c:297-299) -- written to dst (room for 320 characters: the largest double takes 316); returns their count.  Rounds half to
+ * even on the exact binary value, as glibc does; used by the file runners' writers in place of printf. */
+int  hpgv_host_format_f6(double x, char *dst);
+
 /* ---- file level: what run_association_test (assoc_runner.c:23-276) and run_tdt_test
  *      (tdt_runner.c:23-279) do, minus options/filters: read the PED, read the VCF (plain text,
  *      gzip or bgzip -- `--compression`, shared_options.c:60-61; detected from the file's magic, BGZF

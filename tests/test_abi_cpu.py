@@ -76,3 +76,31 @@ def test_status_codes_and_enums_match_header():
     assert "HPGV_TASK_FISHER = 2" in text and hpgv.TASK_FISHER == 2
     assert "HPGV_COND_AFFECTED = 1" in text and hpgv.COND_AFFECTED == 1
     assert "HPGV_SEX_MALE = 0" in text and hpgv.SEX_MALE == 0
+
+
+def test_format_f6_is_printf_percent_6f():
+    # the writers' own "%6f" (hpgv_host_format_f6) against libc's snprintf, character for character: random doubles of every
+    # magnitude, exact ties of the sixth decimal (j / 128 -> ...5 exactly), the fall-back range, denormals, signed zeros, NaN, inf
+    import ctypes.util
+    import struct
+    import numpy as np
+    from importlib import import_module
+    b = import_module("hpg-variant_amd._build")
+    H = C.CDLL(b.HOSTLIB)
+    H.hpgv_host_format_f6.argtypes = [C.c_double, C.c_char_p]
+    H.hpgv_host_format_f6.restype = C.c_int
+    libc = C.CDLL(ctypes.util.find_library("c"))
+    libc.snprintf.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_double]
+    rng = np.random.default_rng(6)
+    xs = [0.0, -0.0, 1.0, -1.0, 0.5, 1e-7, 5e-7, 4.999999e-7, 2.5e-6, 0.0078125, 0.0234375, 1 / 128, 3 / 128, 5 / 128, 255 / 128,
+          0.9999995, 0.99999949999, 0.9999994999999999, 123456.7890125, 8.9999e12, 9e12, 9.0000001e12, 1e15, 1e300, -1e300,
+          5e-324, 2.2250738585072014e-308, float("inf"), float("-inf"), float("nan"), -float("nan"), 16.666666666666668, 4.4557090604024907e-05]
+    xs += [j / 128.0 + k for j in range(1, 128, 2) for k in (0, 7, 1024)]                    # ties: ....5 exactly in binary
+    xs += list(rng.random(20000))                                                           # p-values, frequencies
+    xs += list(rng.random(5000) * 10.0 ** rng.integers(-12, 13, 5000))                       # every magnitude below 1e13
+    xs += [struct.unpack("<d", struct.pack("<Q", int(v)))[0] for v in rng.integers(0, 2 ** 63, 20000, dtype=np.uint64) * 2 + rng.integers(0, 2, 20000, dtype=np.uint64)]
+    got, exp = C.create_string_buffer(512), C.create_string_buffer(512)
+    for x in xs:
+        n = H.hpgv_host_format_f6(x, got)
+        libc.snprintf(exp, 512, b"%6f", C.c_double(x))
+        assert got.value == exp.value and n == len(exp.value), (x, got.value, exp.value)
