@@ -9,6 +9,7 @@
 #include "hpgv_epi_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <cctype>
 
 #include <algorithm>
 #include <cmath>
@@ -535,6 +536,23 @@ int hpgv_dev_free(hpgv_ctx *ctx, void *dptr) {
     if (!ctx) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);
     if (dptr) HIPCHK(ctx, hipFree(dptr));
+    return HPGV_OK;
+}
+// NUMA node the device hangs off (sysfs numa_node of its PCI function), -1 when the system does not say: a host that
+// stages batches for the device does best with its staging threads and page-locked buffers on that node
+int hpgv_device_numa_node(hpgv_ctx *ctx, int *node) {
+    if (!ctx || !node) return HPGV_ERR_INVALID;
+    *node = -1;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, ctx->device) != hipSuccess) return HPGV_OK;
+    for (char *c = bus; *c; ++c) *c = (char)tolower((unsigned char)*c);
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    if (FILE *f = fopen(path, "r")) {
+        int n = -1;
+        if (fscanf(f, "%d", &n) == 1) *node = n;
+        fclose(f);
+    }
     return HPGV_OK;
 }
 int hpgv_host_alloc(hpgv_ctx *ctx, size_t bytes, void **hptr) {

@@ -11,6 +11,7 @@
 
 #include <fcntl.h>
 #include <math.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
@@ -1368,6 +1369,40 @@ int hpgv_host_sort_output_file(const char *path) {
     return rc;
 }
 
+/* ---- NUMA: a run's threads and page-locked buffers go to the node the GPU hangs off ------------------------------
+ * Measured on a two-socket MI355X host: 580 k variants/s with the process on the GPU's node, 334 k on the other one,
+ * anything in between when left to the scheduler (the copy out of the page cache into the staging buffers and the
+ * H2D DMA then cross the socket link).  The calling thread's affinity is narrowed to the node's CPUs for the run
+ * (the threads it creates inherit it, its allocations are first touched there) and put back afterwards.
+ * HPGV_NO_NUMA_BIND=1 switches this off. */
+static int numa_bind_to_device(cpu_set_t *saved) {
+    if (getenv("HPGV_NO_NUMA_BIND") || !g_ctx) return 0;
+    int node = -1;
+    if (hpgv_device_numa_node(g_ctx, &node) != HPGV_OK || node < 0) return 0;
+    char path[96], list[4096];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return 0;
+    const int ok = fgets(list, sizeof list, f) != NULL;
+    fclose(f);
+    if (!ok || sched_getaffinity(0, sizeof *saved, saved) != 0) return 0;
+    cpu_set_t want;
+    CPU_ZERO(&want);
+    int n_set = 0;
+    for (char *p = list; *p;) {                          /* "0-63,128-191" */
+        char *e;
+        long a = strtol(p, &e, 10), b = a;
+        if (e == p) break;
+        if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (CPU_ISSET((int)c, saved)) { CPU_SET((int)c, &want); n_set++; }
+        p = *e == ',' ? e + 1 : e;
+        if (*e != ',') break;
+    }
+    if (n_set == 0) return 0;                            /* the caller is not allowed on that node: leave it alone */
+    return sched_setaffinity(0, sizeof want, &want) == 0;
+}
+static void numa_unbind(const cpu_set_t *saved, int bound) { if (bound) (void)sched_setaffinity(0, sizeof *saved, saved); }
+
 /* ------------------------------------------------------------------------ */
 /* file-level runners: VCF + PED in, sorted TSV out                           */
 /* ------------------------------------------------------------------------ */
@@ -2445,6 +2480,8 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     long written = 0;
     double t_sort = 0;
     const double t_start = now_s();
+    cpu_set_t saved_cpus;
+    const int numa_bound = numa_bind_to_device(&saved_cpus);        /* before the buffers are allocated and the threads start */
     run_pipe_t *P = (run_pipe_t *)calloc(1, sizeof *P);
     out_buf_t *fmt = (out_buf_t *)calloc(RUN_FMT_BUFS, sizeof *fmt);
     int have = 0;
@@ -2539,6 +2576,7 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     for (int k = 0; fmt && k < RUN_FMT_BUFS; k++) free(fmt[k].p);
     free(fmt); free(P);
     if (dev_filters) (void)hpgv_set_text_filters(g_ctx, -1.0, -1.0, -1);
+    numa_unbind(&saved_cpus, numa_bound);
     g_run_times[3] = t_sort; g_run_times[4] = now_s() - t_start;
     if (getenv("HPGV_RUN_TRACE"))
         fprintf(stderr, "hpgv run: %ld records, %.0f batches, %d io threads: read %.3f s, engine %.3f s (%d threads), write %.3f s (stages overlap), sort %.3f s, total %.3f s\n",

@@ -119,6 +119,9 @@ int  hpgv_memcpy_d2h(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, vo
 int  hpgv_stream_sync(hpgv_ctx *ctx, void *stream);   /* stream NULL = default stream */
 /* page-locked host memory: buffers handed to the host entry points copy to the device at full
  * PCIe rate when they come from here (pageable memory is staged by the driver, 2-4x slower) */
+/* NUMA node of the device (-1: unknown).  No reference counterpart: the file runners put their staging threads and
+ * page-locked buffers there (a copy out of the page cache into buffers on the other socket ran at half the rate) */
+int  hpgv_device_numa_node(hpgv_ctx *ctx, int *node);
 int  hpgv_host_alloc(hpgv_ctx *ctx, size_t bytes, void **hptr);
 int  hpgv_host_free(hpgv_ctx *ctx, void *hptr);
 
