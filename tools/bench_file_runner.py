@@ -30,7 +30,7 @@ codes = np.array(["0/0", "0/1", "1/1", "./."])
 d = tempfile.mkdtemp()
 vcf, ped, out = os.path.join(d, "in.vcf"), os.path.join(d, "in.ped"), os.path.join(d, "out.chisq")
 bodies = ["\t".join(codes[rng.choice(4, size=n_samples, p=[0.5, 0.3, 0.19, 0.01])]) for _ in range(32)]
-with open(vcf, "w") as f:
+with open(vcf, "w", buffering=8 << 20) as f:      # large writes: the page cache then holds large folios, as after a copy or a read from disk
     f.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" +
             "\t".join("S%d" % j for j in range(n_samples)) + "\n")
     for i in range(n_variants):
