@@ -266,6 +266,11 @@ int  hpgv_host_sort_output_file(const char *path);
  * even on the exact binary value, as glibc does; used by the file runners' writers in place of printf. */
 int  hpgv_host_format_f6(double x, char *dst);
 
+/* The runners' own raw-DEFLATE decoder for BGZF blocks (`--compression bgzip`, shared_options.c:60-61): `in` -> exactly
+ * out_len bytes.  0 = decoded; non-zero = something the fast path does not take (the runners then let zlib decode and
+ * judge the block).  Exported for the tests. */
+int  hpgv_host_inflate_raw(const unsigned char *in, size_t in_len, unsigned char *out, size_t out_len);
+
 /* ---- file level: what run_association_test (assoc_runner.c:23-276) and run_tdt_test
  *      (tdt_runner.c:23-279) do, minus options/filters: read the PED, read the VCF (plain text,
  *      gzip or bgzip -- `--compression`, shared_options.c:60-61; detected from the file's magic, BGZF

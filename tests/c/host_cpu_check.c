@@ -129,8 +129,72 @@ static int cmd_stage(const char *path) {
     return 0;
 }
 
+
+/* the runners' DEFLATE decoder against zlib: valid streams of several kinds must decode to the original, corrupted
+ * ones must be refused or decoded without touching memory outside the buffers (this binary runs under ASan) */
+#include <zlib.h>
+static int deflate_raw(const unsigned char *src, size_t n, int level, int strategy, unsigned char *dst, size_t cap, size_t *out_n) {
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, strategy) != Z_OK) return 1;
+    zs.next_in = (Bytef *)src; zs.avail_in = (uInt)n; zs.next_out = dst; zs.avail_out = (uInt)cap;
+    int rc = deflate(&zs, Z_FINISH);
+    *out_n = zs.total_out;
+    deflateEnd(&zs);
+    return rc != Z_STREAM_END;
+}
+static int cmd_inflate(void) {
+    enum { MAXN = 1 << 20 };
+    unsigned char *src = malloc(MAXN), *comp = malloc(MAXN * 2 + 1024), *out = malloc(MAXN + 16);
+    unsigned seed = 12345u;
+    int n_ok = 0, n_refused = 0, n_corrupt = 0;
+    const size_t sizes[] = {0, 1, 2, 7, 100, 4096, 65280, 65281, 300000, MAXN};
+    for (int kind = 0; kind < 5; kind++)
+        for (unsigned si = 0; si < sizeof sizes / sizeof sizes[0]; si++) {
+            const size_t n = sizes[si];
+            for (size_t i = 0; i < n; i++) {
+                seed = seed * 1664525u + 1013904223u;
+                const unsigned r = seed >> 16;
+                src[i] = kind == 0 ? (unsigned char)"0/0\t0/1\t1/1\t./.\t0|1\n"[(i * 7 + (r % 3)) % 20]      /* genotype text */
+                       : kind == 1 ? (unsigned char)r                                                         /* incompressible: stored blocks */
+                       : kind == 2 ? 0                                                                        /* one long run: distance 1 */
+                       : kind == 3 ? (unsigned char)("ACGT\t.\tPASS\n"[r % 12])                               /* small alphabet */
+                       : (unsigned char)((i % 251) ^ (r % 5 == 0 ? r : 0));                                   /* long matches with noise */
+            }
+            for (int level = 1; level <= 9; level += 4)
+                for (int strategy = 0; strategy <= 4; strategy++) {     /* default, filtered, huffman only, rle, fixed */
+                    size_t cn = 0;
+                    if (deflate_raw(src, n, level, strategy, comp, MAXN * 2 + 1024, &cn)) { printf("deflate failed\n"); return 1; }
+                    memset(out, 0xEE, n + 16);
+                    const int rc = hpgv_host_inflate_raw(comp, cn, out, n);
+                    if (rc != 0) { printf("valid stream refused: kind %d size %zu level %d strategy %d\n", kind, n, level, strategy); return 1; }
+                    if (memcmp(out, src, n) != 0) { printf("wrong bytes: kind %d size %zu level %d strategy %d\n", kind, n, level, strategy); return 1; }
+                    for (int k = 0; k < 16; k++) if (out[n + k] != 0xEE) { printf("wrote past the end\n"); return 1; }
+                    n_ok++;
+                    /* wrong output size */
+                    if (n > 0 && hpgv_host_inflate_raw(comp, cn, out, n - 1) == 0) { printf("short output accepted\n"); return 1; }
+                    if (hpgv_host_inflate_raw(comp, cn, out, n + 1) == 0) { printf("long output accepted\n"); return 1; }
+                    /* corrupted and truncated copies: any answer, no stray access */
+                    if (cn > 4 && n <= 65281) {
+                        unsigned char *bad = malloc(cn);
+                        for (int t = 0; t < 24; t++) {
+                            memcpy(bad, comp, cn);
+                            seed = seed * 1664525u + 1013904223u;
+                            bad[(seed >> 8) % cn] ^= (unsigned char)(1u << ((seed >> 4) & 7));
+                            if (hpgv_host_inflate_raw(bad, t & 1 ? cn : cn - 1 - (seed >> 20) % (cn - 1), out, n) != 0) n_refused++;
+                            n_corrupt++;
+                        }
+                        free(bad);
+                    }
+                }
+        }
+    printf("inflate ok: %d streams, %d of %d damaged ones refused\n", n_ok, n_refused, n_corrupt);
+    free(src); free(comp); free(out);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc >= 2 && !strcmp(argv[1], "containers")) return cmd_containers();
+    if (argc >= 2 && !strcmp(argv[1], "inflate")) return cmd_inflate();
     if (argc >= 3 && !strcmp(argv[1], "stage")) return cmd_stage(argv[2]);
     if (argc >= 3 && !strcmp(argv[1], "sort")) return hpgv_host_sort_output_file(argv[2]);
     if (argc >= 5 && !strcmp(argv[1], "copy")) {

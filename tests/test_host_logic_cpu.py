@@ -155,3 +155,12 @@ def test_line_reader_header_longer_than_its_buffer(exe, tmp_path, kind):
     assert (tmp_path / "out").read_bytes() == data
     (tmp_path / "nohdr").write_bytes(data)
     assert _run(exe, "copy", str(tmp_path / "nohdr"), str(tmp_path / "out2"), str(1 << 18), "vcf").returncode != 0
+
+
+def test_deflate_decoder_against_zlib_under_sanitizers(exe):
+    # hpgv_host_inflate_raw (the bgzip reader's decoder): 750 valid streams (text, incompressible, runs, every zlib strategy
+    # incl. fixed codes and stored blocks, sizes 0 .. 1 MiB) decode to the original; damaged / truncated streams and wrong
+    # output sizes are refused or decoded without any access outside the buffers
+    r = _run(exe, "inflate")
+    assert r.returncode == 0 and "inflate ok" in r.stdout, r.stdout + r.stderr
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
