@@ -31,7 +31,7 @@ SYMBOLS = [
     "hpgv_set_stats_groups", "hpgv_stats_groups_layout", "hpgv_stats_scan_group_dev",
     "hpgv_set_pedigree", "hpgv_mendel_layout", "hpgv_mendel_scan_dev", "hpgv_mendel_children_dev",
     "hpgv_dev_alloc", "hpgv_dev_free", "hpgv_memcpy_h2d", "hpgv_memcpy_d2h", "hpgv_stream_sync",
-    "hpgv_device_numa_node", "hpgv_host_alloc", "hpgv_host_free",
+    "hpgv_device_numa_node", "hpgv_inflate_blocks_dev", "hpgv_host_alloc", "hpgv_host_free",
     "hpgv_layout_dev", "hpgv_synth_dev", "hpgv_synth_raw_dev",
     "hpgv_assoc_scan_dev", "hpgv_assoc_chisq_dev", "hpgv_assoc_fisher_dev",
     "hpgv_tdt_scan_dev", "hpgv_tdt_stats_dev", "hpgv_stats_scan_dev", "hpgv_stats_hwe_dev",
@@ -108,6 +108,7 @@ def load():
     L.hpgv_sample_missing_dev.argtypes = [vp, vp, i32, vp, vp]
     L.hpgv_genotype_table_dev.argtypes = [vp, vp, sz, i32, vp, i32, vp, vp]
     L.hpgv_tokenize_dev.argtypes = [vp, vp, sz, i32, i32, i32, vp, vp, vp, vp, sz, vp, vp, vp]
+    L.hpgv_inflate_blocks_dev.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]
     L.hpgv_tokenize.argtypes = [vp, C.c_char_p, sz, i32, i32, i32, C.POINTER(i32), vp, vp, vp, sz, vp, vp]
     L.hpgv_assoc_text.argtypes = [vp, i32, C.c_char_p, sz, i32, C.POINTER(i32), vp, vp, vp] + [vp] * 7
     L.hpgv_tdt_text.argtypes = [vp, C.c_char_p, sz, i32, C.POINTER(i32), vp, vp, vp] + [vp] * 5
@@ -464,6 +465,9 @@ class Engine:
 
     def assoc_fisher(self, d_counts, n_variants, d_odds, d_p, stream=None):
         self._chk(self.L.hpgv_assoc_fisher_dev(self.h, d_counts, n_variants, d_odds, d_p, stream))
+
+    def inflate_blocks(self, d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status, stream=None):
+        self._chk(self.L.hpgv_inflate_blocks_dev(self.h, d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status, stream))
 
     def tdt_scan(self, d_gt, n_variants, d_tu, d_is_x=None, stream=None):
         self._chk(self.L.hpgv_tdt_scan_dev(self.h, d_gt, n_variants, d_is_x, d_tu, stream))

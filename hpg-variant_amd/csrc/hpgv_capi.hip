@@ -7,6 +7,7 @@
 #include "hpgv_tdt_stats_kernels.h"
 #include "hpgv_text_kernels.h"
 #include "hpgv_epi_kernels.h"
+#include "hpgv_inflate_kernels.h"
 
 #include <hip/hip_runtime.h>
 #include <cctype>
@@ -1255,6 +1256,23 @@ int hpgv_mendel(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, 
 }
 
 /* ---- text staging ------------------------------------------------------------ */
+
+// raw-DEFLATE blocks (the payloads of BGZF blocks) -> text, all on the device: block b occupies d_comp[in_off[b] .. +in_len[b])
+// and decodes to exactly out_len[b] bytes at d_text + out_off[b]; d_status[b] = 0, or a non-zero code for a block this decoder
+// does not take (the host then decodes that block).  One lane per block: pass many thousands of blocks per call.
+int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                            const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, uint8_t *d_text,
+                            int32_t *d_status, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (n_blocks < 0 || (n_blocks > 0 && (!d_comp || !d_in_off || !d_in_len || !d_out_off || !d_out_len || !d_text || !d_status)))
+        return fail(ctx, HPGV_ERR_INVALID, "bad inflate arguments");
+    if (n_blocks == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    hipLaunchKernelGGL(hpgv::k_inflate_blocks, dim3((unsigned)((n_blocks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                       d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
+    HIPCHK(ctx, hipGetLastError());
+    return HPGV_OK;
+}
 
 int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int n_samples, int strict,
                       int max_lines, int *d_n_lines, uint64_t *d_line_off, uint32_t *d_field_off,

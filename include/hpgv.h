@@ -328,6 +328,14 @@ int  hpgv_epi_rank_triples(hpgv_ctx *ctx, int subset, int max_ranking_size, int3
 int  hpgv_mendel(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, const uint8_t *is_x,
                  int32_t *errors, int32_t *child_errors);
 
+/* ---- bgzip-compressed VCF text (--compression bgzip, shared_options.c:60-61): the raw-DEFLATE payloads of BGZF blocks
+ * decoded on the device, one lane per block (pass a whole file's blocks, or at least many thousands, per call).  Block b
+ * occupies d_comp[in_off[b] .. + in_len[b]) and decodes to exactly out_len[b] bytes at d_text + out_off[b]; d_status[b] is
+ * 0, or non-zero for a block this decoder does not take (the caller decodes it on the host).  Asynchronous on `stream`. */
+int  hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                             const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, uint8_t *d_text,
+                             int32_t *d_status, void *stream);
+
 /* ---- VCF text -> HPGV8 on the GPU (replaces the per-genotype
  *      strdup + get_alleles of assoc.c:45-56 / tdt.c:97-108,150-157) ------------------
  * text: whole VCF DATA lines (no '#' header lines), TAB separated, '\n' terminated (the last

@@ -158,3 +158,47 @@ def test_text_entry_point_from_concurrent_threads(eng):
     [x.join() for x in th]
     e.close()
     assert not errors, errors
+
+
+def test_inflate_blocks_on_the_gpu_against_zlib():
+    # hpgv_inflate_blocks_dev: raw-DEFLATE payloads (as in BGZF blocks) of genotype text, incompressible bytes (stored
+    # blocks), runs, every zlib strategy incl. fixed codes, sizes 0 .. 65 280 -- one lane per block; a damaged block gets a
+    # non-zero status and leaves the others alone
+    import zlib
+    rng = np.random.default_rng(11)
+    codes = np.array(["0/0", "0/1", "1/1", "./.", "0|1"])
+    blobs = []
+    for n in (0, 1, 17, 300, 4096, 65280, 65280, 30000):
+        txt = ("\t".join(codes[rng.choice(5, size=n // 4 + 1, p=[0.5, 0.3, 0.15, 0.01, 0.04])]) + "\n").encode()[:n]
+        blobs += [txt, bytes(rng.integers(0, 256, n, dtype=np.uint8)), b"\0" * n, (b"ACGT\t.\tPASS\n" * (n // 12 + 1))[:n]]
+    comp, raw = [], []
+    for k, blob in enumerate(blobs):
+        for level, strategy in ((1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_FILTERED), (6, zlib.Z_HUFFMAN_ONLY),
+                                (6, zlib.Z_RLE), (6, zlib.Z_FIXED), (0, zlib.Z_DEFAULT_STRATEGY)):
+            co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+            comp.append(co.compress(blob) + co.flush()); raw.append(blob)
+    damaged = len(comp) // 2
+    good = comp[damaged]
+    comp[damaged] = bytes([good[0] | 0x06]) + good[1:]                     # block type 3: invalid
+    n = len(comp)
+    in_len = np.array([len(c) for c in comp], np.uint32); out_len = np.array([len(r) for r in raw], np.uint32)
+    in_off = np.concatenate([[0], np.cumsum(in_len[:-1], dtype=np.uint64)]).astype(np.uint64)
+    out_off = np.concatenate([[0], np.cumsum(out_len[:-1], dtype=np.uint64)]).astype(np.uint64)
+    cbytes = np.frombuffer(b"".join(comp) + b"\0" * 16, np.uint8)
+    total = int(out_len.sum())
+    e = hpgv.Engine(0)
+    d_comp, d_text = e.alloc(len(cbytes)), e.alloc(total + 16)
+    d_io, d_il, d_oo, d_ol, d_st = e.alloc(8 * n), e.alloc(4 * n), e.alloc(8 * n), e.alloc(4 * n), e.alloc(4 * n)
+    for d, a in ((d_comp, cbytes), (d_io, in_off), (d_il, in_len), (d_oo, out_off), (d_ol, out_len)):
+        e.h2d(d, a)
+    e.inflate_blocks(d_comp, d_io, d_il, d_oo, d_ol, n, d_text, d_st)
+    e.sync()
+    status = e.d2h(d_st, (n,), np.int32)
+    text = e.d2h(d_text, (total,), np.uint8).tobytes()
+    assert status[damaged] != 0
+    for k in range(n):
+        if k == damaged:
+            continue
+        assert status[k] == 0, (k, int(status[k]), len(raw[k]))
+        assert text[int(out_off[k]): int(out_off[k]) + len(raw[k])] == raw[k], k
+    e.close()
