@@ -75,6 +75,8 @@ struct hpgv_ctx {
     long vpw = 2;
     long nontemporal = 1;
     long profile = 0;
+    std::mutex alias_mu;
+    std::vector<std::pair<const char *, const char *>> text_alias;   // host text buffer -> the same text already on the device
     long scan_unroll = 4;
     long persistent = 0;       // 0: one wave per vpw consecutive rows; 1: persistent strided grid
     long blocks_per_cu = 8;
@@ -555,6 +557,37 @@ int hpgv_device_numa_node(hpgv_ctx *ctx, int *node) {
         fclose(f);
     }
     return HPGV_OK;
+}
+// a stream of the caller's own (non-blocking), e.g. for copies that should overlap the engine's work
+int hpgv_stream_create(hpgv_ctx *ctx, void **stream) {
+    if (!ctx || !stream) return HPGV_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    hipStream_t st = nullptr;
+    HIPCHK(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *stream = (void *)st;
+    return HPGV_OK;
+}
+int hpgv_stream_destroy(hpgv_ctx *ctx, void *stream) {
+    if (!ctx) return HPGV_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    if (stream) HIPCHK(ctx, hipStreamDestroy((hipStream_t)stream));
+    return HPGV_OK;
+}
+// "the text at host_text is already on the device at d_text": the *_text entry points then tokenize d_text in place
+// instead of copying host_text over (d_text = NULL takes the entry away).  For readers that produce the text on the
+// device (hpgv_inflate_blocks_dev) and keep a host copy for the result writers.
+int hpgv_text_alias(hpgv_ctx *ctx, const char *host_text, const char *d_text) {
+    if (!ctx || !host_text) return HPGV_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->alias_mu);
+    for (size_t i = 0; i < ctx->text_alias.size(); ++i)
+        if (ctx->text_alias[i].first == host_text) { ctx->text_alias.erase(ctx->text_alias.begin() + (long)i); break; }
+    if (d_text) ctx->text_alias.emplace_back(host_text, d_text);
+    return HPGV_OK;
+}
+static const char *text_on_device(hpgv_ctx *ctx, const char *host_text) {
+    std::lock_guard<std::mutex> lk(ctx->alias_mu);
+    for (const auto &a : ctx->text_alias) if (a.first == host_text) return a.second;
+    return nullptr;
 }
 int hpgv_host_alloc(hpgv_ctx *ctx, size_t bytes, void **hptr) {
     if (!ctx || !hptr) return HPGV_ERR_INVALID;
@@ -1378,10 +1411,14 @@ static int text_front(hpgv_ctx *ctx, Slot *s, int which, const Layout &L, const 
     if ((rc = ensure(ctx, s, 5, ml * 4 * sizeof(int32_t) + 16))) return rc;
     if ((rc = ensure(ctx, s, 6, off_fields + ml * 10 * sizeof(uint32_t) + 16))) return rc;
     char *meta = (char *)s->buf[6];
-    if (text_bytes) HIPCHK(ctx, hipMemcpyAsync(s->buf[0], text, text_bytes, hipMemcpyHostToDevice, s->stream));
+    const char *d_src = text_on_device(ctx, text);                  // hpgv_text_alias: the text is on the device already
+    if (!d_src) {
+        if (text_bytes) HIPCHK(ctx, hipMemcpyAsync(s->buf[0], text, text_bytes, hipMemcpyHostToDevice, s->stream));
+        d_src = (const char *)s->buf[0];
+    }
     // the raw matrix keeps half-called genotypes ("./1"): the record filters count alleles as the stats tool does;
     // the strict layouts (assoc, tdt, epi) turn every not fully called genotype into "missing" on their way in
-    if ((rc = hpgv_tokenize_dev(ctx, (const char *)s->buf[0], text_bytes, L.n_samples, 0,
+    if ((rc = hpgv_tokenize_dev(ctx, d_src, text_bytes, L.n_samples, 0,
                                 max_lines, (int *)meta, (uint64_t *)(meta + off_lines), (uint32_t *)(meta + off_fields),
                                 (uint8_t *)s->buf[7], raw_pitch, (uint8_t *)s->buf[2], (int32_t *)s->buf[5], s->stream))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(n_lines, meta, sizeof(int), hipMemcpyDeviceToHost, s->stream));

@@ -396,10 +396,32 @@ static void text_buf_put(char *p, size_t cap) {
     pthread_mutex_unlock(&g_text_mu);
     if (!kept) (void)hpgv_host_free(g_ctx, p);
 }
+/* device memory for a decoded file, kept between runs like the page-locked buffers (an 8 GB allocation and its release
+ * cost 0.1 s); released by hpgv_host_shutdown */
+static void *g_dev_text; static size_t g_dev_text_cap;
+static void *dev_text_get(size_t bytes) {
+    void *p = NULL;
+    pthread_mutex_lock(&g_text_mu);
+    if (g_dev_text && g_dev_text_cap >= bytes) { p = g_dev_text; g_dev_text = NULL; g_dev_text_cap = 0; }
+    pthread_mutex_unlock(&g_text_mu);
+    if (!p && hpgv_dev_alloc(g_ctx, bytes, &p) != HPGV_OK) p = NULL;
+    return p;
+}
+static void dev_text_put(void *p, size_t bytes) {
+    if (!p) return;
+    void *old = NULL;
+    pthread_mutex_lock(&g_text_mu);
+    if (!g_dev_text || g_dev_text_cap < bytes) { old = g_dev_text; g_dev_text = p; g_dev_text_cap = bytes; p = NULL; }
+    pthread_mutex_unlock(&g_text_mu);
+    if (old) (void)hpgv_dev_free(g_ctx, old);
+    if (p) (void)hpgv_dev_free(g_ctx, p);
+}
+
 static void text_cache_release(void) {                  /* g_ctx still alive */
     pthread_mutex_lock(&g_text_mu);
     for (int i = 0; i < TEXT_CACHE_N; i++)
         if (g_text_cache[i].p) { (void)hpgv_host_free(g_ctx, g_text_cache[i].p); g_text_cache[i].p = NULL; g_text_cache[i].cap = 0; }
+    if (g_dev_text) { (void)hpgv_dev_free(g_ctx, g_dev_text); g_dev_text = NULL; g_dev_text_cap = 0; }
     pthread_mutex_unlock(&g_text_mu);
 }
 
@@ -1512,7 +1534,14 @@ typedef struct {
     size_t *blk;                                        /* BGZF: per-call block table (offset, length, destination, size) */
     io_pool_t *pool;                                    /* team for the pread segments / the block inflation (may be NULL) */
     char *job_buf; size_t job_want; int job_bad;        /* the job the team is working on */
+    const char *job_map; size_t job_map_len;            /* ... or the mapped range it is faulting in */
     gzFile gz;                                          /* GZIP */
+    /* BGZF decoded on the GPU: the whole file's text in device memory, handed out window by window */
+    void *d_comp, *d_tab, *d_text, *d_status, *rstream, *cstream; size_t dev_len, dev_pos; int gpu_tried;
+    uint64_t *g_in_off, *g_out_off; uint32_t *g_in_len, *g_out_len; size_t g_nb, g_done;      /* the stager's block tables */
+    size_t dev_ready;                                   /* text bytes decoded so far (under g_mu) */
+    size_t d_text_cap;
+    pthread_t g_thread; pthread_mutex_t g_mu; pthread_cond_t g_cv; int g_started, g_sync, g_err, g_finished;
 } source_t;
 
 static int bgzf_block(const unsigned char *p, size_t avail, size_t *bsize, size_t *cdata_off, size_t *isize) {
@@ -1554,8 +1583,19 @@ static int source_open(source_t *s, const char *path) {
 }
 
 static void source_close(source_t *s) {
+    if (s->g_started) pthread_join(s->g_thread, NULL);               /* the stager reads the mapping: it goes first */
     if (s->kind == SRC_BGZF && s->map) munmap((void *)s->map, (size_t)s->size);
     free(s->pend); free(s->blk);
+    if (s->g_sync) { pthread_mutex_destroy(&s->g_mu); pthread_cond_destroy(&s->g_cv); }
+    free(s->g_in_off); free(s->g_out_off); free(s->g_in_len); free(s->g_out_len);
+    if (g_ctx) {
+        if (s->d_comp) (void)hpgv_dev_free(g_ctx, s->d_comp);
+        if (s->d_tab) (void)hpgv_dev_free(g_ctx, s->d_tab);
+        if (s->d_status) (void)hpgv_dev_free(g_ctx, s->d_status);
+        if (s->d_text) dev_text_put(s->d_text, s->d_text_cap);
+        if (s->rstream) (void)hpgv_stream_destroy(g_ctx, s->rstream);
+        if (s->cstream) (void)hpgv_stream_destroy(g_ctx, s->cstream);
+    }
     if (s->kind == SRC_GZIP && s->gz) gzclose(s->gz);
     if (s->fd >= 0) close(s->fd);
 }
@@ -1804,6 +1844,15 @@ static void source_task_pread(void *v, int k) {
         off += (size_t)got; len -= (size_t)got;
     }
 }
+/* faults one segment of a mapped range in (one byte per page) */
+static volatile unsigned char g_touch_sink;
+static void source_task_touch(void *v, int k) {
+    source_t *s = (source_t *)v;
+    size_t off = (size_t)k * PREAD_SEG, end = off + PREAD_SEG <= s->job_map_len ? off + PREAD_SEG : s->job_map_len;
+    unsigned char acc = 0;
+    for (; off < end; off += 4096) acc ^= (unsigned char)s->job_map[off];
+    g_touch_sink ^= acc;
+}
 static void source_task_inflate(void *v, int g) {
     source_t *s = (source_t *)v;
     const size_t *b_in = s->blk, *b_clen = s->blk + MAXB, *b_out = s->blk + 2 * MAXB, *b_isize = s->blk + 3 * MAXB;
@@ -1813,6 +1862,139 @@ static void source_task_inflate(void *v, int g) {
         if (inflate_block(s->map + b_in[k], b_clen[k], (unsigned char *)s->job_buf + b_out[k], b_isize[k]))
             __atomic_store_n(&s->job_bad, 1, __ATOMIC_RELAXED);
     }
+}
+
+/* BGZF on the GPU: the file's blocks are decoded on the device (hpgv_inflate_blocks_dev: one lane per block, tens of
+ * thousands of blocks per launch; 8 GB of VCF text in 0.12 s) and the text stays in device memory.  The reader copies it
+ * out window by window for the result writers and the engine tokenizes the device copy in place (hpgv_text_alias) --
+ * the compressed bytes are all that goes up the bus.  A stager thread uploads and decodes the file in stretches of
+ * 32 768 blocks, so the pipeline starts after the first stretch; a block the device decoder refuses is decoded by the
+ * host and patched in.  No memory, a file of more than 48 GB of text or fewer than 256 blocks leave the CPU path in
+ * charge.  HPGV_NO_GPU_INFLATE=1 switches it off. */
+enum { GPU_STRETCH = 32768 };
+static void *bgzf_gpu_stager(void *v) {
+    source_t *s = (source_t *)v;
+    const size_t nb = s->g_nb;
+    char *t = (char *)s->d_tab;
+    void *up = NULL;
+    int ok = hpgv_stream_create(g_ctx, &up) == HPGV_OK;
+    int32_t *st = (int32_t *)malloc(sizeof(int32_t) * GPU_STRETCH);
+    unsigned char *tmp = (unsigned char *)malloc(65536);
+    ok = ok && st && tmp;
+    size_t launched = 0;                                 /* blocks [done, launched) are decoding */
+    for (size_t first = 0; ok && (first < nb || launched > s->g_done);) {
+        size_t next = first;
+        if (first < nb) {                                /* upload the next stretch while the previous one decodes */
+            next = first + GPU_STRETCH < nb ? first + GPU_STRETCH : nb;
+            const size_t lo = (size_t)s->g_in_off[first], hi = (size_t)s->g_in_off[next - 1] + s->g_in_len[next - 1];
+            ok = hpgv_memcpy_h2d(g_ctx, (char *)s->d_comp + lo, s->map + lo, hi - lo, up) == HPGV_OK;
+        }
+        if (ok && launched > s->g_done) {                /* the stretch in flight: wait, check, publish */
+            const size_t a = s->g_done, n = launched - a;
+            ok = hpgv_memcpy_d2h(g_ctx, st, (char *)s->d_status + a * 4, n * 4, s->cstream) == HPGV_OK;      /* synchronises cstream */
+            const char *fe = getenv("HPGV_TEST_GPU_INFLATE_REFUSE_EVERY");     /* tests: exercise the host patch path */
+            const size_t refuse_every = fe ? (size_t)atol(fe) : 0;
+            for (size_t k = 0; ok && k < n; k++)
+                if (st[k] || (refuse_every && (a + k) % refuse_every == 0)) {                             /* not taken by the device decoder: the host decodes it, the text is patched */
+                    const size_t bb = a + k;
+                    ok = !inflate_block(s->map + s->g_in_off[bb], s->g_in_len[bb], tmp, s->g_out_len[bb])
+                      && hpgv_memcpy_h2d(g_ctx, (char *)s->d_text + s->g_out_off[bb], tmp, s->g_out_len[bb], s->cstream) == HPGV_OK;
+                }
+            if (ok) {
+                pthread_mutex_lock(&s->g_mu);
+                s->g_done = launched;
+                s->dev_ready = launched == nb ? s->dev_len : (size_t)s->g_out_off[launched];
+                pthread_cond_broadcast(&s->g_cv);
+                pthread_mutex_unlock(&s->g_mu);
+            }
+        }
+        if (ok && first < nb) {
+            ok = hpgv_inflate_blocks_dev(g_ctx, (const uint8_t *)s->d_comp, (const uint64_t *)t + first, (const uint32_t *)(t + nb * 16) + first,
+                                         (const uint64_t *)(t + nb * 8) + first, (const uint32_t *)(t + nb * 20) + first, (int)(next - first),
+                                         (uint8_t *)s->d_text, (int32_t *)s->d_status + first, s->cstream) == HPGV_OK;
+            launched = next;
+        }
+        first = next;
+    }
+    pthread_mutex_lock(&s->g_mu);
+    if (!ok) s->g_err = 1;
+    s->g_finished = 1;
+    pthread_cond_broadcast(&s->g_cv);
+    pthread_mutex_unlock(&s->g_mu);
+    free(st); free(tmp);
+    if (up) (void)hpgv_stream_destroy(g_ctx, up);
+    /* only the text is needed from here on */
+    if (s->d_comp) { (void)hpgv_dev_free(g_ctx, s->d_comp); s->d_comp = NULL; }
+    if (s->d_status) { (void)hpgv_dev_free(g_ctx, s->d_status); s->d_status = NULL; }
+    return NULL;
+}
+
+static int bgzf_gpu_stage(source_t *s) {
+    s->gpu_tried = 1;
+    if (getenv("HPGV_NO_GPU_INFLATE") || !g_ctx || s->map_pos != 0) return 1;
+    {                                                            /* fault the mapping in with a team: the header walk and the uploads then find the pages */
+        io_pool_t tp;
+        pool_init(&tp, default_io_threads());
+        s->job_map = (const char *)s->map; s->job_map_len = (size_t)s->size;
+        pool_run(&tp, source_task_touch, s, (int)(((size_t)s->size + PREAD_SEG - 1) / PREAD_SEG));
+        pool_destroy(&tp);
+    }
+    size_t nb = 0, cap = 1 << 16, text = 0;
+    uint64_t *in_off = (uint64_t *)malloc(cap * 8), *out_off = (uint64_t *)malloc(cap * 8);
+    uint32_t *in_len = (uint32_t *)malloc(cap * 4), *out_len = (uint32_t *)malloc(cap * 4);
+    int ok = in_off && out_off && in_len && out_len;
+    size_t pos = 0;
+    while (ok && pos < (size_t)s->size) {
+        size_t bs, co, is;
+        if (!bgzf_block(s->map + pos, (size_t)s->size - pos, &bs, &co, &is) || is > 65536) { ok = 0; break; }
+        if (nb == cap) {
+            cap *= 2;
+            uint64_t *a = (uint64_t *)realloc(in_off, cap * 8), *b = (uint64_t *)realloc(out_off, cap * 8);
+            uint32_t *c = (uint32_t *)realloc(in_len, cap * 4), *d = (uint32_t *)realloc(out_len, cap * 4);
+            if (a) in_off = a;
+            if (b) out_off = b;
+            if (c) in_len = c;
+            if (d) out_len = d;
+            if (!a || !b || !c || !d) { ok = 0; break; }
+        }
+        in_off[nb] = pos + co; in_len[nb] = (uint32_t)(bs - co - 8); out_off[nb] = text; out_len[nb] = (uint32_t)is;
+        text += is; pos += bs; nb++;
+    }
+    if (ok && (nb < 256 || nb > 0x7FFFFFFFu || text > ((size_t)48 << 30))) ok = 0;     /* a small file is as quick on the host */
+    if (ok) ok = hpgv_stream_create(g_ctx, &s->rstream) == HPGV_OK && hpgv_stream_create(g_ctx, &s->cstream) == HPGV_OK;
+    if (ok) ok = hpgv_dev_alloc(g_ctx, (size_t)s->size + 16, &s->d_comp) == HPGV_OK;
+    if (ok) ok = hpgv_dev_alloc(g_ctx, nb * 24 + 64, &s->d_tab) == HPGV_OK;
+    if (ok) { s->d_text_cap = text + 16; s->d_text = dev_text_get(s->d_text_cap); ok = s->d_text != NULL; }
+    if (ok) ok = hpgv_dev_alloc(g_ctx, nb * 4 + 16, &s->d_status) == HPGV_OK;
+    if (ok) {
+        char *t = (char *)s->d_tab;
+        ok = hpgv_memcpy_h2d(g_ctx, t, in_off, nb * 8, s->cstream) == HPGV_OK
+          && hpgv_memcpy_h2d(g_ctx, t + nb * 8, out_off, nb * 8, s->cstream) == HPGV_OK
+          && hpgv_memcpy_h2d(g_ctx, t + nb * 16, in_len, nb * 4, s->cstream) == HPGV_OK
+          && hpgv_memcpy_h2d(g_ctx, t + nb * 20, out_len, nb * 4, s->cstream) == HPGV_OK;
+    }
+    if (ok) {
+        s->g_in_off = in_off; s->g_out_off = out_off; s->g_in_len = in_len; s->g_out_len = out_len; s->g_nb = nb;
+        s->dev_len = text; s->dev_pos = 0; s->dev_ready = 0; s->g_done = 0; s->g_err = 0; s->g_finished = 0;
+        pthread_mutex_init(&s->g_mu, NULL); pthread_cond_init(&s->g_cv, NULL);
+        s->g_sync = 1;
+        ok = pthread_create(&s->g_thread, NULL, bgzf_gpu_stager, s) == 0;
+        if (ok) s->g_started = 1;
+    }
+    if (!ok) {
+        free(in_off); free(out_off); free(in_len); free(out_len);
+        s->g_in_off = s->g_out_off = NULL; s->g_in_len = s->g_out_len = NULL;
+        if (s->g_sync) { pthread_mutex_destroy(&s->g_mu); pthread_cond_destroy(&s->g_cv); s->g_sync = 0; }
+            if (s->d_comp) { (void)hpgv_dev_free(g_ctx, s->d_comp); s->d_comp = NULL; }
+        if (s->d_tab) { (void)hpgv_dev_free(g_ctx, s->d_tab); s->d_tab = NULL; }
+        if (s->d_status) { (void)hpgv_dev_free(g_ctx, s->d_status); s->d_status = NULL; }
+        if (s->d_text) { dev_text_put(s->d_text, s->d_text_cap); s->d_text = NULL; }
+        if (s->rstream) { (void)hpgv_stream_destroy(g_ctx, s->rstream); s->rstream = NULL; }
+        if (s->cstream) { (void)hpgv_stream_destroy(g_ctx, s->cstream); s->cstream = NULL; }
+        return 1;
+    }
+    s->map_pos = (size_t)s->size;                                    /* the CPU path has nothing left to do */
+    return 0;
 }
 
 /* appends up to cap bytes of (decompressed) data to buf; 0 = end of data, (size_t)-1 = error.  RAW and GZIP
@@ -1842,6 +2024,19 @@ static size_t source_read(source_t *s, char *buf, size_t cap) {
     }
     /* BGZF */
     if (cap == 0) return 0;
+    if (!s->gpu_tried) (void)bgzf_gpu_stage(s);
+    if (s->d_text) {                                                 /* the text is on the device: copy the next stretch out */
+        if (s->dev_pos >= s->dev_len) return 0;
+        const size_t n = s->dev_len - s->dev_pos < cap ? s->dev_len - s->dev_pos : cap;
+        pthread_mutex_lock(&s->g_mu);                                /* until the stager has decoded that far */
+        while (!s->g_err && s->dev_ready < s->dev_pos + n && !s->g_finished) pthread_cond_wait(&s->g_cv, &s->g_mu);
+        const int bad = s->g_err || s->dev_ready < s->dev_pos + n;
+        pthread_mutex_unlock(&s->g_mu);
+        if (bad) return (size_t)-1;
+        if (hpgv_memcpy_d2h(g_ctx, buf, (const char *)s->d_text + s->dev_pos, n, s->rstream) != HPGV_OK) return (size_t)-1;
+        s->dev_pos += n;
+        return n;
+    }
     if (s->pend_pos < s->pend_len) {                                  /* rest of the block set aside last time */
         size_t n = s->pend_len - s->pend_pos < cap ? s->pend_len - s->pend_pos : cap;
         memcpy(buf, s->pend + s->pend_pos, n);
@@ -1885,12 +2080,17 @@ typedef struct {
     source_t src;
     char *carry; size_t carry_len, carry_cap;
     int eof;
+    const char *last_dev;                               /* device copy of the batch read_lines just returned (BGZF on the GPU), or NULL */
 } line_reader_t;
 
 /* fills buf (capacity cap) with whole lines; returns the byte count, 0 at the end, (size_t)-1 when a
  * single line does not fit or the source fails */
 static size_t read_lines(line_reader_t *r, char *buf, size_t cap) {
     size_t n = 0;
+    /* the carry is the stretch of the source right before its read position: with the text on the device the batch is
+     * the device bytes from (position - carry) on */
+    if (!r->src.gpu_tried && r->src.kind == SRC_BGZF) (void)bgzf_gpu_stage(&r->src);
+    r->last_dev = r->src.d_text ? (const char *)r->src.d_text + (r->src.dev_pos - r->carry_len) : NULL;
     if (r->carry_len) {                                 /* may exceed cap: what followed the header in its read buffer */
         n = r->carry_len < cap ? r->carry_len : cap;
         memcpy(buf, r->carry, n);
@@ -1985,6 +2185,7 @@ static int vcf_header_read(line_reader_t *rd, char **hdr_out, char ***names_out,
 
 typedef struct {
     char *text; size_t text_cap;                         /* page-locked, taken from the cache when the batch is first filled */
+    const char *dev_text;                                /* the same bytes on the device (BGZF decoded there), or NULL */
     size_t bytes; int max_lines, n_lines;
     uint64_t *line_off; uint32_t *field_off; int32_t *status;
     int32_t *ints; double *dbl;                          /* 4 (assoc) or 2 (tdt) int arrays, 3 double arrays */
@@ -2387,6 +2588,7 @@ static void *pipe_reader(void *v) {
         const double t0 = now_s();
         if (!P->bt[k].text) P->bt[k].text = text_buf_get(P->bt[k].text_cap);
         const size_t n = P->bt[k].text ? read_lines(P->rd, P->bt[k].text, P->batch_bytes) : (size_t)-1;
+        P->bt[k].dev_text = P->rd->last_dev;
         const double dt = now_s() - t0;
         pthread_mutex_lock(&P->mu);
         P->t_read += dt;
@@ -2415,6 +2617,7 @@ static void *pipe_engine(void *v) {
         const double t0 = now_s();
         run_batch_t *b = &P->bt[k];
         int rc = HPGV_OK;
+        if (b->dev_text) (void)hpgv_text_alias(g_ctx, b->text, b->dev_text);       /* tokenize the device copy in place: no H2D of the text */
         /* max_lines is sized for complete records; a batch of short (damaged) lines can hold more: the
          * engine reports the true count, the arrays grow and the batch is done again */
         for (int attempt = 0; attempt < 2; attempt++) {
@@ -2442,6 +2645,7 @@ static void *pipe_engine(void *v) {
             free(b->mtab); b->mtab = NULL;
             if (run_batch_reserve(b, b->n_lines)) { rc = HPGV_ERR_NOMEM; break; }
         }
+        if (b->dev_text) (void)hpgv_text_alias(g_ctx, b->text, NULL);
         const double dt = now_s() - t0;
         pthread_mutex_lock(&P->mu);
         P->t_engine += dt;

@@ -122,6 +122,9 @@ int  hpgv_stream_sync(hpgv_ctx *ctx, void *stream);   /* stream NULL = default s
 /* NUMA node of the device (-1: unknown).  No reference counterpart: the file runners put their staging threads and
  * page-locked buffers there (a copy out of the page cache into buffers on the other socket ran at half the rate) */
 int  hpgv_device_numa_node(hpgv_ctx *ctx, int *node);
+/* a non-blocking stream of the caller's own, e.g. for copies that overlap the engine's work */
+int  hpgv_stream_create(hpgv_ctx *ctx, void **stream);
+int  hpgv_stream_destroy(hpgv_ctx *ctx, void *stream);
 int  hpgv_host_alloc(hpgv_ctx *ctx, size_t bytes, void **hptr);
 int  hpgv_host_free(hpgv_ctx *ctx, void *hptr);
 
@@ -332,6 +335,10 @@ int  hpgv_mendel(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants,
  * decoded on the device, one lane per block (pass a whole file's blocks, or at least many thousands, per call).  Block b
  * occupies d_comp[in_off[b] .. + in_len[b]) and decodes to exactly out_len[b] bytes at d_text + out_off[b]; d_status[b] is
  * 0, or non-zero for a block this decoder does not take (the caller decodes it on the host).  Asynchronous on `stream`. */
+/* "the text at host_text is on the device at d_text already": the *_text entry points then tokenize d_text in place
+ * instead of copying host_text over; d_text = NULL removes the entry.  For readers that make the text on the device
+ * (hpgv_inflate_blocks_dev) and keep a host copy for the result writers. */
+int  hpgv_text_alias(hpgv_ctx *ctx, const char *host_text, const char *d_text);
 int  hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
                              const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, uint8_t *d_text,
                              int32_t *d_status, void *stream);

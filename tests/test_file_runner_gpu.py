@@ -377,3 +377,36 @@ def test_run_stats_files(host, tmp_path):
             assert (int(t[7]), int(t[8])) == (vs.missing_alleles, vs.missing_genotypes)
             for got, e in ((_fl(t[10]), vs.hw_chi2), (_fl(t[11]), vs.hw_p)):
                 assert (np.isnan(got) and np.isnan(e)) or abs(got - e) <= 1e-5 * max(1.0, abs(e))
+
+
+def test_run_assoc_from_bgzf_decoded_on_the_gpu(host, tmp_path):
+    # a bgzip file of 256 blocks or more is decoded on the device (hpgv_inflate_blocks_dev) and tokenized from device memory:
+    # same result file as from the plain text -- by that path, with every third block refused by the device decoder (decoded
+    # by the host and patched in), and with the device path switched off; several pipeline batches, lines across blocks
+    from test_host_logic_cpu import _bgzf
+    rng = np.random.default_rng(15)
+    people, names, rows = _write_inputs(tmp_path, rng, 50, 40, 4000)
+    vcf = _vcf_from_batch(tmp_path, names, rows)
+    data = open(vcf, "rb").read()
+    packed = str(tmp_path / "in.vcf.gz")
+    open(packed, "wb").write(_bgzf(data, 0x700))
+    assert len(data) // 0x700 > 300
+    ped = str(tmp_path / "ped.txt").encode()
+
+    def run(path, tag, env=None):
+        for k, v in (env or {}).items():
+            os.environ[k] = v
+        try:
+            out = str(tmp_path / ("res_" + tag))
+            n = C.c_long(0)
+            rc = host.hpgv_run_assoc(path.encode(), ped, out.encode(), 1, 1 << 17, C.byref(n))
+            assert rc == 0 and n.value == len(rows), host.hpgv_host_last_error()
+            return open(out, "rb").read()
+        finally:
+            for k in (env or {}):
+                del os.environ[k]
+    plain = run(vcf, "plain")
+    assert plain.count(b"\n") == len(rows) + 1
+    assert run(packed, "gpu") == plain
+    assert run(packed, "patched", {"HPGV_TEST_GPU_INFLATE_REFUSE_EVERY": "3"}) == plain
+    assert run(packed, "cpu", {"HPGV_NO_GPU_INFLATE": "1"}) == plain
