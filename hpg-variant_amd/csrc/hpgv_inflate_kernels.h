@@ -21,23 +21,42 @@ struct InflateBits {
     const uint8_t *in, *end;
     uint64_t buf; int cnt;
     __device__ __forceinline__ void refill() {
-        while (cnt <= 56 && in < end) { buf |= (uint64_t)(*in++) << cnt; cnt += 8; }
+        if (in + 8 <= end) {                                        // one 8-byte load instead of up to seven dependent byte loads
+            uint64_t w;
+            __builtin_memcpy(&w, in, 8);
+            buf |= w << cnt;
+            in += (63 - cnt) >> 3;
+            cnt |= 56;
+        } else {
+            while (cnt <= 56 && in < end) { buf |= (uint64_t)(*in++) << cnt; cnt += 8; }
+        }
     }
     __device__ __forceinline__ uint32_t take(int n) { const uint32_t v = (uint32_t)(buf & ((1ull << n) - 1)); buf >>= n; cnt -= n; return v; }
 };
 
+// the code-length histogram of a code held in registers (the decode loop below is unrolled over the lengths, so every
+// index is static): without it each of the up to 15 steps per symbol waits for a load from private memory
+struct InflateCnt { uint32_t v[16]; };
+__device__ __forceinline__ InflateCnt inflate_counts(const InflateCode &h) {
+    InflateCnt c;
+    #pragma unroll
+    for (int l = 0; l < 16; l++) c.v[l] = h.count[l];
+    return c;
+}
+
 // canonical decode, one bit at a time (codes are packed MSB first): returns the symbol or -1
-__device__ __forceinline__ int inflate_decode(InflateBits &B, const InflateCode &h) {
+__device__ __forceinline__ int inflate_decode(InflateBits &B, const InflateCnt &c, const uint16_t *symbol) {
     int code = 0, first = 0, index = 0;
     if (B.cnt < 15) B.refill();
     uint64_t bits = B.buf;
+    #pragma unroll
     for (int len = 1; len <= 15; len++) {
         code |= (int)(bits & 1); bits >>= 1;
-        const int count = h.count[len];
+        const int count = (int)c.v[len];
         if (code - count < first) {
             if (len > B.cnt) return -1;
             B.buf >>= len; B.cnt -= len;
-            return h.symbol[index + (code - first)];
+            return symbol[index + (code - first)];
         }
         index += count; first += count; first <<= 1; code <<= 1;
     }
@@ -113,9 +132,10 @@ __global__ void __launch_bounds__(64) k_inflate_blocks(const uint8_t *__restrict
             for (int k = 0; k < ncode; k++) { if (B.cnt < 3) B.refill(); if (B.cnt < 3) { rc = 2; break; } lengths[order[k]] = (uint8_t)B.take(3); }
             if (rc) break;
             if (inflate_construct(lencode, lengths, 19) != 0) { rc = 6; break; }
+            const InflateCnt clc = inflate_counts(lencode);
             int idx = 0;
             while (idx < nlen + ndist && !rc) {
-                const int sym = inflate_decode(B, lencode);
+                const int sym = inflate_decode(B, clc, lencode.symbol);
                 if (sym < 0) { rc = 7; break; }
                 if (sym < 16) { lengths[idx++] = (uint8_t)sym; continue; }
                 int rep, val = 0;
@@ -133,8 +153,9 @@ __global__ void __launch_bounds__(64) k_inflate_blocks(const uint8_t *__restrict
             e = inflate_construct(distcode, lengths + nlen, ndist);
             if (e < 0 || (e > 0 && ndist - distcode.count[0] != 1)) { rc = 12; break; }
         }
+        const InflateCnt lc = inflate_counts(lencode), dc = inflate_counts(distcode);
         for (;;) {                                                  // the block's symbols
-            int sym = inflate_decode(B, lencode);
+            int sym = inflate_decode(B, lc, lencode.symbol);
             if (sym < 0) { rc = 13; break; }
             if (sym < 256) { if (n_out >= cap) { rc = 14; break; } out0[n_out++] = (uint8_t)sym; continue; }
             if (sym == 256) break;
@@ -142,14 +163,28 @@ __global__ void __launch_bounds__(64) k_inflate_blocks(const uint8_t *__restrict
             if (sym >= 29) { rc = 15; break; }
             if (B.cnt < 5) B.refill();
             const uint32_t len = len_base[sym] + B.take(len_extra[sym]);
-            const int ds = inflate_decode(B, distcode);
+            const int ds = inflate_decode(B, dc, distcode.symbol);
             if (ds < 0 || ds >= 30) { rc = 16; break; }
             if (B.cnt < 13) B.refill();
             const uint32_t dist = dist_base[ds] + B.take(dist_extra[ds]);
             if (B.cnt < 0 || dist > n_out || n_out + len > cap) { rc = 17; break; }
             uint8_t *d = out0 + n_out;
             const uint8_t *src = d - dist;
-            for (uint32_t k = 0; k < len; k++) d[k] = src[k];
+            // a byte loop makes every byte wait for a load of bytes just stored (a round trip to L2 each); eight bytes at a
+            // time, and for a period below eight from a pattern held in a register
+            if (n_out + len + 8 <= cap) {
+                uint32_t k = 0;
+                if (dist >= 8) {
+                    for (; k < len; k += 8) { uint64_t w; __builtin_memcpy(&w, src + k, 8); __builtin_memcpy(d + k, &w, 8); }
+                } else {
+                    uint64_t w = 0;                                  // dist bytes repeated up to eight
+                    for (uint32_t q = 0; q < 8; q++) w |= (uint64_t)src[q % dist] << (8 * q);
+                    const uint32_t step = dist * (8 / dist);         // whole periods per store
+                    for (; k < len; k += step) __builtin_memcpy(d + k, &w, 8);
+                }
+            } else {
+                for (uint32_t k = 0; k < len; k++) d[k] = src[k];
+            }
             n_out += len;
         }
     }
