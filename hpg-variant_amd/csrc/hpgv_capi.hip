@@ -1412,6 +1412,7 @@ static int text_front(hpgv_ctx *ctx, Slot *s, int which, const Layout &L, const 
     if ((rc = ensure(ctx, s, 6, off_fields + ml * 10 * sizeof(uint32_t) + 16))) return rc;
     char *meta = (char *)s->buf[6];
     const char *d_src = text_on_device(ctx, text);                  // hpgv_text_alias: the text is on the device already
+    const bool aliased = d_src != nullptr;
     if (!d_src) {
         if (text_bytes) HIPCHK(ctx, hipMemcpyAsync(s->buf[0], text, text_bytes, hipMemcpyHostToDevice, s->stream));
         d_src = (const char *)s->buf[0];
@@ -1427,7 +1428,24 @@ static int text_front(hpgv_ctx *ctx, Slot *s, int which, const Layout &L, const 
     *nl_out = nl;
     if (nl == 0) return HPGV_OK;
     if (status) HIPCHK(ctx, hipMemcpyAsync(status, s->buf[5], (size_t)nl * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
-    if (line_off) HIPCHK(ctx, hipMemcpyAsync(line_off, meta + off_lines, ((size_t)nl + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
+    if (aliased) {
+        // the text is on the device only: the caller's host buffer gets the line heads (CHROM .. FORMAT, all it reads for its
+        // result records) and line_off refers to them
+        if ((rc = ensure(ctx, s, 0, text_bytes + ((size_t)nl + 2) * sizeof(uint64_t) + 64))) return rc;
+        unsigned long long *d_head_off = (unsigned long long *)s->buf[0];
+        char *d_heads = (char *)s->buf[0] + (((size_t)nl + 2) * sizeof(uint64_t) + 15) / 16 * 16;
+        hipLaunchKernelGGL(hpgv::k_head_offsets, dim3(1), dim3(1024), 0, s->stream, (const unsigned long long *)(meta + off_lines),
+                           (const uint32_t *)(meta + off_fields), nl, d_head_off);
+        hipLaunchKernelGGL(hpgv::k_copy_heads, dim3((unsigned)nl), dim3(64), 0, s->stream, d_src, (const unsigned long long *)(meta + off_lines),
+                           (const unsigned long long *)d_head_off, nl, d_heads);
+        HIPCHK(ctx, hipGetLastError());
+        unsigned long long total_heads = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&total_heads, d_head_off + nl, sizeof total_heads, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(ctx, hipStreamSynchronize(s->stream));
+        if (total_heads > text_bytes) return fail(ctx, HPGV_ERR_HIP, "line heads longer than the text");
+        if (total_heads) HIPCHK(ctx, hipMemcpyAsync(const_cast<char *>(text), d_heads, (size_t)total_heads, hipMemcpyDeviceToHost, s->stream));
+        if (line_off) HIPCHK(ctx, hipMemcpyAsync(line_off, d_head_off, ((size_t)nl + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
+    } else if (line_off) HIPCHK(ctx, hipMemcpyAsync(line_off, meta + off_lines, ((size_t)nl + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
     if (field_off) HIPCHK(ctx, hipMemcpyAsync(field_off, meta + off_fields, (size_t)nl * 10 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     // ---- record filters (--maf, --missing, --mendel: shared_options.c:44-46,101-115), from the same matrix ----
     const bool f_counts = ctx->filt_min_maf >= 0.0 || ctx->filt_max_missing >= 0.0, f_mendel = ctx->filt_max_mendel >= 0;

@@ -219,4 +219,41 @@ __global__ __launch_bounds__(256) void k_tok_parse(const char *__restrict__ text
     if (threadIdx.x == 0 && status) status[line] = found < n_samples ? 3 : 0;
 }
 
+
+// ---------------------------------------------------------------------------
+// line heads: when the text lives on the device only (bgzip decoded there), the host still needs CHROM .. FORMAT of
+// every line for its result records.  head_off[i] = exclusive prefix sum of the head lengths (a head = the line up to
+// the first sample column, or the whole line when it has fewer than ten fields), head_off[n] = total; then the bytes.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_head_offsets(const unsigned long long *__restrict__ line_off, const uint32_t *__restrict__ field_off,
+                                                       int n_lines, unsigned long long *__restrict__ head_off) {
+    __shared__ unsigned long long part[1024];
+    const int t = threadIdx.x;
+    const int per = (n_lines + 1023) / 1024, lo = t * per, hi = lo + per < n_lines ? lo + per : n_lines;
+    unsigned long long sum = 0;
+    for (int i = lo; i < hi; i++) {
+        const uint32_t f9 = field_off[(size_t)i * 10 + 9];
+        sum += f9 != 0xFFFFFFFFu ? (unsigned long long)f9 : line_off[i + 1] - line_off[i];
+    }
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) { unsigned long long acc = 0; for (int k = 0; k < 1024; k++) { const unsigned long long v = part[k]; part[k] = acc; acc += v; } head_off[n_lines] = acc; }
+    __syncthreads();
+    unsigned long long acc = part[t];
+    for (int i = lo; i < hi; i++) {
+        head_off[i] = acc;
+        const uint32_t f9 = field_off[(size_t)i * 10 + 9];
+        acc += f9 != 0xFFFFFFFFu ? (unsigned long long)f9 : line_off[i + 1] - line_off[i];
+    }
+}
+__global__ __launch_bounds__(64) void k_copy_heads(const char *__restrict__ text, const unsigned long long *__restrict__ line_off,
+                                                   const unsigned long long *__restrict__ head_off, int n_lines, char *__restrict__ heads) {
+    const int i = blockIdx.x;
+    if (i >= n_lines) return;
+    const unsigned long long n = head_off[i + 1] - head_off[i];
+    const char *src = text + line_off[i];
+    char *dst = heads + head_off[i];
+    for (unsigned long long k = threadIdx.x; k < n; k += 64) dst[k] = src[k];
+}
+
 }  // namespace hpgv

@@ -2081,7 +2081,41 @@ typedef struct {
     char *carry; size_t carry_len, carry_cap;
     int eof;
     const char *last_dev;                               /* device copy of the batch read_lines just returned (BGZF on the GPU), or NULL */
+    int devwin;                                         /* batches are windows of the device text; nothing but their cut points is read back */
+    char *tailbuf; size_t tailcap;
 } line_reader_t;
+
+/* bgzip decoded on the device: the next batch is a window of the device text that ends with a line.  Only the stretch
+ * around the window's end comes back to the host, to find that line end; the engine fills the batch's host buffer with
+ * the line heads (hpgv_text_alias).  Returns the window's bytes (0 at the end, (size_t)-1 on error), its device address
+ * in r->last_dev. */
+static size_t read_lines_dev(line_reader_t *r, size_t cap) {
+    source_t *s = &r->src;
+    const size_t start = s->dev_pos;
+    r->last_dev = (const char *)s->d_text + start;
+    if (start >= s->dev_len) return 0;
+    size_t end = s->dev_len - start <= cap ? s->dev_len : start + cap;
+    pthread_mutex_lock(&s->g_mu);                                    /* until the stager has decoded that far */
+    while (!s->g_err && s->dev_ready < end && !s->g_finished) pthread_cond_wait(&s->g_cv, &s->g_mu);
+    const int bad = s->g_err || s->dev_ready < end;
+    pthread_mutex_unlock(&s->g_mu);
+    if (bad) return (size_t)-1;
+    if (end < s->dev_len) {                                          /* cut at the last newline before `end` */
+        size_t look = 1u << 18;
+        for (;;) {
+            if (look > end - start) look = end - start;
+            if (r->tailcap < look) { free(r->tailbuf); r->tailbuf = (char *)malloc(look); r->tailcap = r->tailbuf ? look : 0; }
+            if (!r->tailbuf) return (size_t)-1;
+            if (hpgv_memcpy_d2h(g_ctx, r->tailbuf, (const char *)s->d_text + end - look, look, s->rstream) != HPGV_OK) return (size_t)-1;
+            const char *nl = (const char *)memrchr(r->tailbuf, '\n', look);
+            if (nl) { end = end - look + (size_t)(nl - r->tailbuf) + 1; break; }
+            if (look == end - start) return (size_t)-1;              /* a line longer than the batch */
+            look *= 4;
+        }
+    }
+    s->dev_pos = end;
+    return end - start;
+}
 
 /* fills buf (capacity cap) with whole lines; returns the byte count, 0 at the end, (size_t)-1 when a
  * single line does not fit or the source fails */
@@ -2587,7 +2621,7 @@ static void *pipe_reader(void *v) {
         pthread_mutex_unlock(&P->mu);
         const double t0 = now_s();
         if (!P->bt[k].text) P->bt[k].text = text_buf_get(P->bt[k].text_cap);
-        const size_t n = P->bt[k].text ? read_lines(P->rd, P->bt[k].text, P->batch_bytes) : (size_t)-1;
+        const size_t n = !P->bt[k].text ? (size_t)-1 : P->rd->devwin ? read_lines_dev(P->rd, P->batch_bytes) : read_lines(P->rd, P->bt[k].text, P->batch_bytes);
         P->bt[k].dev_text = P->rd->last_dev;
         const double dt = now_s() - t0;
         pthread_mutex_lock(&P->mu);
@@ -2978,6 +3012,9 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
         pool_init(&rpool, io_threads);
         pool_init(&wpool, io_threads);
         rd.src.pool = &rpool;
+        if (rd.src.d_text && !getenv("HPGV_NO_DEVICE_WINDOWS")) {      /* bgzip decoded on the device: windows of the device text from the first data line on */
+            rd.src.dev_pos -= rd.carry_len; rd.carry_len = 0; rd.devwin = 1;
+        }
         const int n_fmt = io_threads < RUN_FMT_BUFS ? io_threads : RUN_FMT_BUFS;
         pthread_t th[1 + RUN_ENGINES];
         int n_th = 0;
@@ -3041,7 +3078,7 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     if (getenv("HPGV_RUN_TRACE"))
         fprintf(stderr, "hpgv run: %ld records, %.0f batches, %d io threads: read %.3f s, engine %.3f s (%d threads), write %.3f s (stages overlap), sort %.3f s, total %.3f s\n",
                 written, g_run_times[5], io_threads, g_run_times[0], g_run_times[1], RUN_ENGINES, g_run_times[2], t_sort, g_run_times[4]);
-    source_close(&rd.src); free(rd.carry); free(hdr); free(names); ped_table_free(&ped);
+    source_close(&rd.src); free(rd.carry); free(rd.tailbuf); free(hdr); free(names); ped_table_free(&ped);
     if (n_variants_out) *n_variants_out = written;
     return rc;
 }

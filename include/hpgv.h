@@ -335,9 +335,11 @@ int  hpgv_mendel(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants,
  * decoded on the device, one lane per block (pass a whole file's blocks, or at least many thousands, per call).  Block b
  * occupies d_comp[in_off[b] .. + in_len[b]) and decodes to exactly out_len[b] bytes at d_text + out_off[b]; d_status[b] is
  * 0, or non-zero for a block this decoder does not take (the caller decodes it on the host).  Asynchronous on `stream`. */
-/* "the text at host_text is on the device at d_text already": the *_text entry points then tokenize d_text in place
- * instead of copying host_text over; d_text = NULL removes the entry.  For readers that make the text on the device
- * (hpgv_inflate_blocks_dev) and keep a host copy for the result writers. */
+/* "the text of the batch is on the device at d_text already" (e.g. decoded there by hpgv_inflate_blocks_dev): a *_text entry
+ * point called with host_text then tokenizes d_text in place, copies nothing up, and WRITES INTO host_text (a buffer of at
+ * least text_bytes bytes) the heads of the lines -- each line up to its first sample column, CHROM .. FORMAT, or the whole
+ * line when it has fewer than ten fields -- back to back; line_off[i] is the offset of line i's head in host_text, field_off
+ * stays relative to the line start.  d_text = NULL removes the entry. */
 int  hpgv_text_alias(hpgv_ctx *ctx, const char *host_text, const char *d_text);
 int  hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
                              const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, uint8_t *d_text,

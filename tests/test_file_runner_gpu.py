@@ -409,4 +409,22 @@ def test_run_assoc_from_bgzf_decoded_on_the_gpu(host, tmp_path):
     assert plain.count(b"\n") == len(rows) + 1
     assert run(packed, "gpu") == plain
     assert run(packed, "patched", {"HPGV_TEST_GPU_INFLATE_REFUSE_EVERY": "3"}) == plain
+    assert run(packed, "copied_back", {"HPGV_NO_DEVICE_WINDOWS": "1"}) == plain       # device decoding, whole windows copied back
     assert run(packed, "cpu", {"HPGV_NO_GPU_INFLATE": "1"}) == plain
+    # the other runners read more of a line's head (QUAL .. INFO, FORMAT): tdt, vcf2epi, aggregate and the stats files
+    # from the device-decoded file and from the plain text
+    host.hpgv_run_vcf2epi.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_long)]
+    host.hpgv_run_aggregate.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_size_t, C.POINTER(C.c_long)]
+    host.hpgv_run_stats.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_long)]
+    both = {}
+    for tag, path in (("p", vcf), ("z", packed)):
+        n = C.c_long(0)
+        o = lambda name: str(tmp_path / (name + "_" + tag))
+        assert host.hpgv_run_tdt(path.encode(), ped, o("tdt").encode(), 1 << 17, C.byref(n)) == 0, host.hpgv_host_last_error()
+        assert host.hpgv_run_vcf2epi(path.encode(), ped, o("epi").encode(), 1 << 17, C.byref(n)) == 0, host.hpgv_host_last_error()
+        assert host.hpgv_run_aggregate(path.encode(), o("agg").encode(), 1, 1 << 17, C.byref(n)) == 0, host.hpgv_host_last_error()
+        assert host.hpgv_run_stats(path.encode(), ped, o("st").encode(), 1 << 17, C.byref(n)) == 0, host.hpgv_host_last_error()
+        both[tag] = [open(o("tdt"), "rb").read(), open(o("epi"), "rb").read(), open(o("agg"), "rb").read()] + \
+                    [open(o("st") + ext, "rb").read() for ext in (".stats-variants", ".stats-samples", ".stats-summary")]
+    assert all(len(x) > 0 for x in both["p"])
+    assert both["p"] == both["z"]
