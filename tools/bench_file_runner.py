@@ -58,7 +58,9 @@ L = C.CDLL(b.HOSTLIB)
 L.hpgv_run_assoc.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_size_t, C.POINTER(C.c_long)]
 L.hpgv_host_last_error.restype = C.c_char_p
 L.hpgv_host_last_run_times.argtypes = [C.POINTER(C.c_double)]
+import hashlib
 res = []
+digests = set()
 for kind in kinds:
     path = vcf
     if kind == "bgzf":
@@ -74,6 +76,7 @@ for kind in kinds:
         rc = L.hpgv_run_assoc(path.encode(), ped.encode(), out.encode(), 1, batch, C.byref(n))
         dt = time.perf_counter() - t0
         assert rc == 0 and n.value == n_variants, L.hpgv_host_last_error()
+        digests.add(hashlib.md5(open(out, "rb").read()).hexdigest())      # every input form must give the same result file
         tm = (C.c_double * 6)()
         L.hpgv_host_last_run_times(tm)
         res.append({"input": kind, "file_GB": round(os.path.getsize(path) / 1e9, 3), "batch_MB": batch >> 20, "seconds": round(dt, 3),
@@ -82,7 +85,7 @@ for kind in kinds:
     if path != vcf:
         os.remove(path)
 print(json.dumps({"n_samples": n_samples, "n_variants": n_variants, "vcf_GB": round(size / 1e9, 2),
-                  "io_threads": os.environ.get("HPGV_IO_THREADS", "default"), "runs": res}))
+                  "io_threads": os.environ.get("HPGV_IO_THREADS", "default"), "result_files_identical": len(digests) == 1, "runs": res}))
 for p in (vcf, ped, out):
     os.remove(p)
 os.rmdir(d)
