@@ -16,11 +16,30 @@ namespace hpgv {
 
 constexpr int TOK_TILE = 4096;          // bytes per workgroup tile (256 threads x 16 B)
 
+// bit j of the result = byte j of w equals c (exact: no borrow between bytes)
+__device__ __forceinline__ uint32_t tok_byte_mask(uint64_t w, char c) {
+    const uint64_t x = w ^ (0x0101010101010101ull * (uint8_t)c);
+    const uint64_t k7 = 0x7F7F7F7F7F7F7F7Full;
+    const uint64_t z = ~(((x & k7) + k7) | x | k7);          // 0x80 in every byte of x that is zero
+    return (uint32_t)((z * 0x0002040810204081ull) >> 56);          // the eight 0x80 flags gathered into one byte
+}
+
+// the newline bits of a thread's 16 bytes at `base` (two 8-byte loads; byte loop at the end of the text)
+__device__ __forceinline__ uint32_t tok_newlines16(const char *__restrict__ text, size_t base, size_t n) {
+    if (base + 16 <= n) {
+        uint64_t w0, w1;
+        __builtin_memcpy(&w0, text + base, 8); __builtin_memcpy(&w1, text + base + 8, 8);
+        return tok_byte_mask(w0, '\n') | (tok_byte_mask(w1, '\n') << 8);
+    }
+    uint32_t m = 0;
+    for (int j = 0; j < 16; ++j) if (base + j < n && text[base + j] == '\n') m |= 1u << j;
+    return m;
+}
+
 __global__ __launch_bounds__(256) void k_tok_count(const char *__restrict__ text, size_t n, int *__restrict__ block_counts) {
     __shared__ int s[4];
     const size_t base = (size_t)blockIdx.x * TOK_TILE + (size_t)threadIdx.x * 16;
-    int c = 0;
-    for (int j = 0; j < 16; ++j) if (base + j < n && text[base + j] == '\n') c++;
+    int c = __popc(tok_newlines16(text, base, n));
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -63,8 +82,8 @@ __global__ __launch_bounds__(256) void k_tok_mark(const char *__restrict__ text,
                                                   unsigned long long *__restrict__ line_off, int max_lines) {
     __shared__ int s[4];
     const size_t base = (size_t)blockIdx.x * TOK_TILE + (size_t)threadIdx.x * 16;
-    int c = 0;
-    for (int j = 0; j < 16; ++j) if (base + j < n && text[base + j] == '\n') c++;
+    uint32_t nls = tok_newlines16(text, base, n);
+    const int c = __popc(nls);
     int x = c;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
@@ -72,11 +91,12 @@ __global__ __launch_bounds__(256) void k_tok_mark(const char *__restrict__ text,
     __syncthreads();
     int before = block_offsets[blockIdx.x] + x - c;
     for (int k = 0; k < w; ++k) before += s[k];
-    for (int j = 0; j < 16; ++j)
-        if (base + j < n && text[base + j] == '\n') {
-            before++;
-            if (before <= max_lines) line_off[before] = base + j + 1;
-        }
+    while (nls) {
+        const int j = __ffs((int)nls) - 1;
+        nls &= nls - 1;
+        before++;
+        if (before <= max_lines) line_off[before] = base + j + 1;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) line_off[0] = 0;
 }
 
@@ -201,16 +221,43 @@ __global__ __launch_bounds__(256) void k_tok_parse(const char *__restrict__ text
     int before = 8;                                         // TABs in front of r0
     for (size_t base = r0; base < le; base += TOK_TILE) {
         const size_t p0 = base + (size_t)threadIdx.x * 16;
-        int c = 0;
-        for (int j = 0; j < 16; ++j) if (p0 + j < le && t[p0 + j] == '\t') c++;
+        // a thread's 16 bytes and the 8 after them come in three 8-byte loads (the byte loops below cost 32 loads); TABs
+        // by a bit trick; a genotype of the everyday form -- digit, '/' or '|', digit (or ". ." both missing), then TAB
+        // or ':' -- is encoded out of these registers; anything else, and the last bytes of a line, take the general way
+        const bool wide = p0 + 24 <= le;
+        uint64_t w0 = 0, w1 = 0, w2 = 0;
+        uint32_t tabs = 0;
+        if (wide) {
+            __builtin_memcpy(&w0, t + p0, 8); __builtin_memcpy(&w1, t + p0 + 8, 8); __builtin_memcpy(&w2, t + p0 + 16, 8);
+            tabs = tok_byte_mask(w0, '\t') | (tok_byte_mask(w1, '\t') << 8);
+        } else {
+            for (int j = 0; j < 16; ++j) if (p0 + j < le && t[p0 + j] == '\t') tabs |= 1u << j;
+        }
+        const int c = __popc(tabs);
         int total;
         int idx = before + block_excl_scan(c, s4, &total);  // TABs before this thread's bytes
-        for (int j = 0; j < 16; ++j)
-            if (p0 + j < le && t[p0 + j] == '\t') {
-                const int sample = idx - 8;                 // field index idx+1, samples start at field 9
-                idx++;
-                if (sample < n_samples) row[sample] = (uint8_t)tok_encode(t, p0 + j + 1, le, gtpos, strict);
+        while (tabs) {
+            const int j = __ffs((int)tabs) - 1;
+            tabs &= tabs - 1;
+            const int sample = idx - 8;                     // field index idx+1, samples start at field 9
+            idx++;
+            if (sample >= n_samples) continue;
+            uint32_t code = 0x100u;                         // "not decided"
+            if (wide && gtpos == 0) {
+                const int k = j + 1;                        // the four bytes after the TAB: k .. k + 3 <= 19
+                const int wi = k >> 3, sh = (k & 7) * 8;
+                const uint64_t a = wi == 0 ? w0 : wi == 1 ? w1 : w2, b = wi == 0 ? w1 : w2;
+                const uint32_t g = (uint32_t)(sh ? (a >> sh) | (b << (64 - sh)) : a);
+                const uint32_t b0 = g & 0xFF, b1 = (g >> 8) & 0xFF, b2 = (g >> 16) & 0xFF, b3 = g >> 24;
+                if ((b1 == '/' || b1 == '|') && (b3 == '\t' || b3 == ':')) {
+                    const uint32_t d0 = b0 - '0', d1 = b2 - '0';
+                    if (d0 <= 9 && d1 <= 9) code = (d0 << 4) | d1;
+                    else if (b0 == '.' && b2 == '.') code = 0xFFu;      // both alleles missing: 0xFF strict or not
+                }
             }
+            if (code == 0x100u) code = tok_encode(t, p0 + j + 1, le, gtpos, strict);
+            row[sample] = (uint8_t)code;
+        }
         before += total;
         __syncthreads();
     }
