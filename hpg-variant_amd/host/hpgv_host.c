@@ -1872,22 +1872,48 @@ static void source_task_inflate(void *v, int g) {
  * host and patched in.  No memory, a file of more than 48 GB of text or fewer than 256 blocks leave the CPU path in
  * charge.  HPGV_NO_GPU_INFLATE=1 switches it off. */
 enum { GPU_STRETCH = 32768 };
+/* the stager's uploads: out of the (pageable) mapping a copy runs at a fifth of the bus rate, so a team copies 64 MB
+ * pieces into a page-locked buffer and those go up */
+typedef struct { char *dst; const char *src; size_t len; } up_job_t;
+static void up_task_copy(void *v, int k) {
+    up_job_t *j = (up_job_t *)v;
+    const size_t off = (size_t)k * PREAD_SEG, n = off + PREAD_SEG <= j->len ? (size_t)PREAD_SEG : j->len - off;
+    memcpy(j->dst + off, j->src + off, n);
+}
+static int stager_upload(source_t *s, io_pool_t *cp, char *pin, size_t pin_cap, size_t lo, size_t hi, void *up) {
+    if (!pin) return hpgv_memcpy_h2d(g_ctx, (char *)s->d_comp + lo, s->map + lo, hi - lo, up) == HPGV_OK;
+    for (size_t off = lo; off < hi; off += pin_cap) {
+        up_job_t j = { pin, (const char *)s->map + off, hi - off < pin_cap ? hi - off : pin_cap };
+        pool_run(cp, up_task_copy, &j, (int)((j.len + PREAD_SEG - 1) / PREAD_SEG));
+        if (hpgv_memcpy_h2d(g_ctx, (char *)s->d_comp + off, pin, j.len, up) != HPGV_OK) return 0;
+    }
+    return 1;
+}
+
+
 static void *bgzf_gpu_stager(void *v) {
     source_t *s = (source_t *)v;
     const size_t nb = s->g_nb;
     char *t = (char *)s->d_tab;
     void *up = NULL;
     int ok = hpgv_stream_create(g_ctx, &up) == HPGV_OK;
-    int32_t *st = (int32_t *)malloc(sizeof(int32_t) * GPU_STRETCH);
+    int32_t *st = (int32_t *)malloc(sizeof(int32_t) * 4 * GPU_STRETCH);
     unsigned char *tmp = (unsigned char *)malloc(65536);
     ok = ok && st && tmp;
+    const size_t pin_cap = (size_t)64 << 20;
+    char *pin = text_buf_get(pin_cap + 1);                          /* from the runs' cache of page-locked buffers */
+    io_pool_t cp;
+    pool_init(&cp, 8);
     size_t launched = 0;                                 /* blocks [done, launched) are decoding */
     for (size_t first = 0; ok && (first < nb || launched > s->g_done);) {
         size_t next = first;
         if (first < nb) {                                /* upload the next stretch while the previous one decodes */
-            next = first + GPU_STRETCH < nb ? first + GPU_STRETCH : nb;
+            /* the decoder's rate grows with the blocks in flight (32 768: ~100 GB/s, 131 072: ~230 GB/s): after the first
+             * stretch, which the pipeline waits for, the stretches double up to four times the size */
+            const size_t stretch = first == 0 ? GPU_STRETCH : first < 3 * (size_t)GPU_STRETCH ? 2 * (size_t)GPU_STRETCH : 4 * (size_t)GPU_STRETCH;
+            next = first + stretch < nb ? first + stretch : nb;
             const size_t lo = (size_t)s->g_in_off[first], hi = (size_t)s->g_in_off[next - 1] + s->g_in_len[next - 1];
-            ok = hpgv_memcpy_h2d(g_ctx, (char *)s->d_comp + lo, s->map + lo, hi - lo, up) == HPGV_OK;
+            ok = stager_upload(s, &cp, pin, pin_cap, lo, hi, up);
         }
         if (ok && launched > s->g_done) {                /* the stretch in flight: wait, check, publish */
             const size_t a = s->g_done, n = launched - a;
@@ -1922,6 +1948,8 @@ static void *bgzf_gpu_stager(void *v) {
     pthread_cond_broadcast(&s->g_cv);
     pthread_mutex_unlock(&s->g_mu);
     free(st); free(tmp);
+    pool_destroy(&cp);
+    text_buf_put(pin, pin_cap + 1);
     if (up) (void)hpgv_stream_destroy(g_ctx, up);
     /* only the text is needed from here on */
     if (s->d_comp) { (void)hpgv_dev_free(g_ctx, s->d_comp); s->d_comp = NULL; }
