@@ -33,6 +33,7 @@ struct Layout {
     int chunks = 0;
     std::vector<int32_t> col_of_pos;   // size pitch; -1 = pad
     int32_t *d_col_of_pos = nullptr;
+    size_t d_cap = 0;                  // bytes behind d_col_of_pos
 };
 
 // per-call scratch of the synchronous host entry points
@@ -167,8 +168,14 @@ struct DeviceGuard {
 size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 int upload_layout(hpgv_ctx *ctx, Layout &L) {
-    if (L.d_col_of_pos) { (void)hipFree(L.d_col_of_pos); L.d_col_of_pos = nullptr; }
-    HIPCHK(ctx, hipMalloc(&L.d_col_of_pos, L.col_of_pos.size() * sizeof(int32_t)));
+    // the table is kept when it is large enough: hipFree waits for every stream of the device, and a file run sets its
+    // cohort while the decoder of the bgzip text is busy on streams of its own
+    const size_t need = L.col_of_pos.size() * sizeof(int32_t);
+    if (L.d_cap < need) {
+        if (L.d_col_of_pos) { (void)hipFree(L.d_col_of_pos); L.d_col_of_pos = nullptr; L.d_cap = 0; }
+        HIPCHK(ctx, hipMalloc(&L.d_col_of_pos, need));
+        L.d_cap = need;
+    }
     HIPCHK(ctx, hipMemcpy(L.d_col_of_pos, L.col_of_pos.data(), L.col_of_pos.size() * sizeof(int32_t),
                           hipMemcpyHostToDevice));
     L.chunks = (int)(L.pitch / 16);

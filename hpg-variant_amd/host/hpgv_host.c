@@ -1534,7 +1534,6 @@ typedef struct {
     size_t *blk;                                        /* BGZF: per-call block table (offset, length, destination, size) */
     io_pool_t *pool;                                    /* team for the pread segments / the block inflation (may be NULL) */
     char *job_buf; size_t job_want; int job_bad;        /* the job the team is working on */
-    const char *job_map; size_t job_map_len;            /* ... or the mapped range it is faulting in */
     gzFile gz;                                          /* GZIP */
     /* BGZF decoded on the GPU: the whole file's text in device memory, handed out window by window */
     void *d_comp, *d_tab, *d_text, *d_status, *rstream, *cstream; size_t dev_len, dev_pos; int gpu_tried;
@@ -1844,15 +1843,6 @@ static void source_task_pread(void *v, int k) {
         off += (size_t)got; len -= (size_t)got;
     }
 }
-/* faults one segment of a mapped range in (one byte per page) */
-static volatile unsigned char g_touch_sink;
-static void source_task_touch(void *v, int k) {
-    source_t *s = (source_t *)v;
-    size_t off = (size_t)k * PREAD_SEG, end = off + PREAD_SEG <= s->job_map_len ? off + PREAD_SEG : s->job_map_len;
-    unsigned char acc = 0;
-    for (; off < end; off += 4096) acc ^= (unsigned char)s->job_map[off];
-    g_touch_sink ^= acc;
-}
 static void source_task_inflate(void *v, int g) {
     source_t *s = (source_t *)v;
     const size_t *b_in = s->blk, *b_clen = s->blk + MAXB, *b_out = s->blk + 2 * MAXB, *b_isize = s->blk + 3 * MAXB;
@@ -1865,27 +1855,54 @@ static void source_task_inflate(void *v, int g) {
 }
 
 /* BGZF on the GPU: the file's blocks are decoded on the device (hpgv_inflate_blocks_dev: one lane per block, tens of
- * thousands of blocks per launch; 8 GB of VCF text in 0.12 s) and the text stays in device memory.  The reader copies it
+ * thousands of blocks per launch; 8 GB of VCF text in 0.1 s) and the text stays in device memory.  The reader copies it
  * out window by window for the result writers and the engine tokenizes the device copy in place (hpgv_text_alias) --
- * the compressed bytes are all that goes up the bus.  A stager thread uploads and decodes the file in stretches of
- * 32 768 blocks, so the pipeline starts after the first stretch; a block the device decoder refuses is decoded by the
- * host and patched in.  No memory, a file of more than 48 GB of text or fewer than 256 blocks leave the CPU path in
- * charge.  HPGV_NO_GPU_INFLATE=1 switches it off. */
-enum { GPU_STRETCH = 32768 };
-/* the stager's uploads: out of the (pageable) mapping a copy runs at a fifth of the bus rate, so a team copies 64 MB
- * pieces into a page-locked buffer and those go up */
-typedef struct { char *dst; const char *src; size_t len; } up_job_t;
+ * the compressed bytes are all that goes up the bus, read from the file with pread into a page-locked buffer (the
+ * mapping is not touched: faulting a gigabyte in and unmapping it costs more than the decoding).  A stager thread
+ * uploads and decodes the file in stretches: 4 096 blocks first, decoded alone, so that the header reader and the
+ * pipeline start after the time one block takes; then 32 768 and more, several launches side by side on streams of
+ * their own.  A block the device decoder refuses is decoded by the host and patched in.  No memory, a file of more
+ * than 48 GB of text or fewer than 256 blocks leave the CPU path in charge.  HPGV_NO_GPU_INFLATE=1 switches it off. */
+enum { GPU_STRETCH = 32768, GPU_AHEAD_BYTES = 768 << 20 };
+/* the stager's uploads: out of pageable memory a copy runs at a fifth of the bus rate, so a team reads 64 MB pieces
+ * of the file into a page-locked buffer and those go up (pread, not the mapping: faulting a gigabyte in and unmapping
+ * it again costs ~90 ms) */
+enum { UP_SEG = 2 << 20 };
+typedef struct {
+    char *dst; int fd; off_t pos; size_t len; int bad;   /* this piece: file -> one half of the page-locked buffer */
+    const char *h_src; void *h_dst; size_t h_len; void *stream;      /* the piece before it: other half -> device (task 0) */
+} up_job_t;
 static void up_task_copy(void *v, int k) {
     up_job_t *j = (up_job_t *)v;
-    const size_t off = (size_t)k * PREAD_SEG, n = off + PREAD_SEG <= j->len ? (size_t)PREAD_SEG : j->len - off;
-    memcpy(j->dst + off, j->src + off, n);
+    if (j->h_len) {
+        if (k == 0) {
+            if (hpgv_memcpy_h2d(g_ctx, j->h_dst, j->h_src, j->h_len, j->stream) != HPGV_OK) __atomic_store_n(&j->bad, 1, __ATOMIC_RELAXED);
+            return;
+        }
+        k--;
+    }
+    size_t off = (size_t)k * UP_SEG, n = off + UP_SEG <= j->len ? (size_t)UP_SEG : j->len - off;
+    if (off >= j->len) return;
+    while (n > 0) {
+        const ssize_t got = pread(j->fd, j->dst + off, n, j->pos + (off_t)off);
+        if (got <= 0) { __atomic_store_n(&j->bad, 1, __ATOMIC_RELAXED); return; }
+        off += (size_t)got; n -= (size_t)got;
+    }
 }
+/* compressed bytes [lo, hi) of the file -> d_comp: while one half of the buffer goes up the bus the team fills the other */
 static int stager_upload(source_t *s, io_pool_t *cp, char *pin, size_t pin_cap, size_t lo, size_t hi, void *up) {
     if (!pin) return hpgv_memcpy_h2d(g_ctx, (char *)s->d_comp + lo, s->map + lo, hi - lo, up) == HPGV_OK;
-    for (size_t off = lo; off < hi; off += pin_cap) {
-        up_job_t j = { pin, (const char *)s->map + off, hi - off < pin_cap ? hi - off : pin_cap };
-        pool_run(cp, up_task_copy, &j, (int)((j.len + PREAD_SEG - 1) / PREAD_SEG));
-        if (hpgv_memcpy_h2d(g_ctx, (char *)s->d_comp + off, pin, j.len, up) != HPGV_OK) return 0;
+    const size_t half = pin_cap / 2;
+    size_t prev_off = 0, prev_len = 0;
+    int side = 0;
+    for (size_t off = lo; off < hi || prev_len; off += half, side ^= 1) {
+        up_job_t j;
+        memset(&j, 0, sizeof j);
+        j.dst = pin + (size_t)side * half; j.fd = s->fd; j.pos = (off_t)off; j.len = off < hi ? (hi - off < half ? hi - off : half) : 0;
+        j.h_src = pin + (size_t)(side ^ 1) * half; j.h_dst = (char *)s->d_comp + prev_off; j.h_len = prev_len; j.stream = up;
+        pool_run(cp, up_task_copy, &j, (int)((j.len + UP_SEG - 1) / UP_SEG) + (prev_len ? 1 : 0));
+        if (j.bad) return 0;
+        prev_off = off; prev_len = j.len;
     }
     return 1;
 }
@@ -1903,45 +1920,73 @@ static void *bgzf_gpu_stager(void *v) {
     const size_t pin_cap = (size_t)64 << 20;
     char *pin = text_buf_get(pin_cap + 1);                          /* from the runs' cache of page-locked buffers */
     io_pool_t cp;
-    pool_init(&cp, 8);
-    size_t launched = 0;                                 /* blocks [done, launched) are decoding */
-    for (size_t first = 0; ok && (first < nb || launched > s->g_done);) {
-        size_t next = first;
-        if (first < nb) {                                /* upload the next stretch while the previous one decodes */
-            /* the decoder's rate grows with the blocks in flight (32 768: ~100 GB/s, 131 072: ~230 GB/s): after the first
-             * stretch, which the pipeline waits for, the stretches double up to four times the size */
-            const size_t stretch = first == 0 ? GPU_STRETCH : first < 3 * (size_t)GPU_STRETCH ? 2 * (size_t)GPU_STRETCH : 4 * (size_t)GPU_STRETCH;
-            next = first + stretch < nb ? first + stretch : nb;
+    pool_init(&cp, default_io_threads());
+    /* a launch takes the time one lane needs for its block (~40 ms) whatever the number of blocks, so the stretches
+     * decode side by side: up to GPU_INFLIGHT launches on streams of their own, published in file order */
+    enum { GPU_INFLIGHT = 4, GPU_FIRST = 4096 };
+    void *cs[GPU_INFLIGHT] = { s->cstream, NULL, NULL, NULL };
+    for (int q = 1; ok && q < GPU_INFLIGHT; q++) ok = hpgv_stream_create(g_ctx, &cs[q]) == HPGV_OK;
+    size_t q_hi[GPU_INFLIGHT];                           /* the stretches in flight end at these blocks; the oldest starts at g_done */
+    int qh = 0, qn = 0;
+    const int dbg = getenv("HPGV_RUN_TRACE") != NULL; const double T0 = now_s();
+    size_t up_hi = 0;                                    /* compressed bytes [0, up_hi) are on the device */
+    for (size_t first = 0; ok && (first < nb || qn > 0);) {
+        if (first < nb && qn < GPU_INFLIGHT) {           /* upload the next stretch while the earlier ones decode */
+            /* a short first stretch, which the header reader waits for, then 32 768 blocks doubling up to four times that */
+            const size_t stretch = first == 0 ? GPU_FIRST : first < GPU_FIRST + (size_t)GPU_STRETCH ? GPU_STRETCH
+                                 : first < GPU_FIRST + 3 * (size_t)GPU_STRETCH ? 2 * (size_t)GPU_STRETCH : 4 * (size_t)GPU_STRETCH;
+            const size_t next = first + stretch < nb ? first + stretch : nb;
             const size_t lo = (size_t)s->g_in_off[first], hi = (size_t)s->g_in_off[next - 1] + s->g_in_len[next - 1];
-            ok = stager_upload(s, &cp, pin, pin_cap, lo, hi, up);
+            if (hi > up_hi) {
+                ok = stager_upload(s, &cp, pin, pin_cap, lo > up_hi ? lo : up_hi, hi, up);
+                up_hi = hi;
+                if (dbg) fprintf(stderr, "stager: uploaded [%zu,%zu) to byte %.1f MB at %.4f\n", first, next, hi / 1e6, now_s() - T0);
+            }
+            const int q = (qh + qn) % GPU_INFLIGHT;
+            ok = ok && hpgv_inflate_blocks_dev(g_ctx, (const uint8_t *)s->d_comp, (const uint64_t *)t + first, (const uint32_t *)(t + nb * 16) + first,
+                                               (const uint64_t *)(t + nb * 8) + first, (const uint32_t *)(t + nb * 20) + first, (int)(next - first),
+                                               (uint8_t *)s->d_text, (int32_t *)s->d_status + first, cs[q]) == HPGV_OK;
+            q_hi[q] = next; qn++;
+            if (ok && first == 0 && next < nb) {
+                /* launches that run side by side finish together, so the first stretch decodes alone (the time of one
+                 * block, ~40 ms); meanwhile the bytes of the next stretches go up -- as many as that time allows -- and
+                 * those are launched as soon as it is done */
+                size_t ahead = next;
+                while (ahead < nb && (size_t)s->g_in_off[ahead] + s->g_in_len[ahead] <= up_hi + GPU_AHEAD_BYTES) ahead++;
+                const size_t h2 = ahead > next ? (size_t)s->g_in_off[ahead - 1] + s->g_in_len[ahead - 1] : up_hi;
+                if (h2 > up_hi) ok = stager_upload(s, &cp, pin, pin_cap, up_hi, h2, up);
+                up_hi = h2;
+                if (dbg) fprintf(stderr, "stager: uploaded ahead to block %zu, byte %.1f MB at %.4f\n", ahead, h2 / 1e6, now_s() - T0);
+                first = next;
+            } else {
+                first = next;
+                if (first < nb && qn < GPU_INFLIGHT) continue;
+            }
         }
-        if (ok && launched > s->g_done) {                /* the stretch in flight: wait, check, publish */
-            const size_t a = s->g_done, n = launched - a;
-            ok = hpgv_memcpy_d2h(g_ctx, st, (char *)s->d_status + a * 4, n * 4, s->cstream) == HPGV_OK;      /* synchronises cstream */
+        if (ok && qn > 0) {                              /* the oldest stretch in flight: wait, check, publish */
+            const size_t a = s->g_done, n = q_hi[qh] - a;
+            ok = hpgv_memcpy_d2h(g_ctx, st, (char *)s->d_status + a * 4, n * 4, cs[qh]) == HPGV_OK;      /* synchronises that stream */
             const char *fe = getenv("HPGV_TEST_GPU_INFLATE_REFUSE_EVERY");     /* tests: exercise the host patch path */
             const size_t refuse_every = fe ? (size_t)atol(fe) : 0;
             for (size_t k = 0; ok && k < n; k++)
                 if (st[k] || (refuse_every && (a + k) % refuse_every == 0)) {                             /* not taken by the device decoder: the host decodes it, the text is patched */
                     const size_t bb = a + k;
                     ok = !inflate_block(s->map + s->g_in_off[bb], s->g_in_len[bb], tmp, s->g_out_len[bb])
-                      && hpgv_memcpy_h2d(g_ctx, (char *)s->d_text + s->g_out_off[bb], tmp, s->g_out_len[bb], s->cstream) == HPGV_OK;
+                      && hpgv_memcpy_h2d(g_ctx, (char *)s->d_text + s->g_out_off[bb], tmp, s->g_out_len[bb], cs[qh]) == HPGV_OK;
                 }
+            if (dbg) fprintf(stderr, "stager: decoded up to %zu at %.4f\n", q_hi[qh], now_s() - T0);
             if (ok) {
                 pthread_mutex_lock(&s->g_mu);
-                s->g_done = launched;
-                s->dev_ready = launched == nb ? s->dev_len : (size_t)s->g_out_off[launched];
+                s->g_done = q_hi[qh];
+                s->dev_ready = q_hi[qh] == nb ? s->dev_len : (size_t)s->g_out_off[q_hi[qh]];
                 pthread_cond_broadcast(&s->g_cv);
                 pthread_mutex_unlock(&s->g_mu);
             }
+            qh = (qh + 1) % GPU_INFLIGHT; qn--;
         }
-        if (ok && first < nb) {
-            ok = hpgv_inflate_blocks_dev(g_ctx, (const uint8_t *)s->d_comp, (const uint64_t *)t + first, (const uint32_t *)(t + nb * 16) + first,
-                                         (const uint64_t *)(t + nb * 8) + first, (const uint32_t *)(t + nb * 20) + first, (int)(next - first),
-                                         (uint8_t *)s->d_text, (int32_t *)s->d_status + first, s->cstream) == HPGV_OK;
-            launched = next;
-        }
-        first = next;
     }
+    for (int q = 0; q < GPU_INFLIGHT; q++) if (cs[q]) (void)hpgv_stream_sync(g_ctx, cs[q]);      /* after a failure launches may still be running */
+    for (int q = 1; q < GPU_INFLIGHT; q++) if (cs[q]) (void)hpgv_stream_destroy(g_ctx, cs[q]);
     pthread_mutex_lock(&s->g_mu);
     if (!ok) s->g_err = 1;
     s->g_finished = 1;
@@ -1951,49 +1996,189 @@ static void *bgzf_gpu_stager(void *v) {
     pool_destroy(&cp);
     text_buf_put(pin, pin_cap + 1);
     if (up) (void)hpgv_stream_destroy(g_ctx, up);
+    if (dbg) fprintf(stderr, "stager: finished %.4f\n", now_s() - T0);
     /* only the text is needed from here on */
     if (s->d_comp) { (void)hpgv_dev_free(g_ctx, s->d_comp); s->d_comp = NULL; }
     if (s->d_status) { (void)hpgv_dev_free(g_ctx, s->d_status); s->d_status = NULL; }
+    if (dbg) fprintf(stderr, "stager: freed %.4f\n", now_s() - T0);
     return NULL;
+}
+
+/* The BGZF header walk is a chain of dependent cache misses (122 000 blocks: 25 ms), so a team walks the file in
+ * segments: every segment but the first finds a place where three valid block headers follow one another, walks from
+ * there to the first block at or past its end, and the pieces are accepted only if every walk ends exactly where
+ * the next one began -- then their concatenation IS the chain from offset 0.  Anything else: the serial walk.  The
+ * team reads the file with pread (some 60 bytes per block), so that no page of the mapping is touched. */
+typedef struct {
+    int fd; size_t size, seg; int nseg;
+    size_t *start, *end, *cnt;                           /* per segment: first block, where the walk stopped, blocks */
+    uint64_t **in_off; uint32_t **in_len, **out_len; int *bad;
+} bgzf_walk_t;
+static size_t pread_full(int fd, void *buf, size_t n, size_t pos) {
+    size_t have = 0;
+    while (have < n) {
+        const ssize_t got = pread(fd, (char *)buf + have, n - have, (off_t)(pos + have));
+        if (got <= 0) break;
+        have += (size_t)got;
+    }
+    return have;
+}
+/* bgzf_block without the trailer: the first `have` bytes of a block that has `avail` bytes of file left */
+static int bgzf_header(const unsigned char *p, size_t have, size_t avail, size_t *bsize, size_t *cdata_off) {
+    if (have < 18 || p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) return 0;
+    const size_t xlen = (size_t)p[10] | ((size_t)p[11] << 8), end = 12 + xlen;
+    size_t off = 12, bs = 0;
+    if (end > have) return 0;                            /* more extra fields than the walk reads: the serial walk takes the file */
+    while (off + 4 <= end) {
+        const size_t slen = (size_t)p[off + 2] | ((size_t)p[off + 3] << 8);
+        if (p[off] == 'B' && p[off + 1] == 'C' && slen == 2 && off + 6 <= end) bs = ((size_t)p[off + 4] | ((size_t)p[off + 5] << 8)) + 1;
+        off += 4 + slen;
+    }
+    if (bs < end + 8 || bs > avail) return 0;
+    *bsize = bs; *cdata_off = end;
+    return 1;
+}
+static void bgzf_walk_task(void *v, int k) {
+    enum { WINDOW = 4 * 65536 + 256, HEAD = 60 };
+    bgzf_walk_t *w = (bgzf_walk_t *)v;
+    const size_t lim = k + 1 == w->nseg ? w->size : (size_t)(k + 1) * w->seg;
+    size_t pos = (size_t)k * w->seg, bs, co, is;
+    w->bad[k] = 1; w->cnt[k] = 0;
+    if (k > 0) {                                         /* the first place in the segment where three valid blocks follow one another */
+        unsigned char *win = (unsigned char *)malloc(WINDOW);
+        if (!win) return;
+        const size_t base = pos, wn = pread_full(w->fd, win, WINDOW, base), slim = lim - base < wn ? lim - base : wn;
+        int found = 0;
+        size_t o = 0;
+        while (o < slim) {
+            const unsigned char *c = (const unsigned char *)memchr(win + o, 31, slim - o);
+            if (!c) break;
+            o = (size_t)(c - win);
+            size_t q = o;
+            int chain = 0;
+            while (chain < 3 && q < wn && bgzf_block(win + q, wn - q, &bs, &co, &is) && is <= 65536) { q += bs; chain++; }
+            if (chain == 3 || (chain > 0 && base + q == w->size)) { found = 1; break; }
+            o++;
+        }
+        free(win);
+        if (!found) {
+            if (slim < lim - base) return;               /* a segment longer than the window with no block start in the window: not BGZF as we know it */
+            w->start[k] = w->end[k] = lim; w->bad[k] = 0; return;      /* no block begins in this segment */
+        }
+        pos = base + o;
+    }
+    w->start[k] = pos;
+    size_t cap = w->seg / 8192 + 1024, n = 0;
+    uint64_t *a = (uint64_t *)malloc(cap * 8);
+    uint32_t *b = (uint32_t *)malloc(cap * 4), *c = (uint32_t *)malloc(cap * 4);
+    int ok = a && b && c;
+    unsigned char hb[4 + HEAD];
+    size_t hn = ok && pos < lim ? pread_full(w->fd, hb + 4, HEAD, pos) : 0;      /* hb + 4: this block's first bytes */
+    while (ok && pos < lim) {
+        if (!bgzf_header(hb + 4, hn, w->size - pos, &bs, &co)) { ok = 0; break; }
+        /* one read gets this block's last four bytes (ISIZE) and the next block's first ones */
+        const size_t got = pread_full(w->fd, hb, 4 + HEAD, pos + bs - 4);
+        if (got < 4) { ok = 0; break; }
+        is = (size_t)hb[0] | ((size_t)hb[1] << 8) | ((size_t)hb[2] << 16) | ((size_t)hb[3] << 24);
+        hn = got - 4;
+        if (is > 65536) { ok = 0; break; }
+        if (n == cap) {
+            cap *= 2;
+            uint64_t *a2 = (uint64_t *)realloc(a, cap * 8);
+            uint32_t *b2 = (uint32_t *)realloc(b, cap * 4), *c2 = (uint32_t *)realloc(c, cap * 4);
+            if (a2) a = a2;
+            if (b2) b = b2;
+            if (c2) c = c2;
+            if (!a2 || !b2 || !c2) { ok = 0; break; }
+        }
+        a[n] = pos + co; b[n] = (uint32_t)(bs - co - 8); c[n] = (uint32_t)is;
+        n++; pos += bs;
+    }
+    w->in_off[k] = a; w->in_len[k] = b; w->out_len[k] = c; w->cnt[k] = n; w->end[k] = pos; w->bad[k] = !ok;
+}
+/* 0 = the tables are filled (malloc'ed, *nb_out blocks, *text_out bytes of text); non-zero = walk serially */
+static int bgzf_walk_parallel(int fd, size_t size, uint64_t **in_off, uint64_t **out_off, uint32_t **in_len, uint32_t **out_len,
+                              size_t *nb_out, size_t *text_out) {
+    enum { NSEG = 64 };
+    if (size < (size_t)NSEG * 4096) return 1;
+    bgzf_walk_t w;
+    size_t start[NSEG], end[NSEG], cnt[NSEG];
+    uint64_t *a[NSEG]; uint32_t *b[NSEG], *c[NSEG]; int bad[NSEG];
+    memset(a, 0, sizeof a); memset(b, 0, sizeof b); memset(c, 0, sizeof c);
+    w.fd = fd; w.size = size; w.seg = size / NSEG; w.nseg = NSEG;
+    w.start = start; w.end = end; w.cnt = cnt; w.in_off = a; w.in_len = b; w.out_len = c; w.bad = bad;
+    io_pool_t tp;
+    pool_init(&tp, default_io_threads());
+    pool_run(&tp, bgzf_walk_task, &w, NSEG);
+    pool_destroy(&tp);
+    int ok = 1;
+    size_t nb = 0, expect = 0;
+    for (int k = 0; k < NSEG && ok; k++) {
+        if (bad[k]) ok = 0;
+        else if (cnt[k] == 0) { if (start[k] != end[k]) ok = 0; }          /* an empty segment: the chain passes over it */
+        else { if (start[k] != expect) ok = 0; expect = end[k]; nb += cnt[k]; }
+    }
+    if (ok && expect != size) ok = 0;
+    uint64_t *io = NULL, *oo = NULL; uint32_t *il = NULL, *ol = NULL;
+    if (ok) {
+        io = (uint64_t *)malloc((nb + 1) * 8); oo = (uint64_t *)malloc((nb + 1) * 8);
+        il = (uint32_t *)malloc((nb + 1) * 4); ol = (uint32_t *)malloc((nb + 1) * 4);
+        ok = io && oo && il && ol;
+    }
+    if (ok) {
+        size_t n = 0, text = 0;
+        for (int k = 0; k < NSEG; k++) {
+            if (cnt[k] == 0) continue;
+            memcpy(io + n, a[k], cnt[k] * 8); memcpy(il + n, b[k], cnt[k] * 4); memcpy(ol + n, c[k], cnt[k] * 4);
+            n += cnt[k];
+        }
+        for (size_t i = 0; i < nb; i++) { oo[i] = text; text += ol[i]; }
+        *in_off = io; *out_off = oo; *in_len = il; *out_len = ol; *nb_out = nb; *text_out = text;
+    } else { free(io); free(oo); free(il); free(ol); }
+    for (int k = 0; k < NSEG; k++) { free(a[k]); free(b[k]); free(c[k]); }
+    return !ok;
 }
 
 static int bgzf_gpu_stage(source_t *s) {
     s->gpu_tried = 1;
     if (getenv("HPGV_NO_GPU_INFLATE") || !g_ctx || s->map_pos != 0) return 1;
-    {                                                            /* fault the mapping in with a team: the header walk and the uploads then find the pages */
-        io_pool_t tp;
-        pool_init(&tp, default_io_threads());
-        s->job_map = (const char *)s->map; s->job_map_len = (size_t)s->size;
-        pool_run(&tp, source_task_touch, s, (int)(((size_t)s->size + PREAD_SEG - 1) / PREAD_SEG));
-        pool_destroy(&tp);
-    }
+    const int dbg = getenv("HPGV_RUN_TRACE") != NULL; double T0 = now_s();
     size_t nb = 0, cap = 1 << 16, text = 0;
-    uint64_t *in_off = (uint64_t *)malloc(cap * 8), *out_off = (uint64_t *)malloc(cap * 8);
-    uint32_t *in_len = (uint32_t *)malloc(cap * 4), *out_len = (uint32_t *)malloc(cap * 4);
-    int ok = in_off && out_off && in_len && out_len;
-    size_t pos = 0;
-    while (ok && pos < (size_t)s->size) {
-        size_t bs, co, is;
-        if (!bgzf_block(s->map + pos, (size_t)s->size - pos, &bs, &co, &is) || is > 65536) { ok = 0; break; }
-        if (nb == cap) {
-            cap *= 2;
-            uint64_t *a = (uint64_t *)realloc(in_off, cap * 8), *b = (uint64_t *)realloc(out_off, cap * 8);
-            uint32_t *c = (uint32_t *)realloc(in_len, cap * 4), *d = (uint32_t *)realloc(out_len, cap * 4);
-            if (a) in_off = a;
-            if (b) out_off = b;
-            if (c) in_len = c;
-            if (d) out_len = d;
-            if (!a || !b || !c || !d) { ok = 0; break; }
+    uint64_t *in_off = NULL, *out_off = NULL;
+    uint32_t *in_len = NULL, *out_len = NULL;
+    int ok = 1;
+    if (getenv("HPGV_SERIAL_BGZF_WALK") || bgzf_walk_parallel(s->fd, (size_t)s->size, &in_off, &out_off, &in_len, &out_len, &nb, &text)) {
+        nb = 0; text = 0;
+        if (dbg) fprintf(stderr, "stage: serial walk\n");
+        in_off = (uint64_t *)malloc(cap * 8); out_off = (uint64_t *)malloc(cap * 8);
+        in_len = (uint32_t *)malloc(cap * 4); out_len = (uint32_t *)malloc(cap * 4);
+        ok = in_off && out_off && in_len && out_len;
+        size_t pos = 0;
+        while (ok && pos < (size_t)s->size) {
+            size_t bs, co, is;
+            if (!bgzf_block(s->map + pos, (size_t)s->size - pos, &bs, &co, &is) || is > 65536) { ok = 0; break; }
+            if (nb == cap) {
+                cap *= 2;
+                uint64_t *a = (uint64_t *)realloc(in_off, cap * 8), *b = (uint64_t *)realloc(out_off, cap * 8);
+                uint32_t *c = (uint32_t *)realloc(in_len, cap * 4), *d = (uint32_t *)realloc(out_len, cap * 4);
+                if (a) in_off = a;
+                if (b) out_off = b;
+                if (c) in_len = c;
+                if (d) out_len = d;
+                if (!a || !b || !c || !d) { ok = 0; break; }
+            }
+            in_off[nb] = pos + co; in_len[nb] = (uint32_t)(bs - co - 8); out_off[nb] = text; out_len[nb] = (uint32_t)is;
+            text += is; pos += bs; nb++;
         }
-        in_off[nb] = pos + co; in_len[nb] = (uint32_t)(bs - co - 8); out_off[nb] = text; out_len[nb] = (uint32_t)is;
-        text += is; pos += bs; nb++;
     }
+    if (dbg) fprintf(stderr, "stage: walk %.4f\n", now_s() - T0);
     if (ok && (nb < 256 || nb > 0x7FFFFFFFu || text > ((size_t)48 << 30))) ok = 0;     /* a small file is as quick on the host */
     if (ok) ok = hpgv_stream_create(g_ctx, &s->rstream) == HPGV_OK && hpgv_stream_create(g_ctx, &s->cstream) == HPGV_OK;
     if (ok) ok = hpgv_dev_alloc(g_ctx, (size_t)s->size + 16, &s->d_comp) == HPGV_OK;
     if (ok) ok = hpgv_dev_alloc(g_ctx, nb * 24 + 64, &s->d_tab) == HPGV_OK;
     if (ok) { s->d_text_cap = text + 16; s->d_text = dev_text_get(s->d_text_cap); ok = s->d_text != NULL; }
     if (ok) ok = hpgv_dev_alloc(g_ctx, nb * 4 + 16, &s->d_status) == HPGV_OK;
+    if (dbg) fprintf(stderr, "stage: alloc %.4f\n", now_s() - T0);
     if (ok) {
         char *t = (char *)s->d_tab;
         ok = hpgv_memcpy_h2d(g_ctx, t, in_off, nb * 8, s->cstream) == HPGV_OK
@@ -2001,6 +2186,7 @@ static int bgzf_gpu_stage(source_t *s) {
           && hpgv_memcpy_h2d(g_ctx, t + nb * 16, in_len, nb * 4, s->cstream) == HPGV_OK
           && hpgv_memcpy_h2d(g_ctx, t + nb * 20, out_len, nb * 4, s->cstream) == HPGV_OK;
     }
+    if (dbg) fprintf(stderr, "stage: tab %.4f\n", now_s() - T0);
     if (ok) {
         s->g_in_off = in_off; s->g_out_off = out_off; s->g_in_len = in_len; s->g_out_len = out_len; s->g_nb = nb;
         s->dev_len = text; s->dev_pos = 0; s->dev_ready = 0; s->g_done = 0; s->g_err = 0; s->g_finished = 0;

@@ -408,6 +408,7 @@ def test_run_assoc_from_bgzf_decoded_on_the_gpu(host, tmp_path):
     plain = run(vcf, "plain")
     assert plain.count(b"\n") == len(rows) + 1
     assert run(packed, "gpu") == plain
+    assert run(packed, "serial_walk", {"HPGV_SERIAL_BGZF_WALK": "1"}) == plain        # the block table by one thread instead of the team
     assert run(packed, "patched", {"HPGV_TEST_GPU_INFLATE_REFUSE_EVERY": "3"}) == plain
     assert run(packed, "copied_back", {"HPGV_NO_DEVICE_WINDOWS": "1"}) == plain       # device decoding, whole windows copied back
     assert run(packed, "cpu", {"HPGV_NO_GPU_INFLATE": "1"}) == plain
