@@ -1933,7 +1933,8 @@ static void *bgzf_gpu_stager(void *v) {
     for (size_t first = 0; ok && (first < nb || qn > 0);) {
         if (first < nb && qn < GPU_INFLIGHT) {           /* upload the next stretch while the earlier ones decode */
             /* a short first stretch, which the header reader waits for, then 32 768 blocks doubling up to four times that */
-            const size_t stretch = first == 0 ? GPU_FIRST : first < GPU_FIRST + (size_t)GPU_STRETCH ? GPU_STRETCH
+            const size_t stretch = first == 0 ? (nb <= 3 * (size_t)GPU_FIRST ? nb : GPU_FIRST)      /* a small file: one launch */
+                                 : first < GPU_FIRST + (size_t)GPU_STRETCH ? GPU_STRETCH
                                  : first < GPU_FIRST + 3 * (size_t)GPU_STRETCH ? 2 * (size_t)GPU_STRETCH : 4 * (size_t)GPU_STRETCH;
             const size_t next = first + stretch < nb ? first + stretch : nb;
             const size_t lo = (size_t)s->g_in_off[first], hi = (size_t)s->g_in_off[next - 1] + s->g_in_len[next - 1];
