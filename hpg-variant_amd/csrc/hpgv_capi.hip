@@ -107,6 +107,7 @@ struct hpgv_ctx {
     // fisher
     double *d_lf = nullptr;
     size_t n_lf = 0;
+    size_t cap_lf = 0;                 // doubles behind d_lf (kept across tables: hipFree waits for the whole device)
     // synth scratch
     uint32_t *d_thr = nullptr;
     size_t thr_cap = 0;
@@ -402,8 +403,12 @@ int hpgv_set_logfact(hpgv_ctx *ctx, const double *table, size_t n) {
     if (!ctx) return HPGV_ERR_INVALID;
     if (!table || n == 0) return fail(ctx, HPGV_ERR_INVALID, "empty log-factorial table");
     DeviceGuard g(ctx->device);
-    if (ctx->d_lf) { (void)hipFree(ctx->d_lf); ctx->d_lf = nullptr; ctx->n_lf = 0; }
-    HIPCHK(ctx, hipMalloc(&ctx->d_lf, n * sizeof(double)));
+    ctx->n_lf = 0;
+    if (ctx->cap_lf < n) {
+        if (ctx->d_lf) { (void)hipFree(ctx->d_lf); ctx->d_lf = nullptr; ctx->cap_lf = 0; }
+        HIPCHK(ctx, hipMalloc(&ctx->d_lf, n * sizeof(double)));
+        ctx->cap_lf = n;
+    }
     HIPCHK(ctx, hipMemcpy(ctx->d_lf, table, n * sizeof(double), hipMemcpyHostToDevice));
     ctx->n_lf = n;
     return HPGV_OK;
