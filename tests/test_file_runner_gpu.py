@@ -379,7 +379,7 @@ def test_run_stats_files(host, tmp_path):
                 assert (np.isnan(got) and np.isnan(e)) or abs(got - e) <= 1e-5 * max(1.0, abs(e))
 
 
-def test_run_assoc_from_bgzf_decoded_on_the_gpu(host, tmp_path):
+def test_run_assoc_from_bgzf_decoded_on_the_gpu(host, tmp_path, capfd):
     # a bgzip file of 256 blocks or more is decoded on the device (hpgv_inflate_blocks_dev) and tokenized from device memory:
     # same result file as from the plain text -- by that path, with every third block refused by the device decoder (decoded
     # by the host and patched in), and with the device path switched off; several pipeline batches, lines across blocks
@@ -409,6 +409,26 @@ def test_run_assoc_from_bgzf_decoded_on_the_gpu(host, tmp_path):
     assert plain.count(b"\n") == len(rows) + 1
     assert run(packed, "gpu") == plain
     assert run(packed, "serial_walk", {"HPGV_SERIAL_BGZF_WALK": "1"}) == plain        # the block table by one thread instead of the team
+    # blocks of very different sizes: the team that builds the block table walks the file in 64 segments, and with 64 KB
+    # blocks next to 1.8 KB ones some segments hold no block start at all; the trace says which walk built the table
+    import struct
+    import zlib
+
+    def stored(ch):                                                  # one BGZF block holding `ch` uncompressed (deflate level 0)
+        co = zlib.compressobj(0, zlib.DEFLATED, -15)
+        comp = co.compress(ch) + co.flush()
+        return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(comp) + 8 - 1)
+                + comp + struct.pack("<II", zlib.crc32(ch), len(ch)))
+    n_big, big = 10, 0xfe00
+    mixed = str(tmp_path / "mixed.vcf.gz")
+    open(mixed, "wb").write(b"".join(stored(data[i * big:(i + 1) * big]) for i in range(n_big)) + _bgzf(data[n_big * big:], 0x700))
+    assert os.path.getsize(mixed) // 64 < big // 2                   # a stored block spans more than two of the 64 segments
+    capfd.readouterr()
+    assert run(mixed, "mixed", {"HPGV_RUN_TRACE": "1"}) == plain
+    err = capfd.readouterr().err
+    assert "stage: walk" in err and "serial walk" not in err
+    assert run(mixed, "mixed_serial", {"HPGV_RUN_TRACE": "1", "HPGV_SERIAL_BGZF_WALK": "1"}) == plain
+    assert "serial walk" in capfd.readouterr().err
     assert run(packed, "patched", {"HPGV_TEST_GPU_INFLATE_REFUSE_EVERY": "3"}) == plain
     assert run(packed, "copied_back", {"HPGV_NO_DEVICE_WINDOWS": "1"}) == plain       # device decoding, whole windows copied back
     assert run(packed, "cpu", {"HPGV_NO_GPU_INFLATE": "1"}) == plain
