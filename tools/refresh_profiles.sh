@@ -23,9 +23,10 @@ for v in 512 1024 2048; do
 done
 python tools/bench_epistasis.py 1024 10000 10 --order=3 --option=epi_triples_1pass=0 > $O/${TAG}_epi3_bench_1024_two_pass.json 2>> $O/${TAG}_epi.err || exit 1
 python tools/bench_file_runner.py 10000 200000 plain,bgzf 64 > $O/${TAG}_file_runner_10k_samples.json 2> $O/${TAG}_fr.err || exit 1
-python tools/bench_file_runner.py 200 2000000 plain 64 > $O/${TAG}_file_runner_200_samples.json 2>> $O/${TAG}_fr.err || exit 1
+python tools/bench_file_runner.py 200 2000000 plain,bgzf 64 > $O/${TAG}_file_runner_200_samples.json 2>> $O/${TAG}_fr.err || exit 1
 python tools/bench_file_runner.py 40000 200000 bgzf 64 > $O/${TAG}_file_runner_40k_samples_bgzf.json 2>> $O/${TAG}_fr.err || exit 1
 HPGV_NO_GPU_INFLATE=1 python tools/bench_file_runner.py 40000 200000 bgzf 64 > $O/${TAG}_file_runner_40k_samples_bgzf_cpu_inflate.json 2>> $O/${TAG}_fr.err || exit 1
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_file_runner -o fr --output-format csv -- python3 tools/bench_file_runner.py 10000 200000 plain,bgzf 64 > $O/${TAG}_file_runner_under_rocprof.json 2>> $O/${TAG}_fr.err || exit 1
 python tools/bench_inflate.py 125000 6 > $O/${TAG}_inflate_gpu_125k_blocks.json 2>> $O/${TAG}_fr.err || exit 1
 python tools/bench_tokenize.py 10000 20000 > $O/${TAG}_tokenizer_10k_samples.json 2>> $O/${TAG}_fr.err || exit 1
 # rocprofv3: kernel trace + stats of the headline command and of the epistasis scan (the program itself after --)
