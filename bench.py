@@ -1,18 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- chi-square association scan throughput on MI355X.
+"""bench.py -- per-variant statistics scan throughput on MI355X.
 
-A "step" is one pass of the hot path (assoc scan kernel + chi-square statistics
-kernel, and for N > 1 the gather of the result blocks to rank 0) over one
-device-resident synthetic cohort shard.  Inputs are generated ON DEVICE before
-the timed region (SURVEY.md 8d generator), so nothing crosses PCIe while timing.
+  python bench.py --gpus N --steps K --warmup W [--workload m|c2|c3|c4|c5|m8|stats] [...]
 
-  python bench.py --gpus N --steps K --warmup W [--workload c2|m8|c4tdt] [...]
+A "step" is one pass of the hot path over one synthetic cohort: scan kernel +
+statistics kernel over every variant of the rank's shard, and for N > 1 the
+gather of the result blocks to rank 0 (RCCL, overlapped with the next scan).
+Inputs are generated ON DEVICE (SURVEY.md 8d generator, bit-identical to the
+oracle's), so nothing crosses PCIe while timing.
 
-N = 1 default workload is BASELINE.json configs[1] ("c2": 1M biallelic SNP x 10k
-case/control): the metric's own 10M x 50k cohort is 500 GB and does not fit one
-GPU.  "m8" is the per-GPU shard of that metric cohort at 8 GPUs (1.25M x 50k,
-62.5 GB); "c5" one 100 GB tile of a GPU's shard of the 40M x 100k cohort.
-Scaling is weak: every rank scans one such shard.
+Default workload "m" is the cohort BASELINE.json's metric is quoted on: 10M SNP
+x 50k samples (500 GB), STRONG-scaled: rank g scans variants [g*10M/N, (g+1)*10M/N).
+A rank's shard is cut into tiles of at most --tile-gb (126 GB: SURVEY 8d row M).
+When the whole shard fits the GPU's free memory (N >= 2 on a 288 GiB part) it is
+resident and the K steps are timed in ONE region, barrier + device sync on both
+sides (the contract).  When it does not fit (N = 1: 500 GB) ONE tile buffer is
+regenerated on the device before each tile's scan, OUTSIDE the timed region: the
+timed region is then the sum of the per-tile segments, each bracketed by a device
+sync (+ barrier), and `config.timed_region` says so.  The other workloads are
+one resident shard per rank (weak scaling): c2 / c3 / c4 / c5 are BASELINE
+configs[1..4]'s single-GPU shapes, m8 the 1/8 shard of the metric cohort, stats
+the vcf-stats counters + Hardy-Weinberg on 1M x 10k.
+
+`python bench.py --gpus N` with no WORLD_SIZE in the environment starts its own N
+ranks: the parent makes no GPU call, spawns one fresh child per rank (RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) and relays rank
+0's JSON line.  Under torch.distributed.run the ranks are used as given.
 
 Prints ONE JSON line on rank 0.
 """
@@ -20,118 +33,183 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (variants per GPU, samples, description)
-    "c2": (1_000_000, 10_000, "assoc --chisq, synthetic 1M biallelic SNP x 10k case/control (BASELINE configs[1])"),
-    "m8": (1_250_000, 50_000, "assoc --chisq, per-GPU shard (1/8) of the 10M SNP x 50k metric cohort"),
-    "c5": (1_000_000, 100_000, "assoc --chisq, one 100 GB tile (1 of 5) of a GPU's shard of the 40M SNP x 100k cohort on 8 GPUs (BASELINE configs[4])"),
-    "smoke": (20_000, 2_000, "assoc --chisq, tiny smoke cohort"),
-    # secondary configs (not the headline metric; run with --workload):
-    "c3": (1_000_000, 10_000, "assoc --fisher on the 1M x 10k cohort (BASELINE configs[2]): scan + Fisher p-pass"),
-    "c4": (2_000_000, 15_000, "tdt, 2M SNP x 5k trios (BASELINE configs[3]): trio scan + TDT statistics"),
+    # name: (kind, variants, samples, scaling, description); strong: `variants` is the whole cohort,
+    # weak: `variants` per GPU
+    "m": ("chisq", 10_000_000, 50_000, "strong",
+          "assoc --chisq, the metric cohort: synthetic 10M biallelic SNP x 50k case/control (BASELINE metric)"),
+    "c2": ("chisq", 1_000_000, 10_000, "weak", "assoc --chisq, synthetic 1M biallelic SNP x 10k case/control (BASELINE configs[1])"),
+    "c3": ("fisher", 1_000_000, 10_000, "weak", "assoc --fisher on the 1M x 10k cohort (BASELINE configs[2]): scan + Fisher p-pass"),
+    "c4": ("tdt", 2_000_000, 15_000, "weak", "tdt, 2M SNP x 5k trios (BASELINE configs[3]): trio scan + TDT statistics"),
+    "c5": ("chisq", 1_000_000, 100_000, "weak",
+           "assoc --chisq, one 100 GB tile (1 of 5) of a GPU's shard of the 40M SNP x 100k cohort on 8 GPUs (BASELINE configs[4])"),
+    "m8": ("chisq", 1_250_000, 50_000, "weak", "assoc --chisq, per-GPU shard (1/8) of the 10M SNP x 50k metric cohort"),
+    "stats": ("stats", 1_000_000, 10_000, "weak",
+              "vcf stats: genotype / allele / missing counters + Hardy-Weinberg on 1M SNP x 10k samples (get_variants_stats)"),
+    "smoke": ("chisq", 20_000, 2_000, "weak", "assoc --chisq, tiny smoke cohort"),
 }
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# FP64 / 64-bit vector issue peak used for the Fisher p-pass: 256 CUs x 4 SIMDs x 2.4 GHz, one wave64
+# instruction per 4 cycles per SIMD (FP64 FMA rate = 78.6 TFLOP/s spec = 16 lanes/clk/SIMD)
+VALU64_PEAK_GINST = 256 * 4 * 2.4 / 4.0
+METRIC = {"chisq": "variants/s chi2 assoc", "fisher": "variants/s fisher assoc", "tdt": "variants/s tdt",
+          "stats": "variants/s vcf stats"}
+# (bytes of integer tallies at the front of a result block, bytes of a result record = SURVEY 8d payload)
+RESULT = {"chisq": (16, 40), "fisher": (16, 32), "tdt": (8, 32), "stats": (32, 48)}
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--variants", type=int, default=0, help="override variants per GPU")
+    ap.add_argument("--workload", default="m", choices=sorted(WORKLOADS))
+    ap.add_argument("--variants", type=int, default=0, help="override the workload's variant count")
     ap.add_argument("--samples", type=int, default=0, help="override samples")
-    ap.add_argument("--gather-chunks", type=int, default=1,
-                    help="N>1: the shard is scanned in this many variant blocks, each followed by its own "
-                         "asynchronous result gather; with the default 1 the whole step's gather overlaps "
-                         "the next step's scan (result blocks are double-buffered)")
+    ap.add_argument("--tile-gb", type=float, default=126.0, help="largest genotype tile kept in one buffer (GB)")
+    ap.add_argument("--resident", choices=["auto", "no"], default="auto",
+                    help="no: regenerate every tile before its scan even when the shard would fit (rehearses the N = 1 path)")
     ap.add_argument("--event-every", type=int, default=4,
-                    help="bracket the scan kernel with HIP events on every n-th timed step (an event pair costs "
-                         "tens of microseconds of queue bubbles, so not every step carries one)")
+                    help="bracket the scan kernel with HIP events on every n-th timed launch (an event pair costs "
+                         "tens of microseconds of queue bubbles, so not every launch carries one)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1; gloo is a rehearsal mode (blocks are staged through host "
                          "memory and several ranks may share one GPU), never a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target wall time of each CPU baseline leg")
     ap.add_argument("--option", action="append", default=[], help="engine option key=value")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def pmc_traffic(workload, variants, samples, pitch, kernel):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/*_pmc_traffic_<workload>.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    in separate runs, gfx950 correction applied).  None when no matching profile."""
+# ---------------------------------------------------------------------------------------------------------
+# parent: start one fresh process per rank (no GPU call is made here)
+# ---------------------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    n = args.gpus
+    if args.backend == "nccl":
+        import torch                                    # device_count() reads the driver's list; it does not initialise a GPU
+        have = torch.cuda.device_count()
+        if have < n:
+            print("bench.py: --gpus %d but this machine shows %d GPU(s); one rank per GPU over RCCL needs %d "
+                  "(rehearse with --backend gloo, which lets ranks share a GPU)" % (n, have, n), file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = subprocess.PIPE if r == 0 else sys.stderr       # only rank 0 prints the JSON line
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    import threading
+    lines = []
+    reader = threading.Thread(target=lambda: lines.append(procs[0].stdout.read().decode()), daemon=True)
+    reader.start()
+    rc = 0
+    live = list(procs)
+    while live:                                         # a rank that dies takes the job down: the others would wait for it
+        time.sleep(0.2)
+        for p in list(live):
+            if p.poll() is not None:
+                live.remove(p)
+                if p.returncode and not rc:
+                    rc = p.returncode
+                    for q in live:
+                        q.terminate()                   # exactly the children started above
+    reader.join(timeout=10.0)
+    sys.stdout.write("".join(lines))
+    sys.stdout.flush()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------
+# helpers of a rank
+# ---------------------------------------------------------------------------------------------------------
+def pmc_profile(workload, kernel, variants, samples, pitch):
+    """Per-launch figures of `kernel` from the committed PMC passes (profiles/*_pmc_*_<workload>.json:
+    rocprofv3 --pmc in separate runs, gfx950 corrections applied).  Returns the kernel's dict or None."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_%s.json" % workload))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_*_%s.json" % workload))):
         try:
             d = json.load(open(f))
-            if d["variants"] == variants and d["samples"] == samples and d["row_pitch_bytes"] == pitch:
+            if d["samples"] == samples and d["row_pitch_bytes"] == pitch:
                 for k, v in d["kernels"].items():
-                    if kernel.startswith(k):
-                        best = v["hbm_bytes_per_launch"]
+                    if kernel.startswith(k) and (v.get("variants_per_launch", d.get("variants")) == variants or "valu_insts_per_variant" in v):
+                        best = dict(best or {}, **v)
         except Exception:
             pass
     return best
 
 
-def cpu_baseline(n_samples, cond, target_s):
-    """Oracle (oracle/hpgv_oracle.c) timed on the host cores of this box: the
-    reference's worker structure (OpenMP workers pulling 200-variant batches),
-    text-faithful scan = per genotype strdup + parse + free as assoc.c:50-57."""
+def bounded_rate(run, pilot, target_s, cap):
+    """Times run(n) on a pilot, then on a sample sized for about target_s seconds; returns (rate, n, seconds, threads)."""
+    sec, used = run(pilot)
+    n = int(min(max(pilot / max(sec, 1e-9) * target_s, pilot), cap))
+    n = max(200, (n // 200) * 200)
+    sec, used = run(n)
+    return n / sec, n, sec, used
+
+
+def cpu_baseline(kind, n_samples, cond, fam, lf_table, target_s):
+    """Oracle (oracle/hpgv_oracle.c) timed on the host cores of this box: the reference's worker structure
+    (OpenMP workers pulling 200-variant batches, hpg-variant.conf:33), text-faithful = per genotype strdup +
+    parse + free as assoc.c:50-57 / tdt.c:97-108,150-157 do."""
     from oracle import pyoracle as orc
+    import numpy as np
     cores = orc.effective_cpus()                        # affinity mask capped by the cgroup CPU quota
-    # pilot to size the bounded sample
     pilot = 200 * cores
-    sec, used = orc.baseline_assoc_text(0, pilot, n_samples, cond, cores)
-    rate = pilot / max(sec, 1e-9)
-    n_text = int(min(max(rate * target_s, pilot), 5_000_000))
-    n_text = max(200, (n_text // 200) * 200)
-    sec, used = orc.baseline_assoc_text(0, n_text, n_samples, cond, cores)
-    text_rate = n_text / sec
-    # packed leg: same int8 matrix in host RAM
-    n_packed = int(min(4_000_000_000 // max(n_samples, 1), 400_000))
-    gt = orc.synth_matrix(0, n_packed, n_samples, n_samples)
-    reps, psec = 0, 0.0
-    while psec < target_s / 2 and reps < 50:
-        s, _ = orc.baseline_assoc_packed(gt, n_samples, cond, cores)
-        psec += s
-        reps += 1
-    packed_rate = n_packed * reps / psec
-    return {
-        "value": text_rate, "unit": "variants/s", "cores": used, "kind": "port",
-        "sample": "text-faithful scan (strdup+parse+free per genotype, assoc.c:50-57) of %d synthetic variants x %d samples, "
-                  "OpenMP workers on 200-variant batches, %.1f s" % (n_text, n_samples, sec),
-        "packed_value": packed_rate,
-        "packed_sample": "same loop on the packed int8 matrix in host RAM: %d variants x %d passes, %.1f s" % (n_packed, reps, psec),
-    }
+    if kind == "chisq":
+        run, what = (lambda n: orc.baseline_assoc_text(0, n, n_samples, cond, cores)), "assoc.c:50-57 scan + chi-square"
+    elif kind == "fisher":
+        run, what = (lambda n: orc.baseline_fisher_text(0, n, n_samples, cond, lf_table, cores)), \
+            "assoc.c:50-57 scan + Fisher's exact test on the ln(i!) table (assoc.c:69-75)"
+    elif kind == "tdt":
+        run, what = (lambda n: orc.baseline_tdt_text(0, n, n_samples, *fam, cores)), \
+            "tdt.c:41-271 family loop (sample_ids look-ups resolved once, not per variant)"
+    else:
+        run, what = (lambda n: orc.baseline_stats_text(0, n, n_samples, cores)), \
+            "get_variants_stats counters + Hardy-Weinberg per variant (definition of this repo: hpg-libs is absent)"
+    rate, n, sec, used = bounded_rate(run, pilot, target_s, 5_000_000)
+    out = {"value": rate, "unit": "variants/s", "cores": used, "kind": "port",
+           "sample": "text-faithful %s, strdup+parse+free per genotype, of %d synthetic variants x %d samples, "
+                     "OpenMP workers on 200-variant batches, %.1f s" % (what, n, n_samples, sec)}
+    if kind == "chisq":                                 # packed leg: same int8 matrix in host RAM
+        n_packed = int(min(4_000_000_000 // max(n_samples, 1), 400_000))
+        gt = orc.synth_matrix(0, n_packed, n_samples, n_samples)
+        reps, psec = 0, 0.0
+        while psec < target_s / 2 and reps < 50:
+            s, _ = orc.baseline_assoc_packed(gt, n_samples, cond, cores)
+            psec += s
+            reps += 1
+        out["packed_value"] = n_packed * reps / psec
+        out["packed_sample"] = "same loop on the packed int8 matrix in host RAM: %d variants x %d passes, %.1f s" % (n_packed, reps, psec)
+    return out
 
 
-def main():
-    args = parse_args()
+def worker(args):
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(args.gpus, 1):
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+    if world != max(args.gpus, 1) and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; running with %d rank(s)" % (args.gpus, world, world), file=sys.stderr)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; this engine has no CPU path", file=sys.stderr)
-        sys.exit(2)
+        return 2
     dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -143,104 +221,138 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     hpgv = importlib.import_module("hpg-variant_amd")
-    from importlib import import_module
-    sharding = import_module("hpg-variant_amd.sharding")
+    sharding = importlib.import_module("hpg-variant_amd.sharding")
 
-    V, N, desc = WORKLOADS[args.workload]
+    kind, V_all, N, scaling, desc = WORKLOADS[args.workload]
     if args.variants:
-        V = args.variants
+        V_all = args.variants
     if args.samples:
         N = args.samples
+    if scaling == "strong":
+        v_lo, v_hi = sharding.variant_range(rank, world, V_all)     # rank g scans [g*V/G, (g+1)*V/G)
+        total_per_step = V_all
+    else:
+        v_lo, v_hi = rank * V_all, (rank + 1) * V_all               # one shard per rank
+        total_per_step = V_all * world
+    V = v_hi - v_lo
+    V_max = max(sharding.variant_range(r, world, V_all)[1] - sharding.variant_range(r, world, V_all)[0]
+                for r in range(world)) if scaling == "strong" else V
 
     eng = hpgv.Engine(dev_index)
     for kv in args.option:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
-    kind = {"c3": "fisher", "c4": "tdt"}.get(args.workload, "chisq")
     cond = (np.arange(N) % 2).astype(np.uint8)          # odd samples are cases
-    fam = None
+    fam, lf_table = None, None
     if kind == "tdt":
         n_tr = N // 3                                   # trio k = columns (3k, 3k+1, 3k+2), child sex alternating
         kk = np.arange(n_tr)
         fam = (3 * kk, 3 * kk + 1, np.arange(n_tr + 1), 3 * kk + 2, (kk % 2).astype(np.uint8))
         nA, nU, pitch = eng.set_families(3 * n_tr, *fam)      # (fast trios, slow families, pitch)
-        which, res_bytes, payload, scan_name = hpgv.LAYOUT_TDT, 32, 32, "k_tdt_scan"
+        which, scan_name, stats_name = hpgv.LAYOUT_TDT, "k_tdt_scan", "k_tdt_stats"
+    elif kind == "stats":
+        pitch = eng.set_stats_cohort(N)
+        nA, nU = N, 0
+        which, scan_name, stats_name = hpgv.LAYOUT_STATS, "k_stats_scan_hs", "k_stats_hwe"
     else:
         nA, nU, pitch = eng.set_cohort(cond)
         which = hpgv.LAYOUT_ASSOC
         scan_name = "k_assoc_scan" if "pipeline=0" in args.option else "k_assoc_scan_pipe"
-        res_bytes, payload = (40, 40) if kind == "chisq" else (32, 32)
+        stats_name = "k_assoc_chisq" if kind == "chisq" else "k_assoc_fisher"
         if kind == "fisher":
             # ln(i!) table with num_samples * 10 entries, as assoc_runner.c:164-166 builds it (an INPUT of the pass)
             lf_table = np.concatenate([[0.0], np.cumsum(np.log(np.arange(1, N * 10, dtype=np.float64)))])
             eng.set_logfact(lf_table)
-    head = 16 if kind != "tdt" else 8                   # integer tallies at the front of a result block
+    head, res_bytes = RESULT[kind]
+
+    # ---- tiles of the shard -------------------------------------------------------------------------------
+    tile_cap = max(1, int(args.tile_gb * 1e9) // pitch)              # variants per tile buffer
+    n_tiles = max(1, -(-V_max // tile_cap))
+    per_tile = -(-V_max // n_tiles)
+    tiles = [(lo, min(lo + per_tile, V)) for lo in range(0, max(V, 1), per_tile) if lo < V or lo == 0]
+    while len(tiles) < n_tiles:
+        tiles.append((V, V))                                         # ragged shards: every rank walks the same tile count
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    res_need = 2 * res_bytes * per_tile * n_tiles * (1 + (world if rank == 0 and world > 1 else 0))
+    resident = args.resident == "auto" and (V * pitch + res_need + (6 << 30) <= free_b)
+    if world > 1:                                                    # every rank takes the same path
+        flag = torch.tensor([1 if resident else 0], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        resident = bool(flag.item())
+    n_bufs = n_tiles if resident else 1
 
     # device memory owned by torch (plumbing); raw pointers cross the C ABI
-    gt = torch.empty(V * pitch, dtype=torch.uint8, device=dev)
-    res = torch.empty(res_bytes * V, dtype=torch.uint8, device=dev)
+    gt = [torch.empty(max(per_tile, 1) * pitch, dtype=torch.uint8, device=dev) for _ in range(n_bufs)]
     stream = torch.cuda.current_stream()
     sp = stream.cuda_stream
-    v0 = rank * V                                       # global variant ids of this shard
-    eng.synth(which, v0, V, gt.data_ptr(), sp)
+
+    def generate(ti, buf):
+        lo, hi = tiles[ti]
+        if hi > lo:
+            eng.synth(which, v_lo + lo, hi - lo, buf.data_ptr(), sp)
+
+    if resident:
+        for ti in range(n_tiles):
+            generate(ti, gt[ti])
     torch.cuda.synchronize()
 
-    chunks = max(1, args.gather_chunks) if world > 1 else 1
-    bounds = [sharding.variant_range(c, chunks, V) for c in range(chunks)]
-    # a block's result = tallies[n] | f64 arrays[n] ...: each block lives in its own tensor, so the
-    # gather of block i (overlapping the scan of block i+1) needs no repacking
-    # two generations of result blocks: the gathers of step k are only waited for at the end of step k+1
-    # (they overlap that step's scans), so the blocks of step k+1 must not reuse step k's buffers
+    # result blocks: tallies[n] | f64 arrays[n] ..., one block per tile and generation.  Two generations for
+    # N > 1: the gathers of step k are only waited for at the end of step k+1 (they overlap its scans).
     gens = 1 if world == 1 else 2
     comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
-    chunk_res = [[res] if world == 1 else [torch.empty(res_bytes * (hi - lo), dtype=torch.uint8, device=dev) for lo, hi in bounds]
-                 for _ in range(gens)]
+    blocks = [[torch.empty(res_bytes * max(hi - lo, 1), dtype=torch.uint8, device=dev) for lo, hi in tiles] for _ in range(gens)]
+    # sizes of every rank's block of tile ti (known to all ranks: they follow from variant_range)
+    def tile_sizes(ti):
+        out = []
+        for r in range(world):
+            if scaling == "strong":
+                a, b = sharding.variant_range(r, world, V_all)
+                vr = b - a
+            else:
+                vr = V_all
+            lo = min(ti * per_tile, vr)
+            out.append(res_bytes * (min(lo + per_tile, vr) - lo))
+        return out
+
     recv = None
     if world > 1 and rank == 0:
-        recv = [[[torch.empty(res_bytes * (hi - lo), dtype=torch.uint8, device=comm_dev) for _ in range(world)]
-                 for lo, hi in bounds] for _ in range(gens)]
-    pending = []                                       # works of the previous step
+        recv = [[[torch.empty(max(max(tile_sizes(ti)), 1), dtype=torch.uint8, device=comm_dev) for _ in range(world)]
+                 for ti in range(n_tiles)] for _ in range(gens)]
+    pending = []                                        # gather works of the previous step
 
-    def scan_block(lo, n, b):
-        g = gt.data_ptr() + lo * pitch
-        if kind == "tdt":
-            eng.tdt_scan(g, n, b, None, sp)
-        else:
-            eng.assoc_scan(g, n, b, None, sp)
-
-    def stats_block(n, b):
-        if kind == "chisq":
-            eng.assoc_chisq(b, n, b + 16 * n, b + 24 * n, b + 32 * n, sp)
-        elif kind == "fisher":
-            eng.assoc_fisher(b, n, b + 16 * n, b + 24 * n, sp)
-        else:
-            eng.tdt_stats(b, n, b + 8 * n, b + 16 * n, b + 24 * n, sp)
-
-    step_no = [0]
-
-    def step(ev=None):
-        g = step_no[0] % gens
-        step_no[0] += 1
-        works = []
-        for c, (lo, hi) in enumerate(bounds):
-            n = hi - lo
-            blk = chunk_res[g][c]
-            b = blk.data_ptr()
-            if ev and c == 0:
+    def run_tile(ti, g, buf, ev=None):
+        lo, hi = tiles[ti]
+        n = hi - lo
+        blk = blocks[g][ti]
+        b = blk.data_ptr()
+        if n > 0:
+            if ev:
                 ev[0].record(stream)
-            scan_block(lo, n, b)
-            if ev and c == 0:
+            if kind == "tdt":
+                eng.tdt_scan(buf.data_ptr(), n, b, None, sp)
+            elif kind == "stats":
+                eng.stats_scan(buf.data_ptr(), n, b, sp)
+            else:
+                eng.assoc_scan(buf.data_ptr(), n, b, None, sp)
+            if ev:
                 ev[1].record(stream)
-            stats_block(n, b)
-            if world > 1:
-                send = blk if args.backend == "nccl" else blk.cpu()      # gloo rehearsal: through host memory
-                _, w = sharding.gather_blocks(send, [res_bytes * n] * world, dst=0, async_op=True,
-                                              out_bufs=recv[g][c] if recv else None)
-                works.append(w)
-        # the previous step's gathers have had this whole step to finish
-        for w in pending:
-            w.wait()
-        pending[:] = works
+                ev[2].record(stream)
+            if kind == "chisq":
+                eng.assoc_chisq(b, n, b + 16 * n, b + 24 * n, b + 32 * n, sp)
+            elif kind == "fisher":
+                eng.assoc_fisher(b, n, b + 16 * n, b + 24 * n, sp)
+            elif kind == "tdt":
+                eng.tdt_stats(b, n, b + 8 * n, b + 16 * n, b + 24 * n, sp)
+            else:
+                eng.stats_hwe(b, n, b + 32 * n, b + 40 * n, sp)
+            if ev:
+                ev[3].record(stream)
+        if world > 1:
+            sizes = tile_sizes(ti)
+            send = blk[: res_bytes * n] if args.backend == "nccl" else blk[: res_bytes * n].cpu()   # gloo rehearsal: via host
+            _, w = sharding.gather_blocks(send, sizes, dst=0, async_op=True, out_bufs=recv[g][ti] if recv else None)
+            return [w]
+        return []
 
     def drain():
         for w in pending:
@@ -254,33 +366,71 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
     every = max(1, args.event_every)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range((args.steps + every - 1) // every)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(evs[k // every] if k % every == 0 else None)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    evs = []
+    launch_no = [0]
+
+    def maybe_events(timed):
+        if not timed:
+            return None
+        launch_no[0] += 1
+        if (launch_no[0] - 1) % every:
+            return None
+        e = tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))
+        evs.append(e)
+        return e
+
+    step_no = [0]
+    elapsed = 0.0
+    if resident:
+        def step(timed):
+            g = step_no[0] % gens
+            step_no[0] += 1
+            works = []
+            for ti in range(n_tiles):
+                works += run_tile(ti, g, gt[ti], maybe_events(timed))
+            for w in pending:                           # the previous step's gathers have had this whole step to finish
+                w.wait()
+            pending[:] = works
+        for _ in range(args.warmup):
+            step(False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    else:
+        for k in range(args.warmup + args.steps):
+            timed = k >= args.warmup
+            g = step_no[0] % gens
+            step_no[0] += 1
+            for ti in range(n_tiles):
+                generate(ti, gt[0])                     # outside the timed region: the tile is resident when its segment starts
+                barrier()
+                t0 = time.perf_counter()
+                pending[:] = run_tile(ti, g, gt[0], maybe_events(timed))
+                barrier()
+                if timed:
+                    elapsed += time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    scan_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    scan_variants = bounds[0][1] - bounds[0][0]
-    bytes_per_variant = N + payload                     # N x 1 B + result payload
+    scan_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs])) if evs else float("nan")
+    stats_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs])) if evs else float("nan")
+    scan_variants = tiles[0][1] - tiles[0][0]
+    bytes_per_variant = N + res_bytes                   # N x 1 B + result payload
     achieved = scan_variants * bytes_per_variant / (scan_ms * 1e-3) / 1e9
 
     # ---- measured streaming-read ceiling of the same buffer (report both fractions) -----------
     probe_gbps = None
     if rank == 0 and world == 1:
         try:
-            probe_ms = eng.read_probe(gt.data_ptr(), V * pitch, 5)
-            probe_gbps = V * pitch / (probe_ms * 1e-3) / 1e9
+            nb = scan_variants * pitch
+            probe_ms = eng.read_probe(gt[0].data_ptr(), nb, 5)
+            probe_gbps = nb / (probe_ms * 1e-3) / 1e9
         except Exception:
             probe_gbps = None
 
@@ -289,32 +439,47 @@ def main():
     parity_failed = False
     if rank == 0:
         from oracle import pyoracle as orc
-        n0 = bounds[0][1] - bounds[0][0]
         g_last = (step_no[0] - 1) % gens
-        # blocks to check: this rank's first block and, for N > 1, the first block GATHERED from the last rank
-        sources = [(chunk_res[g_last][0], v0)]
+        # blocks to check: this rank's first and last tile and, for N > 1, the last tile GATHERED from the last rank
+        sources = [(blocks[g_last][0], v_lo + tiles[0][0], tiles[0][1] - tiles[0][0])]
+        if n_tiles > 1 and tiles[-1][1] > tiles[-1][0]:
+            sources.append((blocks[g_last][-1], v_lo + tiles[-1][0], tiles[-1][1] - tiles[-1][0]))
         if world > 1:
-            sources.append((recv[g_last][0][world - 1], (world - 1) * V))
-        idx = np.unique(np.concatenate([np.arange(min(256, n0)), np.arange(0, n0, 1000), np.arange(max(0, n0 - 256), n0)]))
-        if kind == "fisher":
-            idx = idx[:: max(1, len(idx) // 400)]
-        ok = True
+            r = world - 1
+            r_lo = sharding.variant_range(r, world, V_all)[0] if scaling == "strong" else r * V_all
+            nb = tile_sizes(n_tiles - 1)[r] // res_bytes
+            if nb > 0:
+                sources.append((recv[g_last][n_tiles - 1][r], r_lo + (n_tiles - 1) * per_tile, nb))
+        ok, checked = True, 0
 
         def same(got, exp):
             with np.errstate(invalid="ignore"):
                 return bool(np.all((np.abs(got - exp) <= 1e-10 * np.maximum(1, np.abs(exp))) | (np.isnan(got) & np.isnan(exp))))
         ncol = N if kind != "tdt" else 3 * (N // 3)
-        for blk, vbase in sources:
+        for blk, vbase, n0 in sources:
+            idx = np.unique(np.concatenate([np.arange(min(256, n0)), np.arange(0, n0, 1000), np.arange(max(0, n0 - 256), n0)]))
+            if len(sources) > 1 or N > 20_000:
+                idx = idx[:: max(1, len(idx) // 600)]
+            if kind in ("fisher", "stats"):
+                idx = idx[:: max(1, len(idx) // 400)]
+            checked += len(idx)
             ints = blk[: head * n0].view(torch.int32).view(n0, head // 4).cpu().numpy()
-            stats = blk[head * n0:].view(torch.float64).view(-1, n0).cpu().numpy()
-            for lo in range(0, len(idx), 512):
-                sel = idx[lo: lo + 512]
+            stats = blk[head * n0: res_bytes * n0].view(torch.float64).view(-1, n0).cpu().numpy()
+            for lo in range(0, len(idx), 256):
+                sel = idx[lo: lo + 256]
                 rows = np.stack([orc.synth_matrix(vbase + int(v), 1, ncol, ncol)[0] for v in sel])
                 if kind == "tdt":
                     t1, t2 = orc.tdt_counts(rows, *fam)
                     ok &= bool(np.array_equal(ints[sel], np.stack([t1, t2], 1)))
                     exp = orc.tdt_stats(t1, t2)
                     ok &= all(same(stats[j][sel], exp[j]) for j in range(3))
+                elif kind == "stats":
+                    for j, v in enumerate(sel):
+                        vs = orc.variant_stats(rows[j], 2)
+                        exp8 = list(vs.genotypes_count)[:4] + [vs.missing_genotypes, vs.missing_alleles,
+                                                               vs.alleles_count[0], vs.alleles_count[1]]
+                        ok &= list(ints[v]) == exp8
+                        ok &= same(stats[0][v: v + 1], np.array([vs.hw_chi2])) and same(stats[1][v: v + 1], np.array([vs.hw_p]))
                 else:
                     A1, A2, U1, U2 = orc.assoc_counts(rows, cond)
                     ok &= bool(np.array_equal(ints[sel], np.stack([A1, A2, U1, U2], 1)))
@@ -324,39 +489,62 @@ def main():
                     else:
                         odds, _, p = orc.assoc_stats(orc.TASK_FISHER, A1, A2, U1, U2, lf_table)
                         ok &= same(stats[0][sel], odds) and same(stats[1][sel], p)
-        parity = {"checked_variants": int(len(idx)) * len(sources), "blocks": len(sources), "ok": bool(ok)}
+        parity = {"checked_variants": int(checked), "blocks": len(sources), "ok": bool(ok)}
 
     if rank == 0:
-        total_variants = V * world * args.steps
+        total_variants = total_per_step * args.steps
+        par = "variant-sharded x%d (%s scaling)" % (world, scaling)
+        if world > 1:
+            par += ", result blocks gathered to rank 0 (%s), each step's gather overlapped with the next step's scan" % args.backend
+        config = {"workload": "%s: %s" % (args.workload, desc), "variants": total_per_step, "variants_per_gpu": V, "samples": N,
+                  ("affected" if kind in ("chisq", "fisher") else "trios" if kind == "tdt" else "columns"): nA,
+                  ("unaffected" if kind in ("chisq", "fisher") else "multi_child_families" if kind == "tdt" else "groups"): nU,
+                  "row_pitch_bytes": pitch, "tiles_per_gpu": n_tiles, "variants_per_tile": per_tile,
+                  "resident": bool(resident), "hbm_total_GB": round(total_b / 1e9, 1),
+                  "timed_region": ("one region over all steps, barrier + device sync on both sides" if resident else
+                                   "sum over steps and tiles of [scan + statistics%s of one tile], each segment between device syncs%s; "
+                                   "the tile buffer (%.1f GB) is regenerated on the device before its segment, outside the timed region"
+                                   % (" + gather" if world > 1 else "", " and barriers" if world > 1 else "", per_tile * pitch / 1e9)),
+                  "parallelism": par}
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "kernel": scan_name, "kernel_ms": scan_ms, "kernel_samples": len(evs),
+                "stream_read_probe_GBps": probe_gbps,
+                "frac_of_probe": (achieved / probe_gbps) if probe_gbps else None,
+                "algorithmic_bytes_per_variant": bytes_per_variant,
+                "variants_per_launch": scan_variants}
+        prof = pmc_profile(args.workload, scan_name, scan_variants, N, pitch) if world == 1 else None
+        if prof and "hbm_bytes_per_launch" in prof:
+            roof["traffic"] = prof["hbm_bytes_per_launch"]
         out = {
-            "metric": {"chisq": "variants/s chi2 assoc", "fisher": "variants/s fisher assoc", "tdt": "variants/s tdt"}[kind],
-            "value": total_variants / elapsed,
-            "unit": "variants/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
+            "metric": METRIC[kind], "value": total_variants / elapsed, "unit": "variants/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": "u8",
             "data": "synthetic (on-device splitmix64 cohort, HWE genotypes, 1% missing, odd samples are cases)",
-            "config": {"workload": "%s: %s" % (args.workload, desc), "variants_per_gpu": V, "samples": N,
-                       ("affected" if kind != "tdt" else "trios"): nA, ("unaffected" if kind != "tdt" else "multi_child_families"): nU,
-                       "row_pitch_bytes": pitch,
-                       "parallelism": "variant-sharded x%d%s" % (world, ", result gather to rank 0 (%s) in %d blocks overlapped with the scans" % (args.backend, chunks) if world > 1 else "")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": pmc_traffic(args.workload, scan_variants, N, pitch, scan_name) if world == 1 else None,
-                         "kernel": scan_name, "kernel_ms": scan_ms, "kernel_samples": len(evs),
-                         "stream_read_probe_GBps": probe_gbps,
-                         "frac_of_probe": (achieved / probe_gbps) if probe_gbps else None,
-                         "algorithmic_bytes_per_variant": bytes_per_variant,
-                         "variants_per_launch": scan_variants},
-            "parity": parity,
+            "config": config,
         }
-        if world == 1 and not args.no_cpu_baseline and kind == "chisq":
-            out["cpu_baseline"] = cpu_baseline(N, cond, args.cpu_seconds)
+        if world > 1:
+            out["rccl_ranks"] = dist.get_world_size() if args.backend == "nccl" else 0
+        if kind == "fisher":
+            # the p-pass dominates this workload and is bound by FP64 / 64-bit vector issue, not by HBM: instructions per
+            # variant come from the committed PMC pass (tools/fisher_prof.sh), the duration from this run's HIP events
+            fprof = pmc_profile(args.workload, "k_assoc_fisher", scan_variants, N, pitch) or {}
+            ipv = fprof.get("valu_insts_per_variant")
+            ginst = (ipv * scan_variants / (stats_ms * 1e-3) / 1e9) if ipv else None
+            out["roofline"] = {"bound": "valu", "achieved": ginst, "peak": VALU64_PEAK_GINST, "unit": "Ginst/s",
+                               "frac": (ginst / VALU64_PEAK_GINST) if ginst else None, "traffic": fprof.get("hbm_bytes_per_launch"),
+                               "kernel": "k_assoc_fisher", "kernel_ms": stats_ms, "kernel_samples": len(evs),
+                               "valu_insts_per_variant": ipv, "variants_per_launch": scan_variants,
+                               "peak_note": "wave64 FP64 / 64-bit vector instructions: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles"}
+            out["roofline_scan"] = roof
+        else:
+            out["roofline"] = roof
+            out["roofline"]["stats_kernel"] = stats_name
+            out["roofline"]["stats_kernel_ms"] = stats_ms
+        out["parity"] = parity
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(kind, N if kind != "tdt" else 3 * (N // 3), cond, fam, lf_table, args.cpu_seconds)
         print(json.dumps(out))
         sys.stdout.flush()
         if parity is not None and not parity["ok"]:
@@ -367,8 +555,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
-    if parity_failed:
-        sys.exit(3)
+    return 3 if parity_failed else 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    sys.exit(worker(args))
 
 
 if __name__ == "__main__":

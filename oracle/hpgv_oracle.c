@@ -596,9 +596,28 @@ double orc_baseline_assoc_packed(const uint8_t *gt, size_t pitch, int n_variants
 
 /* Text-faithful: every batch is first rendered to "a/b" sample strings (not
  * timed), then scanned exactly as assoc.c:45-57 does (strdup + parse + free
- * per genotype).  Only the scan + statistics are timed. */
-double orc_baseline_assoc_text(uint64_t v0, int n_variants, int n_samples,
-                               const uint8_t *condition, int n_threads, int *threads_used) {
+ * per genotype).  Only the scan + statistics are timed.  task selects the
+ * statistic of assoc.c:59-76 (chi-square, or Fisher on the caller's table). */
+static void render_batch(uint64_t v0, int start, int n, int n_samples, char *pool, const char **samples,
+                         const char **formats) {
+    for (int i = 0; i < n; i++) {
+        uint32_t thr[3];
+        uint64_t v = v0 + (uint64_t)(start + i);
+        orc_synth_thresholds(v, thr);
+        formats[i] = "GT";
+        for (int s = 0; s < n_samples; s++) {
+            uint8_t g = orc_synth_genotype(v, (uint64_t)s, thr);
+            char *dst = pool + ((size_t)i * n_samples + s) * 4;
+            if (g == 0xFF) { dst[0] = '.'; dst[2] = '.'; }
+            else { dst[0] = (char)('0' + (g >> 4)); dst[2] = (char)('0' + (g & 0xF)); }
+            dst[1] = '/'; dst[3] = 0;
+            samples[(size_t)i * n_samples + s] = dst;
+        }
+    }
+}
+
+double orc_baseline_assoc_text_task(uint64_t v0, int n_variants, int n_samples, const uint8_t *condition,
+                                    int task, const double *logfact, int n_threads, int *threads_used) {
     const int B = 200;
     int n_batches = (n_variants + B - 1) / B;
     int used = 1;
@@ -621,23 +640,10 @@ double orc_baseline_assoc_text(uint64_t v0, int n_variants, int n_samples,
         #pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < n_batches; b++) {
             int start = b * B, n = (start + B <= n_variants) ? B : n_variants - start;
-            for (int i = 0; i < n; i++) {
-                uint32_t thr[3];
-                uint64_t v = v0 + (uint64_t)(start + i);
-                orc_synth_thresholds(v, thr);
-                formats[i] = "GT";
-                for (int s = 0; s < n_samples; s++) {
-                    uint8_t g = orc_synth_genotype(v, (uint64_t)s, thr);
-                    char *dst = pool + ((size_t)i * n_samples + s) * 4;
-                    if (g == 0xFF) { dst[0] = '.'; dst[2] = '.'; }
-                    else { dst[0] = (char)('0' + (g >> 4)); dst[2] = (char)('0' + (g & 0xF)); }
-                    dst[1] = '/'; dst[3] = 0;
-                    samples[(size_t)i * n_samples + s] = dst;
-                }
-            }
+            render_batch(v0, start, n, n_samples, pool, samples, formats);
             double t0 = now_s();
             orc_assoc_text(samples, n, n_samples, formats, condition, NULL, A1, A2, U1, U2);
-            orc_assoc_stats(ORC_TASK_CHISQ, n, A1, A2, U1, U2, NULL, od, ch, pv);
+            orc_assoc_stats(task, n, A1, A2, U1, U2, logfact, od, ch, pv);
             mine += now_s() - t0;
             for (int i = 0; i < n; i++) local += pv[i];
         }
@@ -648,6 +654,159 @@ double orc_baseline_assoc_text(uint64_t v0, int n_variants, int n_samples,
     if (threads_used) *threads_used = used;
     (void)sink;
     return total;   /* max over workers of their scan time = parallel wall time of the scan */
+}
+
+double orc_baseline_assoc_text(uint64_t v0, int n_variants, int n_samples,
+                               const uint8_t *condition, int n_threads, int *threads_used) {
+    return orc_baseline_assoc_text_task(v0, n_variants, n_samples, condition, ORC_TASK_CHISQ, NULL, n_threads, threads_used);
+}
+
+/* tdt.c:41-271 on sample strings: per family strdup + get_alleles of both parents (tdt.c:97-108), per counted
+ * child strdup + get_alleles (tdt.c:150-157) and a strndup of the chromosome for check_mendel (tdt.c:160).  The
+ * sample_ids hash lookups of tdt.c:83-95,146-148 are NOT repeated per variant here (columns come resolved):
+ * the port is on the fast side of the reference. */
+void orc_tdt_text(const char *const *samples, int n_variants, int n_samples, const char *const *formats,
+                  const uint8_t *chrom_is_x, int n_families, const int32_t *father_col, const int32_t *mother_col,
+                  const int32_t *child_off, const int32_t *child_col, const uint8_t *child_sex,
+                  int32_t *t1_out, int32_t *t2_out) {
+    for (int v = 0; v < n_variants; v++) {
+        const char *const *row = samples + (size_t)v * n_samples;
+        char *format = strdup(formats[v]);                               /* tdt.c:46-48 */
+        int gt_position = orc_get_field_position_in_format("GT", format);
+        free(format);
+        const char *chrom = (chrom_is_x && chrom_is_x[v]) ? "X" : "1";
+        int t1 = 0, t2 = 0;
+        for (int f = 0; f < n_families; f++) {
+            if (father_col[f] < 0 || mother_col[f] < 0) continue;
+            char *fs = strdup(row[father_col[f]]), *ms = strdup(row[mother_col[f]]);   /* tdt.c:97-98 */
+            int fa1, fa2, ma1, ma2;
+            if (orc_get_alleles(fs, gt_position, &fa1, &fa2) != ORC_ALLELES_OK ||
+                orc_get_alleles(ms, gt_position, &ma1, &ma2) != ORC_ALLELES_OK) { free(fs); free(ms); continue; }
+            if ((fa1 == fa2 && ma1 == ma2) || (fa1 && !fa2) || (ma1 && !ma2)) { free(fs); free(ms); continue; }
+            int trA = 0, trB = 0;
+            for (int k = child_off[f]; k < child_off[f + 1]; k++) {
+                char *cs = strdup(row[child_col[k]]);                    /* tdt.c:150 */
+                int ca1, ca2;
+                if (orc_get_alleles(cs, gt_position, &ca1, &ca2)) { free(cs); continue; }
+                char *aux = strdup(chrom);                               /* tdt.c:160 */
+                int bad = orc_check_mendel(aux, fa1, fa2, ma1, ma2, ca1, ca2, child_sex[k]);
+                free(aux);
+                if (bad) { free(cs); continue; }
+                if (!ca1 && !ca2) {
+                    if (((!fa1) && fa2) && ((!ma1) && ma2)) { trA = 1; trB = 1; } else { trA = 1; }
+                } else if ((!ca1) && ca2) {
+                    if (fa1 != fa2) {
+                        if (ma1 != ma2) { trA = 1; trB = 2; }
+                        else if (!ma1) { trA = 2; }
+                        else { trA = 1; }
+                    } else if (!fa1) { trA = 2; }
+                    else { trA = 1; }
+                } else {
+                    if (((!fa1) && fa2) && ((!ma1) && ma2)) { trA = 2; trB = 2; } else { trA = 2; }
+                }
+                if (trA == 1) t1++; else if (trA == 2) t2++;
+                if (trB == 1) t1++; else if (trB == 2) t2++;
+                free(cs);
+            }
+            free(fs); free(ms);
+        }
+        t1_out[v] = t1; t2_out[v] = t2;
+    }
+}
+
+double orc_baseline_tdt_text(uint64_t v0, int n_variants, int n_samples, int n_families,
+                             const int32_t *father_col, const int32_t *mother_col, const int32_t *child_off,
+                             const int32_t *child_col, const uint8_t *child_sex, int n_threads, int *threads_used) {
+    const int B = 200;
+    int n_batches = (n_variants + B - 1) / B;
+    int used = 1;
+    double total = 0.0;
+    volatile double sink = 0.0;
+    #pragma omp parallel num_threads(n_threads)
+    {
+        #pragma omp single
+        {
+#ifdef _OPENMP
+            used = omp_get_num_threads();
+#endif
+        }
+        char *pool = (char *)malloc((size_t)B * n_samples * 4);
+        const char **samples = (const char **)malloc((size_t)B * n_samples * sizeof(char *));
+        const char *formats[200];
+        int32_t t1[200], t2[200];
+        double od[200], ch[200], pv[200];
+        double mine = 0.0, local = 0.0;
+        #pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < n_batches; b++) {
+            int start = b * B, n = (start + B <= n_variants) ? B : n_variants - start;
+            render_batch(v0, start, n, n_samples, pool, samples, formats);
+            double t0 = now_s();
+            orc_tdt_text(samples, n, n_samples, formats, NULL, n_families, father_col, mother_col, child_off, child_col,
+                         child_sex, t1, t2);
+            orc_tdt_stats(n, t1, t2, od, ch, pv);
+            mine += now_s() - t0;
+            for (int i = 0; i < n; i++) local += pv[i];
+        }
+        free(pool); free((void *)samples);
+        #pragma omp critical
+        { if (mine > total) total = mine; sink += local; }
+    }
+    if (threads_used) *threads_used = used;
+    (void)sink;
+    return total;
+}
+
+/* the stats tool's per-variant pass (get_variants_stats, call site stats_runner.c:194-195; body in hpg-libs, this
+ * repo's definition orc_variant_stats) on sample strings: per genotype a strdup + get_alleles + free as the assoc
+ * loop does, then the counters and the Hardy-Weinberg test. */
+double orc_baseline_stats_text(uint64_t v0, int n_variants, int n_samples, int n_threads, int *threads_used) {
+    const int B = 200;
+    int n_batches = (n_variants + B - 1) / B;
+    int used = 1;
+    double total = 0.0;
+    volatile double sink = 0.0;
+    #pragma omp parallel num_threads(n_threads)
+    {
+        #pragma omp single
+        {
+#ifdef _OPENMP
+            used = omp_get_num_threads();
+#endif
+        }
+        char *pool = (char *)malloc((size_t)B * n_samples * 4);
+        const char **samples = (const char **)malloc((size_t)B * n_samples * sizeof(char *));
+        uint8_t *codes = (uint8_t *)malloc((size_t)n_samples);
+        const char *formats[200];
+        double mine = 0.0, local = 0.0;
+        #pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < n_batches; b++) {
+            int start = b * B, n = (start + B <= n_variants) ? B : n_variants - start;
+            render_batch(v0, start, n, n_samples, pool, samples, formats);
+            double t0 = now_s();
+            for (int i = 0; i < n; i++) {
+                char *format = strdup(formats[i]);
+                int gt_position = orc_get_field_position_in_format("GT", format);
+                free(format);
+                for (int s = 0; s < n_samples; s++) {
+                    char *sd = strdup(samples[(size_t)i * n_samples + s]);
+                    int a1 = -1, a2 = -1;
+                    int st = orc_get_alleles(sd, gt_position, &a1, &a2);
+                    codes[s] = orc_encode_alleles(st, a1, a2, 0);
+                    free(sd);
+                }
+                orc_variant_stats_t vs;
+                orc_variant_stats(codes, n_samples, 2, &vs);
+                local += vs.hw_p;
+            }
+            mine += now_s() - t0;
+        }
+        free(pool); free((void *)samples); free(codes);
+        #pragma omp critical
+        { if (mine > total) total = mine; sink += local; }
+    }
+    if (threads_used) *threads_used = used;
+    (void)sink;
+    return total;
 }
 
 /* OpenMP team size of the oracle's parallel loops (a cgroup CPU quota can be far below the visible CPUs) */

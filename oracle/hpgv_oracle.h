@@ -156,6 +156,19 @@ double orc_baseline_assoc_packed(const uint8_t *gt, size_t pitch, int n_variants
 double orc_baseline_assoc_text(uint64_t v0, int n_variants, int n_samples,
                                const uint8_t *condition, int n_threads, int *threads_used);
 
+/* the same driver for either statistic of assoc.c:59-76 (task ORC_TASK_CHISQ / ORC_TASK_FISHER with its table),
+ * for tdt.c:41-271 and for the stats tool's per-variant pass; all text-faithful (strdup + get_alleles + free) */
+double orc_baseline_assoc_text_task(uint64_t v0, int n_variants, int n_samples, const uint8_t *condition,
+                                    int task, const double *logfact, int n_threads, int *threads_used);
+void   orc_tdt_text(const char *const *samples, int n_variants, int n_samples, const char *const *formats,
+                    const uint8_t *chrom_is_x, int n_families, const int32_t *father_col, const int32_t *mother_col,
+                    const int32_t *child_off, const int32_t *child_col, const uint8_t *child_sex,
+                    int32_t *t1, int32_t *t2);
+double orc_baseline_tdt_text(uint64_t v0, int n_variants, int n_samples, int n_families,
+                             const int32_t *father_col, const int32_t *mother_col, const int32_t *child_off,
+                             const int32_t *child_col, const uint8_t *child_sex, int n_threads, int *threads_used);
+double orc_baseline_stats_text(uint64_t v0, int n_variants, int n_samples, int n_threads, int *threads_used);
+
 void orc_set_threads(int n);           /* team size of the oracle's OpenMP loops */
 
 /* ---- epistasis / MDR (hpgv_epi_oracle.c; src/gwas/epistasis/model.c, mdr.c, epistasis.c) ---- */

@@ -133,6 +133,17 @@ def lib():
     L.orc_baseline_assoc_text.restype = C.c_double
     L.orc_baseline_assoc_text.argtypes = [C.c_uint64, C.c_int, C.c_int, p_u8, C.c_int,
                                           C.POINTER(C.c_int)]
+    L.orc_baseline_assoc_text_task.restype = C.c_double
+    L.orc_baseline_assoc_text_task.argtypes = [C.c_uint64, C.c_int, C.c_int, p_u8, C.c_int, p_f64, C.c_int,
+                                               C.POINTER(C.c_int)]
+    L.orc_baseline_tdt_text.restype = C.c_double
+    L.orc_baseline_tdt_text.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, p_i32, p_i32, p_i32, p_i32, p_u8,
+                                        C.c_int, C.POINTER(C.c_int)]
+    L.orc_baseline_stats_text.restype = C.c_double
+    L.orc_baseline_stats_text.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.orc_tdt_text.restype = None
+    L.orc_tdt_text.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(C.c_char_p), p_u8, C.c_int,
+                               p_i32, p_i32, p_i32, p_i32, p_u8, p_i32, p_i32]
     _lib = L
     return L
 
@@ -295,6 +306,45 @@ def baseline_assoc_text(v0, n_variants, n_samples, condition, n_threads):
     sec = lib().orc_baseline_assoc_text(v0, n_variants, n_samples, _p(cond, C.c_uint8),
                                         n_threads, C.byref(used))
     return sec, used.value
+
+
+def baseline_fisher_text(v0, n_variants, n_samples, condition, lf_table, n_threads):
+    """assoc --fisher on sample strings: the scan of assoc.c:50-57 + assoc.c:69-75 on the caller's ln(i!) table."""
+    cond = np.ascontiguousarray(condition, dtype=np.uint8)
+    lf = np.ascontiguousarray(lf_table, dtype=np.float64)
+    used = C.c_int(0)
+    sec = lib().orc_baseline_assoc_text_task(v0, n_variants, n_samples, _p(cond, C.c_uint8), TASK_FISHER,
+                                             _p(lf, C.c_double), n_threads, C.byref(used))
+    return sec, used.value
+
+
+def baseline_tdt_text(v0, n_variants, n_samples, father_col, mother_col, child_off, child_col, child_sex, n_threads):
+    fc, mc, co, cc = (np.ascontiguousarray(a, dtype=np.int32) for a in (father_col, mother_col, child_off, child_col))
+    cs = np.ascontiguousarray(child_sex, dtype=np.uint8)
+    used = C.c_int(0)
+    sec = lib().orc_baseline_tdt_text(v0, n_variants, n_samples, len(fc), _p(fc, C.c_int32), _p(mc, C.c_int32),
+                                      _p(co, C.c_int32), _p(cc, C.c_int32), _p(cs, C.c_uint8), n_threads, C.byref(used))
+    return sec, used.value
+
+
+def baseline_stats_text(v0, n_variants, n_samples, n_threads):
+    used = C.c_int(0)
+    sec = lib().orc_baseline_stats_text(v0, n_variants, n_samples, n_threads, C.byref(used))
+    return sec, used.value
+
+
+def tdt_text(rows, father_col, mother_col, child_off, child_col, child_sex, chrom_is_x=None):
+    """orc_tdt_text on rows of sample strings (all FORMAT "GT"): the text-faithful twin of tdt_counts."""
+    nv, ns = len(rows), len(rows[0]) if rows else 0
+    flat = (C.c_char_p * (nv * ns))(*[s.encode() for r in rows for s in r])
+    fmts = (C.c_char_p * max(nv, 1))(*([b"GT"] * nv))
+    fc, mc, co, cc = (np.ascontiguousarray(a, dtype=np.int32) for a in (father_col, mother_col, child_off, child_col))
+    cs = np.ascontiguousarray(child_sex, dtype=np.uint8)
+    x = None if chrom_is_x is None else np.ascontiguousarray(chrom_is_x, dtype=np.uint8)
+    t1, t2 = np.zeros(nv, np.int32), np.zeros(nv, np.int32)
+    lib().orc_tdt_text(flat, nv, ns, fmts, _p(x, C.c_uint8), len(fc), _p(fc, C.c_int32), _p(mc, C.c_int32),
+                       _p(co, C.c_int32), _p(cc, C.c_int32), _p(cs, C.c_uint8), _p(t1, C.c_int32), _p(t2, C.c_int32))
+    return t1, t2
 
 
 # ---- epistasis / MDR (hpgv_epi_oracle.c) -------------------------------------------------------

@@ -33,7 +33,7 @@ def averages(path, counter):
 def main():
     workload, fetch_csv, write_csv, bench_json, out = sys.argv[1:6]
     cfg = json.loads(open(bench_json).read().strip().splitlines()[-1])["config"]     # the bench line of the same pass
-    V, N, pitch = cfg["variants_per_gpu"], cfg["samples"], cfg["row_pitch_bytes"]
+    V, N, pitch = cfg.get("variants_per_tile", cfg["variants_per_gpu"]), cfg["samples"], cfg["row_pitch_bytes"]    # variants per LAUNCH
     fetch = averages(fetch_csv, "FETCH_SIZE")
     write = averages(write_csv, "WRITE_SIZE")
     kernels = {}
