@@ -7,9 +7,16 @@ HOST    := hpg-variant_amd/host
 
 all: $(LIBDIR)/libhpgv.so $(LIBDIR)/libhpgv_host.so oracle
 
-$(LIBDIR)/libhpgv.so: $(CSRC)/hpgv_capi.hip $(wildcard $(CSRC)/*.h) include/hpgv.h
-	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wall -Wextra -o $@ $(CSRC)/hpgv_capi.hip
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra -Wno-unused-function
+UNITS   := $(wildcard $(CSRC)/*.hip)
+OBJS    := $(patsubst $(CSRC)/%.hip,$(LIBDIR)/obj/%.o,$(UNITS))
+
+$(LIBDIR)/obj/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/hpgv.h
+	@mkdir -p $(LIBDIR)/obj
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIBDIR)/libhpgv.so: $(OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS)
 
 $(LIBDIR)/libhpgv_host.so: $(HOST)/hpgv_host.c include/hpgv_host.h include/hpgv.h $(LIBDIR)/libhpgv.so
 	$(CC) -O2 -g -std=gnu99 -fPIC -shared -fopenmp -Wall -Wextra -Iinclude -o $@ $(HOST)/hpgv_host.c \

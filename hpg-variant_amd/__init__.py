@@ -167,6 +167,9 @@ class Engine:
             for b in self._bufs:
                 self.L.hpgv_dev_free(self.h, b)
             self._bufs = []
+            for b in getattr(self, "_host_bufs", []):
+                self.L.hpgv_host_free(self.h, b)
+            self._host_bufs = []
             self.L.hpgv_destroy(self.h)
             self.h = None
 
@@ -253,6 +256,16 @@ class Engine:
         self._bufs = [b for b in self._bufs if b.value != p.value]
         self._chk(self.L.hpgv_dev_free(self.h, p))
 
+    def host_array(self, shape, dtype=np.uint8):
+        """numpy array in page-locked host memory (hpgv_host_alloc): batches staged into it are read by the
+        per-batch kernels in place, without a copy.  Freed with the engine."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._chk(self.L.hpgv_host_alloc(self.h, max(n, 16), C.byref(p)))
+        self._host_bufs = getattr(self, "_host_bufs", []) + [p]
+        buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
     def h2d(self, dptr, arr):
         arr = np.ascontiguousarray(arr)
         self._chk(self.L.hpgv_memcpy_h2d(self.h, dptr, _ptr(arr), arr.nbytes, None))
@@ -277,6 +290,28 @@ class Engine:
                                     _ptr(chisq) if task == TASK_CHISQ else None, _ptr(p)))
         return dict(A1=A1, A2=A2, U1=U1, U2=U2, odds=odds,
                     chisq=chisq if task == TASK_CHISQ else None, p=p)
+
+    def assoc_view(self, task, gt2d, n_samples, is_x=None):
+        """hpgv_assoc on a 2-D uint8 VIEW as it lies in memory (row stride = pitch): nothing is copied on the way,
+        so a view of page-locked memory (host_array) is read by the kernel in place."""
+        nv, pitch = gt2d.shape[0], gt2d.strides[0]
+        assert gt2d.dtype == np.uint8 and gt2d.strides[1] == 1 and pitch >= n_samples
+        A1, A2, U1, U2 = (np.zeros(nv, np.int32) for _ in range(4))
+        odds, chisq, p = (np.zeros(nv, np.float64) for _ in range(3))
+        self._chk(self.L.hpgv_assoc(self.h, task, C.c_void_p(gt2d.ctypes.data), pitch, nv,
+                                    None if is_x is None else C.c_void_p(is_x.ctypes.data), _ptr(A1), _ptr(A2),
+                                    _ptr(U1), _ptr(U2), _ptr(odds), _ptr(chisq) if task == TASK_CHISQ else None, _ptr(p)))
+        return dict(A1=A1, A2=A2, U1=U1, U2=U2, odds=odds, chisq=chisq if task == TASK_CHISQ else None, p=p)
+
+    def tdt_view(self, gt2d, n_samples, is_x=None):
+        nv, pitch = gt2d.shape[0], gt2d.strides[0]
+        assert gt2d.dtype == np.uint8 and gt2d.strides[1] == 1 and pitch >= n_samples
+        t1, t2 = np.zeros(nv, np.int32), np.zeros(nv, np.int32)
+        odds, chisq, p = (np.zeros(nv, np.float64) for _ in range(3))
+        self._chk(self.L.hpgv_tdt(self.h, C.c_void_p(gt2d.ctypes.data), pitch, nv,
+                                  None if is_x is None else C.c_void_p(is_x.ctypes.data), _ptr(t1), _ptr(t2),
+                                  _ptr(odds), _ptr(chisq), _ptr(p)))
+        return dict(t1=t1, t2=t2, odds=odds, chisq=chisq, p=p)
 
     def tdt(self, gt, is_x=None):
         gt = _np(gt, np.uint8)

@@ -2,241 +2,79 @@
 //
 // There is no CPU path in this library: every entry point that computes
 // launches HIP kernels, and hpgv_create() fails without a device.
-#include "../../include/hpgv.h"
-#include "hpgv_kernels.h"
-#include "hpgv_tdt_stats_kernels.h"
+#include "hpgv_internal.h"
 #include "hpgv_text_kernels.h"
-#include "hpgv_epi_kernels.h"
 #include "hpgv_inflate_kernels.h"
-
-#include <hip/hip_runtime.h>
-#include <cctype>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <mutex>
-#include <new>
-#include <string>
-#include <vector>
+#include "hpgv_batch_kernels.h"
 
 namespace {
 
-thread_local std::string g_create_error;
-
-struct Layout {
-    bool set = false;
-    int n_samples = 0;
-    size_t pitch = 0;
-    int chunks = 0;
-    std::vector<int32_t> col_of_pos;   // size pitch; -1 = pad
-    int32_t *d_col_of_pos = nullptr;
-    size_t d_cap = 0;                  // bytes behind d_col_of_pos
-};
-
-// per-call scratch of the synchronous host entry points
-struct Slot {
-    bool busy = false;
-    hipStream_t stream = nullptr;
-    void *buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-};
-
-// epistasis / MDR state: the vcf2epi dataset on the device, its bit planes for the current folds
-struct EpiState {
-    bool have_data = false, have_folds = false;
-    int V = 0, nA = 0, nU = 0, num_folds = 0, W = 0, V_alloc = 0, n_chunks = 0;
-    uint8_t *d_data = nullptr;
-    uint32_t *d_planes = nullptr;
-    uint32_t *d_marg = nullptr;       // per SNP and (fold, class) group: samples with genotype 0 / 1 (16 bits each)
-    bool complete = false;            // the dataset holds no call other than 0 / 1 / 2
-    hpgv::EpiChunk *d_chunks = nullptr;
-    hpgv::EpiFold *d_folds = nullptr;
-    uint32_t *d_group_w0 = nullptr;
-    std::vector<int32_t> group_size;
-    hpgv::EpiCand *d_cand = nullptr;
-    unsigned *d_cand_count = nullptr;
-    unsigned cand_cap = 0;
-    double *d_thr = nullptr;
-    unsigned *d_tile_base = nullptr;
-    size_t tile_base_cap = 0;
-};
-
-}  // namespace
-
-struct hpgv_ctx {
-    int device = 0;
-    mutable std::string err;
-    std::mutex mu;
-    // options
-    long row_align = 16;
-    long row_pad = 0;          // extra bytes (multiple of 16) appended to every row; pitch exploration knob
-    long vpw = 2;
-    long nontemporal = 1;
-    long profile = 0;
-    std::mutex alias_mu;
-    std::vector<std::pair<const char *, const char *>> text_alias;   // host text buffer -> the same text already on the device
-    long scan_unroll = 4;
-    long persistent = 0;       // 0: one wave per vpw consecutive rows; 1: persistent strided grid
-    long blocks_per_cu = 8;
-    long pipeline = 1;         // 1: software-pipelined scan (loads of the next tile before counting this one)
-    long pipe_waves = 4;       // register budget of the pipelined scan, as waves per SIMD (4, 6 or 8)
-    long fisher_cut_exp = 22;  // Fisher tails stop after a round whose terms are all below 10^-this of the tail's largest term
-    long epi_complete = 1;     // epistasis pair scan on a dataset without missing calls: count four cells, derive the other five
-    long epi_triples_1pass = 1; // epistasis triple ranking with at most 10 folds: one pass, all folds' counts in registers (one wave per SIMD)
-    long scan_lds = 0;         // bytes of (unused) LDS per workgroup of the stats / tdt scans: caps the waves in flight per CU
-    int n_cus = 256;
-    // assoc
-    Layout assoc;
-    int nA = 0, nU = 0, chunksA = 0;
-    // tdt
-    Layout tdt;
-    hpgv::TdtPlan tdt_plan;
-    // stats
-    Layout stats;
-    Layout sgroups;                       // [group 0 | pad16 | group 1 | ...]
-    std::vector<uint32_t> sg_off;         // byte offset of every group's segment in the row
-    std::vector<int> sg_size;             // samples per group
-    // mendelian errors
-    Layout mendel;
-    int mendel_trios = 0, mendel_pchunks = 0;
-    hpgv::MendelLuts mendel_luts{};
-    uint8_t *d_mendel_male = nullptr;
-    // fisher
-    double *d_lf = nullptr;
-    size_t n_lf = 0;
-    size_t cap_lf = 0;                 // doubles behind d_lf (kept across tables: hipFree waits for the whole device)
-    // synth scratch
-    uint32_t *d_thr = nullptr;
-    size_t thr_cap = 0;
-    // profiling
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool have_scan_ev = false, have_stats_ev = false;
-    std::vector<Slot *> slots;
-    uint32_t *d_sink = nullptr;
-    // tokenizer scratch (newline counts per 4 KiB tile, line offsets), one set per stream that has
-    // tokenized: calls on one stream are ordered by the stream, calls on different streams run
-    // concurrently on the device and must not share it.  The table is guarded by tok_mu.
-    struct TokScratch {
-        hipStream_t stream = nullptr;
-        int *d_blocks = nullptr; size_t blocks_cap = 0;
-        unsigned long long *d_line_off = nullptr; size_t line_cap = 0;
-    };
-    std::mutex tok_mu;
-    std::vector<TokScratch *> tok_scratch;
-    // record filters of the text entry points (hpgv_set_text_filters); negative = off
-    double filt_min_maf = -1.0, filt_max_missing = -1.0;
-    long filt_max_mendel = -1;
-    // epistasis (calls are serialised by epi_mu)
-    std::mutex epi_mu;
-    EpiState epi;
-};
-
-namespace {
-
-int fail(const hpgv_ctx *ctx, int code, const char *fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    if (ctx) ctx->err = buf; else g_create_error = buf;
-    return code;
+// ---- the fused per-batch path (hpgv_batch_kernels.h) ---------------------------------------------------------------
+// device-visible address of host pointer p when [p, p + bytes) is page-locked (hipHostMalloc / hipHostRegister) or device
+// memory; nullptr for ordinary pageable memory
+static const void *mapped_view(const void *p, size_t bytes) {
+    if (!p || bytes == 0) return nullptr;
+    const void *ends[2] = {p, (const char *)p + bytes - 1};
+    const void *dev0 = nullptr;
+    for (int k = 0; k < 2; ++k) {
+        hipPointerAttribute_t a;
+        memset(&a, 0, sizeof a);
+        if (hipPointerGetAttributes(&a, ends[k]) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (a.type != hipMemoryTypeHost && a.type != hipMemoryTypeDevice && a.type != hipMemoryTypeManaged) return nullptr;
+        if (!a.devicePointer) return nullptr;
+        if (k == 0) dev0 = a.devicePointer;
+    }
+    return dev0;
 }
 
-#define HIPCHK(ctx, call)                                                                   \
-    do {                                                                                    \
-        hipError_t e_ = (call);                                                             \
-        if (e_ != hipSuccess)                                                               \
-            return fail(ctx, HPGV_ERR_HIP, "%s failed: %s (%s:%d)", #call,                  \
-                        hipGetErrorString(e_), __FILE__, __LINE__);                         \
-    } while (0)
+static int ensure_result_block(hpgv_ctx *ctx, Slot *s, size_t bytes) {
+    if (s->res_cap >= bytes) return HPGV_OK;
+    if (s->h_res) { (void)hipHostFree(s->h_res); s->h_res = nullptr; s->d_res = nullptr; s->res_cap = 0; }
+    const size_t want = round_up(bytes + bytes / 2, 4096);
+    HIPCHK(ctx, hipHostMalloc(&s->h_res, want, hipHostMallocDefault));
+    HIPCHK(ctx, hipHostGetDevicePointer(&s->d_res, s->h_res, 0));
+    s->res_cap = want;
+    return HPGV_OK;
+}
 
-// makes ctx->device current for the scope of one API call
-struct DeviceGuard {
-    int prev = -1;
-    bool changed = false;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
-            changed = (hipSetDevice(dev) == hipSuccess);
+static bool batch_fused_ok(const hpgv_ctx *ctx, int n_samples) {
+    return ctx->batch_fused && (size_t)n_samples + 32 <= (size_t)ctx->batch_lds_max;
+}
+
+// sources of a fused call: the caller's buffers as they are when the device can read them, the slot's copies otherwise
+static int batch_sources(hpgv_ctx *ctx, Slot *s, const uint8_t *gt, size_t pitch, int n_variants, int n_samples, const uint8_t *is_x,
+                         hpgv::BatchArgs *A) {
+    int rc;
+    const size_t bytes = (size_t)(n_variants - 1) * pitch + (size_t)n_samples;     // the last row need not be a whole pitch
+    const void *src = mapped_view(gt, bytes);
+    if (!src) {
+        if ((rc = ensure(ctx, s, 0, bytes + 16))) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(s->buf[0], gt, bytes, hipMemcpyHostToDevice, s->stream));
+        src = s->buf[0];
+    }
+    const void *x = nullptr;
+    if (is_x) {
+        x = mapped_view(is_x, (size_t)n_variants);
+        if (!x) {
+            if ((rc = ensure(ctx, s, 2, (size_t)n_variants))) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(s->buf[2], is_x, (size_t)n_variants, hipMemcpyHostToDevice, s->stream));
+            x = s->buf[2];
         }
     }
-    ~DeviceGuard() { if (changed) (void)hipSetDevice(prev); }
-};
-
-size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-
-int upload_layout(hpgv_ctx *ctx, Layout &L) {
-    // the table is kept when it is large enough: hipFree waits for every stream of the device, and a file run sets its
-    // cohort while the decoder of the bgzip text is busy on streams of its own
-    const size_t need = L.col_of_pos.size() * sizeof(int32_t);
-    if (L.d_cap < need) {
-        if (L.d_col_of_pos) { (void)hipFree(L.d_col_of_pos); L.d_col_of_pos = nullptr; L.d_cap = 0; }
-        HIPCHK(ctx, hipMalloc(&L.d_col_of_pos, need));
-        L.d_cap = need;
-    }
-    HIPCHK(ctx, hipMemcpy(L.d_col_of_pos, L.col_of_pos.data(), L.col_of_pos.size() * sizeof(int32_t),
-                          hipMemcpyHostToDevice));
-    L.chunks = (int)(L.pitch / 16);
-    L.set = true;
+    A->src = (const uint8_t *)src; A->src_pitch = pitch; A->n_variants = n_variants; A->n_samples = n_samples;
+    A->is_x = (const uint8_t *)x;
     return HPGV_OK;
 }
 
-// packed per-lane 16-bit partial sums bound the row length (hpgv_kernels.h)
-constexpr int kScanUnroll = 8;       // unroll of the tdt/stats scans
-constexpr int kMaxUnroll = 16;       // largest assoc unroll option
-bool pitch_supported(size_t pitch) { return pitch / 16 / 64 + kMaxUnroll + 1 <= 2047; }
-
-int ensure(hpgv_ctx *ctx, Slot *s, int idx, size_t bytes) {
-    if (s->cap[idx] >= bytes) return HPGV_OK;
-    if (s->buf[idx]) { (void)hipFree(s->buf[idx]); s->buf[idx] = nullptr; s->cap[idx] = 0; }
-    size_t want = round_up(bytes + bytes / 4, 256);
-    HIPCHK(ctx, hipMalloc(&s->buf[idx], want));
-    s->cap[idx] = want;
-    return HPGV_OK;
-}
-
-int acquire_slot(hpgv_ctx *ctx, Slot **out) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    for (Slot *s : ctx->slots)
-        if (!s->busy) { s->busy = true; *out = s; return HPGV_OK; }
-    Slot *s = new (std::nothrow) Slot();
-    if (!s) return fail(ctx, HPGV_ERR_NOMEM, "out of host memory");
-    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete s; return fail(ctx, HPGV_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
-    s->busy = true;
-    ctx->slots.push_back(s);
-    *out = s;
-    return HPGV_OK;
-}
-void release_slot(hpgv_ctx *ctx, Slot *s) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    s->busy = false;
-}
-struct SlotLease {
-    hpgv_ctx *ctx; Slot *s = nullptr;
-    explicit SlotLease(hpgv_ctx *c) : ctx(c) {}
-    ~SlotLease() { if (s) release_slot(ctx, s); }
-};
-
-template <typename F>
-int launch_profiled(hpgv_ctx *ctx, hipStream_t st, int which /*0 scan,1 stats*/, F &&launch) {
-    if (ctx->profile) HIPCHK(ctx, hipEventRecord(ctx->ev[2 * which], st));
-    launch();
+template <int KIND>
+static int launch_batch(hpgv_ctx *ctx, Slot *s, const hpgv::BatchArgs &A) {
+    const size_t lds = ((size_t)A.n_samples + 15 + 15) / 16 * 16 + 16;
+    hipLaunchKernelGGL((hpgv::k_batch<KIND>), dim3((unsigned)A.n_variants), dim3(256), lds, s->stream, A);
     HIPCHK(ctx, hipGetLastError());
-    if (ctx->profile) {
-        HIPCHK(ctx, hipEventRecord(ctx->ev[2 * which + 1], st));
-        (which == 0 ? ctx->have_scan_ev : ctx->have_stats_ev) = true;
-    }
     return HPGV_OK;
 }
 
 }  // namespace
-
-// the epistasis / MDR entry points (declared extern "C" in hpgv.h)
-#include "hpgv_epi_capi.inc"
 
 extern "C" {
 
@@ -274,8 +112,20 @@ int hpgv_create(int device_id, hpgv_ctx **out) {
         }
     }
     hipDeviceProp_t prop;
+    memset(&prop, 0, sizeof prop);
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->n_cus = prop.multiProcessorCount;
+    {   // the fused per-batch kernel stages one raw row in LDS: ask for the whole 160 KiB where the device has it
+        const int want = 160 * 1024 - 1024;
+        bool ok = true;
+        ok = ok && hipFuncSetAttribute((const void *)hpgv::k_batch<hpgv::BATCH_CHISQ>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)hpgv::k_batch<hpgv::BATCH_FISHER>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)hpgv::k_batch<hpgv::BATCH_TDT>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)hpgv::k_batch<hpgv::BATCH_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+        if (ok && prop.sharedMemPerBlockOptin >= (size_t)want) ctx->batch_lds_max = want;
+        else if (ok && prop.maxSharedMemoryPerMultiProcessor >= (size_t)want) ctx->batch_lds_max = want;
+        (void)hipGetLastError();
+    }
     e = hipMalloc(&ctx->d_sink, 256);
     if (e != hipSuccess) {
         int rc = fail(nullptr, HPGV_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
@@ -303,9 +153,10 @@ void hpgv_destroy(hpgv_ctx *ctx) {
         delete t;
     }
     ctx->tok_scratch.clear();
-    epi_free(ctx->epi);
+    hpgv_epi_release(ctx->epi);
     for (Slot *s : ctx->slots) {
         for (int i = 0; i < 8; ++i) if (s->buf[i]) (void)hipFree(s->buf[i]);
+        if (s->h_res) (void)hipHostFree(s->h_res);
         if (s->stream) (void)hipStreamDestroy(s->stream);
         delete s;
     }
@@ -348,6 +199,8 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
     } else if (!strcmp(key, "scan_lds")) {
         if (value < 0 || value > 160 * 1024) return fail(ctx, HPGV_ERR_INVALID, "scan_lds must be in [0, 163840]");
         ctx->scan_lds = value;
+    } else if (!strcmp(key, "batch_fused")) {
+        ctx->batch_fused = value ? 1 : 0;
     } else if (!strcmp(key, "pipe_waves")) {
         if (value != 4 && value != 6 && value != 8) return fail(ctx, HPGV_ERR_INVALID, "pipe_waves must be 4, 6 or 8");
         ctx->pipe_waves = value;
@@ -1082,9 +935,36 @@ int hpgv_assoc(hpgv_ctx *ctx, int task, const uint8_t *gt, size_t pitch, int n_v
     int rc = acquire_slot(ctx, &lease.s);
     if (rc) return rc;
     Slot *s = lease.s;
+    const size_t n = (size_t)n_variants;
+    if (batch_fused_ok(ctx, ctx->assoc.n_samples)) {
+        // one kernel: raw rows (read in place from page-locked memory) -> counts -> statistics -> packed records in the
+        // slot's page-locked block; the only other work of the call is unpacking them
+        if (task == HPGV_TASK_FISHER) {
+            if (!ctx->d_lf) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_logfact has not been called");
+            if (ctx->n_lf < (size_t)2 * (ctx->nA + ctx->nU) + 1)
+                return fail(ctx, HPGV_ERR_STATE, "log-factorial table has %zu entries, need %d", ctx->n_lf, 2 * (ctx->nA + ctx->nU) + 1);
+        }
+        hpgv::BatchArgs A;
+        memset(&A, 0, sizeof A);
+        if ((rc = batch_sources(ctx, s, gt, pitch, n_variants, ctx->assoc.n_samples, is_x, &A))) return rc;
+        if ((rc = ensure_result_block(ctx, s, n * sizeof(hpgv::BatchAssocRec)))) return rc;
+        A.col_of_pos = ctx->assoc.d_col_of_pos; A.chunks = ctx->assoc.chunks; A.chunksA = ctx->chunksA;
+        A.lf = ctx->d_lf; A.rel_cut = pow(10.0, -(double)ctx->fisher_cut_exp);
+        A.out = s->d_res;
+        if (task == HPGV_TASK_CHISQ) rc = launch_batch<hpgv::BATCH_CHISQ>(ctx, s, A);
+        else rc = launch_batch<hpgv::BATCH_FISHER>(ctx, s, A);
+        if (rc) { (void)hipStreamSynchronize(s->stream); return rc; }
+        HIPCHK(ctx, hipStreamSynchronize(s->stream));
+        const hpgv::BatchAssocRec *r = (const hpgv::BatchAssocRec *)s->h_res;
+        for (size_t i = 0; i < n; ++i) {
+            A1[i] = r[i].A1; A2[i] = r[i].A2; U1[i] = r[i].U1; U2[i] = r[i].U2;
+            odds[i] = r[i].odds; p[i] = r[i].p;
+        }
+        if (task == HPGV_TASK_CHISQ) for (size_t i = 0; i < n; ++i) chisq[i] = r[i].chisq;
+        return HPGV_OK;
+    }
     const uint8_t *d_isx = nullptr;
     if ((rc = stage_batch(ctx, s, HPGV_LAYOUT_ASSOC, ctx->assoc, gt, pitch, n_variants, is_x, &d_isx))) return rc;
-    const size_t n = (size_t)n_variants;
     if ((rc = ensure(ctx, s, 3, n * 16))) return rc;
     if ((rc = ensure(ctx, s, 4, n * 3 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, s, 5, n * 4 * sizeof(int32_t)))) return rc;
@@ -1122,9 +1002,25 @@ int hpgv_tdt(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, con
     int rc = acquire_slot(ctx, &lease.s);
     if (rc) return rc;
     Slot *s = lease.s;
+    const size_t n = (size_t)n_variants;
+    if (batch_fused_ok(ctx, ctx->tdt.n_samples)) {
+        hpgv::BatchArgs A;
+        memset(&A, 0, sizeof A);
+        if ((rc = batch_sources(ctx, s, gt, pitch, n_variants, ctx->tdt.n_samples, is_x, &A))) return rc;
+        if ((rc = ensure_result_block(ctx, s, n * sizeof(hpgv::BatchTdtRec)))) return rc;
+        const hpgv::TdtPlan &P = ctx->tdt_plan;
+        A.col_of_pos = ctx->tdt.d_col_of_pos; A.chunks = ctx->tdt.chunks;
+        A.pchunks = P.pchunks; A.p16 = P.p16; A.n_slow = P.n_slow_families; A.slow_base = P.slow_base; A.luts = P.luts;
+        A.male_plane = P.d_male_plane; A.slow_off = P.d_slow_off; A.slow_male = P.d_slow_male;
+        A.out = s->d_res;
+        if ((rc = launch_batch<hpgv::BATCH_TDT>(ctx, s, A))) { (void)hipStreamSynchronize(s->stream); return rc; }
+        HIPCHK(ctx, hipStreamSynchronize(s->stream));
+        const hpgv::BatchTdtRec *r = (const hpgv::BatchTdtRec *)s->h_res;
+        for (size_t i = 0; i < n; ++i) { t1[i] = r[i].t1; t2[i] = r[i].t2; odds[i] = r[i].odds; chisq[i] = r[i].chisq; p[i] = r[i].p; }
+        return HPGV_OK;
+    }
     const uint8_t *d_isx = nullptr;
     if ((rc = stage_batch(ctx, s, HPGV_LAYOUT_TDT, ctx->tdt, gt, pitch, n_variants, is_x, &d_isx))) return rc;
-    const size_t n = (size_t)n_variants;
     if ((rc = ensure(ctx, s, 3, n * 8))) return rc;
     if ((rc = ensure(ctx, s, 4, n * 3 * sizeof(double)))) return rc;
     int32_t *d_tu = (int32_t *)s->buf[3];
@@ -1158,10 +1054,49 @@ int hpgv_stats_ex(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants
     int rc = acquire_slot(ctx, &lease.s);
     if (rc) return rc;
     Slot *s = lease.s;
-    const uint8_t *d_isx = nullptr;
-    if ((rc = stage_batch(ctx, s, HPGV_LAYOUT_STATS, ctx->stats, gt, pitch, n_variants, nullptr, &d_isx))) return rc;
     const size_t n = (size_t)n_variants;
     const int ns = ctx->stats.n_samples;
+    if (batch_fused_ok(ctx, ns) && !(sample_missing && ns > 0)) {
+        // get_variants_stats' shape: counters + Hardy-Weinberg per variant in one kernel; the 256-bin tables of the rare
+        // multi-allelic variants are counted from the same raw rows afterwards
+        hpgv::BatchArgs A;
+        memset(&A, 0, sizeof A);
+        if ((rc = batch_sources(ctx, s, gt, pitch, n_variants, ns, nullptr, &A))) return rc;
+        if ((rc = ensure_result_block(ctx, s, n * sizeof(hpgv::BatchStatsRec)))) return rc;
+        A.col_of_pos = ctx->stats.d_col_of_pos; A.chunks = ctx->stats.chunks;
+        A.out = s->d_res;
+        if ((rc = launch_batch<hpgv::BATCH_STATS>(ctx, s, A))) { (void)hipStreamSynchronize(s->stream); return rc; }
+        HIPCHK(ctx, hipStreamSynchronize(s->stream));
+        const hpgv::BatchStatsRec *r = (const hpgv::BatchStatsRec *)s->h_res;
+        for (size_t i = 0; i < n; ++i) {
+            memcpy(counts8 + 8 * i, r[i].c8, 8 * sizeof(int32_t));
+            hwe_chi2[i] = r[i].hwe_chi2; hwe_p[i] = r[i].hwe_p;
+        }
+        if (n_multi) {
+            std::vector<int32_t> idx;
+            for (size_t i = 0; i < n; ++i) {
+                const int32_t *c = counts8 + 8 * i;
+                if (ns - c[4] - (c[0] + c[1] + c[2] + c[3]) > 0) idx.push_back((int32_t)i);
+            }
+            *n_multi = (int)idx.size();
+            const int m = (int)idx.size() < cap ? (int)idx.size() : cap;
+            if (m > 0) {
+                if ((rc = ensure(ctx, s, 6, (size_t)m * sizeof(int32_t)))) return rc;
+                if ((rc = ensure(ctx, s, 7, (size_t)m * 256 * sizeof(int32_t)))) return rc;
+                HIPCHK(ctx, hipMemcpyAsync(s->buf[6], idx.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+                if ((rc = hpgv_genotype_table_dev(ctx, A.src, pitch, ns, (const int32_t *)s->buf[6], m, (int32_t *)s->buf[7], s->stream))) {
+                    (void)hipStreamSynchronize(s->stream);
+                    return rc;
+                }
+                HIPCHK(ctx, hipMemcpyAsync(multi_table, s->buf[7], (size_t)m * 256 * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+                HIPCHK(ctx, hipStreamSynchronize(s->stream));
+                memcpy(multi_idx, idx.data(), (size_t)m * sizeof(int32_t));
+            }
+        }
+        return HPGV_OK;
+    }
+    const uint8_t *d_isx = nullptr;
+    if ((rc = stage_batch(ctx, s, HPGV_LAYOUT_STATS, ctx->stats, gt, pitch, n_variants, nullptr, &d_isx))) return rc;
     if ((rc = ensure(ctx, s, 3, n * 32))) return rc;
     if ((rc = ensure(ctx, s, 4, n * 2 * sizeof(double)))) return rc;
     int32_t *d_c8 = (int32_t *)s->buf[3];

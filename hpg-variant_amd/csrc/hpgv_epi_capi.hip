@@ -1,7 +1,7 @@
-// hpgv_epi_capi.inc -- C ABI of the epistasis / MDR path (included by hpgv_capi.hip; the entry points are
-// declared extern "C" in include/hpgv.h).
-// Reference: src/gwas/epistasis/{model.c, mdr.c, epistasis.c, cross_validation.c}, runner
-// src/gwas/epistasis/singlenode/epistasis_runner.c.
+// hpgv_epi_capi.hip -- C ABI of the epistasis / MDR path (its own translation unit of libhpgv.so: the pair and triple
+// scans are instantiated per fold count and compile for minutes).
+#include "hpgv_internal.h"
+
 
 namespace {
 
@@ -190,6 +190,8 @@ int epi_launch_pairs(hpgv_ctx *ctx, int i_begin, int i_end, double *d_acc, uint1
 unsigned long long epi_rank(unsigned long long V, unsigned long long i) { return i * (2ull * V - i - 1ull) / 2ull; }   // rank of (i, i+1)
 
 }  // namespace
+
+void hpgv_epi_release(EpiState &E) { epi_free(E); }
 
 int hpgv_epi_set_dataset(hpgv_ctx *ctx, const uint8_t *genotypes, int n_variants, int n_affected, int n_unaffected) {
     if (!ctx) return HPGV_ERR_INVALID;

@@ -48,7 +48,7 @@ struct EpiCand {                      // a model that reached a fold's current t
 // dataset rows -> bit planes.  planes[(snp * 3 + g) * W + w]; src_of_pos[p] = dataset column of
 // the sample at bit position p, or -1 for a pad bit.  One workgroup per SNP row (rows >= V are zero).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_epi_planes(const uint8_t *__restrict__ data, int n_variants, int n_samples,
+static __global__ void __launch_bounds__(256) k_epi_planes(const uint8_t *__restrict__ data, int n_variants, int n_samples,
                                                      const int32_t *__restrict__ src_of_pos, int W,
                                                      uint32_t *__restrict__ planes, unsigned *__restrict__ any_missing) {
     const int snp = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) k_epi_planes(const uint8_t *__restrict__ 
 
 // per SNP and (fold, class) group: how many of the group's samples have genotype 0 and genotype 1 (low / high 16 bits).
 // marg[snp * (2 * EPI_MAX_FOLDS) + g].  One workgroup per SNP row, wave w takes the groups w, w + 4, ...
-__global__ void __launch_bounds__(256) k_epi_marginals(const uint32_t *__restrict__ planes, int W, const uint32_t *__restrict__ group_w0,
+static __global__ void __launch_bounds__(256) k_epi_marginals(const uint32_t *__restrict__ planes, int W, const uint32_t *__restrict__ group_w0,
                                                         int n_groups, uint32_t *__restrict__ marg) {
     const int snp = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t *p0 = planes + (size_t)snp * 3 * W, *p1 = p0 + W;

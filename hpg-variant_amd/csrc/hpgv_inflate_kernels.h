@@ -77,7 +77,7 @@ __device__ __forceinline__ int inflate_construct(InflateCode &h, const uint8_t *
     return left;
 }
 
-__global__ void __launch_bounds__(64) k_inflate_blocks(const uint8_t *__restrict__ comp, const uint64_t *__restrict__ in_off,
+static __global__ void __launch_bounds__(64) k_inflate_blocks(const uint8_t *__restrict__ comp, const uint64_t *__restrict__ in_off,
                                                        const uint32_t *__restrict__ in_len, const uint64_t *__restrict__ out_off,
                                                        const uint32_t *__restrict__ out_len, int n_blocks,
                                                        uint8_t *__restrict__ text, int32_t *__restrict__ status) {

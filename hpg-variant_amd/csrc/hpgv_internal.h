@@ -1,0 +1,239 @@
+// hpgv_internal.h -- the context behind include/hpgv.h and the helpers shared by the translation units of
+// libhpgv.so (hpgv_capi.hip: association / TDT / stats / text / batch entry points; hpgv_epi_capi.hip: the
+// epistasis entry points, whose many kernel instantiations compile on their own).
+#pragma once
+#include "../../include/hpgv.h"
+#include "hpgv_kernels.h"
+#include "hpgv_tdt_stats_kernels.h"
+#include "hpgv_epi_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <cctype>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace { thread_local std::string g_create_error; }
+
+struct Layout {
+    bool set = false;
+    int n_samples = 0;
+    size_t pitch = 0;
+    int chunks = 0;
+    std::vector<int32_t> col_of_pos;   // size pitch; -1 = pad
+    int32_t *d_col_of_pos = nullptr;
+    size_t d_cap = 0;                  // bytes behind d_col_of_pos
+};
+
+// per-call scratch of the synchronous host entry points
+struct Slot {
+    bool busy = false;
+    hipStream_t stream = nullptr;
+    void *buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void *h_res = nullptr;             // page-locked result block of the fused per-batch kernel (the kernel stores into it)
+    void *d_res = nullptr;             // its device-side address
+    size_t res_cap = 0;
+};
+
+// epistasis / MDR state: the vcf2epi dataset on the device, its bit planes for the current folds
+struct EpiState {
+    bool have_data = false, have_folds = false;
+    int V = 0, nA = 0, nU = 0, num_folds = 0, W = 0, V_alloc = 0, n_chunks = 0;
+    uint8_t *d_data = nullptr;
+    uint32_t *d_planes = nullptr;
+    uint32_t *d_marg = nullptr;       // per SNP and (fold, class) group: samples with genotype 0 / 1 (16 bits each)
+    bool complete = false;            // the dataset holds no call other than 0 / 1 / 2
+    hpgv::EpiChunk *d_chunks = nullptr;
+    hpgv::EpiFold *d_folds = nullptr;
+    uint32_t *d_group_w0 = nullptr;
+    std::vector<int32_t> group_size;
+    hpgv::EpiCand *d_cand = nullptr;
+    unsigned *d_cand_count = nullptr;
+    unsigned cand_cap = 0;
+    double *d_thr = nullptr;
+    unsigned *d_tile_base = nullptr;
+    size_t tile_base_cap = 0;
+};
+
+struct hpgv_ctx {
+    int device = 0;
+    mutable std::string err;
+    std::mutex mu;
+    // options
+    long row_align = 16;
+    long row_pad = 0;          // extra bytes (multiple of 16) appended to every row; pitch exploration knob
+    long vpw = 2;
+    long nontemporal = 1;
+    long profile = 0;
+    std::mutex alias_mu;
+    std::vector<std::pair<const char *, const char *>> text_alias;   // host text buffer -> the same text already on the device
+    long scan_unroll = 4;
+    long persistent = 0;       // 0: one wave per vpw consecutive rows; 1: persistent strided grid
+    long blocks_per_cu = 8;
+    long pipeline = 1;         // 1: software-pipelined scan (loads of the next tile before counting this one)
+    long pipe_waves = 4;       // register budget of the pipelined scan, as waves per SIMD (4, 6 or 8)
+    long fisher_cut_exp = 22;  // Fisher tails stop after a round whose terms are all below 10^-this of the tail's largest term
+    long epi_complete = 1;     // epistasis pair scan on a dataset without missing calls: count four cells, derive the other five
+    long epi_triples_1pass = 1; // epistasis triple ranking with at most 10 folds: one pass, all folds' counts in registers (one wave per SIMD)
+    long scan_lds = 0;         // bytes of (unused) LDS per workgroup of the stats / tdt scans: caps the waves in flight per CU
+    long batch_fused = 1;      // per-batch host entry points: one fused kernel per call (0: copy + layout + scan + statistics kernels)
+    long batch_lds_max = 65536;   // largest raw-row window the fused kernel stages in LDS (raised at hpgv_create when the device allows)
+    int n_cus = 256;
+    // assoc
+    Layout assoc;
+    int nA = 0, nU = 0, chunksA = 0;
+    // tdt
+    Layout tdt;
+    hpgv::TdtPlan tdt_plan;
+    // stats
+    Layout stats;
+    Layout sgroups;                       // [group 0 | pad16 | group 1 | ...]
+    std::vector<uint32_t> sg_off;         // byte offset of every group's segment in the row
+    std::vector<int> sg_size;             // samples per group
+    // mendelian errors
+    Layout mendel;
+    int mendel_trios = 0, mendel_pchunks = 0;
+    hpgv::MendelLuts mendel_luts{};
+    uint8_t *d_mendel_male = nullptr;
+    // fisher
+    double *d_lf = nullptr;
+    size_t n_lf = 0;
+    size_t cap_lf = 0;                 // doubles behind d_lf (kept across tables: hipFree waits for the whole device)
+    // synth scratch
+    uint32_t *d_thr = nullptr;
+    size_t thr_cap = 0;
+    // profiling
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool have_scan_ev = false, have_stats_ev = false;
+    std::vector<Slot *> slots;
+    uint32_t *d_sink = nullptr;
+    // tokenizer scratch (newline counts per 4 KiB tile, line offsets), one set per stream that has
+    // tokenized: calls on one stream are ordered by the stream, calls on different streams run
+    // concurrently on the device and must not share it.  The table is guarded by tok_mu.
+    struct TokScratch {
+        hipStream_t stream = nullptr;
+        int *d_blocks = nullptr; size_t blocks_cap = 0;
+        unsigned long long *d_line_off = nullptr; size_t line_cap = 0;
+    };
+    std::mutex tok_mu;
+    std::vector<TokScratch *> tok_scratch;
+    // record filters of the text entry points (hpgv_set_text_filters); negative = off
+    double filt_min_maf = -1.0, filt_max_missing = -1.0;
+    long filt_max_mendel = -1;
+    // epistasis (calls are serialised by epi_mu)
+    std::mutex epi_mu;
+    EpiState epi;
+};
+
+namespace {
+
+[[maybe_unused]] int fail(const hpgv_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(ctx, HPGV_ERR_HIP, "%s failed: %s (%s:%d)", #call,                  \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                         \
+    } while (0)
+
+// makes ctx->device current for the scope of one API call
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+            changed = (hipSetDevice(dev) == hipSuccess);
+        }
+    }
+    ~DeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+};
+
+[[maybe_unused]] size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+[[maybe_unused]] int upload_layout(hpgv_ctx *ctx, Layout &L) {
+    // the table is kept when it is large enough: hipFree waits for every stream of the device, and a file run sets its
+    // cohort while the decoder of the bgzip text is busy on streams of its own
+    const size_t need = L.col_of_pos.size() * sizeof(int32_t);
+    if (L.d_cap < need) {
+        if (L.d_col_of_pos) { (void)hipFree(L.d_col_of_pos); L.d_col_of_pos = nullptr; L.d_cap = 0; }
+        HIPCHK(ctx, hipMalloc(&L.d_col_of_pos, need));
+        L.d_cap = need;
+    }
+    HIPCHK(ctx, hipMemcpy(L.d_col_of_pos, L.col_of_pos.data(), L.col_of_pos.size() * sizeof(int32_t),
+                          hipMemcpyHostToDevice));
+    L.chunks = (int)(L.pitch / 16);
+    L.set = true;
+    return HPGV_OK;
+}
+
+// packed per-lane 16-bit partial sums bound the row length (hpgv_kernels.h)
+constexpr int kScanUnroll = 8;       // unroll of the tdt/stats scans
+constexpr int kMaxUnroll = 16;       // largest assoc unroll option
+[[maybe_unused]] bool pitch_supported(size_t pitch) { return pitch / 16 / 64 + kMaxUnroll + 1 <= 2047; }
+
+[[maybe_unused]] int ensure(hpgv_ctx *ctx, Slot *s, int idx, size_t bytes) {
+    if (s->cap[idx] >= bytes) return HPGV_OK;
+    if (s->buf[idx]) { (void)hipFree(s->buf[idx]); s->buf[idx] = nullptr; s->cap[idx] = 0; }
+    size_t want = round_up(bytes + bytes / 4, 256);
+    HIPCHK(ctx, hipMalloc(&s->buf[idx], want));
+    s->cap[idx] = want;
+    return HPGV_OK;
+}
+
+[[maybe_unused]] int acquire_slot(hpgv_ctx *ctx, Slot **out) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (Slot *s : ctx->slots)
+        if (!s->busy) { s->busy = true; *out = s; return HPGV_OK; }
+    Slot *s = new (std::nothrow) Slot();
+    if (!s) return fail(ctx, HPGV_ERR_NOMEM, "out of host memory");
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete s; return fail(ctx, HPGV_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    s->busy = true;
+    ctx->slots.push_back(s);
+    *out = s;
+    return HPGV_OK;
+}
+[[maybe_unused]] void release_slot(hpgv_ctx *ctx, Slot *s) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    s->busy = false;
+}
+struct SlotLease {
+    hpgv_ctx *ctx; Slot *s = nullptr;
+    explicit SlotLease(hpgv_ctx *c) : ctx(c) {}
+    ~SlotLease() { if (s) release_slot(ctx, s); }
+};
+
+template <typename F>
+[[maybe_unused]] int launch_profiled(hpgv_ctx *ctx, hipStream_t st, int which /*0 scan,1 stats*/, F &&launch) {
+    if (ctx->profile) HIPCHK(ctx, hipEventRecord(ctx->ev[2 * which], st));
+    launch();
+    HIPCHK(ctx, hipGetLastError());
+    if (ctx->profile) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev[2 * which + 1], st));
+        (which == 0 ? ctx->have_scan_ev : ctx->have_stats_ev) = true;
+    }
+    return HPGV_OK;
+}
+
+}  // namespace
+
+
+// defined in hpgv_epi_capi.hip
+void hpgv_epi_release(EpiState &E);

@@ -262,7 +262,19 @@ __device__ __forceinline__ double assoc_odds(int A1, int A2, int U1, int U2) {
     return (A2 == 0 || U1 == 0) ? __builtin_nan("") : ((double)A1 / A2) * ((double)U2 / U1);
 }
 
-__global__ __launch_bounds__(256) void k_assoc_chisq(const int4 *__restrict__ counts, int n,
+// (a, c, b, d) = (A1, A2, U1, U2): the argument order of assoc.c:61 is (A1, U1, A2, U2)
+__device__ __forceinline__ double assoc_chisq_value(int a, int c, int b, int d) {
+    const double total = a + c + b + d;
+    const double t_aff = a + c, t_un = b + d, t_1 = a + b, t_2 = c + d;
+    const double e_a1 = (t_aff * t_1) / total;
+    const double e_a2 = (t_aff * t_2) / total;
+    const double e_u1 = (t_un * t_1) / total;
+    const double e_u2 = (t_un * t_2) / total;
+    return ((a - e_a1) * (a - e_a1)) / e_a1 + ((c - e_a2) * (c - e_a2)) / e_a2 +
+           ((b - e_u1) * (b - e_u1)) / e_u1 + ((d - e_u2) * (d - e_u2)) / e_u2;
+}
+
+static __global__ __launch_bounds__(256) void k_assoc_chisq(const int4 *__restrict__ counts, int n,
                                                      double *__restrict__ odds,
                                                      double *__restrict__ chisq,
                                                      double *__restrict__ pval) {
@@ -270,14 +282,7 @@ __global__ __launch_bounds__(256) void k_assoc_chisq(const int4 *__restrict__ co
     if (i >= n) return;
     const int4 c4 = counts[i];
     const int a = c4.x, c = c4.y, b = c4.z, d = c4.w;   // assoc.c:61: (A1, U1, A2, U2)
-    const double total = a + c + b + d;
-    const double t_aff = a + c, t_un = b + d, t_1 = a + b, t_2 = c + d;
-    const double e_a1 = (t_aff * t_1) / total;
-    const double e_a2 = (t_aff * t_2) / total;
-    const double e_u1 = (t_un * t_1) / total;
-    const double e_u2 = (t_un * t_2) / total;
-    const double x = ((a - e_a1) * (a - e_a1)) / e_a1 + ((c - e_a2) * (c - e_a2)) / e_a2 +
-                     ((b - e_u1) * (b - e_u1)) / e_u1 + ((d - e_u2) * (d - e_u2)) / e_u2;
+    const double x = assoc_chisq_value(a, c, b, d);
     odds[i] = assoc_odds(a, c, b, d);
     chisq[i] = x;
     pval[i] = chisq_p_value(x);
@@ -456,18 +461,9 @@ __device__ __forceinline__ bool fisher_boundary_windows(const FisherTab &T, doub
     return ok;
 }
 
-__global__ __launch_bounds__(256) void k_assoc_fisher(const int4 *__restrict__ counts, int n,
-                                                      const double *__restrict__ lf,
-                                                      double *__restrict__ odds,
-                                                      double *__restrict__ pval, double rel_cut) {
-    __shared__ double exp_tab[64];
-    if (threadIdx.x < 64) exp_tab[threadIdx.x] = k_exp2_j64[threadIdx.x];
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (v >= n) return;
-    const int4 c4 = counts[v];
-    const int a = c4.x, b = c4.y, c = c4.z, d = c4.w;   // assoc.c:70: (A1, A2, U1, U2)
+// the whole wave computes the two-sided p of the table (a, b, c, d) = (A1, A2, U1, U2) (assoc.c:70); every lane returns it
+__device__ __forceinline__ double fisher_wave(int a, int b, int c, int d, const double *__restrict__ lf,
+                                              const double *exp_tab /* LDS */, double rel_cut, int lane) {
     const int r1 = a + b, r2 = c + d, c1 = a + c, nn = r1 + r2;
     const int lo = (c1 - r2) > 0 ? (c1 - r2) : 0;
     const int hi = r1 < c1 ? r1 : c1;
@@ -500,9 +496,25 @@ __global__ __launch_bounds__(256) void k_assoc_fisher(const int4 *__restrict__ c
         else fisher_boundaries(T, thr, L1, R1, L2, R2, lane, &xL, &xR);
         sum = fisher_tails(T, xL, xR, lo, hi, lane, rel_cut);
     }
+    return sum > 1.0 ? 1.0 : sum;
+}
+
+static __global__ __launch_bounds__(256) void k_assoc_fisher(const int4 *__restrict__ counts, int n,
+                                                      const double *__restrict__ lf,
+                                                      double *__restrict__ odds,
+                                                      double *__restrict__ pval, double rel_cut) {
+    __shared__ double exp_tab[64];
+    if (threadIdx.x < 64) exp_tab[threadIdx.x] = k_exp2_j64[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (v >= n) return;
+    const int4 c4 = counts[v];
+    const int a = c4.x, b = c4.y, c = c4.z, d = c4.w;   // assoc.c:70: (A1, A2, U1, U2)
+    const double p = fisher_wave(a, b, c, d, lf, exp_tab, rel_cut, lane);
     if (lane == 0) {
         odds[v] = assoc_odds(a, b, c, d);
-        pval[v] = sum > 1.0 ? 1.0 : sum;
+        pval[v] = p;
     }
 }
 
@@ -517,7 +529,7 @@ __host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 }
 #define HPGV_SYNTH_SEED 0x4850475631ULL
 
-__global__ void k_synth_thresholds(uint64_t v0, int n, uint32_t *__restrict__ thr) {
+static __global__ void k_synth_thresholds(uint64_t v0, int n, uint32_t *__restrict__ thr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t v = v0 + (uint64_t)i;
@@ -622,7 +634,7 @@ __device__ __forceinline__ uint32_t recode_byte(uint32_t g, int mode, int p16, i
 
 // one thread per 16-byte chunk of the destination row; col_of_pos[p] = VCF column
 // stored at row position p, or -1 for padding (0xFF before recoding).
-__global__ __launch_bounds__(256) void k_synth_layout(uint64_t v0, int n_variants, size_t pitch,
+static __global__ __launch_bounds__(256) void k_synth_layout(uint64_t v0, int n_variants, size_t pitch,
                                                       int chunks, const int32_t *__restrict__ col_of_pos,
                                                       const uint32_t *__restrict__ thr, int mode, int p16,
                                                       uint8_t *__restrict__ dst) {
@@ -655,7 +667,7 @@ __global__ __launch_bounds__(256) void k_synth_layout(uint64_t v0, int n_variant
 // strict != 0 turns any byte with a missing allele into 0xFF first (assoc / tdt
 // drop such genotypes: assoc.c:53, tdt.c:103-108,154).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_layout(const uint8_t *__restrict__ src, size_t src_pitch,
+static __global__ __launch_bounds__(256) void k_layout(const uint8_t *__restrict__ src, size_t src_pitch,
                                                 int n_variants, size_t pitch, int chunks,
                                                 const int32_t *__restrict__ col_of_pos, int strict,
                                                 int mode, int p16, uint8_t *__restrict__ dst) {
@@ -683,7 +695,7 @@ __global__ __launch_bounds__(256) void k_layout(const uint8_t *__restrict__ src,
 }
 
 // de-interleave helpers for the host entry points
-__global__ void k_counts_to_soa(const int4 *__restrict__ counts, int n, int32_t *A1, int32_t *A2,
+static __global__ void k_counts_to_soa(const int4 *__restrict__ counts, int n, int32_t *A1, int32_t *A2,
                                 int32_t *U1, int32_t *U2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

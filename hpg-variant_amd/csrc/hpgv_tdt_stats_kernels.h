@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_tdt_scan(const uint8_t *__restrict__ gt
 }
 
 // tdt.c:255-260 (integer square before the cast) and tdt.c:288-292
-__global__ __launch_bounds__(256) void k_tdt_stats(const int2 *__restrict__ tu, int n, double *__restrict__ odds,
+static __global__ __launch_bounds__(256) void k_tdt_stats(const int2 *__restrict__ tu, int n, double *__restrict__ odds,
                                                    double *__restrict__ chisq, double *__restrict__ pval) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void k_stats_scan_hs(const uint8_t *__restrict
 // SWAR lanes (SB <= 255 so no byte overflows), then 16 atomics per lane.
 // ---------------------------------------------------------------------------
 constexpr int SAMPLE_STATS_ROWS = 128;
-__global__ __launch_bounds__(256) void k_sample_missing(const uint8_t *__restrict__ gt, size_t pitch, int n_variants,
+static __global__ __launch_bounds__(256) void k_sample_missing(const uint8_t *__restrict__ gt, size_t pitch, int n_variants,
                                                         int chunks, int n_samples, int32_t *__restrict__ missing) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);     // column tile
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void k_sample_missing(const uint8_t *__restric
 // atomics.  Meant for the few multi-allelic variants the flag scan reports
 // (cells 0/0..1/1 do not add up), not for the bulk.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_genotype_table(const uint8_t *__restrict__ raw, size_t src_pitch,
+static __global__ __launch_bounds__(256) void k_genotype_table(const uint8_t *__restrict__ raw, size_t src_pitch,
                                                         int n_samples, const int32_t *__restrict__ variant_idx,
                                                         int n_idx, int32_t *__restrict__ table) {
     __shared__ int hist[256];
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void k_mendel_scan(const uint8_t *__restrict__
 }
 
 // per-child error counts: tile of 1024 trios x SAMPLE_STATS_ROWS variants, SWAR byte lanes, atomics at the end
-__global__ __launch_bounds__(256) void k_mendel_children(const uint8_t *__restrict__ gt, size_t pitch, int n_variants,
+static __global__ __launch_bounds__(256) void k_mendel_children(const uint8_t *__restrict__ gt, size_t pitch, int n_variants,
                                                          int pchunks, int n_trios, MendelLuts luts,
                                                          const uint8_t *__restrict__ male_plane,
                                                          const uint8_t *__restrict__ is_x, int32_t *__restrict__ child_errors) {
@@ -737,7 +737,7 @@ inline void build_luts(MendelLuts &out) {
 //   maf        = min(allele0, allele1) / (allele0 + allele1)      (0 when no allele is called)
 //   missing    = missing_genotypes / n_samples
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stats_filter(const int4 *__restrict__ in8, int n, int n_samples,
+static __global__ __launch_bounds__(256) void k_stats_filter(const int4 *__restrict__ in8, int n, int n_samples,
                                                       double min_maf, double max_maf, double max_missing,
                                                       uint8_t *__restrict__ keep) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(256) void k_stats_filter(const int4 *__restrict__ i
 
 // Hardy-Weinberg chi-square on (n_AA, n_Aa, n_aa) = (n_00, n_01 + n_10, n_11);
 // definition: oracle/hpgv_oracle.c orc_hwe (hpg-libs body absent: unpinned)
-__global__ __launch_bounds__(256) void k_stats_hwe(const int4 *__restrict__ in8, int n, double *__restrict__ chi2,
+static __global__ __launch_bounds__(256) void k_stats_hwe(const int4 *__restrict__ in8, int n, double *__restrict__ chi2,
                                                    double *__restrict__ pval) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

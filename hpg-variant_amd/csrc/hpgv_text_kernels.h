@@ -36,7 +36,7 @@ __device__ __forceinline__ uint32_t tok_newlines16(const char *__restrict__ text
     return m;
 }
 
-__global__ __launch_bounds__(256) void k_tok_count(const char *__restrict__ text, size_t n, int *__restrict__ block_counts) {
+static __global__ __launch_bounds__(256) void k_tok_count(const char *__restrict__ text, size_t n, int *__restrict__ block_counts) {
     __shared__ int s[4];
     const size_t base = (size_t)blockIdx.x * TOK_TILE + (size_t)threadIdx.x * 16;
     int c = __popc(tok_newlines16(text, base, n));
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_tok_count(const char *__restrict__ text
 }
 
 // single workgroup: exclusive scan of block_counts in place; n_lines = newlines (+1 for an unterminated tail)
-__global__ __launch_bounds__(256) void k_tok_scan(int *__restrict__ block_counts, int n_blocks, const char *__restrict__ text,
+static __global__ __launch_bounds__(256) void k_tok_scan(int *__restrict__ block_counts, int n_blocks, const char *__restrict__ text,
                                                   size_t n, int *__restrict__ n_lines,
                                                   unsigned long long *__restrict__ line_off, int max_lines) {
     __shared__ int s[256];
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_tok_scan(int *__restrict__ block_counts
 }
 
 // line_off[k] = start of line k; line_off[n_lines] = end of text (one past the last newline or n)
-__global__ __launch_bounds__(256) void k_tok_mark(const char *__restrict__ text, size_t n, const int *__restrict__ block_offsets,
+static __global__ __launch_bounds__(256) void k_tok_mark(const char *__restrict__ text, size_t n, const int *__restrict__ block_offsets,
                                                   unsigned long long *__restrict__ line_off, int max_lines) {
     __shared__ int s[4];
     const size_t base = (size_t)blockIdx.x * TOK_TILE + (size_t)threadIdx.x * 16;
@@ -153,7 +153,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int *s4, int *total) {
 
 // status per line: 0 ok, 1 fewer than 9 TABs (no sample columns), 2 FORMAT has no GT,
 // 3 fewer sample fields than n_samples (the missing ones are 0xFF)
-__global__ __launch_bounds__(256) void k_tok_parse(const char *__restrict__ text, const unsigned long long *__restrict__ line_off,
+static __global__ __launch_bounds__(256) void k_tok_parse(const char *__restrict__ text, const unsigned long long *__restrict__ line_off,
                                                    const int *__restrict__ n_lines_p, int max_lines, int n_samples, int strict,
                                                    uint8_t *__restrict__ gt, size_t pitch, uint8_t *__restrict__ is_x,
                                                    uint32_t *__restrict__ field_off /* n_lines x 10 */, int *__restrict__ status) {
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void k_tok_parse(const char *__restrict__ text
 // every line for its result records.  head_off[i] = exclusive prefix sum of the head lengths (a head = the line up to
 // the first sample column, or the whole line when it has fewer than ten fields), head_off[n] = total; then the bytes.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_head_offsets(const unsigned long long *__restrict__ line_off, const uint32_t *__restrict__ field_off,
+static __global__ __launch_bounds__(1024) void k_head_offsets(const unsigned long long *__restrict__ line_off, const uint32_t *__restrict__ field_off,
                                                        int n_lines, unsigned long long *__restrict__ head_off) {
     __shared__ unsigned long long part[1024];
     const int t = threadIdx.x;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(1024) void k_head_offsets(const unsigned long long 
         acc += f9 != 0xFFFFFFFFu ? (unsigned long long)f9 : line_off[i + 1] - line_off[i];
     }
 }
-__global__ __launch_bounds__(64) void k_copy_heads(const char *__restrict__ text, const unsigned long long *__restrict__ line_off,
+static __global__ __launch_bounds__(64) void k_copy_heads(const char *__restrict__ text, const unsigned long long *__restrict__ line_off,
                                                    const unsigned long long *__restrict__ head_off, int n_lines, char *__restrict__ heads) {
     const int i = blockIdx.x;
     if (i >= n_lines) return;
