@@ -25,7 +25,7 @@ GT_MISSING = 0xFF
 
 # every symbol include/hpgv.h declares (checked by the CPU suite)
 SYMBOLS = [
-    "hpgv_version", "hpgv_device_count", "hpgv_create", "hpgv_destroy", "hpgv_last_error",
+    "hpgv_version", "hpgv_device_count", "hpgv_create", "hpgv_create_multi", "hpgv_group_size", "hpgv_group_member", "hpgv_member_device", "hpgv_destroy", "hpgv_last_error",
     "hpgv_set_option", "hpgv_set_cohort", "hpgv_assoc_layout", "hpgv_set_families",
     "hpgv_tdt_layout", "hpgv_set_logfact", "hpgv_set_stats_cohort", "hpgv_stats_layout",
     "hpgv_set_stats_groups", "hpgv_stats_groups_layout", "hpgv_stats_scan_group_dev",
@@ -72,6 +72,11 @@ def load():
     L.hpgv_last_error.restype = C.c_char_p
     L.hpgv_last_error.argtypes = [vp]
     L.hpgv_create.argtypes = [i32, C.POINTER(vp)]
+    L.hpgv_create_multi.argtypes = [vp, i32, C.POINTER(vp)]
+    L.hpgv_group_size.argtypes = [vp]
+    L.hpgv_group_member.argtypes = [vp, i32]
+    L.hpgv_group_member.restype = vp
+    L.hpgv_member_device.argtypes = [vp, i32]
     L.hpgv_destroy.argtypes = [vp]
     L.hpgv_destroy.restype = None
     L.hpgv_set_option.argtypes = [vp, C.c_char_p, C.c_long]
@@ -153,11 +158,16 @@ class Engine:
     """One engine context on one device (thin wrapper over hpgv_ctx)."""
 
     def __init__(self, device=0):
+        """device: one device id, or a list of ids for a group context (hpgv_create_multi)."""
         self.L = load()
         h = C.c_void_p()
-        rc = self.L.hpgv_create(device, C.byref(h))
+        if isinstance(device, (list, tuple)):
+            ids = (C.c_int * len(device))(*device)
+            rc = self.L.hpgv_create_multi(ids, len(device), C.byref(h))
+        else:
+            rc = self.L.hpgv_create(device, C.byref(h))
         if rc != OK:
-            raise HpgvError("hpgv_create(%d) -> %d: %s" % (device, rc, self.L.hpgv_last_error(None).decode()))
+            raise HpgvError("hpgv_create(%s) -> %d: %s" % (device, rc, self.L.hpgv_last_error(None).decode()))
         self.h = h
         self.device = device
         self._bufs = []

@@ -136,8 +136,51 @@ int hpgv_create(int device_id, hpgv_ctx **out) {
     return HPGV_OK;
 }
 
+int hpgv_create_multi(const int *device_ids, int n_devices, hpgv_ctx **out) {
+    if (!out) return fail(nullptr, HPGV_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > 64) return fail(nullptr, HPGV_ERR_INVALID, "hpgv_create_multi needs 1..64 device ids");
+    hpgv_ctx *g = new (std::nothrow) hpgv_ctx();
+    if (!g) return fail(nullptr, HPGV_ERR_NOMEM, "out of host memory");
+    for (int i = 0; i < n_devices; ++i) {
+        hpgv_ctx *m = nullptr;
+        const int rc = hpgv_create(device_ids[i], &m);          // the same id twice gives two contexts on one device
+        if (rc != HPGV_OK) {
+            for (hpgv_ctx *c : g->members) { c->parent = nullptr; hpgv_destroy(c); }
+            g->members.clear();
+            delete g;
+            return rc;                                          // hpgv_last_error(NULL) holds the member's text
+        }
+        m->parent = g;
+        g->members.push_back(m);
+    }
+    g->device = g->members[0]->device;
+    *out = g;
+    return HPGV_OK;
+}
+
+int hpgv_group_size(const hpgv_ctx *ctx) { return !ctx ? 0 : (is_group(ctx) ? (int)ctx->members.size() : 1); }
+
+hpgv_ctx *hpgv_group_member(hpgv_ctx *ctx, int i) {
+    if (!ctx) return nullptr;
+    if (!is_group(ctx)) return i == 0 ? ctx : nullptr;
+    return (i >= 0 && i < (int)ctx->members.size()) ? ctx->members[(size_t)i] : nullptr;
+}
+
+int hpgv_member_device(const hpgv_ctx *ctx, int i) {
+    if (!ctx) return -1;
+    if (!is_group(ctx)) return i == 0 ? ctx->device : -1;
+    return (i >= 0 && i < (int)ctx->members.size()) ? ctx->members[(size_t)i]->device : -1;
+}
+
 void hpgv_destroy(hpgv_ctx *ctx) {
     if (!ctx) return;
+    if (is_group(ctx)) {
+        for (hpgv_ctx *m : ctx->members) { m->parent = nullptr; hpgv_destroy(m); }
+        ctx->members.clear();
+        delete ctx;
+        return;
+    }
     DeviceGuard g(ctx->device);
     (void)hipDeviceSynchronize();
     if (ctx->d_mendel_male) (void)hipFree(ctx->d_mendel_male);
@@ -165,6 +208,7 @@ void hpgv_destroy(hpgv_ctx *ctx) {
 }
 
 int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
+    GROUP_ALL(ctx, hpgv_set_option(m_, key, value))
     if (!ctx || !key) return HPGV_ERR_INVALID;
     if (!strcmp(key, "row_align")) {
         if (value < 16 || (value & (value - 1))) return fail(ctx, HPGV_ERR_INVALID, "row_align must be a power of two >= 16");
@@ -218,6 +262,7 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
 /* ---- cohort ---------------------------------------------------------------- */
 
 int hpgv_set_cohort(hpgv_ctx *ctx, const uint8_t *condition, int n_samples) {
+    GROUP_ALL(ctx, hpgv_set_cohort(m_, condition, n_samples))
     if (!ctx) return HPGV_ERR_INVALID;
     if (!condition || n_samples < 0) return fail(ctx, HPGV_ERR_INVALID, "bad cohort arguments");
     DeviceGuard g(ctx->device);
@@ -244,6 +289,7 @@ int hpgv_set_cohort(hpgv_ctx *ctx, const uint8_t *condition, int n_samples) {
 }
 
 int hpgv_assoc_layout(const hpgv_ctx *ctx, int *n_affected, int *n_unaffected, size_t *pitch) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->assoc.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_cohort has not been called");
     if (n_affected) *n_affected = ctx->nA;
@@ -253,6 +299,7 @@ int hpgv_assoc_layout(const hpgv_ctx *ctx, int *n_affected, int *n_unaffected, s
 }
 
 int hpgv_set_logfact(hpgv_ctx *ctx, const double *table, size_t n) {
+    GROUP_ALL(ctx, hpgv_set_logfact(m_, table, n))
     if (!ctx) return HPGV_ERR_INVALID;
     if (!table || n == 0) return fail(ctx, HPGV_ERR_INVALID, "empty log-factorial table");
     DeviceGuard g(ctx->device);
@@ -268,6 +315,7 @@ int hpgv_set_logfact(hpgv_ctx *ctx, const double *table, size_t n) {
 }
 
 int hpgv_set_stats_cohort(hpgv_ctx *ctx, int n_samples) {
+    GROUP_ALL(ctx, hpgv_set_stats_cohort(m_, n_samples))
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_samples < 0) return fail(ctx, HPGV_ERR_INVALID, "negative n_samples");
     DeviceGuard g(ctx->device);
@@ -283,6 +331,7 @@ int hpgv_set_stats_cohort(hpgv_ctx *ctx, int n_samples) {
 }
 
 int hpgv_set_stats_groups(hpgv_ctx *ctx, const int32_t *group_of_sample, int n_samples, int n_groups) {
+    GROUP_ALL(ctx, hpgv_set_stats_groups(m_, group_of_sample, n_samples, n_groups))
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_samples < 0 || n_groups < 1 || n_groups > 4096 || (n_samples > 0 && !group_of_sample))
         return fail(ctx, HPGV_ERR_INVALID, "bad stats group arguments");
@@ -311,6 +360,7 @@ int hpgv_set_stats_groups(hpgv_ctx *ctx, const int32_t *group_of_sample, int n_s
 }
 
 int hpgv_stats_groups_layout(const hpgv_ctx *ctx, size_t *pitch, int *group_sizes) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->sgroups.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_groups has not been called");
     if (pitch) *pitch = ctx->sgroups.pitch;
@@ -319,6 +369,7 @@ int hpgv_stats_groups_layout(const hpgv_ctx *ctx, size_t *pitch, int *group_size
 }
 
 int hpgv_stats_layout(const hpgv_ctx *ctx, size_t *pitch) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->stats.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");
     if (pitch) *pitch = ctx->stats.pitch;
@@ -328,6 +379,7 @@ int hpgv_stats_layout(const hpgv_ctx *ctx, size_t *pitch) {
 int hpgv_set_families(hpgv_ctx *ctx, int n_samples, int n_families, const int32_t *father_col,
                       const int32_t *mother_col, const int32_t *child_off, const int32_t *child_col,
                       const uint8_t *child_sex) {
+    GROUP_ALL(ctx, hpgv_set_families(m_, n_samples, n_families, father_col, mother_col, child_off, child_col, child_sex))
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_samples < 0 || n_families < 0 || (n_families > 0 && (!father_col || !mother_col || !child_off)))
         return fail(ctx, HPGV_ERR_INVALID, "bad family arguments");
@@ -344,6 +396,7 @@ int hpgv_set_families(hpgv_ctx *ctx, int n_samples, int n_families, const int32_
 
 int hpgv_set_pedigree(hpgv_ctx *ctx, int n_samples, int n_trios, const int32_t *father_col, const int32_t *mother_col,
                       const int32_t *child_col, const uint8_t *child_sex) {
+    GROUP_ALL(ctx, hpgv_set_pedigree(m_, n_samples, n_trios, father_col, mother_col, child_col, child_sex))
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_samples < 0 || n_trios < 0 || (n_trios > 0 && (!father_col || !mother_col || !child_col || !child_sex)))
         return fail(ctx, HPGV_ERR_INVALID, "bad pedigree arguments");
@@ -377,6 +430,7 @@ int hpgv_set_pedigree(hpgv_ctx *ctx, int n_samples, int n_trios, const int32_t *
 }
 
 int hpgv_mendel_layout(const hpgv_ctx *ctx, size_t *pitch) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->mendel.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_pedigree has not been called");
     if (pitch) *pitch = ctx->mendel.pitch;
@@ -384,6 +438,7 @@ int hpgv_mendel_layout(const hpgv_ctx *ctx, size_t *pitch) {
 }
 
 int hpgv_tdt_layout(const hpgv_ctx *ctx, int *n_trios_fast, int *n_families_slow, size_t *pitch) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->tdt.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_families has not been called");
     if (n_trios_fast) *n_trios_fast = ctx->tdt_plan.n_fast;
@@ -395,12 +450,14 @@ int hpgv_tdt_layout(const hpgv_ctx *ctx, int *n_trios_fast, int *n_families_slow
 /* ---- memory ---------------------------------------------------------------- */
 
 int hpgv_dev_alloc(hpgv_ctx *ctx, size_t bytes, void **dptr) {
+    ctx = first_member(ctx);
     if (!ctx || !dptr) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);
     HIPCHK(ctx, hipMalloc(dptr, bytes ? bytes : 16));
     return HPGV_OK;
 }
 int hpgv_dev_free(hpgv_ctx *ctx, void *dptr) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);
     if (dptr) HIPCHK(ctx, hipFree(dptr));
@@ -409,6 +466,7 @@ int hpgv_dev_free(hpgv_ctx *ctx, void *dptr) {
 // NUMA node the device hangs off (sysfs numa_node of its PCI function), -1 when the system does not say: a host that
 // stages batches for the device does best with its staging threads and page-locked buffers on that node
 int hpgv_device_numa_node(hpgv_ctx *ctx, int *node) {
+    ctx = first_member(ctx);
     if (!ctx || !node) return HPGV_ERR_INVALID;
     *node = -1;
     char bus[64] = {0};
@@ -425,6 +483,7 @@ int hpgv_device_numa_node(hpgv_ctx *ctx, int *node) {
 }
 // a stream of the caller's own (non-blocking), e.g. for copies that should overlap the engine's work
 int hpgv_stream_create(hpgv_ctx *ctx, void **stream) {
+    ctx = first_member(ctx);
     if (!ctx || !stream) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);
     hipStream_t st = nullptr;
@@ -433,6 +492,7 @@ int hpgv_stream_create(hpgv_ctx *ctx, void **stream) {
     return HPGV_OK;
 }
 int hpgv_stream_destroy(hpgv_ctx *ctx, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);
     if (stream) HIPCHK(ctx, hipStreamDestroy((hipStream_t)stream));
@@ -442,6 +502,7 @@ int hpgv_stream_destroy(hpgv_ctx *ctx, void *stream) {
 // instead of copying host_text over (d_text = NULL takes the entry away).  For readers that produce the text on the
 // device (hpgv_inflate_blocks_dev) and keep a host copy for the result writers.
 int hpgv_text_alias(hpgv_ctx *ctx, const char *host_text, const char *d_text) {
+    ctx = first_member(ctx);
     if (!ctx || !host_text) return HPGV_ERR_INVALID;
     std::lock_guard<std::mutex> lk(ctx->alias_mu);
     for (size_t i = 0; i < ctx->text_alias.size(); ++i)
@@ -454,19 +515,27 @@ static const char *text_on_device(hpgv_ctx *ctx, const char *host_text) {
     for (const auto &a : ctx->text_alias) if (a.first == host_text) return a.second;
     return nullptr;
 }
+// the member of a group on whose device `host_text` has been declared resident (hpgv_text_alias), or nullptr
+static hpgv_ctx *alias_owner(hpgv_ctx *group, const char *host_text) {
+    for (hpgv_ctx *m : group->members) if (text_on_device(m, host_text)) return m;
+    return nullptr;
+}
 int hpgv_host_alloc(hpgv_ctx *ctx, size_t bytes, void **hptr) {
+    ctx = first_member(ctx);
     if (!ctx || !hptr) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);
-    HIPCHK(ctx, hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocDefault));
+    HIPCHK(ctx, hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocPortable));     // visible to every device of a group
     return HPGV_OK;
 }
 int hpgv_host_free(hpgv_ctx *ctx, void *hptr) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);
     if (hptr) HIPCHK(ctx, hipHostFree(hptr));
     return HPGV_OK;
 }
 int hpgv_memcpy_h2d(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);
     HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
@@ -474,6 +543,7 @@ int hpgv_memcpy_h2d(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, voi
     return HPGV_OK;
 }
 int hpgv_memcpy_d2h(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);
     HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -481,6 +551,7 @@ int hpgv_memcpy_d2h(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, voi
     return HPGV_OK;
 }
 int hpgv_stream_sync(hpgv_ctx *ctx, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize((hipStream_t)stream));
@@ -512,6 +583,7 @@ static void recode_of(const hpgv_ctx *ctx, int which, int *mode, int *p16) {
 
 int hpgv_layout_dev(hpgv_ctx *ctx, int which, const uint8_t *d_src, size_t src_pitch, int n_variants,
                     uint8_t *d_dst, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     Layout *L = pick_layout(ctx, which);
     if (!L) return fail(ctx, HPGV_ERR_INVALID, "unknown layout %d", which);
@@ -567,6 +639,7 @@ static int synth_common(hpgv_ctx *ctx, uint64_t v0, int n_variants, size_t pitch
 }
 
 int hpgv_synth_dev(hpgv_ctx *ctx, int which, uint64_t v0, int n_variants, uint8_t *d_dst, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     Layout *L = pick_layout(ctx, which);
     if (!L) return fail(ctx, HPGV_ERR_INVALID, "unknown layout %d", which);
@@ -582,6 +655,7 @@ int hpgv_synth_dev(hpgv_ctx *ctx, int which, uint64_t v0, int n_variants, uint8_
 
 int hpgv_synth_raw_dev(hpgv_ctx *ctx, uint64_t v0, int n_variants, int n_samples, size_t pitch,
                        uint8_t *d_dst, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_variants < 0 || n_samples < 0 || pitch % 16 || pitch < (size_t)n_samples || (n_variants > 0 && !d_dst))
         return fail(ctx, HPGV_ERR_INVALID, "bad synth_raw arguments (pitch must be a multiple of 16 >= n_samples)");
@@ -607,6 +681,7 @@ int hpgv_synth_raw_dev(hpgv_ctx *ctx, uint64_t v0, int n_variants, int n_samples
 
 int hpgv_assoc_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, const uint8_t *d_is_x,
                         int32_t *d_counts, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->assoc.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_cohort has not been called");
     if (n_variants < 0 || (n_variants > 0 && (!d_gt || !d_counts))) return fail(ctx, HPGV_ERR_INVALID, "bad scan arguments");
@@ -670,6 +745,7 @@ int hpgv_assoc_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, cons
 
 int hpgv_assoc_chisq_dev(hpgv_ctx *ctx, const int32_t *d_counts, int n_variants, double *d_odds,
                          double *d_chisq, double *d_p, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_variants < 0 || (n_variants > 0 && (!d_counts || !d_odds || !d_chisq || !d_p)))
         return fail(ctx, HPGV_ERR_INVALID, "bad chisq arguments");
@@ -684,6 +760,7 @@ int hpgv_assoc_chisq_dev(hpgv_ctx *ctx, const int32_t *d_counts, int n_variants,
 
 int hpgv_assoc_fisher_dev(hpgv_ctx *ctx, const int32_t *d_counts, int n_variants, double *d_odds,
                           double *d_p, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_variants < 0 || (n_variants > 0 && (!d_counts || !d_odds || !d_p)))
         return fail(ctx, HPGV_ERR_INVALID, "bad fisher arguments");
@@ -703,6 +780,7 @@ int hpgv_assoc_fisher_dev(hpgv_ctx *ctx, const int32_t *d_counts, int n_variants
 
 int hpgv_tdt_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, const uint8_t *d_is_x,
                       int32_t *d_tu, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->tdt.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_families has not been called");
     if (n_variants < 0 || (n_variants > 0 && (!d_gt || !d_tu))) return fail(ctx, HPGV_ERR_INVALID, "bad scan arguments");
@@ -718,6 +796,7 @@ int hpgv_tdt_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, const 
 
 int hpgv_tdt_stats_dev(hpgv_ctx *ctx, const int32_t *d_tu, int n_variants, double *d_odds,
                        double *d_chisq, double *d_p, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_variants < 0 || (n_variants > 0 && (!d_tu || !d_odds || !d_chisq || !d_p)))
         return fail(ctx, HPGV_ERR_INVALID, "bad tdt stats arguments");
@@ -733,6 +812,7 @@ int hpgv_tdt_stats_dev(hpgv_ctx *ctx, const int32_t *d_tu, int n_variants, doubl
 /* ---- stats ----------------------------------------------------------------- */
 
 int hpgv_stats_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, int32_t *d_counts8, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->stats.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");
     if (n_variants < 0 || (n_variants > 0 && (!d_gt || !d_counts8))) return fail(ctx, HPGV_ERR_INVALID, "bad scan arguments");
@@ -760,6 +840,7 @@ int hpgv_stats_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, int3
 }
 
 int hpgv_stats_scan_group_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, int group, int32_t *d_counts8, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->sgroups.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_groups has not been called");
     if (group < 0 || (size_t)group >= ctx->sg_off.size()) return fail(ctx, HPGV_ERR_INVALID, "group %d out of range", group);
@@ -791,6 +872,7 @@ int hpgv_stats_scan_group_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants
 
 int hpgv_stats_hwe_dev(hpgv_ctx *ctx, const int32_t *d_counts8, int n_variants, double *d_chi2,
                        double *d_p, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_variants < 0 || (n_variants > 0 && (!d_counts8 || !d_chi2 || !d_p)))
         return fail(ctx, HPGV_ERR_INVALID, "bad hwe arguments");
@@ -804,6 +886,7 @@ int hpgv_stats_hwe_dev(hpgv_ctx *ctx, const int32_t *d_counts8, int n_variants, 
 }
 
 int hpgv_mendel_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, const uint8_t *d_is_x, int32_t *d_errors, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->mendel.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_pedigree has not been called");
     if (n_variants < 0 || (n_variants > 0 && (!d_gt || !d_errors))) return fail(ctx, HPGV_ERR_INVALID, "bad scan arguments");
@@ -826,6 +909,7 @@ int hpgv_mendel_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, con
 
 int hpgv_mendel_children_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, const uint8_t *d_is_x,
                              int32_t *d_child_errors, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->mendel.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_pedigree has not been called");
     if (n_variants < 0 || (n_variants > 0 && (!d_gt || !d_child_errors))) return fail(ctx, HPGV_ERR_INVALID, "bad scan arguments");
@@ -842,6 +926,7 @@ int hpgv_mendel_children_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants,
 
 int hpgv_stats_filter_dev(hpgv_ctx *ctx, const int32_t *d_counts8, int n_variants, double min_maf, double max_maf,
                           double max_missing, uint8_t *d_keep, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->stats.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");
     if (n_variants < 0 || (n_variants > 0 && (!d_counts8 || !d_keep))) return fail(ctx, HPGV_ERR_INVALID, "bad filter arguments");
@@ -854,6 +939,7 @@ int hpgv_stats_filter_dev(hpgv_ctx *ctx, const int32_t *d_counts8, int n_variant
 }
 
 int hpgv_sample_missing_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, int32_t *d_missing, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->stats.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");
     if (n_variants < 0 || (n_variants > 0 && (!d_gt || !d_missing))) return fail(ctx, HPGV_ERR_INVALID, "bad sample stats arguments");
@@ -871,6 +957,7 @@ int hpgv_sample_missing_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, 
 
 int hpgv_genotype_table_dev(hpgv_ctx *ctx, const uint8_t *d_raw, size_t src_pitch, int n_samples,
                             const int32_t *d_variant_idx, int n_idx, int32_t *d_table, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_idx < 0 || n_samples < 0 || (n_idx > 0 && (!d_raw || !d_table)) || src_pitch < (size_t)n_samples)
         return fail(ctx, HPGV_ERR_INVALID, "bad genotype table arguments");
@@ -883,6 +970,7 @@ int hpgv_genotype_table_dev(hpgv_ctx *ctx, const uint8_t *d_raw, size_t src_pitc
 }
 
 int hpgv_last_kernel_ms(hpgv_ctx *ctx, float *scan_ms, float *stats_ms) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);
     if (scan_ms) {
@@ -922,6 +1010,7 @@ static int stage_batch(hpgv_ctx *ctx, Slot *s, int which, const Layout &L, const
 
 int hpgv_assoc(hpgv_ctx *ctx, int task, const uint8_t *gt, size_t pitch, int n_variants, const uint8_t *is_x,
                int32_t *A1, int32_t *A2, int32_t *U1, int32_t *U2, double *odds, double *chisq, double *p) {
+    GROUP_DEAL(ctx, hpgv_assoc(m_, task, gt, pitch, n_variants, is_x, A1, A2, U1, U2, odds, chisq, p))
     if (!ctx) return HPGV_ERR_INVALID;
     if (task != HPGV_TASK_CHISQ && task != HPGV_TASK_FISHER) return fail(ctx, HPGV_ERR_INVALID, "task must be CHISQ or FISHER");
     if (!ctx->assoc.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_cohort has not been called");
@@ -991,6 +1080,7 @@ int hpgv_assoc(hpgv_ctx *ctx, int task, const uint8_t *gt, size_t pitch, int n_v
 
 int hpgv_tdt(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, const uint8_t *is_x,
              int32_t *t1, int32_t *t2, double *odds, double *chisq, double *p) {
+    GROUP_DEAL(ctx, hpgv_tdt(m_, gt, pitch, n_variants, is_x, t1, t2, odds, chisq, p))
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->tdt.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_families has not been called");
     if (n_variants < 0 || (n_variants > 0 && (!gt || !t1 || !t2 || !odds || !chisq || !p)))
@@ -1040,6 +1130,7 @@ int hpgv_tdt(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, con
 int hpgv_stats_ex(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, int32_t *counts8,
                   double *hwe_chi2, double *hwe_p, int32_t *sample_missing, int32_t *multi_idx,
                   int32_t *multi_table, int *n_multi) {
+    GROUP_DEAL(ctx, hpgv_stats_ex(m_, gt, pitch, n_variants, counts8, hwe_chi2, hwe_p, sample_missing, multi_idx, multi_table, n_multi))
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->stats.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");
     if (n_variants < 0 || (n_variants > 0 && (!gt || !counts8 || !hwe_chi2 || !hwe_p)))
@@ -1148,6 +1239,7 @@ int hpgv_stats(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, i
 
 int hpgv_stats_groups(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, int32_t *counts8,
                       double *hwe_chi2, double *hwe_p) {
+    GROUP_DEAL(ctx, hpgv_stats_groups(m_, gt, pitch, n_variants, counts8, hwe_chi2, hwe_p))
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->sgroups.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_groups has not been called");
     if (n_variants < 0 || (n_variants > 0 && (!gt || !counts8))) return fail(ctx, HPGV_ERR_INVALID, "bad stats group arguments");
@@ -1180,6 +1272,7 @@ int hpgv_stats_groups(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_vari
 }
 
 int hpgv_epi_dataset(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, uint8_t *out) {
+    GROUP_DEAL(ctx, hpgv_epi_dataset(m_, gt, pitch, n_variants, out))
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->assoc.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_cohort has not been called");
     if (n_variants < 0 || (n_variants > 0 && (!gt || !out))) return fail(ctx, HPGV_ERR_INVALID, "bad epi arguments");
@@ -1204,6 +1297,7 @@ int hpgv_epi_dataset(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_varia
 
 int hpgv_mendel(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, const uint8_t *is_x,
                 int32_t *errors, int32_t *child_errors) {
+    GROUP_DEAL(ctx, hpgv_mendel(m_, gt, pitch, n_variants, is_x, errors, child_errors))
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->mendel.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_pedigree has not been called");
     if (n_variants < 0 || (n_variants > 0 && !gt)) return fail(ctx, HPGV_ERR_INVALID, "bad mendel arguments");
@@ -1243,6 +1337,7 @@ int hpgv_mendel(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, 
 int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
                             const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, uint8_t *d_text,
                             int32_t *d_status, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_blocks < 0 || (n_blocks > 0 && (!d_comp || !d_in_off || !d_in_len || !d_out_off || !d_out_len || !d_text || !d_status)))
         return fail(ctx, HPGV_ERR_INVALID, "bad inflate arguments");
@@ -1257,6 +1352,7 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
 int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int n_samples, int strict,
                       int max_lines, int *d_n_lines, uint64_t *d_line_off, uint32_t *d_field_off,
                       uint8_t *d_gt, size_t pitch, uint8_t *d_is_x, int32_t *d_status, void *stream) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_samples < 0 || max_lines < 0 || !d_n_lines || (text_bytes > 0 && !d_text) ||
         (max_lines > 0 && !d_gt) || pitch < (size_t)n_samples)
@@ -1306,6 +1402,7 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
 int hpgv_tokenize(hpgv_ctx *ctx, const char *text, size_t text_bytes, int n_samples, int strict, int max_lines,
                   int *n_lines, uint64_t *line_off, uint32_t *field_off, uint8_t *gt, size_t pitch,
                   uint8_t *is_x, int32_t *status) {
+    GROUP_DEAL(ctx, hpgv_tokenize(m_, text, text_bytes, n_samples, strict, max_lines, n_lines, line_off, field_off, gt, pitch, is_x, status))
     if (!ctx) return HPGV_ERR_INVALID;
     if (!n_lines || n_samples < 0 || max_lines < 0 || (text_bytes > 0 && !text) || (max_lines > 0 && !gt) ||
         pitch < (size_t)n_samples)
@@ -1432,6 +1529,7 @@ static int text_front(hpgv_ctx *ctx, Slot *s, int which, const Layout &L, const 
 }
 
 int hpgv_set_text_filters(hpgv_ctx *ctx, double min_maf, double max_missing, long max_mendel_errors) {
+    GROUP_ALL(ctx, hpgv_set_text_filters(m_, min_maf, max_missing, max_mendel_errors))
     if (!ctx) return HPGV_ERR_INVALID;
     if (min_maf > 0.5 || max_missing > 1.0) return fail(ctx, HPGV_ERR_INVALID, "min_maf is at most 0.5, max_missing at most 1");
     ctx->filt_min_maf = min_maf; ctx->filt_max_missing = max_missing; ctx->filt_max_mendel = max_mendel_errors;
@@ -1441,6 +1539,10 @@ int hpgv_set_text_filters(hpgv_ctx *ctx, double min_maf, double max_missing, lon
 int hpgv_assoc_text(hpgv_ctx *ctx, int task, const char *text, size_t text_bytes, int max_lines, int *n_lines,
                     uint64_t *line_off, uint32_t *field_off, int32_t *status, int32_t *A1, int32_t *A2,
                     int32_t *U1, int32_t *U2, double *odds, double *chisq, double *p) {
+    if (is_group(ctx)) {
+        if (hpgv_ctx *m_ = alias_owner(ctx, text)) return hpgv_assoc_text(m_, task, text, text_bytes, max_lines, n_lines, line_off, field_off, status, A1, A2, U1, U2, odds, chisq, p);
+        Dealt d_(ctx); hpgv_ctx *m_ = d_.m; return hpgv_assoc_text(m_, task, text, text_bytes, max_lines, n_lines, line_off, field_off, status, A1, A2, U1, U2, odds, chisq, p);
+    }
     if (!ctx) return HPGV_ERR_INVALID;
     if (task != HPGV_TASK_CHISQ && task != HPGV_TASK_FISHER) return fail(ctx, HPGV_ERR_INVALID, "task must be CHISQ or FISHER");
     if (!ctx->assoc.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_cohort has not been called");
@@ -1484,6 +1586,10 @@ int hpgv_assoc_text(hpgv_ctx *ctx, int task, const char *text, size_t text_bytes
 int hpgv_tdt_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_lines, int *n_lines,
                   uint64_t *line_off, uint32_t *field_off, int32_t *status, int32_t *t1, int32_t *t2,
                   double *odds, double *chisq, double *p) {
+    if (is_group(ctx)) {
+        if (hpgv_ctx *m_ = alias_owner(ctx, text)) return hpgv_tdt_text(m_, text, text_bytes, max_lines, n_lines, line_off, field_off, status, t1, t2, odds, chisq, p);
+        Dealt d_(ctx); hpgv_ctx *m_ = d_.m; return hpgv_tdt_text(m_, text, text_bytes, max_lines, n_lines, line_off, field_off, status, t1, t2, odds, chisq, p);
+    }
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->tdt.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_families has not been called");
     if (!n_lines || max_lines < 0 || (text_bytes > 0 && !text) || (max_lines > 0 && (!t1 || !t2 || !odds || !chisq || !p)))
@@ -1528,6 +1634,10 @@ int hpgv_stats_text_groups(hpgv_ctx *ctx, const char *text, size_t text_bytes, i
                            double *hwe_p, int32_t *sample_missing, int32_t *multi_idx, int32_t *multi_table, int *n_multi,
                            int32_t *mendel_errors, int32_t *child_errors, int32_t *group_counts8, double *group_hwe_chi2,
                            double *group_hwe_p) {
+    if (is_group(ctx)) {
+        if (hpgv_ctx *m_ = alias_owner(ctx, text)) return hpgv_stats_text_groups(m_, text, text_bytes, max_lines, n_lines, line_off, field_off, status, counts8, hwe_chi2, hwe_p, sample_missing, multi_idx, multi_table, n_multi, mendel_errors, child_errors, group_counts8, group_hwe_chi2, group_hwe_p);
+        Dealt d_(ctx); hpgv_ctx *m_ = d_.m; return hpgv_stats_text_groups(m_, text, text_bytes, max_lines, n_lines, line_off, field_off, status, counts8, hwe_chi2, hwe_p, sample_missing, multi_idx, multi_table, n_multi, mendel_errors, child_errors, group_counts8, group_hwe_chi2, group_hwe_p);
+    }
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->stats.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");
     if (!n_lines || max_lines < 0 || (text_bytes > 0 && !text) || (max_lines > 0 && (!counts8 || !hwe_chi2 || !hwe_p)))
@@ -1639,6 +1749,10 @@ int hpgv_stats_text_groups(hpgv_ctx *ctx, const char *text, size_t text_bytes, i
 
 int hpgv_epi_dataset_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_lines, int *n_lines,
                           uint64_t *line_off, uint32_t *field_off, int32_t *status, uint8_t *out) {
+    if (is_group(ctx)) {
+        if (hpgv_ctx *m_ = alias_owner(ctx, text)) return hpgv_epi_dataset_text(m_, text, text_bytes, max_lines, n_lines, line_off, field_off, status, out);
+        Dealt d_(ctx); hpgv_ctx *m_ = d_.m; return hpgv_epi_dataset_text(m_, text, text_bytes, max_lines, n_lines, line_off, field_off, status, out);
+    }
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->assoc.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_cohort has not been called");
     if (!n_lines || max_lines < 0 || (text_bytes > 0 && !text) || (max_lines > 0 && !out))
@@ -1664,6 +1778,7 @@ int hpgv_epi_dataset_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, in
 }
 
 int hpgv_read_probe(hpgv_ctx *ctx, const uint8_t *d_buf, size_t bytes, int iters, float *ms) {
+    ctx = first_member(ctx);
     if (!ctx || !d_buf || !ms || iters <= 0 || ((uintptr_t)d_buf & 15)) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);
     const size_t n16 = bytes / 16;

@@ -194,6 +194,7 @@ unsigned long long epi_rank(unsigned long long V, unsigned long long i) { return
 void hpgv_epi_release(EpiState &E) { epi_free(E); }
 
 int hpgv_epi_set_dataset(hpgv_ctx *ctx, const uint8_t *genotypes, int n_variants, int n_affected, int n_unaffected) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_variants < 0 || n_affected < 0 || n_unaffected < 0 || (n_variants > 0 && n_affected + n_unaffected > 0 && !genotypes))
         return fail(ctx, HPGV_ERR_INVALID, "bad epistasis dataset arguments");
@@ -212,6 +213,7 @@ int hpgv_epi_set_dataset(hpgv_ctx *ctx, const uint8_t *genotypes, int n_variants
 }
 
 int hpgv_epi_set_folds(hpgv_ctx *ctx, const int32_t *fold_of_sample, int num_folds) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->epi.have_data) return fail(ctx, HPGV_ERR_STATE, "hpgv_epi_set_dataset has not been called");
     if (num_folds < 1 || num_folds > hpgv::EPI_MAX_FOLDS) return fail(ctx, HPGV_ERR_UNSUPPORTED, "num_folds must be in [1, %d]", hpgv::EPI_MAX_FOLDS);
@@ -223,6 +225,7 @@ int hpgv_epi_set_folds(hpgv_ctx *ctx, const int32_t *fold_of_sample, int num_fol
 }
 
 int hpgv_epi_set_fold_masks(hpgv_ctx *ctx, const uint8_t *fold_masks, int num_folds) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->epi.have_data) return fail(ctx, HPGV_ERR_STATE, "hpgv_epi_set_dataset has not been called");
     if (num_folds < 1 || num_folds > hpgv::EPI_MAX_FOLDS || !fold_masks) return fail(ctx, HPGV_ERR_INVALID, "bad fold mask arguments");
@@ -271,6 +274,7 @@ static int epi_infold_counts(hpgv_ctx *ctx, int order, const int32_t *combs, int
 }
 
 int hpgv_epi_counts(hpgv_ctx *ctx, int order, const int32_t *combs, int n_combs, int32_t *counts_aff, int32_t *counts_unaff) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_combs > 0 && (!counts_aff || !counts_unaff)) return fail(ctx, HPGV_ERR_INVALID, "count outputs are NULL");
     DeviceGuard g(ctx->device);
@@ -289,6 +293,7 @@ int hpgv_epi_counts(hpgv_ctx *ctx, int order, const int32_t *combs, int n_combs,
 }
 
 int hpgv_epi_counts_all_folds(hpgv_ctx *ctx, int order, const int32_t *combs, int n_combs, int32_t *counts_aff, int32_t *counts_unaff) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_combs > 0 && (!counts_aff || !counts_unaff)) return fail(ctx, HPGV_ERR_INVALID, "count outputs are NULL");
     DeviceGuard g(ctx->device);
@@ -312,6 +317,7 @@ int hpgv_epi_counts_all_folds(hpgv_ctx *ctx, int order, const int32_t *combs, in
 
 int hpgv_epi_scan_pairs(hpgv_ctx *ctx, int i_begin, int i_end, int subset, double *accuracy, uint16_t *risky_mask,
                         unsigned long long *n_pairs) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     EpiState &E = ctx->epi;
     if (!E.have_folds) return fail(ctx, HPGV_ERR_STATE, "hpgv_epi_set_dataset has not been called");
@@ -345,12 +351,14 @@ int hpgv_epi_scan_pairs(hpgv_ctx *ctx, int i_begin, int i_end, int subset, doubl
 
 int hpgv_epi_rank_pairs(hpgv_ctx *ctx, int subset, int max_ranking_size, int32_t *comb_i, int32_t *comb_j, double *accuracy,
                         uint32_t *risky_mask, int32_t *n_ranked, float *scan_ms) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     return hpgv_epi_rank_pairs_rows(ctx, 0, ctx->epi.V, subset, max_ranking_size, comb_i, comb_j, accuracy, risky_mask, n_ranked, scan_ms);
 }
 
 int hpgv_epi_rank_pairs_rows(hpgv_ctx *ctx, int i_begin, int i_end, int subset, int max_ranking_size, int32_t *comb_i,
                              int32_t *comb_j, double *accuracy, uint32_t *risky_mask, int32_t *n_ranked, float *scan_ms) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     EpiState &E = ctx->epi;
     if (i_begin < 0 || i_end < i_begin || i_end > E.V || (i_begin % 64 && i_begin != i_end))
@@ -559,6 +567,7 @@ int epi_triples_check(hpgv_ctx *ctx, int subset) {
 }  // namespace
 
 int hpgv_epi_scan_triples(hpgv_ctx *ctx, int subset, double *accuracy, uint32_t *risky_mask) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     int rc = epi_triples_check(ctx, subset);
     if (rc) return rc;
@@ -589,6 +598,7 @@ int hpgv_epi_scan_triples(hpgv_ctx *ctx, int subset, double *accuracy, uint32_t 
 
 int hpgv_epi_rank_triples(hpgv_ctx *ctx, int subset, int max_ranking_size, int32_t *comb_i, int32_t *comb_j, int32_t *comb_k,
                           double *accuracy, uint32_t *risky_mask, int32_t *n_ranked, float *scan_ms) {
+    ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     int rc = epi_triples_check(ctx, subset);
     if (rc) return rc;

@@ -11,6 +11,7 @@
 #include <cctype>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -64,6 +65,13 @@ struct EpiState {
 };
 
 struct hpgv_ctx {
+    // ---- a GROUP context (hpgv_create_multi) has members and nothing else: one ordinary context per device.  Cohort
+    // calls go to every member, the synchronous per-batch calls to the member with the fewest calls in flight, the
+    // device-resident calls to member 0; a member's failure text is copied to its group.
+    std::vector<hpgv_ctx *> members;
+    hpgv_ctx *parent = nullptr;
+    std::atomic<unsigned> deal_next{0};
+    std::atomic<int> in_flight{0};
     int device = 0;
     mutable std::string err;
     std::mutex mu;
@@ -141,9 +149,43 @@ namespace {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf; else g_create_error = buf;
+    if (ctx) {
+        ctx->err = buf;
+        if (ctx->parent) {
+            std::lock_guard<std::mutex> lk(ctx->parent->mu);
+            ctx->parent->err = buf;
+        }
+    } else g_create_error = buf;
     return code;
 }
+
+// group dispatch
+inline bool is_group(const hpgv_ctx *c) { return c && !c->members.empty(); }
+inline hpgv_ctx *first_member(hpgv_ctx *c) { return is_group(c) ? c->members[0] : c; }
+inline const hpgv_ctx *first_member(const hpgv_ctx *c) { return is_group(c) ? c->members[0] : c; }
+// the member a synchronous per-batch call runs on: fewest calls in flight, round-robin among equals
+struct Dealt {
+    hpgv_ctx *m;
+    explicit Dealt(hpgv_ctx *g) {
+        const unsigned n = (unsigned)g->members.size(), start = g->deal_next.fetch_add(1u, std::memory_order_relaxed) % n;
+        m = g->members[start];
+        int best = m->in_flight.load(std::memory_order_relaxed);
+        for (unsigned k = 1; k < n && best > 0; ++k) {
+            hpgv_ctx *c = g->members[(start + k) % n];
+            const int f = c->in_flight.load(std::memory_order_relaxed);
+            if (f < best) { best = f; m = c; }
+        }
+        m->in_flight.fetch_add(1, std::memory_order_relaxed);
+    }
+    ~Dealt() { m->in_flight.fetch_sub(1, std::memory_order_relaxed); }
+};
+#define GROUP_ALL(ctx, CALL)                                                                \
+    if (is_group(ctx)) {                                                                    \
+        for (hpgv_ctx *m_ : (ctx)->members) { const int rc_ = CALL; if (rc_) return rc_; }  \
+        return HPGV_OK;                                                                     \
+    }
+#define GROUP_DEAL(ctx, CALL)                                                               \
+    if (is_group(ctx)) { Dealt d_(ctx); hpgv_ctx *m_ = d_.m; return CALL; }
 
 #define HIPCHK(ctx, call)                                                                   \
     do {                                                                                    \

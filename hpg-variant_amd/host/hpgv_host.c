@@ -361,21 +361,54 @@ static int host_fail(const char *what, int rc) {
     return rc;
 }
 
-int hpgv_host_init(int device_id) {
+/* the engine's devices: hpgv_host_init(d) binds device d; hpgv_host_init_devices a list (a group context: batches are
+ * dealt to the devices, hpgv.h hpgv_create_multi); with neither, the first call of an adapter or runner reads the
+ * environment variable HPGV_DEVICES -- "0,1,2,3" or "all" -- and falls back to device 0 */
+int hpgv_host_init_devices(const int *device_ids, int n_devices) {
     pthread_mutex_lock(&g_init_mu);
     int rc = HPGV_OK;
     if (!g_ctx) {
-        g_device = device_id;
-        rc = hpgv_create(device_id, &g_ctx);
-        if (rc != HPGV_OK) host_fail("hpgv_create", rc);
+        if (!device_ids || n_devices < 1) { snprintf(g_err, sizeof g_err, "hpgv_host_init_devices: no device ids"); rc = HPGV_ERR_INVALID; }
+        else {
+            g_device = device_ids[0];
+            rc = n_devices == 1 ? hpgv_create(device_ids[0], &g_ctx) : hpgv_create_multi(device_ids, n_devices, &g_ctx);
+            if (rc != HPGV_OK) host_fail(n_devices == 1 ? "hpgv_create" : "hpgv_create_multi", rc);
+        }
     }
     pthread_mutex_unlock(&g_init_mu);
     return rc;
 }
 
+int hpgv_host_init(int device_id) { return hpgv_host_init_devices(&device_id, 1); }
+
+int hpgv_host_device_count(void) { return g_ctx ? hpgv_group_size(g_ctx) : 0; }
+
+static int init_from_environment(void) {
+    const char *e = getenv("HPGV_DEVICES");
+    int ids[64], n = 0;
+    if (e && *e) {
+        if (!strcmp(e, "all")) {
+            const int have = hpgv_device_count();
+            for (int i = 0; i < have && n < 64; i++) ids[n++] = i;
+        } else {
+            const char *p = e;
+            while (*p && n < 64) {
+                char *end;
+                const long v = strtol(p, &end, 10);
+                if (end == p || v < 0) { snprintf(g_err, sizeof g_err, "HPGV_DEVICES='%s' is not a list of device ids", e); return HPGV_ERR_INVALID; }
+                ids[n++] = (int)v;
+                p = (*end == ',') ? end + 1 : end;
+                if (*end && *end != ',') { snprintf(g_err, sizeof g_err, "HPGV_DEVICES='%s' is not a list of device ids", e); return HPGV_ERR_INVALID; }
+            }
+        }
+    }
+    if (n == 0) { ids[0] = g_device; n = 1; }
+    return hpgv_host_init_devices(ids, n);
+}
+
 /* page-locked text buffers of the file runners, kept between runs: page-locking 5 x 64 MB costs 56 ms and releasing it
  * another 45 ms -- a third of a run over an 8 GB file.  Released by hpgv_host_shutdown. */
-enum { TEXT_CACHE_N = 8 };
+enum { TEXT_CACHE_N = 24 };
 static struct { char *p; size_t cap; } g_text_cache[TEXT_CACHE_N];
 static pthread_mutex_t g_text_mu = PTHREAD_MUTEX_INITIALIZER;
 static char *text_buf_get(size_t cap) {
@@ -396,6 +429,55 @@ static void text_buf_put(char *p, size_t cap) {
     pthread_mutex_unlock(&g_text_mu);
     if (!kept) (void)hpgv_host_free(g_ctx, p);
 }
+/* page-locked staging buffers of the per-batch adapters (assoc_test, tdt_test, get_variants_stats, get_sample_stats):
+ * the genotype bytes are staged straight into page-locked memory, which the engine's per-batch kernel reads in place
+ * over the bus (no copy on the way).  One buffer per concurrent worker, kept between calls, released by
+ * hpgv_host_shutdown; when the pool is full or page-locking fails an ordinary malloc serves (the engine then copies). */
+enum { STAGE_POOL_N = 64 };
+static struct { uint8_t *p; size_t cap; int busy; } g_stage_pool[STAGE_POOL_N];
+static pthread_mutex_t g_stage_mu = PTHREAD_MUTEX_INITIALIZER;
+static uint8_t *stage_get(size_t bytes, int *slot) {
+    *slot = -1;
+    if (bytes == 0) bytes = 16;
+    pthread_mutex_lock(&g_stage_mu);
+    int k = -1, empty = -1;
+    for (int i = 0; i < STAGE_POOL_N; i++) {
+        if (g_stage_pool[i].busy) continue;
+        if (g_stage_pool[i].p && g_stage_pool[i].cap >= bytes && (k < 0 || g_stage_pool[i].cap < g_stage_pool[k].cap)) k = i;
+        if (!g_stage_pool[i].p && empty < 0) empty = i;
+    }
+    if (k < 0 && empty < 0)                             /* every idle buffer is too small: let the smallest one go */
+        for (int i = 0; i < STAGE_POOL_N; i++) if (!g_stage_pool[i].busy && (empty < 0 || g_stage_pool[i].cap < g_stage_pool[empty].cap)) empty = i;
+    if (k < 0 && empty >= 0) { k = empty; g_stage_pool[k].busy = 1; } else if (k >= 0) g_stage_pool[k].busy = 1;
+    pthread_mutex_unlock(&g_stage_mu);
+    if (k < 0) return (uint8_t *)malloc(bytes);
+    if (g_stage_pool[k].cap < bytes) {                  /* slot k is ours (busy): grow it outside the lock */
+        if (g_stage_pool[k].p) (void)hpgv_host_free(g_ctx, g_stage_pool[k].p);
+        g_stage_pool[k].p = NULL; g_stage_pool[k].cap = 0;
+        void *q = NULL;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hpgv_host_alloc(g_ctx, want, &q) == HPGV_OK) { g_stage_pool[k].p = (uint8_t *)q; g_stage_pool[k].cap = want; }
+        else {
+            pthread_mutex_lock(&g_stage_mu); g_stage_pool[k].busy = 0; pthread_mutex_unlock(&g_stage_mu);
+            return (uint8_t *)malloc(bytes);
+        }
+    }
+    *slot = k;
+    return g_stage_pool[k].p;
+}
+static void stage_put(uint8_t *p, int slot) {
+    if (slot < 0) { free(p); return; }
+    pthread_mutex_lock(&g_stage_mu);
+    g_stage_pool[slot].busy = 0;
+    pthread_mutex_unlock(&g_stage_mu);
+}
+static void stage_pool_release(void) {                  /* g_ctx still alive */
+    pthread_mutex_lock(&g_stage_mu);
+    for (int i = 0; i < STAGE_POOL_N; i++)
+        if (g_stage_pool[i].p && !g_stage_pool[i].busy) { (void)hpgv_host_free(g_ctx, g_stage_pool[i].p); g_stage_pool[i].p = NULL; g_stage_pool[i].cap = 0; }
+    pthread_mutex_unlock(&g_stage_mu);
+}
+
 /* device memory for a decoded file, kept between runs like the page-locked buffers (an 8 GB allocation and its release
  * cost 0.1 s); released by hpgv_host_shutdown */
 static void *g_dev_text; static size_t g_dev_text_cap;
@@ -427,7 +509,7 @@ static void text_cache_release(void) {                  /* g_ctx still alive */
 
 void hpgv_host_shutdown(void) {
     pthread_mutex_lock(&g_init_mu);
-    if (g_ctx) { text_cache_release(); hpgv_destroy(g_ctx); g_ctx = NULL; }
+    if (g_ctx) { text_cache_release(); stage_pool_release(); hpgv_destroy(g_ctx); g_ctx = NULL; }
     memset(&g_assoc_key, 0, sizeof g_assoc_key);
     memset(&g_tdt_key, 0, sizeof g_tdt_key);
     memset(&g_stats_key, 0, sizeof g_stats_key);
@@ -437,7 +519,7 @@ void hpgv_host_shutdown(void) {
     pthread_mutex_unlock(&g_init_mu);
 }
 
-static int ensure_engine(void) { return g_ctx ? HPGV_OK : hpgv_host_init(g_device); }
+static int ensure_engine(void) { return g_ctx ? HPGV_OK : init_from_environment(); }
 
 static char *dupn(const char *s, int n) { return strndup(s ? s : "", (size_t)(n > 0 ? n : 0)); }
 
@@ -470,41 +552,45 @@ static int assoc_prepare(enum ASSOC_task task, individual_t **samples, int num_s
         if (!samples[j]) { snprintf(g_err, sizeof g_err, "sample %d has no individual (assoc.c:92)", j); return HPGV_ERR_INVALID; }
         h = (h ^ (uint64_t)samples[j]->condition) * 1099511628211ULL;
     }
-    int need_cohort = !(g_assoc_key.set && g_assoc_key.num_samples == num_samples && g_assoc_key.cond_hash == h);
-    int need_lf = (task == FISHER) && !(g_lf_key.table == opt_input && g_lf_key.n == num_samples * 10);
-    if (!need_cohort && !need_lf) return HPGV_OK;
-    /* upgrade: drop the read lock, take the write lock, re-check */
-    pthread_rwlock_unlock(&g_cohort_lock);
-    pthread_rwlock_wrlock(&g_cohort_lock);
-    int rc = HPGV_OK;
-    if (!(g_assoc_key.set && g_assoc_key.num_samples == num_samples && g_assoc_key.cond_hash == h)) {
-        uint8_t *cond = (uint8_t *)malloc((size_t)(num_samples > 0 ? num_samples : 1));
-        if (!cond) rc = HPGV_ERR_NOMEM;
-        else {
-            for (int j = 0; j < num_samples; j++) {
-                enum Condition c = samples[j]->condition;                 /* assoc.c:95,101 */
-                cond[j] = (c == AFFECTED) ? HPGV_COND_AFFECTED : (c == UNAFFECTED) ? HPGV_COND_UNAFFECTED : HPGV_COND_OTHER;
+    /* called and left with the READ lock held.  Installing needs the write lock; rwlocks do not upgrade, so the read lock is
+     * dropped, the write lock taken, and after coming back to the read lock the keys are checked AGAIN: a thread with another
+     * cohort may have installed its own in the gap.  The loop ends with the wanted layout installed under our read lock. */
+    for (;;) {
+        const int need_cohort = !(g_assoc_key.set && g_assoc_key.num_samples == num_samples && g_assoc_key.cond_hash == h);
+        const int need_lf = (task == FISHER) && !(g_lf_key.table == opt_input && g_lf_key.n == num_samples * 10);
+        if (!need_cohort && !need_lf) return HPGV_OK;
+        pthread_rwlock_unlock(&g_cohort_lock);
+        pthread_rwlock_wrlock(&g_cohort_lock);
+        int rc = HPGV_OK;
+        if (!(g_assoc_key.set && g_assoc_key.num_samples == num_samples && g_assoc_key.cond_hash == h)) {
+            uint8_t *cond = (uint8_t *)malloc((size_t)(num_samples > 0 ? num_samples : 1));
+            if (!cond) { snprintf(g_err, sizeof g_err, "out of memory"); rc = HPGV_ERR_NOMEM; }
+            else {
+                for (int j = 0; j < num_samples; j++) {
+                    enum Condition c = samples[j]->condition;                 /* assoc.c:95,101 */
+                    cond[j] = (c == AFFECTED) ? HPGV_COND_AFFECTED : (c == UNAFFECTED) ? HPGV_COND_UNAFFECTED : HPGV_COND_OTHER;
+                }
+                rc = hpgv_set_cohort(g_ctx, cond, num_samples);
+                free(cond);
+                if (rc == HPGV_OK) {
+                    g_assoc_key.samples = samples; g_assoc_key.num_samples = num_samples;
+                    g_assoc_key.cond_hash = h; g_assoc_key.set = 1;
+                } else host_fail("hpgv_set_cohort", rc);
             }
-            rc = hpgv_set_cohort(g_ctx, cond, num_samples);
-            free(cond);
-            if (rc == HPGV_OK) {
-                g_assoc_key.samples = samples; g_assoc_key.num_samples = num_samples;
-                g_assoc_key.cond_hash = h; g_assoc_key.set = 1;
-            } else host_fail("hpgv_set_cohort", rc);
         }
-    }
-    if (rc == HPGV_OK && task == FISHER && !(g_lf_key.table == opt_input && g_lf_key.n == num_samples * 10)) {
-        if (!opt_input) { snprintf(g_err, sizeof g_err, "FISHER needs the log-factorial table (opt_input)"); rc = HPGV_ERR_INVALID; }
-        else {
-            /* assoc_runner.c:164-166: the table has num_samples * 10 entries */
-            rc = hpgv_set_logfact(g_ctx, (const double *)opt_input, (size_t)num_samples * 10);
-            if (rc == HPGV_OK) { g_lf_key.table = opt_input; g_lf_key.n = num_samples * 10; }
-            else host_fail("hpgv_set_logfact", rc);
+        if (rc == HPGV_OK && task == FISHER && !(g_lf_key.table == opt_input && g_lf_key.n == num_samples * 10)) {
+            if (!opt_input) { snprintf(g_err, sizeof g_err, "FISHER needs the log-factorial table (opt_input)"); rc = HPGV_ERR_INVALID; }
+            else {
+                /* assoc_runner.c:164-166: the table has num_samples * 10 entries */
+                rc = hpgv_set_logfact(g_ctx, (const double *)opt_input, (size_t)num_samples * 10);
+                if (rc == HPGV_OK) { g_lf_key.table = opt_input; g_lf_key.n = num_samples * 10; }
+                else host_fail("hpgv_set_logfact", rc);
+            }
         }
+        pthread_rwlock_unlock(&g_cohort_lock);
+        pthread_rwlock_rdlock(&g_cohort_lock);
+        if (rc != HPGV_OK) return rc;
     }
-    pthread_rwlock_unlock(&g_cohort_lock);
-    pthread_rwlock_rdlock(&g_cohort_lock);
-    return rc;
 }
 
 static int assoc_test_impl(enum ASSOC_task test_type, vcf_record_t **variants, int num_variants,
@@ -517,10 +603,11 @@ static int assoc_test_impl(enum ASSOC_task test_type, vcf_record_t **variants, i
     int tid = thread_id();                                                   /* assoc.c:25 */
     size_t n = (size_t)num_variants, ns = (size_t)(num_samples > 0 ? num_samples : 0);
     size_t pitch = ns ? ns : 1;
-    uint8_t *gt = (uint8_t *)malloc(n * pitch + n);
+    int gt_slot;
+    uint8_t *gt = stage_get(n * pitch + n, &gt_slot);
     int32_t *cnt = (int32_t *)malloc(n * 4 * sizeof(int32_t));
     double *st = (double *)malloc(n * 3 * sizeof(double));
-    if (!gt || !cnt || !st) { free(gt); free(cnt); free(st); snprintf(g_err, sizeof g_err, "out of memory"); return HPGV_ERR_NOMEM; }
+    if (!gt || !cnt || !st) { if (gt) stage_put(gt, gt_slot); free(cnt); free(st); snprintf(g_err, sizeof g_err, "out of memory"); return HPGV_ERR_NOMEM; }
     uint8_t *is_x = gt + n * pitch;
     hpgv_host_stage_records(variants, num_variants, num_samples, 1, gt, is_x);   /* assoc.c:45-57 */
 
@@ -563,7 +650,7 @@ static int assoc_test_impl(enum ASSOC_task test_type, vcf_record_t **variants, i
             list_insert_item(list_item_new(tid, 0, result), output_list);   /* assoc.c:67-68,76-77 */
         }
     }
-    free(gt); free(cnt); free(st);
+    stage_put(gt, gt_slot); free(cnt); free(st);
     return rc;
 }
 
@@ -632,8 +719,9 @@ static int tdt_prepare(family_t **families, int num_families, sample_ids_t *samp
             h = (h ^ (uint64_t)(uint32_t)mcol[f]) * 1099511628211ULL;
             h = (h ^ (uint64_t)(uint32_t)nchild) * 1099511628211ULL;
         }
-        if (!(g_tdt_key.set && g_tdt_key.num_families == num_families && g_tdt_key.num_columns == num_columns &&
-              g_tdt_key.hash == h)) {
+        /* installed under the write lock, re-checked after coming back to the read lock (see assoc_prepare) */
+        while (rc == HPGV_OK && !(g_tdt_key.set && g_tdt_key.num_families == num_families && g_tdt_key.num_columns == num_columns &&
+                                  g_tdt_key.hash == h)) {
             pthread_rwlock_unlock(&g_cohort_lock);
             pthread_rwlock_wrlock(&g_cohort_lock);
             if (!(g_tdt_key.set && g_tdt_key.num_families == num_families && g_tdt_key.num_columns == num_columns &&
@@ -660,10 +748,11 @@ int tdt_test(vcf_record_t **variants, int num_variants, family_t **families, int
     int tid = thread_id();                                                     /* tdt.c:27 */
     int num_columns = (int)variants[0]->samples->size;
     size_t n = (size_t)num_variants, pitch = (size_t)(num_columns > 0 ? num_columns : 1);
-    uint8_t *gt = (uint8_t *)malloc(n * pitch + n);
+    int gt_slot;
+    uint8_t *gt = stage_get(n * pitch + n, &gt_slot);
     int32_t *tu = (int32_t *)malloc(n * 2 * sizeof(int32_t));
     double *st = (double *)malloc(n * 3 * sizeof(double));
-    if (!gt || !tu || !st) { free(gt); free(tu); free(st); snprintf(g_err, sizeof g_err, "out of memory"); return HPGV_ERR_NOMEM; }
+    if (!gt || !tu || !st) { if (gt) stage_put(gt, gt_slot); free(tu); free(st); snprintf(g_err, sizeof g_err, "out of memory"); return HPGV_ERR_NOMEM; }
     uint8_t *is_x = gt + n * pitch;
     hpgv_host_stage_records(variants, num_variants, num_columns, 1, gt, is_x);
 
@@ -689,7 +778,7 @@ int tdt_test(vcf_record_t **variants, int num_variants, family_t **families, int
             list_insert_item(list_item_new(tid, 0, r), output_list);
         }
     }
-    free(gt); free(tu); free(st);
+    stage_put(gt, gt_slot); free(tu); free(st);
     return rc;
 }
 
@@ -699,7 +788,7 @@ int tdt_test(vcf_record_t **variants, int num_variants, family_t **families, int
 
 static int stats_prepare(int num_samples) {
     int rc = HPGV_OK;
-    if (!(g_stats_key.set && g_stats_key.num_samples == num_samples)) {
+    while (rc == HPGV_OK && !(g_stats_key.set && g_stats_key.num_samples == num_samples)) {    /* re-checked under the read lock */
         pthread_rwlock_unlock(&g_cohort_lock);
         pthread_rwlock_wrlock(&g_cohort_lock);
         if (!(g_stats_key.set && g_stats_key.num_samples == num_samples)) {
@@ -731,13 +820,15 @@ int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t *
     int tid = thread_id();
     int num_samples = (int)variants[0]->samples->size;
     size_t n = (size_t)num_variants, pitch = (size_t)(num_samples > 0 ? num_samples : 1);
-    uint8_t *gt = (uint8_t *)malloc(n * pitch);
+    int gt_slot;
+    uint8_t *gt = stage_get(n * pitch, &gt_slot);
     int32_t *c8 = (int32_t *)malloc(n * 8 * sizeof(int32_t));
     double *hw = (double *)malloc(n * 2 * sizeof(double));
     int32_t *midx = (int32_t *)malloc(n * sizeof(int32_t));
     int32_t *mtab = (int32_t *)malloc(n * 256 * sizeof(int32_t));
     if (!gt || !c8 || !hw || !midx || !mtab) {
-        free(gt); free(c8); free(hw); free(midx); free(mtab);
+        if (gt) stage_put(gt, gt_slot);
+        free(c8); free(hw); free(midx); free(mtab);
         snprintf(g_err, sizeof g_err, "out of memory");
         return HPGV_ERR_NOMEM;
     }
@@ -755,7 +846,7 @@ int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t *
         gc8 = (int32_t *)malloc((size_t)ng * n * 8 * sizeof(int32_t));
         ghw = (double *)malloc((size_t)ng * n * 2 * sizeof(double));
         if (!group || !gc8 || !ghw) {
-            free(group); free(gc8); free(ghw); free(gt); free(c8); free(hw); free(midx); free(mtab);
+            free(group); free(gc8); free(ghw); stage_put(gt, gt_slot); free(c8); free(hw); free(midx); free(mtab);
             snprintf(g_err, sizeof g_err, "out of memory");
             return HPGV_ERR_NOMEM;
         }
@@ -774,7 +865,7 @@ int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t *
         if (rc != HPGV_OK) host_fail("hpgv_stats_ex", rc);
     }
     if (rc == HPGV_OK && ng) {
-        if (!(g_group_key.set && g_group_key.num_samples == num_samples && g_group_key.n_groups == ng && g_group_key.hash == gh)) {
+        while (rc == HPGV_OK && !(g_group_key.set && g_group_key.num_samples == num_samples && g_group_key.n_groups == ng && g_group_key.hash == gh)) {
             pthread_rwlock_unlock(&g_cohort_lock);
             pthread_rwlock_wrlock(&g_cohort_lock);
             if (!(g_group_key.set && g_group_key.num_samples == num_samples && g_group_key.n_groups == ng && g_group_key.hash == gh)) {
@@ -871,7 +962,7 @@ int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t *
             pthread_mutex_unlock(&file_stats->lock);
         }
     }
-    free(gt); free(c8); free(hw); free(midx); free(mtab); free(group); free(gc8); free(ghw);
+    stage_put(gt, gt_slot); free(c8); free(hw); free(midx); free(mtab); free(group); free(gc8); free(ghw);
     return rc;
 }
 
@@ -919,7 +1010,7 @@ int get_sample_stats(vcf_record_t **variants, int num_variants, individual_t **i
         if (rc != HPGV_OK) host_fail("hpgv_stats_ex", rc);
     }
     if (rc == HPGV_OK && n_trios > 0) {
-        if (!(g_ped_key.set && g_ped_key.num_samples == num_samples && g_ped_key.n_trios == n_trios && g_ped_key.hash == h)) {
+        while (rc == HPGV_OK && !(g_ped_key.set && g_ped_key.num_samples == num_samples && g_ped_key.n_trios == n_trios && g_ped_key.hash == h)) {
             pthread_rwlock_unlock(&g_cohort_lock);
             pthread_rwlock_wrlock(&g_cohort_lock);
             if (!(g_ped_key.set && g_ped_key.num_samples == num_samples && g_ped_key.n_trios == n_trios && g_ped_key.hash == h)) {
@@ -1500,6 +1591,11 @@ static int ped_table_read(const char *path, ped_table_t *ped) {
     ped->pat = (char **)malloc(sizeof(char *) * (size_t)cap); ped->mat = (char **)malloc(sizeof(char *) * (size_t)cap);
     ped->phe = (char **)malloc(sizeof(char *) * (size_t)cap);
     ped->sex = (int *)malloc(sizeof(int) * (size_t)cap); ped->pheno = (int *)malloc(sizeof(int) * (size_t)cap);
+    if (!ped->fid || !ped->iid || !ped->pat || !ped->mat || !ped->phe || !ped->sex || !ped->pheno) {
+        ped_table_free(ped);
+        snprintf(g_err, sizeof g_err, "out of memory reading the PED file");
+        return HPGV_ERR_NOMEM;
+    }
     char *line = ped->blob;
     while (line && *line) {
         char *eol = strchr(line, '\n');
@@ -1508,10 +1604,22 @@ static int ped_table_read(const char *path, ped_table_t *ped) {
             char *p = line;
             char *a = next_ws_token(&p), *b = next_ws_token(&p), *c = next_ws_token(&p), *d = next_ws_token(&p);
             char *e = next_ws_token(&p), *g = next_ws_token(&p);
-            if (a && b && c && d && e && g && ped->n < cap) {
+            if (!(a && b && c && d && e && g)) {         /* a row without FID IID PAT MAT SEX PHENO is damaged input, not a sample to skip */
+                snprintf(g_err, sizeof g_err, "PED row %d has fewer than 6 columns", ped->n + 1);
+                ped_table_free(ped);
+                return HPGV_ERR_INVALID;
+            }
+            if (ped->n < cap) {
                 ped->fid[ped->n] = a; ped->iid[ped->n] = b; ped->pat[ped->n] = c; ped->mat[ped->n] = d; ped->phe[ped->n] = g;
-                ped->sex[ped->n] = !strcmp(e, "1") ? HPGV_SEX_MALE : !strcmp(e, "2") ? HPGV_SEX_FEMALE : HPGV_SEX_UNKNOWN;
-                ped->pheno[ped->n] = !strcmp(g, "2") ? HPGV_COND_AFFECTED : !strcmp(g, "1") ? HPGV_COND_UNAFFECTED : HPGV_COND_OTHER;
+                /* SEX and PHENO are read as numbers (the reference keeps the phenotype as a float, individual->variable):
+                 * "2" and "2.0" are the same label; anything that is not 1 / 2 -- 0, -9, text -- is unknown / other */
+                char *end;
+                const double sx = strtod(e, &end);
+                const int sx_ok = end != e && *end == 0;
+                ped->sex[ped->n] = (sx_ok && sx == 1.0) ? HPGV_SEX_MALE : (sx_ok && sx == 2.0) ? HPGV_SEX_FEMALE : HPGV_SEX_UNKNOWN;
+                const double ph = strtod(g, &end);
+                const int ph_ok = end != g && *end == 0;
+                ped->pheno[ped->n] = (ph_ok && ph == 2.0) ? HPGV_COND_AFFECTED : (ph_ok && ph == 1.0) ? HPGV_COND_UNAFFECTED : HPGV_COND_OTHER;
                 ped->n++;
             }
         }
@@ -2803,11 +2911,14 @@ static int write_batch(FILE *fd, int kind, const run_batch_t *b, out_buf_t *bufs
 }
 
 /* ---- the runners' pipeline: reader -> engine threads -> writer, batches in rotation ------------------ */
-enum { RUN_NB = 5, RUN_ENGINES = 2, RUN_FMT_BUFS = 64 };
+/* batches in rotation and engine threads: two engine threads per device (one batch's bus copies beside the other's
+ * kernels) and three more batches than engines (reader ahead, writer behind); one device: 5 batches, 2 engines */
+enum { RUN_ENGINES_MAX = 16, RUN_NB_MAX = RUN_ENGINES_MAX + 3, RUN_FMT_BUFS = 64 };
 enum { B_FREE = 0, B_FILLED = 1, B_BUSY = 2, B_DONE = 3 };
 typedef struct {
     pthread_mutex_t mu; pthread_cond_t cv;
-    run_batch_t bt[RUN_NB]; int state[RUN_NB]; long seq[RUN_NB];
+    run_batch_t bt[RUN_NB_MAX]; int state[RUN_NB_MAX]; long seq[RUN_NB_MAX];
+    int nb, n_engines;
     long n_filled, n_taken, n_written;                  /* sequence numbers handed out so far per stage */
     int eof, rc, kind;
     size_t batch_bytes;
@@ -2827,7 +2938,7 @@ static void *pipe_reader(void *v) {
         pthread_mutex_lock(&P->mu);
         int k = -1;
         while (!P->rc) {
-            for (int i = 0; i < RUN_NB && k < 0; i++) if (P->state[i] == B_FREE) k = i;
+            for (int i = 0; i < P->nb && k < 0; i++) if (P->state[i] == B_FREE) k = i;
             if (k >= 0) break;
             pthread_cond_wait(&P->cv, &P->mu);
         }
@@ -2856,7 +2967,7 @@ static void *pipe_engine(void *v) {
         pthread_mutex_lock(&P->mu);
         int k = -1;
         while (!P->rc) {
-            for (int i = 0; i < RUN_NB && k < 0; i++) if (P->state[i] == B_FILLED && P->seq[i] == P->n_taken) k = i;
+            for (int i = 0; i < P->nb && k < 0; i++) if (P->state[i] == B_FILLED && P->seq[i] == P->n_taken) k = i;
             if (k >= 0 || (P->eof && P->n_taken == P->n_filled)) break;
             pthread_cond_wait(&P->cv, &P->mu);
         }
@@ -3008,7 +3119,8 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     const int io_threads = default_io_threads();
     ped_table_t ped;
     memset(&ped, 0, sizeof ped);
-    if (ped_path || kind < 5) { if ((rc = ped_table_read(ped_path, &ped))) return rc; }      /* aggregate / stats run without a PED too */
+    if (!ped_path && kind < 5) { snprintf(g_err, sizeof g_err, "this runner needs a PED file (ped_path is NULL)"); return HPGV_ERR_INVALID; }
+    if (ped_path) { if ((rc = ped_table_read(ped_path, &ped))) return rc; }      /* aggregate / stats run without a PED too */
     line_reader_t rd;
     memset(&rd, 0, sizeof rd);
     if (source_open(&rd.src, vcf_path)) {
@@ -3113,16 +3225,20 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     } else {
         uint8_t *cond = (uint8_t *)malloc((size_t)n_samples + 1);
         for (int j = 0; j < n_samples; j++) cond[j] = HPGV_COND_OTHER;
-        for (int i = 0; i < ped.n; i++) { int j = sample_ids_get(ids, ped.iid[i]); if (j >= 0) cond[j] = (uint8_t)ped.pheno[i]; }
+        int matched = 0;
+        for (int i = 0; i < ped.n; i++) { int j = sample_ids_get(ids, ped.iid[i]); if (j >= 0) { cond[j] = (uint8_t)ped.pheno[i]; matched++; } }
+        if (matched == 0 && n_samples > 0) {             /* assert(individual) of assoc.c:92: a VCF whose samples the PED does not know */
+            snprintf(g_err, sizeof g_err, "no sample of %s is a row of %s", vcf_path, ped_path);
+            rc = HPGV_ERR_INVALID;
+        }
         if (kind == 4) {                                 /* get_individual_phenotypes, dataset_creator.c:279-300: affected, or not */
             for (int j = 0; j < n_samples; j++) {
                 if (cond[j] != HPGV_COND_AFFECTED) cond[j] = HPGV_COND_UNAFFECTED;
                 if (cond[j] == HPGV_COND_AFFECTED) epi_aff++; else epi_unaff++;
             }
         }
-        rc = hpgv_set_cohort(g_ctx, cond, n_samples);
+        if (!rc && (rc = hpgv_set_cohort(g_ctx, cond, n_samples))) host_fail("hpgv_set_cohort", rc);
         g_assoc_key.set = 0;
-        if (rc) host_fail("hpgv_set_cohort", rc);
         free(cond);
         if (!rc && kind == FISHER) {
             double *lf = init_logarithm_array(n_samples * 10 > 16 ? n_samples * 10 : 16);     /* assoc_runner.c:164-166 */
@@ -3157,7 +3273,8 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
         free(tf); free(tm); free(tc); free(ts);
     }
     if (!rc) (void)hpgv_set_text_filters(g_ctx, g_filters.min_maf, g_filters.max_missing, (long)g_filters.max_mendel_errors);
-    pthread_rwlock_unlock(&g_cohort_lock);
+    /* the run keeps the cohort lock (exclusive) until its pipeline is done: the engine threads scan with the layouts installed
+     * above, and an adapter or another runner with a different cohort waits instead of swapping them mid-file */
     sample_ids_free(ids);
 
     char *path6 = NULL;
@@ -3195,7 +3312,14 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     out_buf_t *fmt = (out_buf_t *)calloc(RUN_FMT_BUFS, sizeof *fmt);
     int have = 0;
     if (!P || !fmt) rc = rc ? rc : HPGV_ERR_NOMEM;
-    for (; !rc && have < RUN_NB; have++) rc = run_batch_alloc(&P->bt[have], batch_bytes, n_samples, kind == 4 ? n_samples : 0, kind >= 5, n_trios, n_groups);
+    if (P) {
+        int devs = hpgv_group_size(g_ctx);
+        if (rd.src.d_text && !getenv("HPGV_NO_DEVICE_WINDOWS")) devs = 1;        /* windows of a text decoded on member 0's device stay there */
+        P->n_engines = 2 * (devs < 1 ? 1 : devs);
+        if (P->n_engines > RUN_ENGINES_MAX) P->n_engines = RUN_ENGINES_MAX;
+        P->nb = P->n_engines + 3;
+    }
+    for (; !rc && have < P->nb; have++) rc = run_batch_alloc(&P->bt[have], batch_bytes, n_samples, kind == 4 ? n_samples : 0, kind >= 5, n_trios, n_groups);
     if (rc == HPGV_ERR_NOMEM) snprintf(g_err, sizeof g_err, "out of memory for the batch buffers");
     if (!rc) {
         if (kind == 5) {
@@ -3216,7 +3340,7 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
             if (fwrite(head, sizeof(uint32_t), 3, out) != 3) rc = HPGV_ERR_INVALID;
         } else if (kind == 3) tdt_write_output_header(out);
         else assoc_write_output_header((enum ASSOC_task)kind, out);
-        /* one reader thread (with its team of pread / inflate threads), RUN_ENGINES engine threads (each call
+        /* one reader thread (with its team of pread / inflate threads), two engine threads per device (each call
          * is H2D, tokenize, scan, statistics, D2H on its own stream, so two in flight overlap the copies of one
          * batch with the kernels of the other) and this thread as the writer (with its team of formatters);
          * batches are written in file order */
@@ -3231,16 +3355,16 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
             rd.src.dev_pos -= rd.carry_len; rd.carry_len = 0; rd.devwin = 1;
         }
         const int n_fmt = io_threads < RUN_FMT_BUFS ? io_threads : RUN_FMT_BUFS;
-        pthread_t th[1 + RUN_ENGINES];
+        pthread_t th[1 + RUN_ENGINES_MAX];
         int n_th = 0;
         if (pthread_create(&th[n_th], NULL, pipe_reader, P) == 0) n_th++;
-        for (int e = 0; e < RUN_ENGINES; e++) if (pthread_create(&th[n_th], NULL, pipe_engine, P) == 0) n_th++;
+        for (int e = 0; e < P->n_engines; e++) if (pthread_create(&th[n_th], NULL, pipe_engine, P) == 0) n_th++;
         pthread_mutex_lock(&P->mu);
         if (n_th < 2) pipe_fail(P, HPGV_ERR_NOMEM, "cannot start the pipeline threads");
         for (;;) {
             int k = -1;
             while (!P->rc) {
-                for (int i = 0; i < RUN_NB && k < 0; i++) if (P->state[i] == B_DONE && P->seq[i] == P->n_written) k = i;
+                for (int i = 0; i < P->nb && k < 0; i++) if (P->state[i] == B_DONE && P->seq[i] == P->n_written) k = i;
                 if (k >= 0 || (P->eof && P->n_written == P->n_filled)) break;
                 pthread_cond_wait(&P->cv, &P->mu);
             }
@@ -3286,15 +3410,18 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     free(path6); free(trio_child);
     for (int k = 0; P && k < have; k++) run_batch_free(&P->bt[k]);
     for (int k = 0; fmt && k < RUN_FMT_BUFS; k++) free(fmt[k].p);
-    free(fmt); free(P);
+    free(fmt);
+    const int n_engines_used = P ? P->n_engines : 0;
+    free(P);
     if (dev_filters) (void)hpgv_set_text_filters(g_ctx, -1.0, -1.0, -1);
     numa_unbind(&saved_cpus, numa_bound);
     g_run_times[3] = t_sort; g_run_times[4] = now_s() - t_start;
     if (getenv("HPGV_RUN_TRACE"))
         fprintf(stderr, "hpgv run: %ld records, %.0f batches, %d io threads: read %.3f s, engine %.3f s (%d threads), write %.3f s (stages overlap), sort %.3f s, total %.3f s\n",
-                written, g_run_times[5], io_threads, g_run_times[0], g_run_times[1], RUN_ENGINES, g_run_times[2], t_sort, g_run_times[4]);
+                written, g_run_times[5], io_threads, g_run_times[0], g_run_times[1], n_engines_used, g_run_times[2], t_sort, g_run_times[4]);
     source_close(&rd.src); free(rd.carry); free(rd.tailbuf); free(hdr); free(names); ped_table_free(&ped);
     if (n_variants_out) *n_variants_out = written;
+    pthread_rwlock_unlock(&g_cohort_lock);
     return rc;
 }
 

@@ -64,6 +64,22 @@ typedef struct hpgv_ctx hpgv_ctx;
 const char *hpgv_version(void);
 int  hpgv_device_count(void);                       /* <0 on HIP failure */
 int  hpgv_create(int device_id, hpgv_ctx **out);
+/* Several devices behind ONE context ("the context owns the devices"; the reference's runner deals its
+ * batches to num_threads workers, assoc_runner.c:106-207 -- here they land on n_devices GPUs).  A group context takes
+ * every call an ordinary one takes:
+ *   - cohort / option calls (hpgv_set_*) are applied to every member device;
+ *   - the synchronous per-batch entry points (hpgv_assoc, hpgv_tdt, hpgv_stats*, hpgv_mendel, hpgv_epi_dataset,
+ *     hpgv_tokenize, hpgv_*_text) run on the member with the fewest calls in flight, so concurrent worker threads spread
+ *     over the devices; variants are independent (assoc.c:38-82), so no exchange between devices is needed, and the
+ *     per-sample counters of hpgv_stats_ex / hpgv_stats_text are accumulated into the caller's host arrays by every call;
+ *   - device memory, streams, the device-resident entry points (hpgv_*_dev), hpgv_text_alias and the epistasis calls
+ *     refer to member 0; hpgv_group_member gives the context of another member for device-resident work there.
+ * The same device id may be listed more than once (two contexts on one device: what the tests do on a one-GPU box).
+ * hpgv_destroy of the group destroys its members; a member must not be destroyed on its own. */
+int  hpgv_create_multi(const int *device_ids, int n_devices, hpgv_ctx **out);
+int  hpgv_group_size(const hpgv_ctx *ctx);                 /* 1 for an ordinary context */
+hpgv_ctx *hpgv_group_member(hpgv_ctx *ctx, int i);         /* NULL when out of range */
+int  hpgv_member_device(const hpgv_ctx *ctx, int i);       /* device id of member i, -1 when out of range */
 void hpgv_destroy(hpgv_ctx *ctx);
 /* text of the last failure on this ctx (ctx == NULL: last hpgv_create failure
  * of the calling thread) */

@@ -219,6 +219,11 @@ void file_stats_free(file_stats_t *stats);
 /* Chooses the device the adapters run on (default 0).  Called lazily by the
  * adapters; returns HPGV_OK or an hpgv status.  There is no CPU fallback. */
 int  hpgv_host_init(int device_id);
+/* several devices (hpgv_create_multi of include/hpgv.h): the adapters' and runners' batches are dealt to them; the
+ * runners start two engine threads per device.  Without an explicit init the first call reads the environment variable
+ * HPGV_DEVICES ("0,1,2,3" or "all"; the same id may repeat) and falls back to device 0. */
+int  hpgv_host_init_devices(const int *device_ids, int n_devices);
+int  hpgv_host_device_count(void);                     /* devices behind the adapters (0 before the first call) */
 void hpgv_host_shutdown(void);
 const char *hpgv_host_last_error(void);
 

@@ -1,0 +1,106 @@
+"""Several devices behind one context (hpgv_create_multi) and behind the host library (HPGV_DEVICES /
+hpgv_host_init_devices).  A one-GPU box cannot show a speed-up, but it can show that the dealing is correct: a group of
+two contexts on device 0 must give the results of one context, from concurrent worker threads and from the file runners,
+byte for byte."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import check_assoc, hpgv, make_families, oracle_assoc, random_codes
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_group_context_deals_concurrent_batches():
+    n_samples = 3001
+    rng = np.random.default_rng(11)
+    cond = rng.integers(0, 3, n_samples).astype(np.uint8)
+    g = hpgv.Engine([0, 0])
+    assert g.L.hpgv_group_size(g.h) == 2 and g.L.hpgv_member_device(g.h, 1) == 0
+    g.set_cohort(cond)                                        # goes to both members
+    lf = orc.logfact(n_samples * 10)
+    g.set_logfact(lf)
+    fam = make_families(rng, n_samples, 700, max_children=3)
+    g.set_families(n_samples, *fam)
+    batches = [random_codes(rng, 150 + 13 * k, n_samples, quirks=True, strict=True) for k in range(12)]
+    out = [None] * len(batches)
+
+    def work(k):
+        task = hpgv.TASK_CHISQ if k % 2 else hpgv.TASK_FISHER
+        out[k] = (task, g.assoc(task, batches[k]), g.tdt(batches[k]))
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(batches))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k, (task, res, tdt) in enumerate(out):
+        check_assoc(res, oracle_assoc(task, batches[k], cond, None, lf), task)
+        t1, t2 = orc.tdt_counts(batches[k], *fam)
+        assert np.array_equal(tdt["t1"], t1) and np.array_equal(tdt["t2"], t2)
+    # device-resident calls of a group refer to member 0; the other member is reachable on its own
+    m1 = g.L.hpgv_group_member(g.h, 1)
+    assert m1 and g.L.hpgv_group_member(g.h, 2) is None
+    nA = C.c_int()
+    assert g.L.hpgv_assoc_layout(m1, C.byref(nA), None, None) == 0 and nA.value == int((cond == 1).sum())
+    g.close()
+
+
+_RUNNER = r"""
+import ctypes as C, sys, importlib
+sys.path.insert(0, %(root)r)
+b = importlib.import_module("hpg-variant_amd._build")
+L = C.CDLL(b.HOSTLIB)
+L.hpgv_run_assoc.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_size_t, C.POINTER(C.c_long)]
+L.hpgv_run_tdt.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_long)]
+L.hpgv_host_last_error.restype = C.c_char_p
+vcf, ped, out = [a.encode() for a in sys.argv[1:4]]
+n = C.c_long(0)
+rc = L.hpgv_run_assoc(vcf, ped, out + b".chisq", 1, 1 << 16, C.byref(n))
+assert rc == 0, L.hpgv_host_last_error()
+rc = L.hpgv_run_assoc(vcf, ped, out + b".fisher", 2, 1 << 16, C.byref(n))
+assert rc == 0, L.hpgv_host_last_error()
+rc = L.hpgv_run_tdt(vcf, ped, out + b".tdt", 1 << 16, C.byref(n))
+assert rc == 0, L.hpgv_host_last_error()
+print(L.hpgv_host_device_count(), n.value)
+L.hpgv_host_shutdown()
+"""
+
+
+def test_runners_with_hpgv_devices_are_byte_identical(tmp_path):
+    """hpgv_run_assoc / hpgv_run_tdt with HPGV_DEVICES=0,0,0 (three contexts, six engine threads) write the same sorted files
+    as with one device."""
+    from test_file_runner_gpu import _vcf_from_batch
+    from test_host_mirror_gpu import _write_inputs
+    rng = np.random.default_rng(21)
+    people, names, rows = _write_inputs(tmp_path, rng, 60, 30, 4000)
+    vcf = _vcf_from_batch(tmp_path, names, rows)
+    ped = str(tmp_path / "ped.txt")
+    script = tmp_path / "run.py"
+    script.write_text(_RUNNER % {"root": ROOT})
+    outs = {}
+    for tag, devs in (("one", None), ("three", "0,0,0")):
+        env = {k: v for k, v in os.environ.items() if k != "HPGV_DEVICES"}
+        if devs:
+            env["HPGV_DEVICES"] = devs
+        r = subprocess.run([sys.executable, str(script), vcf, ped, str(tmp_path / tag)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        n_dev, n_rec = r.stdout.split()
+        assert int(n_dev) == (3 if devs else 1) and int(n_rec) == len(rows)
+        outs[tag] = [open(str(tmp_path / tag) + ext, "rb").read() for ext in (".chisq", ".fisher", ".tdt")]
+    assert outs["one"] == outs["three"]
+    assert all(len(x) > 1000 for x in outs["one"])
+
+
+def test_bad_device_list_is_refused(tmp_path):
+    script = tmp_path / "run.py"
+    script.write_text(_RUNNER % {"root": ROOT})
+    env = dict(os.environ, HPGV_DEVICES="0,banana")
+    r = subprocess.run([sys.executable, str(script), "x.vcf", "x.ped", str(tmp_path / "o")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "HPGV_DEVICES" in r.stderr
