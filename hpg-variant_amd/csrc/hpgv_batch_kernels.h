@@ -81,21 +81,36 @@ __device__ __forceinline__ void block_sum(int (&v)[K], int *red /* LDS: 4 x K in
     __syncthreads();
 }
 
-template <int KIND>
-__global__ __launch_bounds__(256) void k_batch(BatchArgs A) {
-    extern __shared__ __align__(16) uint8_t lds_raw[];          // the aligned window of the raw row
-    __shared__ int red[4 * 8];
-    __shared__ double exp_tab[64];
-    const int v = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (KIND == BATCH_FISHER && tid < 64) exp_tab[tid] = k_exp2_j64[tid];
+// the eight flag counts of a row -> {n_00 n_01 n_10 n_11 missing_genotypes missing_alleles allele0 allele1} and the
+// Hardy-Weinberg test on (n_00, n_01 + n_10, n_11): the record k_stats_scan + k_stats_hwe produce
+__device__ __forceinline__ BatchStatsRec stats_record(const int (&cnt)[8]) {
+    BatchStatsRec r;
+    r.c8[0] = cnt[0]; r.c8[1] = cnt[1]; r.c8[2] = cnt[2]; r.c8[3] = cnt[3];
+    r.c8[4] = cnt[4]; r.c8[5] = cnt[4] + cnt[5];
+    r.c8[6] = 2 * cnt[0] + cnt[1] + cnt[2] + cnt[6]; r.c8[7] = 2 * cnt[3] + cnt[1] + cnt[2] + cnt[7];
+    const int n_AA = cnt[0], n_Aa = cnt[1] + cnt[2], n_aa = cnt[3], tot = n_AA + n_Aa + n_aa;
+    if (tot == 0) { r.hwe_chi2 = __builtin_nan(""); r.hwe_p = __builtin_nan(""); }
+    else {                                                     // the body of k_stats_hwe
+        const double pf = (2.0 * n_AA + n_Aa) / (2.0 * tot);
+        const double qf = 1.0 - pf;
+        const double e_AA = pf * pf * tot, e_Aa = 2.0 * pf * qf * tot, e_aa = qf * qf * tot;
+        double x = 0.0;
+        if (e_AA > 0.0) x += ((n_AA - e_AA) * (n_AA - e_AA)) / e_AA;
+        if (e_Aa > 0.0) x += ((n_Aa - e_Aa) * (n_Aa - e_Aa)) / e_Aa;
+        if (e_aa > 0.0) x += ((n_aa - e_aa) * (n_aa - e_aa)) / e_aa;
+        r.hwe_chi2 = x; r.hwe_p = chisq_p_value(x);
+    }
+    return r;
+}
 
-    // ---- 1. raw row -> LDS, aligned 16-byte loads (an aligned 16-byte granule never crosses a page, so the
-    //         bytes before the row's start / after its end that come along are harmless) -------------------------
-    const uintptr_t a = (uintptr_t)(A.src + (size_t)v * A.src_pitch);
+// the raw row of variant v into LDS (aligned 16-byte loads; an aligned granule never crosses a page, so the bytes before
+// the row's start / after its end that come along are harmless); returns the row's offset inside the window
+__device__ __forceinline__ int batch_stage_row(const uint8_t *src, size_t src_pitch, int v, int n_samples, uint8_t *lds_raw) {
+    const int tid = threadIdx.x;
+    const uintptr_t a = (uintptr_t)(src + (size_t)v * src_pitch);
     const uintptr_t a0 = a & ~(uintptr_t)15;
     const int shift = (int)(a - a0);
-    const int n16 = (shift + A.n_samples + 15) >> 4;
+    const int n16 = (shift + n_samples + 15) >> 4;
     for (int c0 = 0; c0 < n16; c0 += 4 * 256) {                   // four loads in flight per thread: one bus round trip per 16 KiB
         uint4 q[4];
 #pragma unroll
@@ -109,6 +124,20 @@ __global__ __launch_bounds__(256) void k_batch(BatchArgs A) {
             if (c < n16) reinterpret_cast<uint4 *>(lds_raw)[c] = q[u];
         }
     }
+    return shift;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_batch(BatchArgs A) {
+    extern __shared__ __align__(16) uint8_t lds_raw[];          // the aligned window of the raw row
+    __shared__ int red[4 * 8];
+    __shared__ double exp_tab[64];
+    const int v = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (KIND == BATCH_FISHER && tid < 64) exp_tab[tid] = k_exp2_j64[tid];
+
+    // ---- 1. raw row -> LDS ---------------------------------------------------------------------------------------
+    const int shift = batch_stage_row(A.src, A.src_pitch, v, A.n_samples, lds_raw);
     const bool x_row = (A.is_x != nullptr) && (A.is_x[v] != 0);
     __syncthreads();
     const uint8_t *raw = lds_raw + shift;
@@ -207,24 +236,124 @@ __global__ __launch_bounds__(256) void k_batch(BatchArgs A) {
                 for (int b = 0; b < 8; ++b) cnt[b] += __builtin_popcount(w[k] & (0x01010101u << b));
         }
         block_sum<8>(cnt, red);
-        if (tid == 0) {
-            BatchStatsRec r;
-            r.c8[0] = cnt[0]; r.c8[1] = cnt[1]; r.c8[2] = cnt[2]; r.c8[3] = cnt[3];
-            r.c8[4] = cnt[4]; r.c8[5] = cnt[4] + cnt[5];
-            r.c8[6] = 2 * cnt[0] + cnt[1] + cnt[2] + cnt[6]; r.c8[7] = 2 * cnt[3] + cnt[1] + cnt[2] + cnt[7];
-            const int n_AA = cnt[0], n_Aa = cnt[1] + cnt[2], n_aa = cnt[3], tot = n_AA + n_Aa + n_aa;
-            if (tot == 0) { r.hwe_chi2 = __builtin_nan(""); r.hwe_p = __builtin_nan(""); }
-            else {                                             // the body of k_stats_hwe
-                const double pf = (2.0 * n_AA + n_Aa) / (2.0 * tot);
-                const double qf = 1.0 - pf;
-                const double e_AA = pf * pf * tot, e_Aa = 2.0 * pf * qf * tot, e_aa = qf * qf * tot;
-                double x = 0.0;
-                if (e_AA > 0.0) x += ((n_AA - e_AA) * (n_AA - e_AA)) / e_AA;
-                if (e_Aa > 0.0) x += ((n_Aa - e_Aa) * (n_Aa - e_Aa)) / e_Aa;
-                if (e_aa > 0.0) x += ((n_aa - e_aa) * (n_aa - e_aa)) / e_aa;
-                r.hwe_chi2 = x; r.hwe_p = chisq_p_value(x);
+        if (tid == 0) reinterpret_cast<BatchStatsRec *>(A.out)[v] = stats_record(cnt);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Everything the stats tool wants of a batch (get_variants_stats + get_sample_stats, stats_runner.c:194-198) in ONE pass
+// over the raw matrix the tokenizer wrote: per variant the counters + Hardy-Weinberg record, the per-sample missing
+// counts, the Mendelian errors per variant and per child, and the counters of every phenotype group.  One workgroup per
+// variant; the row is read from HBM once, every statistic is computed from its LDS copy.  The per-sample / per-child
+// counters are sums over variants: device atomics, and only where something is missing / wrong (rare).
+// ---------------------------------------------------------------------------------------------------------------------
+struct StatsAllArgs {
+    const uint8_t *src; size_t src_pitch; int n_variants, n_samples;
+    const uint8_t *is_x;
+    BatchStatsRec *out;              // [n_variants]
+    int32_t *sample_missing;         // [n_samples] device, accumulated into; or null
+    // Mendelian errors over the trios of hpgv_set_pedigree: planes [father | mother | child] of col_of_pos
+    const int32_t *mendel_cols; int pchunks, n_trios; MendelLuts luts; const uint8_t *male_plane;
+    int32_t *mendel_errors;          // [n_variants]; or null
+    int32_t *child_errors;           // [n_trios] device, accumulated into; or null
+    // phenotype groups of hpgv_set_stats_groups: the grouped layout's permutation, first chunk and chunk count per group
+    const int32_t *group_cols; int n_groups; const int32_t *group_chunk0; const int32_t *group_chunks;
+    BatchStatsRec *group_out;        // [g * n_variants + v]; or null
+};
+
+__device__ __forceinline__ void stats_count_flags(const uint4 q, int (&cnt)[8]) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) cnt[b] += __builtin_popcount(w[k] & (0x01010101u << b));
+}
+
+static __global__ __launch_bounds__(256) void k_stats_all(StatsAllArgs A) {
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    __shared__ int red[4 * 8];
+    const int v = blockIdx.x, tid = threadIdx.x;
+    const int shift = batch_stage_row(A.src, A.src_pitch, v, A.n_samples, lds_raw);
+    const bool x_row = (A.is_x != nullptr) && (A.is_x[v] != 0);
+    __syncthreads();
+    const uint8_t *raw = lds_raw + shift;
+
+    // ---- all columns in VCF order: flags, counters, per-sample missing ---------------------------------------------------
+    {
+        int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int chunks = (A.n_samples + 15) >> 4;
+        for (int c = tid; c < chunks; c += 256) {
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = c * 16 + k * 4 + j;
+                    const uint32_t f = col < A.n_samples ? stats_flags((uint32_t)raw[col]) : 0u;
+                    acc |= f << (8 * j);
+                }
+                w[k] = acc;
             }
-            reinterpret_cast<BatchStatsRec *>(A.out)[v] = r;
+            stats_count_flags(make_uint4(w[0], w[1], w[2], w[3]), cnt);
+            if (A.sample_missing) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t m = (w[k] >> 4) & 0x01010101u;               // flag bit 4: some allele missing
+                    while (m) {
+                        const int j = (__builtin_ctz(m)) >> 3;
+                        atomicAdd(A.sample_missing + c * 16 + k * 4 + j, 1);
+                        m &= m - 1;
+                    }
+                }
+            }
+        }
+        block_sum<8>(cnt, red);
+        if (tid == 0) A.out[v] = stats_record(cnt);
+    }
+
+    // ---- Mendelian errors: class planes gathered per trio, 4 trios per dword ------------------------------------------
+    if (A.mendel_errors || A.child_errors) {
+        int n[1] = {0};
+        for (int c = tid; c < A.pchunks; c += 256) {
+            const uint4 qf = batch_gather_chunk(raw, A.mendel_cols, c, true, RECODE_MENDEL, 0);
+            const uint4 qm = batch_gather_chunk(raw, A.mendel_cols, c + A.pchunks, true, RECODE_MENDEL, 0);
+            const uint4 qc = batch_gather_chunk(raw, A.mendel_cols, c + 2 * A.pchunks, true, RECODE_MENDEL, 0);
+            uint32_t e[4];
+            if (!x_row) {
+                e[0] = mendel4<false>(A.luts, qf.x, qm.x, qc.x, 0); e[1] = mendel4<false>(A.luts, qf.y, qm.y, qc.y, 0);
+                e[2] = mendel4<false>(A.luts, qf.z, qm.z, qc.z, 0); e[3] = mendel4<false>(A.luts, qf.w, qm.w, qc.w, 0);
+            } else {
+                const uint4 ml = reinterpret_cast<const uint4 *>(A.male_plane)[c];
+                e[0] = mendel4<true>(A.luts, qf.x, qm.x, qc.x, ml.x); e[1] = mendel4<true>(A.luts, qf.y, qm.y, qc.y, ml.y);
+                e[2] = mendel4<true>(A.luts, qf.z, qm.z, qc.z, ml.z); e[3] = mendel4<true>(A.luts, qf.w, qm.w, qc.w, ml.w);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                n[0] += __builtin_popcount(e[k]);
+                if (A.child_errors) {
+                    uint32_t m = e[k];
+                    while (m) {
+                        const int t = c * 16 + k * 4 + ((__builtin_ctz(m)) >> 3);
+                        if (t < A.n_trios) atomicAdd(A.child_errors + t, 1);
+                        m &= m - 1;
+                    }
+                }
+            }
+        }
+        block_sum<1>(n, red);
+        if (tid == 0 && A.mendel_errors) A.mendel_errors[v] = n[0];
+    }
+
+    // ---- per phenotype group: the grouped layout's chunks, one group after the other -----------------------------------
+    if (A.group_out) {
+        for (int g = 0; g < A.n_groups; ++g) {
+            int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const int c0 = A.group_chunk0[g], nc = A.group_chunks[g];
+            for (int c = tid; c < nc; c += 256)
+                stats_count_flags(batch_gather_chunk(raw, A.group_cols, c0 + c, false, RECODE_STATS, 0), cnt);
+            block_sum<8>(cnt, red);
+            if (tid == 0) A.group_out[(size_t)g * (size_t)A.n_variants + (size_t)v] = stats_record(cnt);
         }
     }
 }

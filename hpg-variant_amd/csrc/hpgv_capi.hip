@@ -3,6 +3,7 @@
 // There is no CPU path in this library: every entry point that computes
 // launches HIP kernels, and hpgv_create() fails without a device.
 #include "hpgv_internal.h"
+#include <cstdlib>
 #include "hpgv_text_kernels.h"
 #include "hpgv_inflate_kernels.h"
 #include "hpgv_batch_kernels.h"
@@ -122,10 +123,12 @@ int hpgv_create(int device_id, hpgv_ctx **out) {
         ok = ok && hipFuncSetAttribute((const void *)hpgv::k_batch<hpgv::BATCH_FISHER>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)hpgv::k_batch<hpgv::BATCH_TDT>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)hpgv::k_batch<hpgv::BATCH_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)hpgv::k_stats_all, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
         if (ok && prop.sharedMemPerBlockOptin >= (size_t)want) ctx->batch_lds_max = want;
         else if (ok && prop.maxSharedMemoryPerMultiProcessor >= (size_t)want) ctx->batch_lds_max = want;
         (void)hipGetLastError();
     }
+    if (const char *bf = getenv("HPGV_BATCH_FUSED")) ctx->batch_fused = atoi(bf) ? 1 : 0;      // diagnosis: 0 = the kernel chains
     e = hipMalloc(&ctx->d_sink, 256);
     if (e != hipSuccess) {
         int rc = fail(nullptr, HPGV_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
@@ -184,6 +187,7 @@ void hpgv_destroy(hpgv_ctx *ctx) {
     DeviceGuard g(ctx->device);
     (void)hipDeviceSynchronize();
     if (ctx->d_mendel_male) (void)hipFree(ctx->d_mendel_male);
+    if (ctx->d_sg_chunks) (void)hipFree(ctx->d_sg_chunks);
     for (Layout *L : {&ctx->assoc, &ctx->tdt, &ctx->stats, &ctx->sgroups, &ctx->mendel})
         if (L->d_col_of_pos) (void)hipFree(L->d_col_of_pos);
     ctx->tdt_plan.release();
@@ -356,6 +360,19 @@ int hpgv_set_stats_groups(hpgv_ctx *ctx, const int32_t *group_of_sample, int n_s
         if (group_of_sample[j] >= 0) L.col_of_pos[fill[(size_t)group_of_sample[j]]++] = j;
     ctx->sg_off = off;
     ctx->sg_size = size;
+    {   // first chunk / chunk count per group for the one-pass stats kernel
+        std::vector<int32_t> tab((size_t)n_groups * 2);
+        for (int k = 0; k < n_groups; ++k) {
+            tab[(size_t)k] = (int32_t)(off[(size_t)k] / 16);
+            tab[(size_t)n_groups + (size_t)k] = (int32_t)(round_up((size_t)size[(size_t)k], 16) / 16);
+        }
+        if (ctx->sg_chunks_cap < tab.size()) {
+            if (ctx->d_sg_chunks) { (void)hipFree(ctx->d_sg_chunks); ctx->d_sg_chunks = nullptr; ctx->sg_chunks_cap = 0; }
+            HIPCHK(ctx, hipMalloc(&ctx->d_sg_chunks, tab.size() * sizeof(int32_t)));
+            ctx->sg_chunks_cap = tab.size();
+        }
+        HIPCHK(ctx, hipMemcpy(ctx->d_sg_chunks, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     return upload_layout(ctx, L);
 }
 
@@ -1443,7 +1460,7 @@ int hpgv_tokenize(hpgv_ctx *ctx, const char *text, size_t text_bytes, int n_samp
 // 6 {n_lines, line_off..., field_off...}, 7 raw gt (VCF order)
 static int text_front(hpgv_ctx *ctx, Slot *s, int which, const Layout &L, const char *text, size_t text_bytes,
                       int max_lines, int *n_lines, uint64_t *line_off, uint32_t *field_off, int32_t *status,
-                      int *nl_out) {
+                      int *nl_out, bool final_layout = true) {
     int rc;
     const size_t ml = (size_t)max_lines;
     const size_t raw_pitch = (size_t)(L.n_samples > 0 ? (L.n_samples + 15) / 16 * 16 : 16);
@@ -1525,6 +1542,7 @@ static int text_front(hpgv_ctx *ctx, Slot *s, int which, const Layout &L, const 
             if (out) status[i] |= HPGV_LINE_FILTERED;
         }
     }
+    if (!final_layout) return HPGV_OK;                       // the caller's one-pass kernel reads the raw matrix itself
     return hpgv_layout_dev(ctx, which, (const uint8_t *)s->buf[7], raw_pitch, nl, (uint8_t *)s->buf[1], s->stream);
 }
 
@@ -1557,9 +1575,38 @@ int hpgv_assoc_text(hpgv_ctx *ctx, int task, const char *text, size_t text_bytes
     if (rc) return rc;
     Slot *s = lease.s;
     int nl = 0;
-    if ((rc = text_front(ctx, s, HPGV_LAYOUT_ASSOC, ctx->assoc, text, text_bytes, max_lines, n_lines, line_off, field_off, status, &nl))) return rc;
+    const bool fused = batch_fused_ok(ctx, ctx->assoc.n_samples);
+    if (fused && task == HPGV_TASK_FISHER) {
+        if (!ctx->d_lf) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_logfact has not been called");
+        if (ctx->n_lf < (size_t)2 * (ctx->nA + ctx->nU) + 1)
+            return fail(ctx, HPGV_ERR_STATE, "log-factorial table has %zu entries, need %d", ctx->n_lf, 2 * (ctx->nA + ctx->nU) + 1);
+    }
+    if ((rc = text_front(ctx, s, HPGV_LAYOUT_ASSOC, ctx->assoc, text, text_bytes, max_lines, n_lines, line_off, field_off, status, &nl, !fused))) return rc;
     if (nl == 0) { HIPCHK(ctx, hipStreamSynchronize(s->stream)); return HPGV_OK; }
     const size_t n = (size_t)nl;
+    if (fused) {
+        // the tokenizer's raw matrix is read ONCE: layout in registers, counts, statistics, packed records (hpgv_batch_kernels.h)
+        const int ns = ctx->assoc.n_samples;
+        hpgv::BatchArgs A;
+        memset(&A, 0, sizeof A);
+        A.src = (const uint8_t *)s->buf[7]; A.src_pitch = (size_t)(ns > 0 ? (ns + 15) / 16 * 16 : 16);
+        A.n_variants = nl; A.n_samples = ns; A.is_x = (const uint8_t *)s->buf[2];
+        if ((rc = ensure_result_block(ctx, s, n * sizeof(hpgv::BatchAssocRec)))) return rc;
+        A.col_of_pos = ctx->assoc.d_col_of_pos; A.chunks = ctx->assoc.chunks; A.chunksA = ctx->chunksA;
+        A.lf = ctx->d_lf; A.rel_cut = pow(10.0, -(double)ctx->fisher_cut_exp);
+        A.out = s->d_res;
+        if (task == HPGV_TASK_CHISQ) rc = launch_batch<hpgv::BATCH_CHISQ>(ctx, s, A);
+        else rc = launch_batch<hpgv::BATCH_FISHER>(ctx, s, A);
+        if (rc) { (void)hipStreamSynchronize(s->stream); return rc; }
+        HIPCHK(ctx, hipStreamSynchronize(s->stream));
+        const hpgv::BatchAssocRec *r = (const hpgv::BatchAssocRec *)s->h_res;
+        for (size_t i = 0; i < n; ++i) {
+            A1[i] = r[i].A1; A2[i] = r[i].A2; U1[i] = r[i].U1; U2[i] = r[i].U2;
+            odds[i] = r[i].odds; p[i] = r[i].p;
+        }
+        if (task == HPGV_TASK_CHISQ) for (size_t i = 0; i < n; ++i) chisq[i] = r[i].chisq;
+        return HPGV_OK;
+    }
     if ((rc = ensure(ctx, s, 3, n * 16))) return rc;
     if ((rc = ensure(ctx, s, 4, n * 3 * sizeof(double)))) return rc;
     int32_t *d_counts = (int32_t *)s->buf[3];
@@ -1602,9 +1649,28 @@ int hpgv_tdt_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_li
     if (rc) return rc;
     Slot *s = lease.s;
     int nl = 0;
-    if ((rc = text_front(ctx, s, HPGV_LAYOUT_TDT, ctx->tdt, text, text_bytes, max_lines, n_lines, line_off, field_off, status, &nl))) return rc;
+    const bool fused = batch_fused_ok(ctx, ctx->tdt.n_samples);
+    if ((rc = text_front(ctx, s, HPGV_LAYOUT_TDT, ctx->tdt, text, text_bytes, max_lines, n_lines, line_off, field_off, status, &nl, !fused))) return rc;
     if (nl == 0) { HIPCHK(ctx, hipStreamSynchronize(s->stream)); return HPGV_OK; }
     const size_t n = (size_t)nl;
+    if (fused) {
+        const int ns = ctx->tdt.n_samples;
+        hpgv::BatchArgs A;
+        memset(&A, 0, sizeof A);
+        A.src = (const uint8_t *)s->buf[7]; A.src_pitch = (size_t)(ns > 0 ? (ns + 15) / 16 * 16 : 16);
+        A.n_variants = nl; A.n_samples = ns; A.is_x = (const uint8_t *)s->buf[2];
+        if ((rc = ensure_result_block(ctx, s, n * sizeof(hpgv::BatchTdtRec)))) return rc;
+        const hpgv::TdtPlan &P = ctx->tdt_plan;
+        A.col_of_pos = ctx->tdt.d_col_of_pos; A.chunks = ctx->tdt.chunks;
+        A.pchunks = P.pchunks; A.p16 = P.p16; A.n_slow = P.n_slow_families; A.slow_base = P.slow_base; A.luts = P.luts;
+        A.male_plane = P.d_male_plane; A.slow_off = P.d_slow_off; A.slow_male = P.d_slow_male;
+        A.out = s->d_res;
+        if ((rc = launch_batch<hpgv::BATCH_TDT>(ctx, s, A))) { (void)hipStreamSynchronize(s->stream); return rc; }
+        HIPCHK(ctx, hipStreamSynchronize(s->stream));
+        const hpgv::BatchTdtRec *r = (const hpgv::BatchTdtRec *)s->h_res;
+        for (size_t i = 0; i < n; ++i) { t1[i] = r[i].t1; t2[i] = r[i].t2; odds[i] = r[i].odds; chisq[i] = r[i].chisq; p[i] = r[i].p; }
+        return HPGV_OK;
+    }
     if ((rc = ensure(ctx, s, 3, n * 8))) return rc;
     if ((rc = ensure(ctx, s, 4, n * 3 * sizeof(double)))) return rc;
     int32_t *d_tu = (int32_t *)s->buf[3];
@@ -1660,11 +1726,82 @@ int hpgv_stats_text_groups(hpgv_ctx *ctx, const char *text, size_t text_bytes, i
     if (rc) return rc;
     Slot *s = lease.s;
     int nl = 0;
-    if ((rc = text_front(ctx, s, HPGV_LAYOUT_STATS, ctx->stats, text, text_bytes, max_lines, n_lines, line_off, field_off, status, &nl))) return rc;
+    const bool fused = batch_fused_ok(ctx, ctx->stats.n_samples);
+    if ((rc = text_front(ctx, s, HPGV_LAYOUT_STATS, ctx->stats, text, text_bytes, max_lines, n_lines, line_off, field_off, status, &nl, !fused))) return rc;
     if (nl == 0) { HIPCHK(ctx, hipStreamSynchronize(s->stream)); return HPGV_OK; }
     const size_t n = (size_t)nl;
     const int ns = ctx->stats.n_samples;
     const size_t raw_pitch = (size_t)(ns > 0 ? (ns + 15) / 16 * 16 : 16);
+    if (fused) {
+        // ONE pass over the tokenizer's raw matrix gives every statistic of the batch (k_stats_all): the genotype bytes
+        // are read from HBM once after tokenizing
+        const size_t ng = group_counts8 ? ctx->sg_off.size() : 0, nt = (size_t)ctx->mendel_trios;
+        const size_t rec_bytes = (1 + ng) * n * sizeof(hpgv::BatchStatsRec);
+        if ((rc = ensure_result_block(ctx, s, rec_bytes + n * sizeof(int32_t) + 64))) return rc;
+        const bool want_sm = sample_missing && ns > 0, want_ce = child_errors && nt > 0;
+        if ((rc = ensure(ctx, s, 3, ((size_t)ns + nt + 16) * sizeof(int32_t)))) return rc;
+        int32_t *d_sm = (int32_t *)s->buf[3], *d_ce = d_sm + ns;
+        if (want_sm || want_ce) HIPCHK(ctx, hipMemsetAsync(d_sm, 0, ((size_t)ns + nt) * sizeof(int32_t), s->stream));
+        hpgv::StatsAllArgs A;
+        memset(&A, 0, sizeof A);
+        A.src = (const uint8_t *)s->buf[7]; A.src_pitch = raw_pitch; A.n_variants = nl; A.n_samples = ns;
+        A.is_x = (const uint8_t *)s->buf[2];
+        A.out = (hpgv::BatchStatsRec *)s->d_res;
+        A.sample_missing = want_sm ? d_sm : nullptr;
+        if (want_mendel) {
+            A.mendel_cols = ctx->mendel.d_col_of_pos; A.pchunks = ctx->mendel_pchunks; A.n_trios = ctx->mendel_trios;
+            A.luts = ctx->mendel_luts; A.male_plane = ctx->d_mendel_male;
+            A.mendel_errors = mendel_errors ? (int32_t *)((char *)s->d_res + rec_bytes) : nullptr;
+            A.child_errors = want_ce ? d_ce : nullptr;
+        }
+        if (ng) {
+            A.group_cols = ctx->sgroups.d_col_of_pos; A.n_groups = (int)ng;
+            A.group_chunk0 = ctx->d_sg_chunks; A.group_chunks = ctx->d_sg_chunks + ng;
+            A.group_out = (hpgv::BatchStatsRec *)s->d_res + n;
+        }
+        const size_t lds = ((size_t)ns + 15 + 15) / 16 * 16 + 16;
+        hipLaunchKernelGGL(hpgv::k_stats_all, dim3((unsigned)nl), dim3(256), lds, s->stream, A);
+        HIPCHK(ctx, hipGetLastError());
+        std::vector<int32_t> acc;
+        if (want_sm || want_ce) {
+            acc.resize((size_t)ns + nt);
+            HIPCHK(ctx, hipMemcpyAsync(acc.data(), d_sm, acc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+        }
+        HIPCHK(ctx, hipStreamSynchronize(s->stream));
+        const hpgv::BatchStatsRec *r = (const hpgv::BatchStatsRec *)s->h_res;
+        for (size_t i = 0; i < n; ++i) {
+            memcpy(counts8 + 8 * i, r[i].c8, 8 * sizeof(int32_t));
+            hwe_chi2[i] = r[i].hwe_chi2; hwe_p[i] = r[i].hwe_p;
+        }
+        for (size_t k = 0; k < ng; ++k)
+            for (size_t i = 0; i < n; ++i) {
+                const hpgv::BatchStatsRec &q = r[n + k * n + i];
+                memcpy(group_counts8 + (k * (size_t)max_lines + i) * 8, q.c8, 8 * sizeof(int32_t));
+                if (group_hwe_chi2) { group_hwe_chi2[k * (size_t)max_lines + i] = q.hwe_chi2; group_hwe_p[k * (size_t)max_lines + i] = q.hwe_p; }
+            }
+        if (want_mendel && mendel_errors) memcpy(mendel_errors, (const char *)s->h_res + rec_bytes, n * sizeof(int32_t));
+        if (want_sm) for (int j = 0; j < ns; ++j) sample_missing[j] += acc[(size_t)j];
+        if (want_ce) for (size_t t = 0; t < nt; ++t) child_errors[t] += acc[(size_t)ns + t];
+        if (n_multi) {
+            std::vector<int32_t> idx;
+            for (size_t i = 0; i < n; ++i) {
+                const int32_t *c = counts8 + 8 * i;
+                if (ns - c[4] - (c[0] + c[1] + c[2] + c[3]) > 0) idx.push_back((int32_t)i);
+            }
+            *n_multi = (int)idx.size();
+            const int m = (int)idx.size() < cap ? (int)idx.size() : cap;
+            if (m > 0) {
+                if ((rc = ensure(ctx, s, 3, (size_t)m * 257 * sizeof(int32_t)))) return rc;
+                int32_t *d_idx = (int32_t *)s->buf[3], *d_tab = d_idx + m;
+                HIPCHK(ctx, hipMemcpyAsync(d_idx, idx.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+                if ((rc = hpgv_genotype_table_dev(ctx, (const uint8_t *)s->buf[7], raw_pitch, ns, d_idx, m, d_tab, s->stream))) return rc;
+                HIPCHK(ctx, hipMemcpyAsync(multi_table, d_tab, (size_t)m * 256 * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+                HIPCHK(ctx, hipStreamSynchronize(s->stream));
+                memcpy(multi_idx, idx.data(), (size_t)m * sizeof(int32_t));
+            }
+        }
+        return HPGV_OK;
+    }
     if ((rc = ensure(ctx, s, 3, n * 32))) return rc;
     if ((rc = ensure(ctx, s, 4, n * 2 * sizeof(double) + 64))) return rc;
     int32_t *d_c8 = (int32_t *)s->buf[3];

@@ -106,6 +106,8 @@ struct hpgv_ctx {
     Layout sgroups;                       // [group 0 | pad16 | group 1 | ...]
     std::vector<uint32_t> sg_off;         // byte offset of every group's segment in the row
     std::vector<int> sg_size;             // samples per group
+    int32_t *d_sg_chunks = nullptr;       // device: first 16-byte chunk and chunk count of every group ([2 * n_groups])
+    size_t sg_chunks_cap = 0;
     // mendelian errors
     Layout mendel;
     int mendel_trios = 0, mendel_pchunks = 0;

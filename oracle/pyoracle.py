@@ -23,6 +23,11 @@ def build(force=False):
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in src)):
         return _SO
+    # never build from inside a profiled process: the children (make, gcc, ld) would inherit the profiler's preload
+    # and run under it on the GPU box; the profile scripts build before their first rocprofv3 line
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        raise RuntimeError("oracle/_build is missing or stale and this process runs under a profiler: "
+                           "run `python __graft_entry__.py` first")
     subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 

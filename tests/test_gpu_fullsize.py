@@ -20,12 +20,18 @@ def _rows(v0, idx, n_samples):
     return np.stack([orc.synth_matrix(v0 + int(v), 1, n_samples, n_samples)[0] for v in idx])
 
 
-@pytest.mark.parametrize("V,N", [(1_000_000, 10_000), (1_250_000, 50_000)])
+# (1M, 10k) = BASELINE configs[1] / [2]; (1.25M, 50k) = the metric cohort's 1/8 shard; (1M, 100k) = one 100 GB tile of a GPU's
+# shard of configs[4] (40M x 100k on 8 GPUs: 5 such tiles per GPU)
+@pytest.mark.parametrize("V,N", [(1_000_000, 10_000), (1_250_000, 50_000), (1_000_000, 100_000)])
 def test_assoc_chisq_and_fisher_full_size(V, N):
     e = hpgv.Engine(0)
     cond = (np.arange(N) % 2).astype(np.uint8)
     nA, nU, pitch = e.set_cohort(cond)
-    d_gt, d_counts, d_counts2 = e.alloc(V * pitch), e.alloc(V * 16), e.alloc(V * 16)
+    try:
+        d_gt = e.alloc(V * pitch)
+    except hpgv.HpgvError as err:
+        pytest.fail("cannot allocate the %.0f GB genotype tile of the %d x %d case on this GPU: %s" % (V * pitch / 1e9, V, N, err))
+    d_counts, d_counts2 = e.alloc(V * 16), e.alloc(V * 16)
     d_st = e.alloc(V * 24)
     e.synth(hpgv.LAYOUT_ASSOC, 0, V, d_gt)
     e.assoc_scan(d_gt, V, d_counts)

@@ -68,14 +68,17 @@ rc = L.hpgv_run_assoc(vcf, ped, out + b".fisher", 2, 1 << 16, C.byref(n))
 assert rc == 0, L.hpgv_host_last_error()
 rc = L.hpgv_run_tdt(vcf, ped, out + b".tdt", 1 << 16, C.byref(n))
 assert rc == 0, L.hpgv_host_last_error()
+L.hpgv_run_stats.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_long)]
+rc = L.hpgv_run_stats(vcf, ped, out, 1 << 16, C.byref(n))
+assert rc == 0, L.hpgv_host_last_error()
 print(L.hpgv_host_device_count(), n.value)
 L.hpgv_host_shutdown()
 """
 
 
 def test_runners_with_hpgv_devices_are_byte_identical(tmp_path):
-    """hpgv_run_assoc / hpgv_run_tdt with HPGV_DEVICES=0,0,0 (three contexts, six engine threads) write the same sorted files
-    as with one device."""
+    """hpgv_run_assoc / hpgv_run_tdt / hpgv_run_stats with HPGV_DEVICES=0,0,0 (three contexts, six engine threads) write the same
+    files as with one device -- and the one-pass kernels (default) the same files as the kernel chains (HPGV_BATCH_FUSED=0)."""
     from test_file_runner_gpu import _vcf_from_batch
     from test_host_mirror_gpu import _write_inputs
     rng = np.random.default_rng(21)
@@ -85,17 +88,25 @@ def test_runners_with_hpgv_devices_are_byte_identical(tmp_path):
     script = tmp_path / "run.py"
     script.write_text(_RUNNER % {"root": ROOT})
     outs = {}
-    for tag, devs in (("one", None), ("three", "0,0,0")):
-        env = {k: v for k, v in os.environ.items() if k != "HPGV_DEVICES"}
+    exts = (".chisq", ".fisher", ".tdt", ".stats-variants", ".stats-samples", ".stats-summary")
+    for tag, devs in (("one", None), ("three", "0,0,0"), ("chains", None)):
+        env = {k: v for k, v in os.environ.items() if k not in ("HPGV_DEVICES", "HPGV_BATCH_FUSED")}
         if devs:
             env["HPGV_DEVICES"] = devs
+        if tag == "chains":
+            env["HPGV_BATCH_FUSED"] = "0"
         r = subprocess.run([sys.executable, str(script), vcf, ped, str(tmp_path / tag)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         n_dev, n_rec = r.stdout.split()
         assert int(n_dev) == (3 if devs else 1) and int(n_rec) == len(rows)
-        outs[tag] = [open(str(tmp_path / tag) + ext, "rb").read() for ext in (".chisq", ".fisher", ".tdt")]
-    assert outs["one"] == outs["three"]
-    assert all(len(x) > 1000 for x in outs["one"])
+        outs[tag] = [open(str(tmp_path / tag) + ext, "rb").read() for ext in exts]
+        import glob
+        outs[tag] += [open(f, "rb").read() for f in sorted(glob.glob(str(tmp_path / tag) + ".phenotype-*"))]
+    assert len(outs["one"]) > len(exts)                        # the per-phenotype files are there too
+    for k in range(len(outs["one"])):
+        assert outs["one"][k] == outs["three"][k], k
+        assert outs["one"][k] == outs["chains"][k], k
+    assert all(len(x) > 100 for x in outs["one"])
 
 
 def test_bad_device_list_is_refused(tmp_path):
