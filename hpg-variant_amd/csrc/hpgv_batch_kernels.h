@@ -243,12 +243,23 @@ __global__ __launch_bounds__(256) void k_batch(BatchArgs A) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Everything the stats tool wants of a batch (get_variants_stats + get_sample_stats, stats_runner.c:194-198) in ONE pass
 // over the raw matrix the tokenizer wrote: per variant the counters + Hardy-Weinberg record, the per-sample missing
-// counts, the Mendelian errors per variant and per child, and the counters of every phenotype group.  One workgroup per
-// variant; the row is read from HBM once, every statistic is computed from its LDS copy.  The per-sample / per-child
-// counters are sums over variants: device atomics, and only where something is missing / wrong (rare).
+// counts, the Mendelian errors per variant and per child, and the counters of every phenotype group.  A workgroup owns a
+// band of consecutive variants; each row is read from HBM once into LDS and every statistic is computed from that copy:
+//   A. all columns in VCF order, four genotypes per instruction: every byte becomes its PAIR CLASS idx = 4 c1 + c2 with
+//      c = class of an allele nibble (0, 1, other, missing) through 16-entry v_perm_b32 tables, written back over the raw
+//      byte; the one-hot stats flags are a 16-entry table of idx; eight masked popcounts per dword; the "some allele
+//      missing" bits are added to per-column byte counters kept in LDS across the band;
+//   B. the trios' [father | mother | child] planes gather idx bytes by column, a 16-entry table gives the zero-ness class
+//      check_mendel looks at, the error table of k_mendel_scan the error bit per trio; per-trio byte counters in LDS;
+//   C. every phenotype group gathers idx bytes in its own column order and counts the flags.
+// The per-sample / per-child counters are column sums over variants: at the band's end the LDS counters go to the device
+// totals by atomics -- coalesced full-wave atomics over ALL columns when the band saw many events (a dense wave atomic
+// costs what one scattered lane costs), only the non-zero counters when it saw few.
 // ---------------------------------------------------------------------------------------------------------------------
 struct StatsAllArgs {
     const uint8_t *src; size_t src_pitch; int n_variants, n_samples;
+    int rows_per_block;              // band length (<= 255: byte counters)
+    int lds_row;                     // bytes of the row window in LDS (multiple of 16)
     const uint8_t *is_x;
     BatchStatsRec *out;              // [n_variants]
     int32_t *sample_missing;         // [n_samples] device, accumulated into; or null
@@ -261,6 +272,39 @@ struct StatsAllArgs {
     BatchStatsRec *group_out;        // [g * n_variants + v]; or null
 };
 
+// 16-entry byte table look-up on four selectors (0..15) at once: two 8-entry v_perm_b32 + one v_perm_b32 to pick by bit 3
+__device__ __forceinline__ uint32_t lut16x4(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t sel) {
+    const uint32_t s7 = sel & 0x07070707u;
+    const uint32_t lo = __builtin_amdgcn_perm(t1, t0, s7), hi = __builtin_amdgcn_perm(t3, t2, s7);
+    return __builtin_amdgcn_perm(hi, lo, ((sel >> 1) & 0x04040404u) | 0x03020100u);
+}
+// class of an allele nibble: 0 -> 0, 1 -> 1, 2..14 -> 2, 15 (missing) -> 3
+__device__ __forceinline__ uint32_t nib_class4(uint32_t n) { return lut16x4(0x02020100u, 0x02020202u, 0x02020202u, 0x03020202u, n); }
+// four HPGV8 bytes -> four pair classes idx = 4 * class(allele1) + class(allele2)
+__device__ __forceinline__ uint32_t pair_class4(uint32_t g) {
+    return (nib_class4((g >> 4) & 0x0F0F0F0Fu) << 2) | nib_class4(g & 0x0F0F0F0Fu);
+}
+// stats_flags (hpgv_kernels.h) as a table of the pair class: rows c1 = 0, 1, other, missing; columns c2 likewise
+__device__ __forceinline__ uint32_t flags_of_class4(uint32_t idx) { return lut16x4(0x50400201u, 0x90800804u, 0x10008040u, 0x30109050u, idx); }
+// mendel_class (hpgv_kernels.h) as a table of the pair class: 0 "0/0", 1 one zero allele, 2 no zero allele, 3 not fully called
+__device__ __forceinline__ uint32_t mendel_of_class4(uint32_t idx) { return lut16x4(0x03010100u, 0x03020201u, 0x03020201u, 0x03030303u, idx); }
+constexpr uint32_t PAIR_CLASS_NOFLAGS = 10u;   // (other, other): no stats flag -- the pad of a group's segment
+constexpr uint32_t PAIR_CLASS_MISSING = 15u;   // (missing, missing): the pad of a trio plane
+
+// 16 pair-class bytes gathered by column from the row's LDS copy
+__device__ __forceinline__ uint4 gather_class_chunk(const uint8_t *cls /* LDS */, const int32_t *__restrict__ cols, int c, uint32_t pad) {
+    const int4 *cp = reinterpret_cast<const int4 *>(cols + (size_t)c * 16);
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int4 q = cp[k];
+        const uint32_t b0 = q.x < 0 ? pad : (uint32_t)cls[q.x], b1 = q.y < 0 ? pad : (uint32_t)cls[q.y];
+        const uint32_t b2 = q.z < 0 ? pad : (uint32_t)cls[q.z], b3 = q.w < 0 ? pad : (uint32_t)cls[q.w];
+        w[k] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 __device__ __forceinline__ void stats_count_flags(const uint4 q, int (&cnt)[8]) {
     const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
@@ -270,90 +314,128 @@ __device__ __forceinline__ void stats_count_flags(const uint4 q, int (&cnt)[8]) 
 }
 
 static __global__ __launch_bounds__(256) void k_stats_all(StatsAllArgs A) {
-    extern __shared__ __align__(16) uint8_t lds_raw[];
+    extern __shared__ __align__(16) uint8_t lds[];
     __shared__ int red[4 * 8];
-    const int v = blockIdx.x, tid = threadIdx.x;
-    const int shift = batch_stage_row(A.src, A.src_pitch, v, A.n_samples, lds_raw);
-    const bool x_row = (A.is_x != nullptr) && (A.is_x[v] != 0);
-    __syncthreads();
-    const uint8_t *raw = lds_raw + shift;
+    const int tid = threadIdx.x;
+    const int chunks = (A.n_samples + 15) >> 4;
+    uint8_t *lds_raw = lds;
+    uint32_t *miss_cnt = reinterpret_cast<uint32_t *>(lds + A.lds_row);           // [chunks * 4]: byte counters per column
+    uint32_t *trio_cnt = miss_cnt + (size_t)chunks * 4;                            // [pchunks * 4]: byte counters per trio
+    const bool want_sm = A.sample_missing != nullptr, want_ce = A.child_errors != nullptr;
+    const bool want_me = A.mendel_errors != nullptr || want_ce;
+    if (want_sm) for (int i = tid; i < chunks * 4; i += 256) miss_cnt[i] = 0u;
+    if (want_ce) for (int i = tid; i < A.pchunks * 4; i += 256) trio_cnt[i] = 0u;
+    const int v0 = blockIdx.x * A.rows_per_block;
+    const int v1 = v0 + A.rows_per_block < A.n_variants ? v0 + A.rows_per_block : A.n_variants;
+    int events[2] = {0, 0};                                                        // missing genotypes / child errors of the band
 
-    // ---- all columns in VCF order: flags, counters, per-sample missing ---------------------------------------------------
-    {
+    for (int v = v0; v < v1; ++v) {
+        __syncthreads();                                                           // the previous row's readers are done
+        const int shift = batch_stage_row(A.src, A.src_pitch, v, A.n_samples, lds_raw);
+        const bool x_row = (A.is_x != nullptr) && (A.is_x[v] != 0);
+        __syncthreads();
+        uint8_t *row = lds_raw + shift;                                            // raw bytes now, pair classes after pass A
+
+        // ---- A. all columns in VCF order ---------------------------------------------------------------------------------
         int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int chunks = (A.n_samples + 15) >> 4;
         for (int c = tid; c < chunks; c += 256) {
-            uint32_t w[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                uint32_t acc = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int col = c * 16 + k * 4 + j;
-                    const uint32_t f = col < A.n_samples ? stats_flags((uint32_t)raw[col]) : 0u;
-                    acc |= f << (8 * j);
-                }
-                w[k] = acc;
-            }
-            stats_count_flags(make_uint4(w[0], w[1], w[2], w[3]), cnt);
-            if (A.sample_missing) {
+            uint32_t g[4];
+            if (shift == 0) {                                                      // rows of a 16-byte pitch (the tokenizer's): vector reads
+                const uint4 q = reinterpret_cast<const uint4 *>(row)[c];
+                g[0] = q.x; g[1] = q.y; g[2] = q.z; g[3] = q.w;
+            } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    uint32_t m = (w[k] >> 4) & 0x01010101u;               // flag bit 4: some allele missing
-                    while (m) {
-                        const int j = (__builtin_ctz(m)) >> 3;
-                        atomicAdd(A.sample_missing + c * 16 + k * 4 + j, 1);
-                        m &= m - 1;
-                    }
+                    const uint8_t *b = row + c * 16 + k * 4;
+                    g[k] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
                 }
             }
-        }
-        block_sum<8>(cnt, red);
-        if (tid == 0) A.out[v] = stats_record(cnt);
-    }
-
-    // ---- Mendelian errors: class planes gathered per trio, 4 trios per dword ------------------------------------------
-    if (A.mendel_errors || A.child_errors) {
-        int n[1] = {0};
-        for (int c = tid; c < A.pchunks; c += 256) {
-            const uint4 qf = batch_gather_chunk(raw, A.mendel_cols, c, true, RECODE_MENDEL, 0);
-            const uint4 qm = batch_gather_chunk(raw, A.mendel_cols, c + A.pchunks, true, RECODE_MENDEL, 0);
-            const uint4 qc = batch_gather_chunk(raw, A.mendel_cols, c + 2 * A.pchunks, true, RECODE_MENDEL, 0);
-            uint32_t e[4];
-            if (!x_row) {
-                e[0] = mendel4<false>(A.luts, qf.x, qm.x, qc.x, 0); e[1] = mendel4<false>(A.luts, qf.y, qm.y, qc.y, 0);
-                e[2] = mendel4<false>(A.luts, qf.z, qm.z, qc.z, 0); e[3] = mendel4<false>(A.luts, qf.w, qm.w, qc.w, 0);
-            } else {
-                const uint4 ml = reinterpret_cast<const uint4 *>(A.male_plane)[c];
-                e[0] = mendel4<true>(A.luts, qf.x, qm.x, qc.x, ml.x); e[1] = mendel4<true>(A.luts, qf.y, qm.y, qc.y, ml.y);
-                e[2] = mendel4<true>(A.luts, qf.z, qm.z, qc.z, ml.z); e[3] = mendel4<true>(A.luts, qf.w, qm.w, qc.w, ml.w);
-            }
+            uint32_t idx[4], f[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                n[0] += __builtin_popcount(e[k]);
-                if (A.child_errors) {
-                    uint32_t m = e[k];
-                    while (m) {
-                        const int t = c * 16 + k * 4 + ((__builtin_ctz(m)) >> 3);
-                        if (t < A.n_trios) atomicAdd(A.child_errors + t, 1);
-                        m &= m - 1;
-                    }
+                idx[k] = pair_class4(g[k]);
+                const int left = A.n_samples - (c * 16 + k * 4);                   // columns of this dword that exist
+                const uint32_t valid = left >= 4 ? 0xFFFFFFFFu : (left <= 0 ? 0u : ((1u << (8 * left)) - 1u));
+                f[k] = flags_of_class4(idx[k]) & valid;
+            }
+            if (shift == 0) reinterpret_cast<uint4 *>(row)[c] = make_uint4(idx[0], idx[1], idx[2], idx[3]);
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) row[c * 16 + k * 4 + j] = (uint8_t)(idx[k] >> (8 * j));
+            }
+            stats_count_flags(make_uint4(f[0], f[1], f[2], f[3]), cnt);
+            if (want_sm) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t m = (f[k] >> 4) & 0x01010101u;                  // flag bit 4: some allele missing
+                    miss_cnt[c * 4 + k] += m;                                      // this thread's own columns: no atomics
+                    events[0] += __builtin_popcount(m);
                 }
             }
         }
-        block_sum<1>(n, red);
-        if (tid == 0 && A.mendel_errors) A.mendel_errors[v] = n[0];
+        block_sum<8>(cnt, red);                                                    // (its barriers also publish the pair classes)
+        if (tid == 0) A.out[v] = stats_record(cnt);
+
+        // ---- B. Mendelian errors: 4 trios per dword ---------------------------------------------------------------------
+        if (want_me) {
+            int n[1] = {0};
+            for (int c = tid; c < A.pchunks; c += 256) {
+                const uint4 qf = gather_class_chunk(row, A.mendel_cols, c, PAIR_CLASS_MISSING);
+                const uint4 qm = gather_class_chunk(row, A.mendel_cols, c + A.pchunks, PAIR_CLASS_MISSING);
+                const uint4 qc = gather_class_chunk(row, A.mendel_cols, c + 2 * A.pchunks, PAIR_CLASS_MISSING);
+                const uint32_t ff[4] = {mendel_of_class4(qf.x), mendel_of_class4(qf.y), mendel_of_class4(qf.z), mendel_of_class4(qf.w)};
+                const uint32_t mm[4] = {mendel_of_class4(qm.x), mendel_of_class4(qm.y), mendel_of_class4(qm.z), mendel_of_class4(qm.w)};
+                const uint32_t cc[4] = {mendel_of_class4(qc.x), mendel_of_class4(qc.y), mendel_of_class4(qc.z), mendel_of_class4(qc.w)};
+                uint4 ml = make_uint4(0, 0, 0, 0);
+                if (x_row) ml = reinterpret_cast<const uint4 *>(A.male_plane)[c];
+                const uint32_t mlw[4] = {ml.x, ml.y, ml.z, ml.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t e = x_row ? mendel4<true>(A.luts, ff[k], mm[k], cc[k], mlw[k]) : mendel4<false>(A.luts, ff[k], mm[k], cc[k], 0);
+                    n[0] += __builtin_popcount(e);
+                    if (want_ce) trio_cnt[c * 4 + k] += e;
+                }
+            }
+            events[1] += n[0];
+            block_sum<1>(n, red);
+            if (tid == 0 && A.mendel_errors) A.mendel_errors[v] = n[0];
+        }
+
+        // ---- C. per phenotype group: the grouped layout's chunks, one group after the other ------------------------------
+        if (A.group_out) {
+            for (int gk = 0; gk < A.n_groups; ++gk) {
+                int gc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                const int c0 = A.group_chunk0[gk], nc = A.group_chunks[gk];
+                for (int c = tid; c < nc; c += 256) {
+                    const uint4 q = gather_class_chunk(row, A.group_cols, c0 + c, PAIR_CLASS_NOFLAGS);
+                    stats_count_flags(make_uint4(flags_of_class4(q.x), flags_of_class4(q.y), flags_of_class4(q.z), flags_of_class4(q.w)), gc);
+                }
+                block_sum<8>(gc, red);
+                if (tid == 0) A.group_out[(size_t)gk * (size_t)A.n_variants + (size_t)v] = stats_record(gc);
+            }
+        }
     }
 
-    // ---- per phenotype group: the grouped layout's chunks, one group after the other -----------------------------------
-    if (A.group_out) {
-        for (int g = 0; g < A.n_groups; ++g) {
-            int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            const int c0 = A.group_chunk0[g], nc = A.group_chunks[g];
-            for (int c = tid; c < nc; c += 256)
-                stats_count_flags(batch_gather_chunk(raw, A.group_cols, c0 + c, false, RECODE_STATS, 0), cnt);
-            block_sum<8>(cnt, red);
-            if (tid == 0) A.group_out[(size_t)g * (size_t)A.n_variants + (size_t)v] = stats_record(cnt);
+    // ---- the band's column counters -> device totals -------------------------------------------------------------------------
+    if (want_sm || want_ce) {
+        block_sum<2>(events, red);                                                 // (barrier: every thread's counters are written)
+        if (want_sm && events[0] > 0) {
+            const bool dense = events[0] * 64 >= A.n_samples;                      // as many events as a dense sweep has wave instructions
+            const uint8_t *cb = reinterpret_cast<const uint8_t *>(miss_cnt);
+            for (int d = tid; d < A.n_samples; d += 256) {
+                const int val = cb[d];
+                if (dense || val) atomicAdd(A.sample_missing + d, val);
+            }
+        }
+        if (want_ce && events[1] > 0) {
+            const bool dense = events[1] * 64 >= A.n_trios;
+            const uint8_t *cb = reinterpret_cast<const uint8_t *>(trio_cnt);
+            for (int d = tid; d < A.n_trios; d += 256) {
+                const int val = cb[d];
+                if (dense || val) atomicAdd(A.child_errors + d, val);
+            }
         }
     }
 }

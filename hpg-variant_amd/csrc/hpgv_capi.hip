@@ -1402,7 +1402,7 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
     }
     if (n_blocks > 0)
         hipLaunchKernelGGL(hpgv::k_tok_count, dim3((unsigned)n_blocks), dim3(256), 0, st, d_text, text_bytes, ts->d_blocks);
-    hipLaunchKernelGGL(hpgv::k_tok_scan, dim3(1), dim3(256), 0, st, ts->d_blocks, (int)n_blocks, d_text, text_bytes,
+    hipLaunchKernelGGL(hpgv::k_tok_scan, dim3(1), dim3(hpgv::TOK_SCAN_THREADS), 0, st, ts->d_blocks, (int)n_blocks, d_text, text_bytes,
                        d_n_lines, line_off, max_lines);
     if (n_blocks > 0)
         hipLaunchKernelGGL(hpgv::k_tok_mark, dim3((unsigned)n_blocks), dim3(256), 0, st, d_text, text_bytes,
@@ -1726,7 +1726,10 @@ int hpgv_stats_text_groups(hpgv_ctx *ctx, const char *text, size_t text_bytes, i
     if (rc) return rc;
     Slot *s = lease.s;
     int nl = 0;
-    const bool fused = batch_fused_ok(ctx, ctx->stats.n_samples);
+    // LDS of the one-pass kernel: the row window, a byte counter per column and per trio
+    const size_t lds_row = ((size_t)ctx->stats.n_samples + 32 + 15) / 16 * 16;
+    const size_t lds_all = lds_row + ((size_t)ctx->stats.n_samples + 15) / 16 * 16 + (want_mendel ? (size_t)ctx->mendel_pchunks * 16 : 0) + 16;
+    const bool fused = ctx->batch_fused && lds_all <= (size_t)ctx->batch_lds_max;
     if ((rc = text_front(ctx, s, HPGV_LAYOUT_STATS, ctx->stats, text, text_bytes, max_lines, n_lines, line_off, field_off, status, &nl, !fused))) return rc;
     if (nl == 0) { HIPCHK(ctx, hipStreamSynchronize(s->stream)); return HPGV_OK; }
     const size_t n = (size_t)nl;
@@ -1759,8 +1762,11 @@ int hpgv_stats_text_groups(hpgv_ctx *ctx, const char *text, size_t text_bytes, i
             A.group_chunk0 = ctx->d_sg_chunks; A.group_chunks = ctx->d_sg_chunks + ng;
             A.group_out = (hpgv::BatchStatsRec *)s->d_res + n;
         }
-        const size_t lds = ((size_t)ns + 15 + 15) / 16 * 16 + 16;
-        hipLaunchKernelGGL(hpgv::k_stats_all, dim3((unsigned)nl), dim3(256), lds, s->stream, A);
+        // a band of rows per workgroup keeps the column counters in LDS across rows; short batches stay one row per workgroup
+        int rows = (nl + 2047) / 2048;
+        rows = rows < 1 ? 1 : (rows > 255 ? 255 : rows);
+        A.rows_per_block = rows; A.lds_row = (int)lds_row;
+        hipLaunchKernelGGL(hpgv::k_stats_all, dim3((unsigned)((nl + rows - 1) / rows)), dim3(256), lds_all, s->stream, A);
         HIPCHK(ctx, hipGetLastError());
         std::vector<int32_t> acc;
         if (want_sm || want_ce) {

@@ -46,34 +46,33 @@ static __global__ __launch_bounds__(256) void k_tok_count(const char *__restrict
     if (threadIdx.x == 0) block_counts[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-// single workgroup: exclusive scan of block_counts in place; n_lines = newlines (+1 for an unterminated tail)
-static __global__ __launch_bounds__(256) void k_tok_scan(int *__restrict__ block_counts, int n_blocks, const char *__restrict__ text,
-                                                  size_t n, int *__restrict__ n_lines,
-                                                  unsigned long long *__restrict__ line_off, int max_lines) {
-    __shared__ int s[256];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
+// single workgroup of 1024 threads: exclusive scan of block_counts in place; n_lines = newlines (+1 for an unterminated
+// tail).  Every thread owns a contiguous run of the counts: sum it, scan the 1024 sums (wave scans + 16 wave totals), write
+// the run's prefixes -- two sweeps over an array that sits in L2 (a scan of 256 counts per round with two barriers per
+// doubling step took 0.69 ms for the 156 k tiles of a 640 MB batch: as long as parsing it).
+constexpr int TOK_SCAN_THREADS = 1024;
+static __global__ __launch_bounds__(TOK_SCAN_THREADS) void k_tok_scan(int *__restrict__ block_counts, int n_blocks, const char *__restrict__ text,
+                                                                    size_t n, int *__restrict__ n_lines,
+                                                                    unsigned long long *__restrict__ line_off, int max_lines) {
+    __shared__ int wave_tot[TOK_SCAN_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int per = (n_blocks + TOK_SCAN_THREADS - 1) / TOK_SCAN_THREADS;
+    const int lo = tid * per < n_blocks ? tid * per : n_blocks;
+    const int hi = lo + per < n_blocks ? lo + per : n_blocks;
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += block_counts[i];
+    int x = sum;                                                     // inclusive scan within the wave
+    for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
+    if (lane == 63) wave_tot[w] = x;
     __syncthreads();
-    for (int base = 0; base < n_blocks; base += 256) {
-        const int i = base + threadIdx.x;
-        const int v = i < n_blocks ? block_counts[i] : 0;
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
-            const int t = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0;
-            __syncthreads();
-            s[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < n_blocks) block_counts[i] = carry + s[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry += s[255];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
+    int before = x - sum, total = 0;
+    for (int k = 0; k < TOK_SCAN_THREADS / 64; ++k) { if (k < w) before += wave_tot[k]; total += wave_tot[k]; }
+    int run = before;
+    for (int i = lo; i < hi; ++i) { const int v = block_counts[i]; block_counts[i] = run; run += v; }
+    if (tid == 0) {
         const int tail = (n > 0 && text[n - 1] != '\n') ? 1 : 0;     // unterminated last line
-        *n_lines = carry + tail;
-        if (tail && carry + 1 <= max_lines) line_off[carry + 1] = n;
+        *n_lines = total + tail;
+        if (tail && total + 1 <= max_lines) line_off[total + 1] = n;
     }
 }
 
