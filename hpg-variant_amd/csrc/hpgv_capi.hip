@@ -247,6 +247,9 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
     } else if (!strcmp(key, "scan_lds")) {
         if (value < 0 || value > 160 * 1024) return fail(ctx, HPGV_ERR_INVALID, "scan_lds must be in [0, 163840]");
         ctx->scan_lds = value;
+    } else if (!strcmp(key, "fisher_width")) {
+        if (value != 64 && value != 32 && value != 16 && value != 8) return fail(ctx, HPGV_ERR_INVALID, "fisher_width must be 64, 32, 16 or 8");
+        ctx->fisher_width = value;
     } else if (!strcmp(key, "batch_fused")) {
         ctx->batch_fused = value ? 1 : 0;
     } else if (!strcmp(key, "pipe_waves")) {
@@ -787,9 +790,19 @@ int hpgv_assoc_fisher_dev(hpgv_ctx *ctx, const int32_t *d_counts, int n_variants
     if (n_variants == 0) return HPGV_OK;
     DeviceGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
+    const double cut = pow(10.0, -(double)ctx->fisher_cut_exp);
     return launch_profiled(ctx, st, 1, [&] {
-        hipLaunchKernelGGL(hpgv::k_assoc_fisher, dim3((n_variants + 3) / 4), dim3(256), 0, st,
-                           (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, pow(10.0, -(double)ctx->fisher_cut_exp));
+        // fisher_width lanes per variant: 64 / width variants per wave, 4 waves per workgroup
+        const long per_block = 4 * (64 / ctx->fisher_width);
+        const unsigned blocks = (unsigned)(((long)n_variants + per_block - 1) / per_block);
+        if (ctx->fisher_width == 64)
+            hipLaunchKernelGGL(hpgv::k_assoc_fisher<64>, dim3(blocks), dim3(256), 0, st, (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, cut);
+        else if (ctx->fisher_width == 8)
+            hipLaunchKernelGGL(hpgv::k_assoc_fisher<8>, dim3(blocks), dim3(256), 0, st, (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, cut);
+        else if (ctx->fisher_width == 16)
+            hipLaunchKernelGGL(hpgv::k_assoc_fisher<16>, dim3(blocks), dim3(256), 0, st, (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, cut);
+        else
+            hipLaunchKernelGGL(hpgv::k_assoc_fisher<32>, dim3(blocks), dim3(256), 0, st, (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, cut);
     });
 }
 

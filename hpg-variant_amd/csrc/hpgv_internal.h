@@ -92,6 +92,7 @@ struct hpgv_ctx {
     long epi_complete = 1;     // epistasis pair scan on a dataset without missing calls: count four cells, derive the other five
     long epi_triples_1pass = 1; // epistasis triple ranking with at most 10 folds: one pass, all folds' counts in registers (one wave per SIMD)
     long scan_lds = 0;         // bytes of (unused) LDS per workgroup of the stats / tdt scans: caps the waves in flight per CU
+    long fisher_width = 16;    // lanes per variant in the Fisher p-pass (64, 32, 16 or 8): 64 / width variants per wave
     long batch_fused = 1;      // per-batch host entry points: one fused kernel per call (0: copy + layout + scan + statistics kernels)
     long batch_lds_max = 65536;   // largest raw-row window the fused kernel stages in LDS (raised at hpgv_create when the device allows)
     int n_cus = 256;

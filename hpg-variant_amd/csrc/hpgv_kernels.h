@@ -366,89 +366,100 @@ struct FisherTab {
     __device__ __forceinline__ double p(int x) const { return fisher_exp(e(x), xt); }
 };
 
-// Boundary of a prefix-true predicate over [L, R) by 64-ary search: 64 probes per round; UP (left of the mode, p
+// ---- sub-waves: W = 64, 32 or 16 consecutive lanes work on one variant (a wave holds 64 / W variants).  Everything the
+// lanes of a sub-wave decide together goes through these; values that are uniform within a sub-wave may differ between
+// the sub-waves of a wave, and the hardware's lane masking takes care of loops that end at different times.
+template <int W> __device__ __forceinline__ int sub_lane(int lane) { return lane & (W - 1); }
+template <int W> __device__ __forceinline__ uint64_t sub_ballot(bool pred, int lane) {
+    const uint64_t b = __ballot(pred);
+    if constexpr (W == 64) { (void)lane; return b; }
+    else return (b >> (lane & ~(W - 1))) & ((1ull << W) - 1ull);
+}
+template <int W> __device__ __forceinline__ double sub_sum_f64(double v) {
+#pragma unroll
+    for (int off = W / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);   // fixed order: deterministic
+    return v;
+}
+template <int W> __device__ __forceinline__ double sub_first_f64(double v, int lane) { return __shfl(v, lane & ~(W - 1)); }
+
+// Boundary of a prefix-true predicate over [L, R) by W-ary search: W probes per round; UP (left of the mode, p
 // increasing): pred(x) = p(x) <= thr; right of the mode (p decreasing): pred(x) = p(x) > thr.  Returns the first x where
 // the predicate is false (R if none).
-// Both boundary searches in lockstep: the two 64-ary searches are independent, so every round issues the table
+// Both boundary searches in lockstep: the two searches are independent, so every round issues the table
 // reads and the exp of BOTH probes before either result is needed -- half as many latency-bound rounds.
+template <int W>
 __device__ __forceinline__ void fisher_boundaries(const FisherTab &T, double thr /* ln */, int L1, int R1, int L2, int R2, int lane,
                                                   int *xL, int *xR) {
-    while (R1 - L1 > 64 || R2 - L2 > 64) {                          // wave-uniform
-        const bool go1 = R1 - L1 > 64, go2 = R2 - L2 > 64;
-        const int step1 = (R1 - L1 + 63) / 64, step2 = (R2 - L2 + 63) / 64;
-        const int x1 = L1 + lane * step1, x2 = L2 + lane * step2;
+    const int sl = sub_lane<W>(lane);
+    while (R1 - L1 > W || R2 - L2 > W) {                            // uniform within the sub-wave
+        const bool go1 = R1 - L1 > W, go2 = R2 - L2 > W;
+        const int step1 = (R1 - L1 + W - 1) / W, step2 = (R2 - L2 + W - 1) / W;
+        const int x1 = L1 + sl * step1, x2 = L2 + sl * step2;
         const double v1 = (go1 && x1 < R1) ? T.e(x1) : 0.0;
         const double v2 = (go2 && x2 < R2) ? T.e(x2) : 0.0;
         if (go1) {
-            const int j = __builtin_popcountll(__ballot(x1 < R1 && v1 <= thr));
+            const int j = __builtin_popcountll(sub_ballot<W>(x1 < R1 && v1 <= thr, lane));
             const int xj = L1 + j * step1;
-            const int nL = (j == 0) ? L1 : L1 + (j - 1) * step1 + 1, nR = (j == 64 || xj >= R1) ? R1 : xj;
+            const int nL = (j == 0) ? L1 : L1 + (j - 1) * step1 + 1, nR = (j == W || xj >= R1) ? R1 : xj;
             L1 = nL; R1 = nR;
         }
         if (go2) {
-            const int j = __builtin_popcountll(__ballot(x2 < R2 && v2 > thr));
+            const int j = __builtin_popcountll(sub_ballot<W>(x2 < R2 && v2 > thr, lane));
             const int xj = L2 + j * step2;
-            const int nL = (j == 0) ? L2 : L2 + (j - 1) * step2 + 1, nR = (j == 64 || xj >= R2) ? R2 : xj;
+            const int nL = (j == 0) ? L2 : L2 + (j - 1) * step2 + 1, nR = (j == W || xj >= R2) ? R2 : xj;
             L2 = nL; R2 = nR;
         }
     }
-    const int x1 = L1 + lane, x2 = L2 + lane;
+    const int x1 = L1 + sl, x2 = L2 + sl;
     const double v1 = x1 < R1 ? T.e(x1) : 0.0, v2 = x2 < R2 ? T.e(x2) : 0.0;
-    *xL = L1 + __builtin_popcountll(__ballot(x1 < R1 && v1 <= thr));
-    *xR = L2 + __builtin_popcountll(__ballot(x2 < R2 && v2 > thr));
+    *xL = L1 + __builtin_popcountll(sub_ballot<W>(x1 < R1 && v1 <= thr, lane));
+    *xR = L2 + __builtin_popcountll(sub_ballot<W>(x2 < R2 && v2 > thr, lane));
 }
 
-// Both tails in lockstep (left from xL - 1 downwards, right from xR upwards), 4 x 64 tables per side and turn: the
-// table reads and exps of a turn are independent of each other, so a variant costs two or three memory round trips here
-// instead of one per 64 tables (the kernel is bound by such dependent round trips, not by instructions).  Lanes keep
-// private partial sums (one wave reduction at the end); a tail ends after a turn whose outermost 64 tables are all
-// below rel_cut x its own first (largest) table (the tables dropped are further out and decay faster than geometrically).
+// Both tails in lockstep (left from xL - 1 downwards, right from xR upwards), W tables per side and turn: the
+// table reads and exps of a turn are independent of each other.  Lanes keep private partial sums (one reduction at the
+// end); a tail ends after a turn whose W tables are all below rel_cut x its own first (largest) table (the tables
+// dropped are further out and decay faster than geometrically).
+template <int W>
 __device__ __forceinline__ double fisher_tails(const FisherTab &T, int xL, int xR, int lo, int hi, int lane, double rel_cut) {
-    constexpr int U = 1;
+    const int sl = sub_lane<W>(lane);
     double partL = 0.0, partR = 0.0, cutL = 0.0, cutR = 0.0;
     bool onL = true, onR = true;
-    for (int k = 0; onL || onR; ++k) {                              // wave-uniform
-        const int firstL = xL - 1 - 64 * U * k, firstR = xR + 64 * U * k;
+    for (int k = 0; onL || onR; ++k) {                              // uniform within the sub-wave
+        const int firstL = xL - 1 - W * k, firstR = xR + W * k;
         if (firstL < lo) onL = false;
         if (firstR > hi) onR = false;
-        double eL[U], eR[U];
-        #pragma unroll
-        for (int u = 0; u < U; u++) {                               // all the table reads first
-            const int a = firstL - lane - 64 * u, b = firstR + lane + 64 * u;
-            eL[u] = (onL && a >= lo) ? T.e(a) : -2000.0;
-            eR[u] = (onR && b <= hi) ? T.e(b) : -2000.0;
-        }
-        double sL = 0.0, sR = 0.0, lastL = 0.0, lastR = 0.0;
-        #pragma unroll
-        for (int u = 0; u < U; u++) {
-            lastL = fisher_exp(eL[u], T.xt); lastR = fisher_exp(eR[u], T.xt);       // exp(-2000) = 0
-            sL += lastL; sR += lastR;
-        }
+        const int a = firstL - sl, b = firstR + sl;
+        const double eL = (onL && a >= lo) ? T.e(a) : -2000.0;      // all the table reads first
+        const double eR = (onR && b <= hi) ? T.e(b) : -2000.0;
+        const double sL = fisher_exp(eL, T.xt), sR = fisher_exp(eR, T.xt);       // exp(-2000) = 0
         partL += sL; partR += sR;
         // the reference value of a tail: its first table (lane 0 of the first turn), the largest of the tail
-        if (k == 0) { cutL = rel_cut * __shfl(sL, 0); cutR = rel_cut * __shfl(sR, 0); }
-        if (onL && __ballot(lastL > cutL) == 0ull) onL = false;
-        if (onR && __ballot(lastR > cutR) == 0ull) onR = false;
+        if (k == 0) { cutL = rel_cut * sub_first_f64<W>(sL, lane); cutR = rel_cut * sub_first_f64<W>(sR, lane); }
+        if (onL && sub_ballot<W>(sL > cutL, lane) == 0ull) onL = false;
+        if (onR && sub_ballot<W>(sR > cutR, lane) == 0ull) onR = false;
     }
-    return wave_sum_f64(partL + partR);
+    return sub_sum_f64<W>(partL + partR);
 }
 
 // The two boundaries are almost always where a guess puts them: on the observed side right after the observed table
 // (further only by the 1e-7 slack, i.e. next to the mode), on the other side near the mirror image of the observed table
-// about the mode (off by the skew: a few tables).  One round probes a 64-wide window around each guess; a window that
-// does not bracket its boundary leaves a one-sided range to the 64-ary search.  Returns true when both were found.
-__device__ __forceinline__ bool fisher_boundary_windows(const FisherTab &T, double thr /* ln */, int lo, int mode, int hi, int obs, int lane,
+// about the mode (off by the skew: a few tables).  One round probes a W-wide window around each guess; a window that
+// does not bracket its boundary leaves a one-sided range to the W-ary search.  Returns true when both were found.
+template <int W>
+__device__ __forceinline__ bool fisher_boundary_windows(const FisherTab &T, double thr /* ln */, int mode, int obs, int lane,
                                                         int *L1, int *R1, int *L2, int *R2) {
     // left: pred(x) = e(x) <= thr is prefix-true over [lo, mode + 1); right: pred(x) = e(x) > thr over [mode + 1, hi + 1)
+    const int sl = sub_lane<W>(lane);
     const int g1 = obs <= mode ? obs + 1 : 2 * mode - obs + 1, g2 = obs <= mode ? 2 * mode - obs : obs;
-    int w1 = g1 - 32, w2 = g2 - 32;
-    w1 = w1 > *R1 - 64 ? *R1 - 64 : w1; w1 = w1 < *L1 ? *L1 : w1;
-    w2 = w2 > *R2 - 64 ? *R2 - 64 : w2; w2 = w2 < *L2 ? *L2 : w2;
-    const int x1 = w1 + lane, x2 = w2 + lane;
+    int w1 = g1 - W / 2, w2 = g2 - W / 2;
+    w1 = w1 > *R1 - W ? *R1 - W : w1; w1 = w1 < *L1 ? *L1 : w1;
+    w2 = w2 > *R2 - W ? *R2 - W : w2; w2 = w2 < *L2 ? *L2 : w2;
+    const int x1 = w1 + sl, x2 = w2 + sl;
     const bool in1 = x1 < *R1, in2 = x2 < *R2;
     const double v1 = in1 ? T.e(x1) : 0.0, v2 = in2 ? T.e(x2) : 0.0;
-    const int n1 = __builtin_popcountll(__ballot(in1)), n2 = __builtin_popcountll(__ballot(in2));
-    const int c1 = __builtin_popcountll(__ballot(in1 && v1 <= thr)), c2 = __builtin_popcountll(__ballot(in2 && v2 > thr));
+    const int n1 = __builtin_popcountll(sub_ballot<W>(in1, lane)), n2 = __builtin_popcountll(sub_ballot<W>(in2, lane));
+    const int c1 = __builtin_popcountll(sub_ballot<W>(in1 && v1 <= thr, lane)), c2 = __builtin_popcountll(sub_ballot<W>(in2 && v2 > thr, lane));
     bool ok = true;
     // count == 0: the boundary is at or left of the window's start; count == all: at or right of its end
     if (c1 == 0 && w1 > *L1) { *R1 = w1; ok = false; }
@@ -457,13 +468,15 @@ __device__ __forceinline__ bool fisher_boundary_windows(const FisherTab &T, doub
     if (c2 == 0 && w2 > *L2) { *R2 = w2; ok = false; }
     else if (c2 == n2 && w2 + n2 < *R2) { *L2 = w2 + n2; ok = false; }
     else { *L2 = w2 + c2; *R2 = w2 + c2; }
-    (void)lo; (void)hi;
     return ok;
 }
 
-// the whole wave computes the two-sided p of the table (a, b, c, d) = (A1, A2, U1, U2) (assoc.c:70); every lane returns it
-__device__ __forceinline__ double fisher_wave(int a, int b, int c, int d, const double *__restrict__ lf,
-                                              const double *exp_tab /* LDS */, double rel_cut, int lane) {
+// a sub-wave of W lanes computes the two-sided p of the table (a, b, c, d) = (A1, A2, U1, U2) (assoc.c:70); every lane of the
+// sub-wave returns it
+template <int W>
+__device__ __forceinline__ double fisher_sub(int a, int b, int c, int d, const double *__restrict__ lf,
+                                             const double *exp_tab /* LDS */, double rel_cut, int lane) {
+    const int sl = sub_lane<W>(lane);
     const int r1 = a + b, r2 = c + d, c1 = a + c, nn = r1 + r2;
     const int lo = (c1 - r2) > 0 ? (c1 - r2) : 0;
     const int hi = r1 < c1 ? r1 : c1;
@@ -473,13 +486,13 @@ __device__ __forceinline__ double fisher_wave(int a, int b, int c, int d, const 
     // included tables: P(x) <= P_obs * (1 + 1e-7), tested as ln P(x) <= ln P_obs + ln(1 + 1e-7)
     const double thr = T.e(a) + 9.9999995000000333e-08;
     double sum;
-    if (hi - lo < 512) {
+    if (hi - lo < 8 * W) {
         double part = 0.0;
-        for (int x = lo + lane; x <= hi; x += 64) {
+        for (int x = lo + sl; x <= hi; x += W) {
             const double ex = T.e(x);
             if (ex <= thr) part += fisher_exp(ex, exp_tab);
         }
-        sum = wave_sum_f64(part);
+        sum = sub_sum_f64<W>(part);
     } else {
         // mode of the hypergeometric distribution, floor((r1 + 1)(c1 + 1) / (n + 2)), clamped to the support: the quotient
         // in double (the product is below 2^53), put right with the exact remainder
@@ -492,14 +505,24 @@ __device__ __forceinline__ double fisher_wave(int a, int b, int c, int d, const 
         // left of (and including) the mode p grows with x: included x are a prefix [lo, xL)
         // right of the mode p falls: p > thr on a prefix [mode+1, xR), included x are [xR, hi]
         int L1 = lo, R1 = mode + 1, L2 = mode + 1, R2 = hi + 1, xL, xR;
-        if (fisher_boundary_windows(T, thr, lo, mode, hi, a, lane, &L1, &R1, &L2, &R2)) { xL = L1; xR = L2; }
-        else fisher_boundaries(T, thr, L1, R1, L2, R2, lane, &xL, &xR);
-        sum = fisher_tails(T, xL, xR, lo, hi, lane, rel_cut);
+        if (fisher_boundary_windows<W>(T, thr, mode, a, lane, &L1, &R1, &L2, &R2)) { xL = L1; xR = L2; }
+        else fisher_boundaries<W>(T, thr, L1, R1, L2, R2, lane, &xL, &xR);
+        sum = fisher_tails<W>(T, xL, xR, lo, hi, lane, rel_cut);
     }
     return sum > 1.0 ? 1.0 : sum;
 }
 
-static __global__ __launch_bounds__(256) void k_assoc_fisher(const int4 *__restrict__ counts, int n,
+// the whole wave on one table (the per-batch kernel's form)
+__device__ __forceinline__ double fisher_wave(int a, int b, int c, int d, const double *__restrict__ lf,
+                                              const double *exp_tab /* LDS */, double rel_cut, int lane) {
+    return fisher_sub<64>(a, b, c, d, lf, exp_tab, rel_cut, lane);
+}
+
+// W lanes per variant: a wave computes 64 / W variants side by side.  The fixed part of a variant (setup, mode, the two
+// boundary windows: about a third of its instructions at W = 64) is then shared by 64 / W variants, and the last,
+// partly useful turn of each tail wastes W / 2 tables on average instead of 32.
+template <int W>
+__global__ __launch_bounds__(256) void k_assoc_fisher(const int4 *__restrict__ counts, int n,
                                                       const double *__restrict__ lf,
                                                       double *__restrict__ odds,
                                                       double *__restrict__ pval, double rel_cut) {
@@ -507,12 +530,14 @@ static __global__ __launch_bounds__(256) void k_assoc_fisher(const int4 *__restr
     if (threadIdx.x < 64) exp_tab[threadIdx.x] = k_exp2_j64[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    constexpr int PER_WAVE = 64 / W;
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long v = wave * PER_WAVE + lane / W;
     if (v >= n) return;
     const int4 c4 = counts[v];
     const int a = c4.x, b = c4.y, c = c4.z, d = c4.w;   // assoc.c:70: (A1, A2, U1, U2)
-    const double p = fisher_wave(a, b, c, d, lf, exp_tab, rel_cut, lane);
-    if (lane == 0) {
+    const double p = fisher_sub<W>(a, b, c, d, lf, exp_tab, rel_cut, lane);
+    if (sub_lane<W>(lane) == 0) {
         odds[v] = assoc_odds(a, b, c, d);
         pval[v] = p;
     }

@@ -10,12 +10,14 @@ from oracle import pyoracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def _same(a, b):
+def _same(a, b, exact=True):
     for k in a:
         if a[k] is None:
             assert b[k] is None
-        elif a[k].dtype.kind == "f":
+        elif a[k].dtype.kind == "f" and exact:
             assert np.array_equal(a[k], b[k], equal_nan=True), k        # same kernels' arithmetic: identical doubles
+        elif a[k].dtype.kind == "f":
+            assert_close(a[k], b[k], k)
         else:
             assert np.array_equal(a[k], b[k]), k
 
@@ -48,8 +50,10 @@ def test_assoc_batch_fused_equals_unfused_and_oracle(n_samples):
         e.set_option("batch_fused", 0)
         c = e.assoc(task, gt, is_x)                                          # the kernel chain
         check_assoc(a, exp, task)
+        check_assoc(c, exp, task)
         _same(a, b)
-        _same(a, c)
+        # the chain's Fisher pass puts 16 lanes on a table, the per-batch kernel 64: other summation order, same 1e-10 bar
+        _same(a, c, exact=(task == hpgv.TASK_CHISQ))
     e.close()
 
 
