@@ -269,6 +269,7 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
 /* ---- cohort ---------------------------------------------------------------- */
 
 int hpgv_set_cohort(hpgv_ctx *ctx, const uint8_t *condition, int n_samples) {
+    HPGV_ABI_TRY
     GROUP_ALL(ctx, hpgv_set_cohort(m_, condition, n_samples))
     if (!ctx) return HPGV_ERR_INVALID;
     if (!condition || n_samples < 0) return fail(ctx, HPGV_ERR_INVALID, "bad cohort arguments");
@@ -293,6 +294,7 @@ int hpgv_set_cohort(hpgv_ctx *ctx, const uint8_t *condition, int n_samples) {
     }
     ctx->nA = nA; ctx->nU = nU; ctx->chunksA = (int)(segA / 16);
     return upload_layout(ctx, L);
+    HPGV_ABI_CATCH(ctx)
 }
 
 int hpgv_assoc_layout(const hpgv_ctx *ctx, int *n_affected, int *n_unaffected, size_t *pitch) {
@@ -322,6 +324,7 @@ int hpgv_set_logfact(hpgv_ctx *ctx, const double *table, size_t n) {
 }
 
 int hpgv_set_stats_cohort(hpgv_ctx *ctx, int n_samples) {
+    HPGV_ABI_TRY
     GROUP_ALL(ctx, hpgv_set_stats_cohort(m_, n_samples))
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_samples < 0) return fail(ctx, HPGV_ERR_INVALID, "negative n_samples");
@@ -335,9 +338,11 @@ int hpgv_set_stats_cohort(hpgv_ctx *ctx, int n_samples) {
     L.col_of_pos.assign(pitch, -1);
     for (int j = 0; j < n_samples; ++j) L.col_of_pos[j] = j;
     return upload_layout(ctx, L);
+    HPGV_ABI_CATCH(ctx)
 }
 
 int hpgv_set_stats_groups(hpgv_ctx *ctx, const int32_t *group_of_sample, int n_samples, int n_groups) {
+    HPGV_ABI_TRY
     GROUP_ALL(ctx, hpgv_set_stats_groups(m_, group_of_sample, n_samples, n_groups))
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_samples < 0 || n_groups < 1 || n_groups > 4096 || (n_samples > 0 && !group_of_sample))
@@ -377,6 +382,7 @@ int hpgv_set_stats_groups(hpgv_ctx *ctx, const int32_t *group_of_sample, int n_s
         HIPCHK(ctx, hipMemcpy(ctx->d_sg_chunks, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     return upload_layout(ctx, L);
+    HPGV_ABI_CATCH(ctx)
 }
 
 int hpgv_stats_groups_layout(const hpgv_ctx *ctx, size_t *pitch, int *group_sizes) {
@@ -399,6 +405,7 @@ int hpgv_stats_layout(const hpgv_ctx *ctx, size_t *pitch) {
 int hpgv_set_families(hpgv_ctx *ctx, int n_samples, int n_families, const int32_t *father_col,
                       const int32_t *mother_col, const int32_t *child_off, const int32_t *child_col,
                       const uint8_t *child_sex) {
+    HPGV_ABI_TRY
     GROUP_ALL(ctx, hpgv_set_families(m_, n_samples, n_families, father_col, mother_col, child_off, child_col, child_sex))
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_samples < 0 || n_families < 0 || (n_families > 0 && (!father_col || !mother_col || !child_off)))
@@ -412,10 +419,12 @@ int hpgv_set_families(hpgv_ctx *ctx, int n_samples, int n_families, const int32_
     if (!pitch_supported(L.pitch)) return fail(ctx, HPGV_ERR_UNSUPPORTED, "pedigree exceeds the row-length limit");
     L.n_samples = n_samples;
     return upload_layout(ctx, L);
+    HPGV_ABI_CATCH(ctx)
 }
 
 int hpgv_set_pedigree(hpgv_ctx *ctx, int n_samples, int n_trios, const int32_t *father_col, const int32_t *mother_col,
                       const int32_t *child_col, const uint8_t *child_sex) {
+    HPGV_ABI_TRY
     GROUP_ALL(ctx, hpgv_set_pedigree(m_, n_samples, n_trios, father_col, mother_col, child_col, child_sex))
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_samples < 0 || n_trios < 0 || (n_trios > 0 && (!father_col || !mother_col || !child_col || !child_sex)))
@@ -447,6 +456,7 @@ int hpgv_set_pedigree(hpgv_ctx *ctx, int n_samples, int n_trios, const int32_t *
     ctx->mendel_trios = n_trios;
     ctx->mendel_pchunks = (int)(P16 / 16);
     return upload_layout(ctx, L);
+    HPGV_ABI_CATCH(ctx)
 }
 
 int hpgv_mendel_layout(const hpgv_ctx *ctx, size_t *pitch) {
@@ -675,6 +685,7 @@ int hpgv_synth_dev(hpgv_ctx *ctx, int which, uint64_t v0, int n_variants, uint8_
 
 int hpgv_synth_raw_dev(hpgv_ctx *ctx, uint64_t v0, int n_variants, int n_samples, size_t pitch,
                        uint8_t *d_dst, void *stream) {
+    HPGV_ABI_TRY
     ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_variants < 0 || n_samples < 0 || pitch % 16 || pitch < (size_t)n_samples || (n_variants > 0 && !d_dst))
@@ -695,6 +706,7 @@ int hpgv_synth_raw_dev(hpgv_ctx *ctx, uint64_t v0, int n_variants, int n_samples
     (void)hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(d_col);
     return rc;
+    HPGV_ABI_CATCH(ctx)
 }
 
 /* ---- assoc ------------------------------------------------------------------ */
@@ -1110,6 +1122,7 @@ int hpgv_assoc(hpgv_ctx *ctx, int task, const uint8_t *gt, size_t pitch, int n_v
 
 int hpgv_tdt(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, const uint8_t *is_x,
              int32_t *t1, int32_t *t2, double *odds, double *chisq, double *p) {
+    HPGV_ABI_TRY
     GROUP_DEAL(ctx, hpgv_tdt(m_, gt, pitch, n_variants, is_x, t1, t2, odds, chisq, p))
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->tdt.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_families has not been called");
@@ -1155,11 +1168,13 @@ int hpgv_tdt(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, con
     HIPCHK(ctx, hipStreamSynchronize(s->stream));
     for (size_t i = 0; i < n; ++i) { t1[i] = tu[2 * i]; t2[i] = tu[2 * i + 1]; }
     return HPGV_OK;
+    HPGV_ABI_CATCH(ctx)
 }
 
 int hpgv_stats_ex(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, int32_t *counts8,
                   double *hwe_chi2, double *hwe_p, int32_t *sample_missing, int32_t *multi_idx,
                   int32_t *multi_table, int *n_multi) {
+    HPGV_ABI_TRY
     GROUP_DEAL(ctx, hpgv_stats_ex(m_, gt, pitch, n_variants, counts8, hwe_chi2, hwe_p, sample_missing, multi_idx, multi_table, n_multi))
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->stats.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");
@@ -1260,6 +1275,7 @@ int hpgv_stats_ex(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants
         }
     }
     return HPGV_OK;
+    HPGV_ABI_CATCH(ctx)
 }
 
 int hpgv_stats(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, int32_t *counts8,
@@ -1327,6 +1343,7 @@ int hpgv_epi_dataset(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_varia
 
 int hpgv_mendel(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, const uint8_t *is_x,
                 int32_t *errors, int32_t *child_errors) {
+    HPGV_ABI_TRY
     GROUP_DEAL(ctx, hpgv_mendel(m_, gt, pitch, n_variants, is_x, errors, child_errors))
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->mendel.set) return fail(ctx, HPGV_ERR_STATE, "hpgv_set_pedigree has not been called");
@@ -1357,6 +1374,7 @@ int hpgv_mendel(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, 
     HIPCHK(ctx, hipStreamSynchronize(s->stream));
     for (size_t t = 0; t < ce.size(); ++t) child_errors[t] += ce[t];
     return HPGV_OK;
+    HPGV_ABI_CATCH(ctx)
 }
 
 /* ---- text staging ------------------------------------------------------------ */
@@ -1382,6 +1400,7 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
 int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int n_samples, int strict,
                       int max_lines, int *d_n_lines, uint64_t *d_line_off, uint32_t *d_field_off,
                       uint8_t *d_gt, size_t pitch, uint8_t *d_is_x, int32_t *d_status, void *stream) {
+    HPGV_ABI_TRY
     ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_samples < 0 || max_lines < 0 || !d_n_lines || (text_bytes > 0 && !d_text) ||
@@ -1427,6 +1446,7 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
                            (const int *)d_n_lines, max_lines, n_samples, strict, d_gt, pitch, d_is_x, d_field_off, d_status);
     HIPCHK(ctx, hipGetLastError());
     return HPGV_OK;
+    HPGV_ABI_CATCH(ctx)
 }
 
 int hpgv_tokenize(hpgv_ctx *ctx, const char *text, size_t text_bytes, int n_samples, int strict, int max_lines,
@@ -1646,6 +1666,7 @@ int hpgv_assoc_text(hpgv_ctx *ctx, int task, const char *text, size_t text_bytes
 int hpgv_tdt_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_lines, int *n_lines,
                   uint64_t *line_off, uint32_t *field_off, int32_t *status, int32_t *t1, int32_t *t2,
                   double *odds, double *chisq, double *p) {
+    HPGV_ABI_TRY
     if (is_group(ctx)) {
         if (hpgv_ctx *m_ = alias_owner(ctx, text)) return hpgv_tdt_text(m_, text, text_bytes, max_lines, n_lines, line_off, field_off, status, t1, t2, odds, chisq, p);
         Dealt d_(ctx); hpgv_ctx *m_ = d_.m; return hpgv_tdt_text(m_, text, text_bytes, max_lines, n_lines, line_off, field_off, status, t1, t2, odds, chisq, p);
@@ -1698,6 +1719,7 @@ int hpgv_tdt_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_li
     HIPCHK(ctx, hipStreamSynchronize(s->stream));
     for (size_t i = 0; i < n; ++i) { t1[i] = tu[2 * i]; t2[i] = tu[2 * i + 1]; }
     return HPGV_OK;
+    HPGV_ABI_CATCH(ctx)
 }
 
 int hpgv_stats_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_lines, int *n_lines,
@@ -1713,6 +1735,7 @@ int hpgv_stats_text_groups(hpgv_ctx *ctx, const char *text, size_t text_bytes, i
                            double *hwe_p, int32_t *sample_missing, int32_t *multi_idx, int32_t *multi_table, int *n_multi,
                            int32_t *mendel_errors, int32_t *child_errors, int32_t *group_counts8, double *group_hwe_chi2,
                            double *group_hwe_p) {
+    HPGV_ABI_TRY
     if (is_group(ctx)) {
         if (hpgv_ctx *m_ = alias_owner(ctx, text)) return hpgv_stats_text_groups(m_, text, text_bytes, max_lines, n_lines, line_off, field_off, status, counts8, hwe_chi2, hwe_p, sample_missing, multi_idx, multi_table, n_multi, mendel_errors, child_errors, group_counts8, group_hwe_chi2, group_hwe_p);
         Dealt d_(ctx); hpgv_ctx *m_ = d_.m; return hpgv_stats_text_groups(m_, text, text_bytes, max_lines, n_lines, line_off, field_off, status, counts8, hwe_chi2, hwe_p, sample_missing, multi_idx, multi_table, n_multi, mendel_errors, child_errors, group_counts8, group_hwe_chi2, group_hwe_p);
@@ -1901,6 +1924,7 @@ int hpgv_stats_text_groups(hpgv_ctx *ctx, const char *text, size_t text_bytes, i
         }
     }
     return HPGV_OK;
+    HPGV_ABI_CATCH(ctx)
 }
 
 int hpgv_epi_dataset_text(hpgv_ctx *ctx, const char *text, size_t text_bytes, int max_lines, int *n_lines,

@@ -225,6 +225,7 @@ int hpgv_epi_set_folds(hpgv_ctx *ctx, const int32_t *fold_of_sample, int num_fol
 }
 
 int hpgv_epi_set_fold_masks(hpgv_ctx *ctx, const uint8_t *fold_masks, int num_folds) {
+    HPGV_ABI_TRY
     ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->epi.have_data) return fail(ctx, HPGV_ERR_STATE, "hpgv_epi_set_dataset has not been called");
@@ -243,6 +244,7 @@ int hpgv_epi_set_fold_masks(hpgv_ctx *ctx, const uint8_t *fold_masks, int num_fo
         if (fold[(size_t)s] < 0) return fail(ctx, HPGV_ERR_UNSUPPORTED, "sample %d is in the training part of every fold", s);
     }
     return hpgv_epi_set_folds(ctx, fold.data(), num_folds);
+    HPGV_ABI_CATCH(ctx)
 }
 
 // in-fold counts of listed combinations: host vector [(comb * n_groups + g) * cells + c]
@@ -274,6 +276,7 @@ static int epi_infold_counts(hpgv_ctx *ctx, int order, const int32_t *combs, int
 }
 
 int hpgv_epi_counts(hpgv_ctx *ctx, int order, const int32_t *combs, int n_combs, int32_t *counts_aff, int32_t *counts_unaff) {
+    HPGV_ABI_TRY
     ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_combs > 0 && (!counts_aff || !counts_unaff)) return fail(ctx, HPGV_ERR_INVALID, "count outputs are NULL");
@@ -290,9 +293,11 @@ int hpgv_epi_counts(hpgv_ctx *ctx, int order, const int32_t *combs, int n_combs,
             counts_aff[(size_t)k * cells + c] = a; counts_unaff[(size_t)k * cells + c] = u;
         }
     return HPGV_OK;
+    HPGV_ABI_CATCH(ctx)
 }
 
 int hpgv_epi_counts_all_folds(hpgv_ctx *ctx, int order, const int32_t *combs, int n_combs, int32_t *counts_aff, int32_t *counts_unaff) {
+    HPGV_ABI_TRY
     ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_combs > 0 && (!counts_aff || !counts_unaff)) return fail(ctx, HPGV_ERR_INVALID, "count outputs are NULL");
@@ -313,6 +318,7 @@ int hpgv_epi_counts_all_folds(hpgv_ctx *ctx, int order, const int32_t *combs, in
             }
         }
     return HPGV_OK;
+    HPGV_ABI_CATCH(ctx)
 }
 
 int hpgv_epi_scan_pairs(hpgv_ctx *ctx, int i_begin, int i_end, int subset, double *accuracy, uint16_t *risky_mask,
@@ -358,6 +364,7 @@ int hpgv_epi_rank_pairs(hpgv_ctx *ctx, int subset, int max_ranking_size, int32_t
 
 int hpgv_epi_rank_pairs_rows(hpgv_ctx *ctx, int i_begin, int i_end, int subset, int max_ranking_size, int32_t *comb_i,
                              int32_t *comb_j, double *accuracy, uint32_t *risky_mask, int32_t *n_ranked, float *scan_ms) {
+    HPGV_ABI_TRY
     ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     EpiState &E = ctx->epi;
@@ -486,6 +493,7 @@ int hpgv_epi_rank_pairs_rows(hpgv_ctx *ctx, int i_begin, int i_end, int subset, 
     }
     if (scan_ms) *scan_ms = total_ms;
     return HPGV_OK;
+    HPGV_ABI_CATCH(ctx)
 }
 
 // ---- order 3 -------------------------------------------------------------------------------------------------
@@ -598,6 +606,7 @@ int hpgv_epi_scan_triples(hpgv_ctx *ctx, int subset, double *accuracy, uint32_t 
 
 int hpgv_epi_rank_triples(hpgv_ctx *ctx, int subset, int max_ranking_size, int32_t *comb_i, int32_t *comb_j, int32_t *comb_k,
                           double *accuracy, uint32_t *risky_mask, int32_t *n_ranked, float *scan_ms) {
+    HPGV_ABI_TRY
     ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     int rc = epi_triples_check(ctx, subset);
@@ -679,4 +688,5 @@ int hpgv_epi_rank_triples(hpgv_ctx *ctx, int subset, int max_ranking_size, int32
     }
     if (scan_ms) *scan_ms = total_ms;
     return HPGV_OK;
+    HPGV_ABI_CATCH(ctx)
 }

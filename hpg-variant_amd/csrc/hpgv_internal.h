@@ -162,6 +162,13 @@ namespace {
     return code;
 }
 
+// the C ABI never lets a C++ exception out: a failed host allocation inside an entry point (std::vector, std::string)
+// becomes HPGV_ERR_NOMEM.  The slot lease and the device guard are released by their destructors during unwinding.
+#define HPGV_ABI_TRY try {
+#define HPGV_ABI_CATCH(ctx)                                                                         \
+    } catch (const std::bad_alloc &) { return fail(ctx, HPGV_ERR_NOMEM, "out of host memory"); }     \
+      catch (...) { return fail(ctx, HPGV_ERR_INVALID, "unexpected C++ exception inside the engine"); }
+
 // group dispatch
 inline bool is_group(const hpgv_ctx *c) { return c && !c->members.empty(); }
 inline hpgv_ctx *first_member(hpgv_ctx *c) { return is_group(c) ? c->members[0] : c; }
@@ -262,7 +269,14 @@ constexpr int kMaxUnroll = 16;       // largest assoc unroll option
 struct SlotLease {
     hpgv_ctx *ctx; Slot *s = nullptr;
     explicit SlotLease(hpgv_ctx *c) : ctx(c) {}
-    ~SlotLease() { if (s) release_slot(ctx, s); }
+    // an early return on a failure may leave copies into the caller's (or this call's stack) memory queued on the slot's
+    // stream: they are waited for before the slot -- and the caller's buffers -- are handed back
+    ~SlotLease() {
+        if (!s) return;
+        if (s->stream && hipStreamQuery(s->stream) == hipErrorNotReady) (void)hipStreamSynchronize(s->stream);
+        (void)hipGetLastError();
+        release_slot(ctx, s);
+    }
 };
 
 template <typename F>

@@ -131,8 +131,9 @@ __device__ __forceinline__ uint32_t tok_encode(const char *__restrict__ t, size_
         if (q == ge || (ge - q == 1 && t[q] == '.')) status += 2; else a2 = tok_atoi(t, q, ge);
     }
     if (strict && status != 0) return 0xFFu;
-    const uint32_t n1 = (a1 < 0) ? 0xFu : (a1 > 14 ? 14u : (uint32_t)a1);
+    uint32_t n1 = (a1 < 0) ? 0xFu : (a1 > 14 ? 14u : (uint32_t)a1);
     const uint32_t n2 = (a2 < 0) ? 0xFu : (a2 > 14 ? 14u : (uint32_t)a2);
+    if (n1 == 14u && n2 == 14u && a1 != a2) n1 = 13u;    // two different alleles above 14 stay different (host twin: encode_gt)
     return (n1 << 4) | n2;
 }
 

@@ -308,6 +308,9 @@ static inline uint8_t encode_gt(const char *s, int gt_position, int strict) {
     if (strict && st != 0) return 0xFF;
     int n1 = (a1 < 0) ? 0xF : (a1 > 14 ? 14 : a1);
     int n2 = (a2 < 0) ? 0xF : (a2 > 14 ? 14 : a2);
+    /* allele indices above 14 share the code 14; two DIFFERENT alleles must stay different ("15/16" is heterozygous at
+     * tdt.c:113,185-187), so such a pair is stored as 13/14 */
+    if (n1 == 14 && n2 == 14 && a1 != a2) n1 = 13;
     return (uint8_t)((n1 << 4) | n2);
 }
 

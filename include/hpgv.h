@@ -24,7 +24,8 @@
  * fails with HPGV_ERR_NO_DEVICE.
  *
  * Genotype code (one byte per call, "HPGV8"):
- *      byte = (allele1 << 4) | allele2      allele index 0..14 (clamped),
+ *      byte = (allele1 << 4) | allele2      allele index 0..14 (larger ones are stored as 14; two DIFFERENT alleles
+ *                                           above 13 as 13/14, so that "15/16" stays heterozygous: tdt.c:113,185-187),
  *      nibble 0xF = missing allele, 0xFF = missing / unusable genotype.
  *   Biallelic data uses 0x00 0x01 0x10 0x11 0xFF.  The ORDER of the alleles is
  *   kept because tdt.c:119,176-213 tests them in order.

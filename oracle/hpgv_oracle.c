@@ -91,6 +91,9 @@ uint8_t orc_encode_alleles(int status, int a1, int a2, int strict) {
              : (a1 > 14 ? 14 : a1);
     int n2 = (status == ORC_SECOND_ALLELE_MISSING || status == ORC_ALL_ALLELES_MISSING ||
               status == ORC_HAPLOID || a2 < 0) ? 0xF : (a2 > 14 ? 14 : a2);
+    /* the reference compares the raw allele ints (tdt.c:113,185-187): two different alleles that both clamp to 14 are
+     * stored as 13/14 so that a1 != a2 survives the packed code */
+    if (n1 == 14 && n2 == 14 && a1 != a2) n1 = 13;
     return (uint8_t)((n1 << 4) | n2);
 }
 

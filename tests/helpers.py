@@ -34,7 +34,7 @@ def assert_close(got, exp, what="", tol=TOL):
 
 # genotype strings covering every branch of assoc.c:94-125 and tdt.c:103-213
 QUIRK_GTS = ["0/0", "0/1", "1/0", "1/1", "1/2", "2/1", "0/2", "2/0", "./.", "./1", "0/.", "1|0", "0|1",
-             "1", ".", "3/3", "14/0", "20/20"]
+             "1", ".", "3/3", "14/0", "20/20", "15/16", "0/17"]
 
 
 def random_codes(rng, n_variants, n_samples, quirks=True, strict=True, p_missing=0.05):

@@ -221,3 +221,17 @@ def test_text_and_packed_paths_agree():
                      *[o.ctypes.data_as(C.POINTER(C.c_int32)) for o in outs])
     for a, b in zip(A, outs):
         assert np.array_equal(a, b)
+
+
+def test_alleles_above_14_keep_their_inequality():
+    """the packed code stores allele indices above 14 as 14; "15/16" must stay heterozygous, because the reference
+    compares the raw ints (tdt.c:113 skips a family whose parents are both homozygous, :185-187 tests a1 != a2)."""
+    assert orc.encode_sample("15/16") == 0xDE and orc.encode_sample("16/15") == 0xDE
+    assert orc.encode_sample("15/15") == 0xEE and orc.encode_sample("14/20") == 0xDE and orc.encode_sample("3/20") == 0x3E
+    # father 15/16 (het), mother 0/0, affected child 0/15: counted on the sample strings and on the packed codes alike
+    rows = [["15/16", "0/0", "0/15"], ["15/15", "0/0", "0/15"], ["0/16", "16/15", "15/16"]]
+    fam = (np.array([0]), np.array([1]), np.array([0, 1]), np.array([2]), np.array([0], np.uint8))
+    t_text = orc.tdt_text(rows, *fam)
+    t_code = orc.tdt_counts(orc.encode_matrix(rows), *fam)
+    assert np.array_equal(t_text[0], t_code[0]) and np.array_equal(t_text[1], t_code[1])
+    assert t_text[0][0] + t_text[1][0] == 1 and t_text[0][1] + t_text[1][1] == 0      # het father counted, hom father skipped
