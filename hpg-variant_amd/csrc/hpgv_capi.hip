@@ -5,6 +5,7 @@
 #include "hpgv_internal.h"
 #include <cstdlib>
 #include "hpgv_text_kernels.h"
+#include "hpgv_text2_kernels.h"
 #include "hpgv_inflate_kernels.h"
 #include "hpgv_batch_kernels.h"
 
@@ -129,6 +130,7 @@ int hpgv_create(int device_id, hpgv_ctx **out) {
         (void)hipGetLastError();
     }
     if (const char *bf = getenv("HPGV_BATCH_FUSED")) ctx->batch_fused = atoi(bf) ? 1 : 0;      // diagnosis: 0 = the kernel chains
+    if (const char *tt = getenv("HPGV_TOKENIZER_TILES")) ctx->tokenizer_tiles = atoi(tt) ? 1 : 0;   // diagnosis: 0 = the three-sweep tokenizer
     e = hipMalloc(&ctx->d_sink, 256);
     if (e != hipSuccess) {
         int rc = fail(nullptr, HPGV_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
@@ -197,6 +199,7 @@ void hpgv_destroy(hpgv_ctx *ctx) {
     for (auto *t : ctx->tok_scratch) {
         if (t->d_blocks) (void)hipFree(t->d_blocks);
         if (t->d_line_off) (void)hipFree(t->d_line_off);
+        if (t->d_extra) (void)hipFree(t->d_extra);
         delete t;
     }
     ctx->tok_scratch.clear();
@@ -247,6 +250,8 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
     } else if (!strcmp(key, "scan_lds")) {
         if (value < 0 || value > 160 * 1024) return fail(ctx, HPGV_ERR_INVALID, "scan_lds must be in [0, 163840]");
         ctx->scan_lds = value;
+    } else if (!strcmp(key, "tokenizer_tiles")) {
+        ctx->tokenizer_tiles = value ? 1 : 0;
     } else if (!strcmp(key, "fisher_width")) {
         if (value != 64 && value != 32 && value != 16 && value != 8) return fail(ctx, HPGV_ERR_INVALID, "fisher_width must be 64, 32, 16 or 8");
         ctx->fisher_width = value;
@@ -1418,10 +1423,13 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
         if (!ts) { ts = new hpgv_ctx::TokScratch(); ts->stream = st; ctx->tok_scratch.push_back(ts); }
     }
     // from here on `ts` is only touched by calls on stream `st`, which the caller does not issue concurrently
-    if (ts->blocks_cap < n_blocks + 1) {
+    // scratch per tile: the newline counts of the three-sweep form (4 B), or the tile records and tile states of the
+    // tile-parallel form (16 B + 16 B)
+    const size_t scratch_ints = (n_blocks + 1) * 8;
+    if (ts->blocks_cap < scratch_ints) {
         if (ts->d_blocks) { HIPCHK(ctx, hipStreamSynchronize(st)); (void)hipFree(ts->d_blocks); ts->d_blocks = nullptr; ts->blocks_cap = 0; }
-        HIPCHK(ctx, hipMalloc(&ts->d_blocks, (n_blocks + 1) * sizeof(int)));
-        ts->blocks_cap = n_blocks + 1;
+        HIPCHK(ctx, hipMalloc(&ts->d_blocks, scratch_ints * sizeof(int)));
+        ts->blocks_cap = scratch_ints;
     }
     unsigned long long *line_off = (unsigned long long *)d_line_off;
     if (!line_off) {                                   // caller does not want the offsets: use scratch
@@ -1431,6 +1439,37 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
             ts->line_cap = (size_t)max_lines + 2;
         }
         line_off = ts->d_line_off;
+    }
+    if (ctx->tokenizer_tiles) {
+        // two sweeps of the text: tile records, tile states, then one workgroup per tile parses (hpgv_text2_kernels.h)
+        hpgv::TokAgg *agg = (hpgv::TokAgg *)ts->d_blocks;
+        hpgv::TokPre *pre = (hpgv::TokPre *)(agg + n_blocks + 1);
+        const int n_groups = (int)((n_blocks + hpgv::TOK_SCAN_THREADS - 1) / hpgv::TOK_SCAN_THREADS);
+        // the groups' totals and the per-line "parse again" flags live behind the line offsets' scratch
+        const size_t extra = ((size_t)n_groups + 2) * sizeof(hpgv::TokState) + ((size_t)max_lines + 2) * sizeof(int);
+        if (ts->extra_cap < extra) {
+            if (ts->d_extra) { HIPCHK(ctx, hipStreamSynchronize(st)); (void)hipFree(ts->d_extra); ts->d_extra = nullptr; ts->extra_cap = 0; }
+            HIPCHK(ctx, hipMalloc(&ts->d_extra, extra + extra / 4));
+            ts->extra_cap = extra + extra / 4;
+        }
+        hpgv::TokState *gtot = (hpgv::TokState *)ts->d_extra;
+        int *redo = (int *)(gtot + n_groups + 2);
+        if (n_blocks > 0) {
+            hipLaunchKernelGGL(hpgv::k_tok_count2, dim3((unsigned)n_blocks), dim3(256), 0, st, d_text, text_bytes, agg);
+            hipLaunchKernelGGL(hpgv::k_tok_scan2a, dim3((unsigned)n_groups), dim3(hpgv::TOK_SCAN_THREADS), 0, st, (const hpgv::TokAgg *)agg, (int)n_blocks, pre, gtot);
+        }
+        hipLaunchKernelGGL(hpgv::k_tok_scan2b, dim3((unsigned)(n_groups > 0 ? n_groups : 1)), dim3(hpgv::TOK_SCAN_THREADS), 0, st, pre, (int)n_blocks, gtot, n_groups,
+                           d_text, text_bytes, d_n_lines, line_off, max_lines);
+        if (n_blocks > 0 && max_lines > 0) {
+            HIPCHK(ctx, hipMemsetAsync(redo, 0, (size_t)max_lines * sizeof(int), st));
+            hipLaunchKernelGGL(hpgv::k_tok_parse2, dim3((unsigned)n_blocks), dim3(256), 0, st, d_text, text_bytes, (const hpgv::TokPre *)pre,
+                               max_lines, n_samples, strict, d_gt, pitch, d_is_x, line_off, d_field_off, d_status, redo);
+            // the lines whose FORMAT does not begin with GT (flagged by the thread that read it): once more, line by line
+            hipLaunchKernelGGL(hpgv::k_tok_parse, dim3((unsigned)max_lines), dim3(256), 0, st, d_text, line_off,
+                               (const int *)d_n_lines, max_lines, n_samples, strict, d_gt, pitch, d_is_x, d_field_off, d_status, (const int *)redo);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        return HPGV_OK;
     }
     if (n_blocks > 0)
         hipLaunchKernelGGL(hpgv::k_tok_count, dim3((unsigned)n_blocks), dim3(256), 0, st, d_text, text_bytes, ts->d_blocks);
@@ -1443,7 +1482,7 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
         HIPCHK(ctx, hipMemsetAsync(line_off, 0, sizeof(unsigned long long), st));
     if (max_lines > 0)
         hipLaunchKernelGGL(hpgv::k_tok_parse, dim3((unsigned)max_lines), dim3(256), 0, st, d_text, line_off,
-                           (const int *)d_n_lines, max_lines, n_samples, strict, d_gt, pitch, d_is_x, d_field_off, d_status);
+                           (const int *)d_n_lines, max_lines, n_samples, strict, d_gt, pitch, d_is_x, d_field_off, d_status, (const int *)nullptr);
     HIPCHK(ctx, hipGetLastError());
     return HPGV_OK;
     HPGV_ABI_CATCH(ctx)

@@ -93,6 +93,7 @@ struct hpgv_ctx {
     long epi_triples_1pass = 1; // epistasis triple ranking with at most 10 folds: one pass, all folds' counts in registers (one wave per SIMD)
     long scan_lds = 0;         // bytes of (unused) LDS per workgroup of the stats / tdt scans: caps the waves in flight per CU
     long fisher_width = 16;    // lanes per variant in the Fisher p-pass (64, 32, 16 or 8): 64 / width variants per wave
+    long tokenizer_tiles = 1;  // VCF text tokenizer: 1 = tile-parallel, two sweeps (hpgv_text2_kernels.h); 0 = count / mark / parse per line
     long batch_fused = 1;      // per-batch host entry points: one fused kernel per call (0: copy + layout + scan + statistics kernels)
     long batch_lds_max = 65536;   // largest raw-row window the fused kernel stages in LDS (raised at hpgv_create when the device allows)
     int n_cus = 256;
@@ -133,6 +134,7 @@ struct hpgv_ctx {
         hipStream_t stream = nullptr;
         int *d_blocks = nullptr; size_t blocks_cap = 0;
         unsigned long long *d_line_off = nullptr; size_t line_cap = 0;
+        void *d_extra = nullptr; size_t extra_cap = 0;
     };
     std::mutex tok_mu;
     std::vector<TokScratch *> tok_scratch;

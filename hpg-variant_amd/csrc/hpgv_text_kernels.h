@@ -156,13 +156,15 @@ __device__ __forceinline__ int block_excl_scan(int v, int *s4, int *total) {
 static __global__ __launch_bounds__(256) void k_tok_parse(const char *__restrict__ text, const unsigned long long *__restrict__ line_off,
                                                    const int *__restrict__ n_lines_p, int max_lines, int n_samples, int strict,
                                                    uint8_t *__restrict__ gt, size_t pitch, uint8_t *__restrict__ is_x,
-                                                   uint32_t *__restrict__ field_off /* n_lines x 10 */, int *__restrict__ status) {
+                                                   uint32_t *__restrict__ field_off /* n_lines x 10 */, int *__restrict__ status,
+                                                   const int *__restrict__ only /* null: every line; else only lines with only[line] != 0 */) {
     __shared__ int s4[4];
     __shared__ unsigned int s_field[10];
     __shared__ int s_gtpos;
     const int line = blockIdx.x;
     const int n_lines = *n_lines_p < max_lines ? *n_lines_p : max_lines;
     if (line >= n_lines) return;
+    if (only != nullptr && only[line] == 0) return;
     const size_t ls = line_off[line];
     size_t le = line_off[line + 1];
     if (le > ls && text[le - 1] == '\n') le--;              // exclusive end, newline dropped

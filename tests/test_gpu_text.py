@@ -12,9 +12,11 @@ WEIRD = QUIRK_GTS + ["", "0/1:12:99", ".:3", "1/", "/1", "0|0:.", "10/2", "a/1",
                      "./.:0,0", "0/0:1,2:3"]
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=[1, 0], ids=["tile-parallel", "line-by-line"])
+def eng(request):
+    """Both tokenizers: the tile-parallel one (default, hpgv_text2_kernels.h) and the count / mark / parse-per-line one."""
     e = hpgv.Engine(0)
+    e.set_option("tokenizer_tiles", request.param)
     yield e
     e.close()
 
@@ -60,6 +62,31 @@ def test_random_lines_all_shapes(eng, n_samples):
         _check(eng, "\n".join(lines) + "\n", n_samples, strict)
         _check(eng, "\n".join(lines), n_samples, strict)          # last line without newline
         _check(eng, "\r\n".join(lines) + "\r\n", n_samples, strict)   # CRLF files
+
+
+def test_both_tokenizers_give_the_same_offsets():
+    """line_off / field_off (what the host cuts CHROM .. FORMAT with) from the tile-parallel tokenizer equal the
+    line-by-line one's, on lines of every shape: INFO longer than a tile, empty and truncated lines, CRLF, no final newline."""
+    rng = np.random.default_rng(77)
+    lines = []
+    for i in range(60):
+        fmt = ["GT", "GT:DP", "DP:GT", "DP:GQ:GT:PL", "DP:GQ"][i % 5]
+        lines.append(_line(rng, 300, fmt, ["1", "X", "", "chrX"][i % 4], [3, 100, 5000, 9000, 20000][i % 5], n_cols=[300, 300, 298, 303, 0][i % 5]))
+    lines.insert(3, ""); lines.insert(4, ""); lines.insert(17, "1\t5\trs\tA\tC"); lines.insert(18, "X")
+    outs = []
+    for tiles in (1, 0):
+        e = hpgv.Engine(0)
+        e.set_option("tokenizer_tiles", tiles)
+        res = []
+        for text in ("\n".join(lines) + "\n", "\n".join(lines), "\r\n".join(lines) + "\r\n", "\n\n\n", "\t\t\n", "abc"):
+            for max_lines in (None, 7):
+                res.append(e.tokenize(text, 300, False, max_lines))
+        outs.append(res)
+        e.close()
+    for a, b in zip(*outs):
+        assert a["n_lines"] == b["n_lines"]
+        for k in ("gt", "is_x", "status", "line_off", "field_off"):
+            assert np.array_equal(a[k], b[k]), k
 
 
 def test_empty_and_capacity(eng):
