@@ -68,6 +68,83 @@ static int batch_sources(hpgv_ctx *ctx, Slot *s, const uint8_t *gt, size_t pitch
     return HPGV_OK;
 }
 
+// ---- k_stats_all on a matrix the device can read (the tokenizer's raw matrix, or a host batch through batch_sources): every
+// output is optional except the per-variant counters' record block, which the kernel always produces -------------------
+struct StatsAllOut {
+    int32_t *counts8 = nullptr; double *hwe_chi2 = nullptr, *hwe_p = nullptr;        // [n]
+    int32_t *sample_missing = nullptr;                                                // [n_samples], accumulated into
+    int32_t *mendel_errors = nullptr;                                                 // [n]
+    int32_t *child_errors = nullptr;                                                  // [n_trios], accumulated into
+    int32_t *group_counts8 = nullptr; double *group_hwe_chi2 = nullptr, *group_hwe_p = nullptr;   // [g * group_stride + v]
+    size_t group_stride = 0;
+};
+// LDS the kernel needs for this cohort; 0 when it cannot run (row window + column counters + trio counters too large)
+static size_t stats_all_lds(const hpgv_ctx *ctx, bool mendel) {
+    const size_t ns = (size_t)ctx->stats.n_samples;
+    const size_t need = (ns + 32 + 15) / 16 * 16 + (ns + 15) / 16 * 16 + (mendel ? (size_t)ctx->mendel_pchunks * 16 : 0) + 16;
+    return (ctx->batch_fused && need <= (size_t)ctx->batch_lds_max) ? need : 0;
+}
+static int stats_all_call(hpgv_ctx *ctx, Slot *s, const uint8_t *d_src, size_t src_pitch, int n_variants, const uint8_t *d_is_x,
+                          const StatsAllOut &O) {
+    int rc;
+    const size_t n = (size_t)n_variants;
+    const int ns = ctx->stats.n_samples;
+    const bool want_mendel = O.mendel_errors || O.child_errors;
+    const size_t ng = O.group_counts8 ? ctx->sg_off.size() : 0, nt = want_mendel ? (size_t)ctx->mendel_trios : 0;
+    const size_t rec_bytes = (1 + ng) * n * sizeof(hpgv::BatchStatsRec);
+    if ((rc = ensure_result_block(ctx, s, rec_bytes + n * sizeof(int32_t) + 64))) return rc;
+    const bool want_sm = O.sample_missing && ns > 0, want_ce = O.child_errors && nt > 0;
+    if ((rc = ensure(ctx, s, 3, ((size_t)ns + nt + 16) * sizeof(int32_t)))) return rc;
+    int32_t *d_sm = (int32_t *)s->buf[3], *d_ce = d_sm + ns;
+    if (want_sm || want_ce) HIPCHK(ctx, hipMemsetAsync(d_sm, 0, ((size_t)ns + nt) * sizeof(int32_t), s->stream));
+    hpgv::StatsAllArgs A;
+    memset(&A, 0, sizeof A);
+    A.src = d_src; A.src_pitch = src_pitch; A.n_variants = n_variants; A.n_samples = ns;
+    A.is_x = d_is_x;
+    A.out = (hpgv::BatchStatsRec *)s->d_res;
+    A.sample_missing = want_sm ? d_sm : nullptr;
+    if (want_mendel) {
+        A.mendel_cols = ctx->mendel.d_col_of_pos; A.pchunks = ctx->mendel_pchunks; A.n_trios = ctx->mendel_trios;
+        A.luts = ctx->mendel_luts; A.male_plane = ctx->d_mendel_male;
+        A.mendel_errors = O.mendel_errors ? (int32_t *)((char *)s->d_res + rec_bytes) : nullptr;
+        A.child_errors = want_ce ? d_ce : nullptr;
+    }
+    if (ng) {
+        A.group_cols = ctx->sgroups.d_col_of_pos; A.n_groups = (int)ng;
+        A.group_chunk0 = ctx->d_sg_chunks; A.group_chunks = ctx->d_sg_chunks + ng;
+        A.group_out = (hpgv::BatchStatsRec *)s->d_res + n;
+    }
+    // a band of rows per workgroup keeps the column counters in LDS across rows; short batches stay one row per workgroup
+    int rows = (n_variants + 2047) / 2048;
+    rows = rows < 1 ? 1 : (rows > 255 ? 255 : rows);
+    A.rows_per_block = rows; A.lds_row = (int)(((size_t)ns + 32 + 15) / 16 * 16);
+    const size_t lds = stats_all_lds(ctx, want_mendel);
+    hipLaunchKernelGGL(hpgv::k_stats_all, dim3((unsigned)((n_variants + rows - 1) / rows)), dim3(256), lds, s->stream, A);
+    HIPCHK(ctx, hipGetLastError());
+    std::vector<int32_t> acc;
+    if (want_sm || want_ce) {
+        acc.resize((size_t)ns + nt);
+        HIPCHK(ctx, hipMemcpyAsync(acc.data(), d_sm, acc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    const hpgv::BatchStatsRec *r = (const hpgv::BatchStatsRec *)s->h_res;
+    if (O.counts8)
+        for (size_t i = 0; i < n; ++i) {
+            memcpy(O.counts8 + 8 * i, r[i].c8, 8 * sizeof(int32_t));
+            if (O.hwe_chi2) { O.hwe_chi2[i] = r[i].hwe_chi2; O.hwe_p[i] = r[i].hwe_p; }
+        }
+    for (size_t k = 0; k < ng; ++k)
+        for (size_t i = 0; i < n; ++i) {
+            const hpgv::BatchStatsRec &q = r[n + k * n + i];
+            memcpy(O.group_counts8 + (k * O.group_stride + i) * 8, q.c8, 8 * sizeof(int32_t));
+            if (O.group_hwe_chi2) { O.group_hwe_chi2[k * O.group_stride + i] = q.hwe_chi2; O.group_hwe_p[k * O.group_stride + i] = q.hwe_p; }
+        }
+    if (O.mendel_errors) memcpy(O.mendel_errors, (const char *)s->h_res + rec_bytes, n * sizeof(int32_t));
+    if (want_sm) for (int j = 0; j < ns; ++j) O.sample_missing[j] += acc[(size_t)j];
+    if (want_ce) for (size_t t = 0; t < nt; ++t) O.child_errors[t] += acc[(size_t)ns + t];
+    return HPGV_OK;
+}
+
 template <int KIND>
 static int launch_batch(hpgv_ctx *ctx, Slot *s, const hpgv::BatchArgs &A) {
     const size_t lds = ((size_t)A.n_samples + 15 + 15) / 16 * 16 + 16;
@@ -1197,6 +1274,35 @@ int hpgv_stats_ex(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants
     Slot *s = lease.s;
     const size_t n = (size_t)n_variants;
     const int ns = ctx->stats.n_samples;
+    if (sample_missing && ns > 0 && stats_all_lds(ctx, false) != 0) {
+        // get_sample_stats' shape (stats_runner.c:197-198): counters, Hardy-Weinberg and the per-sample missing counts in one
+        // pass over the batch, read in place when it lies in page-locked memory
+        hpgv::BatchArgs B;
+        memset(&B, 0, sizeof B);
+        if ((rc = batch_sources(ctx, s, gt, pitch, n_variants, ns, nullptr, &B))) return rc;
+        StatsAllOut O;
+        O.counts8 = counts8; O.hwe_chi2 = hwe_chi2; O.hwe_p = hwe_p; O.sample_missing = sample_missing;
+        if ((rc = stats_all_call(ctx, s, B.src, pitch, n_variants, nullptr, O))) return rc;
+        if (n_multi) {
+            std::vector<int32_t> idx;
+            for (size_t i = 0; i < n; ++i) {
+                const int32_t *c = counts8 + 8 * i;
+                if (ns - c[4] - (c[0] + c[1] + c[2] + c[3]) > 0) idx.push_back((int32_t)i);
+            }
+            *n_multi = (int)idx.size();
+            const int m = (int)idx.size() < cap ? (int)idx.size() : cap;
+            if (m > 0) {
+                if ((rc = ensure(ctx, s, 6, (size_t)m * sizeof(int32_t)))) return rc;
+                if ((rc = ensure(ctx, s, 7, (size_t)m * 256 * sizeof(int32_t)))) return rc;
+                HIPCHK(ctx, hipMemcpyAsync(s->buf[6], idx.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+                if ((rc = hpgv_genotype_table_dev(ctx, B.src, pitch, ns, (const int32_t *)s->buf[6], m, (int32_t *)s->buf[7], s->stream))) return rc;
+                HIPCHK(ctx, hipMemcpyAsync(multi_table, s->buf[7], (size_t)m * 256 * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+                HIPCHK(ctx, hipStreamSynchronize(s->stream));
+                memcpy(multi_idx, idx.data(), (size_t)m * sizeof(int32_t));
+            }
+        }
+        return HPGV_OK;
+    }
     if (batch_fused_ok(ctx, ns) && !(sample_missing && ns > 0)) {
         // get_variants_stats' shape: counters + Hardy-Weinberg per variant in one kernel; the 256-bin tables of the rare
         // multi-allelic variants are counted from the same raw rows afterwards
@@ -1302,6 +1408,15 @@ int hpgv_stats_groups(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_vari
     int rc = acquire_slot(ctx, &lease.s);
     if (rc) return rc;
     Slot *s = lease.s;
+    if (ctx->stats.set && ctx->stats.n_samples == ctx->sgroups.n_samples && stats_all_lds(ctx, false) != 0) {
+        // the counters of every phenotype group from one pass over the batch (k_stats_all gathers every group's columns)
+        hpgv::BatchArgs B;
+        memset(&B, 0, sizeof B);
+        if ((rc = batch_sources(ctx, s, gt, pitch, n_variants, ctx->stats.n_samples, nullptr, &B))) return rc;
+        StatsAllOut O;
+        O.group_counts8 = counts8; O.group_hwe_chi2 = hwe_chi2; O.group_hwe_p = hwe_p; O.group_stride = (size_t)n_variants;
+        return stats_all_call(ctx, s, B.src, pitch, n_variants, nullptr, O);
+    }
     const uint8_t *d_isx = nullptr;
     if ((rc = stage_batch(ctx, s, HPGV_LAYOUT_STATS_GROUPS, ctx->sgroups, gt, pitch, n_variants, nullptr, &d_isx))) return rc;
     const size_t n = (size_t)n_variants, ng = ctx->sg_off.size();
@@ -1360,6 +1475,16 @@ int hpgv_mendel(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, 
     int rc = acquire_slot(ctx, &lease.s);
     if (rc) return rc;
     Slot *s = lease.s;
+    if (ctx->stats.set && ctx->stats.n_samples == ctx->mendel.n_samples && stats_all_lds(ctx, true) != 0) {
+        hpgv::BatchArgs B;
+        memset(&B, 0, sizeof B);
+        if ((rc = batch_sources(ctx, s, gt, pitch, n_variants, ctx->stats.n_samples, is_x, &B))) return rc;
+        StatsAllOut O;
+        O.mendel_errors = errors; O.child_errors = child_errors;
+        std::vector<int32_t> scratch;
+        if (!errors) { scratch.resize((size_t)n_variants); O.mendel_errors = scratch.data(); }      // the kernel's switch for the Mendel pass
+        return stats_all_call(ctx, s, B.src, pitch, n_variants, B.is_x, O);
+    }
     const uint8_t *d_isx = nullptr;
     if ((rc = stage_batch(ctx, s, HPGV_LAYOUT_MENDEL, ctx->mendel, gt, pitch, n_variants, is_x, &d_isx))) return rc;
     const size_t n = (size_t)n_variants, nt = (size_t)ctx->mendel_trios;
@@ -1801,10 +1926,7 @@ int hpgv_stats_text_groups(hpgv_ctx *ctx, const char *text, size_t text_bytes, i
     if (rc) return rc;
     Slot *s = lease.s;
     int nl = 0;
-    // LDS of the one-pass kernel: the row window, a byte counter per column and per trio
-    const size_t lds_row = ((size_t)ctx->stats.n_samples + 32 + 15) / 16 * 16;
-    const size_t lds_all = lds_row + ((size_t)ctx->stats.n_samples + 15) / 16 * 16 + (want_mendel ? (size_t)ctx->mendel_pchunks * 16 : 0) + 16;
-    const bool fused = ctx->batch_fused && lds_all <= (size_t)ctx->batch_lds_max;
+    const bool fused = stats_all_lds(ctx, want_mendel) != 0;      // LDS: the row window, a byte counter per column and per trio
     if ((rc = text_front(ctx, s, HPGV_LAYOUT_STATS, ctx->stats, text, text_bytes, max_lines, n_lines, line_off, field_off, status, &nl, !fused))) return rc;
     if (nl == 0) { HIPCHK(ctx, hipStreamSynchronize(s->stream)); return HPGV_OK; }
     const size_t n = (size_t)nl;
@@ -1813,56 +1935,11 @@ int hpgv_stats_text_groups(hpgv_ctx *ctx, const char *text, size_t text_bytes, i
     if (fused) {
         // ONE pass over the tokenizer's raw matrix gives every statistic of the batch (k_stats_all): the genotype bytes
         // are read from HBM once after tokenizing
-        const size_t ng = group_counts8 ? ctx->sg_off.size() : 0, nt = (size_t)ctx->mendel_trios;
-        const size_t rec_bytes = (1 + ng) * n * sizeof(hpgv::BatchStatsRec);
-        if ((rc = ensure_result_block(ctx, s, rec_bytes + n * sizeof(int32_t) + 64))) return rc;
-        const bool want_sm = sample_missing && ns > 0, want_ce = child_errors && nt > 0;
-        if ((rc = ensure(ctx, s, 3, ((size_t)ns + nt + 16) * sizeof(int32_t)))) return rc;
-        int32_t *d_sm = (int32_t *)s->buf[3], *d_ce = d_sm + ns;
-        if (want_sm || want_ce) HIPCHK(ctx, hipMemsetAsync(d_sm, 0, ((size_t)ns + nt) * sizeof(int32_t), s->stream));
-        hpgv::StatsAllArgs A;
-        memset(&A, 0, sizeof A);
-        A.src = (const uint8_t *)s->buf[7]; A.src_pitch = raw_pitch; A.n_variants = nl; A.n_samples = ns;
-        A.is_x = (const uint8_t *)s->buf[2];
-        A.out = (hpgv::BatchStatsRec *)s->d_res;
-        A.sample_missing = want_sm ? d_sm : nullptr;
-        if (want_mendel) {
-            A.mendel_cols = ctx->mendel.d_col_of_pos; A.pchunks = ctx->mendel_pchunks; A.n_trios = ctx->mendel_trios;
-            A.luts = ctx->mendel_luts; A.male_plane = ctx->d_mendel_male;
-            A.mendel_errors = mendel_errors ? (int32_t *)((char *)s->d_res + rec_bytes) : nullptr;
-            A.child_errors = want_ce ? d_ce : nullptr;
-        }
-        if (ng) {
-            A.group_cols = ctx->sgroups.d_col_of_pos; A.n_groups = (int)ng;
-            A.group_chunk0 = ctx->d_sg_chunks; A.group_chunks = ctx->d_sg_chunks + ng;
-            A.group_out = (hpgv::BatchStatsRec *)s->d_res + n;
-        }
-        // a band of rows per workgroup keeps the column counters in LDS across rows; short batches stay one row per workgroup
-        int rows = (nl + 2047) / 2048;
-        rows = rows < 1 ? 1 : (rows > 255 ? 255 : rows);
-        A.rows_per_block = rows; A.lds_row = (int)lds_row;
-        hipLaunchKernelGGL(hpgv::k_stats_all, dim3((unsigned)((nl + rows - 1) / rows)), dim3(256), lds_all, s->stream, A);
-        HIPCHK(ctx, hipGetLastError());
-        std::vector<int32_t> acc;
-        if (want_sm || want_ce) {
-            acc.resize((size_t)ns + nt);
-            HIPCHK(ctx, hipMemcpyAsync(acc.data(), d_sm, acc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
-        }
-        HIPCHK(ctx, hipStreamSynchronize(s->stream));
-        const hpgv::BatchStatsRec *r = (const hpgv::BatchStatsRec *)s->h_res;
-        for (size_t i = 0; i < n; ++i) {
-            memcpy(counts8 + 8 * i, r[i].c8, 8 * sizeof(int32_t));
-            hwe_chi2[i] = r[i].hwe_chi2; hwe_p[i] = r[i].hwe_p;
-        }
-        for (size_t k = 0; k < ng; ++k)
-            for (size_t i = 0; i < n; ++i) {
-                const hpgv::BatchStatsRec &q = r[n + k * n + i];
-                memcpy(group_counts8 + (k * (size_t)max_lines + i) * 8, q.c8, 8 * sizeof(int32_t));
-                if (group_hwe_chi2) { group_hwe_chi2[k * (size_t)max_lines + i] = q.hwe_chi2; group_hwe_p[k * (size_t)max_lines + i] = q.hwe_p; }
-            }
-        if (want_mendel && mendel_errors) memcpy(mendel_errors, (const char *)s->h_res + rec_bytes, n * sizeof(int32_t));
-        if (want_sm) for (int j = 0; j < ns; ++j) sample_missing[j] += acc[(size_t)j];
-        if (want_ce) for (size_t t = 0; t < nt; ++t) child_errors[t] += acc[(size_t)ns + t];
+        StatsAllOut O;
+        O.counts8 = counts8; O.hwe_chi2 = hwe_chi2; O.hwe_p = hwe_p; O.sample_missing = sample_missing;
+        O.mendel_errors = mendel_errors; O.child_errors = child_errors;
+        O.group_counts8 = group_counts8; O.group_hwe_chi2 = group_hwe_chi2; O.group_hwe_p = group_hwe_p; O.group_stride = (size_t)max_lines;
+        if ((rc = stats_all_call(ctx, s, (const uint8_t *)s->buf[7], raw_pitch, nl, (const uint8_t *)s->buf[2], O))) return rc;
         if (n_multi) {
             std::vector<int32_t> idx;
             for (size_t i = 0; i < n; ++i) {

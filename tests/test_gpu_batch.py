@@ -118,3 +118,47 @@ def test_long_rows_take_the_kernel_chain():
     res = e.assoc(hpgv.TASK_CHISQ, gt)
     check_assoc(res, oracle_assoc(hpgv.TASK_CHISQ, gt, cond), hpgv.TASK_CHISQ)
     e.close()
+
+
+@pytest.mark.parametrize("n_samples", [5, 333, 4100])
+def test_sample_stats_groups_mendel_in_one_pass(n_samples):
+    """hpgv_stats_ex with per-sample counters, hpgv_stats_groups and hpgv_mendel through k_stats_all (one pass over the batch)
+    against the kernel chains and the oracle."""
+    rng = np.random.default_rng(n_samples)
+    nv = 211
+    gt = random_codes(rng, nv, n_samples, quirks=True, strict=False)
+    is_x = (rng.random(nv) < 0.3).astype(np.uint8)
+    n_trios = n_samples // 4
+    cols = rng.permutation(n_samples)
+    f, m, c = cols[:n_trios], cols[n_trios: 2 * n_trios], cols[2 * n_trios: 3 * n_trios]
+    sex = rng.integers(0, 2, n_trios).astype(np.uint8)
+    groups = rng.integers(-1, 3, n_samples).astype(np.int32)
+    out = {}
+    for fused in (1, 0):
+        e = hpgv.Engine(0)
+        e.set_option("batch_fused", fused)
+        e.set_stats_cohort(n_samples)
+        e.set_pedigree(n_samples, f, m, c, sex)
+        e.set_stats_groups(groups, 3)
+        miss = np.zeros(n_samples, np.int32)
+        a = e.stats_ex(gt, sample_missing=miss, multi_cap=nv)
+        g = e.stats_groups(gt, 3)
+        cerr = np.zeros(n_trios, np.int32)
+        merr = e.mendel(gt, is_x, cerr)
+        out[fused] = (a, miss, g, merr, cerr)
+        e.close()
+    a1, miss1, g1, merr1, cerr1 = out[1]
+    a0, miss0, g0, merr0, cerr0 = out[0]
+    for k in ("counts8", "hwe_chi2", "hwe_p", "multi_idx", "multi_table"):
+        assert np.array_equal(a1[k], a0[k], equal_nan=True), k
+    assert np.array_equal(miss1, miss0) and np.array_equal(miss1, orc.sample_missing(gt))
+    for k in ("counts8", "hwe_chi2", "hwe_p"):
+        assert np.array_equal(g1[k], g0[k], equal_nan=True), k
+    exp_err, exp_trio = orc.mendel_counts(gt, f, m, c, sex, is_x)
+    assert np.array_equal(merr1, exp_err) and np.array_equal(merr0, exp_err)
+    assert np.array_equal(cerr1, exp_trio) and np.array_equal(cerr0, exp_trio)
+    for gi in range(3):
+        sel = groups == gi
+        for v in range(0, nv, 17):
+            vs = orc.variant_stats(np.ascontiguousarray(gt[v][sel]), 2)
+            assert list(g1["counts8"][gi, v, :4]) == list(vs.genotypes_count)[:4]
