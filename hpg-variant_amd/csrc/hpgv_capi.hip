@@ -1567,9 +1567,10 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
     }
     if (ctx->tokenizer_tiles) {
         // two sweeps of the text: tile records, tile states, then one workgroup per tile parses (hpgv_text2_kernels.h)
+        const size_t n_tiles = (text_bytes + hpgv::TOK2_TILE - 1) / hpgv::TOK2_TILE;      // 8 KiB tiles (the scratch is sized for 4 KiB ones)
         hpgv::TokAgg *agg = (hpgv::TokAgg *)ts->d_blocks;
-        hpgv::TokPre *pre = (hpgv::TokPre *)(agg + n_blocks + 1);
-        const int n_groups = (int)((n_blocks + hpgv::TOK_SCAN_THREADS - 1) / hpgv::TOK_SCAN_THREADS);
+        hpgv::TokPre *pre = (hpgv::TokPre *)(agg + n_tiles + 1);
+        const int n_groups = (int)((n_tiles + hpgv::TOK_SCAN_THREADS - 1) / hpgv::TOK_SCAN_THREADS);
         // the groups' totals and the per-line "parse again" flags live behind the line offsets' scratch
         const size_t extra = ((size_t)n_groups + 2) * sizeof(hpgv::TokState) + ((size_t)max_lines + 2) * sizeof(int);
         if (ts->extra_cap < extra) {
@@ -1579,15 +1580,15 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
         }
         hpgv::TokState *gtot = (hpgv::TokState *)ts->d_extra;
         int *redo = (int *)(gtot + n_groups + 2);
-        if (n_blocks > 0) {
-            hipLaunchKernelGGL(hpgv::k_tok_count2, dim3((unsigned)n_blocks), dim3(256), 0, st, d_text, text_bytes, agg);
-            hipLaunchKernelGGL(hpgv::k_tok_scan2a, dim3((unsigned)n_groups), dim3(hpgv::TOK_SCAN_THREADS), 0, st, (const hpgv::TokAgg *)agg, (int)n_blocks, pre, gtot);
+        if (n_tiles > 0) {
+            hipLaunchKernelGGL(hpgv::k_tok_count2, dim3((unsigned)n_tiles), dim3(256), 0, st, d_text, text_bytes, agg);
+            hipLaunchKernelGGL(hpgv::k_tok_scan2a, dim3((unsigned)n_groups), dim3(hpgv::TOK_SCAN_THREADS), 0, st, (const hpgv::TokAgg *)agg, (int)n_tiles, pre, gtot);
         }
-        hipLaunchKernelGGL(hpgv::k_tok_scan2b, dim3((unsigned)(n_groups > 0 ? n_groups : 1)), dim3(hpgv::TOK_SCAN_THREADS), 0, st, pre, (int)n_blocks, gtot, n_groups,
+        hipLaunchKernelGGL(hpgv::k_tok_scan2b, dim3((unsigned)(n_groups > 0 ? n_groups : 1)), dim3(hpgv::TOK_SCAN_THREADS), 0, st, pre, (int)n_tiles, gtot, n_groups,
                            d_text, text_bytes, d_n_lines, line_off, max_lines);
-        if (n_blocks > 0 && max_lines > 0) {
+        if (n_tiles > 0 && max_lines > 0) {
             HIPCHK(ctx, hipMemsetAsync(redo, 0, (size_t)max_lines * sizeof(int), st));
-            hipLaunchKernelGGL(hpgv::k_tok_parse2, dim3((unsigned)n_blocks), dim3(256), 0, st, d_text, text_bytes, (const hpgv::TokPre *)pre,
+            hipLaunchKernelGGL(hpgv::k_tok_parse2, dim3((unsigned)n_tiles), dim3(256), 0, st, d_text, text_bytes, (const hpgv::TokPre *)pre,
                                max_lines, n_samples, strict, d_gt, pitch, d_is_x, line_off, d_field_off, d_status, redo);
             // the lines whose FORMAT does not begin with GT (flagged by the thread that read it): once more, line by line
             hipLaunchKernelGGL(hpgv::k_tok_parse, dim3((unsigned)max_lines), dim3(256), 0, st, d_text, line_off,

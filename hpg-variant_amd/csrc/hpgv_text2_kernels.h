@@ -20,36 +20,44 @@
 
 namespace hpgv {
 
+constexpr int TOK2_TB = 32;                                          // bytes per thread: 32 TAB / newline bits in one register
+constexpr int TOK2_NW = TOK2_TB / 8 + 1;                             // 8-byte words a thread holds: its bytes and the 8 after them
+constexpr int TOK2_TILE = 256 * TOK2_TB;                             // bytes per workgroup tile (8 KiB)
 struct TokAgg { int nl, tabs, last_nl, pad; };                       // last_nl: offset inside the tile, -1 when none
 struct TokPre { int lines, tabs; unsigned long long line_start; };   // state at the tile's first byte
 constexpr int TOK_GT_UNDEF = -2;                                     // "FORMAT of this line not seen yet"
 
-// TAB and newline bits of a thread's 16 bytes (bit j = byte base + j), and the 24 bytes themselves when they all exist
-__device__ __forceinline__ void tok_masks16(const char *__restrict__ t, size_t base, size_t n, uint32_t *tabs, uint32_t *nls,
-                                            uint64_t *w0, uint64_t *w1, uint64_t *w2, bool *wide) {
-    *wide = base + 24 <= n;
-    *w0 = *w1 = *w2 = 0;
+// TAB and newline bits of a thread's TOK2_TB bytes (bit j = byte base + j), and the bytes themselves (+ the 8 after them) when
+// they all exist
+__device__ __forceinline__ void tok_masks(const char *__restrict__ t, size_t base, size_t n, uint32_t *tabs, uint32_t *nls,
+                                          uint64_t (&w)[TOK2_NW], bool *wide) {
+    *wide = base + TOK2_TB + 8 <= n;
+    uint32_t a = 0, b = 0;
     if (*wide) {
-        __builtin_memcpy(w0, t + base, 8); __builtin_memcpy(w1, t + base + 8, 8); __builtin_memcpy(w2, t + base + 16, 8);
-        *tabs = tok_byte_mask(*w0, '\t') | (tok_byte_mask(*w1, '\t') << 8);
-        *nls = tok_byte_mask(*w0, '\n') | (tok_byte_mask(*w1, '\n') << 8);
+#pragma unroll
+        for (int k = 0; k < TOK2_NW; ++k) __builtin_memcpy(&w[k], t + base + 8 * k, 8);
+#pragma unroll
+        for (int k = 0; k < TOK2_TB / 8; ++k) { a |= tok_byte_mask(w[k], '\t') << (8 * k); b |= tok_byte_mask(w[k], '\n') << (8 * k); }
     } else {
-        uint32_t a = 0, b = 0;
-        for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int k = 0; k < TOK2_NW; ++k) w[k] = 0;
+        for (int j = 0; j < TOK2_TB; ++j)
             if (base + j < n) { const char c = t[base + j]; if (c == '\t') a |= 1u << j; else if (c == '\n') b |= 1u << j; }
-        *tabs = a; *nls = b;
     }
+    *tabs = a; *nls = b;
 }
+// TABs behind bit `last` (the thread's last newline): a shift by 32 is not a shift
+__device__ __forceinline__ int tok_tabs_after(uint32_t tabs, int last) { return last >= 31 ? 0 : __popc(tabs >> (last + 1)); }
 
 static __global__ __launch_bounds__(256) void k_tok_count2(const char *__restrict__ text, size_t n, TokAgg *__restrict__ agg) {
     __shared__ int s_nl[4], s_last[4], s_tabs[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const size_t base = (size_t)blockIdx.x * TOK_TILE + (size_t)tid * 16;
-    uint32_t tabs, nls; uint64_t w0, w1, w2; bool wide;
-    tok_masks16(text, base, n, &tabs, &nls, &w0, &w1, &w2, &wide);
+    const size_t base = (size_t)blockIdx.x * TOK2_TILE + (size_t)tid * TOK2_TB;
+    uint32_t tabs, nls; uint64_t ww[TOK2_NW]; bool wide;
+    tok_masks(text, base, n, &tabs, &nls, ww, &wide);
     const int nl = __popc(nls);
     const int last_bit = nl ? 31 - __clz((int)nls) : -1;
-    const int tabs_after = nl ? __popc(tabs >> (last_bit + 1)) : __popc(tabs);
+    const int tabs_after = nl ? tok_tabs_after(tabs, last_bit) : __popc(tabs);
     // the last thread of the workgroup that holds a newline
     int c = nl, key = nl ? tid : -1;
     for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off); const int k2 = __shfl_xor(key, off); key = k2 > key ? k2 : key; }
@@ -64,7 +72,7 @@ static __global__ __launch_bounds__(256) void k_tok_count2(const char *__restric
         TokAgg a;
         a.nl = s_nl[0] + s_nl[1] + s_nl[2] + s_nl[3];
         a.tabs = s_tabs[0] + s_tabs[1] + s_tabs[2] + s_tabs[3];
-        a.last_nl = tlast < 0 ? -1 : tid * 16 + last_bit;
+        a.last_nl = tlast < 0 ? -1 : tid * TOK2_TB + last_bit;
         a.pad = 0;
         agg[blockIdx.x] = a;
     }
@@ -92,7 +100,7 @@ static __global__ __launch_bounds__(TOK_SCAN_THREADS) void k_tok_scan2a(const To
     TokState me = {0, 0, -1};
     if (i < n_tiles) {
         const TokAgg a = agg[i];
-        me.lines = a.nl; me.tabs = a.tabs; me.ls = a.last_nl >= 0 ? (long long)i * TOK_TILE + a.last_nl + 1 : -1;
+        me.lines = a.nl; me.tabs = a.tabs; me.ls = a.last_nl >= 0 ? (long long)i * TOK2_TILE + a.last_nl + 1 : -1;
     }
     TokState inc = me;                                               // inclusive scan within the wave
     for (int off = 1; off < 64; off <<= 1) {
@@ -180,10 +188,10 @@ static __global__ __launch_bounds__(256) void k_tok_parse2(const char *__restric
     __shared__ unsigned long long s_p[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const char *t = text;
-    const size_t tile0 = (size_t)blockIdx.x * TOK_TILE, base = tile0 + (size_t)tid * 16;
+    const size_t base = (size_t)blockIdx.x * TOK2_TILE + (size_t)tid * TOK2_TB;
     const TokPre P = pre[blockIdx.x];
-    uint32_t tabs, nls; uint64_t w0, w1, w2; bool wide;
-    tok_masks16(t, base, n, &tabs, &nls, &w0, &w1, &w2, &wide);
+    uint32_t tabs, nls; uint64_t ww[TOK2_NW]; bool wide;
+    tok_masks(t, base, n, &tabs, &nls, ww, &wide);
 
     // ---- the line in progress when its FORMAT (8th TAB) lies before this tile: GT is ASSUMED to be the first FORMAT key, as the
     //      VCF specification requires; the thread that sees a FORMAT where it is not flags the line for k_tok_parse ----------
@@ -192,7 +200,7 @@ static __global__ __launch_bounds__(256) void k_tok_parse2(const char *__restric
     // ---- scan A: (line, TABs since the line began, where it began) at every thread's first byte --------------------------
     const int nl = __popc(nls);
     const int last_bit = nl ? 31 - __clz((int)nls) : -1;
-    int f = nl ? 1 : 0, v = nl ? __popc(tabs >> (last_bit + 1)) : __popc(tabs), cn = nl;
+    int f = nl ? 1 : 0, v = nl ? tok_tabs_after(tabs, last_bit) : __popc(tabs), cn = nl;
     unsigned long long p = nl ? (unsigned long long)(base + last_bit + 1) : 0ull;
     for (int off = 1; off < 64; off <<= 1) {                         // inclusive, within the wave
         const int f2 = __shfl_up(f, off), v2 = __shfl_up(v, off), n2 = __shfl_up(cn, off);
@@ -236,7 +244,7 @@ static __global__ __launch_bounds__(256) void k_tok_parse2(const char *__restric
     for (int k = 0; k < w; ++k) if (s_d[k]) bg = s_g[k];
     int gtpos = ed ? eg : bg;
 
-    // ---- the walk: every TAB and newline of the thread's 16 bytes, in order ----------------------------------------------
+    // ---- the walk: every TAB and newline of the thread's bytes, in order ----------------------------------------------
     if (blockIdx.x == 0 && tid == 0 && n > 0) {
         line_off[0] = 0;
         if (field_off && max_lines > 0) field_off[0] = 0;
@@ -260,9 +268,11 @@ static __global__ __launch_bounds__(256) void k_tok_parse2(const char *__restric
                 if (sample < n_samples) {
                     uint32_t code = 0x100u;                         // "not decided"
                     if (wide && gtpos == 0) {
-                        const int k = j + 1;                        // the four bytes after the TAB: k .. k + 3 <= 19
+                        const int k = j + 1;                        // the four bytes after the TAB: k .. k + 3 < TOK2_TB + 8
                         const int wi = k >> 3, sh = (k & 7) * 8;
-                        const uint64_t a = wi == 0 ? w0 : wi == 1 ? w1 : w2, b = wi == 0 ? w1 : w2;
+                        uint64_t a = ww[0], b = ww[1];
+#pragma unroll
+                        for (int q2 = 1; q2 < TOK2_NW; ++q2) if (wi == q2) { a = ww[q2]; b = q2 + 1 < TOK2_NW ? ww[q2 + 1] : 0; }
                         const uint32_t q = (uint32_t)(sh ? (a >> sh) | (b << (64 - sh)) : a);
                         const uint32_t b0 = q & 0xFF, b1 = (q >> 8) & 0xFF, b2 = (q >> 16) & 0xFF, b3 = q >> 24;
                         if ((b1 == '/' || b1 == '|') && (b3 == '\t' || b3 == ':' || b3 == '\n')) {
@@ -283,7 +293,7 @@ static __global__ __launch_bounds__(256) void k_tok_parse2(const char *__restric
         }
     }
     // the unterminated last line ends at n: closed by the thread that holds the text's last byte
-    if (n > 0 && base <= n - 1 && n - 1 < base + 16 && t[n - 1] != '\n' && line < max_lines)
+    if (n > 0 && base <= n - 1 && n - 1 < base + TOK2_TB && t[n - 1] != '\n' && line < max_lines)
         tok_close_line(t, line, ntab, gtpos, ls, n, n_samples, gt, pitch, is_x, field_off, status);
 }
 
