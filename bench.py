@@ -228,15 +228,7 @@ def worker(args):
         V_all = args.variants
     if args.samples:
         N = args.samples
-    if scaling == "strong":
-        v_lo, v_hi = sharding.variant_range(rank, world, V_all)     # rank g scans [g*V/G, (g+1)*V/G)
-        total_per_step = V_all
-    else:
-        v_lo, v_hi = rank * V_all, (rank + 1) * V_all               # one shard per rank
-        total_per_step = V_all * world
-    V = v_hi - v_lo
-    V_max = max(sharding.variant_range(r, world, V_all)[1] - sharding.variant_range(r, world, V_all)[0]
-                for r in range(world)) if scaling == "strong" else V
+    total_per_step = V_all if scaling == "strong" else V_all * world
 
     eng = hpgv.Engine(dev_index)
     for kv in args.option:
@@ -265,13 +257,9 @@ def worker(args):
             eng.set_logfact(lf_table)
     head, res_bytes = RESULT[kind]
 
-    # ---- tiles of the shard -------------------------------------------------------------------------------
-    tile_cap = max(1, int(args.tile_gb * 1e9) // pitch)              # variants per tile buffer
-    n_tiles = max(1, -(-V_max // tile_cap))
-    per_tile = -(-V_max // n_tiles)
-    tiles = [(lo, min(lo + per_tile, V)) for lo in range(0, max(V, 1), per_tile) if lo < V or lo == 0]
-    while len(tiles) < n_tiles:
-        tiles.append((V, V))                                         # ragged shards: every rank walks the same tile count
+    # ---- tiles of the shard (strong: rank g scans [g*V/G, (g+1)*V/G); weak: one shard of V_all per rank) -----------------
+    plan = sharding.plan_tiles(rank, world, V_all, pitch, int(args.tile_gb * 1e9), strong=(scaling == "strong"))
+    v_lo, V, n_tiles, per_tile, tiles = plan["v_lo"], plan["n"], plan["n_tiles"], plan["per_tile"], plan["tiles"]
     free_b, total_b = torch.cuda.mem_get_info(dev)
     res_need = 2 * res_bytes * per_tile * n_tiles * (1 + (world if rank == 0 and world > 1 else 0))
     resident = args.resident == "auto" and (V * pitch + res_need + (6 << 30) <= free_b)
@@ -303,16 +291,7 @@ def worker(args):
     blocks = [[torch.empty(res_bytes * max(hi - lo, 1), dtype=torch.uint8, device=dev) for lo, hi in tiles] for _ in range(gens)]
     # sizes of every rank's block of tile ti (known to all ranks: they follow from variant_range)
     def tile_sizes(ti):
-        out = []
-        for r in range(world):
-            if scaling == "strong":
-                a, b = sharding.variant_range(r, world, V_all)
-                vr = b - a
-            else:
-                vr = V_all
-            lo = min(ti * per_tile, vr)
-            out.append(res_bytes * (min(lo + per_tile, vr) - lo))
-        return out
+        return [res_bytes * c for c in plan["counts"][ti]]
 
     recv = None
     if world > 1 and rank == 0:
@@ -446,7 +425,7 @@ def worker(args):
             sources.append((blocks[g_last][-1], v_lo + tiles[-1][0], tiles[-1][1] - tiles[-1][0]))
         if world > 1:
             r = world - 1
-            r_lo = sharding.variant_range(r, world, V_all)[0] if scaling == "strong" else r * V_all
+            r_lo = sharding.plan_tiles(r, world, V_all, pitch, int(args.tile_gb * 1e9), strong=(scaling == "strong"))["v_lo"]
             nb = tile_sizes(n_tiles - 1)[r] // res_bytes
             if nb > 0:
                 sources.append((recv[g_last][n_tiles - 1][r], r_lo + (n_tiles - 1) * per_tile, nb))

@@ -20,6 +20,28 @@ def variant_range(rank, world, n_variants):
     return lo, hi
 
 
+def plan_tiles(rank, world, n_variants, row_bytes, tile_bytes, strong=True):
+    """How rank `rank` of `world` walks its shard in tiles of at most `tile_bytes` (bench.py).
+
+    strong: `n_variants` is the whole cohort and the rank's shard is variant_range(rank, world, n_variants);
+    otherwise every rank has a shard of `n_variants` of its own.  Every rank walks the SAME number of tiles (the
+    gathers of tile t are collective), sized for the largest shard; a shorter shard's last tiles may be empty.
+    Returns dict(v_lo, n, n_tiles, per_tile, tiles=[(lo, hi) within the shard]) and, for every tile, the number of
+    variants EVERY rank holds in it (block sizes are known to all ranks without an exchange)."""
+    def shard(r):
+        return variant_range(r, world, n_variants) if strong else (r * n_variants, (r + 1) * n_variants)
+    v_lo, v_hi = shard(rank)
+    n = v_hi - v_lo
+    n_max = max(shard(r)[1] - shard(r)[0] for r in range(world))
+    cap = max(1, int(tile_bytes) // max(1, int(row_bytes)))            # variants per tile buffer
+    n_tiles = max(1, -(-n_max // cap))
+    per_tile = max(1, -(-n_max // n_tiles))
+    tiles = [(min(t * per_tile, n), min((t + 1) * per_tile, n)) for t in range(n_tiles)]
+    counts = [[min((t + 1) * per_tile, shard(r)[1] - shard(r)[0]) - min(t * per_tile, shard(r)[1] - shard(r)[0])
+               for r in range(world)] for t in range(n_tiles)]
+    return dict(v_lo=v_lo, n=n, n_max=n_max, n_tiles=n_tiles, per_tile=per_tile, tiles=tiles, counts=counts)
+
+
 def result_block_layout(n):
     """Byte offsets of the SoA pieces inside one shard's result block of n variants:
     counts int32[n][4] | odds f64[n] | chisq f64[n] | p f64[n]."""

@@ -125,3 +125,29 @@ def test_pair_row_bands_partition_the_triangle_evenly():
             assert sum(pairs) == V * (V - 1) // 2
             if V >= 16384:
                 assert max(pairs) <= 1.05 * (sum(pairs) / G) + 64 * V
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("V,strong", [(10_000_000, True), (200_001, True), (7, True), (1_000_000, False)])
+def test_tile_plan_covers_every_variant_once(world, V, strong):
+    """bench.py's shard / tile plan: every variant of the cohort lies in exactly one (rank, tile); every rank walks the same
+    number of tiles; no tile exceeds the buffer; the per-rank block sizes every rank computes agree with the ranks' own tiles."""
+    from importlib import import_module
+    sh = import_module("hpg-variant_amd.sharding")
+    row, cap_bytes = 50_016, 126_000_000_000 if V > 1000 else 3 * 50_016
+    plans = [sh.plan_tiles(r, world, V, row, cap_bytes, strong) for r in range(world)]
+    assert len({p["n_tiles"] for p in plans}) == 1 and len({p["per_tile"] for p in plans}) == 1
+    seen = []
+    for r, p in enumerate(plans):
+        assert p["per_tile"] * row <= cap_bytes or p["per_tile"] == 1
+        for t, (lo, hi) in enumerate(p["tiles"]):
+            assert 0 <= lo <= hi <= p["n"] and hi - lo <= p["per_tile"]
+            assert hi - lo == p["counts"][t][r]
+            assert p["counts"][t] == plans[0]["counts"][t]
+            seen.append((p["v_lo"] + lo, p["v_lo"] + hi))
+    seen = sorted(x for x in seen if x[1] > x[0])
+    total = V if strong else V * world
+    assert seen[0][0] == 0 and seen[-1][1] == total
+    assert all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
+    if V == 10_000_000:                                   # the metric cohort: 4 / 2 / 1 / 1 tiles of <= 126 GB at 1 / 2 / 4 / 8 ranks
+        assert plans[0]["n_tiles"] == {1: 4, 2: 2, 3: 2, 4: 1, 8: 1}[world]
