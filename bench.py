@@ -258,9 +258,13 @@ def worker(args):
     head, res_bytes = RESULT[kind]
 
     # ---- tiles of the shard (strong: rank g scans [g*V/G, (g+1)*V/G); weak: one shard of V_all per rank) -----------------
-    plan = sharding.plan_tiles(rank, world, V_all, pitch, int(args.tile_gb * 1e9), strong=(scaling == "strong"))
-    v_lo, V, n_tiles, per_tile, tiles = plan["v_lo"], plan["n"], plan["n_tiles"], plan["per_tile"], plan["tiles"]
     free_b, total_b = torch.cuda.mem_get_info(dev)
+    avail = torch.tensor([free_b], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+    if world > 1:                                                    # every rank plans with the tightest rank's memory
+        dist.all_reduce(avail, op=dist.ReduceOp.MIN)
+    tile_bytes = min(int(args.tile_gb * 1e9), int(0.9 * (int(avail.item()) - (8 << 30))))     # a tile buffer must fit whatever the part
+    plan = sharding.plan_tiles(rank, world, V_all, pitch, max(tile_bytes, pitch), strong=(scaling == "strong"))
+    v_lo, V, n_tiles, per_tile, tiles = plan["v_lo"], plan["n"], plan["n_tiles"], plan["per_tile"], plan["tiles"]
     res_need = 2 * res_bytes * per_tile * n_tiles * (1 + (world if rank == 0 and world > 1 else 0))
     resident = args.resident == "auto" and (V * pitch + res_need + (6 << 30) <= free_b)
     if world > 1:                                                    # every rank takes the same path
@@ -425,7 +429,7 @@ def worker(args):
             sources.append((blocks[g_last][-1], v_lo + tiles[-1][0], tiles[-1][1] - tiles[-1][0]))
         if world > 1:
             r = world - 1
-            r_lo = sharding.plan_tiles(r, world, V_all, pitch, int(args.tile_gb * 1e9), strong=(scaling == "strong"))["v_lo"]
+            r_lo = sharding.plan_tiles(r, world, V_all, pitch, max(tile_bytes, pitch), strong=(scaling == "strong"))["v_lo"]
             nb = tile_sizes(n_tiles - 1)[r] // res_bytes
             if nb > 0:
                 sources.append((recv[g_last][n_tiles - 1][r], r_lo + (n_tiles - 1) * per_tile, nb))
