@@ -11,9 +11,12 @@ HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -
 UNITS   := $(wildcard $(CSRC)/*.hip)
 OBJS    := $(patsubst $(CSRC)/%.hip,$(LIBDIR)/obj/%.o,$(UNITS))
 
+# the bgzip decoder's wave-per-block kernel branches on wave-uniform values only: keep its control flow as written
+$(LIBDIR)/obj/hpgv_inflate_capi.o: UNITFLAGS := -mllvm -structurizecfg-skip-uniform-regions
+
 $(LIBDIR)/obj/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/hpgv.h
 	@mkdir -p $(LIBDIR)/obj
-	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+	$(HIPCC) $(HIPFLAGS) $(UNITFLAGS) -c -o $@ $<
 
 $(LIBDIR)/libhpgv.so: $(OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS)

@@ -13,6 +13,9 @@ HOSTLIB = os.path.join(LIBDIR, "libhpgv_host.so")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-Wall", "-Wextra", "-Wno-unused-function"]
+# per translation unit: the bgzip decoder's wave-per-block kernel branches on wave-uniform values only; this keeps its
+# control flow as written (scalar branches) instead of structurizing it
+UNIT_FLAGS = {"hpgv_inflate_capi.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions"]}
 
 
 def _hipcc():
@@ -50,7 +53,7 @@ def build_device_lib(force=False, verbose=False):
             txt = open(h).read()
             deps.update(x for x in hdrs if os.path.basename(x) in txt)
         if force or _stale(o, [u] + sorted(deps)):
-            cmd = [_hipcc()] + flags + ["-c", "-o", o, u]
+            cmd = [_hipcc()] + flags + UNIT_FLAGS.get(os.path.basename(u), []) + ["-c", "-o", o, u]
             if verbose:
                 print(" ".join(cmd))
             jobs.append((cmd, subprocess.Popen(cmd)))

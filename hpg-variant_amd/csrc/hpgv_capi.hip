@@ -6,7 +6,6 @@
 #include <cstdlib>
 #include "hpgv_text_kernels.h"
 #include "hpgv_text2_kernels.h"
-#include "hpgv_inflate_kernels.h"
 #include "hpgv_batch_kernels.h"
 
 namespace {
@@ -207,6 +206,7 @@ int hpgv_create(int device_id, hpgv_ctx **out) {
         (void)hipGetLastError();
     }
     if (const char *bf = getenv("HPGV_BATCH_FUSED")) ctx->batch_fused = atoi(bf) ? 1 : 0;      // diagnosis: 0 = the kernel chains
+    if (const char *iw = getenv("HPGV_INFLATE_WAVE")) ctx->inflate_wave = atoi(iw) < 0 ? 0 : atoi(iw) > 2 ? 2 : atoi(iw);   // diagnosis: 0 = lane per block, 2 = wave per block, 1 = by size
     if (const char *tt = getenv("HPGV_TOKENIZER_TILES")) ctx->tokenizer_tiles = atoi(tt) ? 1 : 0;   // diagnosis: 0 = the three-sweep tokenizer
     e = hipMalloc(&ctx->d_sink, 256);
     if (e != hipSuccess) {
@@ -255,6 +255,17 @@ int hpgv_member_device(const hpgv_ctx *ctx, int i) {
     return (i >= 0 && i < (int)ctx->members.size()) ? ctx->members[(size_t)i]->device : -1;
 }
 
+}  // extern "C"
+namespace {
+void grow_release(hpgv_ctx::GrowRange &r) {
+    size_t off = 0;
+    for (size_t i = 0; i < r.pieces.size(); ++i) { (void)hipMemUnmap(r.base + off, r.sizes[i]); (void)hipMemRelease(r.pieces[i]); off += r.sizes[i]; }
+    if (r.base) (void)hipMemAddressFree(r.base, r.reserved);
+    r = hpgv_ctx::GrowRange();
+}
+}  // namespace
+extern "C" {
+
 void hpgv_destroy(hpgv_ctx *ctx) {
     if (!ctx) return;
     if (is_group(ctx)) {
@@ -280,6 +291,8 @@ void hpgv_destroy(hpgv_ctx *ctx) {
         delete t;
     }
     ctx->tok_scratch.clear();
+    for (auto &r : ctx->grow) grow_release(r);
+    ctx->grow.clear();
     hpgv_epi_release(ctx->epi);
     for (Slot *s : ctx->slots) {
         for (int i = 0; i < 8; ++i) if (s->buf[i]) (void)hipFree(s->buf[i]);
@@ -327,6 +340,9 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
     } else if (!strcmp(key, "scan_lds")) {
         if (value < 0 || value > 160 * 1024) return fail(ctx, HPGV_ERR_INVALID, "scan_lds must be in [0, 163840]");
         ctx->scan_lds = value;
+    } else if (!strcmp(key, "inflate_wave")) {
+        if (value < 0 || value > 2) return fail(ctx, HPGV_ERR_INVALID, "inflate_wave must be 0 (lane per block), 1 (by the number of blocks) or 2 (wave per block)");
+        ctx->inflate_wave = value;
     } else if (!strcmp(key, "tokenizer_tiles")) {
         ctx->tokenizer_tiles = value ? 1 : 0;
     } else if (!strcmp(key, "fisher_width")) {
@@ -574,6 +590,72 @@ int hpgv_dev_free(hpgv_ctx *ctx, void *dptr) {
     DeviceGuard g(ctx->device);
     if (dptr) HIPCHK(ctx, hipFree(dptr));
     return HPGV_OK;
+}
+// Device memory that grows in place: an address range is reserved (costs nothing), and backed piece by piece as the caller
+// learns how much it needs -- a bgzip file's text, whose size is only known when its last block header has been seen.  The
+// range behaves like any device pointer (kernels, copies).  HPGV_ERR_UNSUPPORTED when the device has no virtual memory management.
+int hpgv_dev_reserve(hpgv_ctx *ctx, size_t max_bytes, void **dptr) {
+    HPGV_ABI_TRY
+    ctx = first_member(ctx);
+    if (!ctx || !dptr || !max_bytes) return HPGV_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    int vmm = 0;
+    if (hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, ctx->device) != hipSuccess || !vmm)
+        return fail(ctx, HPGV_ERR_UNSUPPORTED, "the device has no virtual memory management");
+    const size_t gran = (size_t)2 << 20;
+    hpgv_ctx::GrowRange r;
+    r.reserved = (max_bytes + gran - 1) / gran * gran;
+    void *p = nullptr;
+    HIPCHK(ctx, hipMemAddressReserve(&p, r.reserved, gran, nullptr, 0));
+    r.base = (char *)p;
+    { std::lock_guard<std::mutex> lk(ctx->mu); ctx->grow.push_back(r); }
+    *dptr = p;
+    return HPGV_OK;
+    HPGV_ABI_CATCH(ctx)
+}
+// makes the range's first `bytes` bytes usable (a no-op when they are already); what is backed stays backed
+int hpgv_dev_commit(hpgv_ctx *ctx, void *dptr, size_t bytes) {
+    HPGV_ABI_TRY
+    ctx = first_member(ctx);
+    if (!ctx || !dptr) return HPGV_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (auto &r : ctx->grow) {
+        if (r.base != (char *)dptr) continue;
+        if (bytes <= r.committed) return HPGV_OK;
+        if (bytes > r.reserved) return fail(ctx, HPGV_ERR_INVALID, "commit of %zu bytes in a range of %zu", bytes, r.reserved);
+        const size_t gran = (size_t)64 << 20;
+        size_t add = (bytes - r.committed + gran - 1) / gran * gran;
+        if (r.committed + add > r.reserved) add = r.reserved - r.committed;
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = ctx->device;
+        hipMemGenericAllocationHandle_t h;
+        HIPCHK(ctx, hipMemCreate(&h, add, &prop, 0));
+        hipError_t e = hipMemMap(r.base + r.committed, add, 0, h, 0);
+        if (e == hipSuccess) {
+            hipMemAccessDesc acc = {};
+            acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+            e = hipMemSetAccess(r.base + r.committed, add, &acc, 1);
+            if (e != hipSuccess) (void)hipMemUnmap(r.base + r.committed, add);
+        }
+        if (e != hipSuccess) { (void)hipMemRelease(h); return fail(ctx, HPGV_ERR_NOMEM, "mapping %zu bytes: %s", add, hipGetErrorString(e)); }
+        r.pieces.push_back(h); r.sizes.push_back(add); r.committed += add;
+        return HPGV_OK;
+    }
+    return fail(ctx, HPGV_ERR_INVALID, "not a range of hpgv_dev_reserve");
+    HPGV_ABI_CATCH(ctx)
+}
+int hpgv_dev_release(hpgv_ctx *ctx, void *dptr) {
+    HPGV_ABI_TRY
+    ctx = first_member(ctx);
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!dptr) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (size_t i = 0; i < ctx->grow.size(); ++i)
+        if (ctx->grow[i].base == (char *)dptr) { grow_release(ctx->grow[i]); ctx->grow.erase(ctx->grow.begin() + (long)i); return HPGV_OK; }
+    return fail(ctx, HPGV_ERR_INVALID, "not a range of hpgv_dev_reserve");
+    HPGV_ABI_CATCH(ctx)
 }
 // NUMA node the device hangs off (sysfs numa_node of its PCI function), -1 when the system does not say: a host that
 // stages batches for the device does best with its staging threads and page-locked buffers on that node
@@ -1509,23 +1591,7 @@ int hpgv_mendel(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants, 
 
 /* ---- text staging ------------------------------------------------------------ */
 
-// raw-DEFLATE blocks (the payloads of BGZF blocks) -> text, all on the device: block b occupies d_comp[in_off[b] .. +in_len[b])
-// and decodes to exactly out_len[b] bytes at d_text + out_off[b]; d_status[b] = 0, or a non-zero code for a block this decoder
-// does not take (the host then decodes that block).  One lane per block: pass many thousands of blocks per call.
-int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
-                            const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, uint8_t *d_text,
-                            int32_t *d_status, void *stream) {
-    ctx = first_member(ctx);
-    if (!ctx) return HPGV_ERR_INVALID;
-    if (n_blocks < 0 || (n_blocks > 0 && (!d_comp || !d_in_off || !d_in_len || !d_out_off || !d_out_len || !d_text || !d_status)))
-        return fail(ctx, HPGV_ERR_INVALID, "bad inflate arguments");
-    if (n_blocks == 0) return HPGV_OK;
-    DeviceGuard g(ctx->device);
-    hipLaunchKernelGGL(hpgv::k_inflate_blocks, dim3((unsigned)((n_blocks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
-                       d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
-    HIPCHK(ctx, hipGetLastError());
-    return HPGV_OK;
-}
+// (hpgv_inflate_blocks_dev: hpgv_inflate_capi.hip)
 
 int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int n_samples, int strict,
                       int max_lines, int *d_n_lines, uint64_t *d_line_off, uint32_t *d_field_off,

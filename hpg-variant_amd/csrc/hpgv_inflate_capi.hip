@@ -1,0 +1,80 @@
+// hpgv_inflate_capi.hip -- C ABI of the bgzip decoder (its own translation unit of libhpgv.so: the wave-per-block kernel has
+// wave-uniform branches only and is compiled with -mllvm -structurizecfg-skip-uniform-regions, which leaves them as written).
+#include "hpgv_internal.h"
+#include "hpgv_inflate_kernels.h"
+#include "hpgv_inflate2_kernels.h"
+#include "hpgv_bgzf_kernels.h"
+
+extern "C" {
+
+// raw-DEFLATE blocks (the payloads of BGZF blocks) -> text, all on the device: block b occupies d_comp[in_off[b] .. +in_len[b])
+// and decodes to exactly out_len[b] bytes at d_text + out_off[b]; d_status[b] = 0, or a non-zero code for a block this decoder
+// does not take (the host then decodes that block).  Option inflate_wave: 2 = one wave per block, 0 = one lane per block
+// (wants a hundred thousand blocks per call), 1 (default) = by the number of blocks.
+int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                            const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, uint8_t *d_text,
+                            int32_t *d_status, void *stream) {
+    ctx = first_member(ctx);
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (n_blocks < 0 || (n_blocks > 0 && (!d_comp || !d_in_off || !d_in_len || !d_out_off || !d_out_len || !d_text || !d_status)))
+        return fail(ctx, HPGV_ERR_INVALID, "bad inflate arguments");
+    if (n_blocks == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    // one wave per block decodes a block in a millisecond or two whatever the number of blocks; one lane per block needs 38 ms
+    // for a launch of any size and is the faster one only when a launch holds a hundred thousand blocks or more
+    const bool wave = ctx->inflate_wave == 2 || (ctx->inflate_wave == 1 && n_blocks < 100000);
+    if (wave)
+        hipLaunchKernelGGL(hpgv::k_inflate_wave, dim3((unsigned)n_blocks), dim3(64), 0, (hipStream_t)stream,
+                           d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
+    else
+        hipLaunchKernelGGL(hpgv::k_inflate_blocks, dim3((unsigned)((n_blocks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                           d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
+    HIPCHK(ctx, hipGetLastError());
+    return HPGV_OK;
+}
+
+// The block table of a bgzip file from its compressed bytes on the device: the blocks that form a chain from byte `lo`
+// (a block start) and end at or before `hi` (bytes [0, hi) are there), at most max_rows of them, as rows of the decoder's
+// tables (d_in_off .. d_out_len, index 0 on; out_off counts from text_base).  result[0] = rows, [1] = where the chain
+// stands now (the next call's lo), [2] = text_base + the rows' text bytes, [3] = headers seen in the range.  Zero rows with
+// bytes to spare means the file's headers are not the ones bgzip writes: walk it on the host.  The call returns when the
+// result is there; d_scratch holds hpgv_bgzf_scan_scratch_bytes(hi - lo, max_rows) bytes.
+size_t hpgv_bgzf_scan_scratch_bytes(uint64_t range_bytes, int max_rows) {
+    const size_t tiles = (size_t)((range_bytes + 15 + hpgv::BGZF_TILE - 1) / hpgv::BGZF_TILE) + 1;
+    return 64 + ((tiles * 4 + 63) & ~(size_t)63) + ((size_t)(max_rows > 0 ? max_rows : 0) + 64) * sizeof(hpgv::BgzfHit);
+}
+int hpgv_bgzf_scan_dev(hpgv_ctx *ctx, const uint8_t *d_comp, uint64_t lo, uint64_t hi, uint64_t text_base, int max_rows,
+                       uint64_t *d_in_off, uint32_t *d_in_len, uint64_t *d_out_off, uint32_t *d_out_len,
+                       void *d_scratch, size_t scratch_bytes, uint64_t *result, void *stream) {
+    HPGV_ABI_TRY
+    ctx = first_member(ctx);
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (!d_comp || hi < lo || max_rows <= 0 || !d_in_off || !d_in_len || !d_out_off || !d_out_len || !d_scratch || !result ||
+        scratch_bytes < hpgv_bgzf_scan_scratch_bytes(hi - lo, max_rows) || hi - lo > ((uint64_t)1 << 40))
+        return fail(ctx, HPGV_ERR_INVALID, "bad block scan arguments");
+    DeviceGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t base = lo & ~(uint64_t)15;
+    const int n_tiles = (int)((hi - base + hpgv::BGZF_TILE - 1) / hpgv::BGZF_TILE);
+    uint64_t *d_result = (uint64_t *)d_scratch;                     // 4 x u64, then the total, then the tiles, then the hits
+    uint32_t *d_total = (uint32_t *)((char *)d_scratch + 32), *d_tiles = (uint32_t *)((char *)d_scratch + 64);
+    const size_t tiles_bytes = (((size_t)n_tiles + 1) * 4 + 63) & ~(size_t)63;
+    hpgv::BgzfHit *d_hit = (hpgv::BgzfHit *)((char *)d_scratch + 64 + tiles_bytes);
+    const uint32_t cap = (uint32_t)max_rows + 64;
+    if (n_tiles > 0) {
+        hipLaunchKernelGGL(hpgv::k_bgzf_count, dim3((unsigned)n_tiles), dim3(hpgv::BGZF_TPB), 0, st, d_comp, base, lo, hi, d_tiles);
+        hipLaunchKernelGGL(hpgv::k_bgzf_scan, dim3(1), dim3(1024), 0, st, d_tiles, n_tiles, d_total);
+        hipLaunchKernelGGL(hpgv::k_bgzf_list, dim3((unsigned)n_tiles), dim3(hpgv::BGZF_TPB), 0, st, d_comp, base, lo, hi, (const uint32_t *)d_tiles, d_hit, cap);
+    } else {
+        HIPCHK(ctx, hipMemsetAsync(d_total, 0, 4, st));
+    }
+    hipLaunchKernelGGL(hpgv::k_bgzf_chain, dim3(1), dim3(1024), 0, st, (const hpgv::BgzfHit *)d_hit, (const uint32_t *)d_total, cap, lo, text_base,
+                       (uint32_t)max_rows, d_in_off, d_in_len, d_out_off, d_out_len, d_result);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(result, d_result, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return HPGV_OK;
+    HPGV_ABI_CATCH(ctx)
+}
+
+}  // extern "C"

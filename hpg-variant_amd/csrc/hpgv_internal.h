@@ -93,6 +93,7 @@ struct hpgv_ctx {
     long epi_triples_1pass = 1; // epistasis triple ranking with at most 10 folds: one pass, all folds' counts in registers (one wave per SIMD)
     long scan_lds = 0;         // bytes of (unused) LDS per workgroup of the stats / tdt scans: caps the waves in flight per CU
     long fisher_width = 16;    // lanes per variant in the Fisher p-pass (64, 32, 16 or 8): 64 / width variants per wave
+    long inflate_wave = 1;     // bgzip decoder: 2 = one wave per block (hpgv_inflate2_kernels.h), 0 = one lane per block, 1 = by the number of blocks
     long tokenizer_tiles = 1;  // VCF text tokenizer: 1 = tile-parallel, two sweeps (hpgv_text2_kernels.h); 0 = count / mark / parse per line
     long batch_fused = 1;      // per-batch host entry points: one fused kernel per call (0: copy + layout + scan + statistics kernels)
     long batch_lds_max = 65536;   // largest raw-row window the fused kernel stages in LDS (raised at hpgv_create when the device allows)
@@ -138,6 +139,9 @@ struct hpgv_ctx {
     };
     std::mutex tok_mu;
     std::vector<TokScratch *> tok_scratch;
+    // address ranges whose backing grows (hpgv_dev_reserve / hpgv_dev_commit), under mu
+    struct GrowRange { char *base = nullptr; size_t reserved = 0, committed = 0; std::vector<hipMemGenericAllocationHandle_t> pieces; std::vector<size_t> sizes; };
+    std::vector<GrowRange> grow;
     // record filters of the text entry points (hpgv_set_text_filters); negative = off
     double filt_min_maf = -1.0, filt_max_missing = -1.0;
     long filt_max_mendel = -1;

@@ -2073,17 +2073,22 @@ static void *bgzf_gpu_stager(void *v) {
     int32_t *st = (int32_t *)malloc(sizeof(int32_t) * 4 * GPU_STRETCH);
     unsigned char *tmp = (unsigned char *)malloc(65536);
     ok = ok && st && tmp;
-    /* a launch takes the time one lane needs for its block (~40 ms) whatever the number of blocks, so the stretches
-     * decode side by side: up to GPU_INFLIGHT launches on streams of their own, published in file order */
+    /* The decoder gives a block to a wave when a launch holds fewer than 100 000 blocks -- a block then takes a
+     * millisecond or two -- and to a lane otherwise: such a launch takes the time one lane needs for its block (~40 ms)
+     * whatever the number of blocks, but decodes more text per second once it holds a hundred thousand of them (under
+     * the batches' kernels: 130 GB/s against 90).  So: a short first stretch (wave per block, 2 ms), which the header
+     * reader and the pipeline wait for, then stretches that double up to 131 072 blocks, decoding side by side, up to
+     * GPU_INFLIGHT launches on streams of their own.  Published in file order. */
     enum { GPU_INFLIGHT = 4, GPU_FIRST = 4096 };
+    const int inflight = GPU_INFLIGHT;
     void *cs[GPU_INFLIGHT] = { s->cstream, NULL, NULL, NULL };
-    for (int q = 1; ok && q < GPU_INFLIGHT; q++) ok = hpgv_stream_create(g_ctx, &cs[q]) == HPGV_OK;
+    for (int q = 1; ok && q < inflight; q++) ok = hpgv_stream_create(g_ctx, &cs[q]) == HPGV_OK;
     size_t q_hi[GPU_INFLIGHT];                           /* the stretches in flight end at these blocks; the oldest starts at g_done */
     int qh = 0, qn = 0;
     const int dbg = getenv("HPGV_RUN_TRACE") != NULL; const double T0 = now_s();
     size_t up_hi = 0;                                    /* compressed bytes [0, up_hi) are on the device */
     for (size_t first = 0; ok && (first < nb || qn > 0);) {
-        if (first < nb && qn < GPU_INFLIGHT) {           /* upload the next stretch while the earlier ones decode */
+        if (first < nb && qn < inflight) {               /* upload the next stretch while the earlier ones decode */
             /* a short first stretch, which the header reader waits for, then 32 768 blocks doubling up to four times that */
             const size_t stretch = first == 0 ? (nb <= 3 * (size_t)GPU_FIRST ? nb : GPU_FIRST)      /* a small file: one launch */
                                  : first < GPU_FIRST + (size_t)GPU_STRETCH ? GPU_STRETCH
@@ -2096,7 +2101,7 @@ static void *bgzf_gpu_stager(void *v) {
                 up_hi = hi;
                 if (dbg) fprintf(stderr, "stager: [%zu,%zu) is up, to byte %.1f MB, at %.4f\n", first, next, hi / 1e6, now_s() - T0);
             }
-            const int q = (qh + qn) % GPU_INFLIGHT;
+            const int q = (qh + qn) % inflight;
             ok = ok && hpgv_inflate_blocks_dev(g_ctx, (const uint8_t *)s->d_comp, (const uint64_t *)t + first, (const uint32_t *)(t + nb * 16) + first,
                                                (const uint64_t *)(t + nb * 8) + first, (const uint32_t *)(t + nb * 20) + first, (int)(next - first),
                                                (uint8_t *)s->d_text, (int32_t *)s->d_status + first, cs[q]) == HPGV_OK;
@@ -2107,7 +2112,7 @@ static void *bgzf_gpu_stager(void *v) {
                 first = next;
             } else {
                 first = next;
-                if (first < nb && qn < GPU_INFLIGHT) continue;
+                if (first < nb && qn < inflight) continue;
             }
         }
         if (ok && qn > 0) {                              /* the oldest stretch in flight: wait, check, publish */
@@ -2129,7 +2134,7 @@ static void *bgzf_gpu_stager(void *v) {
                 pthread_cond_broadcast(&s->g_cv);
                 pthread_mutex_unlock(&s->g_mu);
             }
-            qh = (qh + 1) % GPU_INFLIGHT; qn--;
+            qh = (qh + 1) % inflight; qn--;
         }
     }
     for (int q = 0; q < GPU_INFLIGHT; q++) if (cs[q]) (void)hpgv_stream_sync(g_ctx, cs[q]);      /* after a failure launches may still be running */

@@ -131,6 +131,12 @@ int  hpgv_mendel_layout(const hpgv_ctx *ctx, size_t *pitch);
  *      another runtime, e.g. a torch tensor's data_ptr) ---------------------- */
 int  hpgv_dev_alloc(hpgv_ctx *ctx, size_t bytes, void **dptr);
 int  hpgv_dev_free(hpgv_ctx *ctx, void *dptr);
+/* device memory that grows in place: reserve an address range of max_bytes (costs no memory), make its first `bytes` bytes
+ * usable with hpgv_dev_commit (what is backed stays backed; pieces of 64 MB), give everything back with hpgv_dev_release.
+ * For a text whose size is known only when its last block has been seen.  HPGV_ERR_UNSUPPORTED: no virtual memory management. */
+int  hpgv_dev_reserve(hpgv_ctx *ctx, size_t max_bytes, void **dptr);
+int  hpgv_dev_commit(hpgv_ctx *ctx, void *dptr, size_t bytes);
+int  hpgv_dev_release(hpgv_ctx *ctx, void *dptr);
 int  hpgv_memcpy_h2d(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream);
 int  hpgv_memcpy_d2h(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream);
 int  hpgv_stream_sync(hpgv_ctx *ctx, void *stream);   /* stream NULL = default stream */
@@ -361,6 +367,17 @@ int  hpgv_text_alias(hpgv_ctx *ctx, const char *host_text, const char *d_text);
 int  hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
                              const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, uint8_t *d_text,
                              int32_t *d_status, void *stream);
+/* The rows of those tables from the compressed bytes of a bgzip file on the device (bgzf.c of htslib writes the blocks the
+ * reference reads with --compression bgzip, shared_options.c:60-61): the blocks that form a chain from byte `lo` (a block
+ * start; 0 at first) and end at or before `hi` (bytes [0, hi) are on the device), at most max_rows of them, written from
+ * index 0 on; out_off counts from text_base.  result[0] = rows, [1] = where the chain stands (the next call's lo),
+ * [2] = text_base + the text bytes of the rows, [3] = block headers seen in [lo, hi).  No rows although a whole block lies
+ * in the range: the file's headers are not the ones bgzip writes, and the caller walks it itself.  Returns when `result`
+ * is filled.  d_scratch: hpgv_bgzf_scan_scratch_bytes(hi - lo, max_rows) bytes of device memory. */
+size_t hpgv_bgzf_scan_scratch_bytes(uint64_t range_bytes, int max_rows);
+int  hpgv_bgzf_scan_dev(hpgv_ctx *ctx, const uint8_t *d_comp, uint64_t lo, uint64_t hi, uint64_t text_base, int max_rows,
+                        uint64_t *d_in_off, uint32_t *d_in_len, uint64_t *d_out_off, uint32_t *d_out_len,
+                        void *d_scratch, size_t scratch_bytes, uint64_t *result, void *stream);
 
 /* ---- VCF text -> HPGV8 on the GPU (replaces the per-genotype
  *      strdup + get_alleles of assoc.c:45-56 / tdt.c:97-108,150-157) ------------------

@@ -187,10 +187,11 @@ def test_text_entry_point_from_concurrent_threads(eng):
     assert not errors, errors
 
 
-def test_inflate_blocks_on_the_gpu_against_zlib():
+@pytest.mark.parametrize("wave", [2, 0], ids=["wave_per_block", "lane_per_block"])
+def test_inflate_blocks_on_the_gpu_against_zlib(wave):
     # hpgv_inflate_blocks_dev: raw-DEFLATE payloads (as in BGZF blocks) of genotype text, incompressible bytes (stored
-    # blocks), runs, every zlib strategy incl. fixed codes, sizes 0 .. 65 280 -- one lane per block; a damaged block gets a
-    # non-zero status and leaves the others alone
+    # blocks), runs, every zlib strategy incl. fixed codes, sizes 0 .. 65 280 -- one wave per block (the default) and one
+    # lane per block; a damaged block gets a non-zero status and leaves the others alone
     import zlib
     rng = np.random.default_rng(11)
     codes = np.array(["0/0", "0/1", "1/1", "./.", "0|1"])
@@ -214,10 +215,12 @@ def test_inflate_blocks_on_the_gpu_against_zlib():
     cbytes = np.frombuffer(b"".join(comp) + b"\0" * 16, np.uint8)
     total = int(out_len.sum())
     e = hpgv.Engine(0)
+    e.set_option("inflate_wave", wave)
     d_comp, d_text = e.alloc(len(cbytes)), e.alloc(total + 16)
     d_io, d_il, d_oo, d_ol, d_st = e.alloc(8 * n), e.alloc(4 * n), e.alloc(8 * n), e.alloc(4 * n), e.alloc(4 * n)
     for d, a in ((d_comp, cbytes), (d_io, in_off), (d_il, in_len), (d_oo, out_off), (d_ol, out_len)):
         e.h2d(d, a)
+    e.h2d(d_text, np.full(total + 16, 0x5A, np.uint8))
     e.inflate_blocks(d_comp, d_io, d_il, d_oo, d_ol, n, d_text, d_st)
     e.sync()
     status = e.d2h(d_st, (n,), np.int32)
@@ -228,4 +231,88 @@ def test_inflate_blocks_on_the_gpu_against_zlib():
             continue
         assert status[k] == 0, (k, int(status[k]), len(raw[k]))
         assert text[int(out_off[k]): int(out_off[k]) + len(raw[k])] == raw[k], k
+    e.close()
+
+
+def _bgzf_bytes(payloads, raws):
+    """BGZF blocks as bgzip writes them (18-byte header with the BC field, CRC32, ISIZE) around raw-DEFLATE payloads."""
+    import struct
+    import zlib
+    out, rows, pos = [], [], 0
+    for c, r in zip(payloads, raws):
+        bsize = 18 + len(c) + 8
+        out.append(struct.pack("<4BI2BH2BHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, bsize - 1) + c + struct.pack("<II", zlib.crc32(r), len(r)))
+        rows.append((pos + 18, len(c), len(r)))
+        pos += bsize
+    return b"".join(out), rows
+
+
+def test_bgzf_block_table_from_the_device_copy():
+    # hpgv_bgzf_scan_dev: the chain of bgzip blocks found in the compressed bytes on the device, piece by piece as a file
+    # arrives, against the rows a host walk gives; a header's 16 fixed bytes planted inside a block's data must not join
+    import zlib
+    rng = np.random.default_rng(5)
+    codes = np.array(["0/0", "0/1", "1/1", "./."])
+    raws, comps = [], []
+    for k in range(700):
+        n = int(rng.choice([0, 1, 40, 700, 5000, 65280, 65280, 30000]))
+        txt = ("\t".join(codes[rng.choice(4, size=n // 4 + 1, p=[0.6, 0.25, 0.14, 0.01])]) + "\n").encode()[:n]
+        if k % 97 == 5:                                                    # incompressible, and a whole fake block inside it
+            fake = bytes([31, 139, 8, 4, 1, 2, 3, 4, 0, 255, 6, 0, 66, 67, 2, 0, 40, 0]) + bytes(19) + bytes([5, 0, 0, 0])
+            txt = (bytes(rng.integers(0, 256, 3000, dtype=np.uint8)) + fake + bytes(rng.integers(0, 256, 3000, dtype=np.uint8)))
+            co = zlib.compressobj(0, zlib.DEFLATED, -15)
+        else:
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        raws.append(txt); comps.append(co.compress(txt) + co.flush())
+    data, rows = _bgzf_bytes(comps, raws)
+    size = len(data)
+    e = hpgv.Engine(0)
+    d_comp = e.alloc(size + 16)
+    e.h2d(d_comp, np.frombuffer(data + b"\0" * 16, np.uint8))
+    cap = 256
+    d_io, d_il, d_oo, d_ol = e.alloc(8 * cap), e.alloc(4 * cap), e.alloc(8 * cap), e.alloc(4 * cap)
+    got, lo, text, hi, calls, fakes = [], 0, 0, 0, 0, 0
+    step = size // 7 + 1
+    while lo < size:
+        hi = min(size, hi + step)                                          # the file arrives in seven pieces
+        while True:
+            n, lo2, text2, hits = e.bgzf_scan(d_comp, lo, hi, text, cap, d_io, d_il, d_oo, d_ol)
+            calls += 1
+            io = e.d2h(d_io, (cap,), np.uint64)[:n]; il = e.d2h(d_il, (cap,), np.uint32)[:n]
+            oo = e.d2h(d_oo, (cap,), np.uint64)[:n]; ol = e.d2h(d_ol, (cap,), np.uint32)[:n]
+            for a, b, c, d in zip(io, il, oo, ol):
+                got.append((int(a), int(b), int(d)))
+                assert int(c) == text
+                text += int(d)
+            assert text == text2 and lo2 >= lo and (n > 0) == (lo2 > lo)
+            fakes += 1 if 0 < n < min(cap, hits) else 0                     # the chain stopped before the range's hits ran out
+            lo = lo2
+            if n == 0:
+                break
+        assert calls < 200
+    assert got == rows, (len(got), len(rows))
+    assert fakes >= 7                                                       # every planted header was seen, and left out
+    # a file whose first block carries another extra field: no chain, the caller walks it itself
+    odd = bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 12, 0]) + b"XY\x02\x00zz" + data[12:]
+    e.h2d(d_comp, np.frombuffer(odd[:size] + b"\0" * 16, np.uint8))
+    assert e.bgzf_scan(d_comp, 0, size, 0, cap, d_io, d_il, d_oo, d_ol)[0] == 0
+    e.close()
+
+
+def test_device_memory_that_grows_in_place():
+    # hpgv_dev_reserve / hpgv_dev_commit / hpgv_dev_release: what is written stays where it is while the range grows
+    e = hpgv.Engine(0)
+    p = e.dev_reserve(3 << 30)
+    e.dev_commit(p, 100 << 20)
+    a = np.arange(1 << 20, dtype=np.uint32)
+    at = (128 << 20) - (2 << 20)                                            # straddles the end of the first 128 MB
+    e.dev_commit(p, 200 << 20)
+    e.h2d(p.value + at, a)
+    e.dev_commit(p, 1 << 30)
+    assert np.array_equal(e.d2h(p.value + at, a.shape, np.uint32), a)
+    e.h2d(p.value + (1 << 30) - a.nbytes, a)
+    assert np.array_equal(e.d2h(p.value + (1 << 30) - a.nbytes, a.shape, np.uint32), a)
+    with pytest.raises(Exception):
+        e.dev_commit(p, 4 << 30)                                            # more than was reserved
+    e.dev_release(p)
     e.close()

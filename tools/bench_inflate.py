@@ -2,7 +2,7 @@
 """Rate of the GPU raw-DEFLATE decoder (hpgv_inflate_blocks_dev) on BGZF-sized blocks of genotype text: n_blocks payloads of
 65 280 bytes of text each (64 distinct ones, repeated), compressed with zlib at the given level, all decoded in one launch.
 
-  python tools/bench_inflate.py [n_blocks] [level]
+  python tools/bench_inflate.py [n_blocks] [level] [inflate_wave: 2 = one wave per block (default here), 0 = one lane per block, 1 = the library's choice by size]
 """
 import importlib
 import json
@@ -17,6 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 hpgv = importlib.import_module("hpg-variant_amd")
 n_blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 125_000
 level = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+wave = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 rng = np.random.default_rng(0)
 codes = np.array(["0/0", "0/1", "1/1", "./."])
 raw, comp = [], []
@@ -46,6 +47,7 @@ for j in range(64):
 out_off = (np.arange(n_blocks, dtype=np.uint64) * 65280).astype(np.uint64)
 total = n_blocks * 65280
 e = hpgv.Engine(0)
+e.set_option("inflate_wave", wave)
 d_comp, d_text = e.alloc(len(cbytes)), e.alloc(total + 16)
 d_io, d_il, d_oo, d_ol, d_st = e.alloc(8 * n_blocks), e.alloc(4 * n_blocks), e.alloc(8 * n_blocks), e.alloc(4 * n_blocks), e.alloc(4 * n_blocks)
 for d, a in ((d_comp, cbytes), (d_io, in_off), (d_il, in_len), (d_oo, out_off), (d_ol, out_len)):
@@ -59,6 +61,6 @@ status = e.d2h(d_st, (n_blocks,), np.int32)
 chk = e.d2h(d_text.value + (n_blocks - 1) * 65280, (65280,), np.uint8).tobytes()
 ok = bool((status == 0).all()) and chk == raw[int(pick[-1])]
 dt = min(runs)
-print(json.dumps({"blocks": n_blocks, "zlib_level": level, "text_GB": total / 1e9, "compressed_GB": float(in_len.sum()) / 1e9,
+print(json.dumps({"blocks": n_blocks, "zlib_level": level, "decoder": {0: "lane per block", 1: "by size", 2: "wave per block"}[wave], "text_GB": total / 1e9, "compressed_GB": float(in_len.sum()) / 1e9,
                   "seconds": round(dt, 4), "text_GBps": total / dt / 1e9, "compressed_GBps": float(in_len.sum()) / dt / 1e9, "ok": ok}))
 e.close()
