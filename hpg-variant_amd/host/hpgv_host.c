@@ -482,31 +482,64 @@ static void stage_pool_release(void) {                  /* g_ctx still alive */
 }
 
 /* device memory for a decoded file, kept between runs like the page-locked buffers (an 8 GB allocation and its release
- * cost 0.1 s); released by hpgv_host_shutdown */
-static void *g_dev_text; static size_t g_dev_text_cap;
-static void *dev_text_get(size_t bytes) {
+ * cost 0.1 s); released by hpgv_host_shutdown.  Where the device allows it the buffer is a reserved address range that is
+ * backed as far as needed (hpgv_dev_reserve): a bgzip file's text size is known only when its last block has been seen. */
+enum { DEV_TEXT_FIXED = 0, DEV_TEXT_GROWS = 1 };
+#define DEV_TEXT_RESERVE ((size_t)56 << 30)
+static void *g_dev_text; static size_t g_dev_text_cap; static int g_dev_text_kind;
+static void dev_text_free(void *p, int kind) {
+    if (!p) return;
+    if (kind == DEV_TEXT_GROWS) (void)hpgv_dev_release(g_ctx, p); else (void)hpgv_dev_free(g_ctx, p);
+}
+/* a buffer with `bytes` usable bytes (*cap: how many it has); *kind = DEV_TEXT_GROWS when dev_text_grow can extend it */
+static void *dev_text_get(size_t bytes, size_t *cap, int *kind) {
     void *p = NULL;
     pthread_mutex_lock(&g_text_mu);
-    if (g_dev_text && g_dev_text_cap >= bytes) { p = g_dev_text; g_dev_text = NULL; g_dev_text_cap = 0; }
+    if (g_dev_text && (g_dev_text_kind == DEV_TEXT_GROWS || g_dev_text_cap >= bytes)) {
+        p = g_dev_text; *cap = g_dev_text_cap; *kind = g_dev_text_kind;
+        g_dev_text = NULL; g_dev_text_cap = 0;
+    }
     pthread_mutex_unlock(&g_text_mu);
-    if (!p && hpgv_dev_alloc(g_ctx, bytes, &p) != HPGV_OK) p = NULL;
+    if (p) {
+        if (*cap >= bytes) return p;
+        if (bytes <= DEV_TEXT_RESERVE && hpgv_dev_commit(g_ctx, p, bytes) == HPGV_OK) { *cap = bytes; return p; }
+        dev_text_free(p, *kind);
+        p = NULL;
+    }
+    if (bytes <= DEV_TEXT_RESERVE && !getenv("HPGV_NO_GROWING_TEXT") && hpgv_dev_reserve(g_ctx, DEV_TEXT_RESERVE, &p) == HPGV_OK) {
+        if (hpgv_dev_commit(g_ctx, p, bytes) == HPGV_OK) { *cap = bytes; *kind = DEV_TEXT_GROWS; return p; }
+        (void)hpgv_dev_release(g_ctx, p);
+        p = NULL;
+    }
+    if (hpgv_dev_alloc(g_ctx, bytes, &p) != HPGV_OK) return NULL;
+    *cap = bytes; *kind = DEV_TEXT_FIXED;
     return p;
 }
-static void dev_text_put(void *p, size_t bytes) {
+static int dev_text_grow(void *p, size_t bytes, size_t *cap) {
+    if (bytes <= *cap) return 1;
+    if (bytes > DEV_TEXT_RESERVE || hpgv_dev_commit(g_ctx, p, bytes) != HPGV_OK) return 0;
+    *cap = bytes;
+    return 1;
+}
+static void dev_text_put(void *p, size_t bytes, int kind) {
     if (!p) return;
-    void *old = NULL;
+    void *old = NULL; int old_kind = 0;
     pthread_mutex_lock(&g_text_mu);
-    if (!g_dev_text || g_dev_text_cap < bytes) { old = g_dev_text; g_dev_text = p; g_dev_text_cap = bytes; p = NULL; }
+    if (!g_dev_text || g_dev_text_cap < bytes || (kind == DEV_TEXT_GROWS && g_dev_text_kind != DEV_TEXT_GROWS)) {
+        old = g_dev_text; old_kind = g_dev_text_kind;
+        g_dev_text = p; g_dev_text_cap = bytes; g_dev_text_kind = kind;
+        p = NULL;
+    }
     pthread_mutex_unlock(&g_text_mu);
-    if (old) (void)hpgv_dev_free(g_ctx, old);
-    if (p) (void)hpgv_dev_free(g_ctx, p);
+    dev_text_free(old, old_kind);
+    dev_text_free(p, kind);
 }
 
 static void text_cache_release(void) {                  /* g_ctx still alive */
     pthread_mutex_lock(&g_text_mu);
     for (int i = 0; i < TEXT_CACHE_N; i++)
         if (g_text_cache[i].p) { (void)hpgv_host_free(g_ctx, g_text_cache[i].p); g_text_cache[i].p = NULL; g_text_cache[i].cap = 0; }
-    if (g_dev_text) { (void)hpgv_dev_free(g_ctx, g_dev_text); g_dev_text = NULL; g_dev_text_cap = 0; }
+    if (g_dev_text) { dev_text_free(g_dev_text, g_dev_text_kind); g_dev_text = NULL; g_dev_text_cap = 0; }
     pthread_mutex_unlock(&g_text_mu);
 }
 
@@ -1650,7 +1683,9 @@ typedef struct {
     void *d_comp, *d_tab, *d_text, *d_status, *rstream, *cstream; size_t dev_len, dev_pos; int gpu_tried;
     uint64_t *g_in_off, *g_out_off; uint32_t *g_in_len, *g_out_len; size_t g_nb, g_done;      /* the stager's block tables */
     size_t dev_ready;                                   /* text bytes decoded so far (under g_mu) */
-    size_t d_text_cap;
+    size_t d_text_cap; int d_text_kind;
+    int dev_len_known;                                  /* 0 while the stager is still finding the file's blocks (under g_mu) */
+    void *d_scan;                                       /* the streaming stager's tables, statuses and scan scratch */
     pthread_t g_thread; pthread_mutex_t g_mu; pthread_cond_t g_cv; int g_started, g_sync, g_err, g_finished;
     /* the uploader: the compressed file goes up from the moment it is opened, beside the walk of its block headers */
     pthread_t u_thread; int u_started, u_cancel, u_err; size_t up_done;      /* bytes [0, up_done) are on the device (under g_mu) */
@@ -1708,7 +1743,8 @@ static void source_close(source_t *s) {
         if (s->d_comp) (void)hpgv_dev_free(g_ctx, s->d_comp);
         if (s->d_tab) (void)hpgv_dev_free(g_ctx, s->d_tab);
         if (s->d_status) (void)hpgv_dev_free(g_ctx, s->d_status);
-        if (s->d_text) dev_text_put(s->d_text, s->d_text_cap);
+        if (s->d_text) dev_text_put(s->d_text, s->d_text_cap, s->d_text_kind);
+        if (s->d_scan) (void)hpgv_dev_free(g_ctx, s->d_scan);
         if (s->rstream) (void)hpgv_stream_destroy(g_ctx, s->rstream);
         if (s->cstream) (void)hpgv_stream_destroy(g_ctx, s->cstream);
     }
@@ -2292,6 +2328,239 @@ static int bgzf_walk_parallel(int fd, size_t size, uint64_t **in_off, uint64_t *
     return !ok;
 }
 
+/* ---- the streaming form of the device path: the block table comes from the device too ----------------------------------
+ * Walking the 490 000 block headers of a 4.6 GB file on the host takes 0.08 - 0.26 s of dependent reads (beside the
+ * uploader's own reads of the same file) before the first block can be decoded.  Here the stager asks the device for the
+ * blocks in what has been uploaded so far (hpgv_bgzf_scan_dev finds the headers in the compressed bytes and checks that
+ * they form a chain), decodes them, and goes on where the chain stands: the first 4 096 blocks are decoded a few
+ * milliseconds after the file was opened.  The text's size is not known in advance, so the text lies in a range of device
+ * addresses that is backed as the table grows (dev_text_grow); the reader learns the text's end when the stager has seen
+ * the file's last block.  A stretch of the file whose headers are not the ones bgzip writes is walked on the host (through
+ * the mapping).  HPGV_BGZF_HOST_TABLE=1 keeps the table on the host (the form above). */
+enum { SCAN_ROWS_MAX = 131072, SCAN_SLOTS = 4 };
+#define SCAN_RANGE_MAX ((size_t)2 << 30)
+typedef struct {
+    uint64_t *d_in_off, *d_out_off; uint32_t *d_in_len, *d_out_len; int32_t *d_status;       /* device rows of this stretch */
+    uint64_t *h_in_off, *h_out_off; uint32_t *h_in_len, *h_out_len;                          /* and their host copy (for blocks the device refuses) */
+    size_t n, text_end;
+    void *stream;
+} scan_slot_t;
+typedef struct {
+    scan_slot_t slot[SCAN_SLOTS];
+    void *d_scratch; size_t scratch_bytes;
+    size_t chain_pos, text_pos, blocks;                   /* the chain stands at this file offset; text bytes and blocks before it */
+    size_t first_n;                                       /* rows already in slot 0 (found when the path was chosen) */
+    size_t rows_cap;                                      /* tests (HPGV_TEST_SCAN_ROWS): no stretch longer than this */
+    size_t host_rows;                                     /* blocks the next walk on the host may take (doubles while the device finds no chain) */
+} scan_state_t;
+
+/* the uploader's progress: waits until at least `want` bytes are up (or all of the file); returns how many are, 0 on failure */
+static size_t wait_uploaded_some(source_t *s, size_t want) {
+    if (want > (size_t)s->size) want = (size_t)s->size;
+    pthread_mutex_lock(&s->g_mu);
+    while (s->up_done < want && !s->u_err) pthread_cond_wait(&s->g_cv, &s->g_mu);
+    const size_t have = s->u_err ? 0 : s->up_done;
+    pthread_mutex_unlock(&s->g_mu);
+    return have;
+}
+/* rows of the blocks from file offset `pos` on, walked through the mapping (headers the device scan does not know);
+ * returns the number of rows (0: not a block), *end = where the walk stands */
+static size_t bgzf_host_rows(source_t *s, size_t pos, size_t hi, size_t max_rows, size_t text, scan_slot_t *q, size_t *end, size_t *text_end) {
+    size_t n = 0;
+    while (n < max_rows && pos < hi) {
+        size_t bs, co, is;
+        if (!bgzf_block(s->map + pos, (size_t)s->size - pos, &bs, &co, &is) || is > 65536 || pos + bs > hi) break;
+        q->h_in_off[n] = pos + co; q->h_in_len[n] = (uint32_t)(bs - co - 8); q->h_out_off[n] = text; q->h_out_len[n] = (uint32_t)is;
+        text += is; pos += bs; n++;
+    }
+    *end = pos; *text_end = text;
+    return n;
+}
+static int scan_slot_rows_to_host(scan_slot_t *q) {
+    return hpgv_memcpy_d2h(g_ctx, q->h_in_off, q->d_in_off, q->n * 8, q->stream) == HPGV_OK
+        && hpgv_memcpy_d2h(g_ctx, q->h_out_off, q->d_out_off, q->n * 8, q->stream) == HPGV_OK
+        && hpgv_memcpy_d2h(g_ctx, q->h_in_len, q->d_in_len, q->n * 4, q->stream) == HPGV_OK
+        && hpgv_memcpy_d2h(g_ctx, q->h_out_len, q->d_out_len, q->n * 4, q->stream) == HPGV_OK;
+}
+static int scan_slot_rows_to_device(scan_slot_t *q) {
+    return hpgv_memcpy_h2d(g_ctx, q->d_in_off, q->h_in_off, q->n * 8, q->stream) == HPGV_OK
+        && hpgv_memcpy_h2d(g_ctx, q->d_out_off, q->h_out_off, q->n * 8, q->stream) == HPGV_OK
+        && hpgv_memcpy_h2d(g_ctx, q->d_in_len, q->h_in_len, q->n * 4, q->stream) == HPGV_OK
+        && hpgv_memcpy_h2d(g_ctx, q->d_out_len, q->h_out_len, q->n * 4, q->stream) == HPGV_OK;
+}
+/* the next stretch's rows into slot q: up to max_rows blocks from the chain's position among the bytes that are up.
+ * 1 = q->n rows (0 rows: the file has ended), 0 = failure */
+static int scan_next_rows(source_t *s, scan_state_t *S, scan_slot_t *q, size_t max_rows, int dbg, double T0) {
+    q->n = 0; q->text_end = S->text_pos;
+    const size_t avg = S->blocks ? S->chain_pos / S->blocks + 1 : 16384;
+    size_t want = S->chain_pos + max_rows * avg;                      /* bytes that should hold that many blocks */
+    for (;;) {
+        if (S->chain_pos >= (size_t)s->size) return 1;
+        const size_t have = wait_uploaded_some(s, want);
+        if (!have) return 0;
+        size_t hi = have;
+        if (hi - S->chain_pos > SCAN_RANGE_MAX) hi = S->chain_pos + SCAN_RANGE_MAX;
+        uint64_t res[4] = { 0, 0, 0, 0 };
+        if (hpgv_bgzf_scan_dev(g_ctx, (const uint8_t *)s->d_comp, S->chain_pos, hi, S->text_pos, (int)max_rows, q->d_in_off, q->d_in_len,
+                               q->d_out_off, q->d_out_len, S->d_scratch, S->scratch_bytes, res, q->stream) != HPGV_OK) return 0;
+        if (res[0] > 0) {
+            q->n = (size_t)res[0]; q->text_end = (size_t)res[2];
+            if (!scan_slot_rows_to_host(q)) return 0;
+            S->chain_pos = (size_t)res[1]; S->text_pos = q->text_end; S->blocks += q->n; S->host_rows = 64;
+            if (dbg) fprintf(stderr, "stager: %zu blocks found up to byte %.1f MB (%.1f MB are up) at %.4f\n", q->n, S->chain_pos / 1e6, have / 1e6, now_s() - T0);
+            return 1;
+        }
+        /* no block at the chain's position among the bytes that are up: it is not all there yet, or its header is not bgzip's */
+        if (hi < (size_t)s->size && hi - S->chain_pos < ((size_t)1 << 17)) { want = hi + ((size_t)1 << 20); continue; }
+        size_t end = 0, tend = 0;
+        if (S->host_rows < 64) S->host_rows = 64;
+        q->n = bgzf_host_rows(s, S->chain_pos, hi, S->host_rows < max_rows ? S->host_rows : max_rows, S->text_pos, q, &end, &tend);
+        S->host_rows *= 2;                                            /* a few blocks, then the device again; more if it still finds none */
+        if (q->n == 0) {
+            if (hi < (size_t)s->size) { want = hi + ((size_t)1 << 20); continue; }      /* a block that ends beyond what is up */
+            return 0;                                                 /* bytes that are no block */
+        }
+        if (dbg) fprintf(stderr, "stager: %zu blocks walked on the host from byte %zu at %.4f\n", q->n, S->chain_pos, now_s() - T0);
+        q->text_end = tend;
+        if (!scan_slot_rows_to_device(q)) return 0;
+        S->chain_pos = end; S->text_pos = tend; S->blocks += q->n;
+        return 1;
+    }
+}
+
+static void *bgzf_gpu_stream_stager(void *v) {
+    source_t *s = (source_t *)v;
+    scan_state_t *S = (scan_state_t *)s->blk;                        /* (handed over in the field the host path uses for its block list) */
+    s->blk = NULL;
+    const int dbg = getenv("HPGV_RUN_TRACE") != NULL; const double T0 = now_s();
+    int ok = 1;
+    unsigned char *tmp = (unsigned char *)malloc(65536);
+    int32_t *st = (int32_t *)malloc(sizeof(int32_t) * SCAN_ROWS_MAX);
+    ok = tmp && st;
+    const char *fe = getenv("HPGV_TEST_GPU_INFLATE_REFUSE_EVERY");     /* tests: exercise the host patch path */
+    const size_t refuse_every = fe ? (size_t)atol(fe) : 0;
+    int qh = 0, qn = 0, eof = 0;
+    size_t launched = 0, done_blocks = 0;
+    while (ok && (!eof || qn > 0)) {
+        if (!eof && qn < SCAN_SLOTS) {
+            scan_slot_t *q = &S->slot[(qh + qn) % SCAN_SLOTS];
+            /* a short first stretch, which the header reader and the pipeline wait for, then stretches that double */
+            size_t rows = launched == 0 ? 4096 : launched < 4096 + 32768 ? 32768 : launched < 4096 + 3 * 32768 ? 65536 : SCAN_ROWS_MAX;
+            if (S->rows_cap && rows > S->rows_cap) rows = S->rows_cap;
+            if (launched == 0 && S->first_n) { q->n = S->first_n; }  /* found when the path was chosen */
+            else ok = scan_next_rows(s, S, q, rows, dbg, T0);
+            if (ok && q->n == 0) eof = 1;
+            if (ok && q->n) {
+                ok = dev_text_grow(s->d_text, q->text_end + 16 + (q->text_end >> 4), &s->d_text_cap)      /* some room ahead: growing waits for the kernels that run */
+                  || dev_text_grow(s->d_text, q->text_end + 16, &s->d_text_cap);
+                ok = ok && hpgv_inflate_blocks_dev(g_ctx, (const uint8_t *)s->d_comp, q->d_in_off, q->d_in_len, q->d_out_off, q->d_out_len,
+                                                   (int)q->n, (uint8_t *)s->d_text, q->d_status, q->stream) == HPGV_OK;
+                const int first = launched == 0;
+                launched += q->n; qn++;
+                if (S->chain_pos >= (size_t)s->size) eof = 1;
+                if (ok && !first && !eof && qn < SCAN_SLOTS) continue;    /* (the first stretch decodes alone: 2 ms) */
+            }
+        }
+        if (ok && qn > 0) {                                          /* the oldest stretch in flight: wait, check, publish */
+            scan_slot_t *q = &S->slot[qh];
+            ok = hpgv_memcpy_d2h(g_ctx, st, q->d_status, q->n * 4, q->stream) == HPGV_OK;       /* synchronises that stream */
+            for (size_t k = 0; ok && k < q->n; k++)
+                if (st[k] || (refuse_every && (done_blocks + k) % refuse_every == 0)) {         /* not taken by the device decoder: the host decodes it, the text is patched */
+                    ok = !inflate_block(s->map + q->h_in_off[k], q->h_in_len[k], tmp, q->h_out_len[k])
+                      && hpgv_memcpy_h2d(g_ctx, (char *)s->d_text + q->h_out_off[k], tmp, q->h_out_len[k], q->stream) == HPGV_OK;
+                }
+            done_blocks += q->n;
+            if (dbg) fprintf(stderr, "stager: decoded up to block %zu at %.4f\n", done_blocks, now_s() - T0);
+            if (ok) {
+                pthread_mutex_lock(&s->g_mu);
+                s->g_done = done_blocks;
+                s->dev_ready = q->text_end;
+                pthread_cond_broadcast(&s->g_cv);
+                pthread_mutex_unlock(&s->g_mu);
+            }
+            qh = (qh + 1) % SCAN_SLOTS; qn--;
+        }
+    }
+    for (int q = 0; q < SCAN_SLOTS; q++) if (S->slot[q].stream) (void)hpgv_stream_sync(g_ctx, S->slot[q].stream);      /* after a failure launches may still be running */
+    pthread_mutex_lock(&s->g_mu);
+    if (!ok) s->g_err = 1;
+    else { s->dev_len = S->text_pos; s->dev_len_known = 1; s->g_nb = S->blocks; }
+    s->g_finished = 1;
+    pthread_cond_broadcast(&s->g_cv);
+    pthread_mutex_unlock(&s->g_mu);
+    if (s->u_started) {                                  /* the compressed bytes are freed below: the uploader must be through */
+        pthread_mutex_lock(&s->g_mu); s->u_cancel = 1; pthread_mutex_unlock(&s->g_mu);
+        pthread_join(s->u_thread, NULL); s->u_started = 0;
+    }
+    if (dbg) fprintf(stderr, "stager: finished (%zu blocks, %.1f MB of text) at %.4f\n", S->blocks, S->text_pos / 1e6, now_s() - T0);
+    for (int q = 1; q < SCAN_SLOTS; q++) if (S->slot[q].stream) (void)hpgv_stream_destroy(g_ctx, S->slot[q].stream);
+    for (int q = 0; q < SCAN_SLOTS; q++) free(S->slot[q].h_in_off);
+    free(S); free(tmp); free(st);
+    if (s->d_comp) { (void)hpgv_dev_free(g_ctx, s->d_comp); s->d_comp = NULL; }      /* only the text is needed from here on */
+    if (s->d_scan) { (void)hpgv_dev_free(g_ctx, s->d_scan); s->d_scan = NULL; }
+    return NULL;
+}
+
+/* 0 = the streaming stager has the file; 1 = not taken (the caller goes on with the host's table; nothing is left behind) */
+static int bgzf_stream_stage(source_t *s) {
+    const int dbg = getenv("HPGV_RUN_TRACE") != NULL; const double T0 = now_s();
+    scan_state_t *S = (scan_state_t *)calloc(1, sizeof *S);
+    if (!S) return 1;
+    int ok = hpgv_stream_create(g_ctx, &s->rstream) == HPGV_OK && hpgv_stream_create(g_ctx, &s->cstream) == HPGV_OK;
+    const size_t slot_bytes = (size_t)SCAN_ROWS_MAX * 28;
+    S->scratch_bytes = hpgv_bgzf_scan_scratch_bytes(SCAN_RANGE_MAX + 16, SCAN_ROWS_MAX);
+    if (ok) ok = hpgv_dev_alloc(g_ctx, slot_bytes * SCAN_SLOTS + S->scratch_bytes + 256, &s->d_scan) == HPGV_OK;
+    for (int k = 0; ok && k < SCAN_SLOTS; k++) {
+        scan_slot_t *q = &S->slot[k];
+        char *d = (char *)s->d_scan + (size_t)k * slot_bytes;
+        q->d_in_off = (uint64_t *)d; q->d_out_off = (uint64_t *)(d + (size_t)SCAN_ROWS_MAX * 8);
+        q->d_in_len = (uint32_t *)(d + (size_t)SCAN_ROWS_MAX * 16); q->d_out_len = (uint32_t *)(d + (size_t)SCAN_ROWS_MAX * 20);
+        q->d_status = (int32_t *)(d + (size_t)SCAN_ROWS_MAX * 24);
+        char *h = (char *)malloc((size_t)SCAN_ROWS_MAX * 24);
+        ok = h != NULL;
+        q->h_in_off = (uint64_t *)h; q->h_out_off = (uint64_t *)(h + (size_t)SCAN_ROWS_MAX * 8);
+        q->h_in_len = (uint32_t *)(h + (size_t)SCAN_ROWS_MAX * 16); q->h_out_len = (uint32_t *)(h + (size_t)SCAN_ROWS_MAX * 20);
+        if (k == 0) q->stream = s->cstream; else ok = ok && hpgv_stream_create(g_ctx, &q->stream) == HPGV_OK;
+    }
+    if (ok) S->d_scratch = (char *)s->d_scan + slot_bytes * SCAN_SLOTS;
+    /* the first blocks, from the file's first megabytes: is this a file the device can chain, and how much text is it? */
+    const char *tr = getenv("HPGV_TEST_SCAN_ROWS");
+    S->rows_cap = tr && atol(tr) > 0 ? (size_t)atol(tr) : 0;
+    if (ok) ok = scan_next_rows(s, S, &S->slot[0], S->rows_cap && S->rows_cap < 4096 ? S->rows_cap : 4096, dbg, T0) && S->slot[0].n > 0;
+    size_t est = 0;
+    if (ok) {
+        est = (size_t)((double)S->text_pos / (double)S->chain_pos * (double)s->size * 1.06) + ((size_t)64 << 20);
+        if (S->chain_pos >= (size_t)s->size) est = S->text_pos + 16;
+        if (est > ((size_t)48 << 30)) ok = 0;                        /* as with the host's table: such a text stays on the host path, */
+        if (S->chain_pos >= (size_t)s->size && S->blocks < 256) ok = 0;      /* and a small file is as quick there */
+    }
+    if (ok) {
+        s->d_text = dev_text_get(est, &s->d_text_cap, &s->d_text_kind);
+        ok = s->d_text != NULL && ((s->d_text_kind == DEV_TEXT_GROWS && !getenv("HPGV_NO_GROWING_TEXT")) || S->chain_pos >= (size_t)s->size);
+        if (!ok && s->d_text) { dev_text_put(s->d_text, s->d_text_cap, s->d_text_kind); s->d_text = NULL; }
+    }
+    if (dbg) fprintf(stderr, "stage: first %zu blocks found, text estimate %.1f MB, %s at %.4f\n", S->slot[0].n, est / 1e6, ok ? "streaming" : "not taken", now_s() - T0);
+    if (ok) {
+        S->first_n = S->slot[0].n;
+        s->dev_len = 0; s->dev_len_known = 0; s->dev_pos = 0; s->dev_ready = 0; s->g_done = 0; s->g_err = 0; s->g_finished = 0; s->g_nb = 0;
+        s->blk = (size_t *)S;
+        ok = pthread_create(&s->g_thread, NULL, bgzf_gpu_stream_stager, s) == 0;
+        if (ok) s->g_started = 1; else s->blk = NULL;
+    }
+    if (!ok) {
+        for (int k = 1; k < SCAN_SLOTS; k++) if (S->slot[k].stream) (void)hpgv_stream_destroy(g_ctx, S->slot[k].stream);
+        for (int k = 0; k < SCAN_SLOTS; k++) free(S->slot[k].h_in_off);
+        free(S);
+        if (s->d_text) { dev_text_put(s->d_text, s->d_text_cap, s->d_text_kind); s->d_text = NULL; }
+        if (s->d_scan) { (void)hpgv_dev_free(g_ctx, s->d_scan); s->d_scan = NULL; }
+        if (s->rstream) { (void)hpgv_stream_destroy(g_ctx, s->rstream); s->rstream = NULL; }
+        if (s->cstream) { (void)hpgv_stream_destroy(g_ctx, s->cstream); s->cstream = NULL; }
+        return 1;
+    }
+    s->map_pos = (size_t)s->size;                                    /* the CPU path has nothing left to do */
+    return 0;
+}
+
 static int bgzf_gpu_stage(source_t *s) {
     s->gpu_tried = 1;
     if (getenv("HPGV_NO_GPU_INFLATE") || !g_ctx || s->map_pos != 0) return 1;
@@ -2310,6 +2579,7 @@ static int bgzf_gpu_stage(source_t *s) {
         else { (void)hpgv_dev_free(g_ctx, s->d_comp); s->d_comp = NULL; }
     }
     if (!s->u_started) { pthread_mutex_destroy(&s->g_mu); pthread_cond_destroy(&s->g_cv); s->g_sync = 0; return 1; }
+    if (!getenv("HPGV_BGZF_HOST_TABLE") && !getenv("HPGV_SERIAL_BGZF_WALK") && bgzf_stream_stage(s) == 0) return 0;
     if (getenv("HPGV_SERIAL_BGZF_WALK") || bgzf_walk_parallel(s->fd, (size_t)s->size, &in_off, &out_off, &in_len, &out_len, &nb, &text)) {
         nb = 0; text = 0;
         if (dbg) fprintf(stderr, "stage: serial walk\n");
@@ -2338,7 +2608,7 @@ static int bgzf_gpu_stage(source_t *s) {
     if (ok && (nb < 256 || nb > 0x7FFFFFFFu || text > ((size_t)48 << 30))) ok = 0;     /* a small file is as quick on the host */
     if (ok) ok = hpgv_stream_create(g_ctx, &s->rstream) == HPGV_OK && hpgv_stream_create(g_ctx, &s->cstream) == HPGV_OK;
     if (ok) ok = hpgv_dev_alloc(g_ctx, nb * 24 + 64, &s->d_tab) == HPGV_OK;
-    if (ok) { s->d_text_cap = text + 16; s->d_text = dev_text_get(s->d_text_cap); ok = s->d_text != NULL; }
+    if (ok) { s->d_text = dev_text_get(text + 16, &s->d_text_cap, &s->d_text_kind); ok = s->d_text != NULL; }
     if (ok) ok = hpgv_dev_alloc(g_ctx, nb * 4 + 16, &s->d_status) == HPGV_OK;
     if (dbg) fprintf(stderr, "stage: alloc %.4f\n", now_s() - T0);
     if (ok) {
@@ -2351,7 +2621,7 @@ static int bgzf_gpu_stage(source_t *s) {
     if (dbg) fprintf(stderr, "stage: tab %.4f\n", now_s() - T0);
     if (ok) {
         s->g_in_off = in_off; s->g_out_off = out_off; s->g_in_len = in_len; s->g_out_len = out_len; s->g_nb = nb;
-        s->dev_len = text; s->dev_pos = 0; s->dev_ready = 0; s->g_done = 0; s->g_err = 0; s->g_finished = 0;
+        s->dev_len = text; s->dev_len_known = 1; s->dev_pos = 0; s->dev_ready = 0; s->g_done = 0; s->g_err = 0; s->g_finished = 0;
         ok = pthread_create(&s->g_thread, NULL, bgzf_gpu_stager, s) == 0;
         if (ok) s->g_started = 1;
     }
@@ -2366,7 +2636,7 @@ static int bgzf_gpu_stage(source_t *s) {
             if (s->d_comp) { (void)hpgv_dev_free(g_ctx, s->d_comp); s->d_comp = NULL; }
         if (s->d_tab) { (void)hpgv_dev_free(g_ctx, s->d_tab); s->d_tab = NULL; }
         if (s->d_status) { (void)hpgv_dev_free(g_ctx, s->d_status); s->d_status = NULL; }
-        if (s->d_text) { dev_text_put(s->d_text, s->d_text_cap); s->d_text = NULL; }
+        if (s->d_text) { dev_text_put(s->d_text, s->d_text_cap, s->d_text_kind); s->d_text = NULL; }
         if (s->rstream) { (void)hpgv_stream_destroy(g_ctx, s->rstream); s->rstream = NULL; }
         if (s->cstream) { (void)hpgv_stream_destroy(g_ctx, s->cstream); s->cstream = NULL; }
         return 1;
@@ -2404,13 +2674,20 @@ static size_t source_read(source_t *s, char *buf, size_t cap) {
     if (cap == 0) return 0;
     if (!s->gpu_tried) (void)bgzf_gpu_stage(s);
     if (s->d_text) {                                                 /* the text is on the device: copy the next stretch out */
-        if (s->dev_pos >= s->dev_len) return 0;
-        const size_t n = s->dev_len - s->dev_pos < cap ? s->dev_len - s->dev_pos : cap;
-        pthread_mutex_lock(&s->g_mu);                                /* until the stager has decoded that far */
-        while (!s->g_err && s->dev_ready < s->dev_pos + n && !s->g_finished) pthread_cond_wait(&s->g_cv, &s->g_mu);
-        const int bad = s->g_err || s->dev_ready < s->dev_pos + n;
+        pthread_mutex_lock(&s->g_mu);                                /* until the stager has decoded that far (or knows where the text ends) */
+        for (;;) {
+            const size_t limit = s->dev_len_known ? s->dev_len : (size_t)-1;
+            const size_t want = limit - s->dev_pos < cap ? limit : s->dev_pos + cap;
+            if (s->g_err || s->dev_ready >= want || s->g_finished) break;
+            pthread_cond_wait(&s->g_cv, &s->g_mu);
+        }
+        const size_t limit = s->dev_len_known ? s->dev_len : (size_t)-1;
+        const size_t end = limit - s->dev_pos < cap ? limit : s->dev_pos + cap;
+        const int bad = s->g_err || s->dev_ready < end;
         pthread_mutex_unlock(&s->g_mu);
         if (bad) return (size_t)-1;
+        const size_t n = end - s->dev_pos;
+        if (n == 0) return 0;
         if (hpgv_memcpy_d2h(g_ctx, buf, (const char *)s->d_text + s->dev_pos, n, s->rstream) != HPGV_OK) return (size_t)-1;
         s->dev_pos += n;
         return n;
@@ -2471,14 +2748,20 @@ static size_t read_lines_dev(line_reader_t *r, size_t cap) {
     source_t *s = &r->src;
     const size_t start = s->dev_pos;
     r->last_dev = (const char *)s->d_text + start;
-    if (start >= s->dev_len) return 0;
-    size_t end = s->dev_len - start <= cap ? s->dev_len : start + cap;
-    pthread_mutex_lock(&s->g_mu);                                    /* until the stager has decoded that far */
-    while (!s->g_err && s->dev_ready < end && !s->g_finished) pthread_cond_wait(&s->g_cv, &s->g_mu);
+    pthread_mutex_lock(&s->g_mu);                                    /* until the stager has decoded that far (or knows where the text ends) */
+    for (;;) {
+        const size_t lim = s->dev_len_known ? s->dev_len : (size_t)-1;
+        const size_t want = lim - start <= cap ? lim : start + cap;
+        if (s->g_err || s->dev_ready >= want || s->g_finished) break;
+        pthread_cond_wait(&s->g_cv, &s->g_mu);
+    }
+    const size_t limit = s->dev_len_known ? s->dev_len : (size_t)-1;
+    size_t end = limit - start <= cap ? limit : start + cap;
     const int bad = s->g_err || s->dev_ready < end;
     pthread_mutex_unlock(&s->g_mu);
     if (bad) return (size_t)-1;
-    if (end < s->dev_len) {                                          /* cut at the last newline before `end` */
+    if (start >= limit) return 0;
+    if (end < limit) {                                               /* cut at the last newline before `end` */
         size_t look = 1u << 18;
         for (;;) {
             if (look > end - start) look = end - start;

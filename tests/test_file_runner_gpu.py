@@ -424,11 +424,39 @@ def test_run_assoc_from_bgzf_decoded_on_the_gpu(host, tmp_path, capfd):
     open(mixed, "wb").write(b"".join(stored(data[i * big:(i + 1) * big]) for i in range(n_big)) + _bgzf(data[n_big * big:], 0x700))
     assert os.path.getsize(mixed) // 64 < big // 2                   # a stored block spans more than two of the 64 segments
     capfd.readouterr()
-    assert run(mixed, "mixed", {"HPGV_RUN_TRACE": "1"}) == plain
+    assert run(mixed, "mixed", {"HPGV_RUN_TRACE": "1"}) == plain     # the block table found on the device, in the uploaded bytes
     err = capfd.readouterr().err
-    assert "stage: walk" in err and "serial walk" not in err
-    assert run(mixed, "mixed_serial", {"HPGV_RUN_TRACE": "1", "HPGV_SERIAL_BGZF_WALK": "1"}) == plain
+    assert "blocks found" in err and "stage: walk" not in err
+    assert run(mixed, "mixed_team", {"HPGV_RUN_TRACE": "1", "HPGV_BGZF_HOST_TABLE": "1"}) == plain     # ... built by the host's team
+    err = capfd.readouterr().err
+    assert "stage: walk" in err and "serial walk" not in err and "blocks found" not in err
+    assert run(mixed, "mixed_serial", {"HPGV_RUN_TRACE": "1", "HPGV_SERIAL_BGZF_WALK": "1"}) == plain  # ... by one thread
     assert "serial walk" in capfd.readouterr().err
+    assert run(packed, "stretches", {"HPGV_TEST_SCAN_ROWS": "300", "HPGV_RUN_TRACE": "1"}) == plain      # eleven stretches through the four slots
+    assert capfd.readouterr().err.count("blocks found") >= 10
+    assert run(packed, "stretches_patched", {"HPGV_TEST_SCAN_ROWS": "300", "HPGV_TEST_GPU_INFLATE_REFUSE_EVERY": "7"}) == plain
+    capfd.readouterr()
+    # without a text buffer that grows the table has to be complete before the text is allocated: the host builds it
+    assert run(packed, "fixed_text", {"HPGV_TEST_SCAN_ROWS": "300", "HPGV_NO_GROWING_TEXT": "1", "HPGV_RUN_TRACE": "1"}) == plain
+    assert "stage: walk" in capfd.readouterr().err
+    # blocks whose header carries a second extra field are not what the device scan looks for: those stretches are walked on
+    # the host, the rest of the chain is found on the device again
+
+    def odd(ch):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = co.compress(ch) + co.flush()
+        return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 12) + b"XY" + struct.pack("<H", 2) + b"zz" + b"BC"
+                + struct.pack("<HH", 2, 12 + 12 + len(comp) + 8 - 1) + comp + struct.pack("<II", zlib.crc32(ch), len(ch)))
+    pieces, at, k = [], 0, 0
+    while at < len(data):
+        n = 0x700 if k % 40 else 0x300
+        pieces.append(odd(data[at:at + n]) if k % 40 == 0 else _bgzf(data[at:at + n], 0x700)[:-28])
+        at += n; k += 1
+    oddf = str(tmp_path / "odd.vcf.gz")
+    open(oddf, "wb").write(b"".join(pieces) + _bgzf(b"", 0x700))
+    assert run(oddf, "odd", {"HPGV_RUN_TRACE": "1"}) == plain
+    err = capfd.readouterr().err
+    assert "walked on the host" in err and "blocks found" in err
     assert run(packed, "patched", {"HPGV_TEST_GPU_INFLATE_REFUSE_EVERY": "3"}) == plain
     assert run(packed, "copied_back", {"HPGV_NO_DEVICE_WINDOWS": "1"}) == plain       # device decoding, whole windows copied back
     assert run(packed, "cpu", {"HPGV_NO_GPU_INFLATE": "1"}) == plain
