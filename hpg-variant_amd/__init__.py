@@ -31,7 +31,7 @@ SYMBOLS = [
     "hpgv_set_stats_groups", "hpgv_stats_groups_layout", "hpgv_stats_scan_group_dev",
     "hpgv_set_pedigree", "hpgv_mendel_layout", "hpgv_mendel_scan_dev", "hpgv_mendel_children_dev",
     "hpgv_dev_alloc", "hpgv_dev_free", "hpgv_memcpy_h2d", "hpgv_memcpy_d2h", "hpgv_stream_sync",
-    "hpgv_device_numa_node", "hpgv_inflate_blocks_dev", "hpgv_bgzf_scan_dev", "hpgv_bgzf_scan_scratch_bytes", "hpgv_dev_reserve", "hpgv_dev_commit", "hpgv_dev_release", "hpgv_text_alias", "hpgv_stream_create", "hpgv_stream_destroy", "hpgv_host_alloc", "hpgv_host_free",
+    "hpgv_device_numa_node", "hpgv_memcpy_h2d_async", "hpgv_inflate_blocks_dev", "hpgv_bgzf_scan_dev", "hpgv_bgzf_scan_scratch_bytes", "hpgv_dev_reserve", "hpgv_dev_commit", "hpgv_dev_release", "hpgv_text_alias", "hpgv_stream_create", "hpgv_stream_create_low", "hpgv_stream_destroy", "hpgv_host_alloc", "hpgv_host_free",
     "hpgv_layout_dev", "hpgv_synth_dev", "hpgv_synth_raw_dev",
     "hpgv_assoc_scan_dev", "hpgv_assoc_chisq_dev", "hpgv_assoc_fisher_dev",
     "hpgv_tdt_scan_dev", "hpgv_tdt_stats_dev", "hpgv_stats_scan_dev", "hpgv_stats_hwe_dev",

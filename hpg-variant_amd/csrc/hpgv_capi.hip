@@ -685,6 +685,18 @@ int hpgv_stream_create(hpgv_ctx *ctx, void **stream) {
     *stream = (void *)st;
     return HPGV_OK;
 }
+// a stream whose kernels give way to those of the other streams whenever the device has a choice (bulk work beside a pipeline)
+int hpgv_stream_create_low(hpgv_ctx *ctx, void **stream) {
+    ctx = first_member(ctx);
+    if (!ctx || !stream) return HPGV_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    int least = 0, greatest = 0;
+    HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t st = nullptr;
+    HIPCHK(ctx, hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least));
+    *stream = (void *)st;
+    return HPGV_OK;
+}
 int hpgv_stream_destroy(hpgv_ctx *ctx, void *stream) {
     ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
@@ -734,6 +746,14 @@ int hpgv_memcpy_h2d(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, voi
     DeviceGuard g(ctx->device);
     HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     HIPCHK(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return HPGV_OK;
+}
+// the copy is only queued (page-locked source): hpgv_stream_sync says when it is done
+int hpgv_memcpy_h2d_async(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream) {
+    ctx = first_member(ctx);
+    if (!ctx) return HPGV_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     return HPGV_OK;
 }
 int hpgv_memcpy_d2h(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream) {

@@ -2017,77 +2017,102 @@ static void source_task_inflate(void *v, int g) {
  * their own.  A block the device decoder refuses is decoded by the host and patched in.  No memory, a file of more
  * than 48 GB of text or fewer than 256 blocks leave the CPU path in charge.  HPGV_NO_GPU_INFLATE=1 switches it off. */
 enum { GPU_STRETCH = 32768, GPU_AHEAD_BYTES = 768 << 20 };
-/* the stager's uploads: out of pageable memory a copy runs at a fifth of the bus rate, so a team reads 64 MB pieces
- * of the file into a page-locked buffer and those go up (pread, not the mapping: faulting a gigabyte in and unmapping
- * it again costs ~90 ms) */
-enum { UP_SEG = 2 << 20 };
+/* The upload: out of pageable memory a copy runs at a fifth of the bus rate, so the file goes through a page-locked ring
+ * (pread, not the mapping: faulting a gigabyte in and unmapping it again costs ~90 ms).  Readers take the file's 4 MB
+ * segments in turn and fill the ring's slots; the uploader copies the slots up in file order and announces every segment
+ * that has arrived (s->up_done, under g_mu).  Nobody waits at a barrier: a reader waits only for its slot to be free, the
+ * copier only for the next segment to be filled.  (Halves of a buffer filled by a team, with a barrier per half, left
+ * the bus at 18 - 28 GB/s beside the pipeline's own threads.) */
+enum { UP_SEG = 4 << 20, UP_SLOTS = 16, UP_READERS_MAX = 12 };
+static size_t pread_full(int fd, void *buf, size_t n, size_t pos);
 typedef struct {
-    char *dst; int fd; off_t pos; size_t len; int bad;   /* this piece: file -> one half of the page-locked buffer */
-    const char *h_src; void *h_dst; size_t h_len; void *stream;      /* the piece before it: other half -> device (task 0) */
-} up_job_t;
-static void up_task_copy(void *v, int k) {
-    up_job_t *j = (up_job_t *)v;
-    if (j->h_len) {
-        if (k == 0) {
-            if (hpgv_memcpy_h2d(g_ctx, j->h_dst, j->h_src, j->h_len, j->stream) != HPGV_OK) __atomic_store_n(&j->bad, 1, __ATOMIC_RELAXED);
-            return;
-        }
-        k--;
-    }
-    size_t off = (size_t)k * UP_SEG, n = off + UP_SEG <= j->len ? (size_t)UP_SEG : j->len - off;
-    if (off >= j->len) return;
-    while (n > 0) {
-        const ssize_t got = pread(j->fd, j->dst + off, n, j->pos + (off_t)off);
-        if (got <= 0) { __atomic_store_n(&j->bad, 1, __ATOMIC_RELAXED); return; }
-        off += (size_t)got; n -= (size_t)got;
+    source_t *s; char *pin; size_t n_seg;
+    pthread_mutex_t mu; pthread_cond_t cv;
+    size_t next;                                         /* the next segment a reader takes */
+    size_t copied;                                       /* segments [0, copied) are on the device: slot i % UP_SLOTS is free for segment i < copied + UP_SLOTS */
+    unsigned char filled[UP_SLOTS];
+    int bad, stop;
+} up_ring_t;
+static void *up_reader(void *v) {
+    up_ring_t *r = (up_ring_t *)v;
+    for (;;) {
+        pthread_mutex_lock(&r->mu);
+        const size_t i = r->next < r->n_seg ? r->next++ : (size_t)-1;
+        while (i != (size_t)-1 && !r->stop && !r->bad && i >= r->copied + UP_SLOTS) pthread_cond_wait(&r->cv, &r->mu);
+        const int quit = i == (size_t)-1 || r->stop || r->bad;
+        pthread_mutex_unlock(&r->mu);
+        if (quit) return NULL;
+        const size_t off = i * (size_t)UP_SEG, len = off + UP_SEG <= (size_t)r->s->size ? (size_t)UP_SEG : (size_t)r->s->size - off;
+        const int ok = pread_full(r->s->fd, r->pin + (i % UP_SLOTS) * (size_t)UP_SEG, len, off) == len;
+        pthread_mutex_lock(&r->mu);
+        if (ok) r->filled[i % UP_SLOTS] = 1; else r->bad = 1;
+        pthread_cond_broadcast(&r->cv);
+        pthread_mutex_unlock(&r->mu);
     }
 }
-/* compressed bytes [lo, hi) of the file -> d_comp: while one half of the buffer goes up the bus the team fills the other */
-/* [lo, hi) of the file to the device: a team preads one half of the page-locked buffer while the other half goes up the
- * bus.  With `publish` every half that has arrived is announced (s->up_done, under g_mu) and s->u_cancel ends the loop. */
-static int stager_upload(source_t *s, io_pool_t *cp, char *pin, size_t pin_cap, size_t lo, size_t hi, void *up, int publish) {
-    if (!pin) {
-        const int ok = hpgv_memcpy_h2d(g_ctx, (char *)s->d_comp + lo, s->map + lo, hi - lo, up) == HPGV_OK;
-        if (ok && publish) { pthread_mutex_lock(&s->g_mu); s->up_done = hi; pthread_cond_broadcast(&s->g_cv); pthread_mutex_unlock(&s->g_mu); }
-        return ok;
-    }
-    const size_t half = pin_cap / 2;
-    size_t prev_off = 0, prev_len = 0;
-    int side = 0;
-    for (size_t off = lo; off < hi || prev_len; off += half, side ^= 1) {
-        up_job_t j;
-        memset(&j, 0, sizeof j);
-        j.dst = pin + (size_t)side * half; j.fd = s->fd; j.pos = (off_t)off; j.len = off < hi ? (hi - off < half ? hi - off : half) : 0;
-        j.h_src = pin + (size_t)(side ^ 1) * half; j.h_dst = (char *)s->d_comp + prev_off; j.h_len = prev_len; j.stream = up;
-        pool_run(cp, up_task_copy, &j, (int)((j.len + UP_SEG - 1) / UP_SEG) + (prev_len ? 1 : 0));
-        if (j.bad) return 0;
-        if (publish && prev_len) {
-            pthread_mutex_lock(&s->g_mu);
-            s->up_done = prev_off + prev_len;
-            const int cancel = s->u_cancel;
-            pthread_cond_broadcast(&s->g_cv);
-            pthread_mutex_unlock(&s->g_mu);
-            if (cancel) return 0;
-        }
-        prev_off = off; prev_len = j.len;
-    }
-    return 1;
-}
-
 static void *bgzf_uploader(void *v) {
     source_t *s = (source_t *)v;
     void *up = NULL;
     int ok = hpgv_stream_create(g_ctx, &up) == HPGV_OK;
-    const size_t pin_cap = (size_t)64 << 20;
+    const size_t pin_cap = (size_t)UP_SEG * UP_SLOTS;
     char *pin = text_buf_get(pin_cap + 1);                          /* from the runs' cache of page-locked buffers */
-    io_pool_t cp;
-    pool_init(&cp, default_io_threads());
-    ok = ok && stager_upload(s, &cp, pin, pin_cap, 0, (size_t)s->size, up, 1);
-    pool_destroy(&cp);
-    text_buf_put(pin, pin_cap + 1);
+    up_ring_t r;
+    memset(&r, 0, sizeof r);
+    r.s = s; r.pin = pin; r.n_seg = ((size_t)s->size + UP_SEG - 1) / UP_SEG;
+    pthread_mutex_init(&r.mu, NULL); pthread_cond_init(&r.cv, NULL);
+    pthread_t th[UP_READERS_MAX];
+    int n_th = 0;
+    if (ok && pin) {
+        int want = default_io_threads() * 3 / 4;
+        want = want < 1 ? 1 : want > UP_READERS_MAX ? UP_READERS_MAX : want;
+        for (; n_th < want; n_th++) if (pthread_create(&th[n_th], NULL, up_reader, &r) != 0) break;
+    }
+    ok = ok && pin && n_th > 0;
+    double t_wait = 0, t_copy = 0; const double t_begin = now_s();
+    void *up2 = NULL;                                                /* two copies in flight: one is queued while the one before is waited for */
+    ok = ok && hpgv_stream_create(g_ctx, &up2) == HPGV_OK;
+    void *st2[2] = { up, up2 };
+    for (size_t i = 0; ok && i <= r.n_seg; i++) {
+        double t0 = now_s();
+        if (i < r.n_seg) {
+            pthread_mutex_lock(&r.mu);
+            while (!r.filled[i % UP_SLOTS] && !r.bad) pthread_cond_wait(&r.cv, &r.mu);
+            ok = !r.bad;
+            pthread_mutex_unlock(&r.mu);
+            t_wait += now_s() - t0; t0 = now_s();
+            if (!ok) break;
+            const size_t off = i * (size_t)UP_SEG, len = off + UP_SEG <= (size_t)s->size ? (size_t)UP_SEG : (size_t)s->size - off;
+            ok = hpgv_memcpy_h2d_async(g_ctx, (char *)s->d_comp + off, pin + (i % UP_SLOTS) * (size_t)UP_SEG, len, st2[i & 1]) == HPGV_OK;
+            if (!ok) break;
+        }
+        if (i == 0) continue;
+        const size_t j = i - 1, off = j * (size_t)UP_SEG, len = off + UP_SEG <= (size_t)s->size ? (size_t)UP_SEG : (size_t)s->size - off;
+        ok = hpgv_stream_sync(g_ctx, st2[j & 1]) == HPGV_OK;
+        t_copy += now_s() - t0;
+        pthread_mutex_lock(&r.mu);
+        r.filled[j % UP_SLOTS] = 0; r.copied = j + 1;
+        pthread_cond_broadcast(&r.cv);
+        pthread_mutex_unlock(&r.mu);
+        if (!ok) break;
+        pthread_mutex_lock(&s->g_mu);
+        s->up_done = off + len;
+        const int cancel = s->u_cancel;
+        pthread_cond_broadcast(&s->g_cv);
+        pthread_mutex_unlock(&s->g_mu);
+        if (cancel) { ok = 0; break; }
+    }
+    if (up2) { (void)hpgv_stream_sync(g_ctx, up2); (void)hpgv_stream_destroy(g_ctx, up2); }
+    if (up) (void)hpgv_stream_sync(g_ctx, up);
+    if (getenv("HPGV_RUN_TRACE"))
+        fprintf(stderr, "uploader: %.1f MB in %.4f s: %.4f s waiting for the readers (%d), %.4f s in copies\n", s->size / 1e6, now_s() - t_begin, t_wait, n_th, t_copy);
+    pthread_mutex_lock(&r.mu); r.stop = 1; pthread_cond_broadcast(&r.cv); pthread_mutex_unlock(&r.mu);
+    for (int k = 0; k < n_th; k++) pthread_join(th[k], NULL);
+    pthread_mutex_destroy(&r.mu); pthread_cond_destroy(&r.cv);
+    if (pin) text_buf_put(pin, pin_cap + 1);
     if (up) (void)hpgv_stream_destroy(g_ctx, up);
     pthread_mutex_lock(&s->g_mu);
-    if (!ok) s->u_err = 1;
+    if (!ok && !s->u_cancel) s->u_err = 1;
+    if (!ok && s->up_done < (size_t)s->size) s->u_err = 1;
     pthread_cond_broadcast(&s->g_cv);
     pthread_mutex_unlock(&s->g_mu);
     return NULL;
@@ -2389,13 +2414,18 @@ static int scan_slot_rows_to_device(scan_slot_t *q) {
         && hpgv_memcpy_h2d(g_ctx, q->d_out_len, q->h_out_len, q->n * 4, q->stream) == HPGV_OK;
 }
 /* the next stretch's rows into slot q: up to max_rows blocks from the chain's position among the bytes that are up.
- * 1 = q->n rows (0 rows: the file has ended), 0 = failure */
-static int scan_next_rows(source_t *s, scan_state_t *S, scan_slot_t *q, size_t max_rows, int dbg, double T0) {
+ * 1 = q->n rows (0 rows: the file has ended), 0 = failure, 2 = (only with wait = 0) the bytes for that many blocks are
+ * not up yet */
+static int scan_next_rows(source_t *s, scan_state_t *S, scan_slot_t *q, size_t max_rows, int wait, int dbg, double T0) {
     q->n = 0; q->text_end = S->text_pos;
     const size_t avg = S->blocks ? S->chain_pos / S->blocks + 1 : 16384;
     size_t want = S->chain_pos + max_rows * avg;                      /* bytes that should hold that many blocks */
     for (;;) {
         if (S->chain_pos >= (size_t)s->size) return 1;
+        if (!wait) {
+            const size_t now_up = wait_uploaded_some(s, 0);
+            if (now_up < (want < (size_t)s->size ? want : (size_t)s->size)) return 2;
+        }
         const size_t have = wait_uploaded_some(s, want);
         if (!have) return 0;
         size_t hi = have;
@@ -2428,59 +2458,103 @@ static int scan_next_rows(source_t *s, scan_state_t *S, scan_slot_t *q, size_t m
     }
 }
 
+/* the stretches go through a ring of SCAN_SLOTS slots: the stager finds and launches them as their bytes arrive, the
+ * publisher waits for them in file order, patches what the device refused and hands the text to the reader -- neither
+ * waits for the other's event */
+typedef struct {
+    source_t *s; scan_state_t *S;
+    pthread_mutex_t mu; pthread_cond_t cv;
+    size_t n_launched, n_published;                       /* stretches; slot k % SCAN_SLOTS holds stretch k */
+    int launch_done, bad;
+    double T0; int dbg;
+} scan_ring_t;
+static void *bgzf_publisher(void *v) {
+    scan_ring_t *R = (scan_ring_t *)v;
+    source_t *s = R->s;
+    unsigned char *tmp = (unsigned char *)malloc(65536);
+    int32_t *st = (int32_t *)malloc(sizeof(int32_t) * SCAN_ROWS_MAX);
+    int ok = tmp && st;
+    const char *fe = getenv("HPGV_TEST_GPU_INFLATE_REFUSE_EVERY");     /* tests: exercise the host patch path */
+    const size_t refuse_every = fe ? (size_t)atol(fe) : 0;
+    size_t done_blocks = 0;
+    for (size_t k = 0; ok; k++) {
+        pthread_mutex_lock(&R->mu);
+        while (R->n_launched <= k && !R->launch_done && !R->bad) pthread_cond_wait(&R->cv, &R->mu);
+        const int have = R->n_launched > k && !R->bad;
+        pthread_mutex_unlock(&R->mu);
+        if (!have) break;
+        scan_slot_t *q = &R->S->slot[k % SCAN_SLOTS];
+        ok = hpgv_memcpy_d2h(g_ctx, st, q->d_status, q->n * 4, q->stream) == HPGV_OK;           /* synchronises that stream */
+        for (size_t i = 0; ok && i < q->n; i++)
+            if (st[i] || (refuse_every && (done_blocks + i) % refuse_every == 0)) {             /* not taken by the device decoder: the host decodes it, the text is patched */
+                ok = !inflate_block(s->map + q->h_in_off[i], q->h_in_len[i], tmp, q->h_out_len[i])
+                  && hpgv_memcpy_h2d(g_ctx, (char *)s->d_text + q->h_out_off[i], tmp, q->h_out_len[i], q->stream) == HPGV_OK;
+            }
+        done_blocks += q->n;
+        if (R->dbg) fprintf(stderr, "stager: decoded up to block %zu at %.4f\n", done_blocks, now_s() - R->T0);
+        if (ok) {
+            pthread_mutex_lock(&s->g_mu);
+            s->g_done = done_blocks;
+            s->dev_ready = q->text_end;
+            pthread_cond_broadcast(&s->g_cv);
+            pthread_mutex_unlock(&s->g_mu);
+        }
+        pthread_mutex_lock(&R->mu);
+        R->n_published = k + 1;
+        if (!ok) R->bad = 1;
+        pthread_cond_broadcast(&R->cv);
+        pthread_mutex_unlock(&R->mu);
+    }
+    if (!ok) { pthread_mutex_lock(&R->mu); R->bad = 1; pthread_cond_broadcast(&R->cv); pthread_mutex_unlock(&R->mu); }
+    free(tmp); free(st);
+    return NULL;
+}
 static void *bgzf_gpu_stream_stager(void *v) {
     source_t *s = (source_t *)v;
     scan_state_t *S = (scan_state_t *)s->blk;                        /* (handed over in the field the host path uses for its block list) */
     s->blk = NULL;
-    const int dbg = getenv("HPGV_RUN_TRACE") != NULL; const double T0 = now_s();
-    int ok = 1;
-    unsigned char *tmp = (unsigned char *)malloc(65536);
-    int32_t *st = (int32_t *)malloc(sizeof(int32_t) * SCAN_ROWS_MAX);
-    ok = tmp && st;
-    const char *fe = getenv("HPGV_TEST_GPU_INFLATE_REFUSE_EVERY");     /* tests: exercise the host patch path */
-    const size_t refuse_every = fe ? (size_t)atol(fe) : 0;
-    int qh = 0, qn = 0, eof = 0;
-    size_t launched = 0, done_blocks = 0;
-    while (ok && (!eof || qn > 0)) {
-        if (!eof && qn < SCAN_SLOTS) {
-            scan_slot_t *q = &S->slot[(qh + qn) % SCAN_SLOTS];
-            /* a short first stretch, which the header reader and the pipeline wait for, then stretches that double */
-            size_t rows = launched == 0 ? 4096 : launched < 4096 + 32768 ? 32768 : launched < 4096 + 3 * 32768 ? 65536 : SCAN_ROWS_MAX;
-            if (S->rows_cap && rows > S->rows_cap) rows = S->rows_cap;
-            if (launched == 0 && S->first_n) { q->n = S->first_n; }  /* found when the path was chosen */
-            else ok = scan_next_rows(s, S, q, rows, dbg, T0);
-            if (ok && q->n == 0) eof = 1;
-            if (ok && q->n) {
-                ok = dev_text_grow(s->d_text, q->text_end + 16 + (q->text_end >> 4), &s->d_text_cap)      /* some room ahead: growing waits for the kernels that run */
-                  || dev_text_grow(s->d_text, q->text_end + 16, &s->d_text_cap);
-                ok = ok && hpgv_inflate_blocks_dev(g_ctx, (const uint8_t *)s->d_comp, q->d_in_off, q->d_in_len, q->d_out_off, q->d_out_len,
-                                                   (int)q->n, (uint8_t *)s->d_text, q->d_status, q->stream) == HPGV_OK;
-                const int first = launched == 0;
-                launched += q->n; qn++;
-                if (S->chain_pos >= (size_t)s->size) eof = 1;
-                if (ok && !first && !eof && qn < SCAN_SLOTS) continue;    /* (the first stretch decodes alone: 2 ms) */
-            }
-        }
-        if (ok && qn > 0) {                                          /* the oldest stretch in flight: wait, check, publish */
-            scan_slot_t *q = &S->slot[qh];
-            ok = hpgv_memcpy_d2h(g_ctx, st, q->d_status, q->n * 4, q->stream) == HPGV_OK;       /* synchronises that stream */
-            for (size_t k = 0; ok && k < q->n; k++)
-                if (st[k] || (refuse_every && (done_blocks + k) % refuse_every == 0)) {         /* not taken by the device decoder: the host decodes it, the text is patched */
-                    ok = !inflate_block(s->map + q->h_in_off[k], q->h_in_len[k], tmp, q->h_out_len[k])
-                      && hpgv_memcpy_h2d(g_ctx, (char *)s->d_text + q->h_out_off[k], tmp, q->h_out_len[k], q->stream) == HPGV_OK;
-                }
-            done_blocks += q->n;
-            if (dbg) fprintf(stderr, "stager: decoded up to block %zu at %.4f\n", done_blocks, now_s() - T0);
-            if (ok) {
-                pthread_mutex_lock(&s->g_mu);
-                s->g_done = done_blocks;
-                s->dev_ready = q->text_end;
-                pthread_cond_broadcast(&s->g_cv);
-                pthread_mutex_unlock(&s->g_mu);
-            }
-            qh = (qh + 1) % SCAN_SLOTS; qn--;
-        }
+    scan_ring_t R;
+    memset(&R, 0, sizeof R);
+    R.s = s; R.S = S; R.dbg = getenv("HPGV_RUN_TRACE") != NULL; R.T0 = now_s();
+    const int dbg = R.dbg; const double T0 = R.T0;
+    pthread_mutex_init(&R.mu, NULL); pthread_cond_init(&R.cv, NULL);
+    pthread_t pub;
+    int ok = pthread_create(&pub, NULL, bgzf_publisher, &R) == 0;
+    const int have_pub = ok;
+    size_t launched = 0;
+    for (size_t k = 0; ok; k++) {
+        pthread_mutex_lock(&R.mu);                                   /* a free slot */
+        while (k >= R.n_published + SCAN_SLOTS && !R.bad) pthread_cond_wait(&R.cv, &R.mu);
+        ok = !R.bad;
+        pthread_mutex_unlock(&R.mu);
+        if (!ok) break;
+        scan_slot_t *q = &S->slot[k % SCAN_SLOTS];
+        /* a short first stretch, which the header reader and the pipeline wait for, then stretches that double */
+        size_t rows = launched == 0 ? 4096 : launched < 4096 + 32768 ? 32768 : launched < 4096 + 3 * 32768 ? 65536 : SCAN_ROWS_MAX;
+        if (S->rows_cap && rows > S->rows_cap) rows = S->rows_cap;
+        if (k == 0 && S->first_n) q->n = S->first_n;                 /* found when the path was chosen */
+        else ok = scan_next_rows(s, S, q, rows, 1, dbg, T0) == 1;
+        if (!ok || q->n == 0) break;                                 /* (no rows: the file has ended) */
+        ok = dev_text_grow(s->d_text, q->text_end + 16 + (q->text_end >> 4), &s->d_text_cap)      /* some room ahead: growing waits for the kernels that run */
+          || dev_text_grow(s->d_text, q->text_end + 16, &s->d_text_cap);
+        ok = ok && hpgv_inflate_blocks_dev(g_ctx, (const uint8_t *)s->d_comp, q->d_in_off, q->d_in_len, q->d_out_off, q->d_out_len,
+                                           (int)q->n, (uint8_t *)s->d_text, q->d_status, q->stream) == HPGV_OK;
+        if (!ok) break;
+        launched += q->n;
+        pthread_mutex_lock(&R.mu);
+        R.n_launched = k + 1;
+        pthread_cond_broadcast(&R.cv);
+        pthread_mutex_unlock(&R.mu);
+        if (S->chain_pos >= (size_t)s->size) break;
     }
+    pthread_mutex_lock(&R.mu);
+    R.launch_done = 1;
+    if (!ok) R.bad = 1;
+    pthread_cond_broadcast(&R.cv);
+    pthread_mutex_unlock(&R.mu);
+    if (have_pub) pthread_join(pub, NULL);
+    ok = ok && !R.bad;
+    pthread_mutex_destroy(&R.mu); pthread_cond_destroy(&R.cv);
     for (int q = 0; q < SCAN_SLOTS; q++) if (S->slot[q].stream) (void)hpgv_stream_sync(g_ctx, S->slot[q].stream);      /* after a failure launches may still be running */
     pthread_mutex_lock(&s->g_mu);
     if (!ok) s->g_err = 1;
@@ -2495,7 +2569,7 @@ static void *bgzf_gpu_stream_stager(void *v) {
     if (dbg) fprintf(stderr, "stager: finished (%zu blocks, %.1f MB of text) at %.4f\n", S->blocks, S->text_pos / 1e6, now_s() - T0);
     for (int q = 1; q < SCAN_SLOTS; q++) if (S->slot[q].stream) (void)hpgv_stream_destroy(g_ctx, S->slot[q].stream);
     for (int q = 0; q < SCAN_SLOTS; q++) free(S->slot[q].h_in_off);
-    free(S); free(tmp); free(st);
+    free(S);
     if (s->d_comp) { (void)hpgv_dev_free(g_ctx, s->d_comp); s->d_comp = NULL; }      /* only the text is needed from here on */
     if (s->d_scan) { (void)hpgv_dev_free(g_ctx, s->d_scan); s->d_scan = NULL; }
     return NULL;
@@ -2506,7 +2580,9 @@ static int bgzf_stream_stage(source_t *s) {
     const int dbg = getenv("HPGV_RUN_TRACE") != NULL; const double T0 = now_s();
     scan_state_t *S = (scan_state_t *)calloc(1, sizeof *S);
     if (!S) return 1;
-    int ok = hpgv_stream_create(g_ctx, &s->rstream) == HPGV_OK && hpgv_stream_create(g_ctx, &s->cstream) == HPGV_OK;
+    /* the decoder's streams have the lowest priority: the batches' kernels go first whenever a compute unit has room */
+    const int low = !getenv("HPGV_NO_LOW_PRIORITY");
+    int ok = hpgv_stream_create(g_ctx, &s->rstream) == HPGV_OK && (low ? hpgv_stream_create_low(g_ctx, &s->cstream) : hpgv_stream_create(g_ctx, &s->cstream)) == HPGV_OK;
     const size_t slot_bytes = (size_t)SCAN_ROWS_MAX * 28;
     S->scratch_bytes = hpgv_bgzf_scan_scratch_bytes(SCAN_RANGE_MAX + 16, SCAN_ROWS_MAX);
     if (ok) ok = hpgv_dev_alloc(g_ctx, slot_bytes * SCAN_SLOTS + S->scratch_bytes + 256, &s->d_scan) == HPGV_OK;
@@ -2520,13 +2596,13 @@ static int bgzf_stream_stage(source_t *s) {
         ok = h != NULL;
         q->h_in_off = (uint64_t *)h; q->h_out_off = (uint64_t *)(h + (size_t)SCAN_ROWS_MAX * 8);
         q->h_in_len = (uint32_t *)(h + (size_t)SCAN_ROWS_MAX * 16); q->h_out_len = (uint32_t *)(h + (size_t)SCAN_ROWS_MAX * 20);
-        if (k == 0) q->stream = s->cstream; else ok = ok && hpgv_stream_create(g_ctx, &q->stream) == HPGV_OK;
+        if (k == 0) q->stream = s->cstream; else ok = ok && (low ? hpgv_stream_create_low(g_ctx, &q->stream) : hpgv_stream_create(g_ctx, &q->stream)) == HPGV_OK;
     }
     if (ok) S->d_scratch = (char *)s->d_scan + slot_bytes * SCAN_SLOTS;
     /* the first blocks, from the file's first megabytes: is this a file the device can chain, and how much text is it? */
     const char *tr = getenv("HPGV_TEST_SCAN_ROWS");
     S->rows_cap = tr && atol(tr) > 0 ? (size_t)atol(tr) : 0;
-    if (ok) ok = scan_next_rows(s, S, &S->slot[0], S->rows_cap && S->rows_cap < 4096 ? S->rows_cap : 4096, dbg, T0) && S->slot[0].n > 0;
+    if (ok) ok = scan_next_rows(s, S, &S->slot[0], S->rows_cap && S->rows_cap < 4096 ? S->rows_cap : 4096, 1, dbg, T0) == 1 && S->slot[0].n > 0;
     size_t est = 0;
     if (ok) {
         est = (size_t)((double)S->text_pos / (double)S->chain_pos * (double)s->size * 1.06) + ((size_t)64 << 20);

@@ -139,6 +139,7 @@ int  hpgv_dev_commit(hpgv_ctx *ctx, void *dptr, size_t bytes);
 int  hpgv_dev_release(hpgv_ctx *ctx, void *dptr);
 int  hpgv_memcpy_h2d(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream);
 int  hpgv_memcpy_d2h(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream);
+int  hpgv_memcpy_h2d_async(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream);   /* queued only; src page-locked and left alone until hpgv_stream_sync */
 int  hpgv_stream_sync(hpgv_ctx *ctx, void *stream);   /* stream NULL = default stream */
 /* page-locked host memory: buffers handed to the host entry points copy to the device at full
  * PCIe rate when they come from here (pageable memory is staged by the driver, 2-4x slower) */
@@ -147,6 +148,7 @@ int  hpgv_stream_sync(hpgv_ctx *ctx, void *stream);   /* stream NULL = default s
 int  hpgv_device_numa_node(hpgv_ctx *ctx, int *node);
 /* a non-blocking stream of the caller's own, e.g. for copies that overlap the engine's work */
 int  hpgv_stream_create(hpgv_ctx *ctx, void **stream);
+int  hpgv_stream_create_low(hpgv_ctx *ctx, void **stream);      /* lowest priority: its kernels give way to the other streams' */
 int  hpgv_stream_destroy(hpgv_ctx *ctx, void *stream);
 int  hpgv_host_alloc(hpgv_ctx *ctx, size_t bytes, void **hptr);
 int  hpgv_host_free(hpgv_ctx *ctx, void *hptr);
