@@ -10,7 +10,7 @@ extern "C" {
 // raw-DEFLATE blocks (the payloads of BGZF blocks) -> text, all on the device: block b occupies d_comp[in_off[b] .. +in_len[b])
 // and decodes to exactly out_len[b] bytes at d_text + out_off[b]; d_status[b] = 0, or a non-zero code for a block this decoder
 // does not take (the host then decodes that block).  Option inflate_wave: 2 = one wave per block, 0 = one lane per block
-// (wants a hundred thousand blocks per call), 1 (default) = by the number of blocks.
+// (wants a hundred thousand blocks per call), 1 (default) = by the number of blocks (fewer than 16 384: a wave each).
 int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
                             const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, uint8_t *d_text,
                             int32_t *d_status, void *stream) {
@@ -20,9 +20,10 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
         return fail(ctx, HPGV_ERR_INVALID, "bad inflate arguments");
     if (n_blocks == 0) return HPGV_OK;
     DeviceGuard g(ctx->device);
-    // one wave per block decodes a block in a millisecond or two whatever the number of blocks; one lane per block needs 38 ms
-    // for a launch of any size and is the faster one only when a launch holds a hundred thousand blocks or more
-    const bool wave = ctx->inflate_wave == 2 || (ctx->inflate_wave == 1 && n_blocks < 100000);
+    // one wave per block decodes a block in a millisecond or two whatever the number of blocks (4 096 blocks: 2 ms, 128 GB/s;
+    // 192 GB/s from 100 000 on); one lane per block takes 13 - 38 ms for a launch of any size, reaches 230 - 258 GB/s from
+    // 125 000 blocks on, and -- using no LDS -- leaves room on the compute units for the kernels of a pipeline beside it
+    const bool wave = ctx->inflate_wave == 2 || (ctx->inflate_wave == 1 && n_blocks < 16384);
     if (wave)
         hipLaunchKernelGGL(hpgv::k_inflate_wave, dim3((unsigned)n_blocks), dim3(64), 0, (hipStream_t)stream,
                            d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
