@@ -29,9 +29,7 @@ HPGV_TOKENIZER_TILES=0 python3 tools/bench_tokenize.py 10000 16000 > $O/${TAG}_t
 HPGV_TOKENIZER_TILES=0 python3 tools/bench_tokenize.py 200 800000 > $O/${TAG}_tokenizer_200_samples_line_by_line.json 2>> $O/${TAG}_text.err || exit 1
 bash tools/r02_text_traffic.sh > $O/${TAG}_text_traffic.log 2>&1 || { tail -5 $O/${TAG}_text_traffic.log; exit 1; }
 cd $R
-python3 tools/bench_inflate.py 125000 6 > $O/${TAG}_inflate_gpu_125k_blocks.json 2>> $O/${TAG}_text.err || exit 1
-python3 tools/bench_file_runner.py 10000 200000 plain,bgzf 64 > $O/${TAG}_file_runner_10k_samples.json 2>> $O/${TAG}_text.err || exit 1
-python3 tools/bench_file_runner.py 200 2000000 plain,bgzf 64 > $O/${TAG}_file_runner_200_samples.json 2>> $O/${TAG}_text.err || exit 1
-python3 tools/bench_file_runner.py 40000 200000 bgzf 64 > $O/${TAG}_file_runner_40k_samples_bgzf.json 2>> $O/${TAG}_text.err || exit 1
+# the bgzip path (both decoders, their PMC passes, the file runners): tools/r02_bgzf.sh
+bash $R/tools/r02_bgzf.sh > $O/${TAG}_bgzf.log 2>&1 || { tail -5 $O/${TAG}_bgzf.log; exit 1; }
 python3 tools/bench_host_entry.py > $O/${TAG}_host_entry_latency.jsonl 2>> $O/${TAG}_text.err || exit 1
 echo "text path done"
