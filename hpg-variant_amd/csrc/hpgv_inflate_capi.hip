@@ -27,8 +27,11 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
     if (wave)
         hipLaunchKernelGGL(hpgv::k_inflate_wave, dim3((unsigned)n_blocks), dim3(64), 0, (hipStream_t)stream,
                            d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
-    else
+    else if (ctx->inflate_wave != 3)
         hipLaunchKernelGGL(hpgv::k_inflate_blocks, dim3((unsigned)((n_blocks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                           d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
+    else                                                             // (A/B: the lane kernel with its symbol tables in LDS; profiles/experiments_that_did_not_pay.md)
+        hipLaunchKernelGGL(hpgv::k_inflate_blocks_lds, dim3((unsigned)((n_blocks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
                            d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
     HIPCHK(ctx, hipGetLastError());
     return HPGV_OK;

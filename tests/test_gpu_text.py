@@ -187,7 +187,7 @@ def test_text_entry_point_from_concurrent_threads(eng):
     assert not errors, errors
 
 
-@pytest.mark.parametrize("wave", [2, 0], ids=["wave_per_block", "lane_per_block"])
+@pytest.mark.parametrize("wave", [2, 0, 3], ids=["wave_per_block", "lane_per_block", "lane_per_block_lds_tables"])
 def test_inflate_blocks_on_the_gpu_against_zlib(wave):
     # hpgv_inflate_blocks_dev: raw-DEFLATE payloads (as in BGZF blocks) of genotype text, incompressible bytes (stored
     # blocks), runs, every zlib strategy incl. fixed codes, sizes 0 .. 65 280 -- one wave per block (the default) and one
