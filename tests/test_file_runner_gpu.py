@@ -477,3 +477,18 @@ def test_run_assoc_from_bgzf_decoded_on_the_gpu(host, tmp_path, capfd):
                     [open(o("st") + ext, "rb").read() for ext in (".stats-variants", ".stats-samples", ".stats-summary")]
     assert all(len(x) > 0 for x in both["p"])
     assert both["p"] == both["z"]
+    # a file cut off inside a block, and one with bytes that are no block after its end: an error, by either way to the
+    # block table, not a hang and not a result
+    whole = open(packed, "rb").read()
+    for tag, blob in (("cut", whole[:len(whole) * 2 // 3 + 5]), ("tail", whole + b"not a block" * 20)):
+        bad = str(tmp_path / ("bad_" + tag + ".vcf.gz"))
+        open(bad, "wb").write(blob)
+        for env in ({}, {"HPGV_BGZF_HOST_TABLE": "1"}):
+            os.environ.update(env)
+            try:
+                n = C.c_long(0)
+                rc = host.hpgv_run_assoc(bad.encode(), ped, str(tmp_path / "bad_out").encode(), 1, 1 << 17, C.byref(n))
+            finally:
+                for k in env:
+                    del os.environ[k]
+            assert rc != 0, (tag, env, n.value)

@@ -199,7 +199,16 @@ def test_inflate_blocks_on_the_gpu_against_zlib(wave):
     for n in (0, 1, 17, 300, 4096, 65280, 65280, 30000):
         txt = ("\t".join(codes[rng.choice(5, size=n // 4 + 1, p=[0.5, 0.3, 0.15, 0.01, 0.04])]) + "\n").encode()[:n]
         blobs += [txt, bytes(rng.integers(0, 256, n, dtype=np.uint8)), b"\0" * n, (b"ACGT\t.\tPASS\n" * (n // 12 + 1))[:n]]
+    # matches from further back than the wave decoder's 4 KiB ring, up to the longest (258 bytes): a 20 KB random chunk
+    # three times over; several DEFLATE blocks in one stream, with the empty stored block a sync flush leaves between them
+    chunk = bytes(rng.integers(0, 256, 20000, dtype=np.uint8))
+    blobs += [chunk * 3 + chunk[:5280], (chunk[:9000] + b"\t0/1" * 2000) * 2]
     comp, raw = [], []
+    for blob in blobs[:3]:
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        parts = [co.compress(blob[:len(blob) // 3]), co.flush(zlib.Z_SYNC_FLUSH), co.compress(blob[len(blob) // 3:len(blob) // 2]),
+                 co.flush(zlib.Z_FULL_FLUSH), co.compress(blob[len(blob) // 2:]), co.flush()]
+        comp.append(b"".join(parts)); raw.append(blob)
     for k, blob in enumerate(blobs):
         for level, strategy in ((1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_FILTERED), (6, zlib.Z_HUFFMAN_ONLY),
                                 (6, zlib.Z_RLE), (6, zlib.Z_FIXED), (0, zlib.Z_DEFAULT_STRATEGY)):
