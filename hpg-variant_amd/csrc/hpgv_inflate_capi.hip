@@ -24,8 +24,10 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
     // 192 GB/s from 100 000 on); one lane per block takes 13 - 38 ms for a launch of any size, reaches 230 - 258 GB/s from
     // 125 000 blocks on, and -- using no LDS -- leaves room on the compute units for the kernels of a pipeline beside it
     const bool wave = ctx->inflate_wave == 2 || (ctx->inflate_wave == 1 && n_blocks < 16384);
+    // (experiment: unused dynamic LDS per wave caps the waves per compute unit and leaves LDS for the kernels beside it)
+    static const unsigned lds_pad = getenv("HPGV_INFLATE_LDS_PAD") ? (unsigned)atoi(getenv("HPGV_INFLATE_LDS_PAD")) : 0u;
     if (wave)
-        hipLaunchKernelGGL(hpgv::k_inflate_wave, dim3((unsigned)n_blocks), dim3(64), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(hpgv::k_inflate_wave, dim3((unsigned)n_blocks), dim3(64), lds_pad, (hipStream_t)stream,
                            d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
     else if (ctx->inflate_wave != 3)
         hipLaunchKernelGGL(hpgv::k_inflate_blocks, dim3((unsigned)((n_blocks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
