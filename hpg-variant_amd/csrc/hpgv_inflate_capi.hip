@@ -25,14 +25,20 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
     // 125 000 blocks on, and -- using no LDS -- leaves room on the compute units for the kernels of a pipeline beside it
     const bool wave = ctx->inflate_wave == 2 || (ctx->inflate_wave == 1 && n_blocks < 16384);
     // (experiment: unused dynamic LDS per wave caps the waves per compute unit and leaves LDS for the kernels beside it)
-    static const unsigned lds_pad = getenv("HPGV_INFLATE_LDS_PAD") ? (unsigned)atoi(getenv("HPGV_INFLATE_LDS_PAD")) : 0u;
+    const char *lp = getenv("HPGV_INFLATE_LDS_PAD");
+    const unsigned lds_pad = lp ? (unsigned)atoi(lp) : 0u;
     if (wave)
         hipLaunchKernelGGL(hpgv::k_inflate_wave, dim3((unsigned)n_blocks), dim3(64), lds_pad, (hipStream_t)stream,
                            d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
-    else if (ctx->inflate_wave != 3)
-        hipLaunchKernelGGL(hpgv::k_inflate_blocks, dim3((unsigned)((n_blocks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+    else if (ctx->inflate_wave != 3) {
+        // (experiment: HPGV_INFLATE_LANE_WGS = workgroups per compute unit in flight; 0 = one per 64 blocks)
+        const char *pc = getenv("HPGV_INFLATE_LANE_WGS");
+        const unsigned per_cu = pc ? (unsigned)atoi(pc) : 0u;
+        unsigned grid = (unsigned)((n_blocks + 63) / 64);
+        if (per_cu && grid > per_cu * (unsigned)ctx->n_cus) grid = per_cu * (unsigned)ctx->n_cus;
+        hipLaunchKernelGGL(hpgv::k_inflate_blocks, dim3(grid), dim3(64), 0, (hipStream_t)stream,
                            d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
-    else                                                             // (A/B: the lane kernel with its symbol tables in LDS; profiles/experiments_that_did_not_pay.md)
+    } else                                                           // (A/B: the lane kernel with its symbol tables in LDS; profiles/experiments_that_did_not_pay.md)
         hipLaunchKernelGGL(hpgv::k_inflate_blocks_lds, dim3((unsigned)((n_blocks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
                            d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
     HIPCHK(ctx, hipGetLastError());

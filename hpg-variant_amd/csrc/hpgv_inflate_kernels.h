@@ -123,12 +123,10 @@ __device__ __forceinline__ int inflate_construct(InflateCode &h, const uint8_t *
     return left;
 }
 
-static __global__ void __launch_bounds__(64) k_inflate_blocks(const uint8_t *__restrict__ comp, const uint64_t *__restrict__ in_off,
-                                                       const uint32_t *__restrict__ in_len, const uint64_t *__restrict__ out_off,
-                                                       const uint32_t *__restrict__ out_len, int n_blocks,
-                                                       uint8_t *__restrict__ text, int32_t *__restrict__ status) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_blocks) return;
+__device__ __forceinline__ void inflate_one_block(const uint8_t *__restrict__ comp, const uint64_t *__restrict__ in_off,
+                                                  const uint32_t *__restrict__ in_len, const uint64_t *__restrict__ out_off,
+                                                  const uint32_t *__restrict__ out_len, int b,
+                                                  uint8_t *__restrict__ text, int32_t *__restrict__ status) {
     const uint16_t len_base[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
     const uint8_t len_extra[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
     const uint16_t dist_base[30] = {1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,257,385,513,769,1025,1537,2049,3073,4097,6145,8193,12289,16385,24577};
@@ -236,6 +234,16 @@ static __global__ void __launch_bounds__(64) k_inflate_blocks(const uint8_t *__r
     }
     if (!rc && n_out != cap) rc = 18;
     status[b] = rc;
+}
+
+static __global__ void __launch_bounds__(64) k_inflate_blocks(const uint8_t *__restrict__ comp, const uint64_t *__restrict__ in_off,
+                                                       const uint32_t *__restrict__ in_len, const uint64_t *__restrict__ out_off,
+                                                       const uint32_t *__restrict__ out_len, int n_blocks,
+                                                       uint8_t *__restrict__ text, int32_t *__restrict__ status) {
+    // one workgroup per 64 blocks, or (a grid shorter than that) workgroups that go on to further blocks: fewer waves on
+    // the compute units, which leaves registers for the kernels of a pipeline beside the decoder
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += gridDim.x * blockDim.x)
+        inflate_one_block(comp, in_off, in_len, out_off, out_len, b, text, status);
 }
 
 // the same decoder with the symbol tables in LDS (38 KB per workgroup: four workgroups per compute unit) -- measured, not the
