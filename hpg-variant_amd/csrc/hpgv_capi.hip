@@ -47,7 +47,9 @@ static int batch_sources(hpgv_ctx *ctx, Slot *s, const uint8_t *gt, size_t pitch
                          hpgv::BatchArgs *A) {
     int rc;
     const size_t bytes = (size_t)(n_variants - 1) * pitch + (size_t)n_samples;     // the last row need not be a whole pitch
-    const void *src = mapped_view(gt, bytes);
+    // page-locked rows are read in place by the kernel -- unless batch_copy asks for the copy engine first (it moves 2 MB in
+    // 35 us where the kernel's own reads over the bus take 44; the kernel then runs on device memory)
+    const void *src = ctx->batch_copy ? nullptr : mapped_view(gt, bytes);
     if (!src) {
         if ((rc = ensure(ctx, s, 0, bytes + 16))) return rc;
         HIPCHK(ctx, hipMemcpyAsync(s->buf[0], gt, bytes, hipMemcpyHostToDevice, s->stream));
@@ -205,6 +207,7 @@ int hpgv_create(int device_id, hpgv_ctx **out) {
         else if (ok && prop.maxSharedMemoryPerMultiProcessor >= (size_t)want) ctx->batch_lds_max = want;
         (void)hipGetLastError();
     }
+    if (const char *bc = getenv("HPGV_BATCH_COPY")) ctx->batch_copy = atoi(bc) ? 1 : 0;
     if (const char *bf = getenv("HPGV_BATCH_FUSED")) ctx->batch_fused = atoi(bf) ? 1 : 0;      // diagnosis: 0 = the kernel chains
     if (const char *iw = getenv("HPGV_INFLATE_WAVE")) ctx->inflate_wave = atoi(iw) < 0 ? 0 : atoi(iw) > 3 ? 3 : atoi(iw);   // diagnosis: 0 = lane per block, 2 = wave per block, 1 = by size
     if (const char *tt = getenv("HPGV_TOKENIZER_TILES")) ctx->tokenizer_tiles = atoi(tt) ? 1 : 0;   // diagnosis: 0 = the three-sweep tokenizer
@@ -340,6 +343,8 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
     } else if (!strcmp(key, "scan_lds")) {
         if (value < 0 || value > 160 * 1024) return fail(ctx, HPGV_ERR_INVALID, "scan_lds must be in [0, 163840]");
         ctx->scan_lds = value;
+    } else if (!strcmp(key, "batch_copy")) {
+        ctx->batch_copy = value ? 1 : 0;
     } else if (!strcmp(key, "inflate_wave")) {
         if (value < 0 || value > 3) return fail(ctx, HPGV_ERR_INVALID, "inflate_wave must be 0 (lane per block), 1 (by the number of blocks), 2 (wave per block) or 3 (lane per block, symbol tables in LDS)");
         ctx->inflate_wave = value;

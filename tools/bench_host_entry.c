@@ -50,8 +50,9 @@ int main(int argc, char **argv) {
         memcpy(pinned, pageable, bytes + (size_t)B);
         int32_t *ints = malloc(sizeof(int32_t) * 8 * (size_t)B);
         double *dbl = malloc(sizeof(double) * 3 * (size_t)B);
-        for (int fused = 1; fused >= 0; fused--) {
-            CHK(hpgv_set_option(ctx, "batch_fused", fused));
+        for (int fused = 2; fused >= 0; fused--) {                   /* 2: the fused kernel after a copy by the copy engine (option batch_copy) */
+            CHK(hpgv_set_option(ctx, "batch_fused", fused ? 1 : 0));
+            CHK(hpgv_set_option(ctx, "batch_copy", fused == 2));
             for (int where = 0; where < 2; where++) {
                 const uint8_t *gt = where == 0 ? pinned : pageable;
                 for (int tool = 0; tool < 3; tool++) {
@@ -75,6 +76,7 @@ int main(int argc, char **argv) {
             }
         }
         CHK(hpgv_set_option(ctx, "batch_fused", 1));
+        CHK(hpgv_set_option(ctx, "batch_copy", 0));
         free(ints); free(dbl); free(pageable);
         CHK(hpgv_host_free(ctx, pinned));
     }
