@@ -4,7 +4,7 @@
 // The lane-per-block decoder (hpgv_inflate_kernels.h) keeps every lane's code tables in private memory and writes its
 // text a byte at a time 64 KiB apart from its neighbours: it moves ten times the bytes it decodes and a block takes a lane
 // 38 ms.  Here the 64 lanes of a wave work on ONE block:
-//   * the compressed bytes come in through the scalar cache, eight at a time, one load ahead of the wave-uniform bit buffer;
+//   * the compressed bytes come in through the scalar cache, a dword at a time, two loads ahead of the wave-uniform bit buffer;
 //   * the Huffman codes live in LDS as look-up tables (10 bits for literals / lengths, 8 for distances; a longer code takes
 //     the canonical walk over the code's length histogram), built by the whole wave: every lane decodes its share of the
 //     table's indices with that same walk;
@@ -24,7 +24,7 @@
 //     compiler leaves the control flow as written (scalar compares and branches) instead of structurizing it.
 // A block is decoded in a fraction of a millisecond, and only its compressed bytes, its text and the far match sources
 // move.  Same contract as the lane kernel: anything irregular ends with a non-zero status and the host decodes that
-// block.  The compressed bytes must be readable up to 8 bytes past the last block's end.
+// block.  The compressed bytes must be readable up to 4 bytes past the last block's end.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,7 +33,7 @@ namespace hpgv {
 
 enum { INF2_ROOT_L = 10, INF2_ROOT_D = 8, INF2_ROOT_C = 7 };
 // table entry: bits 0-3 code length (0 = not in the table), 4-7 extra bits, 8-9 kind (0 literal, 1 base + extra bits,
-// 2 end of block, 3 not a symbol of the format), 16-31 literal / base
+// 2 end of block, 3 not a symbol of the format), 10-14 code length + extra bits, 16-31 literal / base
 // LDS map (bytes); the code-length code's tables lie where the distance table is built afterwards
 enum { INF2_LUT_L = 0, INF2_LUT_D = 4096, INF2_LUT_C = 4096, INF2_SYM_C = 4608, INF2_CNT_C = 4672, INF2_CLEN = 4704,
        INF2_SYM_L = 5120, INF2_SYM_D = 5696, INF2_CNT_L = 5760, INF2_CNT_D = 5792, INF2_LENS = 5824, INF2_RUN = 6208,
@@ -55,14 +55,14 @@ __device__ __forceinline__ uint32_t inf2_entry_litlen(uint32_t sym, uint32_t len
     const uint32_t xb = wide ? ((s >> 2) - 1) & 7 : 0u;
     const uint32_t base = s == 28 ? 258u : wide ? 3 + ((4 + (s & 3)) << xb) : 3 + s;
     const uint32_t lit = len | (sym << 16), eob = len | (2u << 8), bad = len | (3u << 8);
-    const uint32_t mat = len | (xb << 4) | (1u << 8) | (base << 16);
+    const uint32_t mat = len | (xb << 4) | (1u << 8) | ((len + xb) << 10) | (base << 16);
     return sym < 256 ? lit : sym == 256 ? eob : s >= 29 ? bad : mat;
 }
 __device__ __forceinline__ uint32_t inf2_entry_dist(uint32_t ds, uint32_t len) {
     const bool wide = ds >= 4;
     const uint32_t xb = wide ? ((ds >> 1) - 1) & 15 : 0u;
     const uint32_t base = wide ? 1 + ((2 + (ds & 1)) << xb) : 1 + ds;
-    return ds >= 30 ? len | (3u << 8) : len | (xb << 4) | (1u << 8) | (base << 16);
+    return ds >= 30 ? len | (3u << 8) : len | (xb << 4) | (1u << 8) | ((len + xb) << 10) | (base << 16);
 }
 
 // lanes whose value v (0 .. 15) equals this lane's
@@ -168,24 +168,26 @@ __device__ __forceinline__ uint32_t inf2_slow(const uint8_t *smem, uint64_t buf,
     return 0;
 }
 
-// the compressed stream of one block: wave-uniform bit buffer fed through the scalar cache, a pair of dwords at a time
+// the compressed stream of one block: wave-uniform bit buffer fed through the scalar cache, a dword at a time, two dwords
+// loaded ahead (a scalar load's result is only waited for when it moves up, one refill later)
 struct Inf2In {
     uint64_t buf; int cnt;                             // cnt valid bits in buf
-    uint64_t w0, w1;                                   // the pair being handed out, the pair after it (loaded ahead)
-    int half;                                          // dwords of w0 handed out
+    uint32_t n0, n1;                                   // the next dword, the one after it
     // (the constant address space: the kernel never writes the compressed bytes, and this makes the loads scalar ones)
-    const __attribute__((address_space(4))) uint64_t *base; int n_pairs, next_pair, taken, len_bits, skip;
-    __device__ __forceinline__ uint64_t load(int i) const { return base[i < n_pairs ? i : n_pairs - 1]; }
-    // the stream starts at byte `start` of comp and has `len` bytes (len = 0: one pair is read all the same)
+    const __attribute__((address_space(4))) char *base; uint32_t next_off, last_off;     // byte offsets of dwords from base
+    int taken, len_bits, skip;
+    __device__ __forceinline__ uint32_t load(uint32_t off) const {
+        return *(const __attribute__((address_space(4))) uint32_t *)(base + (off < last_off ? off : last_off));
+    }
+    // the stream starts at byte `start` of comp and has `len` bytes (len = 0: one dword is read all the same)
     __device__ __forceinline__ void open(const uint8_t *comp, uint64_t start, uint32_t len) {
-        const uint64_t a = start & ~7ull;
-        base = (const __attribute__((address_space(4))) uint64_t *)(uintptr_t)(comp + a);
-        skip = (int)(start - a) * 8;                                  // 0 .. 56 bits of the first pair are not the stream's
-        n_pairs = (int)(((uint32_t)(start - a) + len + 7) >> 3);
-        n_pairs = n_pairs < 1 ? 1 : n_pairs;
+        const uint64_t a = start & ~3ull;
+        base = (const __attribute__((address_space(4))) char *)(uintptr_t)(comp + a);
+        skip = (int)(start - a) * 8;                                  // 0 .. 24 bits of the first dword are not the stream's
+        const uint32_t n_words = ((uint32_t)(start - a) + len + 3) >> 2;
+        last_off = n_words ? (n_words - 1) * 4 : 0;
         len_bits = (int)len * 8;
-        w0 = load(0); w1 = load(1); next_pair = 2; half = 0; taken = 0; buf = 0; cnt = 0;
-        if (skip >= 32) { half = 1; skip -= 32; }                     // (consumed_bits counts from the dword the stream starts in)
+        n0 = load(0); n1 = load(4); next_off = 8; taken = 0; buf = 0; cnt = 0;
         refill();
         buf >>= skip; cnt -= skip;
         refill();
@@ -193,10 +195,8 @@ struct Inf2In {
     // at least 33 valid bits afterwards
     __device__ __forceinline__ void refill() {
         if (cnt <= 32) {
-            const uint32_t w = half ? (uint32_t)(w0 >> 32) : (uint32_t)w0;
-            if (half) { w0 = w1; w1 = load(next_pair); next_pair++; }
-            half ^= 1; taken++;
-            buf |= (uint64_t)w << cnt; cnt += 32;
+            buf |= (uint64_t)n0 << cnt; cnt += 32;
+            n0 = n1; n1 = load(next_off); next_off += 4; taken++;
         }
     }
     __device__ __forceinline__ uint32_t take(int n) { const uint32_t v = (uint32_t)(buf & ((1ull << n) - 1)); buf >>= n; cnt -= n; return v; }
@@ -343,8 +343,21 @@ static __global__ void __launch_bounds__(64) k_inflate_wave(const uint8_t *__res
             // lane 0: the literal / length code at the low bits; lane i: the distance code that starts i bits on
             const uint32_t ent = inf2_r32(smem, look_base + (((lo >> look_shift) & look_mask) << 2));
             uint32_t e = inf2_u(ent);
-            const bool spec = (e & 0x300u) == 0x100u;                 // a length code out of the table: the common case
-            if (!spec) {
+            uint32_t len, dist;
+            if ((e & 0x300u) == 0x100u) {                             // a length code out of the table: the common case
+                const uint32_t used = (e >> 10) & 31;                 // the code and its extra bits; the distance code follows
+                len = (e >> 16) + ((lo >> (e & 15)) & ((1u << ((e >> 4) & 15)) - 1));
+                uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)ent, (int)used);
+                B.buf >>= used; B.cnt -= (int)used;
+                B.refill();
+                if ((d & 0x300u) != 0x100u) {                         // not in the distance table (a long code), or no distance
+                    if ((d & 15) == 0) d = inf2_slow<1>(smem, B.buf, INF2_CNT_D, INF2_SYM_D);
+                    if ((d & 0x300u) != 0x100u) { rc = 16; break; }
+                }
+                dist = (d >> 16) + (((uint32_t)B.buf >> (d & 15)) & ((1u << ((d >> 4) & 15)) - 1));
+                const uint32_t du = (d >> 10) & 31;
+                B.buf >>= du; B.cnt -= (int)du;
+            } else {
                 if ((e & 15) == 0) { e = inf2_slow<0>(smem, B.buf, INF2_CNT_L, INF2_SYM_L); if (!e) { rc = 13; break; } }
                 if ((e & 0x300u) == 0) {                              // literal
                     const uint32_t l = e & 15;
@@ -362,22 +375,22 @@ static __global__ void __launch_bounds__(64) k_inflate_wave(const uint8_t *__res
                     if ((e & 0x300u) == 0x300u) rc = 15;
                     break;
                 }
-            }
-            {                                                         // a length: the distance code follows its extra bits
-                const uint32_t l = e & 15, xb = (e >> 4) & 15, used = l + xb;
-                const uint32_t len = (e >> 16) + ((uint32_t)(B.buf >> l) & ((1u << xb) - 1));
-                uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)ent, (int)(used & 31));        // (of no use after the slow walk)
+                // a length code longer than the table's index: the distance code is looked up on its own
+                const uint32_t used = (e >> 10) & 31;
+                len = (e >> 16) + ((uint32_t)(B.buf >> (e & 15)) & ((1u << ((e >> 4) & 15)) - 1));
                 B.buf >>= used; B.cnt -= (int)used;
                 B.refill();
-                if (!spec) d = inf2_u(inf2_r32(smem, (uint32_t)INF2_LUT_D + 4 * ((uint32_t)B.buf & ((1u << INF2_ROOT_D) - 1))));
+                uint32_t d = inf2_u(inf2_r32(smem, (uint32_t)INF2_LUT_D + 4 * ((uint32_t)B.buf & ((1u << INF2_ROOT_D) - 1))));
                 if ((d & 0x300u) != 0x100u) {
                     if ((d & 15) == 0) d = inf2_slow<1>(smem, B.buf, INF2_CNT_D, INF2_SYM_D);
                     if ((d & 0x300u) != 0x100u) { rc = 16; break; }
                 }
-                const uint32_t ld = d & 15, xd = (d >> 4) & 15;
-                const uint32_t dist = (d >> 16) + ((uint32_t)(B.buf >> ld) & ((1u << xd) - 1));
-                B.buf >>= ld + xd; B.cnt -= (int)(ld + xd);
-                if ((int)((n_out - dist) | (cap - n_out - len)) < 0) { rc = 17; break; }      // dist > n_out, or the text would overflow
+                dist = (d >> 16) + (((uint32_t)B.buf >> (d & 15)) & ((1u << ((d >> 4) & 15)) - 1));
+                const uint32_t du = (d >> 10) & 31;
+                B.buf >>= du; B.cnt -= (int)du;
+            }
+            {
+                if (dist > n_out || len > cap - n_out) { rc = 17; break; }      // further back than the text goes, or the text would overflow
                 {                                                     // the ring write and the store of the match before
                     const bool on_ = lane < pend_n;
                     inf2_w8(smem, inf2_ring_at(on_, pend_pos + lane), pend_v);
