@@ -31,13 +31,16 @@
 
 namespace hpgv {
 
-enum { INF2_ROOT_L = 10, INF2_ROOT_D = 8, INF2_ROOT_C = 7 };
+enum { INF2_ROOT_L = 8, INF2_ROOT_D = 8, INF2_ROOT_C = 7 };
 // table entry: bits 0-3 code length (0 = not in the table), 4-7 extra bits, 8-9 kind (0 literal, 1 base + extra bits,
 // 2 end of block, 3 not a symbol of the format), 10-14 code length + extra bits, 16-31 literal / base
-// LDS map (bytes); the code-length code's tables lie where the distance table is built afterwards
-enum { INF2_LUT_L = 0, INF2_LUT_D = 4096, INF2_LUT_C = 4096, INF2_SYM_C = 4608, INF2_CNT_C = 4672, INF2_CLEN = 4704,
-       INF2_SYM_L = 5120, INF2_SYM_D = 5696, INF2_CNT_L = 5760, INF2_CNT_D = 5792, INF2_LENS = 5824, INF2_RUN = 6208,
-       INF2_DUMP = 6240, INF2_RING = 6496, INF2_WINDOW = 4096, INF2_LDS = INF2_RING + INF2_WINDOW };
+// LDS map (bytes); the code-length code's tables lie where the literal / length table is built afterwards
+enum { INF2_LUT_L = 0, INF2_LUT_D = INF2_LUT_L + (4 << INF2_ROOT_L), INF2_LUT_C = INF2_LUT_L, INF2_SYM_C = INF2_LUT_C + (4 << INF2_ROOT_C),
+       INF2_CNT_C = INF2_SYM_C + 64, INF2_CLEN = INF2_CNT_C + 32,
+       INF2_SYM_L = INF2_LUT_D + (4 << INF2_ROOT_D), INF2_SYM_D = INF2_SYM_L + 576, INF2_CNT_L = INF2_SYM_D + 64, INF2_CNT_D = INF2_CNT_L + 32,
+       INF2_LENS = INF2_CNT_D + 32, INF2_RUN = INF2_LENS + 384, INF2_DUMP = INF2_RUN + 32, INF2_RING = INF2_DUMP + 256,
+       INF2_WINDOW = 4096, INF2_LDS = INF2_RING + INF2_WINDOW };
+static_assert(INF2_CLEN + 32 <= INF2_LUT_D, "the code-length code's tables lie inside the literal / length table's room");
 
 __device__ __forceinline__ uint32_t inf2_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // LDS accessors by byte offset; `on ? at : spare` keeps a lane's store without a branch
@@ -245,6 +248,7 @@ static __global__ void __launch_bounds__(64) k_inflate_wave(const uint8_t *__res
     int rc = 0, last = 0;
     uint32_t pend_v = 0, pend_pos = 0, pend_n = 0;      // the (last 64 bytes of a) match read from the ring, not yet written
     // the symbol loop's table read, per lane: which table, from which bit of the buffer on, how many index bits
+    const uint32_t vz = __builtin_amdgcn_mbcnt_lo(0u, 0u);
     const uint32_t look_base = lane == 0 ? (uint32_t)INF2_LUT_L : (uint32_t)INF2_LUT_D, look_shift = lane & 31,
                    look_mask = lane == 0 ? (1u << INF2_ROOT_L) - 1 : (1u << INF2_ROOT_D) - 1;
     while (!last && !rc) {
@@ -346,7 +350,10 @@ static __global__ void __launch_bounds__(64) k_inflate_wave(const uint8_t *__res
             uint32_t len, dist;
             if ((e & 0x300u) == 0x100u) {                             // a length code out of the table: the common case
                 const uint32_t used = (e >> 10) & 31;                 // the code and its extra bits; the distance code follows
-                len = (e >> 16) + ((lo >> (e & 15)) & ((1u << ((e >> 4) & 15)) - 1));
+                // (the scalar unit is what bounds this loop: the fields of the two entries are taken apart in the vector unit --
+                // `vz` is 0 in every lane but not known to be uniform, so what is computed from it stays there)
+                const uint32_t ev = e | vz;
+                len = inf2_u((ev >> 16) + (((lo | vz) >> (ev & 15)) & ((1u << ((ev >> 4) & 15)) - 1)));
                 uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)ent, (int)used);
                 B.buf >>= used; B.cnt -= (int)used;
                 B.refill();
@@ -354,7 +361,8 @@ static __global__ void __launch_bounds__(64) k_inflate_wave(const uint8_t *__res
                     if ((d & 15) == 0) d = inf2_slow<1>(smem, B.buf, INF2_CNT_D, INF2_SYM_D);
                     if ((d & 0x300u) != 0x100u) { rc = 16; break; }
                 }
-                dist = (d >> 16) + (((uint32_t)B.buf >> (d & 15)) & ((1u << ((d >> 4) & 15)) - 1));
+                const uint32_t dv = d | vz;
+                dist = inf2_u((dv >> 16) + ((((uint32_t)B.buf | vz) >> (dv & 15)) & ((1u << ((dv >> 4) & 15)) - 1)));
                 const uint32_t du = (d >> 10) & 31;
                 B.buf >>= du; B.cnt -= (int)du;
             } else {
@@ -396,6 +404,14 @@ static __global__ void __launch_bounds__(64) k_inflate_wave(const uint8_t *__res
                     inf2_w8(smem, inf2_ring_at(on_, pend_pos + lane), pend_v);
                     __builtin_amdgcn_raw_buffer_store_b8((uint8_t)pend_v, ors, on_ ? (int)(pend_pos + lane) : -1, 0, 0);
                     pend_n = 0;
+                }
+                // the everyday match: from the ring, not longer than the distance, 64 bytes at most -- one test (in the vector unit)
+                const uint32_t dvz = dist | vz, lvz = len | vz;
+                if (!inf2_u((uint32_t)(dvz > (uint32_t)INF2_WINDOW) | (uint32_t)(dvz < lvz) | (uint32_t)(lvz > 64u))) {
+                    pend_pos = n_out; pend_n = len;
+                    pend_v = inf2_r8(smem, (uint32_t)INF2_RING + ((n_out - dist + lane) & (INF2_WINDOW - 1)));
+                    n_out += len;
+                    continue;
                 }
                 if (dist > INF2_WINDOW) {                             // from further back than the ring holds: out of global memory
                     #pragma unroll 1

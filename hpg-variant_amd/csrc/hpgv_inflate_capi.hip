@@ -9,8 +9,8 @@ extern "C" {
 
 // raw-DEFLATE blocks (the payloads of BGZF blocks) -> text, all on the device: block b occupies d_comp[in_off[b] .. +in_len[b])
 // and decodes to exactly out_len[b] bytes at d_text + out_off[b]; d_status[b] = 0, or a non-zero code for a block this decoder
-// does not take (the host then decodes that block).  Option inflate_wave: 2 = one wave per block, 0 = one lane per block
-// (wants a hundred thousand blocks per call), 1 (default) = by the number of blocks (fewer than 16 384: a wave each).
+// does not take (the host then decodes that block).  Option inflate_wave: 1 (default) or 2 = one wave per block, 0 = one lane per
+// block (wants a hundred thousand blocks per call), 3 = the lane kernel with its symbol tables in LDS.
 int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
                             const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, uint8_t *d_text,
                             int32_t *d_status, void *stream) {
@@ -20,10 +20,11 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
         return fail(ctx, HPGV_ERR_INVALID, "bad inflate arguments");
     if (n_blocks == 0) return HPGV_OK;
     DeviceGuard g(ctx->device);
-    // one wave per block decodes a block in a millisecond or two whatever the number of blocks (4 096 blocks: 2 ms, 128 GB/s;
-    // 192 GB/s from 100 000 on); one lane per block takes 13 - 38 ms for a launch of any size, reaches 230 - 258 GB/s from
-    // 125 000 blocks on, and -- using no LDS -- leaves room on the compute units for the kernels of a pipeline beside it
-    const bool wave = ctx->inflate_wave == 2 || (ctx->inflate_wave == 1 && n_blocks < 16384);
+    // one wave per block: a block in a millisecond whatever the number of blocks (4 096 blocks: 1.5 ms), 262 - 267 GB/s from
+    // 125 000 blocks on, and only the job's own bytes move; one lane per block (inflate_wave = 0): 13 - 38 ms for a launch of
+    // any size, 230 - 258 GB/s from 125 000 blocks on, ten times the job's bytes through HBM.  inflate_wave = 1 is "the
+    // library's choice": the wave kernel
+    const bool wave = ctx->inflate_wave == 2 || ctx->inflate_wave == 1;
     // (experiment: unused dynamic LDS per wave caps the waves per compute unit and leaves LDS for the kernels beside it)
     const char *lp = getenv("HPGV_INFLATE_LDS_PAD");
     const unsigned lds_pad = lp ? (unsigned)atoi(lp) : 0u;

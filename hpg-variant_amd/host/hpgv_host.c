@@ -2134,12 +2134,9 @@ static void *bgzf_gpu_stager(void *v) {
     int32_t *st = (int32_t *)malloc(sizeof(int32_t) * 4 * GPU_STRETCH);
     unsigned char *tmp = (unsigned char *)malloc(65536);
     ok = ok && st && tmp;
-    /* The decoder gives a block to a wave when a launch holds fewer than 16 384 blocks -- a block then takes a
-     * millisecond or two -- and to a lane otherwise: such a launch takes the time one lane needs for its block (13 - 40 ms)
-     * whatever the number of blocks, but decodes more text per second once it holds a hundred thousand of them and, using
-     * no LDS, leaves the batches' kernels room on the compute units.  So: a short first stretch (wave per block, 2 ms),
-     * which the header reader and the pipeline wait for, then stretches that double up to 131 072 blocks, decoding side by
-     * side, up to GPU_INFLIGHT launches on streams of their own.  Published in file order. */
+    /* (the host's table, HPGV_BGZF_HOST_TABLE=1)  A short first stretch, which the header reader and the pipeline wait for
+     * (a wave per block: 1.5 ms), then stretches that double up to 131 072 blocks, decoding side by side, up to GPU_INFLIGHT
+     * launches on streams of their own.  Published in file order. */
     enum { GPU_INFLIGHT = 4, GPU_FIRST = 4096 };
     const int inflight = GPU_INFLIGHT;
     void *cs[GPU_INFLIGHT] = { s->cstream, NULL, NULL, NULL };
