@@ -618,7 +618,8 @@ int hpgv_dev_reserve(hpgv_ctx *ctx, size_t max_bytes, void **dptr) {
     return HPGV_OK;
     HPGV_ABI_CATCH(ctx)
 }
-// makes the range's first `bytes` bytes usable (a no-op when they are already); what is backed stays backed
+// makes the range's first `bytes` bytes usable (a no-op when they are already); what is backed stays backed; on failure the
+// range stays as it was
 int hpgv_dev_commit(hpgv_ctx *ctx, void *dptr, size_t bytes) {
     HPGV_ABI_TRY
     ctx = first_member(ctx);
@@ -634,17 +635,35 @@ int hpgv_dev_commit(hpgv_ctx *ctx, void *dptr, size_t bytes) {
         if (r.committed + add > r.reserved) add = r.reserved - r.committed;
         hipMemAllocationProp prop = {};
         prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = ctx->device;
-        hipMemGenericAllocationHandle_t h;
-        HIPCHK(ctx, hipMemCreate(&h, add, &prop, 0));
-        hipError_t e = hipMemMap(r.base + r.committed, add, 0, h, 0);
-        if (e == hipSuccess) {
-            hipMemAccessDesc acc = {};
-            acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
-            e = hipMemSetAccess(r.base + r.committed, add, &acc, 1);
-            if (e != hipSuccess) (void)hipMemUnmap(r.base + r.committed, add);
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+        // one piece for all of it; should the runtime refuse that, pieces of 64 MB
+        hipError_t last = hipSuccess;
+        for (size_t piece = add; add > 0; piece = gran) {
+            while (add > 0) {
+                const size_t n = piece < add ? piece : add;
+                hipMemGenericAllocationHandle_t h;
+                const bool trace = getenv("HPGV_VMM_TRACE") != nullptr;
+                last = hipMemCreate(&h, n, &prop, 0);
+                if (trace) fprintf(stderr, "vmm: create %zu MB: %s\n", n >> 20, hipGetErrorString(last));
+                if (last != hipSuccess) break;
+                last = hipMemMap(r.base + r.committed, n, 0, h, 0);
+                if (trace) fprintf(stderr, "vmm: map at +%zu MB (%p): %s\n", r.committed >> 20, (void *)(r.base + r.committed), hipGetErrorString(last));
+                if (last == hipSuccess) {
+                    // access is set for EVERYTHING backed so far, not for the new piece alone: the runtime (ROCm 7.2) refuses the
+                    // third and later pieces of a reservation when it is asked piece by piece ("invalid argument", eleven
+                    // times out of twelve; tools/exp/vmm_seq.py), and never this form
+                    last = hipMemSetAccess(r.base, r.committed + n, &acc, 1);
+                    if (trace) fprintf(stderr, "vmm: set-access: %s\n", hipGetErrorString(last));
+                    if (last != hipSuccess) (void)hipMemUnmap(r.base + r.committed, n);
+                }
+                if (last != hipSuccess) { (void)hipMemRelease(h); break; }
+                r.pieces.push_back(h); r.sizes.push_back(n); r.committed += n; add -= n;
+            }
+            if (add == 0 || piece == gran) break;
+            (void)hipGetLastError();
         }
-        if (e != hipSuccess) { (void)hipMemRelease(h); return fail(ctx, HPGV_ERR_NOMEM, "mapping %zu bytes: %s", add, hipGetErrorString(e)); }
-        r.pieces.push_back(h); r.sizes.push_back(add); r.committed += add;
+        if (add > 0) return fail(ctx, HPGV_ERR_NOMEM, "mapping device memory (%zu bytes short): %s", add, hipGetErrorString(last));
         return HPGV_OK;
     }
     return fail(ctx, HPGV_ERR_INVALID, "not a range of hpgv_dev_reserve");

@@ -2602,10 +2602,21 @@ static int bgzf_stream_stage(source_t *s) {
     if (ok) ok = scan_next_rows(s, S, &S->slot[0], S->rows_cap && S->rows_cap < 4096 ? S->rows_cap : 4096, 1, dbg, T0) == 1 && S->slot[0].n > 0;
     size_t est = 0;
     if (ok) {
-        est = (size_t)((double)S->text_pos / (double)S->chain_pos * (double)s->size * 1.06) + ((size_t)64 << 20);
+        /* committed at once, with room (growing later waits for the kernels that are running) */
+        est = (size_t)((double)S->text_pos / (double)S->chain_pos * (double)s->size * 1.10) + ((size_t)128 << 20);
         if (S->chain_pos >= (size_t)s->size) est = S->text_pos + 16;
         if (est > ((size_t)48 << 30)) ok = 0;                        /* as with the host's table: such a text stays on the host path, */
         if (S->chain_pos >= (size_t)s->size && S->blocks < 256) ok = 0;      /* and a small file is as quick there */
+    }
+    const char *tp = getenv("HPGV_TEST_TEXT_ESTIMATE_PERCENT");    /* tests: a text that outgrows what was committed for it */
+    if (ok && tp && atoi(tp) > 0 && S->chain_pos < (size_t)s->size) {
+        est = (size_t)((double)S->text_pos / (double)S->chain_pos * (double)s->size) / 100 * (size_t)atoi(tp);
+        if (est < S->text_pos + 16) est = S->text_pos + 16;
+        pthread_mutex_lock(&g_text_mu);
+        void *old = g_dev_text; const int old_kind = g_dev_text_kind;
+        g_dev_text = NULL; g_dev_text_cap = 0;
+        pthread_mutex_unlock(&g_text_mu);
+        dev_text_free(old, old_kind);
     }
     if (ok) {
         s->d_text = dev_text_get(est, &s->d_text_cap, &s->d_text_kind);

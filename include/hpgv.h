@@ -133,7 +133,8 @@ int  hpgv_dev_alloc(hpgv_ctx *ctx, size_t bytes, void **dptr);
 int  hpgv_dev_free(hpgv_ctx *ctx, void *dptr);
 /* device memory that grows in place: reserve an address range of max_bytes (costs no memory), make its first `bytes` bytes
  * usable with hpgv_dev_commit (what is backed stays backed; pieces of 64 MB), give everything back with hpgv_dev_release.
- * For a text whose size is known only when its last block has been seen.  HPGV_ERR_UNSUPPORTED: no virtual memory management. */
+ * For a text whose size is known only when its last block has been seen.  HPGV_ERR_UNSUPPORTED: no virtual memory management.
+ * hpgv_dev_commit fails with HPGV_ERR_NOMEM when the memory is not there; the range then stays as it was. */
 int  hpgv_dev_reserve(hpgv_ctx *ctx, size_t max_bytes, void **dptr);
 int  hpgv_dev_commit(hpgv_ctx *ctx, void *dptr, size_t bytes);
 int  hpgv_dev_release(hpgv_ctx *ctx, void *dptr);

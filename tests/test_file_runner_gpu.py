@@ -492,3 +492,51 @@ def test_run_assoc_from_bgzf_decoded_on_the_gpu(host, tmp_path, capfd):
                 for k in env:
                     del os.environ[k]
             assert rc != 0, (tag, env, n.value)
+
+
+def test_run_assoc_bgzf_text_buffer_grows_during_the_run(host, tmp_path, capfd):
+    # a text that outgrows what was committed for it when its first blocks were seen (here: the estimate cut to 30 %): the
+    # device buffer grows -- more pieces mapped into its address range -- while the pipeline reads what is already there
+    import zlib
+    from test_host_logic_cpu import _bgzf
+    rng = np.random.default_rng(21)
+    n_samples, n_variants = 60, 330_000
+    names = ["S%d" % j for j in range(n_samples)]
+    with open(tmp_path / "ped.txt", "w") as f:
+        for j, nm in enumerate(names):
+            f.write("F%d %s 0 0 %d %d\n" % (j, nm, 1 + j % 2, 1 + (j * 7 // 3) % 2))
+    gts = np.array(["0/0", "0/1", "1/1", "./."])
+    bodies = ["\t".join(gts[rng.choice(4, size=n_samples, p=[0.5, 0.3, 0.19, 0.01])]) for _ in range(997)]
+    head = "##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n"
+    text = (head + "".join("%d\t%d\trs%d\tA\tG\t.\tPASS\t.\tGT\t%s\n" % (1 + i * 22 // n_variants, 1000 + i, i, bodies[i % 997])
+                           for i in range(n_variants))).encode()
+    assert len(text) > (80 << 20)                                   # more than one 64 MB piece of the buffer
+    vcf, packed = str(tmp_path / "big.vcf"), str(tmp_path / "big.vcf.gz")
+    open(vcf, "wb").write(text)
+    out = bytearray()
+    for i in range(0, len(text), 0xff00):                            # bgzip blocks, zlib level 1 for speed
+        ch = text[i:i + 0xff00]
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        comp = co.compress(ch) + co.flush()
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + (18 + len(comp) + 8 - 1).to_bytes(2, "little") + comp
+        out += zlib.crc32(ch).to_bytes(4, "little") + len(ch).to_bytes(4, "little")
+    open(packed, "wb").write(bytes(out) + _bgzf(b"", 0x700))
+    ped = str(tmp_path / "ped.txt").encode()
+
+    def run(path, tag, env=None):
+        os.environ.update(env or {})
+        try:
+            o = str(tmp_path / ("res_" + tag))
+            n = C.c_long(0)
+            rc = host.hpgv_run_assoc(path.encode(), ped, o.encode(), 1, 8 << 20, C.byref(n))
+            assert rc == 0 and n.value == n_variants, host.hpgv_host_last_error()
+            return open(o, "rb").read()
+        finally:
+            for k in (env or {}):
+                del os.environ[k]
+    plain = run(vcf, "plain")
+    capfd.readouterr()
+    assert run(packed, "grown", {"HPGV_TEST_SCAN_ROWS": "200", "HPGV_TEST_TEXT_ESTIMATE_PERCENT": "30", "HPGV_RUN_TRACE": "1"}) == plain
+    err = capfd.readouterr().err
+    assert "streaming" in err and err.count("blocks found") >= 6
+    assert run(packed, "as_estimated") == plain
