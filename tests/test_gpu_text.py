@@ -328,3 +328,55 @@ def test_device_memory_that_grows_in_place():
         e.dev_commit(p, 4 << 30)                                            # more than was reserved
     e.dev_release(p)
     e.close()
+
+
+@pytest.mark.parametrize("wave", [2, 0, 3], ids=["wave_per_block", "lane_per_block", "lane_per_block_lds_tables"])
+def test_inflate_random_streams_against_zlib(wave):
+    # 1 500 streams over the parameters zlib offers: level, strategy, window size (256 bytes .. 32 KiB), memLevel (1: a
+    # new dynamic block every 128 symbols, so a stream holds hundreds of code tables), on data of alphabets from 2 to 256
+    # symbols, periodic data and text, sizes 0 .. 65 280; every stream must come back bit for bit
+    import zlib
+    rng = np.random.default_rng(2024)
+    raws, comps = [], []
+    for k in range(1500):
+        n = int(rng.choice([0, 1, 2, 3, 31, 257, 258, 259, 1000, 4095, 4096, 4097, 20000, 65280])) if k % 3 == 0 else int(rng.integers(0, 65281))
+        kind = k % 6
+        if kind == 0:
+            raw = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        elif kind == 1:
+            raw = bytes(rng.integers(0, int(rng.choice([2, 3, 4, 16])), n, dtype=np.uint8) + 48)
+        elif kind == 2:
+            period = int(rng.integers(1, 300))
+            raw = (bytes(rng.integers(0, 256, period, dtype=np.uint8)) * (n // period + 1))[:n]
+        elif kind == 3:
+            gts = np.array(["0/0", "0/1", "1/1", "./.", "0|1", "1|0"])
+            raw = ("\t".join(gts[rng.choice(6, size=n // 4 + 1, p=[0.55, 0.2, 0.1, 0.02, 0.08, 0.05])]) + "\n").encode()[:n]
+        elif kind == 4:
+            far = bytes(rng.integers(0, 256, int(rng.integers(300, 9000)), dtype=np.uint8))
+            raw = (far + bytes(rng.integers(0, 4, int(rng.integers(0, 20000)), dtype=np.uint8)) + far * 2)[:n]
+        else:
+            raw = (b"chr1\t%d\trs%d\tA\tG\t.\tPASS\tAC=%d;AF=0.%d\tGT:DP\t" % (k, k, k % 7, k % 97) * (n // 40 + 1))[:n]
+        co = zlib.compressobj(int(rng.integers(0, 10)), zlib.DEFLATED, -int(rng.integers(9, 16)), int(rng.integers(1, 10)),
+                              int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED])))
+        raws.append(raw); comps.append(co.compress(raw) + co.flush())
+    n = len(comps)
+    in_len = np.array([len(c) for c in comps], np.uint32); out_len = np.array([len(r) for r in raws], np.uint32)
+    in_off = np.concatenate([[0], np.cumsum(in_len[:-1], dtype=np.uint64)]).astype(np.uint64)
+    out_off = np.concatenate([[0], np.cumsum(out_len[:-1], dtype=np.uint64)]).astype(np.uint64)
+    cbytes = np.frombuffer(b"".join(comps) + b"\0" * 16, np.uint8)
+    total = int(out_len.sum())
+    e = hpgv.Engine(0)
+    e.set_option("inflate_wave", wave)
+    d_comp, d_text = e.alloc(len(cbytes)), e.alloc(total + 16)
+    d_io, d_il, d_oo, d_ol, d_st = e.alloc(8 * n), e.alloc(4 * n), e.alloc(8 * n), e.alloc(4 * n), e.alloc(4 * n)
+    for d, a in ((d_comp, cbytes), (d_io, in_off), (d_il, in_len), (d_oo, out_off), (d_ol, out_len)):
+        e.h2d(d, a)
+    e.h2d(d_text, np.full(total + 16, 0xA5, np.uint8))
+    e.inflate_blocks(d_comp, d_io, d_il, d_oo, d_ol, n, d_text, d_st)
+    e.sync()
+    status = e.d2h(d_st, (n,), np.int32)
+    text = e.d2h(d_text, (total + 16,), np.uint8).tobytes()
+    assert not status.any(), (np.flatnonzero(status)[:10], status[status != 0][:10])
+    assert text[:total] == b"".join(raws)
+    assert text[total:] == b"\xa5" * 16                                  # nothing written past the last block's text
+    e.close()
