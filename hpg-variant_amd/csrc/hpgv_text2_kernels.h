@@ -222,7 +222,7 @@ static __global__ __launch_bounds__(256) void k_tok_parse2(const char *__restric
     //      8th TAB (FORMAT begins: parsed by the thread that holds it; at most one per 16 bytes) ---------------------------
     int d = 0, g = TOK_GT_UNDEF, g8 = TOK_GT_UNDEF;
     bool fmt_here = false;
-    {
+    if (nls != 0 || (ntab < 8 && ntab + __popc(tabs) >= 8)) {        // (most threads hold neither a newline nor a line's 8th TAB)
         uint32_t m = tabs | nls;
         int k = ntab;
         while (m) {
@@ -249,7 +249,40 @@ static __global__ __launch_bounds__(256) void k_tok_parse2(const char *__restric
         line_off[0] = 0;
         if (field_off && max_lines > 0) field_off[0] = 0;
     }
-    uint32_t m = tabs | nls;
+    // ---- the everyday stretch: 32 bytes inside the sample columns of one line, a TAB every fourth byte (genotypes of the form
+    //      d/d, d|d or ./.), GT first: the eight genotypes that begin here are taken out of the thread's words in one go --
+    //      the window is shifted so that they lie dword by dword, each is checked and encoded, and the eight codes leave as
+    //      one 8-byte store.  Anything else about the thread's bytes sends it through the walk below.
+    bool everyday = false;
+    if (wide && nls == 0 && tabs != 0 && ntab >= 9 && gtpos == 0 && line < max_lines) {
+        const int phi = __ffs((int)tabs) - 1;
+        const int s0 = ntab - 8;                                       // the sample whose field begins after the first TAB
+        if (phi < 4 && tabs == (0x11111111u << phi) && s0 + 8 <= n_samples) {
+            const int sh = 8 * (phi + 1);                              // 8 .. 32: the first field begins at byte phi + 1
+            uint64_t out = 0;
+            bool all_ok = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t a = (ww[k] >> sh) | (ww[k + 1] << (64 - sh));
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t q = (uint32_t)(a >> (32 * h));
+                    const uint32_t b0 = q & 0xFF, b1 = (q >> 8) & 0xFF, b2 = (q >> 16) & 0xFF, b3 = q >> 24;
+                    const uint32_t d0 = b0 - '0', d1 = b2 - '0';
+                    const bool form = (b1 == '/' || b1 == '|') && (b3 == '\t' || b3 == ':' || b3 == '\n');
+                    const bool digits = d0 <= 9 && d1 <= 9, dots = b0 == '.' && b2 == '.';
+                    all_ok = all_ok && form && (digits || dots);
+                    const uint32_t code = dots ? 0xFFu : ((d0 << 4) | d1) & 0xFFu;
+                    out |= (uint64_t)code << (8 * (2 * k + h));
+                }
+            }
+            if (all_ok) {
+                __builtin_memcpy(gt + (size_t)line * pitch + s0, &out, 8);
+                everyday = true;
+            }
+        }
+    }
+    uint32_t m = everyday ? 0u : (tabs | nls);
     while (m) {
         const int j = __ffs((int)m) - 1;
         m &= m - 1;
