@@ -179,6 +179,14 @@ __device__ __forceinline__ void tok_close_line(const char *__restrict__ t, int l
     if (status) status[line] = ntab < 9 ? 1 : (gtpos < 0 ? 2 : (ntab - 8 < n_samples ? 3 : 0));
 }
 
+// one lane-shift of a wave scan as a DPP move (one instruction per value; a lane without a source keeps `identity`):
+// row_shr:1/2/4/8 inside the rows of 16 lanes, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3; wave_shr:1 for
+// the exclusive value
+template <int CTRL, int ROWS> __device__ __forceinline__ int tok_dpp(int identity, int v) {
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROWS, 0xF, false);
+}
+#define TOK_SCAN_STEPS(STEP) STEP(0x111, 0xF) STEP(0x112, 0xF) STEP(0x114, 0xF) STEP(0x118, 0xF) STEP(0x142, 0xA) STEP(0x143, 0xC)
+
 static __global__ __launch_bounds__(256) void k_tok_parse2(const char *__restrict__ text, size_t n, const TokPre *__restrict__ pre,
                                                     int max_lines, int n_samples, int strict, uint8_t *__restrict__ gt, size_t pitch,
                                                     uint8_t *__restrict__ is_x, unsigned long long *__restrict__ line_off,
@@ -202,15 +210,18 @@ static __global__ __launch_bounds__(256) void k_tok_parse2(const char *__restric
     const int last_bit = nl ? 31 - __clz((int)nls) : -1;
     int f = nl ? 1 : 0, v = nl ? tok_tabs_after(tabs, last_bit) : __popc(tabs), cn = nl;
     unsigned long long p = nl ? (unsigned long long)(base + last_bit + 1) : 0ull;
-    for (int off = 1; off < 64; off <<= 1) {                         // inclusive, within the wave
-        const int f2 = __shfl_up(f, off), v2 = __shfl_up(v, off), n2 = __shfl_up(cn, off);
-        const unsigned long long p2 = __shfl_up(p, off);
-        if (lane >= off) { if (!f) { v += v2; p = p2; } f |= f2; cn += n2; }
-    }
+    int plo = (int)(uint32_t)p, phi = (int)(uint32_t)(p >> 32);
+#define TOK_STEP_A(CTRL, ROWS) {                                                                                          \
+        const int f2 = tok_dpp<CTRL, ROWS>(0, f), v2 = tok_dpp<CTRL, ROWS>(0, v), n2 = tok_dpp<CTRL, ROWS>(0, cn);         \
+        const int l2 = tok_dpp<CTRL, ROWS>(0, plo), h2 = tok_dpp<CTRL, ROWS>(0, phi);                                       \
+        if (!f) { v += v2; plo = l2; phi = h2; }                                                                           \
+        f |= f2; cn += n2; }
+    TOK_SCAN_STEPS(TOK_STEP_A)                                       // inclusive, within the wave
+#undef TOK_STEP_A
+    p = ((unsigned long long)(uint32_t)phi << 32) | (uint32_t)plo;
     if (lane == 63) { s_f[w] = f; s_v[w] = v; s_p[w] = p; s_n[w] = cn; }
-    int ef = __shfl_up(f, 1), ev = __shfl_up(v, 1), en = __shfl_up(cn, 1);      // exclusive within the wave
-    unsigned long long ep = __shfl_up(p, 1);
-    if (lane == 0) { ef = 0; ev = 0; en = 0; ep = 0; }
+    const int ef = tok_dpp<0x138, 0xF>(0, f), ev = tok_dpp<0x138, 0xF>(0, v), en = tok_dpp<0x138, 0xF>(0, cn);      // exclusive within the wave
+    const unsigned long long ep = ((unsigned long long)(uint32_t)tok_dpp<0x138, 0xF>(0, phi) << 32) | (uint32_t)tok_dpp<0x138, 0xF>(0, plo);
     __syncthreads();
     int bv = P.tabs, bn = P.lines;                                   // state at the wave's first byte
     unsigned long long bp = P.line_start;
@@ -232,13 +243,16 @@ static __global__ __launch_bounds__(256) void k_tok_parse2(const char *__restric
             else if (++k == 8) { g8 = tok_format_gtpos(t, base + j + 1, n); d = 1; g = g8; fmt_here = true; }
         }
     }
-    for (int off = 1; off < 64; off <<= 1) {
-        const int d2 = __shfl_up(d, off), g2 = __shfl_up(g, off);
-        if (lane >= off) { if (!d) g = g2; d |= d2; }
-    }
+#define TOK_STEP_B(CTRL, ROWS) {                                                                                          \
+        const int d2 = tok_dpp<CTRL, ROWS>(0, d), g2 = tok_dpp<CTRL, ROWS>(0, g);                                          \
+        if (!d) g = g2;                                                                                                    \
+        d |= d2; }
+    TOK_SCAN_STEPS(TOK_STEP_B)
+#undef TOK_STEP_B
     if (lane == 63) { s_d[w] = d; s_g[w] = g; }
-    int ed = __shfl_up(d, 1), eg = __shfl_up(g, 1);
-    if (lane == 0) { ed = 0; eg = TOK_GT_UNDEF; }
+    const int ed = tok_dpp<0x138, 0xF>(0, d);
+    int eg = tok_dpp<0x138, 0xF>(0, g);
+    if (lane == 0) eg = TOK_GT_UNDEF;
     __syncthreads();
     int bg = gt0;
     for (int k = 0; k < w; ++k) if (s_d[k]) bg = s_g[k];
