@@ -380,3 +380,30 @@ def test_inflate_random_streams_against_zlib(wave):
     assert text[:total] == b"".join(raws)
     assert text[total:] == b"\xa5" * 16                                  # nothing written past the last block's text
     e.close()
+
+
+@pytest.mark.parametrize("strict", [0, 1])
+def test_everyday_genotype_stretches_and_what_breaks_them(eng, strict):
+    # the tile-parallel tokenizer decodes 32-byte stretches of four-byte genotype fields (d/d, d|d, ./.) eight at a time;
+    # every alignment of the fields against the threads' 32 bytes (head lengths 0 .. 40), every digit, and the fields that
+    # end such a stretch -- a sub-field, a half-missing or two-digit allele, a haploid call, a short or a long last column --
+    # must come out as the oracle's TAB-split + get_alleles gives them
+    rng = np.random.default_rng(77 + strict)
+    plain = ["%d%s%d" % (a, s, b) for a in range(10) for b in range(10) for s in "/|"] + ["./.", ".|."] * 20
+    breakers = ["0/1:7", "./1", "1/.", "10/2", "1", ".", "0/12", "3|4:0,1", "", "0/1/1", "x/1", "1/x"]
+    n_samples = 700
+    lines = []
+    for i in range(90):
+        gts = [plain[int(k)] for k in rng.integers(0, len(plain), n_samples)]
+        for _ in range(i % 4):                                     # 0 .. 3 fields that break the pattern, anywhere
+            gts[int(rng.integers(0, n_samples))] = breakers[int(rng.integers(0, len(breakers)))]
+        if i % 9 == 4:
+            gts[-1] = "0/1:99"                                     # the line's last field carries a sub-field
+        n_cols = n_samples if i % 10 else n_samples - 5           # some lines lack trailing samples
+        lines.append(_line(rng, n_samples, "GT" if i % 6 else "GT:DP", "X" if i % 5 == 0 else "7", info_len=i % 41, gts=gts, n_cols=n_cols))
+    text = "\n".join(lines) + ("\n" if strict else "")              # with and without a final newline
+    got = _check(eng, text, n_samples, strict)
+    assert got["n_lines"] == len(lines)
+    # the same with a FORMAT that does not begin with GT: nothing is everyday, and (tile-parallel form) lines are re-done
+    lines2 = [_line(rng, n_samples, "DP:GT", "7", info_len=i, gts=[plain[int(k)] for k in rng.integers(0, len(plain), n_samples)]) for i in range(12)]
+    _check(eng, "\n".join(lines2) + "\n", n_samples, strict)
