@@ -3878,6 +3878,8 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
         /* (in order as written: nothing to do; HPGV_ALWAYS_SORT=1 reads the file back and checks all the same) */
         if (!rc && kind < 4 && (ord.disorder || !ord.have || getenv("HPGV_ALWAYS_SORT")) && hpgv_host_sort_output_file(out_path))      /* assoc_runner.c:255-261: only a warning there */
             fprintf(stderr, "WARN: results could not be sorted by chromosome and position\n");
+        else if (!rc && kind < 4 && getenv("HPGV_RUN_TRACE") && !(ord.disorder || !ord.have || getenv("HPGV_ALWAYS_SORT")))
+            fprintf(stderr, "hpgv run: the result file is in order as written\n");
         t_sort = now_s() - t0;
         free(ord.last);
     }

@@ -540,3 +540,31 @@ def test_run_assoc_bgzf_text_buffer_grows_during_the_run(host, tmp_path, capfd):
     err = capfd.readouterr().err
     assert "streaming" in err and err.count("blocks found") >= 6
     assert run(packed, "as_estimated") == plain
+
+
+@pytest.mark.parametrize("chroms", [("1", "2", "10", "22"), ("1", "2", "22", "X"), ("1", "1", "1", "1")], ids=["numbered", "x_last", "one"])
+def test_run_assoc_result_order_is_known_without_reading_the_file_back(host, tmp_path, chroms, capfd):
+    # a position-sorted VCF gives a result file that is already in `sort -k1,1h -k2,2n` order, and the runner knows that
+    # when it has written the last record; chromosome X after the numbered ones is NOT in that order (-h reads "X" as 0):
+    # then the file is sorted afterwards, as for any other input; equal positions are ordered by the whole line
+    rng = np.random.default_rng(31)
+    people, names, rows = _write_inputs(tmp_path, rng, 30, 20, 6000, chroms=("1",))
+    n = len(rows)
+    with open(tmp_path / "sorted.vcf", "w") as f:
+        f.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n")
+        for v, (_, fmt, samples) in enumerate(rows):
+            pos = 1000 + v // 2 * 2                                # pairs of records share a position
+            f.write("%s\t%d\trs%d\tA\tC\t.\tPASS\t.\t%s\t%s\n" % (chroms[v * len(chroms) // n], pos, v, fmt, "\t".join(samples)))
+    out = str(tmp_path / "res.chisq")
+    cnt = C.c_long(0)
+    os.environ["HPGV_RUN_TRACE"] = "1"
+    try:
+        capfd.readouterr()
+        rc = host.hpgv_run_assoc(str(tmp_path / "sorted.vcf").encode(), str(tmp_path / "ped.txt").encode(), out.encode(), 1, 1 << 16, C.byref(cnt))
+        err = capfd.readouterr().err
+    finally:
+        del os.environ["HPGV_RUN_TRACE"]
+    assert rc == 0 and cnt.value == n, host.hpgv_host_last_error()
+    gnu = subprocess.run(["sort", "-k1,1h", "-k2,2n", out], capture_output=True, text=True, env=dict(os.environ, LC_ALL="C"), check=True).stdout
+    assert open(out).read() == gnu
+    assert ("in order as written" in err) == (chroms[-1] != "X")       # read back and sorted only where it had to be
