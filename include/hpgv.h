@@ -358,9 +358,11 @@ int  hpgv_mendel(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants,
                  int32_t *errors, int32_t *child_errors);
 
 /* ---- bgzip-compressed VCF text (--compression bgzip, shared_options.c:60-61): the raw-DEFLATE payloads of BGZF blocks
- * decoded on the device, one lane per block (pass a whole file's blocks, or at least many thousands, per call).  Block b
- * occupies d_comp[in_off[b] .. + in_len[b]) and decodes to exactly out_len[b] bytes at d_text + out_off[b]; d_status[b] is
- * 0, or non-zero for a block this decoder does not take (the caller decodes it on the host).  Asynchronous on `stream`. */
+ * decoded on the device, one wave per block (any number of blocks per call; option inflate_wave = 0: one lane per block,
+ * which wants a hundred thousand blocks per call).  Block b occupies d_comp[in_off[b] .. + in_len[b]) and decodes to exactly
+ * out_len[b] <= 65 536 bytes at d_text + out_off[b]; d_status[b] is 0, or non-zero for a block this decoder does not take (the
+ * caller decodes it on the host).  d_comp must be readable for 8 bytes past the end of the last block, d_text for 8 bytes
+ * past the last block's text.  Asynchronous on `stream`. */
 /* "the text of the batch is on the device at d_text already" (e.g. decoded there by hpgv_inflate_blocks_dev): a *_text entry
  * point called with host_text then tokenizes d_text in place, copies nothing up, and WRITES INTO host_text (a buffer of at
  * least text_bytes bytes) the heads of the lines -- each line up to its first sample column, CHROM .. FORMAT, or the whole
