@@ -535,7 +535,35 @@ static void dev_text_put(void *p, size_t bytes, int kind) {
     dev_text_free(p, kind);
 }
 
+/* streams of the bgzip device path, kept between runs: creating the seven a run uses took 18 ms of a 0.14 s run (they are
+ * idle when they come back) */
+enum { STREAM_CACHE_N = 16 };
+static void *g_stream_cache[2][STREAM_CACHE_N];        /* [0] normal priority, [1] lowest */
+static int stream_get(int low, void **out) {
+    pthread_mutex_lock(&g_text_mu);
+    for (int i = 0; i < STREAM_CACHE_N; i++)
+        if (g_stream_cache[low][i]) { *out = g_stream_cache[low][i]; g_stream_cache[low][i] = NULL; pthread_mutex_unlock(&g_text_mu); return HPGV_OK; }
+    pthread_mutex_unlock(&g_text_mu);
+    return low ? hpgv_stream_create_low(g_ctx, out) : hpgv_stream_create(g_ctx, out);
+}
+static void stream_put(int low, void *st) {
+    if (!st) return;
+    (void)hpgv_stream_sync(g_ctx, st);
+    pthread_mutex_lock(&g_text_mu);
+    for (int i = 0; i < STREAM_CACHE_N; i++)
+        if (!g_stream_cache[low][i]) { g_stream_cache[low][i] = st; st = NULL; break; }
+    pthread_mutex_unlock(&g_text_mu);
+    if (st) (void)hpgv_stream_destroy(g_ctx, st);
+}
+
 static void text_cache_release(void) {                  /* g_ctx still alive */
+    for (int low = 0; low < 2; low++)
+        for (int i = 0; i < STREAM_CACHE_N; i++) {
+            pthread_mutex_lock(&g_text_mu);
+            void *st = g_stream_cache[low][i]; g_stream_cache[low][i] = NULL;
+            pthread_mutex_unlock(&g_text_mu);
+            if (st) (void)hpgv_stream_destroy(g_ctx, st);
+        }
     pthread_mutex_lock(&g_text_mu);
     for (int i = 0; i < TEXT_CACHE_N; i++)
         if (g_text_cache[i].p) { (void)hpgv_host_free(g_ctx, g_text_cache[i].p); g_text_cache[i].p = NULL; g_text_cache[i].cap = 0; }
@@ -1686,6 +1714,7 @@ typedef struct {
     size_t d_text_cap; int d_text_kind;
     int dev_len_known;                                  /* 0 while the stager is still finding the file's blocks (under g_mu) */
     void *d_scan;                                       /* the streaming stager's tables, statuses and scan scratch */
+    int c_low;                                          /* cstream (and the slots' streams) have the lowest priority */
     pthread_t g_thread; pthread_mutex_t g_mu; pthread_cond_t g_cv; int g_started, g_sync, g_err, g_finished;
     /* the uploader: the compressed file goes up from the moment it is opened, beside the walk of its block headers */
     pthread_t u_thread; int u_started, u_cancel, u_err; size_t up_done;      /* bytes [0, up_done) are on the device (under g_mu) */
@@ -1745,8 +1774,8 @@ static void source_close(source_t *s) {
         if (s->d_status) (void)hpgv_dev_free(g_ctx, s->d_status);
         if (s->d_text) dev_text_put(s->d_text, s->d_text_cap, s->d_text_kind);
         if (s->d_scan) (void)hpgv_dev_free(g_ctx, s->d_scan);
-        if (s->rstream) (void)hpgv_stream_destroy(g_ctx, s->rstream);
-        if (s->cstream) (void)hpgv_stream_destroy(g_ctx, s->cstream);
+        stream_put(0, s->rstream);
+        stream_put(s->c_low, s->cstream);
     }
     if (s->kind == SRC_GZIP && s->gz) gzclose(s->gz);
     if (s->fd >= 0) close(s->fd);
@@ -2053,7 +2082,7 @@ static void *up_reader(void *v) {
 static void *bgzf_uploader(void *v) {
     source_t *s = (source_t *)v;
     void *up = NULL;
-    int ok = hpgv_stream_create(g_ctx, &up) == HPGV_OK;
+    int ok = stream_get(0, &up) == HPGV_OK;
     const size_t pin_cap = (size_t)UP_SEG * UP_SLOTS;
     char *pin = text_buf_get(pin_cap + 1);                          /* from the runs' cache of page-locked buffers */
     up_ring_t r;
@@ -2070,7 +2099,7 @@ static void *bgzf_uploader(void *v) {
     ok = ok && pin && n_th > 0;
     double t_wait = 0, t_copy = 0; const double t_begin = now_s();
     void *up2 = NULL;                                                /* two copies in flight: one is queued while the one before is waited for */
-    ok = ok && hpgv_stream_create(g_ctx, &up2) == HPGV_OK;
+    ok = ok && stream_get(0, &up2) == HPGV_OK;
     void *st2[2] = { up, up2 };
     for (size_t i = 0; ok && i <= r.n_seg; i++) {
         double t0 = now_s();
@@ -2094,6 +2123,7 @@ static void *bgzf_uploader(void *v) {
         pthread_cond_broadcast(&r.cv);
         pthread_mutex_unlock(&r.mu);
         if (!ok) break;
+        if (j == 0 && getenv("HPGV_RUN_TRACE")) fprintf(stderr, "uploader: first segment up %.4f s after its start\n", now_s() - t_begin);
         pthread_mutex_lock(&s->g_mu);
         s->up_done = off + len;
         const int cancel = s->u_cancel;
@@ -2101,7 +2131,7 @@ static void *bgzf_uploader(void *v) {
         pthread_mutex_unlock(&s->g_mu);
         if (cancel) { ok = 0; break; }
     }
-    if (up2) { (void)hpgv_stream_sync(g_ctx, up2); (void)hpgv_stream_destroy(g_ctx, up2); }
+    stream_put(0, up2);
     if (up) (void)hpgv_stream_sync(g_ctx, up);
     if (getenv("HPGV_RUN_TRACE"))
         fprintf(stderr, "uploader: %.1f MB in %.4f s: %.4f s waiting for the readers (%d), %.4f s in copies\n", s->size / 1e6, now_s() - t_begin, t_wait, n_th, t_copy);
@@ -2109,7 +2139,7 @@ static void *bgzf_uploader(void *v) {
     for (int k = 0; k < n_th; k++) pthread_join(th[k], NULL);
     pthread_mutex_destroy(&r.mu); pthread_cond_destroy(&r.cv);
     if (pin) text_buf_put(pin, pin_cap + 1);
-    if (up) (void)hpgv_stream_destroy(g_ctx, up);
+    stream_put(0, up);
     pthread_mutex_lock(&s->g_mu);
     if (!ok && !s->u_cancel) s->u_err = 1;
     if (!ok && s->up_done < (size_t)s->size) s->u_err = 1;
@@ -2140,7 +2170,7 @@ static void *bgzf_gpu_stager(void *v) {
     enum { GPU_INFLIGHT = 4, GPU_FIRST = 4096 };
     const int inflight = GPU_INFLIGHT;
     void *cs[GPU_INFLIGHT] = { s->cstream, NULL, NULL, NULL };
-    for (int q = 1; ok && q < inflight; q++) ok = hpgv_stream_create(g_ctx, &cs[q]) == HPGV_OK;
+    for (int q = 1; ok && q < inflight; q++) ok = stream_get(0, &cs[q]) == HPGV_OK;
     size_t q_hi[GPU_INFLIGHT];                           /* the stretches in flight end at these blocks; the oldest starts at g_done */
     int qh = 0, qn = 0;
     const int dbg = getenv("HPGV_RUN_TRACE") != NULL; const double T0 = now_s();
@@ -2196,7 +2226,7 @@ static void *bgzf_gpu_stager(void *v) {
         }
     }
     for (int q = 0; q < GPU_INFLIGHT; q++) if (cs[q]) (void)hpgv_stream_sync(g_ctx, cs[q]);      /* after a failure launches may still be running */
-    for (int q = 1; q < GPU_INFLIGHT; q++) if (cs[q]) (void)hpgv_stream_destroy(g_ctx, cs[q]);
+    for (int q = 1; q < GPU_INFLIGHT; q++) stream_put(0, cs[q]);
     pthread_mutex_lock(&s->g_mu);
     if (!ok) s->g_err = 1;
     s->g_finished = 1;
@@ -2564,7 +2594,7 @@ static void *bgzf_gpu_stream_stager(void *v) {
         pthread_join(s->u_thread, NULL); s->u_started = 0;
     }
     if (dbg) fprintf(stderr, "stager: finished (%zu blocks, %.1f MB of text) at %.4f\n", S->blocks, S->text_pos / 1e6, now_s() - T0);
-    for (int q = 1; q < SCAN_SLOTS; q++) if (S->slot[q].stream) (void)hpgv_stream_destroy(g_ctx, S->slot[q].stream);
+    for (int q = 1; q < SCAN_SLOTS; q++) stream_put(s->c_low, S->slot[q].stream);
     for (int q = 0; q < SCAN_SLOTS; q++) free(S->slot[q].h_in_off);
     free(S);
     if (s->d_comp) { (void)hpgv_dev_free(g_ctx, s->d_comp); s->d_comp = NULL; }      /* only the text is needed from here on */
@@ -2579,7 +2609,8 @@ static int bgzf_stream_stage(source_t *s) {
     if (!S) return 1;
     /* the decoder's streams have the lowest priority: the batches' kernels go first whenever a compute unit has room */
     const int low = !getenv("HPGV_NO_LOW_PRIORITY");
-    int ok = hpgv_stream_create(g_ctx, &s->rstream) == HPGV_OK && (low ? hpgv_stream_create_low(g_ctx, &s->cstream) : hpgv_stream_create(g_ctx, &s->cstream)) == HPGV_OK;
+    s->c_low = low;
+    int ok = stream_get(0, &s->rstream) == HPGV_OK && stream_get(low, &s->cstream) == HPGV_OK;
     const size_t slot_bytes = (size_t)SCAN_ROWS_MAX * 28;
     S->scratch_bytes = hpgv_bgzf_scan_scratch_bytes(SCAN_RANGE_MAX + 16, SCAN_ROWS_MAX);
     if (ok) ok = hpgv_dev_alloc(g_ctx, slot_bytes * SCAN_SLOTS + S->scratch_bytes + 256, &s->d_scan) == HPGV_OK;
@@ -2593,9 +2624,10 @@ static int bgzf_stream_stage(source_t *s) {
         ok = h != NULL;
         q->h_in_off = (uint64_t *)h; q->h_out_off = (uint64_t *)(h + (size_t)SCAN_ROWS_MAX * 8);
         q->h_in_len = (uint32_t *)(h + (size_t)SCAN_ROWS_MAX * 16); q->h_out_len = (uint32_t *)(h + (size_t)SCAN_ROWS_MAX * 20);
-        if (k == 0) q->stream = s->cstream; else ok = ok && (low ? hpgv_stream_create_low(g_ctx, &q->stream) : hpgv_stream_create(g_ctx, &q->stream)) == HPGV_OK;
+        if (k == 0) q->stream = s->cstream; else ok = ok && stream_get(low, &q->stream) == HPGV_OK;
     }
     if (ok) S->d_scratch = (char *)s->d_scan + slot_bytes * SCAN_SLOTS;
+    if (dbg) fprintf(stderr, "stage: streams and tables at %.4f\n", now_s() - T0);
     /* the first blocks, from the file's first megabytes: is this a file the device can chain, and how much text is it? */
     const char *tr = getenv("HPGV_TEST_SCAN_ROWS");
     S->rows_cap = tr && atol(tr) > 0 ? (size_t)atol(tr) : 0;
@@ -2632,13 +2664,13 @@ static int bgzf_stream_stage(source_t *s) {
         if (ok) s->g_started = 1; else s->blk = NULL;
     }
     if (!ok) {
-        for (int k = 1; k < SCAN_SLOTS; k++) if (S->slot[k].stream) (void)hpgv_stream_destroy(g_ctx, S->slot[k].stream);
+        for (int k = 1; k < SCAN_SLOTS; k++) stream_put(low, S->slot[k].stream);
         for (int k = 0; k < SCAN_SLOTS; k++) free(S->slot[k].h_in_off);
         free(S);
         if (s->d_text) { dev_text_put(s->d_text, s->d_text_cap, s->d_text_kind); s->d_text = NULL; }
         if (s->d_scan) { (void)hpgv_dev_free(g_ctx, s->d_scan); s->d_scan = NULL; }
-        if (s->rstream) { (void)hpgv_stream_destroy(g_ctx, s->rstream); s->rstream = NULL; }
-        if (s->cstream) { (void)hpgv_stream_destroy(g_ctx, s->cstream); s->cstream = NULL; }
+        stream_put(0, s->rstream); s->rstream = NULL;
+        stream_put(low, s->cstream); s->cstream = NULL; s->c_low = 0;
         return 1;
     }
     s->map_pos = (size_t)s->size;                                    /* the CPU path has nothing left to do */
@@ -2659,6 +2691,7 @@ static int bgzf_gpu_stage(source_t *s) {
     pthread_mutex_init(&s->g_mu, NULL); pthread_cond_init(&s->g_cv, NULL);
     s->g_sync = 1; s->up_done = 0; s->u_cancel = 0; s->u_err = 0;
     if (hpgv_dev_alloc(g_ctx, (size_t)s->size + 16, &s->d_comp) == HPGV_OK) {
+        if (dbg) fprintf(stderr, "stage: room for the compressed file at %.4f\n", now_s() - T0);
         if (pthread_create(&s->u_thread, NULL, bgzf_uploader, s) == 0) s->u_started = 1;
         else { (void)hpgv_dev_free(g_ctx, s->d_comp); s->d_comp = NULL; }
     }
@@ -2690,7 +2723,7 @@ static int bgzf_gpu_stage(source_t *s) {
     }
     if (dbg) fprintf(stderr, "stage: walk %.4f\n", now_s() - T0);
     if (ok && (nb < 256 || nb > 0x7FFFFFFFu || text > ((size_t)48 << 30))) ok = 0;     /* a small file is as quick on the host */
-    if (ok) ok = hpgv_stream_create(g_ctx, &s->rstream) == HPGV_OK && hpgv_stream_create(g_ctx, &s->cstream) == HPGV_OK;
+    if (ok) { s->c_low = 0; ok = stream_get(0, &s->rstream) == HPGV_OK && stream_get(0, &s->cstream) == HPGV_OK; }
     if (ok) ok = hpgv_dev_alloc(g_ctx, nb * 24 + 64, &s->d_tab) == HPGV_OK;
     if (ok) { s->d_text = dev_text_get(text + 16, &s->d_text_cap, &s->d_text_kind); ok = s->d_text != NULL; }
     if (ok) ok = hpgv_dev_alloc(g_ctx, nb * 4 + 16, &s->d_status) == HPGV_OK;
@@ -2721,8 +2754,8 @@ static int bgzf_gpu_stage(source_t *s) {
         if (s->d_tab) { (void)hpgv_dev_free(g_ctx, s->d_tab); s->d_tab = NULL; }
         if (s->d_status) { (void)hpgv_dev_free(g_ctx, s->d_status); s->d_status = NULL; }
         if (s->d_text) { dev_text_put(s->d_text, s->d_text_cap, s->d_text_kind); s->d_text = NULL; }
-        if (s->rstream) { (void)hpgv_stream_destroy(g_ctx, s->rstream); s->rstream = NULL; }
-        if (s->cstream) { (void)hpgv_stream_destroy(g_ctx, s->cstream); s->cstream = NULL; }
+        stream_put(0, s->rstream); s->rstream = NULL;
+        stream_put(0, s->cstream); s->cstream = NULL;
         return 1;
     }
     s->map_pos = (size_t)s->size;                                    /* the CPU path has nothing left to do */
