@@ -46,18 +46,45 @@ with open(ped, "w") as f:
 size = os.path.getsize(vcf)
 
 
-def bgzf_file(src, dst, block=0xff00):
-    with open(src, "rb") as fi, open(dst, "wb") as fo:
-        while True:
-            ch = fi.read(block)
-            co = zlib.compressobj(1, zlib.DEFLATED, -15)
-            comp = co.compress(ch) + co.flush()
-            fo.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(comp) + 8 - 1)
+bgzf_level = int(os.environ.get("BENCH_BGZF_LEVEL", "6"))      # bgzip's default is zlib's (6); round 1 measured files of level 1
+BGZF_BLOCK = 0xff00
+
+
+def bgzf_blocks(args):
+    src, off, n = args
+    with open(src, "rb") as fi:
+        fi.seek(off)
+        data = fi.read(n)
+    parts = []
+    for k in range(0, len(data), BGZF_BLOCK):
+        ch = data[k:k + BGZF_BLOCK]
+        co = zlib.compressobj(bgzf_level, zlib.DEFLATED, -15)
+        comp = co.compress(ch) + co.flush()
+        parts.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(comp) + 8 - 1)
                      + comp + struct.pack("<II", zlib.crc32(ch), len(ch)))
-            if not ch:
-                break
+    return b"".join(parts)
 
 
+def bgzf_file(src, dst):
+    """what `bgzip -l level` writes: blocks of 0xff00 bytes of text and the empty block at the end; compressed by a pool of
+    processes (level 6 of 32 GB would take minutes on one core)"""
+    import multiprocessing as mp
+    piece = BGZF_BLOCK * 256
+    tasks = [(src, off, piece) for off in range(0, os.path.getsize(src), piece)]
+    with mp.get_context("fork").Pool(min(16, os.cpu_count() or 1)) as pool, open(dst, "wb", buffering=8 << 20) as fo:
+        for out_bytes in pool.imap(bgzf_blocks, tasks, chunksize=1):
+            fo.write(out_bytes)
+        fo.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0\x1b\0\x03\0\0\0\0\0\0\0\0\0")
+
+
+# every input file before the library is loaded: the compressing processes are forked from one that has not touched the device
+paths = {"plain": vcf}
+if "bgzf" in kinds:
+    paths["bgzf"] = vcf + ".bgz"
+    bgzf_file(vcf, paths["bgzf"])
+if "gzip" in kinds:
+    paths["gzip"] = vcf + ".gz"
+    os.system("gzip -1 -c %s > %s" % (vcf, paths["gzip"]))
 L = C.CDLL(b.HOSTLIB)
 L.hpgv_run_assoc.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_size_t, C.POINTER(C.c_long)]
 L.hpgv_host_last_error.restype = C.c_char_p
@@ -66,13 +93,7 @@ import hashlib
 res = []
 digests = set()
 for kind in kinds:
-    path = vcf
-    if kind == "bgzf":
-        path = vcf + ".bgz"
-        bgzf_file(vcf, path)
-    elif kind == "gzip":
-        path = vcf + ".gz"
-        os.system("gzip -1 -c %s > %s" % (vcf, path))
+    path = paths[kind]
     for batch in batches:
         n = C.c_long(0)
         # warm: engine, buffers, and the page cache -- the SECOND read of a freshly written file is a slow one (its pages move
@@ -81,6 +102,9 @@ for kind in kinds:
             L.hpgv_run_assoc(path.encode(), ped.encode(), out.encode(), 1, batch, C.byref(n))
         all_dt = []
         for _ in range(3):
+            if os.path.exists(out) and not os.environ.get("BENCH_KEEP_RESULT"):
+                os.remove(out)                                          # a run writes a new file (truncating the last run's 160 MB of page cache costs 15 - 35 ms)
+            time.sleep(float(os.environ.get("BENCH_PAUSE_S", "0")))      # idle time between the runs (diagnosis: the first H2D copies of a run that follows another at once are slower)
             t0 = time.perf_counter()
             rc = L.hpgv_run_assoc(path.encode(), ped.encode(), out.encode(), 1, batch, C.byref(n))
             all_dt.append(time.perf_counter() - t0)
@@ -89,12 +113,14 @@ for kind in kinds:
         digests.add(hashlib.md5(open(out, "rb").read()).hexdigest())      # every input form must give the same result file
         tm = (C.c_double * 6)()
         L.hpgv_host_last_run_times(tm)
-        res.append({"input": kind, "file_GB": round(os.path.getsize(path) / 1e9, 3), "batch_MB": batch >> 20, "seconds": round(dt, 3),
+        res.append({"input": kind, **({"bgzf_level": bgzf_level} if kind == "bgzf" else {}), "file_GB": round(os.path.getsize(path) / 1e9, 3), "batch_MB": batch >> 20, "seconds": round(dt, 3),
                     "seconds_of_3_runs": [round(x, 3) for x in all_dt],
                     "variants_per_s": round(n_variants / dt), "vcf_text_GBps": round(size / dt / 1e9, 2),
                     "stages_s_last_run": {k: round(v, 3) for k, v in zip(("read", "engine", "write", "sort", "total"), tm)}, "batches": int(tm[5])})
         for env in variants_env:
             os.environ.update(env)
+            if os.path.exists(out) and not os.environ.get("BENCH_KEEP_RESULT"):
+                os.remove(out)
             try:
                 t0 = time.perf_counter()
                 rc = L.hpgv_run_assoc(path.encode(), ped.encode(), out.encode(), 1, batch, C.byref(n))

@@ -18,11 +18,4 @@ C="FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU;SQ_INSTS_LDS SQ_INSTS_SMEM;
 COUNTERS="$C" WAVE=2 bash tools/exp/inflate_pmc.sh 125000 r02_inflate_pmc_wave_per_block > /dev/null || exit 1
 COUNTERS="$C" WAVE=0 bash tools/exp/inflate_pmc.sh 125000 r02_inflate_pmc_lane_per_block > /dev/null || exit 1
 cat $O/r02_inflate_pmc_wave_per_block.json $O/r02_inflate_pmc_lane_per_block.json
-cd $R
-python3 tools/bench_file_runner.py 10000 200000 plain,bgzf 64 "HPGV_BGZF_HOST_TABLE=1" > $O/r02_file_runner_10k_samples.json 2> $O/r02_fr10k.err || { tail -3 $O/r02_fr10k.err; exit 1; }
-cat $O/r02_file_runner_10k_samples.json
-python3 tools/bench_file_runner.py 200 2000000 plain,bgzf 64 > $O/r02_file_runner_200_samples.json 2> $O/r02_fr200.err || { tail -3 $O/r02_fr200.err; exit 1; }
-cat $O/r02_file_runner_200_samples.json
-HPGV_RUN_TRACE=1 python3 tools/bench_file_runner.py 40000 200000 bgzf 64 "HPGV_BGZF_HOST_TABLE=1|HPGV_INFLATE_WAVE=0|HPGV_NO_GPU_INFLATE=1" > $O/r02_file_runner_40k_samples_bgzf.log 2>&1 || { tail -3 $O/r02_file_runner_40k_samples_bgzf.log; exit 1; }
-tail -1 $O/r02_file_runner_40k_samples_bgzf.log > $O/r02_file_runner_40k_samples_bgzf.json
-cat $O/r02_file_runner_40k_samples_bgzf.json
+bash $R/tools/r02_file_runners.sh || exit 1
