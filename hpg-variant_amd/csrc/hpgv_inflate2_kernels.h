@@ -228,13 +228,10 @@ __device__ __forceinline__ uint32_t inf2_mod(uint32_t k, uint32_t dist, float rc
     return r;
 }
 
-static __global__ void __launch_bounds__(64) k_inflate_wave(const uint8_t *__restrict__ comp, const uint64_t *__restrict__ in_off,
-                                                     const uint32_t *__restrict__ in_len, const uint64_t *__restrict__ out_off,
-                                                     const uint32_t *__restrict__ out_len, int n_blocks,
-                                                     uint8_t *text, int32_t *__restrict__ status) {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[INF2_LDS];
-    const int b = (int)blockIdx.x;
-    if (b >= n_blocks) return;
+// block b of the table, by the whole wave
+__device__ __forceinline__ void inf2_one_block(uint8_t *smem, const int b, const uint8_t *__restrict__ comp, const uint64_t *__restrict__ in_off,
+                                               const uint32_t *__restrict__ in_len, const uint64_t *__restrict__ out_off,
+                                               const uint32_t *__restrict__ out_len, uint8_t *text, int32_t *__restrict__ status) {
     const uint32_t lane = threadIdx.x;
     uint64_t start = in_off[b];                         // of what is left of the stream (a stored block moves it on)
     uint32_t clen_bytes = in_len[b];
@@ -452,6 +449,19 @@ static __global__ void __launch_bounds__(64) k_inflate_wave(const uint8_t *__res
     if (!rc && B.consumed_bits() > B.len_bits) rc = 2;              // the codes ran past the block's last byte
     if (!rc && n_out != cap) rc = 18;
     status[b] = rc;
+}
+
+// a wave per block; with fewer workgroups than blocks (a grid of so many per compute unit) a wave goes on to further blocks
+static __global__ void __launch_bounds__(64) k_inflate_wave(const uint8_t *__restrict__ comp, const uint64_t *__restrict__ in_off,
+                                                     const uint32_t *__restrict__ in_len, const uint64_t *__restrict__ out_off,
+                                                     const uint32_t *__restrict__ out_len, int n_blocks,
+                                                     uint8_t *text, int32_t *__restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[INF2_LDS];
+    #pragma unroll 1
+    for (int b = (int)blockIdx.x; b < n_blocks; b += (int)gridDim.x) {
+        inf2_one_block(smem, b, comp, in_off, in_len, out_off, out_len, text, status);
+        __syncthreads();
+    }
 }
 
 }  // namespace hpgv

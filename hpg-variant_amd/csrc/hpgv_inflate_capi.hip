@@ -28,9 +28,15 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
     // (experiment: unused dynamic LDS per wave caps the waves per compute unit and leaves LDS for the kernels beside it)
     const char *lp = getenv("HPGV_INFLATE_LDS_PAD");
     const unsigned lds_pad = lp ? (unsigned)atoi(lp) : 0u;
-    if (wave)
-        hipLaunchKernelGGL(hpgv::k_inflate_wave, dim3((unsigned)n_blocks), dim3(64), lds_pad, (hipStream_t)stream,
+    if (wave) {
+        // (experiment: HPGV_INFLATE_WAVE_WGS = waves per compute unit in flight, each going on to further blocks; 0 = a wave per block)
+        const char *pw = getenv("HPGV_INFLATE_WAVE_WGS");
+        const unsigned per_cu = pw ? (unsigned)atoi(pw) : 0u;
+        unsigned grid = (unsigned)n_blocks;
+        if (per_cu && grid > per_cu * (unsigned)ctx->n_cus) grid = per_cu * (unsigned)ctx->n_cus;
+        hipLaunchKernelGGL(hpgv::k_inflate_wave, dim3(grid), dim3(64), lds_pad, (hipStream_t)stream,
                            d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
+    }
     else if (ctx->inflate_wave != 3) {
         // (experiment: HPGV_INFLATE_LANE_WGS = workgroups per compute unit in flight; 0 = one per 64 blocks)
         const char *pc = getenv("HPGV_INFLATE_LANE_WGS");

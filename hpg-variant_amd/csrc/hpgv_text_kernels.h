@@ -286,9 +286,14 @@ static __global__ __launch_bounds__(1024) void k_head_offsets(const unsigned lon
     }
     part[t] = sum;
     __syncthreads();
-    if (t == 0) { unsigned long long acc = 0; for (int k = 0; k < 1024; k++) { const unsigned long long v = part[k]; part[k] = acc; acc += v; } head_off[n_lines] = acc; }
-    __syncthreads();
-    unsigned long long acc = part[t];
+    for (int d = 1; d < 1024; d <<= 1) {                            // inclusive scan of the 1024 partial sums (one thread walking them took 12 us)
+        const unsigned long long v = t >= d ? part[t - d] : 0ull;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    if (t == 1023) head_off[n_lines] = part[1023];
+    unsigned long long acc = part[t] - sum;
     for (int i = lo; i < hi; i++) {
         head_off[i] = acc;
         const uint32_t f9 = field_off[(size_t)i * 10 + 9];

@@ -1712,6 +1712,7 @@ typedef struct {
     uint64_t *g_in_off, *g_out_off; uint32_t *g_in_len, *g_out_len; size_t g_nb, g_done;      /* the stager's block tables */
     size_t dev_ready;                                   /* text bytes decoded so far (under g_mu) */
     size_t d_text_cap; int d_text_kind;
+    size_t text_est;                                     /* about how much text the file holds (known when the stage has chosen its path) */
     int dev_len_known;                                  /* 0 while the stager is still finding the file's blocks (under g_mu) */
     void *d_scan;                                       /* the streaming stager's tables, statuses and scan scratch */
     int c_low;                                          /* cstream (and the slots' streams) have the lowest priority */
@@ -2052,7 +2053,7 @@ enum { GPU_STRETCH = 32768, GPU_AHEAD_BYTES = 768 << 20 };
  * that has arrived (s->up_done, under g_mu).  Nobody waits at a barrier: a reader waits only for its slot to be free, the
  * copier only for the next segment to be filled.  (Halves of a buffer filled by a team, with a barrier per half, left
  * the bus at 18 - 28 GB/s beside the pipeline's own threads.) */
-enum { UP_SEG = 4 << 20, UP_SLOTS = 16, UP_READERS_MAX = 12 };
+enum { UP_SEG = 4 << 20, UP_SLOTS = 16, UP_READERS_MAX = 12, UP_INFLIGHT = 2 };
 static size_t pread_full(int fd, void *buf, size_t n, size_t pos);
 typedef struct {
     source_t *s; char *pin; size_t n_seg;
@@ -2098,10 +2099,13 @@ static void *bgzf_uploader(void *v) {
     }
     ok = ok && pin && n_th > 0;
     double t_wait = 0, t_copy = 0; const double t_begin = now_s();
-    void *up2 = NULL;                                                /* two copies in flight: one is queued while the one before is waited for */
-    ok = ok && stream_get(0, &up2) == HPGV_OK;
-    void *st2[2] = { up, up2 };
-    for (size_t i = 0; ok && i <= r.n_seg; i++) {
+    /* UP_INFLIGHT copies in flight: one is waited for while the others are queued or running */
+    enum { UP_INFLIGHT_MAX = 8 };
+    const char *uf = getenv("HPGV_UPLOAD_INFLIGHT");
+    const int depth = uf && atoi(uf) >= 1 && atoi(uf) <= UP_INFLIGHT_MAX ? atoi(uf) : UP_INFLIGHT;
+    void *stq[UP_INFLIGHT_MAX] = { up };
+    for (int k = 1; ok && k < depth; k++) ok = stream_get(0, &stq[k]) == HPGV_OK;
+    for (size_t i = 0; ok && i < r.n_seg + (size_t)depth - 1; i++) {
         double t0 = now_s();
         if (i < r.n_seg) {
             pthread_mutex_lock(&r.mu);
@@ -2111,12 +2115,12 @@ static void *bgzf_uploader(void *v) {
             t_wait += now_s() - t0; t0 = now_s();
             if (!ok) break;
             const size_t off = i * (size_t)UP_SEG, len = off + UP_SEG <= (size_t)s->size ? (size_t)UP_SEG : (size_t)s->size - off;
-            ok = hpgv_memcpy_h2d_async(g_ctx, (char *)s->d_comp + off, pin + (i % UP_SLOTS) * (size_t)UP_SEG, len, st2[i & 1]) == HPGV_OK;
+            ok = hpgv_memcpy_h2d_async(g_ctx, (char *)s->d_comp + off, pin + (i % UP_SLOTS) * (size_t)UP_SEG, len, stq[i % (size_t)depth]) == HPGV_OK;
             if (!ok) break;
         }
-        if (i == 0) continue;
-        const size_t j = i - 1, off = j * (size_t)UP_SEG, len = off + UP_SEG <= (size_t)s->size ? (size_t)UP_SEG : (size_t)s->size - off;
-        ok = hpgv_stream_sync(g_ctx, st2[j & 1]) == HPGV_OK;
+        if (i + 1 < (size_t)depth) continue;
+        const size_t j = i + 1 - (size_t)depth, off = j * (size_t)UP_SEG, len = off + UP_SEG <= (size_t)s->size ? (size_t)UP_SEG : (size_t)s->size - off;
+        ok = hpgv_stream_sync(g_ctx, stq[j % (size_t)depth]) == HPGV_OK;
         t_copy += now_s() - t0;
         pthread_mutex_lock(&r.mu);
         r.filled[j % UP_SLOTS] = 0; r.copied = j + 1;
@@ -2131,7 +2135,7 @@ static void *bgzf_uploader(void *v) {
         pthread_mutex_unlock(&s->g_mu);
         if (cancel) { ok = 0; break; }
     }
-    stream_put(0, up2);
+    for (int k = 1; k < depth; k++) if (stq[k]) { (void)hpgv_stream_sync(g_ctx, stq[k]); stream_put(0, stq[k]); }
     if (up) (void)hpgv_stream_sync(g_ctx, up);
     if (getenv("HPGV_RUN_TRACE"))
         fprintf(stderr, "uploader: %.1f MB in %.4f s: %.4f s waiting for the readers (%d), %.4f s in copies\n", s->size / 1e6, now_s() - t_begin, t_wait, n_th, t_copy);
@@ -2652,6 +2656,7 @@ static int bgzf_stream_stage(source_t *s) {
         dev_text_free(old, old_kind);
     }
     if (ok) {
+        s->text_est = est;
         s->d_text = dev_text_get(est, &s->d_text_cap, &s->d_text_kind);
         ok = s->d_text != NULL && ((s->d_text_kind == DEV_TEXT_GROWS && !getenv("HPGV_NO_GROWING_TEXT")) || S->chain_pos >= (size_t)s->size);
         if (!ok && s->d_text) { dev_text_put(s->d_text, s->d_text_cap, s->d_text_kind); s->d_text = NULL; }
@@ -2726,7 +2731,7 @@ static int bgzf_gpu_stage(source_t *s) {
     if (ok && (nb < 256 || nb > 0x7FFFFFFFu || text > ((size_t)48 << 30))) ok = 0;     /* a small file is as quick on the host */
     if (ok) { s->c_low = 0; ok = stream_get(0, &s->rstream) == HPGV_OK && stream_get(0, &s->cstream) == HPGV_OK; }
     if (ok) ok = hpgv_dev_alloc(g_ctx, nb * 24 + 64, &s->d_tab) == HPGV_OK;
-    if (ok) { s->d_text = dev_text_get(text + 16, &s->d_text_cap, &s->d_text_kind); ok = s->d_text != NULL; }
+    if (ok) { s->text_est = text; s->d_text = dev_text_get(text + 16, &s->d_text_cap, &s->d_text_kind); ok = s->d_text != NULL; }
     if (ok) ok = hpgv_dev_alloc(g_ctx, nb * 4 + 16, &s->d_status) == HPGV_OK;
     if (dbg) fprintf(stderr, "stage: alloc %.4f\n", now_s() - T0);
     if (ok) {
@@ -3830,6 +3835,14 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
         if (et && atoi(et) > 0) P->n_engines = atoi(et);
         if (P->n_engines > RUN_ENGINES_MAX) P->n_engines = RUN_ENGINES_MAX;
         P->nb = P->n_engines + 3;
+    }
+    /* windows of a text that is on the device are not copied anywhere, so they need not be as small as the caller's batches:
+     * about 64 of them per file, 256 MB at most, amortise what a batch costs whatever its size (three waits for the
+     * device and 50 us of short kernels beside 100 us per 64 MB of tokenizing and scanning) */
+    if (P && rd.src.d_text && !getenv("HPGV_NO_DEVICE_WINDOWS") && !getenv("HPGV_NO_LARGE_WINDOWS")) {
+        size_t w = rd.src.text_est / 64;
+        if (w > ((size_t)256 << 20)) w = (size_t)256 << 20;
+        if (w > batch_bytes) batch_bytes = w;
     }
     for (; !rc && have < P->nb; have++) rc = run_batch_alloc(&P->bt[have], batch_bytes, n_samples, kind == 4 ? n_samples : 0, kind >= 5, n_trios, n_groups);
     if (rc == HPGV_ERR_NOMEM) snprintf(g_err, sizeof g_err, "out of memory for the batch buffers");

@@ -11,11 +11,13 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 bin_ns = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 10e6
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
-# runs are separated by gaps without an inflate kernel; take the launches after the last gap of > 20 ms between any kernels
-cut = 0
-for i in range(1, len(ev)):
-    if ev[i][0] - max(e[1] for e in ev[max(0, i - 50):i]) > 20e6:
-        cut = i
+# a run begins with the block-table scan (k_bgzf_count) that follows a batch kernel of the run before; the last run is taken
+cut, seen_batch = 0, False
+for i, (_, _, n) in enumerate(ev):
+    if "k_batch" in n:
+        seen_batch = True
+    elif "k_bgzf_count" in n and seen_batch:
+        cut, seen_batch = i, False
 ev = ev[cut:]
 t0 = ev[0][0]
 t1 = max(e[1] for e in ev)
