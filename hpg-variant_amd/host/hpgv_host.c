@@ -2053,7 +2053,9 @@ enum { GPU_STRETCH = 32768, GPU_AHEAD_BYTES = 768 << 20 };
  * that has arrived (s->up_done, under g_mu).  Nobody waits at a barrier: a reader waits only for its slot to be free, the
  * copier only for the next segment to be filled.  (Halves of a buffer filled by a team, with a barrier per half, left
  * the bus at 18 - 28 GB/s beside the pipeline's own threads.) */
-enum { UP_SEG = 4 << 20, UP_SLOTS = 16, UP_READERS_MAX = 12, UP_INFLIGHT = 2 };
+enum { UP_SEG_DEFAULT = 4 << 20, UP_SLOTS = 16, UP_READERS_MAX = 12, UP_INFLIGHT = 2 };
+static size_t g_up_seg = UP_SEG_DEFAULT;                 /* bytes per segment (HPGV_UPLOAD_SEGMENT_MB: diagnosis) */
+#define UP_SEG g_up_seg
 static size_t pread_full(int fd, void *buf, size_t n, size_t pos);
 typedef struct {
     source_t *s; char *pin; size_t n_seg;
@@ -2084,6 +2086,8 @@ static void *bgzf_uploader(void *v) {
     source_t *s = (source_t *)v;
     void *up = NULL;
     int ok = stream_get(0, &up) == HPGV_OK;
+    const char *us = getenv("HPGV_UPLOAD_SEGMENT_MB");
+    g_up_seg = us && atoi(us) >= 1 && atoi(us) <= 64 ? (size_t)atoi(us) << 20 : (size_t)UP_SEG_DEFAULT;
     const size_t pin_cap = (size_t)UP_SEG * UP_SLOTS;
     char *pin = text_buf_get(pin_cap + 1);                          /* from the runs' cache of page-locked buffers */
     up_ring_t r;
@@ -2151,6 +2155,7 @@ static void *bgzf_uploader(void *v) {
     pthread_mutex_unlock(&s->g_mu);
     return NULL;
 }
+#undef UP_SEG
 /* the stager waits until the file's first `hi` bytes are on the device; 0 when the uploader failed */
 static int wait_uploaded(source_t *s, size_t hi) {
     pthread_mutex_lock(&s->g_mu);
@@ -2560,8 +2565,10 @@ static void *bgzf_gpu_stream_stager(void *v) {
         pthread_mutex_unlock(&R.mu);
         if (!ok) break;
         scan_slot_t *q = &S->slot[k % SCAN_SLOTS];
-        /* a short first stretch, which the header reader and the pipeline wait for, then stretches that double */
-        size_t rows = launched == 0 ? 4096 : launched < 4096 + 32768 ? 32768 : launched < 4096 + 3 * 32768 ? 65536 : SCAN_ROWS_MAX;
+        /* a short first stretch, which the header reader and the pipeline wait for, then 16 384 and 32 768 blocks at a time:
+         * a stretch is launched when its bytes are up, and the decoder (23 GB/s of bgzip's level-6 bytes) is not much slower than
+         * the bus -- behind stretches that double (up to 131 072 blocks) the device waited for the next one's bytes */
+        size_t rows = launched == 0 ? 4096 : launched < 4096 + 16384 ? 16384 : 32768;
         if (S->rows_cap && rows > S->rows_cap) rows = S->rows_cap;
         if (k == 0 && S->first_n) q->n = S->first_n;                 /* found when the path was chosen */
         else ok = scan_next_rows(s, S, q, rows, 1, dbg, T0) == 1;

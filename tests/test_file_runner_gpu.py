@@ -523,12 +523,12 @@ def test_run_assoc_bgzf_text_buffer_grows_during_the_run(host, tmp_path, capfd):
     open(packed, "wb").write(bytes(out) + _bgzf(b"", 0x700))
     ped = str(tmp_path / "ped.txt").encode()
 
-    def run(path, tag, env=None):
+    def run(path, tag, env=None, batch=8 << 20):
         os.environ.update(env or {})
         try:
             o = str(tmp_path / ("res_" + tag))
             n = C.c_long(0)
-            rc = host.hpgv_run_assoc(path.encode(), ped, o.encode(), 1, 8 << 20, C.byref(n))
+            rc = host.hpgv_run_assoc(path.encode(), ped, o.encode(), 1, batch, C.byref(n))
             assert rc == 0 and n.value == n_variants, host.hpgv_host_last_error()
             return open(o, "rb").read()
         finally:
@@ -540,6 +540,14 @@ def test_run_assoc_bgzf_text_buffer_grows_during_the_run(host, tmp_path, capfd):
     err = capfd.readouterr().err
     assert "streaming" in err and err.count("blocks found") >= 6
     assert run(packed, "as_estimated") == plain
+    # the windows of a text that stays on the device are about a 64th of the file whatever the caller's batch size: with
+    # batches of 256 KB this text goes through in some 70 windows of 1.5 MB, or, with that switched off, in 370 of 256 KB
+    capfd.readouterr()
+    assert run(packed, "large_windows", {"HPGV_RUN_TRACE": "1"}, batch=1 << 18) == plain
+    n_large = int(capfd.readouterr().err.split(" records, ")[1].split(" batches")[0])
+    assert run(packed, "callers_windows", {"HPGV_RUN_TRACE": "1", "HPGV_NO_LARGE_WINDOWS": "1"}, batch=1 << 18) == plain
+    n_small = int(capfd.readouterr().err.split(" records, ")[1].split(" batches")[0])
+    assert 50 <= n_large <= 90 and n_small >= 4 * n_large, (n_large, n_small)
 
 
 @pytest.mark.parametrize("chroms", [("1", "2", "10", "22"), ("1", "2", "22", "X"), ("1", "1", "1", "1")], ids=["numbered", "x_last", "one"])

@@ -10,15 +10,18 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 bin_ns = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 10e6
-ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
-# a run begins with the block-table scan (k_bgzf_count) that follows a batch kernel of the run before; the last run is taken
-cut, seen_batch = 0, False
-for i, (_, _, n) in enumerate(ev):
-    if "k_batch" in n:
-        seen_batch = True
-    elif "k_bgzf_count" in n and seen_batch:
-        cut, seen_batch = i, False
-ev = ev[cut:]
+ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0)) for r in rows)
+# a run's first decoder launch is the short stretch of 4 096 blocks (a wave each); the run begins with the block-table scan
+# before it.  The last run in the trace is taken.
+first = [i for i, e in enumerate(ev) if "inflate" in e[2] and e[3] == 4096 * 64]
+cut = 0
+if first:
+    cut = first[-1]
+    while cut > 0 and ("bgzf" in ev[cut - 1][2] or "inflate" in ev[cut - 1][2] or ev[cut][0] - ev[cut - 1][1] < 2e6):
+        cut -= 1
+        if "k_bgzf_count" in ev[cut][2]:
+            break
+ev = [(s0, e0, n) for s0, e0, n, _ in ev[cut:]]
 t0 = ev[0][0]
 t1 = max(e[1] for e in ev)
 
