@@ -490,14 +490,23 @@ __device__ __forceinline__ void stats_consume_tile(const uint4 (&q)[4], StatsAcc
     stats_count_tile(q, a);
     const int r = t / ipr;
     if (t - r * ipr == ipr - 1) {                               // the row's last tile: weigh the residual words, reduce, store
-        int s[8];
+        int s[8], c[8];
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const uint32_t m = 0x01010101u << b;
-            const int c = 16 * a.c16[b] + 8 * __builtin_popcount(a.eights & m) + 4 * __builtin_popcount(a.fours & m) +
-                          2 * __builtin_popcount(a.twos & m) + __builtin_popcount(a.ones & m);
-            s[b] = wave_sum(c);
+            c[b] = 16 * a.c16[b] + 8 * __builtin_popcount(a.eights & m) + 4 * __builtin_popcount(a.fours & m) +
+                   2 * __builtin_popcount(a.twos & m) + __builtin_popcount(a.ones & m);
             a.c16[b] = 0;
+        }
+        if (ipr * 4096 < 65536) {                               // a row of fewer than 65 536 bytes: two counters share a wave sum
+#pragma unroll
+            for (int b = 0; b < 8; b += 2) {
+                const int two = wave_sum(c[b] | (c[b + 1] << 16));
+                s[b] = two & 0xFFFF; s[b + 1] = (int)((uint32_t)two >> 16);
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) s[b] = wave_sum(c[b]);
         }
         a.ones = a.twos = a.fours = a.eights = 0u;
         const long v = v_begin + r;

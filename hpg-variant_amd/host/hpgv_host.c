@@ -411,21 +411,33 @@ static int init_from_environment(void) {
 
 /* page-locked text buffers of the file runners, kept between runs: page-locking 5 x 64 MB costs 56 ms and releasing it
  * another 45 ms -- a third of a run over an 8 GB file.  Released by hpgv_host_shutdown. */
-enum { TEXT_CACHE_N = 24 };
+enum { TEXT_CACHE_N = 24, TEXT_LIVE_N = 64 };
 static struct { char *p; size_t cap; } g_text_cache[TEXT_CACHE_N];
+static struct { char *p; size_t cap; } g_text_live[TEXT_LIVE_N];      /* buffers that are out, with what they really hold */
 static pthread_mutex_t g_text_mu = PTHREAD_MUTEX_INITIALIZER;
 static char *text_buf_get(size_t cap) {
     char *p = NULL;
+    size_t real = cap;
     pthread_mutex_lock(&g_text_mu);
-    for (int i = 0; i < TEXT_CACHE_N && !p; i++)
-        if (g_text_cache[i].p && g_text_cache[i].cap >= cap) { p = g_text_cache[i].p; g_text_cache[i].p = NULL; g_text_cache[i].cap = 0; }
+    int best = -1;                                        /* the smallest one that is large enough: the 256 MB windows of a bgzip run stay for the next such run */
+    for (int i = 0; i < TEXT_CACHE_N; i++)
+        if (g_text_cache[i].p && g_text_cache[i].cap >= cap && (best < 0 || g_text_cache[i].cap < g_text_cache[best].cap)) best = i;
+    if (best >= 0) { p = g_text_cache[best].p; real = g_text_cache[best].cap; g_text_cache[best].p = NULL; g_text_cache[best].cap = 0; }
     pthread_mutex_unlock(&g_text_mu);
     if (!p && hpgv_host_alloc(g_ctx, cap, (void **)&p) != HPGV_OK) p = NULL;      /* pinned: full-rate H2D */
+    if (p) {                                              /* a larger buffer that served a smaller request goes back as what it is */
+        pthread_mutex_lock(&g_text_mu);
+        for (int i = 0; i < TEXT_LIVE_N; i++)
+            if (!g_text_live[i].p) { g_text_live[i].p = p; g_text_live[i].cap = real; break; }
+        pthread_mutex_unlock(&g_text_mu);
+    }
     return p;
 }
 static void text_buf_put(char *p, size_t cap) {
     if (!p) return;
     pthread_mutex_lock(&g_text_mu);
+    for (int i = 0; i < TEXT_LIVE_N; i++)
+        if (g_text_live[i].p == p) { if (g_text_live[i].cap > cap) cap = g_text_live[i].cap; g_text_live[i].p = NULL; break; }
     int kept = 0;
     for (int i = 0; i < TEXT_CACHE_N && !kept; i++)
         if (!g_text_cache[i].p) { g_text_cache[i].p = p; g_text_cache[i].cap = cap; kept = 1; }
