@@ -280,7 +280,9 @@ int  hpgv_host_inflate_raw(const unsigned char *in, size_t in_len, unsigned char
  *      (tdt_runner.c:23-279) do, minus options/filters: read the PED, read the VCF (plain text,
  *      gzip or bgzip -- `--compression`, shared_options.c:60-61; detected from the file's magic, BGZF
  *      blocks are inflated in parallel) in text batches of about batch_bytes, hand every batch to the engine as TEXT (the GPU
- *      tokenizes it), write the reference's TSV and sort it in process.  Reader, engine and
+ *      tokenizes it), write the reference's TSV and sort it in process.  (A bgzip file of 256 blocks or more is decoded on the
+ *      device and its text stays there: batch_bytes is then a lower bound, the windows are about a 64th of the text, 256 MB
+ *      at most.)  Reader, engine and
  *      writer overlap (one batch in flight each way).  PED columns: FID IID PAT MAT SEX PHENO
  *      with SEX 1 = male, 2 = female and PHENO 2 = affected, 1 = unaffected
  *      (stats_runner.c:50,86-87).  Returns 0 or an hpgv / errno-style non-zero code;
