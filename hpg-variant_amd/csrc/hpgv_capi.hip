@@ -209,7 +209,7 @@ int hpgv_create(int device_id, hpgv_ctx **out) {
     }
     if (const char *bc = getenv("HPGV_BATCH_COPY")) ctx->batch_copy = atoi(bc) ? 1 : 0;
     if (const char *bf = getenv("HPGV_BATCH_FUSED")) ctx->batch_fused = atoi(bf) ? 1 : 0;      // diagnosis: 0 = the kernel chains
-    if (const char *iw = getenv("HPGV_INFLATE_WAVE")) ctx->inflate_wave = atoi(iw) < 0 ? 0 : atoi(iw) > 3 ? 3 : atoi(iw);   // diagnosis: 0 = lane per block, 2 = wave per block, 1 = by size
+    if (const char *iw = getenv("HPGV_INFLATE_WAVE")) ctx->inflate_wave = atoi(iw) < 0 ? 0 : atoi(iw) > 4 ? 4 : atoi(iw);   // diagnosis: 0 = lane per block, 2 = wave per block, 1 = by size
     if (const char *tt = getenv("HPGV_TOKENIZER_TILES")) ctx->tokenizer_tiles = atoi(tt) ? 1 : 0;   // diagnosis: 0 = the three-sweep tokenizer
     e = hipMalloc(&ctx->d_sink, 256);
     if (e != hipSuccess) {
@@ -346,7 +346,7 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
     } else if (!strcmp(key, "batch_copy")) {
         ctx->batch_copy = value ? 1 : 0;
     } else if (!strcmp(key, "inflate_wave")) {
-        if (value < 0 || value > 3) return fail(ctx, HPGV_ERR_INVALID, "inflate_wave must be 0 (lane per block), 1 (by the number of blocks), 2 (wave per block) or 3 (lane per block, symbol tables in LDS)");
+        if (value < 0 || value > 4) return fail(ctx, HPGV_ERR_INVALID, "inflate_wave must be 0 (lane per block), 1 (by the number of blocks), 2 (wave per block), 4 (wave per block, several symbols per round) or 3 (lane per block, symbol tables in LDS)");
         ctx->inflate_wave = value;
     } else if (!strcmp(key, "tokenizer_tiles")) {
         ctx->tokenizer_tiles = value ? 1 : 0;

@@ -219,6 +219,57 @@ __device__ __forceinline__ uint32_t inf2_ring_at(bool on, uint32_t p) { return i
     }                                                                                                                  \
 } while (0)
 
+// a match of `len_` bytes from `dist_` bytes back, as the single-symbol loop below copies it (rc = 17: it reaches back further
+// than the text goes, or the text would overflow)
+#define INF2_MATCH(len_, dist_) do {                                                                                   \
+    const uint32_t ml_ = (len_), md_ = (dist_);                                                                        \
+    if (md_ > n_out || ml_ > cap - n_out) { rc = 17; break; }                                                          \
+    {                                                                                                                  \
+        const bool on_ = lane < pend_n;                                                                                \
+        inf2_w8(smem, inf2_ring_at(on_, pend_pos + lane), pend_v);                                                     \
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)pend_v, ors, on_ ? (int)(pend_pos + lane) : -1, 0, 0);           \
+        pend_n = 0;                                                                                                    \
+    }                                                                                                                  \
+    const uint32_t dvz_ = md_ | vz, lvz_ = ml_ | vz;                                                                   \
+    if (!inf2_u((uint32_t)(dvz_ > (uint32_t)INF2_WINDOW) | (uint32_t)(dvz_ < lvz_) | (uint32_t)(lvz_ > 64u))) {        \
+        pend_pos = n_out; pend_n = ml_;                                                                                \
+        pend_v = inf2_r8(smem, (uint32_t)INF2_RING + ((n_out - md_ + lane) & (INF2_WINDOW - 1)));                      \
+        n_out += ml_;                                                                                                  \
+        break;                                                                                                         \
+    }                                                                                                                  \
+    if (md_ > INF2_WINDOW) {                                                                                           \
+        _Pragma("unroll 1")                                                                                            \
+        for (uint32_t done_ = 0; done_ < ml_; done_ += 64) {                                                           \
+            const uint32_t k_ = done_ + lane;                                                                          \
+            const bool on_ = k_ < ml_;                                                                                 \
+            const uint8_t v_ = __builtin_amdgcn_raw_buffer_load_b8(ors, on_ ? (int)(n_out - md_ + k_) : -1, 0, 0);     \
+            inf2_w8(smem, inf2_ring_at(on_, n_out + k_), v_);                                                          \
+            __builtin_amdgcn_raw_buffer_store_b8(v_, ors, on_ ? (int)(n_out + k_) : -1, 0, 0);                         \
+        }                                                                                                              \
+        n_out += ml_;                                                                                                  \
+        break;                                                                                                         \
+    }                                                                                                                  \
+    const uint32_t from_ = n_out - md_;                                                                                \
+    const bool wrap_ = md_ < ml_;                                                                                      \
+    const float rcp_ = __builtin_amdgcn_rcpf((float)md_);                                                              \
+    uint32_t done_ = 0;                                                                                                \
+    _Pragma("unroll 1")                                                                                                \
+    for (; done_ + 64 < ml_; done_ += 64) {                                                                            \
+        const uint32_t k_ = done_ + lane;                                                                              \
+        const uint32_t r_ = wrap_ ? inf2_mod(k_, md_, rcp_) : k_;                                                      \
+        const uint32_t v_ = inf2_r8(smem, (uint32_t)INF2_RING + ((from_ + r_) & (INF2_WINDOW - 1)));                   \
+        inf2_w8(smem, (uint32_t)INF2_RING + ((n_out + k_) & (INF2_WINDOW - 1)), v_);                                   \
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v_, ors, (int)(n_out + k_), 0, 0);                               \
+    }                                                                                                                  \
+    {                                                                                                                  \
+        const uint32_t k_ = done_ + lane;                                                                              \
+        const uint32_t r_ = wrap_ ? inf2_mod(k_, md_, rcp_) : k_;                                                      \
+        pend_pos = n_out + done_; pend_n = ml_ - done_;                                                                \
+        pend_v = inf2_r8(smem, (uint32_t)INF2_RING + ((from_ + r_) & (INF2_WINDOW - 1)));                              \
+    }                                                                                                                  \
+    n_out += ml_;                                                                                                      \
+} while (0)
+
 // byte k of a match that repeats its own output is byte k mod dist of the dist bytes before it
 __device__ __forceinline__ uint32_t inf2_mod(uint32_t k, uint32_t dist, float rcp) {
     const uint32_t q = (uint32_t)((float)k * rcp);
@@ -228,7 +279,8 @@ __device__ __forceinline__ uint32_t inf2_mod(uint32_t k, uint32_t dist, float rc
     return r;
 }
 
-// block b of the table, by the whole wave
+// block b of the table, by the whole wave.  MULTI: several symbols per round of the symbol loop (below)
+template <bool MULTI>
 __device__ __forceinline__ void inf2_one_block(uint8_t *smem, const int b, const uint8_t *__restrict__ comp, const uint64_t *__restrict__ in_off,
                                                const uint32_t *__restrict__ in_len, const uint64_t *__restrict__ out_off,
                                                const uint32_t *__restrict__ out_len, uint8_t *text, int32_t *__restrict__ status) {
@@ -338,6 +390,125 @@ __device__ __forceinline__ void inf2_one_block(uint8_t *smem, const int b, const
         __syncthreads();
         inf2_fill<INF2_ROOT_D, 1>(smem, INF2_CNT_D, INF2_SYM_D, INF2_LUT_D);
         __syncthreads();
+        if (MULTI) {
+            // ---- several symbols per round.  The next 2 048 bits of the stream lie in ONE vector register (lane j: dword
+            // W0 + j); the 128 bits from the stream's position P on are picked out of it with five v_readlane, and lane i
+            // decodes the symbol that would start i bits further on -- its length code, extra bits, distance code, extra bits,
+            // all inside its own 64-bit window -- with two LDS reads for the whole wave.  The lanes on the true chain are then
+            // visited one after the other (lane 0, then the lane its symbol ends at, ...): two v_readlane per symbol give the
+            // scalar unit its length and distance, and the copy is the one of the single-symbol loop.  A symbol that is not an
+            // everyday one (a code longer than the table's index, the end of the block, a code that is none) ends the chain
+            // and is decoded on its own from the window of lane 0.
+            const uint32_t *wsrc = (const uint32_t *)(uintptr_t)B.base;
+            const uint32_t w_last = B.last_off;
+            const uint32_t gp = (uint32_t)(B.consumed_bits() + B.skip);      // bits from the dword-aligned base on
+            uint32_t W0 = gp >> 5, P = gp & 31;
+            #define INF2_WLOAD(w) wsrc[(((w) + lane) * 4 < w_last ? ((w) + lane) * 4 : w_last) >> 2]
+            uint32_t win = INF2_WLOAD(W0), nxt = INF2_WLOAD(W0 + 32);
+            int done = 0;
+            #pragma unroll 1
+            while (!done) {
+                if (P >= 1024) { win = nxt; W0 += 32; P -= 1024; nxt = INF2_WLOAD(W0 + 32); }
+                const uint32_t Q = P >> 5, sh = P & 31;
+                const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)Q), w1 = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)Q + 1),
+                               w2 = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)Q + 2), w3 = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)Q + 3),
+                               w4 = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)Q + 4);
+                const uint64_t lo64 = (uint64_t)w0 | ((uint64_t)w1 << 32), mid64 = (uint64_t)w2 | ((uint64_t)w3 << 32);
+                const uint64_t A0 = sh ? (lo64 >> sh) | (mid64 << (64 - sh)) : lo64;
+                const uint64_t A1 = sh ? (mid64 >> sh) | ((uint64_t)w4 << (64 - sh)) : mid64;
+                const uint64_t X = (A0 >> lane) | ((A1 << 1) << (63 - lane));          // the 64 bits from lane bits on
+                const uint32_t xl = (uint32_t)X;
+                const uint32_t e = inf2_r32(smem, (uint32_t)INF2_LUT_L + ((xl & ((1u << INF2_ROOT_L) - 1)) << 2));
+                const uint32_t cl = e & 15, used1 = (e >> 10) & 31;
+                const bool is_lit = cl != 0 && (e & 0x300u) == 0, is_len = cl != 0 && (e & 0x300u) == 0x100u;
+                const uint32_t len = (e >> 16) + ((xl >> cl) & ((1u << ((e >> 4) & 15)) - 1));
+                const uint32_t y = (uint32_t)(X >> (is_len ? used1 : 0u));
+                const uint32_t d = inf2_r32(smem, (uint32_t)INF2_LUT_D + ((y & ((1u << INF2_ROOT_D) - 1)) << 2));
+                const bool d_ok = (d & 15) != 0 && (d & 0x300u) == 0x100u;
+                const uint32_t dist = (d >> 16) + ((y >> (d & 15)) & ((1u << ((d >> 4) & 15)) - 1));
+                // bits of the symbol (0: not an everyday one), and what the copy needs: a literal's byte, or length | distance << 16
+                const uint32_t tbv = is_lit ? cl : (is_len && d_ok) ? used1 + ((d >> 10) & 31) : 0u;
+                const uint32_t infov = is_lit ? (e >> 16) : (len | (dist << 16));
+                // which lanes hold a literal, and which a match of the everyday kind (out of the ring, not longer than its
+                // distance, 64 bytes at most, not from before the text as it stands now): one bit test per symbol in the chain
+                const uint64_t lit_m = __ballot(is_lit);
+                // (64 symbols of 64 bytes at most: with 4 096 bytes of room left no everyday match needs its own look at the room)
+                const uint64_t easy_m = cap - n_out >= 4096u
+                    ? __ballot(!is_lit & !((dist > (uint32_t)INF2_WINDOW) | (dist < len) | (len > 64u) | (dist > n_out))) : 0ull;
+                uint32_t pos = 0;
+                #pragma unroll 1
+                while (pos < 64) {
+                    const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tbv, (int)pos);
+                    if (t == 0) break;
+                    const uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)infov, (int)pos);
+                    const uint32_t here = pos;
+                    pos += t;
+                    const uint32_t mlen = info & 0x1FFu, mdist = info >> 16;
+                    if (!((easy_m >> here) & 1)) {                    // a literal, or a match that is not an everyday one
+                        if ((lit_m >> here) & 1) {
+                            INF2_COMPLETE();
+                            if (n_out >= cap) rc = 14;
+                            else {
+                                inf2_w8(smem, inf2_ring_at(lane == 0, n_out), info);
+                                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)info, ors, lane == 0 ? (int)n_out : -1, 0, 0);
+                                n_out++;
+                            }
+                        } else {
+                            INF2_MATCH(mlen, mdist);
+                        }
+                        if (rc) break;
+                        continue;
+                    }
+                    const bool on_ = lane < pend_n;                  // the ring write and the store of the match before
+                    inf2_w8(smem, inf2_ring_at(on_, pend_pos + lane), pend_v);
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)pend_v, ors, on_ ? (int)(pend_pos + lane) : -1, 0, 0);
+                    pend_pos = n_out; pend_n = mlen;
+                    pend_v = inf2_r8(smem, (uint32_t)INF2_RING + ((n_out - mdist + lane) & (INF2_WINDOW - 1)));
+                    n_out += mlen;
+                }
+                if (rc) break;
+                if (pos == 0) {                                       // the symbol at the position itself is not an everyday one
+                    const uint64_t sb = A0;
+                    uint32_t e0 = inf2_u(e);
+                    if ((e0 & 15) == 0) { e0 = inf2_slow<0>(smem, sb, INF2_CNT_L, INF2_SYM_L); if (!e0) { rc = 13; break; } }
+                    if ((e0 & 0x300u) == 0) {                         // a literal with a long code
+                        pos = e0 & 15;
+                        INF2_COMPLETE();
+                        if (n_out >= cap) { rc = 14; break; }
+                        inf2_w8(smem, inf2_ring_at(lane == 0, n_out), e0 >> 16);
+                        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(e0 >> 16), ors, lane == 0 ? (int)n_out : -1, 0, 0);
+                        n_out++;
+                    } else if ((e0 & 0x300u) != 0x100u) {             // end of block, or not a symbol
+                        pos = e0 & 15;
+                        if ((e0 & 0x300u) == 0x300u) rc = 15;
+                        done = 1;
+                    } else {
+                        const uint32_t used = (e0 >> 10) & 31;
+                        const uint32_t slen = (e0 >> 16) + ((uint32_t)(sb >> (e0 & 15)) & ((1u << ((e0 >> 4) & 15)) - 1));
+                        const uint64_t sb2 = sb >> used;
+                        uint32_t d0 = inf2_u(inf2_r32(smem, (uint32_t)INF2_LUT_D + 4 * ((uint32_t)sb2 & ((1u << INF2_ROOT_D) - 1))));
+                        if ((d0 & 0x300u) != 0x100u) {
+                            if ((d0 & 15) == 0) d0 = inf2_slow<1>(smem, sb2, INF2_CNT_D, INF2_SYM_D);
+                            if ((d0 & 0x300u) != 0x100u) { rc = 16; break; }
+                        }
+                        const uint32_t sdist = (d0 >> 16) + (((uint32_t)sb2 >> (d0 & 15)) & ((1u << ((d0 >> 4) & 15)) - 1));
+                        pos = used + ((d0 >> 10) & 31);
+                        INF2_MATCH(slen, sdist);
+                        if (rc) break;
+                    }
+                }
+                P += pos;
+            }
+            #undef INF2_WLOAD
+            if (rc) break;
+            // the bit buffer takes over where the symbols ended (the next block's header, or the end of the stream)
+            const uint32_t bit = (W0 << 5) + P - (uint32_t)B.skip, byte = bit >> 3;
+            if (byte > clen_bytes) { rc = 2; break; }
+            start += byte; clen_bytes -= byte;
+            B.open(comp, start, clen_bytes);
+            B.take((int)(bit & 7));
+            continue;
+        }
         for (;;) {                                                   // the block's symbols
             B.refill();
             const uint32_t lo = (uint32_t)B.buf;
@@ -452,6 +623,7 @@ __device__ __forceinline__ void inf2_one_block(uint8_t *smem, const int b, const
 }
 
 // a wave per block; with fewer workgroups than blocks (a grid of so many per compute unit) a wave goes on to further blocks
+template <bool MULTI>
 static __global__ void __launch_bounds__(64) k_inflate_wave(const uint8_t *__restrict__ comp, const uint64_t *__restrict__ in_off,
                                                      const uint32_t *__restrict__ in_len, const uint64_t *__restrict__ out_off,
                                                      const uint32_t *__restrict__ out_len, int n_blocks,
@@ -459,7 +631,7 @@ static __global__ void __launch_bounds__(64) k_inflate_wave(const uint8_t *__res
     __shared__ __attribute__((aligned(16))) uint8_t smem[INF2_LDS];
     #pragma unroll 1
     for (int b = (int)blockIdx.x; b < n_blocks; b += (int)gridDim.x) {
-        inf2_one_block(smem, b, comp, in_off, in_len, out_off, out_len, text, status);
+        inf2_one_block<MULTI>(smem, b, comp, in_off, in_len, out_off, out_len, text, status);
         __syncthreads();
     }
 }

@@ -24,7 +24,7 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
     // 125 000 blocks on, and only the job's own bytes move; one lane per block (inflate_wave = 0): 13 - 38 ms for a launch of
     // any size, 230 - 258 GB/s from 125 000 blocks on, ten times the job's bytes through HBM.  inflate_wave = 1 is "the
     // library's choice": the wave kernel
-    const bool wave = ctx->inflate_wave == 2 || ctx->inflate_wave == 1;
+    const bool wave = ctx->inflate_wave == 2 || ctx->inflate_wave == 1 || ctx->inflate_wave == 4;
     // (experiment: unused dynamic LDS per wave caps the waves per compute unit and leaves LDS for the kernels beside it)
     const char *lp = getenv("HPGV_INFLATE_LDS_PAD");
     const unsigned lds_pad = lp ? (unsigned)atoi(lp) : 0u;
@@ -34,8 +34,12 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
         const unsigned per_cu = pw ? (unsigned)atoi(pw) : 0u;
         unsigned grid = (unsigned)n_blocks;
         if (per_cu && grid > per_cu * (unsigned)ctx->n_cus) grid = per_cu * (unsigned)ctx->n_cus;
-        hipLaunchKernelGGL(hpgv::k_inflate_wave, dim3(grid), dim3(64), lds_pad, (hipStream_t)stream,
-                           d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
+        if (ctx->inflate_wave == 4)                                  // several symbols per round (hpgv_inflate2_kernels.h)
+            hipLaunchKernelGGL(hpgv::k_inflate_wave<true>, dim3(grid), dim3(64), lds_pad, (hipStream_t)stream,
+                               d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
+        else
+            hipLaunchKernelGGL(hpgv::k_inflate_wave<false>, dim3(grid), dim3(64), lds_pad, (hipStream_t)stream,
+                               d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
     }
     else if (ctx->inflate_wave != 3) {
         // (experiment: HPGV_INFLATE_LANE_WGS = workgroups per compute unit in flight; 0 = one per 64 blocks)

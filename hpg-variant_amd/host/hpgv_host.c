@@ -3412,6 +3412,7 @@ static void fmt_task(void *v, int t) {
     }
 }
 
+static double g_write_split[2];                         /* of the last run's write stage: formatting, writing (HPGV_RUN_TRACE) */
 static int write_batch(FILE *fd, int kind, const run_batch_t *b, out_buf_t *bufs, int n_bufs, io_pool_t *pool, order_track_t *ord) {
     if (kind == 4) {                                     /* vcf2epi: the rows of the records, in line order (dataset_creator.c:196-199) */
         const int n = b->n_lines < b->max_lines ? b->n_lines : b->max_lines;
@@ -3430,8 +3431,11 @@ static int write_batch(FILE *fd, int kind, const run_batch_t *b, out_buf_t *bufs
     j.b = b; j.bufs = bufs; j.kind = kind; j.bad = 0;
     j.n = b->n_lines < b->max_lines ? b->n_lines : b->max_lines;
     j.parts = j.n >= 2048 ? n_bufs : 1;
+    const double t_f0 = now_s();
     pool_run(pool, fmt_task, &j, j.parts);
+    g_write_split[0] += now_s() - t_f0;
     if (j.bad) return 1;
+    const double t_w0 = now_s();
     for (int t = 0; t < j.parts; t++) {
         if (!bufs[t].len) continue;
         if (ord && kind < 4) {                                       /* the seam before this task's lines, and its own verdict */
@@ -3444,6 +3448,7 @@ static int write_batch(FILE *fd, int kind, const run_batch_t *b, out_buf_t *bufs
         }
         if (fwrite(bufs[t].p, 1, bufs[t].len, fd) != bufs[t].len) return 1;
     }
+    g_write_split[1] += now_s() - t_w0;
     return 0;
 }
 
@@ -3651,6 +3656,7 @@ static void write_group_lines(FILE **gfd, const run_batch_t *b) {
 static int run_file(const char *vcf_path, const char *ped_path, const char *out_path, int kind, size_t batch_bytes,
                     long *n_variants_out) {
     const double t_enter = now_s();
+    g_write_split[0] = g_write_split[1] = 0;
     int rc = ensure_engine();
     if (rc) return rc;
     if (batch_bytes < (1u << 16)) batch_bytes = 1u << 16;
@@ -3987,8 +3993,8 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     if (n_variants_out) *n_variants_out = written;
     pthread_rwlock_unlock(&g_cohort_lock);
     if (getenv("HPGV_RUN_TRACE"))
-        fprintf(stderr, "hpgv run: before the pipeline: PED and open %.4f s, VCF header %.4f s, cohort and buffers %.4f s; after it: %.4f s\n",
-                t_opened - t_enter, t_header - t_opened, t_start - t_header, now_s() - t_done);
+        fprintf(stderr, "hpgv run: before the pipeline: PED and open %.4f s, VCF header %.4f s, cohort and buffers %.4f s; after it: %.4f s; of the write stage: formatting %.4f s, writing %.4f s\n",
+                t_opened - t_enter, t_header - t_opened, t_start - t_header, now_s() - t_done, g_write_split[0], g_write_split[1]);
     return rc;
 }
 

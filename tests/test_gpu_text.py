@@ -187,7 +187,7 @@ def test_text_entry_point_from_concurrent_threads(eng):
     assert not errors, errors
 
 
-@pytest.mark.parametrize("wave", [2, 0, 3], ids=["wave_per_block", "lane_per_block", "lane_per_block_lds_tables"])
+@pytest.mark.parametrize("wave", [2, 4, 0, 3], ids=["wave_per_block", "wave_per_block_several_symbols", "lane_per_block", "lane_per_block_lds_tables"])
 def test_inflate_blocks_on_the_gpu_against_zlib(wave):
     # hpgv_inflate_blocks_dev: raw-DEFLATE payloads (as in BGZF blocks) of genotype text, incompressible bytes (stored
     # blocks), runs, every zlib strategy incl. fixed codes, sizes 0 .. 65 280 -- one wave per block (the default) and one
@@ -330,7 +330,7 @@ def test_device_memory_that_grows_in_place():
     e.close()
 
 
-@pytest.mark.parametrize("wave", [2, 0, 3], ids=["wave_per_block", "lane_per_block", "lane_per_block_lds_tables"])
+@pytest.mark.parametrize("wave", [2, 4, 0, 3], ids=["wave_per_block", "wave_per_block_several_symbols", "lane_per_block", "lane_per_block_lds_tables"])
 def test_inflate_random_streams_against_zlib(wave):
     # 1 500 streams over the parameters zlib offers: level, strategy, window size (256 bytes .. 32 KiB), memLevel (1: a
     # new dynamic block every 128 symbols, so a stream holds hundreds of code tables), on data of alphabets from 2 to 256

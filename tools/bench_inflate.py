@@ -67,7 +67,7 @@ status = e.d2h(d_st, (n_blocks,), np.int32)
 chk = e.d2h(d_text.value + (n_blocks - 1) * 65280, (65280,), np.uint8).tobytes()
 ok = bool((status == 0).all()) and chk == raw[int(pick[-1])]
 dt = min(runs)
-print(json.dumps({"blocks": n_blocks, "zlib_level": level, "decoder": {0: "lane per block", 1: "by size", 2: "wave per block", 3: "lane per block, tables in LDS"}[wave], "text_buffer": "reserved range" if grows else "allocation", "text_GB": total / 1e9, "compressed_GB": float(in_len.sum()) / 1e9,
+print(json.dumps({"blocks": n_blocks, "zlib_level": level, "decoder": {0: "lane per block", 1: "by size", 2: "wave per block", 3: "lane per block, tables in LDS", 4: "wave per block, several symbols per round"}[wave], "text_buffer": "reserved range" if grows else "allocation", "text_GB": total / 1e9, "compressed_GB": float(in_len.sum()) / 1e9,
                   "seconds": round(dt, 4), "text_GBps": total / dt / 1e9, "compressed_GBps": float(in_len.sum()) / dt / 1e9, "ok": ok}))
 if grows:
     e.dev_release(d_text)
