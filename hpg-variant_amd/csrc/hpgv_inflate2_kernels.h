@@ -409,14 +409,12 @@ __device__ __forceinline__ void inf2_one_block(uint8_t *smem, const int b, const
             #pragma unroll 1
             while (!done) {
                 if (P >= 1024) { win = nxt; W0 += 32; P -= 1024; nxt = INF2_WLOAD(W0 + 32); }
-                const uint32_t Q = P >> 5, sh = P & 31;
-                const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)Q), w1 = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)Q + 1),
-                               w2 = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)Q + 2), w3 = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)Q + 3),
-                               w4 = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)Q + 4);
-                const uint64_t lo64 = (uint64_t)w0 | ((uint64_t)w1 << 32), mid64 = (uint64_t)w2 | ((uint64_t)w3 << 32);
-                const uint64_t A0 = sh ? (lo64 >> sh) | (mid64 << (64 - sh)) : lo64;
-                const uint64_t A1 = sh ? (mid64 >> sh) | ((uint64_t)w4 << (64 - sh)) : mid64;
-                const uint64_t X = (A0 >> lane) | ((A1 << 1) << (63 - lane));          // the 64 bits from lane bits on
+                // the 64 bits from bit P + lane on: three dwords of the window register (ds_bpermute: lane q's value), two funnel shifts
+                const uint32_t g = P + lane, qa = (g >> 3) & ~3u, r = g & 31;
+                const uint32_t da = (uint32_t)__builtin_amdgcn_ds_bpermute((int)qa, (int)win), db = (uint32_t)__builtin_amdgcn_ds_bpermute((int)qa + 4, (int)win),
+                               dc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)qa + 8, (int)win);
+                const uint32_t xl0 = __builtin_amdgcn_alignbit(db, da, r), xh0 = __builtin_amdgcn_alignbit(dc, db, r);
+                const uint64_t X = (uint64_t)xl0 | ((uint64_t)xh0 << 32);
                 const uint32_t xl = (uint32_t)X;
                 const uint32_t e = inf2_r32(smem, (uint32_t)INF2_LUT_L + ((xl & ((1u << INF2_ROOT_L) - 1)) << 2));
                 const uint32_t cl = e & 15, used1 = (e >> 10) & 31;
@@ -468,7 +466,7 @@ __device__ __forceinline__ void inf2_one_block(uint8_t *smem, const int b, const
                 }
                 if (rc) break;
                 if (pos == 0) {                                       // the symbol at the position itself is not an everyday one
-                    const uint64_t sb = A0;
+                    const uint64_t sb = (uint64_t)inf2_u(xl0) | ((uint64_t)inf2_u(xh0) << 32);      // lane 0's window
                     uint32_t e0 = inf2_u(e);
                     if ((e0 & 15) == 0) { e0 = inf2_slow<0>(smem, sb, INF2_CNT_L, INF2_SYM_L); if (!e0) { rc = 13; break; } }
                     if ((e0 & 0x300u) == 0) {                         // a literal with a long code

@@ -9,8 +9,9 @@ extern "C" {
 
 // raw-DEFLATE blocks (the payloads of BGZF blocks) -> text, all on the device: block b occupies d_comp[in_off[b] .. +in_len[b])
 // and decodes to exactly out_len[b] bytes at d_text + out_off[b]; d_status[b] = 0, or a non-zero code for a block this decoder
-// does not take (the host then decodes that block).  Option inflate_wave: 1 (default) or 2 = one wave per block, 0 = one lane per
-// block (wants a hundred thousand blocks per call), 3 = the lane kernel with its symbol tables in LDS.
+// does not take (the host then decodes that block).  Option inflate_wave: 1 (default) or 4 = one wave per block, several symbols
+// per round of its loop; 2 = one wave per block, one symbol per round; 0 = one lane per block (wants a hundred thousand blocks
+// per call), 3 = the lane kernel with its symbol tables in LDS.
 int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
                             const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, uint8_t *d_text,
                             int32_t *d_status, void *stream) {
@@ -20,11 +21,13 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
         return fail(ctx, HPGV_ERR_INVALID, "bad inflate arguments");
     if (n_blocks == 0) return HPGV_OK;
     DeviceGuard g(ctx->device);
-    // one wave per block: a block in a millisecond whatever the number of blocks (4 096 blocks: 1.5 ms), 262 - 267 GB/s from
-    // 125 000 blocks on, and only the job's own bytes move; one lane per block (inflate_wave = 0): 13 - 38 ms for a launch of
-    // any size, 230 - 258 GB/s from 125 000 blocks on, ten times the job's bytes through HBM.  inflate_wave = 1 is "the
-    // library's choice": the wave kernel
-    const bool wave = ctx->inflate_wave == 2 || ctx->inflate_wave == 1 || ctx->inflate_wave == 4;
+    // one wave per block: a block in a millisecond whatever the number of blocks (4 096 blocks: 1.3 ms), 373 GB/s from
+    // 125 000 blocks on (one symbol per round: 262 - 267), and only the job's own bytes move; one lane per block
+    // (inflate_wave = 0): 13 - 38 ms for a launch of any size, 230 - 258 GB/s from 125 000 blocks on, ten times the job's bytes
+    // through HBM.  inflate_wave = 1 is "the library's choice": the wave kernel with several symbols per round
+    const char *iw = getenv("HPGV_INFLATE_WAVE");                    // diagnosis: the decoder of this call, whatever the option says
+    const long mode = iw && atoi(iw) >= 0 && atoi(iw) <= 4 ? atoi(iw) : ctx->inflate_wave;
+    const bool wave = mode == 2 || mode == 1 || mode == 4;
     // (experiment: unused dynamic LDS per wave caps the waves per compute unit and leaves LDS for the kernels beside it)
     const char *lp = getenv("HPGV_INFLATE_LDS_PAD");
     const unsigned lds_pad = lp ? (unsigned)atoi(lp) : 0u;
@@ -34,14 +37,14 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
         const unsigned per_cu = pw ? (unsigned)atoi(pw) : 0u;
         unsigned grid = (unsigned)n_blocks;
         if (per_cu && grid > per_cu * (unsigned)ctx->n_cus) grid = per_cu * (unsigned)ctx->n_cus;
-        if (ctx->inflate_wave == 4)                                  // several symbols per round (hpgv_inflate2_kernels.h)
+        if (mode != 2)                                               // several symbols per round (hpgv_inflate2_kernels.h); 2: one symbol per round (A/B)
             hipLaunchKernelGGL(hpgv::k_inflate_wave<true>, dim3(grid), dim3(64), lds_pad, (hipStream_t)stream,
                                d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
         else
             hipLaunchKernelGGL(hpgv::k_inflate_wave<false>, dim3(grid), dim3(64), lds_pad, (hipStream_t)stream,
                                d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
     }
-    else if (ctx->inflate_wave != 3) {
+    else if (mode != 3) {
         // (experiment: HPGV_INFLATE_LANE_WGS = workgroups per compute unit in flight; 0 = one per 64 blocks)
         const char *pc = getenv("HPGV_INFLATE_LANE_WGS");
         const unsigned per_cu = pc ? (unsigned)atoi(pc) : 0u;

@@ -13,7 +13,7 @@ run r02_file_runner_10k_samples python3 tools/bench_file_runner.py 10000 200000 
 BENCH_PAUSE_S=0.05 run r02_file_runner_10k_samples_runs_apart python3 tools/bench_file_runner.py 10000 200000 bgzf 64
 BENCH_BGZF_LEVEL=1 run r02_file_runner_10k_samples_level1 python3 tools/bench_file_runner.py 10000 200000 bgzf 64
 run r02_file_runner_200_samples python3 tools/bench_file_runner.py 200 2000000 plain,bgzf 64
-HPGV_RUN_TRACE=1 python3 tools/bench_file_runner.py 40000 200000 bgzf 64 "HPGV_BGZF_HOST_TABLE=1|HPGV_INFLATE_WAVE=0|HPGV_NO_GPU_INFLATE=1" > $O/r02_file_runner_40k_samples_bgzf.log 2>&1 || { tail -3 $O/r02_file_runner_40k_samples_bgzf.log; exit 1; }
+HPGV_RUN_TRACE=1 python3 tools/bench_file_runner.py 40000 200000 bgzf 64 "HPGV_BGZF_HOST_TABLE=1|HPGV_INFLATE_WAVE=2|HPGV_INFLATE_WAVE=0|HPGV_NO_GPU_INFLATE=1" > $O/r02_file_runner_40k_samples_bgzf.log 2>&1 || { tail -3 $O/r02_file_runner_40k_samples_bgzf.log; exit 1; }
 tail -1 $O/r02_file_runner_40k_samples_bgzf.log > $O/r02_file_runner_40k_samples_bgzf.json
 cat $O/r02_file_runner_40k_samples_bgzf.json
-BENCH_BGZF_LEVEL=1 run r02_file_runner_40k_samples_bgzf_level1 python3 tools/bench_file_runner.py 40000 200000 bgzf 64 "HPGV_INFLATE_WAVE=0"
+BENCH_BGZF_LEVEL=1 run r02_file_runner_40k_samples_bgzf_level1 python3 tools/bench_file_runner.py 40000 200000 bgzf 64 "HPGV_INFLATE_WAVE=2|HPGV_INFLATE_WAVE=0"
