@@ -4,14 +4,18 @@
 // The lane-per-block decoder (hpgv_inflate_kernels.h) keeps every lane's code tables in private memory and writes its
 // text a byte at a time 64 KiB apart from its neighbours: it moves ten times the bytes it decodes and a block takes a lane
 // 38 ms.  Here the 64 lanes of a wave work on ONE block:
-//   * the compressed bytes come in through the scalar cache, a dword at a time, two loads ahead of the wave-uniform bit buffer;
-//   * the Huffman codes live in LDS as look-up tables (10 bits for literals / lengths, 8 for distances; a longer code takes
+//   * the headers' bits come in through the scalar cache, a dword at a time, two loads ahead of a wave-uniform bit buffer;
+//   * the Huffman codes live in LDS as look-up tables (8 bits for literals / lengths, 8 for distances; a longer code takes
 //     the canonical walk over the code's length histogram), built by the whole wave: every lane decodes its share of the
 //     table's indices with that same walk;
-//   * the decoding itself is serial and uniform -- scalar registers and scalar branches; ONE LDS read serves a length code
-//     and the distance code behind it: lane 0 reads the literal / length table at the buffer's low bits while lane i reads
-//     the distance table at the bits from i on, and the entry of the lane the length code ends at is picked with
-//     v_readlane;
+//   * the decoding: SEVERAL symbols per round of the loop (MULTI, the default).  The next 2 048 bits of the stream lie in
+//     one vector register; every lane takes the 64 bits from "position + lane" on out of it and decodes the symbol that
+//     would start there (two LDS reads for the whole wave), and the lanes on the true chain -- lane 0, the lane its symbol
+//     ends at, ... -- are visited one after the other with two v_readlane and a bit test each: 27 scalar + 25 vector
+//     instructions per symbol.  (The form before it, kept for A/B: ONE symbol per round, serial and uniform -- scalar
+//     registers and scalar branches; one LDS read serves a length code and the distance code behind it: lane 0 reads the
+//     literal / length table at the buffer's low bits while lane i reads the distance table at the bits from i on, and the
+//     entry of the lane the length code ends at is picked with v_readlane: 41 + 39 instructions per symbol.)
 //   * the last 4 KiB of the block's text are also kept in LDS (a ring): nineteen matches in twenty of genotype text reach
 //     back less than that (zlib follows its hash chains from the nearest candidate), so a match is copied by the lanes
 //     side by side out of LDS -- byte k from k mod distance -- into the ring and into global memory, and the wave never
