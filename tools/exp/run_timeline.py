@@ -11,9 +11,9 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 bin_ns = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 10e6
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0)) for r in rows)
-# a run's first decoder launch is the short stretch of 4 096 blocks (a wave each); the run begins with the block-table scan
-# before it.  The last run in the trace is taken.
-first = [i for i, e in enumerate(ev) if "inflate" in e[2] and e[3] == 4096 * 64]
+# a run's first decoder launch is the short first stretch (4 096 blocks at most, a wave each; the later ones hold 16 384 or
+# more); the run begins with the block-table scan before it.  The last run in the trace is taken.
+first = [i for i, e in enumerate(ev) if "inflate" in e[2] and e[3] <= 4096 * 64]
 cut = 0
 if first:
     cut = first[-1]
