@@ -428,26 +428,24 @@ __device__ __forceinline__ void inf2_one_block(uint8_t *smem, const int b, const
                 const uint32_t d = inf2_r32(smem, (uint32_t)INF2_LUT_D + ((y & ((1u << INF2_ROOT_D) - 1)) << 2));
                 const bool d_ok = (d & 15) != 0 && (d & 0x300u) == 0x100u;
                 const uint32_t dist = (d >> 16) + ((y >> (d & 15)) & ((1u << ((d >> 4) & 15)) - 1));
-                // bits of the symbol (0: not an everyday one), and what the copy needs: a literal's byte, or length | distance << 16
-                const uint32_t tbv = is_lit ? cl : (is_len && d_ok) ? used1 + ((d >> 10) & 31) : 0u;
-                const uint32_t infov = is_lit ? (e >> 16) : (len | (dist << 16));
-                // which lanes hold a literal, and which a match of the everyday kind (out of the ring, not longer than its
-                // distance, 64 bytes at most, not from before the text as it stands now): one bit test per symbol in the chain
-                const uint64_t lit_m = __ballot(is_lit);
-                // (64 symbols of 64 bytes at most: with 4 096 bytes of room left no everyday match needs its own look at the room)
-                const uint64_t easy_m = cap - n_out >= 4096u
-                    ? __ballot(!is_lit & !((dist > (uint32_t)INF2_WINDOW) | (dist < len) | (len > 64u) | (dist > n_out))) : 0ull;
+                // one word per lane for the walk along the chain: bits 0-8 the match's length (or the literal's byte), 9-14 the
+                // symbol's bits (0: not an everyday symbol, the chain ends before it), 15 "an everyday match" (out of the ring, not
+                // longer than its distance, 64 bytes at most, not from before the text as it stands now -- and, 64 symbols of 64
+                // bytes at most, with 4 096 bytes of room left no such match needs its own look at the room), 16-31 the distance
+                // (0: a literal)
+                const uint32_t tb = is_lit ? cl : (is_len && d_ok) ? used1 + ((d >> 10) & 31) : 0u;
+                const bool easy = !is_lit & !((dist > (uint32_t)INF2_WINDOW) | (dist < len) | (len > 64u) | (dist > n_out)) & (cap - n_out >= 4096u);
+                const uint32_t infov = tb == 0 ? 0u : ((is_lit ? (e >> 16) : (len | (dist << 16))) | (tb << 9) | (easy ? 0x8000u : 0u));
                 uint32_t pos = 0;
                 #pragma unroll 1
                 while (pos < 64) {
-                    const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tbv, (int)pos);
-                    if (t == 0) break;
                     const uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)infov, (int)pos);
-                    const uint32_t here = pos;
+                    const uint32_t t = (info >> 9) & 63;
+                    if (t == 0) break;
                     pos += t;
                     const uint32_t mlen = info & 0x1FFu, mdist = info >> 16;
-                    if (!((easy_m >> here) & 1)) {                    // a literal, or a match that is not an everyday one
-                        if ((lit_m >> here) & 1) {
+                    if (!(info & 0x8000u)) {                          // a literal, or a match that is not an everyday one
+                        if (mdist == 0) {
                             INF2_COMPLETE();
                             if (n_out >= cap) rc = 14;
                             else {
