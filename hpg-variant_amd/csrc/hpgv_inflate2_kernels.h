@@ -11,7 +11,7 @@
 //   * the decoding: SEVERAL symbols per round of the loop (MULTI, the default).  The next 2 048 bits of the stream lie in
 //     one vector register; every lane takes the 64 bits from "position + lane" on out of it and decodes the symbol that
 //     would start there (two LDS reads for the whole wave), and the lanes on the true chain -- lane 0, the lane its symbol
-//     ends at, ... -- are visited one after the other with two v_readlane and a bit test each: 27 scalar + 25 vector
+//     ends at, ... -- are visited one after the other with two v_readlane and a bit test each: 25 scalar + 24 vector
 //     instructions per symbol.  (The form before it, kept for A/B: ONE symbol per round, serial and uniform -- scalar
 //     registers and scalar branches; one LDS read serves a length code and the distance code behind it: lane 0 reads the
 //     literal / length table at the buffer's low bits while lane i reads the distance table at the bits from i on, and the

@@ -21,7 +21,7 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
         return fail(ctx, HPGV_ERR_INVALID, "bad inflate arguments");
     if (n_blocks == 0) return HPGV_OK;
     DeviceGuard g(ctx->device);
-    // one wave per block: a block in a millisecond whatever the number of blocks (4 096 blocks: 1.3 ms), 373 GB/s from
+    // one wave per block: a block in a millisecond whatever the number of blocks (4 096 blocks: 1.3 ms), 390 GB/s from
     // 125 000 blocks on (one symbol per round: 262 - 267), and only the job's own bytes move; one lane per block
     // (inflate_wave = 0): 13 - 38 ms for a launch of any size, 230 - 258 GB/s from 125 000 blocks on, ten times the job's bytes
     // through HBM.  inflate_wave = 1 is "the library's choice": the wave kernel with several symbols per round
