@@ -754,7 +754,9 @@ int hpgv_host_alloc(hpgv_ctx *ctx, size_t bytes, void **hptr) {
     ctx = first_member(ctx);
     if (!ctx || !hptr) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);
-    HIPCHK(ctx, hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocPortable));     // visible to every device of a group
+    // visible to every device of a group.  (experiment: HPGV_PINNED_NONCOHERENT=1 -- no difference measured, profiles/experiments_that_did_not_pay.md)
+    const unsigned flags = hipHostMallocPortable | (getenv("HPGV_PINNED_NONCOHERENT") ? hipHostMallocNonCoherent : 0u);
+    HIPCHK(ctx, hipHostMalloc(hptr, bytes ? bytes : 16, flags));
     return HPGV_OK;
 }
 int hpgv_host_free(hpgv_ctx *ctx, void *hptr) {
