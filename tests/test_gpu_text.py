@@ -382,6 +382,66 @@ def test_inflate_random_streams_against_zlib(wave):
     e.close()
 
 
+@pytest.mark.parametrize("wave", [4, 2], ids=["wave_per_block_several_symbols", "wave_per_block"])
+def test_inflate_damaged_streams_end_with_a_status_or_a_text_of_the_right_size(wave):
+    # streams with one to three bytes overwritten: the decoder may refuse a block (non-zero status: the host decodes it and
+    # reports the damage) or decode what the changed bits say, but it writes nothing outside the block's own text, leaves the
+    # undamaged neighbours alone and always comes back
+    import zlib
+    rng = np.random.default_rng(99)
+    gts = np.array(["0/0", "0/1", "1/1", "./.", "0|1", "1|0"])
+    raws, comps, hurt = [], [], []
+    for k in range(400):
+        n = int(rng.integers(200, 65281))
+        if k % 3 == 0:
+            raw = bytes(rng.integers(0, int(rng.choice([2, 4, 64, 256])), n, dtype=np.uint8))
+        else:
+            raw = ("\t".join(gts[rng.choice(6, size=n // 4 + 1, p=[0.55, 0.2, 0.1, 0.02, 0.08, 0.05])]) + "\n").encode()[:n]
+        co = zlib.compressobj(int(rng.integers(1, 10)), zlib.DEFLATED, -15, int(rng.integers(1, 10)),
+                              int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_FIXED])))
+        comp = bytearray(co.compress(raw) + co.flush())
+        damaged = k % 4 != 3
+        if damaged:
+            for _ in range(int(rng.integers(1, 4))):
+                comp[int(rng.integers(0, len(comp)))] = int(rng.integers(0, 256))
+        raws.append(raw); comps.append(bytes(comp)); hurt.append(damaged)
+    n = len(comps)
+    in_len = np.array([len(c) for c in comps], np.uint32); out_len = np.array([len(r) for r in raws], np.uint32)
+    in_off = np.concatenate([[0], np.cumsum(in_len[:-1], dtype=np.uint64)]).astype(np.uint64)
+    gap = 64                                                            # guard bytes between the blocks' texts
+    out_off = (np.concatenate([[0], np.cumsum(out_len[:-1].astype(np.uint64) + gap)])).astype(np.uint64)
+    cbytes = np.frombuffer(b"".join(comps) + b"\0" * 16, np.uint8)
+    total = int(out_off[-1]) + int(out_len[-1]) + gap
+    e = hpgv.Engine(0)
+    e.set_option("inflate_wave", wave)
+    d_comp, d_text = e.alloc(len(cbytes)), e.alloc(total + 16)
+    d_io, d_il, d_oo, d_ol, d_st = e.alloc(8 * n), e.alloc(4 * n), e.alloc(8 * n), e.alloc(4 * n), e.alloc(4 * n)
+    for d, a in ((d_comp, cbytes), (d_io, in_off), (d_il, in_len), (d_oo, out_off), (d_ol, out_len)):
+        e.h2d(d, a)
+    e.h2d(d_text, np.full(total + 16, 0xA5, np.uint8))
+    e.inflate_blocks(d_comp, d_io, d_il, d_oo, d_ol, n, d_text, d_st)
+    e.sync()
+    status = e.d2h(d_st, (n,), np.int32)
+    text = e.d2h(d_text, (total + 16,), np.uint8).tobytes()
+    refused = 0
+    for k in range(n):
+        a, m = int(out_off[k]), int(out_len[k])
+        assert text[a + m:a + m + gap] == b"\xa5" * gap, k               # nothing behind the block's text
+        if not hurt[k]:
+            assert status[k] == 0 and text[a:a + m] == raws[k], k
+        elif status[k] != 0:
+            refused += 1
+        else:                                                           # taken: then it is what zlib makes of the same bytes, if zlib takes them
+            try:
+                want = zlib.decompressobj(-15).decompress(comps[k])
+            except zlib.error:
+                want = None
+            if want is not None and len(want) == m:
+                assert text[a:a + m] == want, k
+    assert refused > 100
+    e.close()
+
+
 @pytest.mark.parametrize("strict", [0, 1])
 def test_everyday_genotype_stretches_and_what_breaks_them(eng, strict):
     # the tile-parallel tokenizer decodes 32-byte stretches of four-byte genotype fields (d/d, d|d, ./.) eight at a time;
