@@ -15,6 +15,7 @@ echo "default bench done"
 cp $(find $O/${TAG}_prof_m -name '*kernel_stats.csv' | head -1) $O/${TAG}_bench_m_kernel_stats.csv
 echo "rocprof stats done"
 STEPS=2 bash tools/pmc_traffic.sh m $TAG || exit 1
+for w in c2 c4 stats; do STEPS=3 bash tools/pmc_traffic.sh $w $TAG || exit 1; done
 echo "pmc traffic done"
 bash tools/fisher_prof.sh $TAG || exit 1
 for w in c2 c3 c4 stats c5; do
