@@ -2405,8 +2405,8 @@ static int bgzf_walk_parallel(int fd, size_t size, uint64_t **in_off, uint64_t *
  * Walking the 490 000 block headers of a 4.6 GB file on the host takes 0.08 - 0.26 s of dependent reads (beside the
  * uploader's own reads of the same file) before the first block can be decoded.  Here the stager asks the device for the
  * blocks in what has been uploaded so far (hpgv_bgzf_scan_dev finds the headers in the compressed bytes and checks that
- * they form a chain), decodes them, and goes on where the chain stands: the first 4 096 blocks are decoded a few
- * milliseconds after the file was opened.  The text's size is not known in advance, so the text lies in a range of device
+ * they form a chain), decodes them, and goes on where the chain stands: the blocks of the first 8 MB are decoded a few
+ * milliseconds after the file was opened, then stretches of 16 384 and 32 768 blocks as their bytes arrive.  The text's size is not known in advance, so the text lies in a range of device
  * addresses that is backed as the table grows (dev_text_grow); the reader learns the text's end when the stager has seen
  * the file's last block.  A stretch of the file whose headers are not the ones bgzip writes is walked on the host (through
  * the mapping).  HPGV_BGZF_HOST_TABLE=1 keeps the table on the host (the form above). */
