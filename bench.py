@@ -84,6 +84,15 @@ def parse_args(argv=None):
                     help="process-group backend for N>1; gloo is a rehearsal mode (blocks are staged through host "
                          "memory and several ranks may share one GPU), never a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="N = 1: initialise the process group all the same and send the result blocks through its gather "
+                         "(one real RCCL rank through the N > 1 code path; a check, not a measurement)")
+    ap.add_argument("--configs", choices=["auto", "none", "all"], default="auto",
+                    help="attach BASELINE configs[1..3] + stats (c2, c3, c4, stats) as \"configs\" to the line: auto = when "
+                         "the default workload runs at N = 1 without overrides")
+    ap.add_argument("--config-steps", type=int, default=10)
+    ap.add_argument("--config-warmup", type=int, default=3)
+    ap.add_argument("--config-cpu-seconds", type=float, default=3.0)
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target wall time of each CPU baseline leg")
     ap.add_argument("--option", action="append", default=[], help="engine option key=value")
     return ap.parse_args(argv)
@@ -92,11 +101,34 @@ def parse_args(argv=None):
 # ---------------------------------------------------------------------------------------------------------
 # parent: start one fresh process per rank (no GPU call is made here)
 # ---------------------------------------------------------------------------------------------------------
+def count_gpus_no_hip():
+    """GPUs this process may use, WITHOUT any HIP / torch call (the parent of the ranks must not initialise a GPU): the KFD
+    topology's nodes with SIMDs (/sys/class/kfd), capped by the render nodes the container is given (/dev/dri/renderD*) and by
+    a *_VISIBLE_DEVICES list.  A rank that still finds no device of its own ends with exit code 2 and says so."""
+    import glob
+    n_kfd = 0
+    for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(prop):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n_kfd += 1
+        except (OSError, ValueError):
+            pass
+    n_render = len(glob.glob("/dev/dri/renderD*"))
+    if not os.path.exists("/dev/kfd"):
+        return 0
+    n = min(n_kfd, n_render) if n_kfd and n_render else max(n_kfd, n_render)
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if os.environ.get(var, "").strip():
+            n = min(n, len([x for x in os.environ[var].split(",") if x.strip()]))
+    return n
+
+
 def launch_ranks(args):
     n = args.gpus
     if args.backend == "nccl":
-        import torch                                    # device_count() reads the driver's list; it does not initialise a GPU
-        have = torch.cuda.device_count()
+        have = count_gpus_no_hip()
         if have < n:
             print("bench.py: --gpus %d but this machine shows %d GPU(s); one rank per GPU over RCCL needs %d "
                   "(rehearse with --backend gloo, which lets ranks share a GPU)" % (n, have, n), file=sys.stderr)
@@ -197,41 +229,26 @@ def cpu_baseline(kind, n_samples, cond, fam, lf_table, target_s):
     return out
 
 
-def worker(args):
+def measure(args, wl, steps, warmup, cpu_seconds, main, world, rank, dev, dev_index, pg):
+    """One workload on this rank's GPU: returns (the JSON object on rank 0 / None elsewhere, parity_failed).  `main`: the
+    workload named on the command line (its --variants / --samples / --option overrides apply to it alone).  `pg`: a process
+    group exists and the result blocks are gathered through it (N > 1, or --force-process-group at N = 1)."""
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(args.gpus, 1) and rank == 0:
-        print("bench.py: --gpus %d but WORLD_SIZE=%d; running with %d rank(s)" % (args.gpus, world, world), file=sys.stderr)
-    if not torch.cuda.is_available():
-        print("bench.py: no GPU visible; this engine has no CPU path", file=sys.stderr)
-        return 2
-    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-
     hpgv = importlib.import_module("hpg-variant_amd")
     sharding = importlib.import_module("hpg-variant_amd.sharding")
 
-    kind, V_all, N, scaling, desc = WORKLOADS[args.workload]
-    if args.variants:
+    kind, V_all, N, scaling, desc = WORKLOADS[wl]
+    if args.variants and main:
         V_all = args.variants
-    if args.samples:
+    if args.samples and main:
         N = args.samples
     total_per_step = V_all if scaling == "strong" else V_all * world
 
     eng = hpgv.Engine(dev_index)
-    for kv in args.option:
+    for kv in (args.option if main else []):
         k, v = kv.split("=")
         eng.set_option(k, int(v))
     cond = (np.arange(N) % 2).astype(np.uint8)          # odd samples are cases (SURVEY 8d)
@@ -260,14 +277,14 @@ def worker(args):
     # ---- tiles of the shard (strong: rank g scans [g*V/G, (g+1)*V/G); weak: one shard of V_all per rank) -----------------
     free_b, total_b = torch.cuda.mem_get_info(dev)
     avail = torch.tensor([free_b], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
-    if world > 1:                                                    # every rank plans with the tightest rank's memory
+    if pg:                                                           # every rank plans with the tightest rank's memory
         dist.all_reduce(avail, op=dist.ReduceOp.MIN)
     tile_bytes = min(int(args.tile_gb * 1e9), int(0.9 * (int(avail.item()) - (8 << 30))))     # a tile buffer must fit whatever the part
     plan = sharding.plan_tiles(rank, world, V_all, pitch, max(tile_bytes, pitch), strong=(scaling == "strong"))
     v_lo, V, n_tiles, per_tile, tiles = plan["v_lo"], plan["n"], plan["n_tiles"], plan["per_tile"], plan["tiles"]
-    res_need = 2 * res_bytes * per_tile * n_tiles * (1 + (world if rank == 0 and world > 1 else 0))
+    res_need = 2 * res_bytes * per_tile * n_tiles * (1 + (world if rank == 0 and pg else 0))
     resident = args.resident == "auto" and (V * pitch + res_need + (6 << 30) <= free_b)
-    if world > 1:                                                    # every rank takes the same path
+    if pg:                                                           # every rank takes the same path
         flag = torch.tensor([1 if resident else 0], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         resident = bool(flag.item())
@@ -290,7 +307,7 @@ def worker(args):
 
     # result blocks: tallies[n] | f64 arrays[n] ..., one block per tile and generation.  Two generations for
     # N > 1: the gathers of step k are only waited for at the end of step k+1 (they overlap its scans).
-    gens = 1 if world == 1 else 2
+    gens = 2 if pg else 1
     comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
     blocks = [[torch.empty(res_bytes * max(hi - lo, 1), dtype=torch.uint8, device=dev) for lo, hi in tiles] for _ in range(gens)]
     # sizes of every rank's block of tile ti (known to all ranks: they follow from variant_range)
@@ -298,7 +315,7 @@ def worker(args):
         return [res_bytes * c for c in plan["counts"][ti]]
 
     recv = None
-    if world > 1 and rank == 0:
+    if pg and rank == 0:
         recv = [[[torch.empty(max(max(tile_sizes(ti)), 1), dtype=torch.uint8, device=comm_dev) for _ in range(world)]
                  for ti in range(n_tiles)] for _ in range(gens)]
     pending = []                                        # gather works of the previous step
@@ -330,10 +347,10 @@ def worker(args):
                 eng.stats_hwe(b, n, b + 32 * n, b + 40 * n, sp)
             if ev:
                 ev[3].record(stream)
-        if world > 1:
+        if pg:
             sizes = tile_sizes(ti)
             send = blk[: res_bytes * n] if args.backend == "nccl" else blk[: res_bytes * n].cpu()   # gloo rehearsal: via host
-            _, w = sharding.gather_blocks(send, sizes, dst=0, async_op=True, out_bufs=recv[g][ti] if recv else None)
+            _, w = sharding.gather_blocks(send, sizes, dst=0, async_op=True, out_bufs=recv[g][ti] if recv else None, force=True)
             return [w]
         return []
 
@@ -345,7 +362,7 @@ def worker(args):
     def barrier():
         drain()
         torch.cuda.synchronize()
-        if world > 1:
+        if pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -375,17 +392,17 @@ def worker(args):
             for w in pending:                           # the previous step's gathers have had this whole step to finish
                 w.wait()
             pending[:] = works
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step(False)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step(True)
         barrier()
         elapsed = time.perf_counter() - t0
     else:
-        for k in range(args.warmup + args.steps):
-            timed = k >= args.warmup
+        for k in range(warmup + steps):
+            timed = k >= warmup
             g = step_no[0] % gens
             step_no[0] += 1
             for ti in range(n_tiles):
@@ -396,7 +413,7 @@ def worker(args):
                 barrier()
                 if timed:
                     elapsed += time.perf_counter() - t0
-    if world > 1:
+    if pg:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -409,7 +426,7 @@ def worker(args):
 
     # ---- measured streaming-read ceiling of the same buffer (report both fractions) -----------
     probe_gbps = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and main:
         try:
             nb = scan_variants * pitch
             probe_ms = eng.read_probe(gt[0].data_ptr(), nb, 5)
@@ -420,6 +437,7 @@ def worker(args):
     # ---- parity spot check: the oracle as CHECKER of the timed run's outputs (not timed, not on the product path)
     parity = None
     parity_failed = False
+    out = None
     if rank == 0:
         from oracle import pyoracle as orc
         g_last = (step_no[0] - 1) % gens
@@ -427,7 +445,7 @@ def worker(args):
         sources = [(blocks[g_last][0], v_lo + tiles[0][0], tiles[0][1] - tiles[0][0])]
         if n_tiles > 1 and tiles[-1][1] > tiles[-1][0]:
             sources.append((blocks[g_last][-1], v_lo + tiles[-1][0], tiles[-1][1] - tiles[-1][0]))
-        if world > 1:
+        if pg:
             r = world - 1
             r_lo = sharding.plan_tiles(r, world, V_all, pitch, max(tile_bytes, pitch), strong=(scaling == "strong"))["v_lo"]
             nb = tile_sizes(n_tiles - 1)[r] // res_bytes
@@ -475,11 +493,11 @@ def worker(args):
         parity = {"checked_variants": int(checked), "blocks": len(sources), "ok": bool(ok)}
 
     if rank == 0:
-        total_variants = total_per_step * args.steps
+        total_variants = total_per_step * steps
         par = "variant-sharded x%d (%s scaling)" % (world, scaling)
-        if world > 1:
+        if pg:
             par += ", result blocks gathered to rank 0 (%s), each step's gather overlapped with the next step's scan" % args.backend
-        config = {"workload": "%s: %s" % (args.workload, desc), "variants": total_per_step, "variants_per_gpu": V, "samples": N,
+        config = {"workload": "%s: %s" % (wl, desc), "variants": total_per_step, "variants_per_gpu": V, "samples": N,
                   ("affected" if kind in ("chisq", "fisher") else "trios" if kind == "tdt" else "columns"): nA,
                   ("unaffected" if kind in ("chisq", "fisher") else "multi_child_families" if kind == "tdt" else "groups"): nU,
                   "row_pitch_bytes": pitch, "tiles_per_gpu": n_tiles, "variants_per_tile": per_tile,
@@ -487,32 +505,32 @@ def worker(args):
                   "timed_region": ("one region over all steps, barrier + device sync on both sides" if resident else
                                    "sum over steps and tiles of [scan + statistics%s of one tile], each segment between device syncs%s; "
                                    "the tile buffer (%.1f GB) is regenerated on the device before its segment, outside the timed region"
-                                   % (" + gather" if world > 1 else "", " and barriers" if world > 1 else "", per_tile * pitch / 1e9)),
+                                   % (" + gather" if pg else "", " and barriers" if pg else "", per_tile * pitch / 1e9)),
                   "parallelism": par}
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                 "kernel": scan_name, "kernel_ms": scan_ms, "kernel_samples": len(evs),
-                "stream_read_probe_GBps": probe_gbps,
-                "frac_of_probe": (achieved / probe_gbps) if probe_gbps else None,
+                "read_probe_GBps": probe_gbps,
+                "read_probe_note": "a plain (unpipelined) streaming-read kernel over the same buffer: informational, NOT a ceiling",
                 "algorithmic_bytes_per_variant": bytes_per_variant,
                 "variants_per_launch": scan_variants}
-        prof = pmc_profile(args.workload, scan_name, scan_variants, N, pitch) if world == 1 else None
+        prof = pmc_profile(wl, scan_name, scan_variants, N, pitch) if world == 1 else None
         if prof and "hbm_bytes_per_launch" in prof:
             roof["traffic"] = prof["hbm_bytes_per_launch"]
         out = {
             "metric": METRIC[kind], "value": total_variants / elapsed, "unit": "variants/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u8",
             "data": "synthetic (on-device splitmix64 cohort, HWE genotypes, 1% missing, odd samples are cases)",
             "config": config,
         }
-        if world > 1:
+        if pg:
             out["rccl_ranks"] = dist.get_world_size() if args.backend == "nccl" else 0
         if kind == "fisher":
             # the p-pass dominates this workload and is bound by FP64 / 64-bit vector issue, not by HBM: instructions per
             # variant come from the committed PMC pass (tools/fisher_prof.sh), the duration from this run's HIP events
-            fprof = pmc_profile(args.workload, "k_assoc_fisher", scan_variants, N, pitch) or {}
+            fprof = pmc_profile(wl, "k_assoc_fisher", scan_variants, N, pitch) or {}
             ipv = fprof.get("valu_insts_per_variant")
             ginst = (ipv * scan_variants / (stats_ms * 1e-3) / 1e9) if ipv else None
             out["roofline"] = {"bound": "valu", "achieved": ginst, "peak": VALU64_PEAK_GINST, "unit": "Ginst/s",
@@ -527,18 +545,68 @@ def worker(args):
             out["roofline"]["stats_kernel_ms"] = stats_ms
         out["parity"] = parity
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(kind, N if kind != "tdt" else 3 * (N // 3), cond, fam, lf_table, args.cpu_seconds)
-        print(json.dumps(out))
-        sys.stdout.flush()
+            out["cpu_baseline"] = cpu_baseline(kind, N if kind != "tdt" else 3 * (N // 3), cond, fam, lf_table, cpu_seconds)
         if parity is not None and not parity["ok"]:
-            print("bench.py: the timed run's outputs DIFFER from the oracle on the sampled variants: the number above is invalid",
+            print("bench.py: workload %s: the timed run's outputs DIFFER from the oracle on the sampled variants: its number is invalid" % wl,
                   file=sys.stderr)
             parity_failed = True
-    if world > 1:
+    eng.close()
+    del gt, blocks, recv
+    torch.cuda.empty_cache()
+    return out, parity_failed
+
+
+def worker(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1) and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; running with %d rank(s)" % (args.gpus, world, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; this engine has no CPU path", file=sys.stderr)
+        return 2
+    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if local_rank >= torch.cuda.device_count() and args.backend == "nccl":
+        print("bench.py: rank %d wants GPU %d but this machine shows %d GPU(s): one rank per GPU over RCCL"
+              % (rank, local_rank, torch.cuda.device_count()), file=sys.stderr)
+        return 2
+    pg = world > 1 or args.force_process_group
+    if pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    out, failed = measure(args, args.workload, args.steps, args.warmup, args.cpu_seconds, True, world, rank, dev, dev_index, pg)
+    # ---- the other BASELINE configs in the same driver-timed line (N = 1, default workload, no overrides): a few seconds each
+    want_configs = args.configs == "all" or (args.configs == "auto" and args.workload == "m" and world == 1
+                                              and not args.variants and not args.samples and not args.option)
+    if rank == 0 and world == 1 and want_configs and out is not None:
+        out["configs"] = {}
+        for name in ("c2", "c3", "c4", "stats"):
+            if name == args.workload:
+                continue
+            sub, f = measure(args, name, args.config_steps, args.config_warmup, args.config_cpu_seconds, False, world, rank, dev, dev_index, False)
+            failed = failed or f
+            keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "scaling", "dtype", "roofline", "roofline_scan",
+                    "parity", "cpu_baseline")
+            out["configs"][name] = dict({k: sub[k] for k in keep if k in sub},
+                                        config={k: sub["config"][k] for k in ("workload", "variants", "samples", "row_pitch_bytes")})
+    if rank == 0 and out is not None:
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if pg:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
-    return 3 if parity_failed else 0
+    return 3 if failed else 0
 
 
 def main():

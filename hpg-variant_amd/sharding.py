@@ -48,7 +48,7 @@ def result_block_layout(n):
     return {"counts": 0, "odds": 16 * n, "chisq": 24 * n, "p": 32 * n, "bytes": 40 * n}
 
 
-def gather_blocks(block, sizes, dst=0, group=None, async_op=False, out_bufs=None):
+def gather_blocks(block, sizes, dst=0, group=None, async_op=False, out_bufs=None, force=False):
     """Gathers one uint8 result block per rank on `dst`.
 
     block : 1-D uint8 tensor of this rank (length sizes[rank])
@@ -56,6 +56,7 @@ def gather_blocks(block, sizes, dst=0, group=None, async_op=False, out_bufs=None
             from variant_range), so ragged shards need no size exchange.
     out_bufs : optional preallocated receive buffers on dst (world tensors of
             max(sizes) bytes), so a steady-state loop allocates nothing.
+    force : with one rank, still go through the collective (one real RCCL rank through the N > 1 path: a check).
     Returns (list_of_tensors_or_None, work): on dst the list holds every rank's
     block trimmed to its size, elsewhere None.
     """
@@ -63,7 +64,7 @@ def gather_blocks(block, sizes, dst=0, group=None, async_op=False, out_bufs=None
     rank = dist.get_rank(group)
     assert block.dtype == torch.uint8 and block.dim() == 1 and block.numel() == sizes[rank]
     cap = max(sizes)
-    if world == 1:
+    if world == 1 and not force:
         return [block], None
     send = block
     if block.numel() != cap:                      # pad ragged shards to a common size
