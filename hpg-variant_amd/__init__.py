@@ -40,6 +40,7 @@ SYMBOLS = [
     "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_stats_groups",
     "hpgv_epi_dataset_text", "hpgv_set_text_filters", "hpgv_stats_text", "hpgv_stats_text_groups", "hpgv_epi_set_dataset", "hpgv_epi_set_folds", "hpgv_epi_set_fold_masks", "hpgv_epi_counts",
     "hpgv_epi_counts_all_folds", "hpgv_epi_scan_pairs", "hpgv_epi_rank_pairs", "hpgv_epi_rank_pairs_rows", "hpgv_epi_scan_triples", "hpgv_epi_rank_triples", "hpgv_read_probe",
+    "hpgv_group_comm_init", "hpgv_group_comm_ranks", "hpgv_group_shard", "hpgv_group_assoc", "hpgv_group_tdt", "hpgv_group_stats", "hpgv_group_sync",
 ]
 
 
@@ -148,6 +149,14 @@ def load():
     L.hpgv_epi_rank_triples.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
     L.hpgv_epi_rank_pairs_rows.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
     L.hpgv_read_probe.argtypes = [vp, vp, sz, i32, C.POINTER(C.c_float)]
+    i64 = C.c_int64
+    L.hpgv_group_comm_init.argtypes = [vp]
+    L.hpgv_group_comm_ranks.argtypes = [vp]
+    L.hpgv_group_shard.argtypes = [vp, i64, i32, C.POINTER(i64), C.POINTER(i64)]
+    L.hpgv_group_assoc.argtypes = [vp, i32, vp, vp, i64, vp, vp, vp, vp]
+    L.hpgv_group_tdt.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
+    L.hpgv_group_stats.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    L.hpgv_group_sync.argtypes = [vp]
     _lib = L
     return L
 
@@ -186,7 +195,8 @@ class Engine:
             for b in getattr(self, "_host_bufs", []):
                 self.L.hpgv_host_free(self.h, b)
             self._host_bufs = []
-            self.L.hpgv_destroy(self.h)
+            if not getattr(self, "_view", False):
+                self.L.hpgv_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -568,6 +578,47 @@ class Engine:
         a, b = C.c_float(), C.c_float()
         self._chk(self.L.hpgv_last_kernel_ms(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    # ---- group context: the variant-sharded resident scan (hpgv_group_*) ---------------------------------
+    def group_size(self):
+        return self.L.hpgv_group_size(self.h)
+
+    def member(self, i):
+        """Engine view of member i of a group context (its device memory, generator, *_dev calls); owned by the group."""
+        h = self.L.hpgv_group_member(self.h, i)
+        if not h:
+            raise HpgvError("no member %d" % i)
+        m = Engine.__new__(Engine)
+        m.L, m.h, m.device, m._bufs, m._host_bufs, m._view = self.L, C.c_void_p(h), self.L.hpgv_member_device(self.h, i), [], [], True
+        return m
+
+    def group_comm_init(self):
+        self._chk(self.L.hpgv_group_comm_init(self.h))
+        return self.L.hpgv_group_comm_ranks(self.h)
+
+    def group_shard(self, n_variants, member):
+        lo, hi = C.c_int64(), C.c_int64()
+        self._chk(self.L.hpgv_group_shard(self.h, n_variants, member, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    @staticmethod
+    def _ptr_array(ptrs):
+        if ptrs is None:
+            return None
+        return (C.c_void_p * len(ptrs))(*[p.value if isinstance(p, C.c_void_p) else p for p in ptrs])
+
+    def group_assoc(self, task, d_gt, n_variants, d_counts, d_odds, d_chisq, d_p, d_is_x=None):
+        self._chk(self.L.hpgv_group_assoc(self.h, task, self._ptr_array(d_gt), self._ptr_array(d_is_x), n_variants,
+                                          d_counts, d_odds, d_chisq, d_p))
+
+    def group_tdt(self, d_gt, n_variants, d_tu, d_odds, d_chisq, d_p, d_is_x=None):
+        self._chk(self.L.hpgv_group_tdt(self.h, self._ptr_array(d_gt), self._ptr_array(d_is_x), n_variants, d_tu, d_odds, d_chisq, d_p))
+
+    def group_stats(self, d_gt, n_variants, d_counts8, d_chi2, d_p, d_sample_missing=None):
+        self._chk(self.L.hpgv_group_stats(self.h, self._ptr_array(d_gt), n_variants, d_counts8, d_chi2, d_p, d_sample_missing))
+
+    def group_sync(self):
+        self._chk(self.L.hpgv_group_sync(self.h))
 
     def read_probe(self, d_buf, nbytes, iters=5):
         ms = C.c_float()

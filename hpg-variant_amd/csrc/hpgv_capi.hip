@@ -272,6 +272,7 @@ extern "C" {
 void hpgv_destroy(hpgv_ctx *ctx) {
     if (!ctx) return;
     if (is_group(ctx)) {
+        hpgv_group_release(ctx);
         for (hpgv_ctx *m : ctx->members) { m->parent = nullptr; hpgv_destroy(m); }
         ctx->members.clear();
         delete ctx;
@@ -308,6 +309,7 @@ void hpgv_destroy(hpgv_ctx *ctx) {
 }
 
 int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
+    if (is_group(ctx) && key && !strcmp(key, "group_self_exchange")) { ctx->group_self_exchange = value ? 1 : 0; return HPGV_OK; }
     GROUP_ALL(ctx, hpgv_set_option(m_, key, value))
     if (!ctx || !key) return HPGV_ERR_INVALID;
     if (!strcmp(key, "row_align")) {

@@ -70,6 +70,8 @@ struct hpgv_ctx {
     // device-resident calls to member 0; a member's failure text is copied to its group.
     std::vector<hpgv_ctx *> members;
     hpgv_ctx *parent = nullptr;
+    struct GroupState *grp = nullptr;   // streams, scratch and the RCCL communicator of the group-wide resident scans (hpgv_group_capi.hip)
+    long group_self_exchange = 0;       // test switch: member 0 also hands its results over through the communicator (send / recv to itself)
     std::atomic<unsigned> deal_next{0};
     std::atomic<int> in_flight{0};
     int device = 0;
@@ -303,3 +305,5 @@ template <typename F>
 
 // defined in hpgv_epi_capi.hip
 void hpgv_epi_release(EpiState &E);
+// defined in hpgv_group_capi.hip: streams, scratch and communicator of a group context (before its members go)
+void hpgv_group_release(hpgv_ctx *group);

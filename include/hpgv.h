@@ -230,6 +230,34 @@ int  hpgv_stats_filter_dev(hpgv_ctx *ctx, const int32_t *d_counts8, int n_varian
                            double min_maf, double max_maf, double max_missing,
                            uint8_t *d_keep, void *stream);
 
+/* ---- the variant-sharded resident scan of a GROUP context: what the runner's worker loop
+ *      (assoc_runner.c:106-207, tdt_runner.c:150-200, stats_runner.c:176-215) becomes when the cohort lies in the HBM of
+ *      the group's devices.  Variants are independent (assoc.c:38-82, tdt.c:41-271), so member g owns the contiguous
+ *      shard [g*V/G, (g+1)*V/G) of the V variants (hpgv_group_shard), scans it on a stream of its own, and the ONE
+ *      exchange is the gather of the per-variant results onto member 0: grouped ncclSend / ncclRecv over a communicator
+ *      the group owns (ncclCommInitAll over the members' devices, RCCL over xGMI; librccl is loaded when
+ *      hpgv_group_comm_init is called, not before).  Per-sample counters (get_sample_stats, stats_runner.c:197-198) are
+ *      the one sum over variants: ncclReduce onto member 0.
+ *      d_gt[g] / d_is_x[g]: member g's shard on ITS device, in the tool's engine layout (d_is_x or its entries may be
+ *      NULL).  Result arrays: on member 0's device, sized for all V variants, variant v at index v (the *_dev entry
+ *      points' element layouts).  The calls are asynchronous: they return when everything is queued; results are
+ *      complete after hpgv_group_sync.  The gather of one call overlaps the scans of the next (each member keeps two
+ *      generations of result scratch), so a caller that pipelines alternates between two sets of result arrays.
+ *      A device may be listed twice only if it is member 0's (the one-GPU test rig): such members hand their results
+ *      over by a device-local copy instead of RCCL, which refuses one device twice. ------------------------------ */
+int  hpgv_group_comm_init(hpgv_ctx *group);               /* idempotent; HPGV_ERR_UNSUPPORTED without librccl */
+int  hpgv_group_comm_ranks(const hpgv_ctx *group);        /* ranks of the group's communicator (ncclCommCount); 0 before init */
+int  hpgv_group_shard(const hpgv_ctx *group, int64_t n_variants, int member, int64_t *lo, int64_t *hi);
+int  hpgv_group_assoc(hpgv_ctx *group, int task, const uint8_t *const *d_gt, const uint8_t *const *d_is_x,
+                      int64_t n_variants, int32_t *d_counts /* V x 4 */, double *d_odds,
+                      double *d_chisq /* NULL for Fisher */, double *d_p);
+int  hpgv_group_tdt(hpgv_ctx *group, const uint8_t *const *d_gt, const uint8_t *const *d_is_x, int64_t n_variants,
+                    int32_t *d_tu /* V x 2 */, double *d_odds, double *d_chisq, double *d_p);
+/* d_sample_missing (n_samples ints on member 0, may be NULL) is OVERWRITTEN with the sum over every member's shard */
+int  hpgv_group_stats(hpgv_ctx *group, const uint8_t *const *d_gt, int64_t n_variants, int32_t *d_counts8 /* V x 8 */,
+                      double *d_hwe_chi2, double *d_hwe_p, int32_t *d_sample_missing);
+int  hpgv_group_sync(hpgv_ctx *group);
+
 /* duration (ms) of the last scan / statistics kernel launched through this ctx
  * when option "profile" = 1 (HIP events on the launch stream; synchronises) */
 int  hpgv_last_kernel_ms(hpgv_ctx *ctx, float *scan_ms, float *stats_ms);
