@@ -84,6 +84,11 @@ def parse_args(argv=None):
                     help="process-group backend for N>1; gloo is a rehearsal mode (blocks are staged through host "
                          "memory and several ranks may share one GPU), never a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-process", action="store_true",
+                    help="ONE process drives all N GPUs through the C ABI's group context (hpgv_create_multi + hpgv_group_*: "
+                         "shards scanned on per-device streams, results gathered onto device 0 over the communicator the "
+                         "group owns, ncclCommInitAll); no torch.distributed.  What a C host would run")
+    ap.add_argument("--devices", default="", help="--single-process: device ids of the group, e.g. 0,0 to rehearse on one GPU")
     ap.add_argument("--force-process-group", action="store_true",
                     help="N = 1: initialise the process group all the same and send the result blocks through its gather "
                          "(one real RCCL rank through the N > 1 code path; a check, not a measurement)")
@@ -609,8 +614,171 @@ def worker(args):
     return 3 if failed else 0
 
 
+def worker_group(args):
+    """--single-process: the north star's shards + gather behind the C ABI, one process, no torch.distributed."""
+    import numpy as np
+    hpgv = importlib.import_module("hpg-variant_amd")
+    kind, V_all, N, scaling, desc = WORKLOADS[args.workload]
+    V_all = args.variants or V_all
+    N = args.samples or N
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    G = len(devices)
+    V = V_all if scaling == "strong" else V_all * G
+    try:
+        grp = hpgv.Engine(devices)
+    except hpgv.HpgvError as e:
+        print("bench.py: %s" % e, file=sys.stderr)
+        return 2
+    for kv in args.option:
+        k, v = kv.split("=")
+        grp.set_option(k, int(v))
+    cond = (np.arange(N) % 2).astype(np.uint8)
+    fam = lf_table = None
+    if kind == "tdt":
+        n_tr = N // 3
+        kk = np.arange(n_tr)
+        fam = (3 * kk, 3 * kk + 1, np.arange(n_tr + 1), 3 * kk + 2, (kk % 2).astype(np.uint8))
+        nA, nU, pitch = grp.set_families(3 * n_tr, *fam)
+        which = hpgv.LAYOUT_TDT
+    elif kind == "stats":
+        pitch = grp.set_stats_cohort(N)
+        nA, nU, which = N, 0, hpgv.LAYOUT_STATS
+    else:
+        nA, nU, pitch = grp.set_cohort(cond)
+        which = hpgv.LAYOUT_ASSOC
+        if kind == "fisher":
+            lf_table = np.concatenate([[0.0], np.cumsum(np.log(np.arange(1, N * 10, dtype=np.float64)))])
+            grp.set_logfact(lf_table)
+    head, res_bytes = RESULT[kind]
+    ranks = grp.group_comm_init()
+    members = [grp.member(k) for k in range(G)]
+    shards = []
+    try:
+        for k, m in enumerate(members):
+            lo, hi = grp.group_shard(V, k)
+            p = m.alloc(max(hi - lo, 1) * pitch)
+            for v0 in range(lo, hi, 1 << 24):                  # the generator takes an int count
+                m.synth(which, v0, min(1 << 24, hi - v0), p.value + (v0 - lo) * pitch)
+            shards.append(p)
+        for m in members:
+            m.sync()
+        m0 = members[0]
+        # two sets of result arrays: the gather of step k runs under the scans of step k + 1
+        sets = [[m0.alloc(head * max(V, 1))] + [m0.alloc(8 * max(V, 1)) for _ in range(3)] for _ in range(2)]
+    except hpgv.HpgvError as e:
+        print("bench.py: the shards of this workload do not fit %d device(s) resident: %s" % (G, e), file=sys.stderr)
+        return 2
+
+    def step(k):
+        ints, f0, f1, f2 = sets[k & 1]
+        if kind == "chisq":
+            grp.group_assoc(hpgv.TASK_CHISQ, shards, V, ints, f0, f1, f2)
+        elif kind == "fisher":
+            grp.group_assoc(hpgv.TASK_FISHER, shards, V, ints, f0, None, f2)
+        elif kind == "tdt":
+            grp.group_tdt(shards, V, ints, f0, f1, f2)
+        else:
+            grp.group_stats(shards, V, ints, f1, f2, None)
+
+    for k in range(args.warmup):
+        step(k)
+    grp.group_sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    grp.group_sync()
+    elapsed = time.perf_counter() - t0
+
+    # the scan kernel alone on member 0's shard (HIP events on its stream, option "profile"), for the roofline line
+    lo0, hi0 = grp.group_shard(V, 0)
+    m0.set_option("profile", 1)
+    tmp = m0.alloc(head * max(hi0 - lo0, 1))
+    scan_ms = []
+    for _ in range(3):
+        if kind == "tdt":
+            m0.tdt_scan(shards[0], hi0 - lo0, tmp, None, None)
+        elif kind == "stats":
+            m0.stats_scan(shards[0], hi0 - lo0, tmp, None)
+        else:
+            m0.assoc_scan(shards[0], hi0 - lo0, tmp, None, None)
+        scan_ms.append(m0.last_kernel_ms()[0])
+    m0.set_option("profile", 0)
+    scan_ms = float(np.median(scan_ms))
+    achieved = (hi0 - lo0) * (N + res_bytes) / (scan_ms * 1e-3) / 1e9
+
+    # parity: the GATHERED arrays on member 0 against the oracle, sampled over every member's shard
+    from oracle import pyoracle as orc
+    last = sets[(args.warmup + args.steps - 1) & 1]
+    idx = []
+    for k in range(G):
+        lo, hi = grp.group_shard(V, k)
+        n = hi - lo
+        if n:
+            idx.append(lo + np.unique(np.concatenate([np.arange(min(64, n)), np.arange(0, n, max(1000, n // 100)), np.arange(max(0, n - 64), n)])))
+    idx = np.concatenate(idx) if idx else np.zeros(0, np.int64)
+    if kind in ("fisher", "stats"):
+        idx = idx[:: max(1, len(idx) // 400)]
+    ints = m0.d2h(last[0], (V, head // 4), np.int32)
+    fl = [m0.d2h(last[i], (V,), np.float64) for i in (1, 2, 3)]
+    ncol = N if kind != "tdt" else 3 * (N // 3)
+
+    def same(got, exp):
+        with np.errstate(invalid="ignore"):
+            return bool(np.all((np.abs(got - exp) <= 1e-10 * np.maximum(1, np.abs(exp))) | (np.isnan(got) & np.isnan(exp))))
+    ok = True
+    for a in range(0, len(idx), 256):
+        sel = idx[a: a + 256]
+        rows = np.stack([orc.synth_matrix(int(v), 1, ncol, ncol)[0] for v in sel])
+        if kind == "tdt":
+            t1, t2 = orc.tdt_counts(rows, *fam)
+            exp = orc.tdt_stats(t1, t2)
+            ok &= bool(np.array_equal(ints[sel], np.stack([t1, t2], 1))) and all(same(fl[j][sel], exp[j]) for j in range(3))
+        elif kind == "stats":
+            for j, v in enumerate(sel):
+                vs = orc.variant_stats(rows[j], 2)
+                exp8 = list(vs.genotypes_count)[:4] + [vs.missing_genotypes, vs.missing_alleles, vs.alleles_count[0], vs.alleles_count[1]]
+                ok &= list(ints[v]) == exp8 and same(fl[1][v: v + 1], np.array([vs.hw_chi2])) and same(fl[2][v: v + 1], np.array([vs.hw_p]))
+        else:
+            A1, A2, U1, U2 = orc.assoc_counts(rows, cond)
+            ok &= bool(np.array_equal(ints[sel], np.stack([A1, A2, U1, U2], 1)))
+            if kind == "chisq":
+                exp = orc.assoc_stats(orc.TASK_CHISQ, A1, A2, U1, U2)
+                ok &= all(same(fl[j][sel], exp[j]) for j in range(3))
+            else:
+                odds, _, p = orc.assoc_stats(orc.TASK_FISHER, A1, A2, U1, U2, lf_table)
+                ok &= same(fl[0][sel], odds) and same(fl[2][sel], p)
+    out = {
+        "metric": METRIC[kind], "value": V * args.steps / elapsed, "unit": "variants/s", "n_gpus": G, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic (on-device splitmix64 cohort, HWE genotypes, 1% missing, odd samples are cases)",
+        "config": {"workload": "%s: %s" % (args.workload, desc), "variants": V, "variants_per_gpu": -(-V // G), "samples": N,
+                   "row_pitch_bytes": pitch, "resident": True, "devices": devices,
+                   "timed_region": "one region over all steps between two hpgv_group_sync",
+                   "parallelism": "ONE process, group context over %d device(s) behind the C ABI (hpgv_group_*): variant shards on "
+                                  "per-device streams, results gathered onto device 0 over the group's own communicator "
+                                  "(ncclCommInitAll), each step's gather under the next step's scans" % G},
+        "rccl_ranks": ranks,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": None, "kernel": "scan kernel of member 0's shard, alone", "kernel_ms": scan_ms,
+                     "algorithmic_bytes_per_variant": N + res_bytes, "variants_per_launch": hi0 - lo0},
+        "parity": {"checked_variants": int(len(idx)), "ok": bool(ok), "what": "arrays gathered on member 0 vs the oracle, sampled over every member's shard"},
+    }
+    print(json.dumps(out))
+    sys.stdout.flush()
+    for m in members:
+        m.close()
+    grp.close()
+    if not ok:
+        print("bench.py: the gathered results DIFFER from the oracle on the sampled variants: the number above is invalid", file=sys.stderr)
+        return 3
+    return 0
+
+
 def main():
     args = parse_args()
+    if args.single_process:
+        sys.exit(worker_group(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     sys.exit(worker(args))

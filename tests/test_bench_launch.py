@@ -97,3 +97,16 @@ def test_default_line_carries_every_baseline_config():
         assert c["roofline"]["frac"] is None or 0.0 < c["roofline"]["frac"] < 1.0, name
         assert c["cpu_baseline"]["value"] > 0 and c["value"] > 0
     assert d["configs"]["c3"]["roofline"]["bound"] == "valu" and d["configs"]["c2"]["roofline"]["bound"] == "hbm"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["c2", "c3", "c4", "stats"])
+def test_single_process_group_mode(workload):
+    """`--single-process`: one process, the C ABI's group context ([0, 0] on the one-GPU box), results gathered on member 0
+    through hpgv_group_*, checked against the oracle over both members' shards; rccl_ranks comes from the communicator."""
+    r = subprocess.run([sys.executable, BENCH, "--single-process", "--devices", "0,0", "--workload", workload, "--variants", "60001",
+                        "--samples", "1503", "--steps", "4", "--warmup", "1"], env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 1 and d["config"]["variants"] == 2 * 60001
+    assert d["parity"]["ok"] and d["parity"]["checked_variants"] > 100 and d["value"] > 0
