@@ -31,7 +31,7 @@ SYMBOLS = [
     "hpgv_set_stats_groups", "hpgv_stats_groups_layout", "hpgv_stats_scan_group_dev",
     "hpgv_set_pedigree", "hpgv_mendel_layout", "hpgv_mendel_scan_dev", "hpgv_mendel_children_dev",
     "hpgv_dev_alloc", "hpgv_dev_free", "hpgv_memcpy_h2d", "hpgv_memcpy_d2h", "hpgv_stream_sync",
-    "hpgv_device_numa_node", "hpgv_memcpy_h2d_async", "hpgv_inflate_blocks_dev", "hpgv_bgzf_scan_dev", "hpgv_bgzf_scan_scratch_bytes", "hpgv_dev_reserve", "hpgv_dev_commit", "hpgv_dev_release", "hpgv_text_alias", "hpgv_stream_create", "hpgv_stream_create_low", "hpgv_stream_destroy", "hpgv_host_alloc", "hpgv_host_free",
+    "hpgv_device_numa_node", "hpgv_memcpy_h2d_async", "hpgv_inflate_blocks_dev", "hpgv_bgzf_verify_dev", "hpgv_bgzf_scan_dev", "hpgv_bgzf_scan_scratch_bytes", "hpgv_dev_reserve", "hpgv_dev_commit", "hpgv_dev_release", "hpgv_text_alias", "hpgv_stream_create", "hpgv_stream_create_low", "hpgv_stream_destroy", "hpgv_host_alloc", "hpgv_host_free",
     "hpgv_layout_dev", "hpgv_synth_dev", "hpgv_synth_raw_dev",
     "hpgv_assoc_scan_dev", "hpgv_assoc_chisq_dev", "hpgv_assoc_fisher_dev",
     "hpgv_tdt_scan_dev", "hpgv_tdt_stats_dev", "hpgv_stats_scan_dev", "hpgv_stats_hwe_dev",
@@ -115,6 +115,7 @@ def load():
     L.hpgv_genotype_table_dev.argtypes = [vp, vp, sz, i32, vp, i32, vp, vp]
     L.hpgv_tokenize_dev.argtypes = [vp, vp, sz, i32, i32, i32, vp, vp, vp, vp, sz, vp, vp, vp]
     L.hpgv_inflate_blocks_dev.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]
+    L.hpgv_bgzf_verify_dev.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]
     L.hpgv_bgzf_scan_scratch_bytes.argtypes = [u64, i32]
     L.hpgv_bgzf_scan_scratch_bytes.restype = sz
     L.hpgv_bgzf_scan_dev.argtypes = [vp, vp, u64, u64, u64, i32, vp, vp, vp, vp, vp, sz, vp, vp]
@@ -529,6 +530,9 @@ class Engine:
 
     def inflate_blocks(self, d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status, stream=None):
         self._chk(self.L.hpgv_inflate_blocks_dev(self.h, d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status, stream))
+
+    def bgzf_verify(self, d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status, stream=None):
+        self._chk(self.L.hpgv_bgzf_verify_dev(self.h, d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status, stream))
 
     def bgzf_scan(self, d_comp, lo, hi, text_base, max_rows, d_in_off, d_in_len, d_out_off, d_out_len, stream=None):
         """Rows of the decoder's tables for the chain of bgzip blocks from byte lo that end by hi -> (rows, chain end, text end, headers seen)."""

@@ -288,6 +288,7 @@ void hpgv_destroy(hpgv_ctx *ctx) {
     if (ctx->d_lf) (void)hipFree(ctx->d_lf);
     if (ctx->d_thr) (void)hipFree(ctx->d_thr);
     if (ctx->d_sink) (void)hipFree(ctx->d_sink);
+    if (ctx->d_crc_tab) (void)hipFree(ctx->d_crc_tab);
     for (auto *t : ctx->tok_scratch) {
         if (t->d_blocks) (void)hipFree(t->d_blocks);
         if (t->d_line_off) (void)hipFree(t->d_line_off);

@@ -1,0 +1,96 @@
+// hpgv_crc_kernels.h -- CRC-32 of decoded BGZF blocks on the device (the check htslib's bgzf reader and zlib's gzread make on
+// every block: a stream that inflates to ISIZE bytes of the WRONG text must not reach the statistics).
+//
+// One wave per block.  CRC-32 is linear over GF(2): the register after a message is the XOR of what every piece of the message
+// contributes, each piece advanced over the bytes that follow it.  So the 64 lanes read the text coalesced -- lane i takes
+// dwords i, i + 64, i + 128, ... -- and each keeps a register of its own: XOR the dword in, advance by 256 bytes (the distance to
+// the lane's next dword) with four table look-ups, exactly as slice-by-4 advances by 4 bytes, only with tables built for
+// x^2048 instead of x^32.  At the end lane i's register stands 64 - i dwords before the end of the interleaved part: it is
+// advanced by multiplying with x^(32 (64 - i)) mod P, one conditional multiplication per bit of 64 - i with the constants
+// x^(32 * 2^b), and the 64 registers are XORed together.  The bytes in front of the first aligned dword (at most three) and
+// behind the last full 256-byte row are taken byte by byte.  Reflected polynomial 0xEDB88320, as zlib.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hpgv {
+
+enum { CRC_T0 = 0, CRC_W = 256, CRC_X2N = 256 + 1024, CRC_TAB_WORDS = 256 + 1024 + 8 };
+enum { BGZF_STATUS_BAD_CRC = 9 };       // status of a block whose text does not have the CRC-32 its trailer gives
+
+// a * b mod P, reflected representation (bit 31 = x^0)
+__host__ __device__ inline uint32_t crc_multmodp(uint32_t a, uint32_t b) {
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+
+// host: t0 = the byte table; w[j][b] = (b << 8 j) advanced by 256 bytes; x2n[b] = x^(32 * 2^b), b = 0 .. 6
+inline void crc_build_tables(uint32_t *tab) {
+    for (uint32_t b = 0; b < 256; ++b) {
+        uint32_t c = b;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
+        tab[CRC_T0 + b] = c;
+    }
+    uint32_t x = 0x40000000u;                                   // x^1
+    uint32_t x2n[16];
+    for (int k = 0; k < 16; ++k) { x2n[k] = x; x = crc_multmodp(x, x); }      // x^(2^k)
+    for (int b = 0; b < 7; ++b) tab[CRC_X2N + b] = x2n[5 + b];  // x^(32 * 2^b)
+    tab[CRC_X2N + 7] = 0;
+    const uint32_t x2048 = x2n[11];
+    for (int j = 0; j < 4; ++j)
+        for (uint32_t b = 0; b < 256; ++b) tab[CRC_W + 256 * j + b] = crc_multmodp(x2048, b << (8 * j));
+}
+
+static __global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t *__restrict__ comp, const uint64_t *__restrict__ in_off,
+                                                   const uint32_t *__restrict__ in_len, const uint64_t *__restrict__ out_off,
+                                                   const uint32_t *__restrict__ out_len, int n_blocks,
+                                                   const uint8_t *__restrict__ text, int32_t *__restrict__ status,
+                                                   const uint32_t *__restrict__ tab) {
+    __shared__ uint32_t s_tab[CRC_TAB_WORDS];
+    for (int i = threadIdx.x; i < CRC_TAB_WORDS; i += 256) s_tab[i] = tab[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int b = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    if (b >= n_blocks || status[b] != 0) return;
+    const uint8_t *p = text + out_off[b];
+    uint32_t L = out_len[b];
+    const uint8_t *t = comp + in_off[b] + in_len[b];            // the block's trailer: CRC32, ISIZE
+    const uint32_t stored = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+    const uint32_t *t0 = s_tab + CRC_T0;
+    uint32_t s = 0xFFFFFFFFu;
+    uint32_t head = (uint32_t)((4 - ((uintptr_t)p & 3)) & 3);
+    if (head > L) head = L;
+    for (uint32_t i = 0; i < head; ++i) s = t0[(s ^ p[i]) & 0xFFu] ^ (s >> 8);
+    p += head; L -= head;
+    const uint32_t steps = L >> 8;                              // dwords per lane
+    if (steps) {
+        const uint32_t *q = (const uint32_t *)p + lane;
+        const uint32_t *w0 = s_tab + CRC_W, *w1 = w0 + 256, *w2 = w0 + 512, *w3 = w0 + 768;
+        uint32_t a = lane == 0 ? s : 0u;
+        uint32_t d = q[0];
+        for (uint32_t k = 1; k < steps; ++k) {
+            const uint32_t nx = q[64 * (size_t)k];
+            a ^= d;
+            a = w0[a & 0xFFu] ^ w1[(a >> 8) & 0xFFu] ^ w2[(a >> 16) & 0xFFu] ^ w3[a >> 24];
+            d = nx;
+        }
+        a ^= d;                                                  // stands 64 - lane dwords before the end of the rows
+        const uint32_t adv = 64u - (uint32_t)lane;
+        #pragma unroll 1
+        for (int bit = 0; bit < 7; ++bit)
+            if ((adv >> bit) & 1u) a = crc_multmodp(s_tab[CRC_X2N + bit], a);
+        #pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a ^= __shfl_xor(a, off);
+        s = a;
+        p += (size_t)steps << 8; L -= steps << 8;
+    }
+    for (uint32_t i = 0; i < L; ++i) s = t0[(s ^ p[i]) & 0xFFu] ^ (s >> 8);
+    if (lane == 0 && ~s != stored) status[b] = BGZF_STATUS_BAD_CRC;
+}
+
+}  // namespace hpgv

@@ -4,6 +4,7 @@
 #include "hpgv_inflate_kernels.h"
 #include "hpgv_inflate2_kernels.h"
 #include "hpgv_bgzf_kernels.h"
+#include "hpgv_crc_kernels.h"
 
 extern "C" {
 
@@ -57,6 +58,37 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
                            d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
     HIPCHK(ctx, hipGetLastError());
     return HPGV_OK;
+}
+
+// The CRC-32 check of decoded BGZF blocks (htslib's bgzf reader and zlib's gzread reject a block whose text does not have the
+// CRC its trailer gives; a DEFLATE stream can be damaged and still inflate to ISIZE bytes).  For every block whose d_status is
+// 0: CRC-32 of its out_len bytes at d_text + out_off against the four bytes at d_comp + in_off + in_len (the trailer follows
+// the payload); a mismatch sets d_status to HPGV_BLOCK_BAD_CRC.  Asynchronous on `stream`, behind the decoder's launch.
+int hpgv_bgzf_verify_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                         const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, const uint8_t *d_text,
+                         int32_t *d_status, void *stream) {
+    HPGV_ABI_TRY
+    ctx = first_member(ctx);
+    if (!ctx) return HPGV_ERR_INVALID;
+    if (n_blocks < 0 || (n_blocks > 0 && (!d_comp || !d_in_off || !d_in_len || !d_out_off || !d_out_len || !d_text || !d_status)))
+        return fail(ctx, HPGV_ERR_INVALID, "bad block check arguments");
+    if (n_blocks == 0) return HPGV_OK;
+    DeviceGuard g(ctx->device);
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (!ctx->d_crc_tab) {
+            static_assert(HPGV_BLOCK_BAD_CRC == hpgv::BGZF_STATUS_BAD_CRC, "status code of the header and of the kernel");
+            std::vector<uint32_t> tab(hpgv::CRC_TAB_WORDS);
+            hpgv::crc_build_tables(tab.data());
+            HIPCHK(ctx, hipMalloc(&ctx->d_crc_tab, tab.size() * sizeof(uint32_t)));
+            HIPCHK(ctx, hipMemcpy(ctx->d_crc_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+    }
+    hipLaunchKernelGGL(hpgv::k_bgzf_crc, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_comp, d_in_off, d_in_len,
+                       d_out_off, d_out_len, n_blocks, d_text, d_status, (const uint32_t *)ctx->d_crc_tab);
+    HIPCHK(ctx, hipGetLastError());
+    return HPGV_OK;
+    HPGV_ABI_CATCH(ctx)
 }
 
 // The block table of a bgzip file from its compressed bytes on the device: the blocks that form a chain from byte `lo`

@@ -131,6 +131,7 @@ struct hpgv_ctx {
     bool have_scan_ev = false, have_stats_ev = false;
     std::vector<Slot *> slots;
     uint32_t *d_sink = nullptr;
+    uint32_t *d_crc_tab = nullptr;     // tables of the BGZF CRC-32 check (hpgv_crc_kernels.h), built at first use
     // tokenizer scratch (newline counts per 4 KiB tile, line offsets), one set per stream that has
     // tokenized: calls on one stream are ordered by the stream, calls on different streams run
     // concurrently on the device and must not share it.  The table is guarded by tok_mu.

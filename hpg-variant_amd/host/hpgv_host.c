@@ -2016,8 +2016,27 @@ int hpgv_host_inflate_raw(const unsigned char *in, size_t in_len, unsigned char 
     return fast_inflate(in, in_len, out, out_len);
 }
 
+/* HPGV_BGZF_VERIFY (default 1): every BGZF block's text is checked against the CRC-32 of its trailer, as htslib's bgzf reader
+ * and zlib's gzread do -- a damaged stream can still inflate to ISIZE bytes.  On the device path the check runs on the device
+ * (hpgv_bgzf_verify_dev); a block it rejects comes here like any block the device decoder refused, and fails the run. */
+static char g_input_err[192];
+static int bgzf_verify_on(void) {
+    const char *e = getenv("HPGV_BGZF_VERIFY");
+    return !e || atoi(e) != 0;
+}
+/* in[clen .. clen + 4) is the block's CRC-32 (the BGZF trailer follows the payload) */
+static int block_crc_bad(const unsigned char *in, size_t clen, const unsigned char *out, size_t isize) {
+    const unsigned char *t = in + clen;
+    const uint32_t stored = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), out, (uInt)isize) == stored) return 0;
+    /* written by a reader / stager thread while the run may be reporting what it saw fail downstream: kept apart, and put in
+     * front when the run ends with an error (run_file) */
+    snprintf(g_input_err, sizeof g_input_err, "bgzip input: a block's text does not have the CRC-32 its trailer gives (damaged file)");
+    return 1;
+}
 static int inflate_block(const unsigned char *in, size_t clen, unsigned char *out, size_t isize) {
-    if (!getenv("HPGV_ZLIB_INFLATE") && fast_inflate(in, clen, out, isize) == 0) return 0;      /* anything unusual: zlib decides */
+    if (!getenv("HPGV_ZLIB_INFLATE") && fast_inflate(in, clen, out, isize) == 0)       /* anything unusual: zlib decides */
+        return bgzf_verify_on() ? block_crc_bad(in, clen, out, isize) : 0;
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, -15) != Z_OK) return 1;
@@ -2025,6 +2044,7 @@ static int inflate_block(const unsigned char *in, size_t clen, unsigned char *ou
     zs.next_out = (Bytef *)out; zs.avail_out = (uInt)isize;
     int bad = inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.total_out != isize;
     inflateEnd(&zs);
+    if (!bad && bgzf_verify_on()) bad = block_crc_bad(in, clen, out, isize);
     return bad;
 }
 
@@ -2203,7 +2223,7 @@ static void *bgzf_gpu_stager(void *v) {
                                  : first < GPU_FIRST + (size_t)GPU_STRETCH ? GPU_STRETCH
                                  : first < GPU_FIRST + 3 * (size_t)GPU_STRETCH ? 2 * (size_t)GPU_STRETCH : 4 * (size_t)GPU_STRETCH;
             const size_t next = first + stretch < nb ? first + stretch : nb;
-            const size_t lo = (size_t)s->g_in_off[first], hi = (size_t)s->g_in_off[next - 1] + s->g_in_len[next - 1];
+            const size_t lo = (size_t)s->g_in_off[first], hi = (size_t)s->g_in_off[next - 1] + s->g_in_len[next - 1] + 8;   /* + the last block's trailer: its CRC-32 is checked */
             (void)lo;
             if (hi > up_hi) {                             /* the uploader has been at it since the file was opened */
                 ok = wait_uploaded(s, hi);
@@ -2214,6 +2234,10 @@ static void *bgzf_gpu_stager(void *v) {
             ok = ok && hpgv_inflate_blocks_dev(g_ctx, (const uint8_t *)s->d_comp, (const uint64_t *)t + first, (const uint32_t *)(t + nb * 16) + first,
                                                (const uint64_t *)(t + nb * 8) + first, (const uint32_t *)(t + nb * 20) + first, (int)(next - first),
                                                (uint8_t *)s->d_text, (int32_t *)s->d_status + first, cs[q]) == HPGV_OK;
+            if (bgzf_verify_on())                         /* the blocks' CRC-32, on the device behind the decoder */
+                ok = ok && hpgv_bgzf_verify_dev(g_ctx, (const uint8_t *)s->d_comp, (const uint64_t *)t + first, (const uint32_t *)(t + nb * 16) + first,
+                                                (const uint64_t *)(t + nb * 8) + first, (const uint32_t *)(t + nb * 20) + first, (int)(next - first),
+                                                (const uint8_t *)s->d_text, (int32_t *)s->d_status + first, cs[q]) == HPGV_OK;
             q_hi[q] = next; qn++;
             if (ok && first == 0 && next < nb) {
                 /* launches that run side by side finish together, so the first stretch decodes alone (the time of one
@@ -2599,6 +2623,9 @@ static void *bgzf_gpu_stream_stager(void *v) {
           || dev_text_grow(s->d_text, q->text_end + 16, &s->d_text_cap);
         ok = ok && hpgv_inflate_blocks_dev(g_ctx, (const uint8_t *)s->d_comp, q->d_in_off, q->d_in_len, q->d_out_off, q->d_out_len,
                                            (int)q->n, (uint8_t *)s->d_text, q->d_status, q->stream) == HPGV_OK;
+        if (bgzf_verify_on())                                        /* the blocks' CRC-32, on the device behind the decoder */
+            ok = ok && hpgv_bgzf_verify_dev(g_ctx, (const uint8_t *)s->d_comp, q->d_in_off, q->d_in_len, q->d_out_off, q->d_out_len,
+                                            (int)q->n, (const uint8_t *)s->d_text, q->d_status, q->stream) == HPGV_OK;
         if (!ok) break;
         if (dbg && k == 0) fprintf(stderr, "stager: first stretch launched at %.4f\n", now_s() - T0);
         launched += q->n;
@@ -3720,6 +3747,7 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
                     long *n_variants_out) {
     const double t_enter = now_s();
     g_write_split[0] = g_write_split[1] = 0;
+    g_input_err[0] = 0;
     int rc = ensure_engine();
     if (rc) return rc;
     if (batch_bytes < (1u << 16)) batch_bytes = 1u << 16;
@@ -3741,7 +3769,7 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     const double t_opened = now_s();
     const int n_samples = vcf_header_read(&rd, &hdr, &names, &chrom_off);
     const double t_header = now_s();
-    if (n_samples < 0) { source_close(&rd.src); free(rd.carry); free(hdr); ped_table_free(&ped); snprintf(g_err, sizeof g_err, "no #CHROM header line in %s", vcf_path); return HPGV_ERR_INVALID; }
+    if (n_samples < 0) { source_close(&rd.src); free(rd.carry); free(hdr); ped_table_free(&ped); snprintf(g_err, sizeof g_err, "%s%sno #CHROM header line in %s", g_input_err, g_input_err[0] ? "; " : "", vcf_path); return HPGV_ERR_INVALID; }
 
     /* cohort: PED rows looked up by sample name (associate_samples_and_positions + sort_individuals) */
     sample_ids_t *ids = sample_ids_new((size_t)n_samples);
@@ -4023,7 +4051,7 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
         for (int i = 0; i < n_th; i++) pthread_join(th[i], NULL);
         rd.src.pool = NULL;
         pool_destroy(&rpool); pool_destroy(&wpool);
-        if (P->rc) { rc = P->rc; snprintf(g_err, sizeof g_err, "%s", P->err); }
+        if (P->rc) { rc = P->rc; snprintf(g_err, sizeof g_err, "%s%s%s", g_input_err, g_input_err[0] ? "; " : "", P->err); }
         g_run_times[0] = P->t_read; g_run_times[1] = P->t_engine; g_run_times[2] = P->t_write; g_run_times[5] = (double)P->n_filled;
         pthread_mutex_destroy(&P->mu); pthread_cond_destroy(&P->cv);
     }

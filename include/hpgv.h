@@ -400,6 +400,14 @@ int  hpgv_text_alias(hpgv_ctx *ctx, const char *host_text, const char *d_text);
 int  hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
                              const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, uint8_t *d_text,
                              int32_t *d_status, void *stream);
+/* The CRC-32 check of decoded BGZF blocks (what htslib's bgzf reader / zlib's gzread do per block behind --compression bgzip,
+ * shared_options.c:60-61): for every block with d_status 0, the CRC-32 of its text against the block's trailer, which follows
+ * its payload (the four bytes at d_comp + in_off + in_len); a mismatch sets d_status to HPGV_BLOCK_BAD_CRC.  Same tables as
+ * hpgv_inflate_blocks_dev; asynchronous on `stream`. */
+#define HPGV_BLOCK_BAD_CRC 9
+int  hpgv_bgzf_verify_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                          const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, const uint8_t *d_text,
+                          int32_t *d_status, void *stream);
 /* The rows of those tables from the compressed bytes of a bgzip file on the device (bgzf.c of htslib writes the blocks the
  * reference reads with --compression bgzip, shared_options.c:60-61): the blocks that form a chain from byte `lo` (a block
  * start; 0 at first) and end at or before `hi` (bytes [0, hi) are on the device), at most max_rows of them, written from

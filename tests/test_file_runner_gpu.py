@@ -576,3 +576,62 @@ def test_run_assoc_result_order_is_known_without_reading_the_file_back(host, tmp
     gnu = subprocess.run(["sort", "-k1,1h", "-k2,2n", out], capture_output=True, text=True, env=dict(os.environ, LC_ALL="C"), check=True).stdout
     assert open(out).read() == gnu
     assert ("in order as written" in err) == (chroms[-1] != "X")       # read back and sorted only where it had to be
+
+
+def test_run_fails_on_a_bgzf_block_with_a_wrong_crc(host, tmp_path):
+    # one literal byte flipped inside a STORED block -- the stream still inflates to ISIZE bytes, only the
+    # CRC-32 of the trailer tells.  The run must fail (as htslib's reader does) by the device path and by the host path, and say
+    # why; HPGV_BGZF_VERIFY=0 switches the check off and the damaged genotype goes into the statistics unnoticed.
+    import struct
+    import zlib
+    from test_host_logic_cpu import _bgzf
+    rng = np.random.default_rng(16)
+    people, names, rows = _write_inputs(tmp_path, rng, 50, 40, 4000)
+    vcf = _vcf_from_batch(tmp_path, names, rows)
+    data = open(vcf, "rb").read()
+    ped = str(tmp_path / "ped.txt").encode()
+
+    def stored(ch, damage_at=None):
+        co = zlib.compressobj(0, zlib.DEFLATED, -15)
+        comp = bytearray(co.compress(ch) + co.flush())
+        if damage_at is not None:
+            at = 5 + damage_at                                        # one stored DEFLATE block: 5 header bytes, then the text as it is
+            assert comp[at] == ch[damage_at]
+            comp[at] = ord("1") if comp[at] == ord("0") else ord("0")
+        return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(comp) + 8 - 1)
+                + bytes(comp) + struct.pack("<II", zlib.crc32(ch), len(ch)))
+    cut = 0x700 * 150
+    block = data[cut: cut + 0x3000]
+    # a genotype character (the byte after a TAB inside the sample columns): 0 <-> 1 keeps the line well-formed
+    line_start = block.index(b"\n") + 1
+    tabs, at = 0, line_start
+    while tabs < 12:
+        at = block.index(b"\t", at) + 1
+        tabs += 1
+    assert block[at] in b"01"
+    good = str(tmp_path / "good.vcf.gz")
+    bad = str(tmp_path / "bad.vcf.gz")
+    open(good, "wb").write(_bgzf(data[:cut], 0x700)[:-28] + stored(block) + _bgzf(data[cut + 0x3000:], 0x700))
+    open(bad, "wb").write(_bgzf(data[:cut], 0x700)[:-28] + stored(block, at) + _bgzf(data[cut + 0x3000:], 0x700))
+
+    def run(path, env):
+        os.environ.update(env)
+        try:
+            n = C.c_long(0)
+            out = str(tmp_path / "res")
+            rc = host.hpgv_run_assoc(path.encode(), ped, out.encode(), 1, 1 << 17, C.byref(n))
+            return rc, (open(out, "rb").read() if rc == 0 else None), host.hpgv_host_last_error()
+        finally:
+            for k in env:
+                del os.environ[k]
+    host.hpgv_host_last_error.restype = C.c_char_p
+    rc, ref, _ = run(good, {})
+    assert rc == 0
+    for env in ({}, {"HPGV_BGZF_HOST_TABLE": "1"}, {"HPGV_NO_GPU_INFLATE": "1"}):
+        rc, _, why = run(bad, env)
+        assert rc != 0, env
+        assert b"CRC-32" in why, (env, why)
+        rc, res, _ = run(good, env)
+        assert rc == 0 and res == ref
+    rc, res, _ = run(bad, {"HPGV_BGZF_VERIFY": "0"})
+    assert rc == 0 and res != ref                                     # unchecked: the wrong genotype is counted

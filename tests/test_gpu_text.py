@@ -467,3 +467,55 @@ def test_everyday_genotype_stretches_and_what_breaks_them(eng, strict):
     # the same with a FORMAT that does not begin with GT: nothing is everyday, and (tile-parallel form) lines are re-done
     lines2 = [_line(rng, n_samples, "DP:GT", "7", info_len=i, gts=[plain[int(k)] for k in rng.integers(0, len(plain), n_samples)]) for i in range(12)]
     _check(eng, "\n".join(lines2) + "\n", n_samples, strict)
+
+
+def test_bgzf_crc_check_on_the_gpu_against_zlib():
+    # hpgv_bgzf_verify_dev: CRC-32 of every decoded block against its BGZF trailer (a damaged stream can inflate to
+    # ISIZE bytes of the wrong text).  Lengths around every boundary of the kernel (the 0 - 3 bytes before the first aligned
+    # dword, whole 256-byte rows, the rest), text offsets of every alignment, blocks already refused by the decoder left alone
+    import zlib
+    rng = np.random.default_rng(5)
+    lens = [0, 1, 2, 3, 4, 5, 7, 255, 256, 257, 258, 259, 260, 511, 512, 513, 1023, 1024, 4099, 65279, 65280, 65281, 65535, 65536]
+    lens += [int(x) for x in rng.integers(0, 65537, 40)]
+    texts = [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in lens]
+    n = len(texts)
+    out_len = np.array(lens, np.uint32)
+    gaps = rng.integers(0, 4, n)                                        # texts start at every alignment
+    out_off = np.zeros(n, np.uint64)
+    at = 1
+    for k in range(n):
+        at += int(gaps[k])
+        out_off[k] = at
+        at += lens[k]
+    total = at + 16
+    text = np.zeros(total, np.uint8)
+    for k in range(n):
+        text[int(out_off[k]): int(out_off[k]) + lens[k]] = np.frombuffer(texts[k], np.uint8)
+    # the "compressed" side only needs each block's trailer behind its payload: payload = k % 5 filler bytes
+    comp = bytearray()
+    in_off, in_len = np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+    for k in range(n):
+        in_off[k], in_len[k] = len(comp), k % 5
+        comp += b"\xAA" * (k % 5) + int(zlib.crc32(texts[k])).to_bytes(4, "little") + lens[k].to_bytes(4, "little")
+    comp += b"\0" * 16
+    wrong_text = [5, 9, 20, 23, n - 1]                                   # one flipped bit in the text
+    for k in wrong_text:
+        if lens[k]:
+            text[int(out_off[k]) + lens[k] // 2] ^= 0x10
+    wrong_text = [k for k in wrong_text if lens[k]]
+    refused = [3, 30]                                                    # a status the decoder left: not touched, not checked
+    status = np.zeros(n, np.int32)
+    status[refused] = 4
+    e = hpgv.Engine(0)
+    d_comp, d_text = e.alloc(len(comp)), e.alloc(total)
+    d_io, d_il, d_oo, d_ol, d_st = e.alloc(8 * n), e.alloc(4 * n), e.alloc(8 * n), e.alloc(4 * n), e.alloc(4 * n)
+    for d, a in ((d_comp, np.frombuffer(bytes(comp), np.uint8)), (d_text, text), (d_io, in_off), (d_il, in_len), (d_oo, out_off),
+                 (d_ol, out_len), (d_st, status)):
+        e.h2d(d, a)
+    e.bgzf_verify(d_comp, d_io, d_il, d_oo, d_ol, n, d_text, d_st)
+    e.sync()
+    got = e.d2h(d_st, (n,), np.int32)
+    exp = status.copy()
+    exp[[k for k in wrong_text if k not in refused]] = 9                 # HPGV_BLOCK_BAD_CRC
+    assert np.array_equal(got, exp), (np.nonzero(got != exp)[0], got[got != exp], [lens[k] for k in np.nonzero(got != exp)[0]])
+    e.close()
