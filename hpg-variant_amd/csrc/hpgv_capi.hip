@@ -116,11 +116,20 @@ static int stats_all_call(hpgv_ctx *ctx, Slot *s, const uint8_t *d_src, size_t s
         A.group_out = (hpgv::BatchStatsRec *)s->d_res + n;
     }
     // a band of rows per workgroup keeps the column counters in LDS across rows; short batches stay one row per workgroup
-    int rows = (n_variants + 2047) / 2048;
+    // (one band per workgroup slot of the chip, about three per compute unit: the band's end -- its column counters' atomics --
+    // costs as much as several rows, and fewer workgroups than slots leave units idle: 16 000 rows, 8 / 21 / 42 per band:
+    // 105 / 65 / 84 us)
+    int rows = (n_variants + 3 * ctx->n_cus - 1) / (3 * ctx->n_cus);
+    if (const char *rb = getenv("HPGV_STATS_ROWS")) rows = atoi(rb);        // tuning: the band length
     rows = rows < 1 ? 1 : (rows > 255 ? 255 : rows);
     A.rows_per_block = rows; A.lds_row = (int)(((size_t)ns + 32 + 15) / 16 * 16);
-    const size_t lds = stats_all_lds(ctx, want_mendel);
-    hipLaunchKernelGGL(hpgv::k_stats_all, dim3((unsigned)((n_variants + rows - 1) / rows)), dim3(256), lds, s->stream, A);
+    // columns owned by threads across the band (hpgv_statsall_kernels.h); what that kernel does not take -- unaligned rows,
+    // very wide cohorts, many groups -- goes to the row-staging kernel
+    const char *a2 = getenv("HPGV_STATS_ALL2");                     // diagnosis: 0 = the row-staging kernel for every batch
+    if ((a2 && atoi(a2) == 0) || hpgv_launch_stats_all2(ctx, A, &s->cnt_buf, &s->cnt_cap, s->stream) != 0) {
+        const size_t lds = stats_all_lds(ctx, want_mendel);
+        hipLaunchKernelGGL(hpgv::k_stats_all, dim3((unsigned)((n_variants + rows - 1) / rows)), dim3(256), lds, s->stream, A);
+    }
     HIPCHK(ctx, hipGetLastError());
     std::vector<int32_t> acc;
     if (want_sm || want_ce) {
@@ -282,6 +291,7 @@ void hpgv_destroy(hpgv_ctx *ctx) {
     (void)hipDeviceSynchronize();
     if (ctx->d_mendel_male) (void)hipFree(ctx->d_mendel_male);
     if (ctx->d_sg_chunks) (void)hipFree(ctx->d_sg_chunks);
+    if (ctx->d_group_of_col) (void)hipFree(ctx->d_group_of_col);
     for (Layout *L : {&ctx->assoc, &ctx->tdt, &ctx->stats, &ctx->sgroups, &ctx->mendel})
         if (L->d_col_of_pos) (void)hipFree(L->d_col_of_pos);
     ctx->tdt_plan.release();
@@ -302,6 +312,7 @@ void hpgv_destroy(hpgv_ctx *ctx) {
     for (Slot *s : ctx->slots) {
         for (int i = 0; i < 8; ++i) if (s->buf[i]) (void)hipFree(s->buf[i]);
         if (s->h_res) (void)hipHostFree(s->h_res);
+        if (s->cnt_buf) (void)hipFree(s->cnt_buf);
         if (s->stream) (void)hipStreamDestroy(s->stream);
         delete s;
     }
@@ -486,6 +497,21 @@ int hpgv_set_stats_groups(hpgv_ctx *ctx, const int32_t *group_of_sample, int n_s
             ctx->sg_chunks_cap = tab.size();
         }
         HIPCHK(ctx, hipMemcpy(ctx->d_sg_chunks, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    {   // the group of every column, for the kernel that counts groups with masks over the columns in VCF order (k_stats_all2)
+        std::vector<uint8_t> gid(round_up((size_t)n_samples, 16) + 16, 0xFF);
+        bool all = n_samples > 0;
+        for (int j = 0; j < n_samples; ++j) {
+            if (group_of_sample[j] >= 0 && group_of_sample[j] < 255) gid[(size_t)j] = (uint8_t)group_of_sample[j];
+            else all = false;
+        }
+        ctx->all_grouped = all;
+        if (ctx->group_of_col_cap < gid.size()) {
+            if (ctx->d_group_of_col) { (void)hipFree(ctx->d_group_of_col); ctx->d_group_of_col = nullptr; ctx->group_of_col_cap = 0; }
+            HIPCHK(ctx, hipMalloc(&ctx->d_group_of_col, gid.size()));
+            ctx->group_of_col_cap = gid.size();
+        }
+        HIPCHK(ctx, hipMemcpy(ctx->d_group_of_col, gid.data(), gid.size(), hipMemcpyHostToDevice));
     }
     return upload_layout(ctx, L);
     HPGV_ABI_CATCH(ctx)

@@ -42,6 +42,8 @@ struct Slot {
     void *h_res = nullptr;             // page-locked result block of the fused per-batch kernel (the kernel stores into it)
     void *d_res = nullptr;             // its device-side address
     size_t res_cap = 0;
+    void *cnt_buf = nullptr;           // k_stats_all2's per-row counters between its two kernels
+    size_t cnt_cap = 0;
 };
 
 // epistasis / MDR state: the vcf2epi dataset on the device, its bit planes for the current folds
@@ -114,6 +116,9 @@ struct hpgv_ctx {
     std::vector<int> sg_size;             // samples per group
     int32_t *d_sg_chunks = nullptr;       // device: first 16-byte chunk and chunk count of every group ([2 * n_groups])
     size_t sg_chunks_cap = 0;
+    uint8_t *d_group_of_col = nullptr;    // device: group id of every column (0xFF: in no group), padded to whole 16-byte chunks -- k_stats_all2's masks
+    size_t group_of_col_cap = 0;
+    bool all_grouped = false;             // every column is in a group: the last group's counters are "all minus the others"
     // mendelian errors
     Layout mendel;
     int mendel_trios = 0, mendel_pchunks = 0;
@@ -304,6 +309,9 @@ template <typename F>
 }  // namespace
 
 
+// defined in hpgv_statsall_capi.hip: k_stats_all2 on a batch (0 = launched, 1 = not a batch it takes: run k_stats_all)
+namespace hpgv { struct StatsAllArgs; }
+int hpgv_launch_stats_all2(hpgv_ctx *ctx, hpgv::StatsAllArgs &A, void **cnt_buf, size_t *cnt_cap, hipStream_t st);
 // defined in hpgv_epi_capi.hip
 void hpgv_epi_release(EpiState &E);
 // defined in hpgv_group_capi.hip: streams, scratch and communicator of a group context (before its members go)
