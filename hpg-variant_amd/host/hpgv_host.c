@@ -349,6 +349,7 @@ static char g_err[512];
 /* what the current device-side cohort descriptions were built from */
 static struct {
     const void *samples; int num_samples; uint64_t cond_hash; int set;
+    uint8_t *cond;                                       /* the installed condition vector itself: a hash hit is confirmed against it */
 } g_assoc_key;
 static struct { int num_families; int num_columns; uint64_t hash; int set; } g_tdt_key;
 static struct { int num_samples; int set; } g_stats_key;
@@ -586,6 +587,7 @@ static void text_cache_release(void) {                  /* g_ctx still alive */
 void hpgv_host_shutdown(void) {
     pthread_mutex_lock(&g_init_mu);
     if (g_ctx) { text_cache_release(); stage_pool_release(); hpgv_destroy(g_ctx); g_ctx = NULL; }
+    free(g_assoc_key.cond);
     memset(&g_assoc_key, 0, sizeof g_assoc_key);
     memset(&g_tdt_key, 0, sizeof g_tdt_key);
     memset(&g_stats_key, 0, sizeof g_stats_key);
@@ -632,13 +634,19 @@ static int assoc_prepare(enum ASSOC_task task, individual_t **samples, int num_s
      * dropped, the write lock taken, and after coming back to the read lock the keys are checked AGAIN: a thread with another
      * cohort may have installed its own in the gap.  The loop ends with the wanted layout installed under our read lock. */
     for (;;) {
-        const int need_cohort = !(g_assoc_key.set && g_assoc_key.num_samples == num_samples && g_assoc_key.cond_hash == h);
+        int same_cohort = g_assoc_key.set && g_assoc_key.num_samples == num_samples && g_assoc_key.cond_hash == h && g_assoc_key.cond;
+        /* the 64-bit hash only says "probably": the vector decides (a collision would scan with another cohort's layout) */
+        for (int j = 0; same_cohort && j < num_samples; j++) {
+            const enum Condition c = samples[j]->condition;
+            same_cohort = g_assoc_key.cond[j] == ((c == AFFECTED) ? HPGV_COND_AFFECTED : (c == UNAFFECTED) ? HPGV_COND_UNAFFECTED : HPGV_COND_OTHER);
+        }
+        const int need_cohort = !same_cohort;
         const int need_lf = (task == FISHER) && !(g_lf_key.table == opt_input && g_lf_key.n == num_samples * 10);
         if (!need_cohort && !need_lf) return HPGV_OK;
         pthread_rwlock_unlock(&g_cohort_lock);
         pthread_rwlock_wrlock(&g_cohort_lock);
         int rc = HPGV_OK;
-        if (!(g_assoc_key.set && g_assoc_key.num_samples == num_samples && g_assoc_key.cond_hash == h)) {
+        if (need_cohort) {                                            /* (re-checked from scratch by the next turn of the loop, under the read lock) */
             uint8_t *cond = (uint8_t *)malloc((size_t)(num_samples > 0 ? num_samples : 1));
             if (!cond) { snprintf(g_err, sizeof g_err, "out of memory"); rc = HPGV_ERR_NOMEM; }
             else {
@@ -647,11 +655,11 @@ static int assoc_prepare(enum ASSOC_task task, individual_t **samples, int num_s
                     cond[j] = (c == AFFECTED) ? HPGV_COND_AFFECTED : (c == UNAFFECTED) ? HPGV_COND_UNAFFECTED : HPGV_COND_OTHER;
                 }
                 rc = hpgv_set_cohort(g_ctx, cond, num_samples);
-                free(cond);
                 if (rc == HPGV_OK) {
                     g_assoc_key.samples = samples; g_assoc_key.num_samples = num_samples;
                     g_assoc_key.cond_hash = h; g_assoc_key.set = 1;
-                } else host_fail("hpgv_set_cohort", rc);
+                    free(g_assoc_key.cond); g_assoc_key.cond = cond;
+                } else { free(cond); host_fail("hpgv_set_cohort", rc); }
             }
         }
         if (rc == HPGV_OK && task == FISHER && !(g_lf_key.table == opt_input && g_lf_key.n == num_samples * 10)) {
