@@ -341,6 +341,18 @@ int hpgv_host_stage_records(vcf_record_t **variants, int num_variants, int num_s
 /* ------------------------------------------------------------------------ */
 
 static hpgv_ctx *g_ctx = NULL;
+/* The bgzip device path may run in PARTS, one per member of a group context (bgzf_parts_stage): the threads that stage,
+ * decode and hand out a part work on that member's device.  They say so once -- ctx_use(member context, member index) --
+ * and everything below them that allocates, copies or launches uses CTX, and the per-member caches (streams, the decoded
+ * text) slot t_member.  Threads that never say so work on g_ctx, which for a group is its first member: the single-device
+ * path is unchanged. */
+enum { MEMBERS_MAX = 16 };
+static __thread hpgv_ctx *t_ctx = NULL;
+static __thread int t_member = 0;
+#define CTX (t_ctx ? t_ctx : g_ctx)
+typedef struct { hpgv_ctx *ctx; int member; } ctx_saved_t;
+static ctx_saved_t ctx_use(hpgv_ctx *ctx, int member) { ctx_saved_t o = { t_ctx, t_member }; t_ctx = ctx; t_member = ctx ? member : 0; return o; }
+static void ctx_back(ctx_saved_t o) { t_ctx = o.ctx; t_member = o.member; }
 static int g_device = 0;
 static pthread_mutex_t g_init_mu = PTHREAD_MUTEX_INITIALIZER;
 static pthread_rwlock_t g_cohort_lock = PTHREAD_RWLOCK_INITIALIZER;
@@ -499,10 +511,13 @@ static void stage_pool_release(void) {                  /* g_ctx still alive */
  * backed as far as needed (hpgv_dev_reserve): a bgzip file's text size is known only when its last block has been seen. */
 enum { DEV_TEXT_FIXED = 0, DEV_TEXT_GROWS = 1 };
 #define DEV_TEXT_RESERVE ((size_t)56 << 30)
-static void *g_dev_text; static size_t g_dev_text_cap; static int g_dev_text_kind;
+static void *g_dev_text_m[MEMBERS_MAX]; static size_t g_dev_text_cap_m[MEMBERS_MAX]; static int g_dev_text_kind_m[MEMBERS_MAX];
+#define g_dev_text g_dev_text_m[t_member]
+#define g_dev_text_cap g_dev_text_cap_m[t_member]
+#define g_dev_text_kind g_dev_text_kind_m[t_member]
 static void dev_text_free(void *p, int kind) {
     if (!p) return;
-    if (kind == DEV_TEXT_GROWS) (void)hpgv_dev_release(g_ctx, p); else (void)hpgv_dev_free(g_ctx, p);
+    if (kind == DEV_TEXT_GROWS) (void)hpgv_dev_release(CTX, p); else (void)hpgv_dev_free(CTX, p);
 }
 /* a buffer with `bytes` usable bytes (*cap: how many it has); *kind = DEV_TEXT_GROWS when dev_text_grow can extend it */
 static void *dev_text_get(size_t bytes, size_t *cap, int *kind) {
@@ -515,22 +530,22 @@ static void *dev_text_get(size_t bytes, size_t *cap, int *kind) {
     pthread_mutex_unlock(&g_text_mu);
     if (p) {
         if (*cap >= bytes) return p;
-        if (bytes <= DEV_TEXT_RESERVE && hpgv_dev_commit(g_ctx, p, bytes) == HPGV_OK) { *cap = bytes; return p; }
+        if (bytes <= DEV_TEXT_RESERVE && hpgv_dev_commit(CTX, p, bytes) == HPGV_OK) { *cap = bytes; return p; }
         dev_text_free(p, *kind);
         p = NULL;
     }
-    if (bytes <= DEV_TEXT_RESERVE && !getenv("HPGV_NO_GROWING_TEXT") && hpgv_dev_reserve(g_ctx, DEV_TEXT_RESERVE, &p) == HPGV_OK) {
-        if (hpgv_dev_commit(g_ctx, p, bytes) == HPGV_OK) { *cap = bytes; *kind = DEV_TEXT_GROWS; return p; }
-        (void)hpgv_dev_release(g_ctx, p);
+    if (bytes <= DEV_TEXT_RESERVE && !getenv("HPGV_NO_GROWING_TEXT") && hpgv_dev_reserve(CTX, DEV_TEXT_RESERVE, &p) == HPGV_OK) {
+        if (hpgv_dev_commit(CTX, p, bytes) == HPGV_OK) { *cap = bytes; *kind = DEV_TEXT_GROWS; return p; }
+        (void)hpgv_dev_release(CTX, p);
         p = NULL;
     }
-    if (hpgv_dev_alloc(g_ctx, bytes, &p) != HPGV_OK) return NULL;
+    if (hpgv_dev_alloc(CTX, bytes, &p) != HPGV_OK) return NULL;
     *cap = bytes; *kind = DEV_TEXT_FIXED;
     return p;
 }
 static int dev_text_grow(void *p, size_t bytes, size_t *cap) {
     if (bytes <= *cap) return 1;
-    if (bytes > DEV_TEXT_RESERVE || hpgv_dev_commit(g_ctx, p, bytes) != HPGV_OK) return 0;
+    if (bytes > DEV_TEXT_RESERVE || hpgv_dev_commit(CTX, p, bytes) != HPGV_OK) return 0;
     *cap = bytes;
     return 1;
 }
@@ -551,36 +566,46 @@ static void dev_text_put(void *p, size_t bytes, int kind) {
 /* streams of the bgzip device path, kept between runs: creating the seven a run uses took 18 ms of a 0.14 s run (they are
  * idle when they come back) */
 enum { STREAM_CACHE_N = 16 };
-static void *g_stream_cache[2][STREAM_CACHE_N];        /* [0] normal priority, [1] lowest */
+static void *g_stream_cache_m[MEMBERS_MAX][2][STREAM_CACHE_N];        /* per member; [0] normal priority, [1] lowest */
+#define g_stream_cache g_stream_cache_m[t_member]
 static int stream_get(int low, void **out) {
     pthread_mutex_lock(&g_text_mu);
     for (int i = 0; i < STREAM_CACHE_N; i++)
         if (g_stream_cache[low][i]) { *out = g_stream_cache[low][i]; g_stream_cache[low][i] = NULL; pthread_mutex_unlock(&g_text_mu); return HPGV_OK; }
     pthread_mutex_unlock(&g_text_mu);
-    return low ? hpgv_stream_create_low(g_ctx, out) : hpgv_stream_create(g_ctx, out);
+    return low ? hpgv_stream_create_low(CTX, out) : hpgv_stream_create(CTX, out);
 }
 static void stream_put(int low, void *st) {
     if (!st) return;
-    (void)hpgv_stream_sync(g_ctx, st);
+    (void)hpgv_stream_sync(CTX, st);
     pthread_mutex_lock(&g_text_mu);
     for (int i = 0; i < STREAM_CACHE_N; i++)
         if (!g_stream_cache[low][i]) { g_stream_cache[low][i] = st; st = NULL; break; }
     pthread_mutex_unlock(&g_text_mu);
-    if (st) (void)hpgv_stream_destroy(g_ctx, st);
+    if (st) (void)hpgv_stream_destroy(CTX, st);
 }
 
 static void text_cache_release(void) {                  /* g_ctx still alive */
-    for (int low = 0; low < 2; low++)
-        for (int i = 0; i < STREAM_CACHE_N; i++) {
-            pthread_mutex_lock(&g_text_mu);
-            void *st = g_stream_cache[low][i]; g_stream_cache[low][i] = NULL;
-            pthread_mutex_unlock(&g_text_mu);
-            if (st) (void)hpgv_stream_destroy(g_ctx, st);
-        }
+    const int G = hpgv_group_size(g_ctx);
+    for (int m = 0; m < G && m < MEMBERS_MAX; m++) {    /* every member's streams and decoded-text buffer */
+        const ctx_saved_t o = ctx_use(G > 1 ? hpgv_group_member(g_ctx, m) : NULL, m);
+        for (int low = 0; low < 2; low++)
+            for (int i = 0; i < STREAM_CACHE_N; i++) {
+                pthread_mutex_lock(&g_text_mu);
+                void *st = g_stream_cache[low][i]; g_stream_cache[low][i] = NULL;
+                pthread_mutex_unlock(&g_text_mu);
+                if (st) (void)hpgv_stream_destroy(CTX, st);
+            }
+        pthread_mutex_lock(&g_text_mu);
+        void *dt = g_dev_text; const int dk = g_dev_text_kind;
+        g_dev_text = NULL; g_dev_text_cap = 0;
+        pthread_mutex_unlock(&g_text_mu);
+        dev_text_free(dt, dk);
+        ctx_back(o);
+    }
     pthread_mutex_lock(&g_text_mu);
     for (int i = 0; i < TEXT_CACHE_N; i++)
         if (g_text_cache[i].p) { (void)hpgv_host_free(g_ctx, g_text_cache[i].p); g_text_cache[i].p = NULL; g_text_cache[i].cap = 0; }
-    if (g_dev_text) { dev_text_free(g_dev_text, g_dev_text_kind); g_dev_text = NULL; g_dev_text_cap = 0; }
     pthread_mutex_unlock(&g_text_mu);
 }
 
@@ -1739,7 +1764,20 @@ typedef struct {
     pthread_t g_thread; pthread_mutex_t g_mu; pthread_cond_t g_cv; int g_started, g_sync, g_err, g_finished;
     /* the uploader: the compressed file goes up from the moment it is opened, beside the walk of its block headers */
     pthread_t u_thread; int u_started, u_cancel, u_err; size_t up_done;      /* bytes [0, up_done) are on the device (under g_mu) */
+    /* a PART of a bgzip file staged on one member of a group context (bgzf_parts_stage): the bytes [file_off, file_off + size)
+     * of the file, `map` pointing at its first byte, everything else as for a whole file.  ctx == NULL: an ordinary source */
+    hpgv_ctx *ctx; int member; off_t file_off; int is_part;
+    size_t map_len; const unsigned char *map_base;      /* the mapping as it was made (a part's is its file's) */
+    struct src_parts *mp;                               /* the file's parts, when it is staged in parts (this source is part 0) */
 } source_t;
+/* the parts of one bgzip file, in file order; the reader walks them and joins the line that straddles two of them */
+typedef struct src_parts {
+    int n, cur;
+    source_t *p[MEMBERS_MAX];                           /* p[0] = the reader's own source */
+    char *seam; size_t seam_len, seam_cap;              /* the line across the seam in front of part `cur`, waiting to be handed out */
+    off_t whole_size;
+} src_parts_t;
+#define SRC_CTX(s) ctx_use((s)->ctx, (s)->member)
 
 static int bgzf_block(const unsigned char *p, size_t avail, size_t *bsize, size_t *cdata_off, size_t *isize) {
     if (avail < 18 || p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) return 0;
@@ -1768,9 +1806,10 @@ static int source_open(source_t *s, const char *path) {
     if (got >= 2 && head[0] == 31 && head[1] == 139) {
         size_t bs, co, is;
         s->map = (const unsigned char *)mmap(NULL, (size_t)s->size, PROT_READ, MAP_PRIVATE, s->fd, 0);
+        s->map_base = s->map; s->map_len = (size_t)s->size;
         if (s->map != MAP_FAILED && bgzf_block(s->map, (size_t)s->size, &bs, &co, &is)) { s->kind = SRC_BGZF; return 0; }
         if (s->map != MAP_FAILED) munmap((void *)s->map, (size_t)s->size);
-        s->map = NULL;
+        s->map = NULL; s->map_base = NULL; s->map_len = 0;
         s->gz = gzdopen(dup(s->fd), "rb");
         if (!s->gz) { close(s->fd); return 1; }
         gzbuffer(s->gz, 1u << 20);
@@ -1780,26 +1819,33 @@ static int source_open(source_t *s, const char *path) {
 }
 
 static void source_close(source_t *s) {
+    if (s->mp) {                                                     /* the other parts of the file (this one is part 0) */
+        for (int k = 1; k < s->mp->n; k++) if (s->mp->p[k]) { source_close(s->mp->p[k]); free(s->mp->p[k]); }
+        s->size = s->mp->whole_size;
+        free(s->mp->seam); free(s->mp); s->mp = NULL;
+    }
+    const ctx_saved_t saved = SRC_CTX(s);
     if (s->g_started) pthread_join(s->g_thread, NULL);               /* the stager reads the mapping: it goes first */
     if (s->u_started) {
         pthread_mutex_lock(&s->g_mu); s->u_cancel = 1; pthread_mutex_unlock(&s->g_mu);
         pthread_join(s->u_thread, NULL); s->u_started = 0;
     }
-    if (s->kind == SRC_BGZF && s->map) munmap((void *)s->map, (size_t)s->size);
+    if (s->kind == SRC_BGZF && s->map_base && !s->is_part) munmap((void *)s->map_base, s->map_len);
     free(s->pend); free(s->blk);
     if (s->g_sync) { pthread_mutex_destroy(&s->g_mu); pthread_cond_destroy(&s->g_cv); }
     free(s->g_in_off); free(s->g_out_off); free(s->g_in_len); free(s->g_out_len);
     if (g_ctx) {
-        if (s->d_comp) (void)hpgv_dev_free(g_ctx, s->d_comp);
-        if (s->d_tab) (void)hpgv_dev_free(g_ctx, s->d_tab);
-        if (s->d_status) (void)hpgv_dev_free(g_ctx, s->d_status);
+        if (s->d_comp) (void)hpgv_dev_free(CTX, s->d_comp);
+        if (s->d_tab) (void)hpgv_dev_free(CTX, s->d_tab);
+        if (s->d_status) (void)hpgv_dev_free(CTX, s->d_status);
         if (s->d_text) dev_text_put(s->d_text, s->d_text_cap, s->d_text_kind);
-        if (s->d_scan) (void)hpgv_dev_free(g_ctx, s->d_scan);
+        if (s->d_scan) (void)hpgv_dev_free(CTX, s->d_scan);
         stream_put(0, s->rstream);
         stream_put(s->c_low, s->cstream);
     }
     if (s->kind == SRC_GZIP && s->gz) gzclose(s->gz);
     if (s->fd >= 0) close(s->fd);
+    ctx_back(saved);
 }
 
 /* ---- raw DEFLATE (RFC 1951) decoder for BGZF blocks ------------------------------------------------------------
@@ -2115,7 +2161,7 @@ static void *up_reader(void *v) {
         pthread_mutex_unlock(&r->mu);
         if (quit) return NULL;
         const size_t off = i * (size_t)UP_SEG, len = off + UP_SEG <= (size_t)r->s->size ? (size_t)UP_SEG : (size_t)r->s->size - off;
-        const int ok = pread_full(r->s->fd, r->pin + (i % UP_SLOTS) * (size_t)UP_SEG, len, off) == len;
+        const int ok = pread_full(r->s->fd, r->pin + (i % UP_SLOTS) * (size_t)UP_SEG, len, off + (size_t)r->s->file_off) == len;
         pthread_mutex_lock(&r->mu);
         if (ok) r->filled[i % UP_SLOTS] = 1; else r->bad = 1;
         pthread_cond_broadcast(&r->cv);
@@ -2124,6 +2170,7 @@ static void *up_reader(void *v) {
 }
 static void *bgzf_uploader(void *v) {
     source_t *s = (source_t *)v;
+    (void)SRC_CTX(s);                                               /* this thread works on the part's member device from here on */
     void *up = NULL;
     int ok = stream_get(0, &up) == HPGV_OK;
     const char *us = getenv("HPGV_UPLOAD_SEGMENT_MB");
@@ -2138,6 +2185,7 @@ static void *bgzf_uploader(void *v) {
     int n_th = 0;
     if (ok && pin) {
         int want = default_io_threads() * 3 / 4;
+        if (s->is_part || s->mp) want = want / 2 > 2 ? want / 2 : 2;    /* several parts go up side by side: they share the host's threads */
         want = want < 1 ? 1 : want > UP_READERS_MAX ? UP_READERS_MAX : want;
         for (; n_th < want; n_th++) if (pthread_create(&th[n_th], NULL, up_reader, &r) != 0) break;
     }
@@ -2159,12 +2207,12 @@ static void *bgzf_uploader(void *v) {
             t_wait += now_s() - t0; t0 = now_s();
             if (!ok) break;
             const size_t off = i * (size_t)UP_SEG, len = off + UP_SEG <= (size_t)s->size ? (size_t)UP_SEG : (size_t)s->size - off;
-            ok = hpgv_memcpy_h2d_async(g_ctx, (char *)s->d_comp + off, pin + (i % UP_SLOTS) * (size_t)UP_SEG, len, stq[i % (size_t)depth]) == HPGV_OK;
+            ok = hpgv_memcpy_h2d_async(CTX, (char *)s->d_comp + off, pin + (i % UP_SLOTS) * (size_t)UP_SEG, len, stq[i % (size_t)depth]) == HPGV_OK;
             if (!ok) break;
         }
         if (i + 1 < (size_t)depth) continue;
         const size_t j = i + 1 - (size_t)depth, off = j * (size_t)UP_SEG, len = off + UP_SEG <= (size_t)s->size ? (size_t)UP_SEG : (size_t)s->size - off;
-        ok = hpgv_stream_sync(g_ctx, stq[j % (size_t)depth]) == HPGV_OK;
+        ok = hpgv_stream_sync(CTX, stq[j % (size_t)depth]) == HPGV_OK;
         t_copy += now_s() - t0;
         pthread_mutex_lock(&r.mu);
         r.filled[j % UP_SLOTS] = 0; r.copied = j + 1;
@@ -2179,8 +2227,8 @@ static void *bgzf_uploader(void *v) {
         pthread_mutex_unlock(&s->g_mu);
         if (cancel) { ok = 0; break; }
     }
-    for (int k = 1; k < depth; k++) if (stq[k]) { (void)hpgv_stream_sync(g_ctx, stq[k]); stream_put(0, stq[k]); }
-    if (up) (void)hpgv_stream_sync(g_ctx, up);
+    for (int k = 1; k < depth; k++) if (stq[k]) { (void)hpgv_stream_sync(CTX, stq[k]); stream_put(0, stq[k]); }
+    if (up) (void)hpgv_stream_sync(CTX, up);
     if (getenv("HPGV_RUN_TRACE"))
         fprintf(stderr, "uploader: %.1f MB in %.4f s: %.4f s waiting for the readers (%d), %.4f s in copies\n", s->size / 1e6, now_s() - t_begin, t_wait, n_th, t_copy);
     pthread_mutex_lock(&r.mu); r.stop = 1; pthread_cond_broadcast(&r.cv); pthread_mutex_unlock(&r.mu);
@@ -2207,6 +2255,7 @@ static int wait_uploaded(source_t *s, size_t hi) {
 
 static void *bgzf_gpu_stager(void *v) {
     source_t *s = (source_t *)v;
+    (void)SRC_CTX(s);                                               /* this thread works on the part's member device from here on */
     const size_t nb = s->g_nb;
     char *t = (char *)s->d_tab;
     int ok = 1;
@@ -2239,11 +2288,11 @@ static void *bgzf_gpu_stager(void *v) {
                 if (dbg) fprintf(stderr, "stager: [%zu,%zu) is up, to byte %.1f MB, at %.4f\n", first, next, hi / 1e6, now_s() - T0);
             }
             const int q = (qh + qn) % inflight;
-            ok = ok && hpgv_inflate_blocks_dev(g_ctx, (const uint8_t *)s->d_comp, (const uint64_t *)t + first, (const uint32_t *)(t + nb * 16) + first,
+            ok = ok && hpgv_inflate_blocks_dev(CTX, (const uint8_t *)s->d_comp, (const uint64_t *)t + first, (const uint32_t *)(t + nb * 16) + first,
                                                (const uint64_t *)(t + nb * 8) + first, (const uint32_t *)(t + nb * 20) + first, (int)(next - first),
                                                (uint8_t *)s->d_text, (int32_t *)s->d_status + first, cs[q]) == HPGV_OK;
             if (bgzf_verify_on())                         /* the blocks' CRC-32, on the device behind the decoder */
-                ok = ok && hpgv_bgzf_verify_dev(g_ctx, (const uint8_t *)s->d_comp, (const uint64_t *)t + first, (const uint32_t *)(t + nb * 16) + first,
+                ok = ok && hpgv_bgzf_verify_dev(CTX, (const uint8_t *)s->d_comp, (const uint64_t *)t + first, (const uint32_t *)(t + nb * 16) + first,
                                                 (const uint64_t *)(t + nb * 8) + first, (const uint32_t *)(t + nb * 20) + first, (int)(next - first),
                                                 (const uint8_t *)s->d_text, (int32_t *)s->d_status + first, cs[q]) == HPGV_OK;
             q_hi[q] = next; qn++;
@@ -2258,14 +2307,14 @@ static void *bgzf_gpu_stager(void *v) {
         }
         if (ok && qn > 0) {                              /* the oldest stretch in flight: wait, check, publish */
             const size_t a = s->g_done, n = q_hi[qh] - a;
-            ok = hpgv_memcpy_d2h(g_ctx, st, (char *)s->d_status + a * 4, n * 4, cs[qh]) == HPGV_OK;      /* synchronises that stream */
+            ok = hpgv_memcpy_d2h(CTX, st, (char *)s->d_status + a * 4, n * 4, cs[qh]) == HPGV_OK;      /* synchronises that stream */
             const char *fe = getenv("HPGV_TEST_GPU_INFLATE_REFUSE_EVERY");     /* tests: exercise the host patch path */
             const size_t refuse_every = fe ? (size_t)atol(fe) : 0;
             for (size_t k = 0; ok && k < n; k++)
                 if (st[k] || (refuse_every && (a + k) % refuse_every == 0)) {                             /* not taken by the device decoder: the host decodes it, the text is patched */
                     const size_t bb = a + k;
                     ok = !inflate_block(s->map + s->g_in_off[bb], s->g_in_len[bb], tmp, s->g_out_len[bb])
-                      && hpgv_memcpy_h2d(g_ctx, (char *)s->d_text + s->g_out_off[bb], tmp, s->g_out_len[bb], cs[qh]) == HPGV_OK;
+                      && hpgv_memcpy_h2d(CTX, (char *)s->d_text + s->g_out_off[bb], tmp, s->g_out_len[bb], cs[qh]) == HPGV_OK;
                 }
             if (dbg) fprintf(stderr, "stager: decoded up to %zu at %.4f\n", q_hi[qh], now_s() - T0);
             if (ok) {
@@ -2278,7 +2327,7 @@ static void *bgzf_gpu_stager(void *v) {
             qh = (qh + 1) % inflight; qn--;
         }
     }
-    for (int q = 0; q < GPU_INFLIGHT; q++) if (cs[q]) (void)hpgv_stream_sync(g_ctx, cs[q]);      /* after a failure launches may still be running */
+    for (int q = 0; q < GPU_INFLIGHT; q++) if (cs[q]) (void)hpgv_stream_sync(CTX, cs[q]);      /* after a failure launches may still be running */
     for (int q = 1; q < GPU_INFLIGHT; q++) stream_put(0, cs[q]);
     pthread_mutex_lock(&s->g_mu);
     if (!ok) s->g_err = 1;
@@ -2292,8 +2341,8 @@ static void *bgzf_gpu_stager(void *v) {
     }
     if (dbg) fprintf(stderr, "stager: finished %.4f\n", now_s() - T0);
     /* only the text is needed from here on */
-    if (s->d_comp) { (void)hpgv_dev_free(g_ctx, s->d_comp); s->d_comp = NULL; }
-    if (s->d_status) { (void)hpgv_dev_free(g_ctx, s->d_status); s->d_status = NULL; }
+    if (s->d_comp) { (void)hpgv_dev_free(CTX, s->d_comp); s->d_comp = NULL; }
+    if (s->d_status) { (void)hpgv_dev_free(CTX, s->d_status); s->d_status = NULL; }
     if (dbg) fprintf(stderr, "stager: freed %.4f\n", now_s() - T0);
     return NULL;
 }
@@ -2482,16 +2531,16 @@ static size_t bgzf_host_rows(source_t *s, size_t pos, size_t hi, size_t max_rows
     return n;
 }
 static int scan_slot_rows_to_host(scan_slot_t *q) {
-    return hpgv_memcpy_d2h(g_ctx, q->h_in_off, q->d_in_off, q->n * 8, q->stream) == HPGV_OK
-        && hpgv_memcpy_d2h(g_ctx, q->h_out_off, q->d_out_off, q->n * 8, q->stream) == HPGV_OK
-        && hpgv_memcpy_d2h(g_ctx, q->h_in_len, q->d_in_len, q->n * 4, q->stream) == HPGV_OK
-        && hpgv_memcpy_d2h(g_ctx, q->h_out_len, q->d_out_len, q->n * 4, q->stream) == HPGV_OK;
+    return hpgv_memcpy_d2h(CTX, q->h_in_off, q->d_in_off, q->n * 8, q->stream) == HPGV_OK
+        && hpgv_memcpy_d2h(CTX, q->h_out_off, q->d_out_off, q->n * 8, q->stream) == HPGV_OK
+        && hpgv_memcpy_d2h(CTX, q->h_in_len, q->d_in_len, q->n * 4, q->stream) == HPGV_OK
+        && hpgv_memcpy_d2h(CTX, q->h_out_len, q->d_out_len, q->n * 4, q->stream) == HPGV_OK;
 }
 static int scan_slot_rows_to_device(scan_slot_t *q) {
-    return hpgv_memcpy_h2d(g_ctx, q->d_in_off, q->h_in_off, q->n * 8, q->stream) == HPGV_OK
-        && hpgv_memcpy_h2d(g_ctx, q->d_out_off, q->h_out_off, q->n * 8, q->stream) == HPGV_OK
-        && hpgv_memcpy_h2d(g_ctx, q->d_in_len, q->h_in_len, q->n * 4, q->stream) == HPGV_OK
-        && hpgv_memcpy_h2d(g_ctx, q->d_out_len, q->h_out_len, q->n * 4, q->stream) == HPGV_OK;
+    return hpgv_memcpy_h2d(CTX, q->d_in_off, q->h_in_off, q->n * 8, q->stream) == HPGV_OK
+        && hpgv_memcpy_h2d(CTX, q->d_out_off, q->h_out_off, q->n * 8, q->stream) == HPGV_OK
+        && hpgv_memcpy_h2d(CTX, q->d_in_len, q->h_in_len, q->n * 4, q->stream) == HPGV_OK
+        && hpgv_memcpy_h2d(CTX, q->d_out_len, q->h_out_len, q->n * 4, q->stream) == HPGV_OK;
 }
 /* the next stretch's rows into slot q: up to max_rows blocks from the chain's position among the bytes that are up.
  * 1 = q->n rows (0 rows: the file has ended), 0 = failure, 2 = (only with wait = 0) the bytes for that many blocks are
@@ -2514,7 +2563,7 @@ static int scan_next_rows(source_t *s, scan_state_t *S, scan_slot_t *q, size_t m
         size_t hi = have;
         if (hi - S->chain_pos > SCAN_RANGE_MAX) hi = S->chain_pos + SCAN_RANGE_MAX;
         uint64_t res[4] = { 0, 0, 0, 0 };
-        if (hpgv_bgzf_scan_dev(g_ctx, (const uint8_t *)s->d_comp, S->chain_pos, hi, S->text_pos, (int)max_rows, q->d_in_off, q->d_in_len,
+        if (hpgv_bgzf_scan_dev(CTX, (const uint8_t *)s->d_comp, S->chain_pos, hi, S->text_pos, (int)max_rows, q->d_in_off, q->d_in_len,
                                q->d_out_off, q->d_out_len, S->d_scratch, S->scratch_bytes, res, q->stream) != HPGV_OK) return 0;
         if (res[0] > 0) {
             q->n = (size_t)res[0]; q->text_end = (size_t)res[2];
@@ -2554,6 +2603,7 @@ typedef struct {
 static void *bgzf_publisher(void *v) {
     scan_ring_t *R = (scan_ring_t *)v;
     source_t *s = R->s;
+    (void)SRC_CTX(s);                                               /* this thread works on the part's member device from here on */
     unsigned char *tmp = (unsigned char *)malloc(65536);
     int32_t *st = (int32_t *)malloc(sizeof(int32_t) * SCAN_ROWS_MAX);
     int ok = tmp && st;
@@ -2567,11 +2617,11 @@ static void *bgzf_publisher(void *v) {
         pthread_mutex_unlock(&R->mu);
         if (!have) break;
         scan_slot_t *q = &R->S->slot[k % SCAN_SLOTS];
-        ok = hpgv_memcpy_d2h(g_ctx, st, q->d_status, q->n * 4, q->stream) == HPGV_OK;           /* synchronises that stream */
+        ok = hpgv_memcpy_d2h(CTX, st, q->d_status, q->n * 4, q->stream) == HPGV_OK;           /* synchronises that stream */
         for (size_t i = 0; ok && i < q->n; i++)
             if (st[i] || (refuse_every && (done_blocks + i) % refuse_every == 0)) {             /* not taken by the device decoder: the host decodes it, the text is patched */
                 ok = !inflate_block(s->map + q->h_in_off[i], q->h_in_len[i], tmp, q->h_out_len[i])
-                  && hpgv_memcpy_h2d(g_ctx, (char *)s->d_text + q->h_out_off[i], tmp, q->h_out_len[i], q->stream) == HPGV_OK;
+                  && hpgv_memcpy_h2d(CTX, (char *)s->d_text + q->h_out_off[i], tmp, q->h_out_len[i], q->stream) == HPGV_OK;
             }
         done_blocks += q->n;
         if (R->dbg) fprintf(stderr, "stager: decoded up to block %zu at %.4f\n", done_blocks, now_s() - R->T0);
@@ -2594,6 +2644,7 @@ static void *bgzf_publisher(void *v) {
 }
 static void *bgzf_gpu_stream_stager(void *v) {
     source_t *s = (source_t *)v;
+    (void)SRC_CTX(s);                                               /* this thread works on the part's member device from here on */
     scan_state_t *S = (scan_state_t *)s->blk;                        /* (handed over in the field the host path uses for its block list) */
     s->blk = NULL;
     scan_ring_t R;
@@ -2629,10 +2680,10 @@ static void *bgzf_gpu_stream_stager(void *v) {
         }
         ok = dev_text_grow(s->d_text, q->text_end + 16 + (q->text_end >> 4), &s->d_text_cap)      /* some room ahead: growing waits for the kernels that run */
           || dev_text_grow(s->d_text, q->text_end + 16, &s->d_text_cap);
-        ok = ok && hpgv_inflate_blocks_dev(g_ctx, (const uint8_t *)s->d_comp, q->d_in_off, q->d_in_len, q->d_out_off, q->d_out_len,
+        ok = ok && hpgv_inflate_blocks_dev(CTX, (const uint8_t *)s->d_comp, q->d_in_off, q->d_in_len, q->d_out_off, q->d_out_len,
                                            (int)q->n, (uint8_t *)s->d_text, q->d_status, q->stream) == HPGV_OK;
         if (bgzf_verify_on())                                        /* the blocks' CRC-32, on the device behind the decoder */
-            ok = ok && hpgv_bgzf_verify_dev(g_ctx, (const uint8_t *)s->d_comp, q->d_in_off, q->d_in_len, q->d_out_off, q->d_out_len,
+            ok = ok && hpgv_bgzf_verify_dev(CTX, (const uint8_t *)s->d_comp, q->d_in_off, q->d_in_len, q->d_out_off, q->d_out_len,
                                             (int)q->n, (const uint8_t *)s->d_text, q->d_status, q->stream) == HPGV_OK;
         if (!ok) break;
         if (dbg && k == 0) fprintf(stderr, "stager: first stretch launched at %.4f\n", now_s() - T0);
@@ -2651,7 +2702,7 @@ static void *bgzf_gpu_stream_stager(void *v) {
     if (have_pub) pthread_join(pub, NULL);
     ok = ok && !R.bad;
     pthread_mutex_destroy(&R.mu); pthread_cond_destroy(&R.cv);
-    for (int q = 0; q < SCAN_SLOTS; q++) if (S->slot[q].stream) (void)hpgv_stream_sync(g_ctx, S->slot[q].stream);      /* after a failure launches may still be running */
+    for (int q = 0; q < SCAN_SLOTS; q++) if (S->slot[q].stream) (void)hpgv_stream_sync(CTX, S->slot[q].stream);      /* after a failure launches may still be running */
     pthread_mutex_lock(&s->g_mu);
     if (!ok) s->g_err = 1;
     else { s->dev_len = S->text_pos; s->dev_len_known = 1; s->g_nb = S->blocks; }
@@ -2666,8 +2717,8 @@ static void *bgzf_gpu_stream_stager(void *v) {
     for (int q = 1; q < SCAN_SLOTS; q++) stream_put(s->c_low, S->slot[q].stream);
     for (int q = 0; q < SCAN_SLOTS; q++) free(S->slot[q].h_in_off);
     free(S);
-    if (s->d_comp) { (void)hpgv_dev_free(g_ctx, s->d_comp); s->d_comp = NULL; }      /* only the text is needed from here on */
-    if (s->d_scan) { (void)hpgv_dev_free(g_ctx, s->d_scan); s->d_scan = NULL; }
+    if (s->d_comp) { (void)hpgv_dev_free(CTX, s->d_comp); s->d_comp = NULL; }      /* only the text is needed from here on */
+    if (s->d_scan) { (void)hpgv_dev_free(CTX, s->d_scan); s->d_scan = NULL; }
     return NULL;
 }
 
@@ -2682,7 +2733,7 @@ static int bgzf_stream_stage(source_t *s) {
     int ok = stream_get(0, &s->rstream) == HPGV_OK && stream_get(low, &s->cstream) == HPGV_OK;
     const size_t slot_bytes = (size_t)SCAN_ROWS_MAX * 28;
     S->scratch_bytes = hpgv_bgzf_scan_scratch_bytes(SCAN_RANGE_MAX + 16, SCAN_ROWS_MAX);
-    if (ok) ok = hpgv_dev_alloc(g_ctx, slot_bytes * SCAN_SLOTS + S->scratch_bytes + 256, &s->d_scan) == HPGV_OK;
+    if (ok) ok = hpgv_dev_alloc(CTX, slot_bytes * SCAN_SLOTS + S->scratch_bytes + 256, &s->d_scan) == HPGV_OK;
     for (int k = 0; ok && k < SCAN_SLOTS; k++) {
         scan_slot_t *q = &S->slot[k];
         char *d = (char *)s->d_scan + (size_t)k * slot_bytes;
@@ -2707,7 +2758,7 @@ static int bgzf_stream_stage(source_t *s) {
         est = (size_t)((double)S->text_pos / (double)S->chain_pos * (double)s->size * 1.10) + ((size_t)128 << 20);
         if (S->chain_pos >= (size_t)s->size) est = S->text_pos + 16;
         if (est > ((size_t)48 << 30)) ok = 0;                        /* as with the host's table: such a text stays on the host path, */
-        if (S->chain_pos >= (size_t)s->size && S->blocks < 256) ok = 0;      /* and a small file is as quick there */
+        if (S->chain_pos >= (size_t)s->size && S->blocks < 256 && !s->is_part && !s->mp) ok = 0;      /* and a small file is as quick there */
     }
     const char *tp = getenv("HPGV_TEST_TEXT_ESTIMATE_PERCENT");    /* tests: a text that outgrows what was committed for it */
     if (ok && tp && atoi(tp) > 0 && S->chain_pos < (size_t)s->size) {
@@ -2738,7 +2789,7 @@ static int bgzf_stream_stage(source_t *s) {
         for (int k = 0; k < SCAN_SLOTS; k++) free(S->slot[k].h_in_off);
         free(S);
         if (s->d_text) { dev_text_put(s->d_text, s->d_text_cap, s->d_text_kind); s->d_text = NULL; }
-        if (s->d_scan) { (void)hpgv_dev_free(g_ctx, s->d_scan); s->d_scan = NULL; }
+        if (s->d_scan) { (void)hpgv_dev_free(CTX, s->d_scan); s->d_scan = NULL; }
         stream_put(0, s->rstream); s->rstream = NULL;
         stream_put(low, s->cstream); s->cstream = NULL; s->c_low = 0;
         return 1;
@@ -2747,9 +2798,107 @@ static int bgzf_stream_stage(source_t *s) {
     return 0;
 }
 
+/* ---- a bgzip file on SEVERAL devices (a group context: HPGV_DEVICES, hpgv_host_init_devices; --num-threads / the devices
+ * option of shared_options.c:60-61 has no such notion: the reference reads the file with one thread).  BGZF blocks are
+ * independent, so the file is cut at block starts into one contiguous PART per member: every part goes up ITS device's own
+ * link (the upload is what a run of the device path waits for), is decoded and kept there, and its windows are tokenized and
+ * scanned there.  Each part is staged by the streaming stager exactly as a whole file is (a source_t whose map / size /
+ * file_off describe the part).  The reader walks the parts in file order; a part's text ends inside a line as a rule: the
+ * line's head (the end of part k) and tail (the start of part k + 1) come back to the host, and the joined line goes through
+ * the ordinary host-text entry as a batch of one line between the two parts' windows (read_lines_dev). ---- */
+static int bgzf_stream_stage(source_t *s);
+static void *bgzf_uploader(void *v);
+/* one part (or, when the parts are given up, nothing): 0 = the streaming stager has it */
+static int part_stream_stage(source_t *s) {
+    const ctx_saved_t saved = SRC_CTX(s);
+    int taken = 0;
+    s->gpu_tried = 1;
+    pthread_mutex_init(&s->g_mu, NULL); pthread_cond_init(&s->g_cv, NULL);
+    s->g_sync = 1; s->up_done = 0; s->u_cancel = 0; s->u_err = 0;
+    if (hpgv_dev_alloc(CTX, (size_t)s->size + 16, &s->d_comp) == HPGV_OK) {
+        if (pthread_create(&s->u_thread, NULL, bgzf_uploader, s) == 0) s->u_started = 1;
+        else { (void)hpgv_dev_free(CTX, s->d_comp); s->d_comp = NULL; }
+    }
+    if (s->u_started && bgzf_stream_stage(s) == 0) taken = 1;
+    if (!taken) {                                                    /* nothing is left behind */
+        if (s->u_started) {
+            pthread_mutex_lock(&s->g_mu); s->u_cancel = 1; pthread_mutex_unlock(&s->g_mu);
+            pthread_join(s->u_thread, NULL); s->u_started = 0;
+        }
+        if (s->d_comp) { (void)hpgv_dev_free(CTX, s->d_comp); s->d_comp = NULL; }
+        pthread_mutex_destroy(&s->g_mu); pthread_cond_destroy(&s->g_cv); s->g_sync = 0;
+    }
+    ctx_back(saved);
+    return taken ? 0 : 1;
+}
+/* the first block start at or after `from` from which four blocks chain (a header's magic inside compressed data does not) */
+static size_t bgzf_find_block_start(const source_t *s, size_t from) {
+    const size_t size = (size_t)s->size, lim = from + ((size_t)1 << 20) < size ? from + ((size_t)1 << 20) : size;
+    for (size_t pos = from; pos + 28 <= lim; pos++) {
+        if (s->map[pos] != 31 || s->map[pos + 1] != 139) continue;
+        size_t q = pos;
+        int n = 0;
+        while (n < 4 && q < size) {
+            size_t bs, co, is;
+            if (!bgzf_block(s->map + q, size - q, &bs, &co, &is) || is > 65536) break;
+            q += bs; n++;
+        }
+        if (n == 4 || (n > 0 && q == size)) return pos;
+    }
+    return 0;
+}
+/* 0 = the file is staged in parts (s is part 0); 1 = not taken, s is as it was */
+static int bgzf_parts_stage(source_t *s) {
+    const int G = g_ctx ? hpgv_group_size(g_ctx) : 1;
+    if (G < 2 || getenv("HPGV_BGZF_ONE_DEVICE") || getenv("HPGV_NO_DEVICE_WINDOWS") || getenv("HPGV_BGZF_HOST_TABLE") ||
+        getenv("HPGV_SERIAL_BGZF_WALK") || getenv("HPGV_NO_GROWING_TEXT")) return 1;
+    const char *pm = getenv("HPGV_BGZF_PART_MIN_KB");               /* tests: parts of small files */
+    const size_t part_min = pm && atol(pm) > 0 ? (size_t)atol(pm) << 10 : (size_t)64 << 20;
+    int n = G < MEMBERS_MAX ? G : MEMBERS_MAX;
+    if ((size_t)s->size / part_min < (size_t)n) n = (int)((size_t)s->size / part_min);
+    if (n < 2) return 1;
+    size_t b[MEMBERS_MAX + 1];
+    b[0] = 0; b[n] = (size_t)s->size;
+    for (int k = 1; k < n; k++) {
+        b[k] = bgzf_find_block_start(s, (size_t)s->size / (size_t)n * (size_t)k);
+        if (b[k] == 0 || b[k] <= b[k - 1]) return 1;
+    }
+    src_parts_t *mp = (src_parts_t *)calloc(1, sizeof *mp);
+    if (!mp) return 1;
+    mp->n = n; mp->p[0] = s; mp->whole_size = s->size;
+    const int dbg = getenv("HPGV_RUN_TRACE") != NULL;
+    int ok = 1;
+    for (int k = 1; ok && k < n; k++) {                              /* the later parts first: if one of them is not taken, part 0 is still the whole file */
+        source_t *p = (source_t *)calloc(1, sizeof *p);
+        if (!p) { ok = 0; break; }
+        p->kind = SRC_BGZF; p->fd = dup(s->fd); p->is_part = 1;
+        p->map_base = s->map_base; p->map_len = s->map_len;
+        p->map = s->map + b[k]; p->size = (off_t)(b[k + 1] - b[k]); p->file_off = (off_t)b[k];
+        p->ctx = hpgv_group_member(g_ctx, k); p->member = k;
+        mp->p[k] = p;
+        ok = p->fd >= 0 && p->ctx && part_stream_stage(p) == 0;
+        if (ok) p->map_pos = (size_t)p->size;
+    }
+    if (ok) {
+        s->ctx = hpgv_group_member(g_ctx, 0); s->member = 0; s->mp = mp; s->size = (off_t)b[1];
+        ok = part_stream_stage(s) == 0;
+        if (!ok) { s->ctx = NULL; s->mp = NULL; s->size = mp->whole_size; s->gpu_tried = 0; }
+    }
+    if (!ok) {
+        for (int k = 1; k < n; k++) if (mp->p[k]) { source_close(mp->p[k]); free(mp->p[k]); }
+        free(mp);
+        if (dbg) fprintf(stderr, "stage: the file is not taken in parts\n");
+        return 1;
+    }
+    if (dbg) { fprintf(stderr, "stage: %d parts, one per device, cut at bytes", n); for (int k = 1; k < n; k++) fprintf(stderr, " %zu", b[k]); fprintf(stderr, "\n"); }
+    s->map_pos = (size_t)s->size;                                    /* the CPU path has nothing left to do */
+    return 0;
+}
+
 static int bgzf_gpu_stage(source_t *s) {
     s->gpu_tried = 1;
     if (getenv("HPGV_NO_GPU_INFLATE") || !g_ctx || s->map_pos != 0) return 1;
+    if (!s->is_part && !s->mp && (size_t)s->size >= ((size_t)64 << 10) && bgzf_parts_stage(s) == 0) return 0;
     const int dbg = getenv("HPGV_RUN_TRACE") != NULL; double T0 = now_s();
     size_t nb = 0, cap = 1 << 16, text = 0;
     uint64_t *in_off = NULL, *out_off = NULL;
@@ -2760,10 +2909,10 @@ static int bgzf_gpu_stage(source_t *s) {
      * 4.6 GB file): the decoder needs the table, the bus does not */
     pthread_mutex_init(&s->g_mu, NULL); pthread_cond_init(&s->g_cv, NULL);
     s->g_sync = 1; s->up_done = 0; s->u_cancel = 0; s->u_err = 0;
-    if (hpgv_dev_alloc(g_ctx, (size_t)s->size + 16, &s->d_comp) == HPGV_OK) {
+    if (hpgv_dev_alloc(CTX, (size_t)s->size + 16, &s->d_comp) == HPGV_OK) {
         if (dbg) fprintf(stderr, "stage: room for the compressed file at %.4f\n", now_s() - T0);
         if (pthread_create(&s->u_thread, NULL, bgzf_uploader, s) == 0) s->u_started = 1;
-        else { (void)hpgv_dev_free(g_ctx, s->d_comp); s->d_comp = NULL; }
+        else { (void)hpgv_dev_free(CTX, s->d_comp); s->d_comp = NULL; }
     }
     if (!s->u_started) { pthread_mutex_destroy(&s->g_mu); pthread_cond_destroy(&s->g_cv); s->g_sync = 0; return 1; }
     if (!getenv("HPGV_BGZF_HOST_TABLE") && !getenv("HPGV_SERIAL_BGZF_WALK") && bgzf_stream_stage(s) == 0) return 0;
@@ -2794,16 +2943,16 @@ static int bgzf_gpu_stage(source_t *s) {
     if (dbg) fprintf(stderr, "stage: walk %.4f\n", now_s() - T0);
     if (ok && (nb < 256 || nb > 0x7FFFFFFFu || text > ((size_t)48 << 30))) ok = 0;     /* a small file is as quick on the host */
     if (ok) { s->c_low = 0; ok = stream_get(0, &s->rstream) == HPGV_OK && stream_get(0, &s->cstream) == HPGV_OK; }
-    if (ok) ok = hpgv_dev_alloc(g_ctx, nb * 24 + 64, &s->d_tab) == HPGV_OK;
+    if (ok) ok = hpgv_dev_alloc(CTX, nb * 24 + 64, &s->d_tab) == HPGV_OK;
     if (ok) { s->text_est = text; s->d_text = dev_text_get(text + 16, &s->d_text_cap, &s->d_text_kind); ok = s->d_text != NULL; }
-    if (ok) ok = hpgv_dev_alloc(g_ctx, nb * 4 + 16, &s->d_status) == HPGV_OK;
+    if (ok) ok = hpgv_dev_alloc(CTX, nb * 4 + 16, &s->d_status) == HPGV_OK;
     if (dbg) fprintf(stderr, "stage: alloc %.4f\n", now_s() - T0);
     if (ok) {
         char *t = (char *)s->d_tab;
-        ok = hpgv_memcpy_h2d(g_ctx, t, in_off, nb * 8, s->cstream) == HPGV_OK
-          && hpgv_memcpy_h2d(g_ctx, t + nb * 8, out_off, nb * 8, s->cstream) == HPGV_OK
-          && hpgv_memcpy_h2d(g_ctx, t + nb * 16, in_len, nb * 4, s->cstream) == HPGV_OK
-          && hpgv_memcpy_h2d(g_ctx, t + nb * 20, out_len, nb * 4, s->cstream) == HPGV_OK;
+        ok = hpgv_memcpy_h2d(CTX, t, in_off, nb * 8, s->cstream) == HPGV_OK
+          && hpgv_memcpy_h2d(CTX, t + nb * 8, out_off, nb * 8, s->cstream) == HPGV_OK
+          && hpgv_memcpy_h2d(CTX, t + nb * 16, in_len, nb * 4, s->cstream) == HPGV_OK
+          && hpgv_memcpy_h2d(CTX, t + nb * 20, out_len, nb * 4, s->cstream) == HPGV_OK;
     }
     if (dbg) fprintf(stderr, "stage: tab %.4f\n", now_s() - T0);
     if (ok) {
@@ -2820,9 +2969,9 @@ static int bgzf_gpu_stage(source_t *s) {
         free(in_off); free(out_off); free(in_len); free(out_len);
         s->g_in_off = s->g_out_off = NULL; s->g_in_len = s->g_out_len = NULL;
         if (s->g_sync) { pthread_mutex_destroy(&s->g_mu); pthread_cond_destroy(&s->g_cv); s->g_sync = 0; }
-            if (s->d_comp) { (void)hpgv_dev_free(g_ctx, s->d_comp); s->d_comp = NULL; }
-        if (s->d_tab) { (void)hpgv_dev_free(g_ctx, s->d_tab); s->d_tab = NULL; }
-        if (s->d_status) { (void)hpgv_dev_free(g_ctx, s->d_status); s->d_status = NULL; }
+            if (s->d_comp) { (void)hpgv_dev_free(CTX, s->d_comp); s->d_comp = NULL; }
+        if (s->d_tab) { (void)hpgv_dev_free(CTX, s->d_tab); s->d_tab = NULL; }
+        if (s->d_status) { (void)hpgv_dev_free(CTX, s->d_status); s->d_status = NULL; }
         if (s->d_text) { dev_text_put(s->d_text, s->d_text_cap, s->d_text_kind); s->d_text = NULL; }
         stream_put(0, s->rstream); s->rstream = NULL;
         stream_put(0, s->cstream); s->cstream = NULL;
@@ -2875,7 +3024,7 @@ static size_t source_read(source_t *s, char *buf, size_t cap) {
         if (bad) return (size_t)-1;
         const size_t n = end - s->dev_pos;
         if (n == 0) return 0;
-        if (hpgv_memcpy_d2h(g_ctx, buf, (const char *)s->d_text + s->dev_pos, n, s->rstream) != HPGV_OK) return (size_t)-1;
+        if (hpgv_memcpy_d2h(CTX, buf, (const char *)s->d_text + s->dev_pos, n, s->rstream) != HPGV_OK) return (size_t)-1;
         s->dev_pos += n;
         return n;
     }
@@ -2923,6 +3072,7 @@ typedef struct {
     char *carry; size_t carry_len, carry_cap;
     int eof;
     const char *last_dev;                               /* device copy of the batch read_lines just returned (BGZF on the GPU), or NULL */
+    hpgv_ctx *last_ctx;                                 /* ... and the member context of that device when the file is staged in parts */
     int devwin;                                         /* batches are windows of the device text; nothing but their cut points is read back */
     char *tailbuf; size_t tailcap;
 } line_reader_t;
@@ -2930,11 +3080,15 @@ typedef struct {
 /* bgzip decoded on the device: the next batch is a window of the device text that ends with a line.  Only the stretch
  * around the window's end comes back to the host, to find that line end; the engine fills the batch's host buffer with
  * the line heads (hpgv_text_alias).  Returns the window's bytes (0 at the end, (size_t)-1 on error), its device address
- * in r->last_dev. */
-static size_t read_lines_dev(line_reader_t *r, size_t cap) {
-    source_t *s = &r->src;
+ * in r->last_dev and the context of its device in r->last_ctx.  `last`: the text's end is the file's end (the last line may
+ * lack its newline); otherwise -- a part that another part follows -- every window ends with a newline and what is left
+ * behind the text's last newline stays unread (the seam line's head). */
+static size_t read_window(line_reader_t *r, source_t *s, size_t cap, int last) {
+    const ctx_saved_t saved = SRC_CTX(s);
     const size_t start = s->dev_pos;
+    size_t ret = (size_t)-1;
     r->last_dev = (const char *)s->d_text + start;
+    r->last_ctx = s->ctx;
     pthread_mutex_lock(&s->g_mu);                                    /* until the stager has decoded that far (or knows where the text ends) */
     for (;;) {
         const size_t lim = s->dev_len_known ? s->dev_len : (size_t)-1;
@@ -2946,23 +3100,113 @@ static size_t read_lines_dev(line_reader_t *r, size_t cap) {
     size_t end = limit - start <= cap ? limit : start + cap;
     const int bad = s->g_err || s->dev_ready < end;
     pthread_mutex_unlock(&s->g_mu);
-    if (bad) return (size_t)-1;
-    if (start >= limit) return 0;
-    if (end < limit) {                                               /* cut at the last newline before `end` */
+    if (bad) goto out;
+    if (start >= limit) { ret = 0; goto out; }
+    if (end < limit || !last) {                                      /* cut at the last newline before `end` */
         size_t look = 1u << 18;
         for (;;) {
             if (look > end - start) look = end - start;
             if (r->tailcap < look) { free(r->tailbuf); r->tailbuf = (char *)malloc(look); r->tailcap = r->tailbuf ? look : 0; }
-            if (!r->tailbuf) return (size_t)-1;
-            if (hpgv_memcpy_d2h(g_ctx, r->tailbuf, (const char *)s->d_text + end - look, look, s->rstream) != HPGV_OK) return (size_t)-1;
+            if (!r->tailbuf) goto out;
+            if (hpgv_memcpy_d2h(CTX, r->tailbuf, (const char *)s->d_text + end - look, look, s->rstream) != HPGV_OK) goto out;
             const char *nl = (const char *)memrchr(r->tailbuf, '\n', look);
             if (nl) { end = end - look + (size_t)(nl - r->tailbuf) + 1; break; }
-            if (look == end - start) return (size_t)-1;              /* a line longer than the batch */
+            if (look == end - start) {
+                if (end == limit && !last) { ret = 0; goto out; }    /* the part's rest holds no line end: all of it is the seam line's head */
+                goto out;                                            /* a line longer than the batch */
+            }
             look *= 4;
         }
     }
     s->dev_pos = end;
-    return end - start;
+    ret = end - start;
+out:
+    ctx_back(saved);
+    return ret;
+}
+/* a part's text length, known when its stager has seen its last block; (size_t)-1 on failure */
+static size_t part_text_len(source_t *s) {
+    pthread_mutex_lock(&s->g_mu);
+    while (!s->dev_len_known && !s->g_err && !s->g_finished) pthread_cond_wait(&s->g_cv, &s->g_mu);
+    const size_t n = (s->g_err || !s->dev_len_known) ? (size_t)-1 : s->dev_len;
+    pthread_mutex_unlock(&s->g_mu);
+    return n;
+}
+/* bytes [from, to) of a part's text to the host, once they are decoded */
+static int part_text_fetch(source_t *s, size_t from, size_t to, char *dst) {
+    if (to <= from) return 1;
+    pthread_mutex_lock(&s->g_mu);
+    while (s->dev_ready < to && !s->g_err && !s->g_finished) pthread_cond_wait(&s->g_cv, &s->g_mu);
+    const int ok = !s->g_err && s->dev_ready >= to;
+    pthread_mutex_unlock(&s->g_mu);
+    if (!ok) return 0;
+    const ctx_saved_t saved = SRC_CTX(s);
+    const int rc = hpgv_memcpy_d2h(CTX, dst, (const char *)s->d_text + from, to - from, s->rstream);
+    ctx_back(saved);
+    return rc == HPGV_OK;
+}
+static int seam_room(src_parts_t *mp, size_t more) {
+    if (mp->seam_len + more <= mp->seam_cap) return 1;
+    const size_t cap = (mp->seam_len + more) * 2 + 4096;
+    char *q = (char *)realloc(mp->seam, cap);
+    if (!q) return 0;
+    mp->seam = q; mp->seam_cap = cap;
+    return 1;
+}
+/* the next batch of a file on the device: a window of its text (r->last_dev set: the engine tokenizes it in place and writes
+ * the lines' heads into the batch's host buffer), or -- a file staged in parts -- the line that straddles two parts, copied
+ * into buf as ordinary host text (r->last_dev NULL). */
+static size_t read_lines_dev(line_reader_t *r, char *buf, size_t bufcap, size_t cap) {
+    src_parts_t *mp = r->src.mp;
+    if (!mp) return read_window(r, &r->src, cap, 1);
+    for (;;) {
+        if (mp->seam_len) {                                          /* the seam line in front of part `cur` */
+            if (mp->seam_len > bufcap) return (size_t)-1;
+            memcpy(buf, mp->seam, mp->seam_len);
+            const size_t n = mp->seam_len;
+            mp->seam_len = 0;
+            r->last_dev = NULL; r->last_ctx = NULL;
+            return n;
+        }
+        source_t *s = mp->p[mp->cur];
+        const int last = mp->cur == mp->n - 1;
+        const size_t n = read_window(r, s, cap, last);
+        if (n != 0 || last) return n;
+        /* part `cur` is through: what lies behind its last newline is the head of a line that goes on in the next part(s) */
+        const size_t len = part_text_len(s);
+        if (len == (size_t)-1) return (size_t)-1;
+        const size_t head = len - s->dev_pos;
+        if (!seam_room(mp, head) || !part_text_fetch(s, s->dev_pos, len, mp->seam)) return (size_t)-1;
+        mp->seam_len = head;
+        s->dev_pos = len;
+        while (++mp->cur < mp->n) {
+            source_t *t = mp->p[mp->cur];
+            if (head == 0 && mp->seam_len == 0) break;               /* the part ended with a newline: the next one starts a line */
+            /* the tail: the next part's text up to its first newline, looked for in growing stretches */
+            size_t have = 0, look = 1u << 16, nl_at = (size_t)-1;
+            for (;;) {
+                size_t tlen = (size_t)-1;
+                pthread_mutex_lock(&t->g_mu);
+                while (t->dev_ready < have + look && !t->dev_len_known && !t->g_err && !t->g_finished) pthread_cond_wait(&t->g_cv, &t->g_mu);
+                if (t->dev_len_known) tlen = t->dev_len;
+                const int bad = t->g_err || (!t->dev_len_known && t->dev_ready < have + look);
+                pthread_mutex_unlock(&t->g_mu);
+                if (bad) return (size_t)-1;
+                size_t to = have + look;
+                if (tlen != (size_t)-1 && to > tlen) to = tlen;
+                if (!seam_room(mp, to - have) || !part_text_fetch(t, have, to, mp->seam + mp->seam_len)) return (size_t)-1;
+                const char *nl = (const char *)memchr(mp->seam + mp->seam_len, '\n', to - have);
+                if (nl) { nl_at = have + (size_t)(nl - (mp->seam + mp->seam_len)); mp->seam_len += nl_at - have + 1; break; }
+                mp->seam_len += to - have;
+                have = to;
+                if (tlen != (size_t)-1 && have >= tlen) break;       /* the whole part is one piece of this line: on to the next part */
+                look *= 4;
+            }
+            if (nl_at != (size_t)-1) { t->dev_pos = nl_at + 1; break; }
+            t->dev_pos = have;
+        }
+        if (mp->cur >= mp->n) mp->cur = mp->n - 1;                   /* the line ran to the file's end: hand it out, then the last part reports the end */
+    }
 }
 
 /* fills buf (capacity cap) with whole lines; returns the byte count, 0 at the end, (size_t)-1 when a
@@ -3068,6 +3312,7 @@ static int vcf_header_read(line_reader_t *rd, char **hdr_out, char ***names_out,
 typedef struct {
     char *text; size_t text_cap;                         /* page-locked, taken from the cache when the batch is first filled */
     const char *dev_text;                                /* the same bytes on the device (BGZF decoded there), or NULL */
+    hpgv_ctx *dev_ctx;                                   /* the member context of that device (a file staged in parts), or NULL */
     size_t bytes; int max_lines, n_lines;
     uint64_t *line_off; uint32_t *field_off; int32_t *status;
     int32_t *ints; double *dbl;                          /* 4 (assoc) or 2 (tdt) int arrays, 3 double arrays */
@@ -3587,8 +3832,8 @@ static void *pipe_reader(void *v) {
         pthread_mutex_unlock(&P->mu);
         const double t0 = now_s();
         if (!P->bt[k].text) P->bt[k].text = text_buf_get(P->bt[k].text_cap);
-        const size_t n = !P->bt[k].text ? (size_t)-1 : P->rd->devwin ? read_lines_dev(P->rd, P->batch_bytes) : read_lines(P->rd, P->bt[k].text, P->batch_bytes);
-        P->bt[k].dev_text = P->rd->last_dev;
+        const size_t n = !P->bt[k].text ? (size_t)-1 : P->rd->devwin ? read_lines_dev(P->rd, P->bt[k].text, P->bt[k].text_cap, P->batch_bytes) : read_lines(P->rd, P->bt[k].text, P->batch_bytes);
+        P->bt[k].dev_text = P->rd->last_dev; P->bt[k].dev_ctx = P->rd->devwin ? P->rd->last_ctx : NULL;
         const double dt = now_s() - t0;
         pthread_mutex_lock(&P->mu);
         P->t_read += dt;
@@ -3617,7 +3862,7 @@ static void *pipe_engine(void *v) {
         const double t0 = now_s();
         run_batch_t *b = &P->bt[k];
         int rc = HPGV_OK;
-        if (b->dev_text) (void)hpgv_text_alias(g_ctx, b->text, b->dev_text);       /* tokenize the device copy in place: no H2D of the text */
+        if (b->dev_text) (void)hpgv_text_alias(b->dev_ctx ? b->dev_ctx : g_ctx, b->text, b->dev_text);       /* tokenize the device copy in place (on the device that holds it): no H2D of the text */
         /* max_lines is sized for complete records; a batch of short (damaged) lines can hold more: the
          * engine reports the true count, the arrays grow and the batch is done again */
         for (int attempt = 0; attempt < 2; attempt++) {
@@ -3645,7 +3890,7 @@ static void *pipe_engine(void *v) {
             free(b->mtab); b->mtab = NULL;
             if (run_batch_reserve(b, b->n_lines)) { rc = HPGV_ERR_NOMEM; break; }
         }
-        if (b->dev_text) (void)hpgv_text_alias(g_ctx, b->text, NULL);
+        if (b->dev_text) (void)hpgv_text_alias(b->dev_ctx ? b->dev_ctx : g_ctx, b->text, NULL);
         const double dt = now_s() - t0;
         pthread_mutex_lock(&P->mu);
         P->t_engine += dt;
@@ -3964,7 +4209,7 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
         P->n_engines = 2 * (devs < 1 ? 1 : devs);
         /* windows of a text decoded on member 0's device stay there; a batch is then a chain of short kernels and two
          * small copies back, which four in flight overlap better than two (8 GB of text: 0.111 -> 0.100 s) */
-        if (rd.src.d_text && !getenv("HPGV_NO_DEVICE_WINDOWS")) P->n_engines = 4;
+        if (rd.src.d_text && !getenv("HPGV_NO_DEVICE_WINDOWS")) P->n_engines = rd.src.mp && 2 * rd.src.mp->n > 4 ? 2 * rd.src.mp->n : 4;
         const char *et = getenv("HPGV_ENGINE_THREADS");              /* diagnosis: engine threads (batches in flight on the devices) */
         if (et && atoi(et) > 0) P->n_engines = atoi(et);
         if (P->n_engines > RUN_ENGINES_MAX) P->n_engines = RUN_ENGINES_MAX;

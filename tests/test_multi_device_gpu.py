@@ -115,3 +115,41 @@ def test_bad_device_list_is_refused(tmp_path):
     env = dict(os.environ, HPGV_DEVICES="0,banana")
     r = subprocess.run([sys.executable, str(script), "x.vcf", "x.ped", str(tmp_path / "o")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "HPGV_DEVICES" in r.stderr
+
+
+@pytest.mark.parametrize("devs,block", [("0,0", 0x700), ("0,0,0", 0x700), ("0,0,0,0", 0x3000), ("0,0", 0xff00)])
+def test_bgzip_file_staged_in_parts_one_per_device_is_byte_identical(tmp_path, devs, block):
+    """the bgzip DEVICE path on every device of the group.  The file is cut at block starts into one part
+    per member; every part is uploaded to, decoded on and tokenized on its own device; the line that straddles two parts is
+    joined on the host and goes through as a batch of its own.  HPGV_DEVICES=0,0 / 0,0,0 / 0,0,0,0 on the one GPU of the box:
+    same files as one device, byte for byte (assoc, tdt and the stats tool's files), and the trace says the parts were used."""
+    from test_file_runner_gpu import _vcf_from_batch
+    from test_host_logic_cpu import _bgzf
+    from test_host_mirror_gpu import _write_inputs
+    rng = np.random.default_rng(len(devs) + block)
+    people, names, rows = _write_inputs(tmp_path, rng, 60, 30, 6000)
+    vcf = _vcf_from_batch(tmp_path, names, rows)
+    packed = str(tmp_path / "in.vcf.gz")
+    data = open(vcf, "rb").read()
+    open(packed, "wb").write(_bgzf(data, block))
+    ped = str(tmp_path / "ped.txt")
+    script = tmp_path / "run.py"
+    script.write_text(_RUNNER % {"root": ROOT})
+    exts = (".chisq", ".fisher", ".tdt", ".stats-variants", ".stats-samples", ".stats-summary")
+    outs = {}
+    for tag, d in (("one", None), ("parts", devs)):
+        env = {k: v for k, v in os.environ.items() if k not in ("HPGV_DEVICES",)}
+        env["HPGV_RUN_TRACE"] = "1"
+        env["HPGV_BGZF_PART_MIN_KB"] = "64"
+        if d:
+            env["HPGV_DEVICES"] = d
+        r = subprocess.run([sys.executable, str(script), packed, ped, str(tmp_path / tag)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        n_dev, n_rec = r.stdout.split()
+        assert int(n_rec) == len(rows)
+        n_parts = min(len(d.split(",")), os.path.getsize(packed) // (64 << 10)) if d else 0
+        assert ("stage: %d parts, one per device" % n_parts in r.stderr) == bool(d and n_parts >= 2), r.stderr[-3000:]
+        outs[tag] = [open(str(tmp_path / tag) + ext, "rb").read() for ext in exts]
+    for k in range(len(exts)):
+        assert outs["one"][k] == outs["parts"][k], exts[k]
+    assert all(len(x) > 100 for x in outs["one"])
