@@ -1835,11 +1835,16 @@ static int text_front(hpgv_ctx *ctx, Slot *s, int which, const Layout &L, const 
     if (aliased) {
         // the text is on the device only: the caller's host buffer gets the line heads (CHROM .. FORMAT, all it reads for its
         // result records) and line_off refers to them
-        if ((rc = ensure(ctx, s, 0, text_bytes + ((size_t)nl + 2) * sizeof(uint64_t) + 64))) return rc;
-        unsigned long long *d_head_off = (unsigned long long *)s->buf[0];
-        char *d_heads = (char *)s->buf[0] + (((size_t)nl + 2) * sizeof(uint64_t) + 15) / 16 * 16;
-        hipLaunchKernelGGL(hpgv::k_head_offsets, dim3(1), dim3(1024), 0, s->stream, (const unsigned long long *)(meta + off_lines),
-                           (const uint32_t *)(meta + off_fields), nl, d_head_off);
+        const int hb = (nl + 1023) / 1024;                          // workgroups of 1024 lines
+        const size_t off_heads = (((size_t)nl + 2 + (size_t)hb + 1) * sizeof(uint64_t) + 15) / 16 * 16;
+        if ((rc = ensure(ctx, s, 0, text_bytes + off_heads + 64))) return rc;
+        unsigned long long *d_head_off = (unsigned long long *)s->buf[0], *d_block = d_head_off + (size_t)nl + 2;
+        char *d_heads = (char *)s->buf[0] + off_heads;
+        hipLaunchKernelGGL(hpgv::k_head_sums, dim3((unsigned)hb), dim3(1024), 0, s->stream, (const unsigned long long *)(meta + off_lines),
+                           (const uint32_t *)(meta + off_fields), nl, d_block);
+        hipLaunchKernelGGL(hpgv::k_head_bases, dim3(1), dim3(1024), 0, s->stream, d_block, hb);
+        hipLaunchKernelGGL(hpgv::k_head_offsets, dim3((unsigned)hb), dim3(1024), 0, s->stream, (const unsigned long long *)(meta + off_lines),
+                           (const uint32_t *)(meta + off_fields), nl, (const unsigned long long *)d_block, d_head_off);
         hipLaunchKernelGGL(hpgv::k_copy_heads, dim3((unsigned)nl), dim3(64), 0, s->stream, d_src, (const unsigned long long *)(meta + off_lines),
                            (const unsigned long long *)d_head_off, nl, d_heads);
         HIPCHK(ctx, hipGetLastError());

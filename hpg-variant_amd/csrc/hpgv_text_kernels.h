@@ -274,31 +274,56 @@ static __global__ __launch_bounds__(256) void k_tok_parse(const char *__restrict
 // every line for its result records.  head_off[i] = exclusive prefix sum of the head lengths (a head = the line up to
 // the first sample column, or the whole line when it has fewer than ten fields), head_off[n] = total; then the bytes.
 // ---------------------------------------------------------------------------
-static __global__ __launch_bounds__(1024) void k_head_offsets(const unsigned long long *__restrict__ line_off, const uint32_t *__restrict__ field_off,
-                                                       int n_lines, unsigned long long *__restrict__ head_off) {
-    __shared__ unsigned long long part[1024];
-    const int t = threadIdx.x;
-    const int per = (n_lines + 1023) / 1024, lo = t * per, hi = lo + per < n_lines ? lo + per : n_lines;
-    unsigned long long sum = 0;
-    for (int i = lo; i < hi; i++) {
-        const uint32_t f9 = field_off[(size_t)i * 10 + 9];
-        sum += f9 != 0xFFFFFFFFu ? (unsigned long long)f9 : line_off[i + 1] - line_off[i];
-    }
-    part[t] = sum;
+// Three launches over all the lines (one workgroup walking them took 3.2 ms for 800 000 lines, a tenth of such a call):
+// k_head_sums: every workgroup of 1024 lines sums its head lengths; k_head_bases: one workgroup scans those sums (a thousand
+// of them per million lines); k_head_offsets: every workgroup scans its 1024 lengths from its base.
+__device__ __forceinline__ unsigned long long head_len(const unsigned long long *__restrict__ line_off, const uint32_t *__restrict__ field_off, int i) {
+    const uint32_t f9 = field_off[(size_t)i * 10 + 9];
+    return f9 != 0xFFFFFFFFu ? (unsigned long long)f9 : line_off[i + 1] - line_off[i];
+}
+// inclusive scan of one value per thread over a workgroup of 1024 (wave scans by shuffles, the 16 wave totals through LDS)
+__device__ __forceinline__ unsigned long long head_block_scan(unsigned long long v, unsigned long long *s_w /* [16] */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) { const unsigned long long o = __shfl_up(v, off); if (lane >= off) v += o; }
+    if (lane == 63) s_w[w] = v;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {                            // inclusive scan of the 1024 partial sums (one thread walking them took 12 us)
-        const unsigned long long v = t >= d ? part[t - d] : 0ull;
+    unsigned long long before = 0;
+    for (int k = 0; k < w; ++k) before += s_w[k];
+    __syncthreads();
+    return v + before;
+}
+static __global__ __launch_bounds__(1024) void k_head_sums(const unsigned long long *__restrict__ line_off, const uint32_t *__restrict__ field_off,
+                                                    int n_lines, unsigned long long *__restrict__ block_sum) {
+    __shared__ unsigned long long s_w[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const unsigned long long inc = head_block_scan(i < n_lines ? head_len(line_off, field_off, i) : 0ull, s_w);
+    if (threadIdx.x == 1023) block_sum[blockIdx.x] = inc;
+}
+static __global__ __launch_bounds__(1024) void k_head_bases(unsigned long long *__restrict__ block_sum, int n_blocks) {
+    __shared__ unsigned long long s_w[16];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < n_blocks; b0 += 1024) {                   // exclusive, in place, 1024 block sums per turn
+        const int b = b0 + threadIdx.x;
+        const unsigned long long v = b < n_blocks ? block_sum[b] : 0ull;
+        const unsigned long long inc = head_block_scan(v, s_w);
+        const unsigned long long base = carry;
+        if (b < n_blocks) block_sum[b] = base + inc - v;
         __syncthreads();
-        part[t] += v;
+        if (threadIdx.x == 1023) carry = base + inc;
         __syncthreads();
     }
-    if (t == 1023) head_off[n_lines] = part[1023];
-    unsigned long long acc = part[t] - sum;
-    for (int i = lo; i < hi; i++) {
-        head_off[i] = acc;
-        const uint32_t f9 = field_off[(size_t)i * 10 + 9];
-        acc += f9 != 0xFFFFFFFFu ? (unsigned long long)f9 : line_off[i + 1] - line_off[i];
-    }
+}
+static __global__ __launch_bounds__(1024) void k_head_offsets(const unsigned long long *__restrict__ line_off, const uint32_t *__restrict__ field_off,
+                                                       int n_lines, const unsigned long long *__restrict__ block_base,
+                                                       unsigned long long *__restrict__ head_off) {
+    __shared__ unsigned long long s_w[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const unsigned long long len = i < n_lines ? head_len(line_off, field_off, i) : 0ull;
+    const unsigned long long inc = head_block_scan(len, s_w) + block_base[blockIdx.x];
+    if (i < n_lines) head_off[i] = inc - len;
+    if (i == n_lines - 1) head_off[n_lines] = inc;
 }
 static __global__ __launch_bounds__(64) void k_copy_heads(const char *__restrict__ text, const unsigned long long *__restrict__ line_off,
                                                    const unsigned long long *__restrict__ head_off, int n_lines, char *__restrict__ heads) {
