@@ -83,6 +83,9 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1; gloo is a rehearsal mode (blocks are staged through host "
                          "memory and several ranks may share one GPU), never a measurement")
+    ap.add_argument("--fisher-pieces", type=int, default=1,
+                    help="Fisher workload, experiment: pieces of a tile whose Fisher pass runs on a second stream beside the next piece's scan "
+                         "(measured: no gain, profiles/experiments_that_did_not_pay.md; 1 = one after the other)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-process", action="store_true",
                     help="ONE process drives all N GPUs through the C ABI's group context (hpgv_create_multi + hpgv_group_*: "
@@ -324,13 +327,29 @@ def measure(args, wl, steps, warmup, cpu_seconds, main, world, rank, dev, dev_in
         recv = [[[torch.empty(max(max(tile_sizes(ti)), 1), dtype=torch.uint8, device=comm_dev) for _ in range(world)]
                  for ti in range(n_tiles)] for _ in range(gens)]
     pending = []                                        # gather works of the previous step
+    side = torch.cuda.Stream(device=dev) if kind == "fisher" else None
+    side_ev = [torch.cuda.Event() for _ in range(2)] if kind == "fisher" else None
+    side_done = torch.cuda.Event() if kind == "fisher" else None
 
     def run_tile(ti, g, buf, ev=None):
         lo, hi = tiles[ti]
         n = hi - lo
         blk = blocks[g][ti]
         b = blk.data_ptr()
-        if n > 0:
+        if n > 0 and kind == "fisher" and ev is None and args.fisher_pieces > 1:
+            # the scan is bound by HBM, the Fisher pass by arithmetic: the tile goes through in pieces, piece p's Fisher pass on a
+            # second stream beside piece p + 1's scan.  Launches that carry events (every n-th) run one after the other, so that
+            # the kernels' own durations are measured alone.
+            P = min(args.fisher_pieces, n)
+            for pi in range(P):
+                a, z = n * pi // P, n * (pi + 1) // P
+                eng.assoc_scan(buf.data_ptr() + a * pitch, z - a, b + 16 * a, None, sp)
+                side_ev[pi % 2].record(stream)
+                side.wait_event(side_ev[pi % 2])
+                eng.assoc_fisher(b + 16 * a, z - a, b + 16 * n + 8 * a, b + 24 * n + 8 * a, side.cuda_stream)
+            side_done.record(side)
+            stream.wait_event(side_done)
+        elif n > 0:
             if ev:
                 ev[0].record(stream)
             if kind == "tdt":
@@ -542,7 +561,10 @@ def measure(args, wl, steps, warmup, cpu_seconds, main, world, rank, dev, dev_in
                                "frac": (ginst / VALU64_PEAK_GINST) if ginst else None, "traffic": fprof.get("hbm_bytes_per_launch"),
                                "kernel": "k_assoc_fisher", "kernel_ms": stats_ms, "kernel_samples": len(evs),
                                "valu_insts_per_variant": ipv, "variants_per_launch": scan_variants,
-                               "peak_note": "wave64 FP64 / 64-bit vector instructions: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles"}
+                               "peak_note": "wave64 FP64 / 64-bit vector instructions: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles",
+                               "overlap_note": ("value: the tile goes through in %d pieces, a piece's Fisher pass on a second stream beside the next "
+                                                "piece's scan; kernel_ms: the launches that carry events (every %d-th of the timed region) run the two "
+                                                "kernels one after the other, alone" % (args.fisher_pieces, every)) if args.fisher_pieces > 1 else None}
             out["roofline_scan"] = roof
         else:
             out["roofline"] = roof

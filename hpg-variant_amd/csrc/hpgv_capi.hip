@@ -1046,14 +1046,16 @@ int hpgv_assoc_fisher_dev(hpgv_ctx *ctx, const int32_t *d_counts, int n_variants
         // fisher_width lanes per variant: 64 / width variants per wave, 4 waves per workgroup
         const long per_block = 4 * (64 / ctx->fisher_width);
         const unsigned blocks = (unsigned)(((long)n_variants + per_block - 1) / per_block);
+        const char *fl = getenv("HPGV_FISHER_LDS");                 // experiment: unused LDS per workgroup caps the pass's waves per unit (room for a scan beside it)
+        const unsigned pad = fl ? (unsigned)atoi(fl) : 0u;
         if (ctx->fisher_width == 64)
-            hipLaunchKernelGGL(hpgv::k_assoc_fisher<64>, dim3(blocks), dim3(256), 0, st, (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, cut);
+            hipLaunchKernelGGL(hpgv::k_assoc_fisher<64>, dim3(blocks), dim3(256), pad, st, (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, cut);
         else if (ctx->fisher_width == 8)
-            hipLaunchKernelGGL(hpgv::k_assoc_fisher<8>, dim3(blocks), dim3(256), 0, st, (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, cut);
+            hipLaunchKernelGGL(hpgv::k_assoc_fisher<8>, dim3(blocks), dim3(256), pad, st, (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, cut);
         else if (ctx->fisher_width == 16)
-            hipLaunchKernelGGL(hpgv::k_assoc_fisher<16>, dim3(blocks), dim3(256), 0, st, (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, cut);
+            hipLaunchKernelGGL(hpgv::k_assoc_fisher<16>, dim3(blocks), dim3(256), pad, st, (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, cut);
         else
-            hipLaunchKernelGGL(hpgv::k_assoc_fisher<32>, dim3(blocks), dim3(256), 0, st, (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, cut);
+            hipLaunchKernelGGL(hpgv::k_assoc_fisher<32>, dim3(blocks), dim3(256), pad, st, (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, cut);
     });
 }
 
