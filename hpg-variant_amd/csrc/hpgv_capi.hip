@@ -295,7 +295,7 @@ void hpgv_destroy(hpgv_ctx *ctx) {
     for (Layout *L : {&ctx->assoc, &ctx->tdt, &ctx->stats, &ctx->sgroups, &ctx->mendel})
         if (L->d_col_of_pos) (void)hipFree(L->d_col_of_pos);
     ctx->tdt_plan.release();
-    if (ctx->d_lf) (void)hipFree(ctx->d_lf);
+    if (ctx->d_lf_base) (void)hipFree(ctx->d_lf_base);
     if (ctx->d_thr) (void)hipFree(ctx->d_thr);
     if (ctx->d_sink) (void)hipFree(ctx->d_sink);
     if (ctx->d_crc_tab) (void)hipFree(ctx->d_crc_tab);
@@ -431,8 +431,12 @@ int hpgv_set_logfact(hpgv_ctx *ctx, const double *table, size_t n) {
     DeviceGuard g(ctx->device);
     ctx->n_lf = 0;
     if (ctx->cap_lf < n) {
-        if (ctx->d_lf) { (void)hipFree(ctx->d_lf); ctx->d_lf = nullptr; ctx->cap_lf = 0; }
-        HIPCHK(ctx, hipMalloc(&ctx->d_lf, n * sizeof(double)));
+        // two doubles of padding in front and behind: the Fisher pass reads the table two entries per load, and the neighbour
+        // of a term at the edge of its support may be entry -1 or n (read, never used)
+        if (ctx->d_lf_base) { (void)hipFree(ctx->d_lf_base); ctx->d_lf_base = nullptr; ctx->d_lf = nullptr; ctx->cap_lf = 0; }
+        HIPCHK(ctx, hipMalloc(&ctx->d_lf_base, (n + 4) * sizeof(double)));
+        HIPCHK(ctx, hipMemset(ctx->d_lf_base, 0, (n + 4) * sizeof(double)));
+        ctx->d_lf = ctx->d_lf_base + 2;
         ctx->cap_lf = n;
     }
     HIPCHK(ctx, hipMemcpy(ctx->d_lf, table, n * sizeof(double), hipMemcpyHostToDevice));

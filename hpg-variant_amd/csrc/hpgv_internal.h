@@ -126,6 +126,7 @@ struct hpgv_ctx {
     uint8_t *d_mendel_male = nullptr;
     // fisher
     double *d_lf = nullptr;
+    double *d_lf_base = nullptr;       // the allocation: d_lf - 2 (padding for the two-entries-per-load reads of the Fisher pass)
     size_t n_lf = 0;
     size_t cap_lf = 0;                 // doubles behind d_lf (kept across tables: hipFree waits for the whole device)
     // synth scratch

@@ -364,6 +364,23 @@ struct FisherTab {
         return konst - at(x8) - at(((uint32_t)r1 << 3) - x8) - at(((uint32_t)c1 << 3) - x8) - at(((uint32_t)d0 << 3) + x8);
     }
     __device__ __forceinline__ double p(int x) const { return fisher_exp(e(x), xt); }
+    // e(x) and e(x + 1) from FOUR 16-byte loads instead of eight 8-byte ones: the pass is bound by its vector memory
+    // instructions (48 gathers of 64 x 8 bytes per variant, profiles/r03_pmc_fisher.json), and neighbouring terms read
+    // neighbouring table entries -- lf[x], lf[x + 1]; lf[r1 - x - 1], lf[r1 - x]; lf[c1 - x - 1], lf[c1 - x]; lf[d0 + x],
+    // lf[d0 + x + 1] (the table is 8-byte aligned: dwordx4 loads need no more).  Same subtractions in the same order as e().
+    // At the edge of the support one of the two neighbours may be entry -1 or one past the table: the allocation is padded.
+    __device__ __forceinline__ void e2(int x, double *e0, double *e1) const {
+        // (offsets are UNSIGNED 32-bit off a scalar base, so they are taken from entry -2, the start of the padding: entry -1 is
+        // offset 8, not 2^32 - 8)
+        const char *b = reinterpret_cast<const char *>(lf) - 16;
+        double2 q0, q1, q2, q3;
+        __builtin_memcpy(&q0, b + ((uint32_t)(x + 2) << 3), 16);
+        __builtin_memcpy(&q1, b + ((uint32_t)(r1 - x + 1) << 3), 16);
+        __builtin_memcpy(&q2, b + ((uint32_t)(c1 - x + 1) << 3), 16);
+        __builtin_memcpy(&q3, b + ((uint32_t)(d0 + x + 2) << 3), 16);
+        *e0 = konst - q0.x - q1.y - q2.y - q3.x;
+        *e1 = konst - q0.y - q1.x - q2.x - q3.y;
+    }
 };
 
 // ---- sub-waves: W = 64, 32 or 16 consecutive lanes work on one variant (a wave holds 64 / W variants).  Everything the
@@ -422,22 +439,24 @@ __device__ __forceinline__ void fisher_boundaries(const FisherTab &T, double thr
 // dropped are further out and decay faster than geometrically).
 template <int W>
 __device__ __forceinline__ double fisher_tails(const FisherTab &T, int xL, int xR, int lo, int hi, int lane, double rel_cut) {
+    // two neighbouring tables per lane and side and turn (FisherTab::e2): 2 W tables per side and turn
     const int sl = sub_lane<W>(lane);
     double partL = 0.0, partR = 0.0, cutL = 0.0, cutR = 0.0;
     bool onL = true, onR = true;
     for (int k = 0; onL || onR; ++k) {                              // uniform within the sub-wave
-        const int firstL = xL - 1 - W * k, firstR = xR + W * k;
+        const int firstL = xL - 1 - 2 * W * k, firstR = xR + 2 * W * k;
         if (firstL < lo) onL = false;
         if (firstR > hi) onR = false;
-        const int a = firstL - sl, b = firstR + sl;
-        const double eL = (onL && a >= lo) ? T.e(a) : -2000.0;      // all the table reads first
-        const double eR = (onR && b <= hi) ? T.e(b) : -2000.0;
-        const double sL = fisher_exp(eL, T.xt), sR = fisher_exp(eR, T.xt);       // exp(-2000) = 0
-        partL += sL; partR += sR;
+        const int a = firstL - 2 * sl, b = firstR + 2 * sl;         // this lane's tables: a, a - 1 on the left; b, b + 1 on the right
+        double eL0 = -2000.0, eL1 = -2000.0, eR0 = -2000.0, eR1 = -2000.0;
+        if (onL && a >= lo) { double lo_e, hi_e; T.e2(a - 1, &lo_e, &hi_e); eL0 = hi_e; if (a - 1 >= lo) eL1 = lo_e; }      // all the table reads first
+        if (onR && b <= hi) { double lo_e, hi_e; T.e2(b, &lo_e, &hi_e); eR0 = lo_e; if (b + 1 <= hi) eR1 = hi_e; }
+        const double sL0 = fisher_exp(eL0, T.xt), sL1 = fisher_exp(eL1, T.xt), sR0 = fisher_exp(eR0, T.xt), sR1 = fisher_exp(eR1, T.xt);   // exp(-2000) = 0
+        partL += sL0 + sL1; partR += sR0 + sR1;
         // the reference value of a tail: its first table (lane 0 of the first turn), the largest of the tail
-        if (k == 0) { cutL = rel_cut * sub_first_f64<W>(sL, lane); cutR = rel_cut * sub_first_f64<W>(sR, lane); }
-        if (onL && sub_ballot<W>(sL > cutL, lane) == 0ull) onL = false;
-        if (onR && sub_ballot<W>(sR > cutR, lane) == 0ull) onR = false;
+        if (k == 0) { cutL = rel_cut * sub_first_f64<W>(sL0, lane); cutR = rel_cut * sub_first_f64<W>(sR0, lane); }
+        if (onL && sub_ballot<W>(sL0 > cutL || sL1 > cutL, lane) == 0ull) onL = false;
+        if (onR && sub_ballot<W>(sR0 > cutR || sR1 > cutR, lane) == 0ull) onR = false;
     }
     return sub_sum_f64<W>(partL + partR);
 }
