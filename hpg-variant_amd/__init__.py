@@ -31,7 +31,7 @@ SYMBOLS = [
     "hpgv_set_stats_groups", "hpgv_stats_groups_layout", "hpgv_stats_scan_group_dev",
     "hpgv_set_pedigree", "hpgv_mendel_layout", "hpgv_mendel_scan_dev", "hpgv_mendel_children_dev",
     "hpgv_dev_alloc", "hpgv_dev_free", "hpgv_memcpy_h2d", "hpgv_memcpy_d2h", "hpgv_stream_sync",
-    "hpgv_device_numa_node", "hpgv_memcpy_h2d_async", "hpgv_inflate_blocks_dev", "hpgv_bgzf_verify_dev", "hpgv_bgzf_scan_dev", "hpgv_bgzf_scan_scratch_bytes", "hpgv_dev_reserve", "hpgv_dev_commit", "hpgv_dev_release", "hpgv_text_alias", "hpgv_stream_create", "hpgv_stream_create_low", "hpgv_stream_destroy", "hpgv_host_alloc", "hpgv_host_free",
+    "hpgv_device_numa_node", "hpgv_memcpy_h2d_async", "hpgv_inflate_blocks_dev", "hpgv_bgzf_verify_dev", "hpgv_bgzf_scan_dev", "hpgv_bgzf_scan_scratch_bytes", "hpgv_dev_reserve", "hpgv_dev_commit", "hpgv_dev_committed", "hpgv_dev_release", "hpgv_text_alias", "hpgv_stream_create", "hpgv_stream_create_low", "hpgv_stream_destroy", "hpgv_host_alloc", "hpgv_host_free",
     "hpgv_layout_dev", "hpgv_synth_dev", "hpgv_synth_raw_dev",
     "hpgv_assoc_scan_dev", "hpgv_assoc_chisq_dev", "hpgv_assoc_fisher_dev",
     "hpgv_tdt_scan_dev", "hpgv_tdt_stats_dev", "hpgv_stats_scan_dev", "hpgv_stats_hwe_dev",
@@ -122,6 +122,7 @@ def load():
     L.hpgv_dev_reserve.argtypes = [vp, sz, C.POINTER(vp)]
     L.hpgv_dev_commit.argtypes = [vp, vp, sz]
     L.hpgv_dev_release.argtypes = [vp, vp]
+    L.hpgv_dev_committed.argtypes = [vp, vp, C.POINTER(sz)]
     L.hpgv_tokenize.argtypes = [vp, C.c_char_p, sz, i32, i32, i32, C.POINTER(i32), vp, vp, vp, sz, vp, vp]
     L.hpgv_assoc_text.argtypes = [vp, i32, C.c_char_p, sz, i32, C.POINTER(i32), vp, vp, vp] + [vp] * 7
     L.hpgv_tdt_text.argtypes = [vp, C.c_char_p, sz, i32, C.POINTER(i32), vp, vp, vp] + [vp] * 5

@@ -632,6 +632,14 @@ int hpgv_dev_free(hpgv_ctx *ctx, void *dptr) {
 // Device memory that grows in place: an address range is reserved (costs nothing), and backed piece by piece as the caller
 // learns how much it needs -- a bgzip file's text, whose size is only known when its last block header has been seen.  The
 // range behaves like any device pointer (kernels, copies).  HPGV_ERR_UNSUPPORTED when the device has no virtual memory management.
+// the allocation granularity of the device's virtual memory management, as a multiple of it that is at least `at_least`
+static size_t vmm_granularity(int device, size_t at_least) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+    size_t g = 0;
+    if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || g == 0) { (void)hipGetLastError(); g = (size_t)2 << 20; }
+    return (at_least + g - 1) / g * g;
+}
 int hpgv_dev_reserve(hpgv_ctx *ctx, size_t max_bytes, void **dptr) {
     HPGV_ABI_TRY
     ctx = first_member(ctx);
@@ -640,7 +648,7 @@ int hpgv_dev_reserve(hpgv_ctx *ctx, size_t max_bytes, void **dptr) {
     int vmm = 0;
     if (hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, ctx->device) != hipSuccess || !vmm)
         return fail(ctx, HPGV_ERR_UNSUPPORTED, "the device has no virtual memory management");
-    const size_t gran = (size_t)2 << 20;
+    const size_t gran = vmm_granularity(ctx->device, (size_t)2 << 20);      // what the device asks for, at least 2 MB
     hpgv_ctx::GrowRange r;
     r.reserved = (max_bytes + gran - 1) / gran * gran;
     void *p = nullptr;
@@ -651,8 +659,8 @@ int hpgv_dev_reserve(hpgv_ctx *ctx, size_t max_bytes, void **dptr) {
     return HPGV_OK;
     HPGV_ABI_CATCH(ctx)
 }
-// makes the range's first `bytes` bytes usable (a no-op when they are already); what is backed stays backed; on failure the
-// range stays as it was
+// makes the range's first `bytes` bytes usable (a no-op when they are already); what is backed stays backed -- also the pieces
+// a failing call mapped before it failed: hpgv_dev_committed says how far the range is backed
 int hpgv_dev_commit(hpgv_ctx *ctx, void *dptr, size_t bytes) {
     HPGV_ABI_TRY
     ctx = first_member(ctx);
@@ -663,7 +671,7 @@ int hpgv_dev_commit(hpgv_ctx *ctx, void *dptr, size_t bytes) {
         if (r.base != (char *)dptr) continue;
         if (bytes <= r.committed) return HPGV_OK;
         if (bytes > r.reserved) return fail(ctx, HPGV_ERR_INVALID, "commit of %zu bytes in a range of %zu", bytes, r.reserved);
-        const size_t gran = (size_t)64 << 20;
+        const size_t gran = vmm_granularity(ctx->device, (size_t)64 << 20);      // pieces of 64 MB, rounded to the device's granularity
         size_t add = (bytes - r.committed + gran - 1) / gran * gran;
         if (r.committed + add > r.reserved) add = r.reserved - r.committed;
         hipMemAllocationProp prop = {};
@@ -701,6 +709,13 @@ int hpgv_dev_commit(hpgv_ctx *ctx, void *dptr, size_t bytes) {
     }
     return fail(ctx, HPGV_ERR_INVALID, "not a range of hpgv_dev_reserve");
     HPGV_ABI_CATCH(ctx)
+}
+int hpgv_dev_committed(hpgv_ctx *ctx, void *dptr, size_t *bytes) {
+    ctx = first_member(ctx);
+    if (!ctx || !dptr || !bytes) return HPGV_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (auto &r : ctx->grow) if (r.base == (char *)dptr) { *bytes = r.committed; return HPGV_OK; }
+    return fail(ctx, HPGV_ERR_INVALID, "not a range of hpgv_dev_reserve");
 }
 int hpgv_dev_release(hpgv_ctx *ctx, void *dptr) {
     HPGV_ABI_TRY

@@ -424,7 +424,7 @@ static int init_from_environment(void) {
 
 /* page-locked text buffers of the file runners, kept between runs: page-locking 5 x 64 MB costs 56 ms and releasing it
  * another 45 ms -- a third of a run over an 8 GB file.  Released by hpgv_host_shutdown. */
-enum { TEXT_CACHE_N = 24, TEXT_LIVE_N = 64 };
+enum { TEXT_CACHE_N = 24, TEXT_LIVE_N = 160 };      /* live: every batch buffer of a run (RUN_NB_MAX) + the cache + the uploaders' rings */
 static struct { char *p; size_t cap; } g_text_cache[TEXT_CACHE_N];
 static struct { char *p; size_t cap; } g_text_live[TEXT_LIVE_N];      /* buffers that are out, with what they really hold */
 static pthread_mutex_t g_text_mu = PTHREAD_MUTEX_INITIALIZER;
@@ -545,7 +545,12 @@ static void *dev_text_get(size_t bytes, size_t *cap, int *kind) {
 }
 static int dev_text_grow(void *p, size_t bytes, size_t *cap) {
     if (bytes <= *cap) return 1;
-    if (bytes > DEV_TEXT_RESERVE || hpgv_dev_commit(CTX, p, bytes) != HPGV_OK) return 0;
+    if (bytes > DEV_TEXT_RESERVE) return 0;
+    if (hpgv_dev_commit(CTX, p, bytes) != HPGV_OK) {
+        size_t have = 0;                                 /* a failed growth may still have mapped some pieces: the cached size follows */
+        if (hpgv_dev_committed(CTX, p, &have) == HPGV_OK && have > *cap) *cap = have < bytes ? have : bytes;
+        return *cap >= bytes;
+    }
     *cap = bytes;
     return 1;
 }
@@ -611,7 +616,12 @@ static void text_cache_release(void) {                  /* g_ctx still alive */
 
 void hpgv_host_shutdown(void) {
     pthread_mutex_lock(&g_init_mu);
+    /* per-batch calls run under the cohort lock's read side: the write side waits for the ones in flight before the engine
+     * goes.  (A worker between stage_get and its call keeps its page-locked buffer: that memory is the HIP runtime's, not the
+     * context's, and the slot serves the next engine.) */
+    pthread_rwlock_wrlock(&g_cohort_lock);
     if (g_ctx) { text_cache_release(); stage_pool_release(); hpgv_destroy(g_ctx); g_ctx = NULL; }
+    pthread_rwlock_unlock(&g_cohort_lock);
     free(g_assoc_key.cond);
     memset(&g_assoc_key, 0, sizeof g_assoc_key);
     memset(&g_tdt_key, 0, sizeof g_tdt_key);
@@ -3865,12 +3875,14 @@ static void *pipe_engine(void *v) {
         if (b->dev_text) (void)hpgv_text_alias(b->dev_ctx ? b->dev_ctx : g_ctx, b->text, b->dev_text);       /* tokenize the device copy in place (on the device that holds it): no H2D of the text */
         /* max_lines is sized for complete records; a batch of short (damaged) lines can hold more: the
          * engine reports the true count, the arrays grow and the batch is done again */
-        for (int attempt = 0; attempt < 2; attempt++) {
+        for (int attempt = 0; attempt < 4; attempt++) {
             const int m = b->max_lines;
             if (kind == 5 || kind == 6) {
                 memset(b->smiss, 0, sizeof(int32_t) * (size_t)b->n_smiss);
                 memset(b->cerr, 0, sizeof(int32_t) * (size_t)b->n_cerr);
-                if (!b->mtab) { b->multi_cap = m; b->mtab = (int32_t *)malloc(sizeof(int32_t) * 256 * (size_t)m); if (!b->mtab) { rc = HPGV_ERR_NOMEM; break; } }
+                /* the 256-bin tables of multi-allelic lines: room for 4 096 of them (4 MB), grown to what a batch really holds -- one
+                 * per possible line is 1 KB x max_lines, hundreds of MB per batch for a narrow cohort in 256 MB windows */
+                if (!b->mtab) { b->multi_cap = m < 4096 ? m : 4096; b->mtab = (int32_t *)malloc(sizeof(int32_t) * 256 * (size_t)b->multi_cap); if (!b->mtab) { rc = HPGV_ERR_NOMEM; break; } }
                 b->n_multi = b->multi_cap;
                 const int mend = kind == 6 && b->n_cerr > 0;
                 const size_t gm = (size_t)m * (size_t)b->n_groups;
@@ -3886,6 +3898,14 @@ static void *pipe_engine(void *v) {
                 rc = hpgv_assoc_text(g_ctx, kind, b->text, b->bytes, m, &b->n_lines, b->line_off, b->field_off, b->status,
                                      b->ints, b->ints + m, b->ints + 2 * m, b->ints + 3 * m,
                                      b->dbl, kind == CHI_SQUARE ? b->dbl + m : NULL, b->dbl + 2 * m);
+            if (!rc && b->n_lines <= b->max_lines && (kind == 5 || kind == 6) && b->n_multi > b->multi_cap) {      /* more multi-allelic lines than tables: again, with room */
+                free(b->mtab);
+                b->multi_cap = b->n_multi + b->n_multi / 8 + 16;
+                if (b->multi_cap > b->max_lines) b->multi_cap = b->max_lines;
+                b->mtab = (int32_t *)malloc(sizeof(int32_t) * 256 * (size_t)b->multi_cap);
+                if (!b->mtab) { rc = HPGV_ERR_NOMEM; break; }
+                continue;
+            }
             if (rc || b->n_lines <= b->max_lines) break;
             free(b->mtab); b->mtab = NULL;
             if (run_batch_reserve(b, b->n_lines)) { rc = HPGV_ERR_NOMEM; break; }

@@ -134,9 +134,11 @@ int  hpgv_dev_free(hpgv_ctx *ctx, void *dptr);
 /* device memory that grows in place: reserve an address range of max_bytes (costs no memory), make its first `bytes` bytes
  * usable with hpgv_dev_commit (what is backed stays backed; pieces of 64 MB), give everything back with hpgv_dev_release.
  * For a text whose size is known only when its last block has been seen.  HPGV_ERR_UNSUPPORTED: no virtual memory management.
- * hpgv_dev_commit fails with HPGV_ERR_NOMEM when the memory is not there; the range then stays as it was. */
+ * hpgv_dev_commit fails with HPGV_ERR_NOMEM when the memory is not there; the pieces it mapped before failing stay mapped
+ * (hpgv_dev_committed).  Sizes are rounded to the device's allocation granularity (hipMemGetAllocationGranularity). */
 int  hpgv_dev_reserve(hpgv_ctx *ctx, size_t max_bytes, void **dptr);
 int  hpgv_dev_commit(hpgv_ctx *ctx, void *dptr, size_t bytes);
+int  hpgv_dev_committed(hpgv_ctx *ctx, void *dptr, size_t *bytes);   /* how far the range is backed (a failed commit may have grown it) */
 int  hpgv_dev_release(hpgv_ctx *ctx, void *dptr);
 int  hpgv_memcpy_h2d(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream);
 int  hpgv_memcpy_d2h(hpgv_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream);
