@@ -219,7 +219,7 @@ int hpgv_create(int device_id, hpgv_ctx **out) {
     if (const char *bc = getenv("HPGV_BATCH_COPY")) ctx->batch_copy = atoi(bc) ? 1 : 0;
     if (const char *bf = getenv("HPGV_BATCH_FUSED")) ctx->batch_fused = atoi(bf) ? 1 : 0;      // diagnosis: 0 = the kernel chains
     if (const char *iw = getenv("HPGV_INFLATE_WAVE")) ctx->inflate_wave = atoi(iw) < 0 ? 0 : atoi(iw) > 4 ? 4 : atoi(iw);   // diagnosis: 0 = lane per block, 2 = wave per block, 1 = by size
-    if (const char *tt = getenv("HPGV_TOKENIZER_TILES")) ctx->tokenizer_tiles = atoi(tt) ? 1 : 0;   // diagnosis: 0 = the three-sweep tokenizer
+    if (const char *tt = getenv("HPGV_TOKENIZER_TILES")) ctx->tokenizer_tiles = atoi(tt) < 0 ? 0 : atoi(tt) > 2 ? 2 : atoi(tt);   // diagnosis: 0 = the three-sweep tokenizer
     e = hipMalloc(&ctx->d_sink, 256);
     if (e != hipSuccess) {
         int rc = fail(nullptr, HPGV_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
@@ -363,7 +363,8 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
         if (value < 0 || value > 4) return fail(ctx, HPGV_ERR_INVALID, "inflate_wave must be 0 (lane per block), 1 (by the number of blocks), 2 (wave per block), 4 (wave per block, several symbols per round) or 3 (lane per block, symbol tables in LDS)");
         ctx->inflate_wave = value;
     } else if (!strcmp(key, "tokenizer_tiles")) {
-        ctx->tokenizer_tiles = value ? 1 : 0;
+        if (value < 0 || value > 2) return fail(ctx, HPGV_ERR_INVALID, "tokenizer_tiles must be 2 (one sweep), 1 (two sweeps) or 0 (line by line)");
+        ctx->tokenizer_tiles = value;
     } else if (!strcmp(key, "fisher_width")) {
         if (value != 64 && value != 32 && value != 16 && value != 8) return fail(ctx, HPGV_ERR_INVALID, "fisher_width must be 64, 32, 16 or 8");
         ctx->fisher_width = value;
@@ -1746,6 +1747,24 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
         }
         hpgv::TokState *gtot = (hpgv::TokState *)ts->d_extra;
         int *redo = (int *)(gtot + n_groups + 2);
+        if (ctx->tokenizer_tiles >= 2 && n_tiles > 0 && max_lines > 0) {
+            // ONE sweep: count, scan and parse in one kernel, the segments' start states by look-back (k_tok_parse3).  The
+            // records, the ticket and the error flag share the tile scratch (zeroed per call: 16 bytes per 32 KiB of text).
+            const size_t n_seg = (text_bytes + hpgv::TOK3_SEG - 1) / hpgv::TOK3_SEG;
+            unsigned *tk = (unsigned *)ts->d_blocks;
+            int *err = (int *)ts->d_blocks + 1;
+            const size_t n_sup = (n_seg + hpgv::TOK3_SUPER - 1) / hpgv::TOK3_SUPER;
+            hpgv::TokRec *rec = (hpgv::TokRec *)((char *)ts->d_blocks + 64), *sup = rec + n_seg;
+            HIPCHK(ctx, hipMemsetAsync(ts->d_blocks, 0, 64 + (n_seg + n_sup) * sizeof(hpgv::TokRec), st));
+            HIPCHK(ctx, hipMemsetAsync(redo, 0, (size_t)max_lines * sizeof(int), st));
+            hipLaunchKernelGGL(hpgv::k_tok_parse3, dim3((unsigned)n_seg), dim3(256), 0, st, d_text, text_bytes, rec, sup, tk, err, d_n_lines,
+                               max_lines, n_samples, strict, d_gt, pitch, d_is_x, line_off, d_field_off, d_status, redo);
+            hipLaunchKernelGGL(hpgv::k_tok_finish, dim3(1), dim3(1), 0, st, (const int *)err, d_n_lines);
+            hipLaunchKernelGGL(hpgv::k_tok_parse, dim3((unsigned)max_lines), dim3(256), 0, st, d_text, line_off,
+                               (const int *)d_n_lines, max_lines, n_samples, strict, d_gt, pitch, d_is_x, d_field_off, d_status, (const int *)redo);
+            HIPCHK(ctx, hipGetLastError());
+            return HPGV_OK;
+        }
         if (n_tiles > 0) {
             hipLaunchKernelGGL(hpgv::k_tok_count2, dim3((unsigned)n_tiles), dim3(256), 0, st, d_text, text_bytes, agg);
             hipLaunchKernelGGL(hpgv::k_tok_scan2a, dim3((unsigned)n_groups), dim3(hpgv::TOK_SCAN_THREADS), 0, st, (const hpgv::TokAgg *)agg, (int)n_tiles, pre, gtot);
@@ -1807,6 +1826,14 @@ int hpgv_tokenize(hpgv_ctx *ctx, const char *text, size_t text_bytes, int n_samp
                                 (uint8_t *)s->buf[2], (int32_t *)s->buf[5], s->stream))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(n_lines, s->buf[6], sizeof(int), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    if (*n_lines < 0) {                                             // the one-sweep tokenizer gave up a look-back: the two-sweep kernels from now on
+        ctx->tokenizer_tiles = 1;
+        if ((rc = hpgv_tokenize_dev(ctx, (const char *)s->buf[0], text_bytes, n_samples, strict, max_lines, (int *)s->buf[6],
+                                    (uint64_t *)s->buf[3], (uint32_t *)s->buf[4], (uint8_t *)s->buf[1], pitch,
+                                    (uint8_t *)s->buf[2], (int32_t *)s->buf[5], s->stream))) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(n_lines, s->buf[6], sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    }
     const size_t nl = (size_t)(*n_lines < max_lines ? *n_lines : max_lines);
     if (nl) {
         HIPCHK(ctx, hipMemcpyAsync(gt, s->buf[1], nl * pitch, hipMemcpyDeviceToHost, s->stream));
@@ -1849,6 +1876,14 @@ static int text_front(hpgv_ctx *ctx, Slot *s, int which, const Layout &L, const 
                                 (uint8_t *)s->buf[7], raw_pitch, (uint8_t *)s->buf[2], (int32_t *)s->buf[5], s->stream))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(n_lines, meta, sizeof(int), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    if (*n_lines < 0) {                                             // the one-sweep tokenizer gave up a look-back: the two-sweep kernels from now on
+        ctx->tokenizer_tiles = 1;
+        if ((rc = hpgv_tokenize_dev(ctx, d_src, text_bytes, L.n_samples, 0,
+                                    max_lines, (int *)meta, (uint64_t *)(meta + off_lines), (uint32_t *)(meta + off_fields),
+                                    (uint8_t *)s->buf[7], raw_pitch, (uint8_t *)s->buf[2], (int32_t *)s->buf[5], s->stream))) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(n_lines, meta, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(ctx, hipStreamSynchronize(s->stream));
+    }
     const int nl = *n_lines < max_lines ? *n_lines : max_lines;
     *nl_out = nl;
     if (nl == 0) return HPGV_OK;

@@ -187,19 +187,27 @@ template <int CTRL, int ROWS> __device__ __forceinline__ int tok_dpp(int identit
 }
 #define TOK_SCAN_STEPS(STEP) STEP(0x111, 0xF) STEP(0x112, 0xF) STEP(0x114, 0xF) STEP(0x118, 0xF) STEP(0x142, 0xA) STEP(0x143, 0xC)
 
-static __global__ __launch_bounds__(256) void k_tok_parse2(const char *__restrict__ text, size_t n, const TokPre *__restrict__ pre,
-                                                    int max_lines, int n_samples, int strict, uint8_t *__restrict__ gt, size_t pitch,
-                                                    uint8_t *__restrict__ is_x, unsigned long long *__restrict__ line_off,
-                                                    uint32_t *__restrict__ field_off, int *__restrict__ status,
-                                                    int *__restrict__ redo /* per line: 1 = parse again line by line */) {
-    __shared__ int s_f[4], s_v[4], s_n[4], s_d[4], s_g[4];
-    __shared__ unsigned long long s_p[4];
+// what a tile's parse writes
+struct TokOut {
+    int max_lines, n_samples, strict;
+    uint8_t *gt; size_t pitch; uint8_t *is_x;
+    unsigned long long *line_off; uint32_t *field_off; int *status;
+    int *redo;                                                        // per line: 1 = parse again line by line
+};
+struct TokShared { int s_f[4], s_v[4], s_n[4], s_d[4], s_g[4]; unsigned long long s_p[4]; };
+
+// One tile (TOK2_TILE bytes from tile_base) parsed by the workgroup: P = the state at the tile's first byte, (tabs, nls, ww, wide) =
+// tok_masks of this thread's bytes.  Two workgroup barriers; the shared arrays may be used again right after the call.
+__device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const size_t n, const size_t tile_base, const bool first_tile, const TokPre P,
+                                               uint32_t tabs, uint32_t nls, const uint64_t (&ww)[TOK2_NW], const bool wide, TokShared &S, const TokOut &O) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const char *t = text;
-    const size_t base = (size_t)blockIdx.x * TOK2_TILE + (size_t)tid * TOK2_TB;
-    const TokPre P = pre[blockIdx.x];
-    uint32_t tabs, nls; uint64_t ww[TOK2_NW]; bool wide;
-    tok_masks(t, base, n, &tabs, &nls, ww, &wide);
+    const size_t base = tile_base + (size_t)tid * TOK2_TB;
+    const int max_lines = O.max_lines, n_samples = O.n_samples, strict = O.strict;
+    uint8_t *__restrict__ gt = O.gt; const size_t pitch = O.pitch; uint8_t *__restrict__ is_x = O.is_x;
+    unsigned long long *__restrict__ line_off = O.line_off; uint32_t *__restrict__ field_off = O.field_off; int *__restrict__ status = O.status;
+    int *__restrict__ redo = O.redo;
+    int (&s_f)[4] = S.s_f, (&s_v)[4] = S.s_v, (&s_n)[4] = S.s_n, (&s_d)[4] = S.s_d, (&s_g)[4] = S.s_g;
+    unsigned long long (&s_p)[4] = S.s_p;
 
     // ---- the line in progress when its FORMAT (8th TAB) lies before this tile: GT is ASSUMED to be the first FORMAT key, as the
     //      VCF specification requires; the thread that sees a FORMAT where it is not flags the line for k_tok_parse ----------
@@ -259,7 +267,7 @@ static __global__ __launch_bounds__(256) void k_tok_parse2(const char *__restric
     int gtpos = ed ? eg : bg;
 
     // ---- the walk: every TAB and newline of the thread's bytes, in order ----------------------------------------------
-    if (blockIdx.x == 0 && tid == 0 && n > 0) {
+    if (first_tile && tid == 0 && n > 0) {
         line_off[0] = 0;
         if (field_off && max_lines > 0) field_off[0] = 0;
     }
@@ -343,5 +351,216 @@ static __global__ __launch_bounds__(256) void k_tok_parse2(const char *__restric
     if (n > 0 && base <= n - 1 && n - 1 < base + TOK2_TB && t[n - 1] != '\n' && line < max_lines)
         tok_close_line(t, line, ntab, gtpos, ls, n, n_samples, gt, pitch, is_x, field_off, status);
 }
+
+static __global__ __launch_bounds__(256) void k_tok_parse2(const char *__restrict__ text, size_t n, const TokPre *__restrict__ pre,
+                                                    int max_lines, int n_samples, int strict, uint8_t *__restrict__ gt, size_t pitch,
+                                                    uint8_t *__restrict__ is_x, unsigned long long *__restrict__ line_off,
+                                                    uint32_t *__restrict__ field_off, int *__restrict__ status,
+                                                    int *__restrict__ redo /* per line: 1 = parse again line by line */) {
+    __shared__ TokShared S;
+    const size_t tile_base = (size_t)blockIdx.x * TOK2_TILE;
+    uint32_t tabs, nls; uint64_t ww[TOK2_NW]; bool wide;
+    tok_masks(text, tile_base + (size_t)threadIdx.x * TOK2_TB, n, &tabs, &nls, ww, &wide);
+    const TokOut O = {max_lines, n_samples, strict, gt, pitch, is_x, line_off, field_off, status, redo};
+    tok_parse_tile(text, n, tile_base, blockIdx.x == 0, pre[blockIdx.x], tabs, nls, ww, wide, S, O);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ONE sweep of the text (round 3): k_tok_parse3 = count + scan + parse in one kernel, the states at the segments' starts by
+// decoupled look-back.  A workgroup takes a SEGMENT of TOK3_TILES tiles (32 KiB): every thread loads its 32 + 8 bytes of each
+// of the four tiles ONCE, into registers, and keeps them (and their TAB / newline masks) for both phases:
+//   1. the tiles' aggregates (newlines, TABs behind the last newline, where that newline is -- what k_tok_count2 writes) by
+//      workgroup reductions; their fold is the segment's aggregate, PUBLISHED at once: it depends on no other workgroup;
+//   2. look-back in two levels.  64 segments form a SUPER (2 MB of text) with a record of its own: its aggregate is published by
+//      its last segment's workgroup as soon as that has read the other 63 aggregates (which it needs anyway), its prefix when that
+//      workgroup has its own.  A workgroup reads the aggregates of the segments between its super's start and itself (wave 0:
+//      at most 63 records) and the supers' records backwards from there (waves 1 - 3: 192 records, more rounds if none of them
+//      carries a prefix yet), folds them in order onto the nearest prefix (the combine is associative, not commutative: a
+//      newline resets the TAB count) -- about a hundred 16-byte records per 32 KiB of text, one round as a rule;
+//   3. the four tiles are parsed by tok_parse_tile, each from its own start state.
+// Why two levels: prefixes spread by one look-back's reach per round trip (4 - 10 us with agent-scope loads and a workgroup
+// fold).  The text moves at ~60 segments per us, a one-level look-back of 256 segment records falls behind -- every segment looks
+// back further than the one before it (measured: 1.45 ms for 640 MB, three times the two-sweep form) -- and reading a thousand
+// records per segment would be half the text's bytes again.  With supers the reach of one round is 192 x 2 MB.
+// Records: two 64-bit words per segment, each carrying the record's status in its top two bits (0 nothing, 1 aggregate,
+// 2 prefix), written and read with relaxed agent-scope atomics (a record is only what these two loads return: no other
+// memory is handed over, so no fence); a reader takes a record when both words show the same status.
+// Segments are numbered by a ticket taken at the workgroup's start, so every segment a workgroup waits for has started: it
+// publishes its aggregate without waiting for anyone.  Every wait is bounded all the same: a workgroup that gives up raises the
+// error flag, the kernel drains, k_tok_finish reports -1 lines, and the caller falls back to the two-sweep kernels.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int TOK3_TILES = 2;
+constexpr int TOK3_SEG = TOK3_TILES * TOK2_TILE;
+constexpr int TOK3_SUPER = 64;                      // segments per super (2 MB of text)
+struct TokRec { unsigned long long w0, w1; };           // w0: status:2 | lines:31 | tabs:31;  w1: status:2 | (line start + 1):62 (0: no newline)
+__device__ __forceinline__ void tok_rec_store(TokRec *r, unsigned status, const TokState st) {
+    const unsigned long long w0 = ((unsigned long long)status << 62) | ((unsigned long long)(uint32_t)st.lines << 31) | (unsigned long long)(uint32_t)st.tabs;
+    const unsigned long long w1 = ((unsigned long long)status << 62) | (unsigned long long)(st.ls + 1);
+    __hip_atomic_store(&r->w0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&r->w1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// status of the record (0 while nothing consistent is there), the state in *st
+__device__ __forceinline__ unsigned tok_rec_load(const TokRec *r, TokState *st) {
+    const unsigned long long w0 = __hip_atomic_load(&r->w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w1 = __hip_atomic_load(&r->w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned s0 = (unsigned)(w0 >> 62), s1 = (unsigned)(w1 >> 62);
+    if (s0 != s1) return 0u;
+    st->lines = (int)((w0 >> 31) & 0x7FFFFFFFu); st->tabs = (int)(w0 & 0x7FFFFFFFu);
+    st->ls = (long long)(w1 & 0x3FFFFFFFFFFFFFFFull) - 1;
+    return s0;
+}
+// (has a prefix been reached, state): `older` happened before `newer`; a prefix in `newer` supersedes everything older
+struct TokLook { int pre; TokState st; };
+__device__ __forceinline__ TokLook tok_look_fold(const TokLook older, const TokLook newer) {
+    if (newer.pre) return newer;
+    TokLook r; r.pre = older.pre; r.st = tok_fold(older.st, newer.st);
+    return r;
+}
+
+static __global__ __launch_bounds__(256) void k_tok_parse3(const char *__restrict__ text, size_t n, TokRec *__restrict__ rec, TokRec *__restrict__ super_rec,
+                                                    unsigned *__restrict__ ticket,
+                                                    int *__restrict__ err, int *__restrict__ n_lines,
+                                                    int max_lines, int n_samples, int strict, uint8_t *__restrict__ gt, size_t pitch,
+                                                    uint8_t *__restrict__ is_x, unsigned long long *__restrict__ line_off,
+                                                    uint32_t *__restrict__ field_off, int *__restrict__ status, int *__restrict__ redo) {
+    __shared__ TokShared S;
+    __shared__ int s_nl[TOK3_TILES][4], s_last[TOK3_TILES][4], s_tabs[TOK3_TILES][4];
+    __shared__ unsigned s_seg;
+    __shared__ int l_pre[4], l_lines[4], l_tabs[4];
+    __shared__ long long l_ls[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // The segment is the workgroup's index: workgroups are dispatched in index order, so every segment this one waits for has
+    // started (and publishes without waiting for anyone).  A ticket taken at the start (atomicAdd on one counter) would make that
+    // order certain instead of customary -- and cost more than the whole kernel: 19 550 agent-scope atomics on one address are
+    // performed one after the other at the memory side, 1.4 ms for 640 MB of text.  Should the order ever fail, the bounded waits
+    // below end the kernel with the error flag set and the caller goes back to two sweeps.
+    (void)ticket; (void)s_seg;
+    const unsigned seg = blockIdx.x;
+    const size_t seg_base = (size_t)seg * TOK3_SEG;
+    if (seg_base >= n) return;                                       // (the grid is exact: cannot happen)
+
+    // ---- 1. the segment's bytes (once) and its tiles' aggregates -------------------------------------------------------
+    uint32_t tabs[TOK3_TILES], nls[TOK3_TILES];
+    uint64_t ww[TOK3_TILES][TOK2_NW];
+    bool wide[TOK3_TILES];
+    int last_bit[TOK3_TILES];
+#pragma unroll
+    for (int k = 0; k < TOK3_TILES; ++k) tok_masks(text, seg_base + (size_t)k * TOK2_TILE + (size_t)tid * TOK2_TB, n, &tabs[k], &nls[k], ww[k], &wide[k]);
+#pragma unroll
+    for (int k = 0; k < TOK3_TILES; ++k) {
+        const int nl = __popc(nls[k]);
+        last_bit[k] = nl ? 31 - __clz((int)nls[k]) : -1;
+        int c = nl, key = nl ? tid : -1;
+        for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off); const int k2 = __shfl_xor(key, off); key = k2 > key ? k2 : key; }
+        if (lane == 0) { s_nl[k][w] = c; s_last[k][w] = key; }
+    }
+    __syncthreads();
+    int tlast[TOK3_TILES];
+#pragma unroll
+    for (int k = 0; k < TOK3_TILES; ++k) {
+        tlast[k] = max(max(s_last[k][0], s_last[k][1]), max(s_last[k][2], s_last[k][3]));
+        int mine = tid > tlast[k] ? __popc(tabs[k]) : (tid == tlast[k] ? tok_tabs_after(tabs[k], last_bit[k]) : 0);
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+        if (lane == 0) s_tabs[k][w] = mine;
+    }
+    __syncthreads();
+    // every thread folds the four tile aggregates (same values everywhere): rel[k] = the state at tile k's start relative to the segment's
+    TokState rel[TOK3_TILES + 1];
+    rel[0].lines = 0; rel[0].tabs = 0; rel[0].ls = -1;
+#pragma unroll
+    for (int k = 0; k < TOK3_TILES; ++k) {
+        TokState a;
+        a.lines = s_nl[k][0] + s_nl[k][1] + s_nl[k][2] + s_nl[k][3];
+        a.tabs = s_tabs[k][0] + s_tabs[k][1] + s_tabs[k][2] + s_tabs[k][3];
+        // where the tile's last newline is: known to the thread that holds it; the others take it from that thread's lane... every
+        // thread can compute it from tlast and that thread's last_bit only if it IS that thread, so it goes through LDS below
+        a.ls = -1;
+        rel[k + 1] = a;                                              // (ls filled in below)
+    }
+#pragma unroll
+    for (int k = 0; k < TOK3_TILES; ++k)
+        if (tid == tlast[k]) s_last[k][0] = last_bit[k];             // (s_last is free again: every thread has read it)
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TOK3_TILES; ++k) {
+        TokState a = rel[k + 1];
+        a.ls = tlast[k] >= 0 ? (long long)(seg_base + (size_t)k * TOK2_TILE + (size_t)tlast[k] * TOK2_TB + (size_t)s_last[k][0] + 1) : -1;
+        rel[k + 1] = tok_fold(rel[k], a);
+    }
+    const TokState seg_agg = rel[TOK3_TILES];
+    if (tid == 0) tok_rec_store(&rec[seg], 1u, seg_agg);
+
+    // ---- 2. look-back, two levels: the segments of this segment's SUPER (64 segments, 2 MB) back to the super's start, and
+    //         from there the supers' own records back to one that carries a prefix.  One round as a rule: 63 + 192 records. ------
+    const long long sup = (long long)(seg / TOK3_SUPER);
+    const int r_in = (int)(seg % TOK3_SUPER);                        // segments of this super in front of this one
+    TokLook acc; acc.pre = 0; acc.st.lines = 0; acc.st.tabs = 0; acc.st.ls = -1;      // what lies between the prefix found so far and this segment
+    bool gave_up = false;
+    long long next_super = sup - 1;                                  // the nearest super not yet read
+    for (int round = 0; !acc.pre; ++round) {
+        // round 0: wave 0 reads the segments seg - 1 .. of this super, waves 1 - 3 the supers sup - 1 ..; later rounds: supers only.
+        // Thread order = age: tid 0 the nearest record, tid 255 the oldest.
+        const TokRec *src = nullptr;
+        TokLook me; me.pre = 0; me.st.lines = 0; me.st.tabs = 0; me.st.ls = -1;      // (no record: the identity)
+        if (round == 0 && tid < 64) { if (tid < r_in) src = &rec[(long long)seg - 1 - tid]; }
+        else {
+            // (round 0: 64 supers, wave 1; waves 2 and 3 hold the identity -- the records read are memory traffic too)
+            const long long q = next_super - (round == 0 ? tid - 64 : tid);
+            if (round == 0 && tid >= 128) { }
+            else if (q < 0) { me.pre = 1; me.st.ls = 0; }            // the text's start is a prefix: no lines, no TABs, the line starts at 0
+            else src = &super_rec[q];
+        }
+        if (src) {
+            unsigned stt = 0;
+            for (int spin = 0; spin < (1 << 20); ++spin) {
+                stt = tok_rec_load(src, &me.st);
+                if (stt || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!stt) { gave_up = true; me.st.lines = 0; me.st.tabs = 0; me.st.ls = -1; me.pre = 1; }
+            else me.pre = stt == 2u;
+        }
+        // ordered fold over the 256 threads, oldest (tid 255) first: within the wave by shuffles from the higher lanes, across the waves in LDS
+        TokLook inc = me;
+        for (int off = 1; off < 64; off <<= 1) {
+            TokLook o;
+            o.pre = __shfl_down(inc.pre, off); o.st.lines = __shfl_down(inc.st.lines, off); o.st.tabs = __shfl_down(inc.st.tabs, off); o.st.ls = __shfl_down(inc.st.ls, off);
+            if (lane + off < 64) inc = tok_look_fold(o, inc);        // lane + off is OLDER
+        }
+        // the super's last segment: wave 0 has just read the aggregates of all the others -- the super's aggregate goes out NOW, before
+        // the workgroup's barrier, which waits for the waves that are still waiting for OLDER supers (behind the barrier every
+        // super's aggregate would wait for the one before it: a chain through all 300 supers of a 640 MB text, 1.6 ms)
+        if (round == 0 && tid == 0 && r_in == TOK3_SUPER - 1) tok_rec_store(&super_rec[sup], 1u, tok_fold(inc.st, seg_agg));
+        if (lane == 0) { l_pre[w] = inc.pre; l_lines[w] = inc.st.lines; l_tabs[w] = inc.st.tabs; l_ls[w] = inc.st.ls; }
+        __syncthreads();
+        TokLook rnd; rnd.pre = l_pre[3]; rnd.st.lines = l_lines[3]; rnd.st.tabs = l_tabs[3]; rnd.st.ls = l_ls[3];
+        for (int k = 2; k >= 0; --k) { TokLook nw; nw.pre = l_pre[k]; nw.st.lines = l_lines[k]; nw.st.tabs = l_tabs[k]; nw.st.ls = l_ls[k]; rnd = tok_look_fold(rnd, nw); }
+        acc = tok_look_fold(rnd, acc);                               // this round's records are older than what has been folded
+        next_super -= round == 0 ? 64 : 256;
+        __syncthreads();
+    }
+    if (__syncthreads_or(gave_up ? 1 : 0)) { if (tid == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    const TokState start = acc.st;                                   // the state at the segment's first byte
+    const TokState incl = tok_fold(start, seg_agg);
+    if (tid == 0 && r_in == TOK3_SUPER - 1) tok_rec_store(&super_rec[sup], 2u, incl);      // the prefix at the next super's start
+    if (seg_base + TOK3_SEG >= n && tid == 0) {                      // the text's last segment: the line count (k_tok_scan2b's part)
+        const int tail = (n > 0 && text[n - 1] != '\n') ? 1 : 0;     // unterminated last line
+        *n_lines = incl.lines + tail;
+        if (tail && incl.lines + 1 <= max_lines) line_off[incl.lines + 1] = n;
+    }
+
+    // ---- 3. the tiles ------------------------------------------------------------------------------------------------------
+    const TokOut O = {max_lines, n_samples, strict, gt, pitch, is_x, line_off, field_off, status, redo};
+#pragma unroll
+    for (int k = 0; k < TOK3_TILES; ++k) {
+        const size_t tile_base = seg_base + (size_t)k * TOK2_TILE;
+        if (tile_base >= n) break;                                   // (uniform)
+        const TokState st = tok_fold(start, rel[k]);
+        TokPre P; P.lines = st.lines; P.tabs = st.tabs; P.line_start = (unsigned long long)st.ls;
+        tok_parse_tile(text, n, tile_base, seg == 0 && k == 0, P, tabs[k], nls[k], ww[k], wide[k], S, O);
+    }
+}
+// the fused kernel's verdict: a look-back that gave up makes the line count -1 (the caller runs the two-sweep kernels instead)
+static __global__ void k_tok_finish(const int *__restrict__ err, int *__restrict__ n_lines) { if (*err) *n_lines = -1; }
 
 }  // namespace hpgv

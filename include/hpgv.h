@@ -432,7 +432,10 @@ int  hpgv_bgzf_scan_dev(hpgv_ctx *ctx, const uint8_t *d_comp, uint64_t lo, uint6
  * gt rows in VCF column order (strict != 0: genotypes get_alleles() would not report as
  * ALLELES_OK become 0xFF); is_x per line (assoc.c:94 rule); status per line: 0 ok, 1 fewer
  * than 10 columns, 2 FORMAT has no GT (row all missing), 3 fewer sample columns than n_samples.
- * More than max_lines lines: the first max_lines are parsed and *n_lines reports the true count. */
+ * More than max_lines lines: the first max_lines are parsed and *n_lines reports the true count.
+ * *n_lines = -1 (hpgv_tokenize_dev only, after the stream has been waited for): the one-sweep form (option tokenizer_tiles = 2)
+ * gave up waiting for another workgroup's record -- set the option to 1 and call again; hpgv_tokenize and the *_text
+ * entry points do that themselves. */
 int  hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int n_samples, int strict,
                        int max_lines, int *d_n_lines, uint64_t *d_line_off, uint32_t *d_field_off,
                        uint8_t *d_gt, size_t pitch, uint8_t *d_is_x, int32_t *d_status, void *stream);

@@ -12,9 +12,10 @@ WEIRD = QUIRK_GTS + ["", "0/1:12:99", ".:3", "1/", "/1", "0|0:.", "10/2", "a/1",
                      "./.:0,0", "0/0:1,2:3"]
 
 
-@pytest.fixture(scope="module", params=[1, 0], ids=["tile-parallel", "line-by-line"])
+@pytest.fixture(scope="module", params=[2, 1, 0], ids=["one-sweep", "tile-parallel", "line-by-line"])
 def eng(request):
-    """Both tokenizers: the tile-parallel one (default, hpgv_text2_kernels.h) and the count / mark / parse-per-line one."""
+    """The three tokenizers: one sweep with look-back (default), tile-parallel in two sweeps (both hpgv_text2_kernels.h), count / mark /
+    parse per line."""
     e = hpgv.Engine(0)
     e.set_option("tokenizer_tiles", request.param)
     yield e
@@ -74,7 +75,7 @@ def test_both_tokenizers_give_the_same_offsets():
         lines.append(_line(rng, 300, fmt, ["1", "X", "", "chrX"][i % 4], [3, 100, 5000, 9000, 20000][i % 5], n_cols=[300, 300, 298, 303, 0][i % 5]))
     lines.insert(3, ""); lines.insert(4, ""); lines.insert(17, "1\t5\trs\tA\tC"); lines.insert(18, "X")
     outs = []
-    for tiles in (1, 0):
+    for tiles in (2, 1, 0):
         e = hpgv.Engine(0)
         e.set_option("tokenizer_tiles", tiles)
         res = []
@@ -83,10 +84,10 @@ def test_both_tokenizers_give_the_same_offsets():
                 res.append(e.tokenize(text, 300, False, max_lines))
         outs.append(res)
         e.close()
-    for a, b in zip(*outs):
-        assert a["n_lines"] == b["n_lines"]
+    for a, b, c in zip(*outs):
+        assert a["n_lines"] == b["n_lines"] == c["n_lines"]
         for k in ("gt", "is_x", "status", "line_off", "field_off"):
-            assert np.array_equal(a[k], b[k]), k
+            assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
 
 
 def test_empty_and_capacity(eng):
@@ -519,3 +520,27 @@ def test_bgzf_crc_check_on_the_gpu_against_zlib():
     exp[[k for k in wrong_text if k not in refused]] = 9                 # HPGV_BLOCK_BAD_CRC
     assert np.array_equal(got, exp), (np.nonzero(got != exp)[0], got[got != exp], [lens[k] for k in np.nonzero(got != exp)[0]])
     e.close()
+
+
+def test_one_sweep_tokenizer_on_a_large_text_equals_two_sweeps():
+    """Thousands of segments in flight (look-backs over several rounds, segments that end inside lines, lines longer than a
+    segment): the one-sweep tokenizer's matrix, line offsets, field offsets and statuses equal the two-sweep form's, call after
+    call (the records are zeroed per call)."""
+    rng = np.random.default_rng(99)
+    res = {}
+    for n_samples, n_lines in ((20000, 3000), (300, 120000), (70000, 400)):
+        codes = np.array(["0/0", "0/1", "1/1", "./.", "1|0", "0/2"])
+        bodies = ["\t".join(codes[rng.choice(6, size=n_samples, p=[0.5, 0.25, 0.15, 0.02, 0.05, 0.03])]) for _ in range(16)]
+        text = "".join("%s\t%d\trs%d\tA\tG,T\t.\tPASS\t%s\tGT\t%s\n" % (["1", "X"][i % 2], 100 + i, i, "X" * int(rng.integers(1, 200)), bodies[i % 16])
+                       for i in range(n_lines))
+        for tiles in (2, 1):
+            e = hpgv.Engine(0)
+            e.set_option("tokenizer_tiles", tiles)
+            out = [e.tokenize(text, n_samples, True, None) for _ in range(2)]
+            e.close()
+            res[tiles] = out
+        for call in range(2):
+            a, b = res[2][call], res[1][call]
+            assert a["n_lines"] == b["n_lines"] == n_lines
+            for k in ("gt", "is_x", "status", "line_off", "field_off"):
+                assert np.array_equal(a[k], b[k]), (n_samples, k)
