@@ -11,7 +11,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd $R && python3 __graft_entry__.py > $O/${TAG}_fisher_build.log 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --workload c3 --steps 3 --warmup 1 --no-cpu-baseline"
+CMD="python3 $R/bench.py --workload c3 --steps 3 --warmup 1 --no-cpu-baseline --configs none"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVES -d $O/${TAG}_fi_pmc1 -o pmc1 --output-format csv -- $CMD > $O/${TAG}_fi_pmc1.json 2> $O/${TAG}_fi_pmc1.err || exit 1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/${TAG}_fi_pmc2 -o pmc2 --output-format csv -- $CMD > $O/${TAG}_fi_pmc2.json 2> $O/${TAG}_fi_pmc2.err || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${TAG}_fi_pmc3 -o pmc3 --output-format csv -- $CMD > $O/${TAG}_fi_pmc3.json 2> $O/${TAG}_fi_pmc3.err || exit 1
