@@ -292,6 +292,7 @@ void hpgv_destroy(hpgv_ctx *ctx) {
     if (ctx->d_mendel_male) (void)hipFree(ctx->d_mendel_male);
     if (ctx->d_sg_chunks) (void)hipFree(ctx->d_sg_chunks);
     if (ctx->d_group_of_col) (void)hipFree(ctx->d_group_of_col);
+    if (ctx->d_cond) (void)hipFree(ctx->d_cond);
     for (Layout *L : {&ctx->assoc, &ctx->tdt, &ctx->stats, &ctx->sgroups, &ctx->mendel})
         if (L->d_col_of_pos) (void)hipFree(L->d_col_of_pos);
     ctx->tdt_plan.release();
@@ -411,6 +412,16 @@ int hpgv_set_cohort(hpgv_ctx *ctx, const uint8_t *condition, int n_samples) {
         else if (condition[j] == HPGV_COND_UNAFFECTED) L.col_of_pos[u++] = j;
     }
     ctx->nA = nA; ctx->nU = nU; ctx->chunksA = (int)(segA / 16);
+    {   // the conditions themselves, for the kernel that counts in VCF column order with masks (k_assoc_rows)
+        std::vector<uint8_t> cond(round_up((size_t)n_samples, 16) + 16, (uint8_t)HPGV_COND_OTHER);
+        for (int j = 0; j < n_samples; ++j) cond[(size_t)j] = condition[j] == HPGV_COND_AFFECTED ? 1 : condition[j] == HPGV_COND_UNAFFECTED ? 0 : 2;
+        if (ctx->cond_cap < cond.size()) {
+            if (ctx->d_cond) { (void)hipFree(ctx->d_cond); ctx->d_cond = nullptr; ctx->cond_cap = 0; }
+            HIPCHK(ctx, hipMalloc(&ctx->d_cond, cond.size()));
+            ctx->cond_cap = cond.size();
+        }
+        HIPCHK(ctx, hipMemcpy(ctx->d_cond, cond.data(), cond.size(), hipMemcpyHostToDevice));
+    }
     return upload_layout(ctx, L);
     HPGV_ABI_CATCH(ctx)
 }
@@ -1988,6 +1999,33 @@ int hpgv_assoc_text(hpgv_ctx *ctx, int task, const char *text, size_t text_bytes
     if ((rc = text_front(ctx, s, HPGV_LAYOUT_ASSOC, ctx->assoc, text, text_bytes, max_lines, n_lines, line_off, field_off, status, &nl, !fused))) return rc;
     if (nl == 0) { HIPCHK(ctx, hipStreamSynchronize(s->stream)); return HPGV_OK; }
     const size_t n = (size_t)nl;
+    if (fused && !(getenv("HPGV_ASSOC_ROWS") && atoi(getenv("HPGV_ASSOC_ROWS")) == 0)) {
+        // the raw matrix read once by threads that own columns (k_assoc_rows), then the scans' own statistics kernels
+        const int ns = ctx->assoc.n_samples;
+        if ((rc = ensure(ctx, s, 3, n * 16))) return rc;
+        if ((rc = ensure(ctx, s, 4, n * 3 * sizeof(double)))) return rc;
+        if ((rc = ensure_result_block(ctx, s, n * 40 + 64))) return rc;
+        int32_t *d_counts = (int32_t *)s->buf[3];
+        double *d_odds = (double *)s->buf[4], *d_chisq = d_odds + n, *d_p = d_odds + 2 * n;
+        if (hpgv_launch_assoc_rows(ctx, (const uint8_t *)s->buf[7], (size_t)(ns > 0 ? (ns + 15) / 16 * 16 : 16), nl, (const uint8_t *)s->buf[2], d_counts, s->stream) == 0) {
+            HIPCHK(ctx, hipGetLastError());
+            if (task == HPGV_TASK_CHISQ) rc = hpgv_assoc_chisq_dev(ctx, d_counts, nl, d_odds, d_chisq, d_p, s->stream);
+            else rc = hpgv_assoc_fisher_dev(ctx, d_counts, nl, d_odds, d_p, s->stream);
+            if (rc) { (void)hipStreamSynchronize(s->stream); return rc; }
+            // results come back through the slot's page-locked block (one copy each at the bus rate), then into the caller's arrays
+            char *h = (char *)s->h_res;
+            HIPCHK(ctx, hipMemcpyAsync(h, d_counts, n * 16, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(ctx, hipMemcpyAsync(h + n * 16, d_odds, n * 24, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(ctx, hipStreamSynchronize(s->stream));
+            const int32_t *c4 = (const int32_t *)h;
+            const double *dd = (const double *)(h + n * 16);
+            for (size_t i = 0; i < n; ++i) { A1[i] = c4[4 * i]; A2[i] = c4[4 * i + 1]; U1[i] = c4[4 * i + 2]; U2[i] = c4[4 * i + 3]; }
+            memcpy(odds, dd, n * 8);
+            if (task == HPGV_TASK_CHISQ) memcpy(chisq, dd + n, n * 8);
+            memcpy(p, dd + 2 * n, n * 8);
+            return HPGV_OK;
+        }
+    }
     if (fused) {
         // the tokenizer's raw matrix is read ONCE: layout in registers, counts, statistics, packed records (hpgv_batch_kernels.h)
         const int ns = ctx->assoc.n_samples;

@@ -106,6 +106,8 @@ struct hpgv_ctx {
     // assoc
     Layout assoc;
     int nA = 0, nU = 0, chunksA = 0;
+    uint8_t *d_cond = nullptr;            // the condition of every column as given (padded with 2 to whole 16-byte chunks): k_assoc_rows' masks
+    size_t cond_cap = 0;
     // tdt
     Layout tdt;
     hpgv::TdtPlan tdt_plan;
@@ -313,6 +315,8 @@ template <typename F>
 // defined in hpgv_statsall_capi.hip: k_stats_all2 on a batch (0 = launched, 1 = not a batch it takes: run k_stats_all)
 namespace hpgv { struct StatsAllArgs; }
 int hpgv_launch_stats_all2(hpgv_ctx *ctx, hpgv::StatsAllArgs &A, void **cnt_buf, size_t *cnt_cap, hipStream_t st);
+// k_assoc_rows: the allele counts from the tokenizer's raw rows (0 = launched, 1 = not a batch it takes: run k_batch)
+int hpgv_launch_assoc_rows(hpgv_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int n_variants, const uint8_t *d_is_x, int32_t *d_counts, hipStream_t st);
 // defined in hpgv_epi_capi.hip
 void hpgv_epi_release(EpiState &E);
 // defined in hpgv_group_capi.hip: streams, scratch and communicator of a group context (before its members go)

@@ -108,3 +108,32 @@ int hpgv_launch_stats_all2(hpgv_ctx *ctx, hpgv::StatsAllArgs &A, void **cnt_buf,
                        A.n_variants, G.n_masked, G.derive_last, A.out, A.group_out, A.mendel_errors);
     return 0;
 }
+
+// k_assoc_rows on the tokenizer's raw rows (0 = launched, 1 = not a batch it takes: the caller runs k_batch)
+int hpgv_launch_assoc_rows(hpgv_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int n_variants, const uint8_t *d_is_x, int32_t *d_counts, hipStream_t st) {
+    const int ns = ctx->assoc.n_samples, chunks = (ns + 15) / 16;
+    if (ns <= 0 || ns > 65535 || !ctx->d_cond) return 1;
+    if (((uintptr_t)d_src & 15) || (src_pitch & 15) || src_pitch < (size_t)chunks * 16 || ((uintptr_t)d_counts & 15)) return 1;
+    int cpt = 0;
+    unsigned bs = 0;
+    for (int c = 1; c <= 4 && !cpt; ++c) {                          // the fewest chunks per thread that 512 threads cover
+        const unsigned b = (unsigned)(((chunks + c - 1) / c + 63) / 64 * 64);
+        if (b <= 512) { cpt = c; bs = b; }
+    }
+    if (!cpt) return 1;
+    // one round of workgroups over the chip, bands of at most 32 rows (as k_stats_all2)
+    const long slots = 4L * ctx->n_cus;
+    long k = 1;
+    while (((long)n_variants + slots * k - 1) / (slots * k) > 32) ++k;
+    long rows = ((long)n_variants + slots * k - 1) / (slots * k);
+    if (rows < 1) rows = 1;
+    const unsigned grid = (unsigned)((n_variants + rows - 1) / rows);
+    const size_t lds = (size_t)rows * 16 + 16;
+    switch (cpt) {
+        case 1: hipLaunchKernelGGL(hpgv::k_assoc_rows<1>, dim3(grid), dim3(bs), lds, st, d_src, src_pitch, n_variants, ns, (int)rows, d_is_x, (const uint8_t *)ctx->d_cond, (int4 *)d_counts); break;
+        case 2: hipLaunchKernelGGL(hpgv::k_assoc_rows<2>, dim3(grid), dim3(bs), lds, st, d_src, src_pitch, n_variants, ns, (int)rows, d_is_x, (const uint8_t *)ctx->d_cond, (int4 *)d_counts); break;
+        case 3: hipLaunchKernelGGL(hpgv::k_assoc_rows<3>, dim3(grid), dim3(bs), lds, st, d_src, src_pitch, n_variants, ns, (int)rows, d_is_x, (const uint8_t *)ctx->d_cond, (int4 *)d_counts); break;
+        default: hipLaunchKernelGGL(hpgv::k_assoc_rows<4>, dim3(grid), dim3(bs), lds, st, d_src, src_pitch, n_variants, ns, (int)rows, d_is_x, (const uint8_t *)ctx->d_cond, (int4 *)d_counts); break;
+    }
+    return 0;
+}

@@ -357,6 +357,104 @@ static __global__ __launch_bounds__(256) void k_stats_all2_records(const uint32_
     } else group_out[(size_t)(s - 1) * (size_t)n_variants + v] = stats_record(c);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_assoc_rows: the allele counts of assoc_count_individual (assoc.c:87-134) from the tokenizer's raw rows (VCF column order,
+// not strict), threads owning columns across a band of rows as in k_stats_all2: the affected / unaffected columns are two
+// masks in the transposed layout, a genotype's contribution a 3-bit flag of its pair class -- "0/0", exactly one zero allele,
+// both alleles non-zero; anything with a missing allele counts nothing, which is the strict rule of assoc.c:53 -- and
+//     A1 = 2 n00 + nhet, A2 = 2 nxx + nhet   (chromosome "X", assoc.c:94-107: A1 = n00, A2 = nxx)
+// per phenotype group.  No LDS staging, no barrier per row, no column gather (k_batch<BATCH_CHISQ> on the same rows: one
+// workgroup per row, layout gathered through col_of_pos: 110 us per 16 000 x 10 k).  The counts go to an int4 array; the
+// statistics are the scans' own kernels (k_assoc_chisq / k_assoc_fisher).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t assoc_flags_of_class4(uint32_t idx) { return lut16x4(0x00020201u, 0x00040402u, 0x00040402u, 0x00000000u, idx); }
+
+template <int CPT>
+__global__ __launch_bounds__(512) void k_assoc_rows(const uint8_t *__restrict__ src, size_t src_pitch, int n_variants, int n_samples, int rows_per_block,
+                                                     const uint8_t *__restrict__ is_x, const uint8_t *__restrict__ cond /* per column: 1 affected, 0 unaffected, else neither; padded */,
+                                                     int4 *__restrict__ counts) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    constexpr int NB = (CPT + 1) / 2;
+    uint32_t *rowcnt = reinterpret_cast<uint32_t *>(lds);                 // [rows][4]: n00A | nhetA << 16, nxxA | n00U << 16, nhetU | nxxU << 16, -
+    const int tid = threadIdx.x, lane = tid & 63, BS = blockDim.x;
+    const int chunks = (n_samples + 15) >> 4;
+    const int v0 = blockIdx.x * rows_per_block;
+    const int rows = (v0 + rows_per_block <= n_variants) ? rows_per_block : n_variants - v0;
+    for (int i = tid; i < rows * 4; i += BS) rowcnt[i] = 0u;
+    uint32_t tA[NB], tU[NB];
+    bool own[CPT];
+    {
+        uint32_t mA[NB][8], mU[NB][8];
+#pragma unroll
+        for (int i = 0; i < 2 * NB; ++i) {
+            const int c = tid + BS * i;
+            const bool mine = i < CPT && c < chunks;
+            if (i < CPT) own[i] = mine;
+            uint4 cq = make_uint4(0x02020202u, 0x02020202u, 0x02020202u, 0x02020202u);
+            if (mine) cq = reinterpret_cast<const uint4 *>(cond)[c];
+            const uint32_t cw[4] = {cq.x, cq.y, cq.z, cq.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { mA[i / 2][(i & 1) * 4 + k] = byte_eq_mask(cw[k], 1u); mU[i / 2][(i & 1) * 4 + k] = byte_eq_mask(cw[k], 0u); }
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) { tA[q] = transposed_mask(mA[q]); tU[q] = transposed_mask(mU[q]); }
+    }
+    uint4 cur[CPT], nxt[CPT];
+    const uint8_t *rowp = src + (size_t)v0 * src_pitch;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) cur[i] = own[i] ? reinterpret_cast<const uint4 *>(rowp)[tid + BS * i] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    __syncthreads();
+    for (int r = 0; r < rows; ++r) {
+        if (r + 1 < rows) {
+            const uint8_t *np = rowp + (size_t)(r + 1) * src_pitch;
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) nxt[i] = own[i] ? reinterpret_cast<const uint4 *>(np)[tid + BS * i] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        }
+        uint32_t cA[3] = {0u, 0u, 0u}, cU[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            uint32_t f[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = 2 * q + h;
+                if (i >= CPT) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) f[4 * h + k] = 0u;
+                    continue;
+                }
+                const uint32_t g[4] = {cur[i].x, cur[i].y, cur[i].z, cur[i].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) f[4 * h + k] = assoc_flags_of_class4(pair_class4(g[k]));
+            }
+            bit_transpose8(f);                                       // (only rows 0 - 2 are used: the rest of the network is dead code)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) { cA[b] += (uint32_t)__builtin_popcount(f[b] & tA[q]); cU[b] += (uint32_t)__builtin_popcount(f[b] & tU[q]); }
+        }
+        uint32_t v16[16], red[2];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v16[j] = 0u;
+        v16[0] = cA[0] | (cA[1] << 16); v16[1] = cA[2] | (cU[0] << 16); v16[2] = cU[1] | (cU[2] << 16);
+        row_reduce16(v16, red, lane);
+        if (!(lane & 4)) {
+            const int slot = ((lane >> 1) & 4) | (lane & 3);
+            if (slot < 3 && red[0]) atomicAdd(&rowcnt[r * 4 + slot], red[0]);
+        }
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) cur[i] = nxt[i];
+    }
+    __syncthreads();
+    for (int r = tid; r < rows; r += BS) {
+        const uint32_t a = rowcnt[r * 4], b = rowcnt[r * 4 + 1], c = rowcnt[r * 4 + 2];
+        const int n00A = (int)(a & 0xFFFFu), nhetA = (int)(a >> 16), nxxA = (int)(b & 0xFFFFu);
+        const int n00U = (int)(b >> 16), nhetU = (int)(c & 0xFFFFu), nxxU = (int)(c >> 16);
+        const bool x = is_x != nullptr && is_x[v0 + r] != 0;
+        int4 o;
+        o.x = x ? n00A : 2 * n00A + nhetA; o.y = x ? nxxA : 2 * nxxA + nhetA;
+        o.z = x ? n00U : 2 * n00U + nhetU; o.w = x ? nxxU : 2 * nxxU + nhetU;
+        counts[v0 + r] = o;
+    }
+}
+
 // LDS bytes of a launch
 inline size_t stats_all2_lds(int rows_per_block) {
     return 2 * (size_t)STATS2_CLS + ((size_t)rows_per_block * STATS2_W + 2) * sizeof(uint32_t) + 16;

@@ -544,3 +544,30 @@ def test_one_sweep_tokenizer_on_a_large_text_equals_two_sweeps():
             assert a["n_lines"] == b["n_lines"] == n_lines
             for k in ("gt", "is_x", "status", "line_off", "field_off"):
                 assert np.array_equal(a[k], b[k]), (n_samples, k)
+
+
+@pytest.mark.parametrize("n_samples", [17, 1000, 4100, 8200, 16390, 33000])
+def test_assoc_text_rows_kernel_equals_the_per_row_kernel(n_samples):
+    """hpgv_assoc_text counts with k_assoc_rows (threads own columns across a band of rows; one to four chunks per thread, 64 to 512
+    threads) -- against k_batch (HPGV_ASSOC_ROWS=0: one workgroup per row; also what wider cohorts fall back to) and the oracle:
+    chromosome X rows, samples that are neither affected nor unaffected, half-missing and multi-allelic calls."""
+    import os
+    from helpers import check_assoc, oracle_assoc
+    rng = np.random.default_rng(n_samples)
+    lines = [_line(rng, n_samples, "GT", ["1", "X", "7", "X"][i % 4], 6) for i in range(37)]
+    text = "\n".join(lines) + "\n"
+    tok = orc.tokenize(text, n_samples, True)
+    cond = rng.choice([0, 1, 2], size=n_samples, p=[0.45, 0.45, 0.1]).astype(np.uint8)
+    out = {}
+    for rows in ("1", "0"):
+        os.environ["HPGV_ASSOC_ROWS"] = rows
+        try:
+            e = hpgv.Engine(0)
+            e.set_cohort(cond)
+            out[rows] = e.assoc_text(hpgv.TASK_CHISQ, text)
+            e.close()
+        finally:
+            del os.environ["HPGV_ASSOC_ROWS"]
+    for k in ("A1", "A2", "U1", "U2", "odds", "chisq", "p", "status"):
+        assert np.array_equal(out["1"][k], out["0"][k], equal_nan=True), k
+    check_assoc(out["1"], oracle_assoc(orc.TASK_CHISQ, tok["gt"], cond, tok["is_x"], None), hpgv.TASK_CHISQ)
