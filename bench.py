@@ -51,6 +51,9 @@ WORKLOADS = {
     "c4": ("tdt", 2_000_000, 15_000, "weak", "tdt, 2M SNP x 5k trios (BASELINE configs[3]): trio scan + TDT statistics"),
     "c5": ("chisq", 1_000_000, 100_000, "weak",
            "assoc --chisq, one 100 GB tile (1 of 5) of a GPU's shard of the 40M SNP x 100k cohort on 8 GPUs (BASELINE configs[4])"),
+    "c5full": ("chisq", 40_000_000, 100_000, "strong",
+               "assoc --chisq, the whole 40M SNP x 100k cohort (4 TB) of BASELINE configs[4], variant-sharded over the ranks: on 8 GPUs "
+               "5M variants = 4 tiles of 125 GB per rank, regenerated on the device before each tile's scan; meant for --gpus 8"),
     "m8": ("chisq", 1_250_000, 50_000, "weak", "assoc --chisq, per-GPU shard (1/8) of the 10M SNP x 50k metric cohort"),
     "stats": ("stats", 1_000_000, 10_000, "weak",
               "vcf stats: genotype / allele / missing counters + Hardy-Weinberg on 1M SNP x 10k samples (get_variants_stats)"),

@@ -1757,22 +1757,23 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
             ts->extra_cap = extra + extra / 4;
         }
         hpgv::TokState *gtot = (hpgv::TokState *)ts->d_extra;
-        int *redo = (int *)(gtot + n_groups + 2);
+        int *redo = (int *)(gtot + n_groups + 2), *redo_n = redo + max_lines + 1;      // the list of lines to parse again, its length
+        const unsigned redo_grid = (unsigned)(max_lines < 1024 ? max_lines : 1024);
         if (ctx->tokenizer_tiles >= 2 && n_tiles > 0 && max_lines > 0) {
             // ONE sweep: count, scan and parse in one kernel, the segments' start states by look-back (k_tok_parse3).  The
             // records, the ticket and the error flag share the tile scratch (zeroed per call: 16 bytes per 32 KiB of text).
             const size_t n_seg = (text_bytes + hpgv::TOK3_SEG - 1) / hpgv::TOK3_SEG;
             unsigned *tk = (unsigned *)ts->d_blocks;
             int *err = (int *)ts->d_blocks + 1;
+            redo_n = (int *)ts->d_blocks + 2;                          // (zeroed with the records)
             const size_t n_sup = (n_seg + hpgv::TOK3_SUPER - 1) / hpgv::TOK3_SUPER;
             hpgv::TokRec *rec = (hpgv::TokRec *)((char *)ts->d_blocks + 64), *sup = rec + n_seg;
             HIPCHK(ctx, hipMemsetAsync(ts->d_blocks, 0, 64 + (n_seg + n_sup) * sizeof(hpgv::TokRec), st));
-            HIPCHK(ctx, hipMemsetAsync(redo, 0, (size_t)max_lines * sizeof(int), st));
             hipLaunchKernelGGL(hpgv::k_tok_parse3, dim3((unsigned)n_seg), dim3(256), 0, st, d_text, text_bytes, rec, sup, tk, err, d_n_lines,
-                               max_lines, n_samples, strict, d_gt, pitch, d_is_x, line_off, d_field_off, d_status, redo);
+                               max_lines, n_samples, strict, d_gt, pitch, d_is_x, line_off, d_field_off, d_status, redo, redo_n);
             hipLaunchKernelGGL(hpgv::k_tok_finish, dim3(1), dim3(1), 0, st, (const int *)err, d_n_lines);
-            hipLaunchKernelGGL(hpgv::k_tok_parse, dim3((unsigned)max_lines), dim3(256), 0, st, d_text, line_off,
-                               (const int *)d_n_lines, max_lines, n_samples, strict, d_gt, pitch, d_is_x, d_field_off, d_status, (const int *)redo);
+            hipLaunchKernelGGL(hpgv::k_tok_parse_listed, dim3(redo_grid), dim3(256), 0, st, d_text, line_off,
+                               (const int *)d_n_lines, max_lines, n_samples, strict, d_gt, pitch, d_is_x, d_field_off, d_status, (const int *)redo, (const int *)redo_n);
             HIPCHK(ctx, hipGetLastError());
             return HPGV_OK;
         }
@@ -1781,14 +1782,13 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
             hipLaunchKernelGGL(hpgv::k_tok_scan2a, dim3((unsigned)n_groups), dim3(hpgv::TOK_SCAN_THREADS), 0, st, (const hpgv::TokAgg *)agg, (int)n_tiles, pre, gtot);
         }
         hipLaunchKernelGGL(hpgv::k_tok_scan2b, dim3((unsigned)(n_groups > 0 ? n_groups : 1)), dim3(hpgv::TOK_SCAN_THREADS), 0, st, pre, (int)n_tiles, gtot, n_groups,
-                           d_text, text_bytes, d_n_lines, line_off, max_lines);
+                           d_text, text_bytes, d_n_lines, line_off, max_lines, redo_n);
         if (n_tiles > 0 && max_lines > 0) {
-            HIPCHK(ctx, hipMemsetAsync(redo, 0, (size_t)max_lines * sizeof(int), st));
             hipLaunchKernelGGL(hpgv::k_tok_parse2, dim3((unsigned)n_tiles), dim3(256), 0, st, d_text, text_bytes, (const hpgv::TokPre *)pre,
-                               max_lines, n_samples, strict, d_gt, pitch, d_is_x, line_off, d_field_off, d_status, redo);
-            // the lines whose FORMAT does not begin with GT (flagged by the thread that read it): once more, line by line
-            hipLaunchKernelGGL(hpgv::k_tok_parse, dim3((unsigned)max_lines), dim3(256), 0, st, d_text, line_off,
-                               (const int *)d_n_lines, max_lines, n_samples, strict, d_gt, pitch, d_is_x, d_field_off, d_status, (const int *)redo);
+                               max_lines, n_samples, strict, d_gt, pitch, d_is_x, line_off, d_field_off, d_status, redo, redo_n);
+            // the lines whose FORMAT does not begin with GT (listed by the thread that read it): once more, line by line
+            hipLaunchKernelGGL(hpgv::k_tok_parse_listed, dim3(redo_grid), dim3(256), 0, st, d_text, line_off,
+                               (const int *)d_n_lines, max_lines, n_samples, strict, d_gt, pitch, d_is_x, d_field_off, d_status, (const int *)redo, (const int *)redo_n);
         }
         HIPCHK(ctx, hipGetLastError());
         return HPGV_OK;
@@ -1804,7 +1804,7 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
         HIPCHK(ctx, hipMemsetAsync(line_off, 0, sizeof(unsigned long long), st));
     if (max_lines > 0)
         hipLaunchKernelGGL(hpgv::k_tok_parse, dim3((unsigned)max_lines), dim3(256), 0, st, d_text, line_off,
-                           (const int *)d_n_lines, max_lines, n_samples, strict, d_gt, pitch, d_is_x, d_field_off, d_status, (const int *)nullptr);
+                           (const int *)d_n_lines, max_lines, n_samples, strict, d_gt, pitch, d_is_x, d_field_off, d_status);
     HIPCHK(ctx, hipGetLastError());
     return HPGV_OK;
     HPGV_ABI_CATCH(ctx)

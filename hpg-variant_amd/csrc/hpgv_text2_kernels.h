@@ -27,46 +27,144 @@ struct TokAgg { int nl, tabs, last_nl, pad; };                       // last_nl:
 struct TokPre { int lines, tabs; unsigned long long line_start; };   // state at the tile's first byte
 constexpr int TOK_GT_UNDEF = -2;                                     // "FORMAT of this line not seen yet"
 
-// TAB and newline bits of a thread's TOK2_TB bytes (bit j = byte base + j), and the bytes themselves (+ the 8 after them) when
-// they all exist
-__device__ __forceinline__ void tok_masks(const char *__restrict__ t, size_t base, size_t n, uint32_t *tabs, uint32_t *nls,
-                                          uint64_t (&w)[TOK2_NW], bool *wide) {
-    *wide = base + TOK2_TB + 8 <= n;
+// 0x80 in every byte of w that equals the byte repeated in c4 (exact: no carry crosses a byte)
+__device__ __forceinline__ uint32_t tok_eq_flags(uint32_t w, uint32_t c4) {
+    const uint32_t x = w ^ c4, k7 = 0x7F7F7F7Fu;
+    return ~(((x & k7) + k7) | x | k7);
+}
+
+// What a thread knows about its TOK2_TB bytes: the TAB and newline bits (bit j = byte base + j), the bytes themselves and
+// the 8 after them (when they all exist: `wide`), and whether they have the EVERYDAY SHAPE `pat`:
+//     [not TAB, not newline]{phi}  (TAB g s g){8}  e        phi = 0 .. 3;  g s g one of d/d d|d ./. .|.;  e a TAB, ':' or newline
+// i.e. 32 bytes inside the sample columns of one line with eight everyday genotypes beginning in them.  The shape is
+// recognised from the bytes, not from the masks: phi from the first dword's TAB flags, then the ten dwords are realigned so that
+// every genotype is one dword [TAB g s g] (v_alignbyte_b32) and checked whole -- a digit is a byte whose high nibble is 3 both as
+// it is and after + 6 (a byte that wraps loses its 3, so a carry into the next byte only ever follows a failure);
+// the code (first allele << 4 | second) comes out of two shifts in byte 1 and four of them are packed by three v_perm_b32.  A
+// thread with the shape has tabs = 0x11111111 << phi and no newline BY CONSTRUCTION, and `codes` holds its eight HPGV8 bytes; any
+// other thread computes the masks exactly (SWAR zero-byte test + multiply gather, 3 quarter-rate multiplies per 8 bytes and
+// character: what every thread used to pay).  Whether the codes may be stored is the state's business (tok_parse_tile).
+struct TokThread { uint32_t tabs, nls; uint64_t w[TOK2_NW]; bool wide, pat; uint64_t codes; };
+
+__device__ __forceinline__ bool tok_pattern(const uint64_t (&w)[TOK2_NW], int *phi_out, uint64_t *codes) {
+    uint32_t d[2 * TOK2_NW];
+#pragma unroll
+    for (int k = 0; k < TOK2_NW; ++k) { d[2 * k] = (uint32_t)w[k]; d[2 * k + 1] = (uint32_t)(w[k] >> 32); }
+    const uint32_t zt = tok_eq_flags(d[0], 0x09090909u), zn = tok_eq_flags(d[0], 0x0A0A0A0Au);
+    const uint32_t below = (zt & (0u - zt)) - 1u;                     // the bits below the first TAB's flag
+    const int phi = ((__ffs((int)zt) - 1) >> 3) & 3;
+    // no branch and one verdict at the end: what is wrong with any of the eight genotypes is OR-ed into `wrong` (under M: the TAB byte
+    // and the high nibbles of the allele bytes), the separators are OR-ed and AND-ed -- all '/' (0 after the XOR) or all '|' (0x53);
+    // a thread that mixes the two walks.  "./." and ".|." become the pseudo-digits 0x3F: the code byte comes out 0xFF by itself, and
+    // '.' + 6 = 0x34 passes the second digit test, which is taken on the bytes as they were.
+    constexpr uint32_t C = 0x302F3009u, M = 0xF000F0FFu;
+    uint32_t wrong = 0, sep_and = 0xFFFFFFFFu;
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t a = __builtin_amdgcn_alignbyte(d[k + 1], d[k], (uint32_t)phi);      // [TAB g s g]
+        const uint32_t kd = (a & 0xFF00FF00u) == 0x2E002E00u ? 0x11001100u : 0u;
+        const uint32_t x = a ^ kd ^ C;                                 // allele bytes 0 .. 9 (15: '.'), TAB byte 0, separator 0 or 0x53
+        const uint32_t t = a + 0x06000600u;                            // '0' .. '9' + 6 stays 0x3?; so does 0x2A .. 0x2F, which x catches
+        wrong |= x | (t ^ C);
+        sep_and &= x;
+        v[k] = (x << 4) | (x >> 16);                                   // byte 1: first allele << 4 | second allele
+    }
+    const uint32_t e = __builtin_amdgcn_alignbyte(d[9], d[8], (uint32_t)phi) & 0xFFu;       // what ends the eighth genotype
+    const uint32_t so = wrong & 0x00FF0000u, sa = sep_and & 0x00FF0000u;
+    const bool ok = (zt != 0) & ((zn & below) == 0) & ((wrong & M) == 0) & ((so == 0) | ((so == 0x00530000u) & (sa == 0x00530000u))) &
+                    ((e == '\t') | (e == ':') | (e == '\n'));
+    const uint32_t lo = __builtin_amdgcn_perm(v[1], v[0], 0x0C0C0501u) | __builtin_amdgcn_perm(v[3], v[2], 0x05010C0Cu);
+    const uint32_t hi = __builtin_amdgcn_perm(v[5], v[4], 0x0C0C0501u) | __builtin_amdgcn_perm(v[7], v[6], 0x05010C0Cu);
+    *codes = ((uint64_t)hi << 32) | lo;
+    *phi_out = phi;
+    return ok;
+}
+
+__device__ __forceinline__ void tok_read(const char *__restrict__ t, size_t base, size_t n, TokThread &T) {
+    T.wide = base + TOK2_TB + 8 <= n;
+    T.pat = false; T.codes = 0;
     uint32_t a = 0, b = 0;
-    if (*wide) {
+    if (T.wide) {
 #pragma unroll
-        for (int k = 0; k < TOK2_NW; ++k) __builtin_memcpy(&w[k], t + base + 8 * k, 8);
+        for (int k = 0; k < TOK2_NW; ++k) __builtin_memcpy(&T.w[k], t + base + 8 * k, 8);
+        int phi;
+        T.pat = tok_pattern(T.w, &phi, &T.codes);
+        if (T.pat) a = 0x11111111u << phi;
+        else {
 #pragma unroll
-        for (int k = 0; k < TOK2_TB / 8; ++k) { a |= tok_byte_mask(w[k], '\t') << (8 * k); b |= tok_byte_mask(w[k], '\n') << (8 * k); }
+            for (int k = 0; k < TOK2_TB / 8; ++k) { a |= tok_byte_mask(T.w[k], '\t') << (8 * k); b |= tok_byte_mask(T.w[k], '\n') << (8 * k); }
+        }
     } else {
 #pragma unroll
-        for (int k = 0; k < TOK2_NW; ++k) w[k] = 0;
+        for (int k = 0; k < TOK2_NW; ++k) T.w[k] = 0;
         for (int j = 0; j < TOK2_TB; ++j)
             if (base + j < n) { const char c = t[base + j]; if (c == '\t') a |= 1u << j; else if (c == '\n') b |= 1u << j; }
     }
-    *tabs = a; *nls = b;
+    T.tabs = a; T.nls = b;
+}
+// the counting sweep's view of the same bytes: newlines, the TABs behind the last newline (all the TABs when there is none) and
+// that newline's bit (-1).  Flags stay where the SWAR test leaves them (0x80 per byte) and are only counted -- 6 operations per
+// dword and character, no gather; a thread that does hold a newline (one in 1 250 at 10 k samples) takes the exact masks
+__device__ __forceinline__ void tok_count_thread(const char *__restrict__ t, size_t base, size_t n, int *nl, int *tabs_after, int *last_bit) {
+    uint32_t tabs = 0, nls = 0;
+    if (base + TOK2_TB <= n) {
+        uint32_t d[TOK2_TB / 4];
+        __builtin_memcpy(d, t + base, TOK2_TB);
+        int ct = 0; uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < TOK2_TB / 4; ++k) { ct += __popc(tok_eq_flags(d[k], 0x09090909u)); any |= tok_eq_flags(d[k], 0x0A0A0A0Au); }
+        if (any == 0) { *nl = 0; *tabs_after = ct; *last_bit = -1; return; }
+#pragma unroll
+        for (int k = 0; k < TOK2_TB / 8; ++k) {
+            const uint64_t w = ((uint64_t)d[2 * k + 1] << 32) | d[2 * k];
+            tabs |= tok_byte_mask(w, '\t') << (8 * k); nls |= tok_byte_mask(w, '\n') << (8 * k);
+        }
+    } else {
+        for (int j = 0; j < TOK2_TB; ++j)
+            if (base + j < n) { const char c = t[base + j]; if (c == '\t') tabs |= 1u << j; else if (c == '\n') nls |= 1u << j; }
+    }
+    *nl = __popc(nls);
+    *last_bit = *nl ? 31 - __clz((int)nls) : -1;
+    *tabs_after = *nl ? (*last_bit >= 31 ? 0 : __popc(tabs >> (*last_bit + 1))) : __popc(tabs);
 }
 // TABs behind bit `last` (the thread's last newline): a shift by 32 is not a shift
 __device__ __forceinline__ int tok_tabs_after(uint32_t tabs, int last) { return last >= 31 ? 0 : __popc(tabs >> (last + 1)); }
 
+// one lane-shift of a wave scan as a DPP move (one instruction per value; a lane without a source keeps `identity`):
+// row_shr:1/2/4/8 inside the rows of 16 lanes, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3; wave_shr:1 for
+// the exclusive value
+template <int CTRL, int ROWS> __device__ __forceinline__ int tok_dpp(int identity, int v) {
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROWS, 0xF, false);
+}
+#define TOK_RFL(x) __builtin_amdgcn_readfirstlane(x)                  // a value every lane holds alike, into a scalar register
+#define TOK_SCAN_STEPS(STEP) STEP(0x111, 0xF) STEP(0x112, 0xF) STEP(0x114, 0xF) STEP(0x118, 0xF) STEP(0x142, 0xA) STEP(0x143, 0xC)
+
 static __global__ __launch_bounds__(256) void k_tok_count2(const char *__restrict__ text, size_t n, TokAgg *__restrict__ agg) {
     __shared__ int s_nl[4], s_last[4], s_tabs[4];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t base = (size_t)blockIdx.x * TOK2_TILE + (size_t)tid * TOK2_TB;
-    uint32_t tabs, nls; uint64_t ww[TOK2_NW]; bool wide;
-    tok_masks(text, base, n, &tabs, &nls, ww, &wide);
-    const int nl = __popc(nls);
-    const int last_bit = nl ? 31 - __clz((int)nls) : -1;
-    const int tabs_after = nl ? tok_tabs_after(tabs, last_bit) : __popc(tabs);
-    // the last thread of the workgroup that holds a newline
-    int c = nl, key = nl ? tid : -1;
-    for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off); const int k2 = __shfl_xor(key, off); key = k2 > key ? k2 : key; }
-    if (lane == 0) { s_nl[w] = c; s_last[w] = key; }
+    int nl, tabs_after, last_bit;                                     // tabs_after: all the thread's TABs when it holds no newline
+    tok_count_thread(text, base, n, &nl, &tabs_after, &last_bit);
+    const int all_tabs = nl ? 0 : tabs_after;                         // (only asked of threads behind the tile's last newline: they hold none)
+    // the last thread of the workgroup that holds a newline, and how many newlines there are: a wave without one (19 of 20 at 10 k
+    // samples) knows from its ballot; sums over the wave are DPP scans (the total arrives in lane 63)
+    const unsigned long long has = __ballot(nl != 0);
+    int c = 0;
+    if (has) {
+        c = nl;
+#define TOK_STEP_C(CTRL, ROWS) c += tok_dpp<CTRL, ROWS>(0, c);
+        TOK_SCAN_STEPS(TOK_STEP_C)
+#undef TOK_STEP_C
+    }
+    if (lane == 63) { s_nl[w] = c; s_last[w] = has ? w * 64 + 63 - __clzll(has) : -1; }
     __syncthreads();
-    const int tlast = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
-    int mine = tid > tlast ? __popc(tabs) : (tid == tlast ? tabs_after : 0);
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
-    if (lane == 0) s_tabs[w] = mine;
+    const int tlast = __builtin_amdgcn_readfirstlane(max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3])));
+    int mine = tid > tlast ? all_tabs : (tid == tlast ? tabs_after : 0);
+#define TOK_STEP_M(CTRL, ROWS) mine += tok_dpp<CTRL, ROWS>(0, mine);
+    TOK_SCAN_STEPS(TOK_STEP_M)
+#undef TOK_STEP_M
+    if (lane == 63) s_tabs[w] = mine;
     __syncthreads();
     if (tid == (tlast < 0 ? 0 : tlast)) {                             // one thread writes the whole record
         TokAgg a;
@@ -118,26 +216,46 @@ static __global__ __launch_bounds__(TOK_SCAN_THREADS) void k_tok_scan2a(const To
     if (tid == TOK_SCAN_THREADS - 1) group_total[blockIdx.x] = tok_fold(st, me);
 }
 
+// the fold of the first `count` group totals onto the text's start, by the whole workgroup (the same value in every thread):
+// a thousand totals per round, a wave scan by shuffles and the 16 wave totals through LDS
+__device__ __forceinline__ TokState tok_fold_groups(const TokState *__restrict__ group_total, int count, int *w_lines, int *w_tabs, long long *w_ls) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    TokState c = {0, 0, 0};                                          // the text's start begins a line
+    for (int g0 = 0; g0 < count; g0 += TOK_SCAN_THREADS) {
+        TokState inc = {0, 0, -1};
+        if (g0 + tid < count) inc = group_total[g0 + tid];
+        for (int off = 1; off < 64; off <<= 1) {
+            TokState o; o.lines = __shfl_up(inc.lines, off); o.tabs = __shfl_up(inc.tabs, off); o.ls = __shfl_up(inc.ls, off);
+            if (lane >= off) inc = tok_fold(o, inc);
+        }
+        if (lane == 63) { w_lines[w] = inc.lines; w_tabs[w] = inc.tabs; w_ls[w] = inc.ls; }
+        __syncthreads();
+        for (int k = 0; k < TOK_SCAN_THREADS / 64; ++k) { const TokState o = {w_lines[k], w_tabs[k], w_ls[k]}; c = tok_fold(c, o); }
+        __syncthreads();
+    }
+    return c;
+}
+
 static __global__ __launch_bounds__(TOK_SCAN_THREADS) void k_tok_scan2b(TokPre *__restrict__ pre, int n_tiles, TokState *__restrict__ group_total,
                                                                       int n_groups, const char *__restrict__ text, size_t n,
-                                                                      int *__restrict__ n_lines, unsigned long long *__restrict__ line_off, int max_lines) {
-    // grid-stride over the groups' totals would need a second scan; n_groups = n_tiles / 1024 is small (150 for 640 MB of text),
-    // so thread 0 of workgroup 0 folds them, and every workgroup then fixes up its own group
-    __shared__ TokState base;
-    if (threadIdx.x == 0) {
-        TokState c = {0, 0, 0};
-        for (int k = 0; k < (int)blockIdx.x && k < n_groups; ++k) c = tok_fold(c, group_total[k]);
-        base = c;
-        if (blockIdx.x == 0) {
-            TokState all = c;
-            for (int k = 0; k < n_groups; ++k) all = tok_fold(all, group_total[k]);
+                                                                      int *__restrict__ n_lines, unsigned long long *__restrict__ line_off, int max_lines,
+                                                                      int *__restrict__ redo_n) {
+    // every workgroup folds the totals of the groups in front of its own (n_groups = n_tiles / 1024: 77 for 640 MB of text) and
+    // fixes up its group; workgroup 0 folds them all for the line count (one thread doing this took 11 us per call)
+    __shared__ int w_lines[TOK_SCAN_THREADS / 64], w_tabs[TOK_SCAN_THREADS / 64];
+    __shared__ long long w_ls[TOK_SCAN_THREADS / 64];
+    const int mine = (int)blockIdx.x < n_groups ? (int)blockIdx.x : n_groups;
+    const TokState base = tok_fold_groups(group_total, mine, w_lines, w_tabs, w_ls);
+    if (blockIdx.x == 0) {
+        const TokState all = tok_fold_groups(group_total, n_groups, w_lines, w_tabs, w_ls);
+        if (threadIdx.x == 0) {
             const int tail = (n > 0 && text[n - 1] != '\n') ? 1 : 0;      // unterminated last line
             *n_lines = all.lines + tail;
             if (tail && all.lines + 1 <= max_lines) line_off[all.lines + 1] = n;
             if (n == 0) line_off[0] = 0;
+            if (redo_n) *redo_n = 0;                                 // (k_tok_parse2 runs behind this kernel)
         }
     }
-    __syncthreads();
     const int i = blockIdx.x * TOK_SCAN_THREADS + threadIdx.x;
     if (i < n_tiles) {
         const TokPre q = pre[i];
@@ -179,33 +297,25 @@ __device__ __forceinline__ void tok_close_line(const char *__restrict__ t, int l
     if (status) status[line] = ntab < 9 ? 1 : (gtpos < 0 ? 2 : (ntab - 8 < n_samples ? 3 : 0));
 }
 
-// one lane-shift of a wave scan as a DPP move (one instruction per value; a lane without a source keeps `identity`):
-// row_shr:1/2/4/8 inside the rows of 16 lanes, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3; wave_shr:1 for
-// the exclusive value
-template <int CTRL, int ROWS> __device__ __forceinline__ int tok_dpp(int identity, int v) {
-    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROWS, 0xF, false);
-}
-#define TOK_SCAN_STEPS(STEP) STEP(0x111, 0xF) STEP(0x112, 0xF) STEP(0x114, 0xF) STEP(0x118, 0xF) STEP(0x142, 0xA) STEP(0x143, 0xC)
-
 // what a tile's parse writes
 struct TokOut {
     int max_lines, n_samples, strict;
     uint8_t *gt; size_t pitch; uint8_t *is_x;
     unsigned long long *line_off; uint32_t *field_off; int *status;
-    int *redo;                                                        // per line: 1 = parse again line by line
+    int *redo, *redo_n;                                               // the lines to parse again line by line: a list and its length
 };
 struct TokShared { int s_f[4], s_v[4], s_n[4], s_d[4], s_g[4]; unsigned long long s_p[4]; };
 
 // One tile (TOK2_TILE bytes from tile_base) parsed by the workgroup: P = the state at the tile's first byte, (tabs, nls, ww, wide) =
-// tok_masks of this thread's bytes.  Two workgroup barriers; the shared arrays may be used again right after the call.
+// tok_read of this thread's bytes.  Two workgroup barriers; the shared arrays may be used again right after the call.
 __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const size_t n, const size_t tile_base, const bool first_tile, const TokPre P,
-                                               uint32_t tabs, uint32_t nls, const uint64_t (&ww)[TOK2_NW], const bool wide, TokShared &S, const TokOut &O) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+                                               const TokThread &T, TokShared &S, const TokOut &O) {
+    const uint32_t tabs = T.tabs, nls = T.nls; const uint64_t (&ww)[TOK2_NW] = T.w; const bool wide = T.wide;
+    const int tid = threadIdx.x, lane = tid & 63, w = TOK_RFL(tid >> 6);
     const size_t base = tile_base + (size_t)tid * TOK2_TB;
     const int max_lines = O.max_lines, n_samples = O.n_samples, strict = O.strict;
     uint8_t *__restrict__ gt = O.gt; const size_t pitch = O.pitch; uint8_t *__restrict__ is_x = O.is_x;
     unsigned long long *__restrict__ line_off = O.line_off; uint32_t *__restrict__ field_off = O.field_off; int *__restrict__ status = O.status;
-    int *__restrict__ redo = O.redo;
     int (&s_f)[4] = S.s_f, (&s_v)[4] = S.s_v, (&s_n)[4] = S.s_n, (&s_d)[4] = S.s_d, (&s_g)[4] = S.s_g;
     unsigned long long (&s_p)[4] = S.s_p;
 
@@ -214,26 +324,46 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
     const int gt0 = P.tabs >= 8 ? 0 : TOK_GT_UNDEF;
 
     // ---- scan A: (line, TABs since the line began, where it began) at every thread's first byte --------------------------
-    const int nl = __popc(nls);
-    const int last_bit = nl ? 31 - __clz((int)nls) : -1;
-    int f = nl ? 1 : 0, v = nl ? tok_tabs_after(tabs, last_bit) : __popc(tabs), cn = nl;
-    unsigned long long p = nl ? (unsigned long long)(base + last_bit + 1) : 0ull;
-    int plo = (int)(uint32_t)p, phi = (int)(uint32_t)(p >> 32);
+    // A wave without a newline (19 of 20 at 10 k samples) only adds up its TABs: one DPP addition per step instead of five moves and
+    // their selects.  (The branch is uniform: the ballot is the wave's.)
+    int f, v, cn, ef, ev, en;
+    unsigned long long p, ep;
+    if (__ballot(nls != 0) == 0) {
+        f = 0; cn = 0; p = 0; ef = 0; en = 0; ep = 0;
+        v = __popc(tabs);
+#define TOK_STEP_A0(CTRL, ROWS) v += tok_dpp<CTRL, ROWS>(0, v);
+        TOK_SCAN_STEPS(TOK_STEP_A0)
+#undef TOK_STEP_A0
+        ev = tok_dpp<0x138, 0xF>(0, v);
+    } else {
+        const int nl = __popc(nls);
+        const int last_bit = nl ? 31 - __clz((int)nls) : -1;
+        f = nl ? 1 : 0; v = nl ? tok_tabs_after(tabs, last_bit) : __popc(tabs); cn = nl;
+        p = nl ? (unsigned long long)(base + last_bit + 1) : 0ull;
+        int plo = (int)(uint32_t)p, phi = (int)(uint32_t)(p >> 32);
 #define TOK_STEP_A(CTRL, ROWS) {                                                                                          \
         const int f2 = tok_dpp<CTRL, ROWS>(0, f), v2 = tok_dpp<CTRL, ROWS>(0, v), n2 = tok_dpp<CTRL, ROWS>(0, cn);         \
         const int l2 = tok_dpp<CTRL, ROWS>(0, plo), h2 = tok_dpp<CTRL, ROWS>(0, phi);                                       \
         if (!f) { v += v2; plo = l2; phi = h2; }                                                                           \
         f |= f2; cn += n2; }
-    TOK_SCAN_STEPS(TOK_STEP_A)                                       // inclusive, within the wave
+        TOK_SCAN_STEPS(TOK_STEP_A)                                   // inclusive, within the wave
 #undef TOK_STEP_A
-    p = ((unsigned long long)(uint32_t)phi << 32) | (uint32_t)plo;
+        p = ((unsigned long long)(uint32_t)phi << 32) | (uint32_t)plo;
+        ef = tok_dpp<0x138, 0xF>(0, f); ev = tok_dpp<0x138, 0xF>(0, v); en = tok_dpp<0x138, 0xF>(0, cn);         // exclusive within the wave
+        ep = ((unsigned long long)(uint32_t)tok_dpp<0x138, 0xF>(0, phi) << 32) | (uint32_t)tok_dpp<0x138, 0xF>(0, plo);
+    }
     if (lane == 63) { s_f[w] = f; s_v[w] = v; s_p[w] = p; s_n[w] = cn; }
-    const int ef = tok_dpp<0x138, 0xF>(0, f), ev = tok_dpp<0x138, 0xF>(0, v), en = tok_dpp<0x138, 0xF>(0, cn);      // exclusive within the wave
-    const unsigned long long ep = ((unsigned long long)(uint32_t)tok_dpp<0x138, 0xF>(0, phi) << 32) | (uint32_t)tok_dpp<0x138, 0xF>(0, plo);
     __syncthreads();
     int bv = P.tabs, bn = P.lines;                                   // state at the wave's first byte
     unsigned long long bp = P.line_start;
-    for (int k = 0; k < w; ++k) { if (s_f[k]) { bv = s_v[k]; bp = s_p[k]; } else bv += s_v[k]; bn += s_n[k]; }
+    for (int k = 0; k < w; ++k) {                                    // (the waves in front of this one: values every lane reads alike)
+        const int kf = TOK_RFL(s_f[k]), kv = TOK_RFL(s_v[k]), kn = TOK_RFL(s_n[k]);
+        if (kf) {
+            bv = kv;
+            bp = ((unsigned long long)(uint32_t)TOK_RFL((int)(s_p[k] >> 32)) << 32) | (uint32_t)TOK_RFL((int)(uint32_t)s_p[k]);
+        } else bv += kv;
+        bn += kn;
+    }
     int line = bn + en, ntab = ef ? ev : bv + ev;
     size_t ls = (size_t)(ef ? ep : bp);
 
@@ -241,7 +371,9 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
     //      8th TAB (FORMAT begins: parsed by the thread that holds it; at most one per 16 bytes) ---------------------------
     int d = 0, g = TOK_GT_UNDEF, g8 = TOK_GT_UNDEF;
     bool fmt_here = false;
-    if (nls != 0 || (ntab < 8 && ntab + __popc(tabs) >= 8)) {        // (most threads hold neither a newline nor a line's 8th TAB)
+    const bool events = nls != 0 || (ntab < 8 && ntab + __popc(tabs) >= 8);
+    const bool wave_events = __ballot(events) != 0;                    // (uniform; most waves hold neither a newline nor a line's 8th TAB)
+    if (events) {
         uint32_t m = tabs | nls;
         int k = ntab;
         while (m) {
@@ -251,19 +383,22 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
             else if (++k == 8) { g8 = tok_format_gtpos(t, base + j + 1, n); d = 1; g = g8; fmt_here = true; }
         }
     }
+    int ed = 0, eg = TOK_GT_UNDEF;
+    if (wave_events) {
 #define TOK_STEP_B(CTRL, ROWS) {                                                                                          \
         const int d2 = tok_dpp<CTRL, ROWS>(0, d), g2 = tok_dpp<CTRL, ROWS>(0, g);                                          \
         if (!d) g = g2;                                                                                                    \
         d |= d2; }
-    TOK_SCAN_STEPS(TOK_STEP_B)
+        TOK_SCAN_STEPS(TOK_STEP_B)
 #undef TOK_STEP_B
+        ed = tok_dpp<0x138, 0xF>(0, d);
+        eg = tok_dpp<0x138, 0xF>(0, g);
+        if (lane == 0) eg = TOK_GT_UNDEF;
+    }
     if (lane == 63) { s_d[w] = d; s_g[w] = g; }
-    const int ed = tok_dpp<0x138, 0xF>(0, d);
-    int eg = tok_dpp<0x138, 0xF>(0, g);
-    if (lane == 0) eg = TOK_GT_UNDEF;
     __syncthreads();
     int bg = gt0;
-    for (int k = 0; k < w; ++k) if (s_d[k]) bg = s_g[k];
+    for (int k = 0; k < w; ++k) if (TOK_RFL(s_d[k])) bg = TOK_RFL(s_g[k]);
     int gtpos = ed ? eg : bg;
 
     // ---- the walk: every TAB and newline of the thread's bytes, in order ----------------------------------------------
@@ -272,36 +407,14 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
         if (field_off && max_lines > 0) field_off[0] = 0;
     }
     // ---- the everyday stretch: 32 bytes inside the sample columns of one line, a TAB every fourth byte (genotypes of the form
-    //      d/d, d|d or ./.), GT first: the eight genotypes that begin here are taken out of the thread's words in one go --
-    //      the window is shifted so that they lie dword by dword, each is checked and encoded, and the eight codes leave as
-    //      one 8-byte store.  Anything else about the thread's bytes sends it through the walk below.
+    //      d/d, d|d, ./. or .|.): tok_read has recognised the shape and encoded the eight genotypes that begin here; with GT first
+    //      in FORMAT and all eight samples inside the row they leave as one 8-byte store.  Anything else walks.
     bool everyday = false;
-    if (wide && nls == 0 && tabs != 0 && ntab >= 9 && gtpos == 0 && line < max_lines) {
-        const int phi = __ffs((int)tabs) - 1;
+    if (T.pat && ntab >= 9 && gtpos == 0 && line < max_lines) {
         const int s0 = ntab - 8;                                       // the sample whose field begins after the first TAB
-        if (phi < 4 && tabs == (0x11111111u << phi) && s0 + 8 <= n_samples) {
-            const int sh = 8 * (phi + 1);                              // 8 .. 32: the first field begins at byte phi + 1
-            uint64_t out = 0;
-            bool all_ok = true;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint64_t a = (ww[k] >> sh) | (ww[k + 1] << (64 - sh));
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const uint32_t q = (uint32_t)(a >> (32 * h));
-                    const uint32_t b0 = q & 0xFF, b1 = (q >> 8) & 0xFF, b2 = (q >> 16) & 0xFF, b3 = q >> 24;
-                    const uint32_t d0 = b0 - '0', d1 = b2 - '0';
-                    const bool form = (b1 == '/' || b1 == '|') && (b3 == '\t' || b3 == ':' || b3 == '\n');
-                    const bool digits = d0 <= 9 && d1 <= 9, dots = b0 == '.' && b2 == '.';
-                    all_ok = all_ok && form && (digits || dots);
-                    const uint32_t code = dots ? 0xFFu : ((d0 << 4) | d1) & 0xFFu;
-                    out |= (uint64_t)code << (8 * (2 * k + h));
-                }
-            }
-            if (all_ok) {
-                __builtin_memcpy(gt + (size_t)line * pitch + s0, &out, 8);
-                everyday = true;
-            }
+        if (s0 + 8 <= n_samples) {
+            __builtin_memcpy(gt + (size_t)line * pitch + s0, &T.codes, 8);
+            everyday = true;
         }
     }
     uint32_t m = everyday ? 0u : (tabs | nls);
@@ -317,7 +430,7 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
                 is_x[line] = (clen == 0 || (clen == 1 && t[ls] == 'X')) ? 1 : 0;
             }
             if (ntab <= 9 && ok_line && field_off) field_off[(size_t)line * 10 + ntab] = (uint32_t)(pos + 1 - ls);
-            if (ntab == 8) { gtpos = g8; if (fmt_here && g8 != 0 && ok_line) redo[line] = 1; }      // later tiles assumed GT first
+            if (ntab == 8) { gtpos = g8; if (fmt_here && g8 != 0 && ok_line) O.redo[atomicAdd(O.redo_n, 1)] = line; }      // later tiles assumed GT first (one thread per line: no line is listed twice)
             if (ntab >= 9 && ok_line && gtpos >= 0) {
                 const int sample = ntab - 9;
                 if (sample < n_samples) {
@@ -356,13 +469,13 @@ static __global__ __launch_bounds__(256) void k_tok_parse2(const char *__restric
                                                     int max_lines, int n_samples, int strict, uint8_t *__restrict__ gt, size_t pitch,
                                                     uint8_t *__restrict__ is_x, unsigned long long *__restrict__ line_off,
                                                     uint32_t *__restrict__ field_off, int *__restrict__ status,
-                                                    int *__restrict__ redo /* per line: 1 = parse again line by line */) {
+                                                    int *__restrict__ redo, int *__restrict__ redo_n /* the lines to parse again line by line */) {
     __shared__ TokShared S;
     const size_t tile_base = (size_t)blockIdx.x * TOK2_TILE;
-    uint32_t tabs, nls; uint64_t ww[TOK2_NW]; bool wide;
-    tok_masks(text, tile_base + (size_t)threadIdx.x * TOK2_TB, n, &tabs, &nls, ww, &wide);
-    const TokOut O = {max_lines, n_samples, strict, gt, pitch, is_x, line_off, field_off, status, redo};
-    tok_parse_tile(text, n, tile_base, blockIdx.x == 0, pre[blockIdx.x], tabs, nls, ww, wide, S, O);
+    TokThread T;
+    tok_read(text, tile_base + (size_t)threadIdx.x * TOK2_TB, n, T);
+    const TokOut O = {max_lines, n_samples, strict, gt, pitch, is_x, line_off, field_off, status, redo, redo_n};
+    tok_parse_tile(text, n, tile_base, blockIdx.x == 0, pre[blockIdx.x], T, S, O);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -422,7 +535,7 @@ static __global__ __launch_bounds__(256) void k_tok_parse3(const char *__restric
                                                     int *__restrict__ err, int *__restrict__ n_lines,
                                                     int max_lines, int n_samples, int strict, uint8_t *__restrict__ gt, size_t pitch,
                                                     uint8_t *__restrict__ is_x, unsigned long long *__restrict__ line_off,
-                                                    uint32_t *__restrict__ field_off, int *__restrict__ status, int *__restrict__ redo) {
+                                                    uint32_t *__restrict__ field_off, int *__restrict__ status, int *__restrict__ redo, int *__restrict__ redo_n) {
     __shared__ TokShared S;
     __shared__ int s_nl[TOK3_TILES][4], s_last[TOK3_TILES][4], s_tabs[TOK3_TILES][4];
     __shared__ unsigned s_seg;
@@ -440,16 +553,14 @@ static __global__ __launch_bounds__(256) void k_tok_parse3(const char *__restric
     if (seg_base >= n) return;                                       // (the grid is exact: cannot happen)
 
     // ---- 1. the segment's bytes (once) and its tiles' aggregates -------------------------------------------------------
-    uint32_t tabs[TOK3_TILES], nls[TOK3_TILES];
-    uint64_t ww[TOK3_TILES][TOK2_NW];
-    bool wide[TOK3_TILES];
+    TokThread T[TOK3_TILES];
     int last_bit[TOK3_TILES];
 #pragma unroll
-    for (int k = 0; k < TOK3_TILES; ++k) tok_masks(text, seg_base + (size_t)k * TOK2_TILE + (size_t)tid * TOK2_TB, n, &tabs[k], &nls[k], ww[k], &wide[k]);
+    for (int k = 0; k < TOK3_TILES; ++k) tok_read(text, seg_base + (size_t)k * TOK2_TILE + (size_t)tid * TOK2_TB, n, T[k]);
 #pragma unroll
     for (int k = 0; k < TOK3_TILES; ++k) {
-        const int nl = __popc(nls[k]);
-        last_bit[k] = nl ? 31 - __clz((int)nls[k]) : -1;
+        const int nl = __popc(T[k].nls);
+        last_bit[k] = nl ? 31 - __clz((int)T[k].nls) : -1;
         int c = nl, key = nl ? tid : -1;
         for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off); const int k2 = __shfl_xor(key, off); key = k2 > key ? k2 : key; }
         if (lane == 0) { s_nl[k][w] = c; s_last[k][w] = key; }
@@ -459,7 +570,7 @@ static __global__ __launch_bounds__(256) void k_tok_parse3(const char *__restric
 #pragma unroll
     for (int k = 0; k < TOK3_TILES; ++k) {
         tlast[k] = max(max(s_last[k][0], s_last[k][1]), max(s_last[k][2], s_last[k][3]));
-        int mine = tid > tlast[k] ? __popc(tabs[k]) : (tid == tlast[k] ? tok_tabs_after(tabs[k], last_bit[k]) : 0);
+        int mine = tid > tlast[k] ? __popc(T[k].tabs) : (tid == tlast[k] ? tok_tabs_after(T[k].tabs, last_bit[k]) : 0);
         for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
         if (lane == 0) s_tabs[k][w] = mine;
     }
@@ -550,14 +661,14 @@ static __global__ __launch_bounds__(256) void k_tok_parse3(const char *__restric
     }
 
     // ---- 3. the tiles ------------------------------------------------------------------------------------------------------
-    const TokOut O = {max_lines, n_samples, strict, gt, pitch, is_x, line_off, field_off, status, redo};
+    const TokOut O = {max_lines, n_samples, strict, gt, pitch, is_x, line_off, field_off, status, redo, redo_n};
 #pragma unroll
     for (int k = 0; k < TOK3_TILES; ++k) {
         const size_t tile_base = seg_base + (size_t)k * TOK2_TILE;
         if (tile_base >= n) break;                                   // (uniform)
         const TokState st = tok_fold(start, rel[k]);
         TokPre P; P.lines = st.lines; P.tabs = st.tabs; P.line_start = (unsigned long long)st.ls;
-        tok_parse_tile(text, n, tile_base, seg == 0 && k == 0, P, tabs[k], nls[k], ww[k], wide[k], S, O);
+        tok_parse_tile(text, n, tile_base, seg == 0 && k == 0, P, T[k], S, O);
     }
 }
 // the fused kernel's verdict: a look-back that gave up makes the line count -1 (the caller runs the two-sweep kernels instead)

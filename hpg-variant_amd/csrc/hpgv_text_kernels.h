@@ -153,18 +153,15 @@ __device__ __forceinline__ int block_excl_scan(int v, int *s4, int *total) {
 
 // status per line: 0 ok, 1 fewer than 9 TABs (no sample columns), 2 FORMAT has no GT,
 // 3 fewer sample fields than n_samples (the missing ones are 0xFF)
-static __global__ __launch_bounds__(256) void k_tok_parse(const char *__restrict__ text, const unsigned long long *__restrict__ line_off,
-                                                   const int *__restrict__ n_lines_p, int max_lines, int n_samples, int strict,
-                                                   uint8_t *__restrict__ gt, size_t pitch, uint8_t *__restrict__ is_x,
-                                                   uint32_t *__restrict__ field_off /* n_lines x 10 */, int *__restrict__ status,
-                                                   const int *__restrict__ only /* null: every line; else only lines with only[line] != 0 */) {
+// one line, by the whole workgroup (every `return` is the workgroup's)
+__device__ __forceinline__ void tok_parse_line(const int line, const char *__restrict__ text, const unsigned long long *__restrict__ line_off,
+                                               const int n_lines, int n_samples, int strict,
+                                               uint8_t *__restrict__ gt, size_t pitch, uint8_t *__restrict__ is_x,
+                                               uint32_t *__restrict__ field_off /* n_lines x 10 */, int *__restrict__ status) {
     __shared__ int s4[4];
     __shared__ unsigned int s_field[10];
     __shared__ int s_gtpos;
-    const int line = blockIdx.x;
-    const int n_lines = *n_lines_p < max_lines ? *n_lines_p : max_lines;
     if (line >= n_lines) return;
-    if (only != nullptr && only[line] == 0) return;
     const size_t ls = line_off[line];
     size_t le = line_off[line + 1];
     if (le > ls && text[le - 1] == '\n') le--;              // exclusive end, newline dropped
@@ -266,6 +263,28 @@ static __global__ __launch_bounds__(256) void k_tok_parse(const char *__restrict
     const int found = before - 8;                           // sample fields present on the line
     for (int j = (found < 0 ? 0 : found) + threadIdx.x; j < n_samples; j += 256) row[j] = 0xFF;
     if (threadIdx.x == 0 && status) status[line] = found < n_samples ? 3 : 0;
+}
+
+// every line, one workgroup each (the three-sweep form's parse)
+static __global__ __launch_bounds__(256) void k_tok_parse(const char *__restrict__ text, const unsigned long long *__restrict__ line_off,
+                                                   const int *__restrict__ n_lines_p, int max_lines, int n_samples, int strict,
+                                                   uint8_t *__restrict__ gt, size_t pitch, uint8_t *__restrict__ is_x,
+                                                   uint32_t *__restrict__ field_off, int *__restrict__ status) {
+    tok_parse_line((int)blockIdx.x, text, line_off, *n_lines_p < max_lines ? *n_lines_p : max_lines, n_samples, strict, gt, pitch, is_x, field_off, status);
+}
+// the LISTED lines only (the tile-parallel forms flag the lines whose FORMAT does not begin with GT: as a rule none), a fixed
+// grid striding over the list: an empty list costs a thousand workgroups that read one counter, not one workgroup per line
+static __global__ __launch_bounds__(256) void k_tok_parse_listed(const char *__restrict__ text, const unsigned long long *__restrict__ line_off,
+                                                          const int *__restrict__ n_lines_p, int max_lines, int n_samples, int strict,
+                                                          uint8_t *__restrict__ gt, size_t pitch, uint8_t *__restrict__ is_x,
+                                                          uint32_t *__restrict__ field_off, int *__restrict__ status,
+                                                          const int *__restrict__ list, const int *__restrict__ list_n) {
+    const int n_lines = *n_lines_p < max_lines ? *n_lines_p : max_lines;
+    const int n = *list_n < max_lines ? *list_n : max_lines;
+    for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
+        tok_parse_line(list[i], text, line_off, n_lines, n_samples, strict, gt, pitch, is_x, field_off, status);
+        __syncthreads();                                     // the line's shared arrays are written again by the next one
+    }
 }
 
 

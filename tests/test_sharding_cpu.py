@@ -151,3 +151,25 @@ def test_tile_plan_covers_every_variant_once(world, V, strong):
     assert all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
     if V == 10_000_000:                                   # the metric cohort: 4 / 2 / 1 / 1 tiles of <= 126 GB at 1 / 2 / 4 / 8 ranks
         assert plans[0]["n_tiles"] == {1: 4, 2: 2, 3: 2, 4: 1, 8: 1}[world]
+
+
+def test_whole_genome_config_is_tiled_per_rank():
+    """BASELINE configs[4] (40M SNP x 100k samples on 8 GPUs) as bench.py --workload c5full plans it: 5M variants per rank in four
+    tiles of at most 126 GB, every rank the same number of tiles, all variants covered once."""
+    import importlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    sharding = importlib.import_module("hpg-variant_amd.sharding")
+    kind, V, N, scaling, _ = bench.WORKLOADS["c5full"]
+    assert (kind, V, N, scaling) == ("chisq", 40_000_000, 100_000, "strong")
+    pitch = 100_016
+    seen = 0
+    for rank in range(8):
+        plan = sharding.plan_tiles(rank, 8, V, pitch, int(126e9), strong=True)
+        assert plan["n"] == 5_000_000 and plan["n_tiles"] == 4 and plan["per_tile"] * pitch <= 126e9
+        assert plan["v_lo"] == rank * 5_000_000
+        assert sum(hi - lo for lo, hi in plan["tiles"]) == plan["n"]
+        seen += plan["n"]
+    assert seen == V

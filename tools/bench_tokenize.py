@@ -25,6 +25,8 @@ for i in range(64):                                      # 64 distinct lines, re
 text = ("".join(lines) * (n_lines // 64)).encode()
 n_lines = (n_lines // 64) * 64
 e = hpgv.Engine(0)
+if os.environ.get("TOK_TILES"):                          # 1: two sweeps (default), 2: one sweep with look-back, 0: the three-sweep form
+    e.set_option("tokenizer_tiles", int(os.environ["TOK_TILES"]))
 dev = torch.device("cuda", 0)
 d_text = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
 pitch = n_samples
