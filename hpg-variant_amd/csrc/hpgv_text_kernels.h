@@ -112,8 +112,8 @@ __device__ __forceinline__ int tok_atoi(const char *__restrict__ t, size_t p, si
 // one sample field starting at p (line ends at e, exclusive): the product's statement of
 // get_alleles + the HPGV8 encoding (host twin: hpgv_host.c encode_gt)
 __device__ __forceinline__ uint32_t tok_encode(const char *__restrict__ t, size_t p, size_t e, int gt_position, int strict) {
-    size_t fe = p;                                      // end of this sample field
-    while (fe < e && t[fe] != '\t') fe++;
+    size_t fe = p;                                      // end of this sample field: the next TAB -- or a NUL byte before it: the
+    while (fe < e && t[fe] != '\t' && t[fe] != 0) fe++;  // reference's sample fields are C strings (vcf_record_t.samples), get_alleles stops there
     for (int i = 0; i < gt_position; ++i) {             // skip to the GT sub-field
         while (p < fe && t[p] != ':') p++;
         if (p >= fe) return 0xFFu;                      // sub-field absent: all alleles missing

@@ -470,6 +470,37 @@ def test_everyday_genotype_stretches_and_what_breaks_them(eng, strict):
     _check(eng, "\n".join(lines2) + "\n", n_samples, strict)
 
 
+@pytest.mark.parametrize("strict", [0, 1])
+def test_three_byte_fields_of_every_kind(eng, strict):
+    # the shape recogniser of the tile-parallel forms (tok_pattern) checks a genotype as one dword: [TAB g s g] with carries, XORs and
+    # nibble masks.  Every byte that could slip through such arithmetic is put into the three positions of otherwise everyday
+    # columns: the neighbours of the digits ('/' 0x2F, ':' 0x3A ... '?'), 0x2A .. 0x2F (which + 6 turns into 0x3?), bytes that wrap
+    # under + 6 (0xFA ..), bytes that differ from '/' or '|' in the separators' own bits (0x7C ^ 0x2F = 0x53), NUL, CR, and mixtures
+    # of '/' and '|' inside one stretch of eight.  The oracle's TAB-split + get_alleles says what each field is.
+    rng = np.random.default_rng(1234 + strict)
+    odd = bytes([0x00, 0x0D, 0x20, 0x2A, 0x2B, 0x2C, 0x2D, 0x2E, 0x2F, 0x30, 0x39, 0x3A, 0x3B, 0x3F, 0x40, 0x50, 0x52, 0x53, 0x54, 0x5C,
+                 0x6F, 0x7C, 0x7D, 0x7F, 0x80, 0xAE, 0xAF, 0xCA, 0xD0, 0xF9, 0xFA, 0xFB, 0xFF])
+    n_samples = 520
+    lines = []
+    for i in range(120):
+        cols = []
+        for j in range(n_samples):
+            a, b = b"0123456789"[int(rng.integers(0, 10))], b"0123456789"[int(rng.integers(0, 10))]
+            f = bytearray([a, b"/|"[int(rng.integers(0, 2)) if i % 3 == 0 else (i // 3) % 2], b])
+            if rng.random() < 0.02:
+                f = bytearray(b"./." if rng.random() < 0.5 else b".|.")
+            if rng.random() < 0.01 * (1 + i % 5):                   # one position gets an odd byte
+                f[int(rng.integers(0, 3))] = odd[int(rng.integers(0, len(odd)))]
+            if rng.random() < 0.002:                                 # all three do
+                f = bytearray(odd[int(k)] for k in rng.integers(0, len(odd), 3))
+            cols.append(bytes(f))
+        head = b"\t".join([b"X" if i % 7 == 0 else b"3", b"9", b"r", b"A", b"C", b"5", b"P", b"I" * (i % 37), b"GT"])
+        lines.append(head + b"\t" + b"\t".join(cols))
+    text = b"\n".join(lines) + (b"\n" if strict else b"")
+    got = _check(eng, text, n_samples, strict)
+    assert got["n_lines"] == len(lines)
+
+
 def test_bgzf_crc_check_on_the_gpu_against_zlib():
     # hpgv_bgzf_verify_dev: CRC-32 of every decoded block against its BGZF trailer (a damaged stream can inflate to
     # ISIZE bytes of the wrong text).  Lengths around every boundary of the kernel (the 0 - 3 bytes before the first aligned
