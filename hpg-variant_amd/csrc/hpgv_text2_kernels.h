@@ -310,7 +310,7 @@ struct TokShared { int s_f[4], s_v[4], s_n[4], s_d[4], s_g[4]; unsigned long lon
 // tok_read of this thread's bytes.  Two workgroup barriers; the shared arrays may be used again right after the call.
 __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const size_t n, const size_t tile_base, const bool first_tile, const TokPre P,
                                                const TokThread &T, TokShared &S, const TokOut &O) {
-    const uint32_t tabs = T.tabs, nls = T.nls; const uint64_t (&ww)[TOK2_NW] = T.w; const bool wide = T.wide;
+    const uint32_t tabs = T.tabs, nls = T.nls;
     const int tid = threadIdx.x, lane = tid & 63, w = TOK_RFL(tid >> 6);
     const size_t base = tile_base + (size_t)tid * TOK2_TB;
     const int max_lines = O.max_lines, n_samples = O.n_samples, strict = O.strict;
@@ -417,7 +417,81 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
             everyday = true;
         }
     }
-    uint32_t m = everyday ? 0u : (tabs | nls);
+    // ---- everything else: the thread's TABs and newlines BY KIND.  What a TAB or a newline does depends on (line, TABs so far, line
+    //      start, GT position) at its byte, and all four follow from the thread's start state and its two masks without walking: so
+    //      the sample TABs, the header TABs (a line's first nine) and the newlines get a loop each, every one with a short body of its
+    //      own.  One loop over all of them in order ran every body in every round of a wave that holds all three kinds -- and at 200
+    //      samples every wave does: 1 390 vector instructions per wave, 97 % of the issue rate (profiles/r03_tokenizer_pmc.json).
+    //      Only a thread with eight or more TABs behind its first newline (a second FORMAT inside the same 32 bytes: lines of empty
+    //      fields) walks in order, as before.
+    const uint32_t m_all = everyday ? 0u : (tabs | nls);
+    const int n_nl = __popc(nls);
+    const uint32_t seg0 = n_nl ? ((1u << (__ffs((int)nls) - 1)) - 1u) : 0xFFFFFFFFu;      // the bits in front of the first newline
+    const bool in_order = n_nl != 0 && __popc(tabs & ~seg0) >= 8;
+    if (m_all != 0 && !in_order) {
+        const uint32_t t0 = tabs & seg0;                             // the TABs of the line in progress
+        const int gt_seg0 = ntab >= 8 ? gtpos : (fmt_here ? g8 : TOK_GT_UNDEF);            // that line's GT position once its FORMAT has gone by
+        uint32_t ts = t0;                                            // its sample TABs: from the line's ninth TAB on
+        for (int drop = 8 - ntab; drop > 0 && ts; --drop) ts &= ts - 1;
+        uint32_t th = tabs & ~ts;                                    // header TABs: they set field offsets (the ninth is both)
+        if (ntab < 9) th |= ts & (0u - ts);
+        // -- sample fields
+        if (line < max_lines && gt_seg0 >= 0) {
+            uint8_t *row = gt + (size_t)line * pitch;
+            for (uint32_t m = ts; m; m &= m - 1) {
+                const int j = __ffs((int)m) - 1;
+                const int sample = ntab + __popc(t0 & ((2u << j) - 1u)) - 9;
+                if (sample >= n_samples) break;                      // (the samples only grow)
+                const size_t q0 = base + j + 1;
+                uint32_t code = 0x100u;                              // "not decided"
+                if (gt_seg0 == 0 && q0 + 4 <= n) {                   // the everyday forms, out of the four bytes behind the TAB
+                    uint32_t q;
+                    __builtin_memcpy(&q, t + q0, 4);
+                    const uint32_t b0 = q & 0xFF, b1 = (q >> 8) & 0xFF, b2 = (q >> 16) & 0xFF, b3 = q >> 24;
+                    if ((b1 == '/' || b1 == '|') && (b3 == '\t' || b3 == ':' || b3 == '\n')) {
+                        const uint32_t d0 = b0 - '0', d1 = b2 - '0';
+                        if (d0 <= 9 && d1 <= 9) code = (d0 << 4) | d1;
+                        else if (b0 == '.' && b2 == '.') code = 0xFFu;      // both alleles missing: 0xFF strict or not
+                    }
+                }
+                if (code == 0x100u) code = tok_encode_open(t, q0, n, gt_seg0, strict);
+                row[sample] = (uint8_t)code;
+            }
+        }
+        // -- header TABs: CHROM's end (chromosome "X": assoc.c:94), the field offsets, the FORMAT that does not begin with GT
+        for (uint32_t m = th; m; m &= m - 1) {
+            const int j = __ffs((int)m) - 1;
+            const uint32_t below = (1u << j) - 1u, nb = nls & below;
+            const int line_j = line + __popc(nb);
+            int ntab_j; size_t ls_j;
+            if (nb == 0) { ntab_j = ntab + __popc(tabs & below) + 1; ls_j = ls; }
+            else { const int last = 31 - __clz((int)nb); ntab_j = __popc(tabs & below & ~((2u << last) - 1u)) + 1; ls_j = base + last + 1; }
+            if (line_j >= max_lines) break;                          // (the lines only grow)
+            const size_t pos = base + j;
+            if (ntab_j == 1 && is_x) { const size_t clen = pos - ls_j; is_x[line_j] = (clen == 0 || (clen == 1 && t[ls_j] == 'X')) ? 1 : 0; }
+            if (field_off) field_off[(size_t)line_j * 10 + ntab_j] = (uint32_t)(pos + 1 - ls_j);
+            if (ntab_j == 8 && fmt_here && g8 != 0) O.redo[atomicAdd(O.redo_n, 1)] = line_j;      // later tiles assumed GT first (one thread per line: no line is listed twice)
+        }
+        // -- newlines: what a line's end settles, and where the next line begins
+        for (uint32_t m = nls; m; m &= m - 1) {
+            const int j = __ffs((int)m) - 1;
+            const uint32_t below = (1u << j) - 1u, nb = nls & below;
+            const int line_j = line + __popc(nb);
+            int ntab_j, g_j; size_t ls_j;
+            if (nb == 0) { ntab_j = ntab + __popc(tabs & below); ls_j = ls; g_j = gt_seg0; }
+            else { const int last = 31 - __clz((int)nb); ntab_j = __popc(tabs & below & ~((2u << last) - 1u)); ls_j = base + last + 1; g_j = TOK_GT_UNDEF; }
+            const size_t pos = base + j;
+            if (line_j < max_lines) tok_close_line(t, line_j, ntab_j, g_j, ls_j, pos, n_samples, gt, pitch, is_x, field_off, status);
+            if (line_j + 1 <= max_lines) line_off[line_j + 1] = pos + 1;
+            if (line_j + 1 < max_lines && pos + 1 < n && field_off) field_off[(size_t)(line_j + 1) * 10] = 0;
+        }
+    }
+    // the state behind the thread's last byte (all the unterminated last line needs)
+    if (!in_order) {
+        if (n_nl == 0) { gtpos = ntab >= 8 ? gtpos : (fmt_here ? g8 : TOK_GT_UNDEF); ntab += __popc(tabs); }
+        else { const int last = 31 - __clz((int)nls); line += n_nl; ntab = __popc(tabs & ~((2u << last) - 1u)); ls = base + last + 1; gtpos = TOK_GT_UNDEF; }
+    }
+    uint32_t m = in_order ? m_all : 0u;
     while (m) {
         const int j = __ffs((int)m) - 1;
         m &= m - 1;
@@ -430,28 +504,13 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
                 is_x[line] = (clen == 0 || (clen == 1 && t[ls] == 'X')) ? 1 : 0;
             }
             if (ntab <= 9 && ok_line && field_off) field_off[(size_t)line * 10 + ntab] = (uint32_t)(pos + 1 - ls);
-            if (ntab == 8) { gtpos = g8; if (fmt_here && g8 != 0 && ok_line) O.redo[atomicAdd(O.redo_n, 1)] = line; }      // later tiles assumed GT first (one thread per line: no line is listed twice)
+            if (ntab == 8) {                                         // (several FORMATs may lie in this thread: g8 is only the last one's)
+                gtpos = tok_format_gtpos(t, pos + 1, n);
+                if (gtpos != 0 && ok_line) O.redo[atomicAdd(O.redo_n, 1)] = line;
+            }
             if (ntab >= 9 && ok_line && gtpos >= 0) {
                 const int sample = ntab - 9;
-                if (sample < n_samples) {
-                    uint32_t code = 0x100u;                         // "not decided"
-                    if (wide && gtpos == 0) {
-                        const int k = j + 1;                        // the four bytes after the TAB: k .. k + 3 < TOK2_TB + 8
-                        const int wi = k >> 3, sh = (k & 7) * 8;
-                        uint64_t a = ww[0], b = ww[1];
-#pragma unroll
-                        for (int q2 = 1; q2 < TOK2_NW; ++q2) if (wi == q2) { a = ww[q2]; b = q2 + 1 < TOK2_NW ? ww[q2 + 1] : 0; }
-                        const uint32_t q = (uint32_t)(sh ? (a >> sh) | (b << (64 - sh)) : a);
-                        const uint32_t b0 = q & 0xFF, b1 = (q >> 8) & 0xFF, b2 = (q >> 16) & 0xFF, b3 = q >> 24;
-                        if ((b1 == '/' || b1 == '|') && (b3 == '\t' || b3 == ':' || b3 == '\n')) {
-                            const uint32_t d0 = b0 - '0', d1 = b2 - '0';
-                            if (d0 <= 9 && d1 <= 9) code = (d0 << 4) | d1;
-                            else if (b0 == '.' && b2 == '.') code = 0xFFu;      // both alleles missing: 0xFF strict or not
-                        }
-                    }
-                    if (code == 0x100u) code = tok_encode_open(t, pos + 1, n, gtpos, strict);
-                    gt[(size_t)line * pitch + sample] = (uint8_t)code;
-                }
+                if (sample < n_samples) gt[(size_t)line * pitch + sample] = (uint8_t)tok_encode_open(t, pos + 1, n, gtpos, strict);
             }
         } else {                                                     // newline: the line ends at pos
             if (ok_line) tok_close_line(t, line, ntab, gtpos, ls, pos, n_samples, gt, pitch, is_x, field_off, status);
