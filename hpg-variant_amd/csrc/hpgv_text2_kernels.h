@@ -336,21 +336,26 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
 #undef TOK_STEP_A0
         ev = tok_dpp<0x138, 0xF>(0, v);
     } else {
+        // three values per lane: "a newline so far" in the sign bit over the TABs since it (or since the wave began), the newlines, and
+        // where the line in progress began INSIDE THE TILE (0: not inside) -- a lane without a newline adds the TABs and takes the
+        // place of what lies in front of it
         const int nl = __popc(nls);
         const int last_bit = nl ? 31 - __clz((int)nls) : -1;
-        f = nl ? 1 : 0; v = nl ? tok_tabs_after(tabs, last_bit) : __popc(tabs); cn = nl;
-        p = nl ? (unsigned long long)(base + last_bit + 1) : 0ull;
-        int plo = (int)(uint32_t)p, phi = (int)(uint32_t)(p >> 32);
+        int fv = nl ? (int)(0x80000000u | (uint32_t)tok_tabs_after(tabs, last_bit)) : __popc(tabs);
+        int rp = nl ? tid * TOK2_TB + last_bit + 1 : 0;
+        cn = nl;
 #define TOK_STEP_A(CTRL, ROWS) {                                                                                          \
-        const int f2 = tok_dpp<CTRL, ROWS>(0, f), v2 = tok_dpp<CTRL, ROWS>(0, v), n2 = tok_dpp<CTRL, ROWS>(0, cn);         \
-        const int l2 = tok_dpp<CTRL, ROWS>(0, plo), h2 = tok_dpp<CTRL, ROWS>(0, phi);                                       \
-        if (!f) { v += v2; plo = l2; phi = h2; }                                                                           \
-        f |= f2; cn += n2; }
+        const int fv2 = tok_dpp<CTRL, ROWS>(0, fv), r2 = tok_dpp<CTRL, ROWS>(0, rp);                                        \
+        cn += tok_dpp<CTRL, ROWS>(0, cn);                                                                                  \
+        if (fv >= 0) { fv += fv2; rp = r2; } }
         TOK_SCAN_STEPS(TOK_STEP_A)                                   // inclusive, within the wave
 #undef TOK_STEP_A
-        p = ((unsigned long long)(uint32_t)phi << 32) | (uint32_t)plo;
-        ef = tok_dpp<0x138, 0xF>(0, f); ev = tok_dpp<0x138, 0xF>(0, v); en = tok_dpp<0x138, 0xF>(0, cn);         // exclusive within the wave
-        ep = ((unsigned long long)(uint32_t)tok_dpp<0x138, 0xF>(0, phi) << 32) | (uint32_t)tok_dpp<0x138, 0xF>(0, plo);
+        f = fv < 0; v = fv & 0x7FFFFFFF;
+        p = f ? (unsigned long long)(tile_base + (size_t)rp) : 0ull;
+        const int efv = tok_dpp<0x138, 0xF>(0, fv), erp = tok_dpp<0x138, 0xF>(0, rp);                                 // exclusive within the wave
+        en = tok_dpp<0x138, 0xF>(0, cn);
+        ef = efv < 0; ev = efv & 0x7FFFFFFF;
+        ep = (unsigned long long)(tile_base + (size_t)erp);
     }
     if (lane == 63) { s_f[w] = f; s_v[w] = v; s_p[w] = p; s_n[w] = cn; }
     __syncthreads();
@@ -369,11 +374,26 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
 
     // ---- scan B: the GT position of the line at every thread's first byte.  Events: a newline (undefined again), a line's
     //      8th TAB (FORMAT begins: parsed by the thread that holds it; at most one per 16 bytes) ---------------------------
+    //      The line in progress reaches its 8th TAB inside this thread when it has fewer than eight in front of it and enough here:
+    //      `from8` = its TABs from the 8th on.  Only a thread with eight or more TABs BEHIND its first newline (a second FORMAT inside
+    //      the same 32 bytes: lines of empty fields) goes through its TABs and newlines one by one, here and below.
     int d = 0, g = TOK_GT_UNDEF, g8 = TOK_GT_UNDEF;
     bool fmt_here = false;
-    const bool events = nls != 0 || (ntab < 8 && ntab + __popc(tabs) >= 8);
-    const bool wave_events = __ballot(events) != 0;                    // (uniform; most waves hold neither a newline nor a line's 8th TAB)
-    if (events) {
+    const int n_nl = __popc(nls);
+    const uint32_t seg0 = n_nl ? ((1u << (__ffs((int)nls) - 1)) - 1u) : 0xFFFFFFFFu;      // the bits in front of the first newline
+    const uint32_t t0 = tabs & seg0;                                 // the TABs of the line in progress
+    const bool in_order = n_nl != 0 && __popc(tabs & ~seg0) >= 8;
+    uint32_t from8 = 0;
+    if (!in_order) {
+        if (ntab < 8 && ntab + __popc(t0) >= 8) {
+            from8 = t0;
+            for (int drop = 7 - ntab; drop > 0; --drop) from8 &= from8 - 1;
+            g8 = tok_format_gtpos(t, base + (__ffs((int)from8) - 1) + 1, n);
+            fmt_here = true;
+        }
+        d = (n_nl != 0 || fmt_here) ? 1 : 0;
+        g = n_nl != 0 ? TOK_GT_UNDEF : g8;
+    } else {
         uint32_t m = tabs | nls;
         int k = ntab;
         while (m) {
@@ -383,17 +403,16 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
             else if (++k == 8) { g8 = tok_format_gtpos(t, base + j + 1, n); d = 1; g = g8; fmt_here = true; }
         }
     }
+    const bool wave_events = __ballot(d != 0) != 0;                    // (uniform; most waves hold neither a newline nor a line's 8th TAB)
     int ed = 0, eg = TOK_GT_UNDEF;
     if (wave_events) {
-#define TOK_STEP_B(CTRL, ROWS) {                                                                                          \
-        const int d2 = tok_dpp<CTRL, ROWS>(0, d), g2 = tok_dpp<CTRL, ROWS>(0, g);                                          \
-        if (!d) g = g2;                                                                                                    \
-        d |= d2; }
+        int e = d ? g + 3 : 0;                                       // one value: 0 = no event, else the GT position + 3 (GT_UNDEF + 3 = 1)
+#define TOK_STEP_B(CTRL, ROWS) { const int e2 = tok_dpp<CTRL, ROWS>(0, e); if (!e) e = e2; }
         TOK_SCAN_STEPS(TOK_STEP_B)
 #undef TOK_STEP_B
-        ed = tok_dpp<0x138, 0xF>(0, d);
-        eg = tok_dpp<0x138, 0xF>(0, g);
-        if (lane == 0) eg = TOK_GT_UNDEF;
+        const int ee = tok_dpp<0x138, 0xF>(0, e);
+        d = e != 0; g = e ? e - 3 : TOK_GT_UNDEF;
+        ed = ee != 0; eg = ee ? ee - 3 : TOK_GT_UNDEF;
     }
     if (lane == 63) { s_d[w] = d; s_g[w] = g; }
     __syncthreads();
@@ -425,14 +444,9 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
     //      Only a thread with eight or more TABs behind its first newline (a second FORMAT inside the same 32 bytes: lines of empty
     //      fields) walks in order, as before.
     const uint32_t m_all = everyday ? 0u : (tabs | nls);
-    const int n_nl = __popc(nls);
-    const uint32_t seg0 = n_nl ? ((1u << (__ffs((int)nls) - 1)) - 1u) : 0xFFFFFFFFu;      // the bits in front of the first newline
-    const bool in_order = n_nl != 0 && __popc(tabs & ~seg0) >= 8;
     if (m_all != 0 && !in_order) {
-        const uint32_t t0 = tabs & seg0;                             // the TABs of the line in progress
         const int gt_seg0 = ntab >= 8 ? gtpos : (fmt_here ? g8 : TOK_GT_UNDEF);            // that line's GT position once its FORMAT has gone by
-        uint32_t ts = t0;                                            // its sample TABs: from the line's ninth TAB on
-        for (int drop = 8 - ntab; drop > 0 && ts; --drop) ts &= ts - 1;
+        const uint32_t ts = ntab >= 8 ? t0 : (from8 & (from8 - 1));   // its sample TABs: from the line's ninth TAB on
         uint32_t th = tabs & ~ts;                                    // header TABs: they set field offsets (the ninth is both)
         if (ntab < 9) th |= ts & (0u - ts);
         // -- sample fields

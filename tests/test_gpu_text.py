@@ -501,6 +501,29 @@ def test_three_byte_fields_of_every_kind(eng, strict):
     assert got["n_lines"] == len(lines)
 
 
+@pytest.mark.parametrize("strict", [0, 1])
+def test_lines_of_empty_fields(eng, strict):
+    # lines whose header fields are empty or one byte long: several lines -- and several FORMAT fields -- inside one thread's 32
+    # bytes.  The tile-parallel forms derive what a TAB or a newline does from the thread's masks; a thread with eight or more TABs
+    # behind its first newline goes through them one by one instead, and each FORMAT it meets decides for its own line
+    rng = np.random.default_rng(99 + strict)
+    n_samples = 5
+    fmts = ["GT", "DP:GT", "A:B:GT", "DP", "", "GT:DP"]
+    gts = ["0/1", "1|1", "./.", ".", "", "0/1:3", "7:1/0", "1:2:0|1", "2/3:x"]
+    lines = []
+    for i in range(400):
+        head = [["", "X", "1"][int(rng.integers(0, 3))]] + [["", "7", "ab"][int(rng.integers(0, 3))] for _ in range(7)]
+        n_cols = int(rng.integers(0, 8))
+        cols = [gts[int(rng.integers(0, len(gts)))] for _ in range(n_cols)]
+        k = int(rng.integers(0, 12))
+        fields = head + [fmts[int(rng.integers(0, len(fmts)))]] + cols
+        lines.append("\t".join(fields[:k] if k < 9 and i % 5 == 0 else fields))      # some lines stop inside the header
+    text = "\n".join(lines) + ("\n" if strict else "")
+    _check(eng, text, n_samples, strict)
+    _check(eng, text, 0, strict)
+    _check(eng, text, n_samples, strict, max_lines=137)
+
+
 def test_bgzf_crc_check_on_the_gpu_against_zlib():
     # hpgv_bgzf_verify_dev: CRC-32 of every decoded block against its BGZF trailer (a damaged stream can inflate to
     # ISIZE bytes of the wrong text).  Lengths around every boundary of the kernel (the 0 - 3 bytes before the first aligned
