@@ -540,13 +540,15 @@ int epi_launch_triples(hpgv_ctx *ctx, int i_first, int n_i, double *d_acc, uint3
     HIPCHK(ctx, hipMemcpyAsync(d_rb, rb.data(), rb.size() * sizeof(unsigned), hipMemcpyHostToDevice, nullptr));
     const dim3 grid((unsigned)total);
     const bool balanced = E.nA == E.nU && E.nA < (1 << 22);
-    // ranking, at most 10 folds: the one-pass kernel (all folds' counts in registers)
-    if (ctx->epi_triples_1pass && candidates && !d_acc && E.num_folds <= 10 && E.nA < 65536 && E.nU < 65536) {
+    // ranking, at most 10 folds: the one-pass kernel (all folds' counts in registers).  Not for unequal classes above 5 folds: that
+    // instantiation (270 packed counters + the float decision of every cell) does not fit the register file -- 1 534 registers in
+    // scratch, 128 ms where the two-pass form below takes 37 (512 SNPs x 10 k samples x 10 folds, 4 000 cases)
+    if (ctx->epi_triples_1pass && candidates && !d_acc && E.num_folds <= 10 && E.nA < 65536 && E.nU < 65536 && (balanced || E.num_folds <= 5)) {
 #define HPGV_EPI3_LAUNCH(KK, BAL)                                                                                                               \
         hipLaunchKernelGGL((hpgv::k_epi_triples1<KK, TRAINING, BAL>), grid, dim3(256), 0, nullptr, E.d_planes, E.W, E.V, i_first, d_rb, n_i, d_jbp, n_jb, \
                            E.d_chunks, E.n_chunks, E.d_folds, E.nA, E.nU, E.d_thr, d_cand, E.d_cand_count, cap)
         if (E.num_folds <= 5) { if (balanced) HPGV_EPI3_LAUNCH(5, true); else HPGV_EPI3_LAUNCH(5, false); }
-        else { if (balanced) HPGV_EPI3_LAUNCH(10, true); else HPGV_EPI3_LAUNCH(10, false); }
+        else HPGV_EPI3_LAUNCH(10, true);                              // (above 5 folds only equal classes come here)
 #undef HPGV_EPI3_LAUNCH
         HIPCHK(ctx, hipGetLastError());
         return HPGV_OK;

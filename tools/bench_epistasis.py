@@ -3,7 +3,7 @@
 Bound: VALU integer issue -- 18 operations (9 v_and_b32 + 9 v_bcnt_u32_b32) per pair and 32 samples; peak =
 256 CUs x 64 lanes x clock.  Diagnostic tool (not the headline metric).
 
-  python tools/bench_epistasis.py [V] [N] [k] [--cpu] [--complete] [--order=3] [--option=key=value]
+  python tools/bench_epistasis.py [V] [N] [k] [--cpu] [--complete] [--order=3] [--unbalanced] [--option=key=value]
 
 --complete: a dataset without missing calls (the scan then counts four cells per pair and derives the other five:
 8 operations per pair and word; the roofline line keeps the 18 of the general case so that the two are comparable).
@@ -26,6 +26,8 @@ K = int(args[2]) if len(args) > 2 else 10
 CLOCK_GHZ = 2.4
 rng = np.random.default_rng(1)
 nA = nU = N // 2
+if "--unbalanced" in sys.argv:                              # cases != controls: the threshold of a high-risk cell is a ratio, not 1
+    nA = (2 * N) // 5; nU = N - nA
 COMPLETE = "--complete" in sys.argv
 data = rng.choice(np.array([0, 1, 2, 255], np.uint8), size=(V, nA + nU), p=[0.5, 0.35, 0.15, 0.0] if COMPLETE else [0.5, 0.35, 0.14, 0.01])
 fold = np.empty(nA + nU, np.int32)
@@ -50,10 +52,10 @@ if ORDER == 3:
         runs.append((time.perf_counter() - t0, res["scan_ms"]))
     wall, scan_ms = min(runs)
     triples = V * (V - 1) * (V - 2) // 6
-    words = -(-(N // (2 * K)) // 128) * 4 * 2 * K
+    words = (-(-(nA // K) // 128) + -(-(nU // K) // 128)) * 4 * K
     wave_instr = triples * words * 54 / 64
     peak = 256 * 4 * CLOCK_GHZ * 1e9 / 4
-    print(json.dumps({"order": 3, "V": V, "samples": N, "folds": K, "triples": triples, "wall_s": round(wall, 4), "scan_ms": round(scan_ms, 3),
+    print(json.dumps({"order": 3, "V": V, "samples": N, "affected": nA, "folds": K, "triples": triples, "wall_s": round(wall, 4), "scan_ms": round(scan_ms, 3),
                       "triples_per_s": triples / (scan_ms * 1e-3),
                       "roofline": {"bound": "valu", "achieved": wave_instr / (scan_ms * 1e-3) / 1e9, "peak": peak / 1e9,
                                    "unit": "G wave64 VALU instructions/s", "frac": wave_instr / (scan_ms * 1e-3) / peak,
@@ -68,9 +70,9 @@ for _ in range(3):
     runs.append((time.perf_counter() - t0, res["scan_ms"]))
 wall, scan_ms = min(runs)
 pairs = V * (V - 1) // 2
-words = -(-(N // (2 * K)) // 128) * 4 * 2 * K                 # words per row after padding every (fold, class) run to 4 words
+words = (-(-(nA // K) // 128) + -(-(nU // K) // 128)) * 4 * K   # words per row after padding every (fold, class) run to 4 words
 ops = pairs * words * 18
-out = {"V": V, "samples": N, "folds": K, "missing_calls": not COMPLETE, "pairs": pairs, "setup_s": round(t_setup, 3), "wall_s": round(wall, 4), "scan_ms": round(scan_ms, 3),
+out = {"V": V, "samples": N, "affected": nA, "folds": K, "missing_calls": not COMPLETE, "pairs": pairs, "setup_s": round(t_setup, 3), "wall_s": round(wall, 4), "scan_ms": round(scan_ms, 3),
        "pairs_per_s": pairs / (scan_ms * 1e-3), "pair_samples_per_s": pairs * N / (scan_ms * 1e-3),
        "valu_lane_ops_per_s": ops * 32 / (scan_ms * 1e-3) / 32 * 1.0,
        "roofline": {"bound": "valu", "achieved_Tops": ops / (scan_ms * 1e-3) / 1e12 * 64 / 64,
