@@ -430,7 +430,8 @@ int  hpgv_bgzf_scan_dev(hpgv_ctx *ctx, const uint8_t *d_comp, uint64_t lo, uint6
  * field_off[line*10 + k] offset, relative to the line start, of field k = CHROM..FORMAT (0..8)
  * and of the first sample column (9) so the host can build result records without re-scanning;
  * gt rows in VCF column order (strict != 0: genotypes get_alleles() would not report as
- * ALLELES_OK become 0xFF); is_x per line (assoc.c:94 rule); status per line: 0 ok, 1 fewer
+ * ALLELES_OK become 0xFF; a NUL byte inside a sample column ends that column's string, as it does in the
+ * reference's char* samples); is_x per line (assoc.c:94 rule); status per line: 0 ok, 1 fewer
  * than 10 columns, 2 FORMAT has no GT (row all missing), 3 fewer sample columns than n_samples.
  * More than max_lines lines: the first max_lines are parsed and *n_lines reports the true count.
  * *n_lines = -1 (hpgv_tokenize_dev only, after the stream has been waited for): the one-sweep form (option tokenizer_tiles = 2)
