@@ -1728,7 +1728,7 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
     // from here on `ts` is only touched by calls on stream `st`, which the caller does not issue concurrently
     // scratch per tile: the newline counts of the three-sweep form (4 B), or the tile records and tile states of the
     // tile-parallel form (16 B + 16 B)
-    const size_t scratch_ints = (n_blocks + 1) * 8;
+    const size_t scratch_ints = (n_blocks + 1) * 8 + 64;            // (+ the one-sweep form's 64-byte head and the records of a text of a few bytes)
     if (ts->blocks_cap < scratch_ints) {
         if (ts->d_blocks) { HIPCHK(ctx, hipStreamSynchronize(st)); (void)hipFree(ts->d_blocks); ts->d_blocks = nullptr; ts->blocks_cap = 0; }
         HIPCHK(ctx, hipMalloc(&ts->d_blocks, scratch_ints * sizeof(int)));

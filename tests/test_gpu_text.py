@@ -524,6 +524,33 @@ def test_lines_of_empty_fields(eng, strict):
     _check(eng, text, n_samples, strict, max_lines=137)
 
 
+def test_random_bytes_from_a_small_alphabet(eng):
+    # texts no VCF writer would produce: bytes drawn from the characters the tokenizer gives a meaning to (TAB, newline, digits, the
+    # separators, '.', ':', the letters of "GT" and "X", CR), in proportions that make every shape of line likely -- headers of
+    # empty fields, several lines and several FORMAT fields inside 32 bytes, lines longer than a tile, sample columns of any form.
+    # Whatever the oracle's TAB-split + get_alleles makes of them, the three GPU forms must make the same.
+    rng = np.random.default_rng(20260401)
+    for tiles in (2, 1, 0):                                          # a context whose FIRST call is a text of a few bytes (its scratch is sized by that call)
+        fresh = hpgv.Engine(0)
+        fresh.set_option("tokenizer_tiles", tiles)
+        for tiny in (b"1", b"\n", b"1\t2\n", b""):
+            _check(fresh, tiny, 3, 1)
+        fresh.close()
+    alphabets = [(b"\t\n0123./|:GTX", 0.30, 0.03), (b"\t\n01/|.:GT\r9", 0.24, 0.01), (b"\t\n0/1", 0.25, 0.02), (b"\t\nGT:0/1|.", 0.35, 0.08)]
+    for it in range(1200):
+        chars, p_tab, p_nl = alphabets[it % len(alphabets)]          # (the first two characters are TAB and newline)
+        p = np.array([p_tab, p_nl] + [(1.0 - p_tab - p_nl) / (len(chars) - 2)] * (len(chars) - 2))
+        n = int(rng.choice([0, 1, 7, 31, 32, 33, 200, 1500, 9000, 20000, 70000], p=[0.05, 0.05, 0.1, 0.1, 0.1, 0.1, 0.2, 0.15, 0.1, 0.04, 0.01]))
+        text = bytes(np.frombuffer(chars, np.uint8)[rng.choice(len(chars), size=n, p=p / p.sum())])
+        if it % 3 == 0 and n > 40:                                  # a well-formed head now and then, so that sample columns are reached
+            text = b"1\t2\t.\tA\tC\t.\t.\t.\tGT\t" + text
+        n_samples = int(rng.choice([0, 1, 2, 5, 8, 9, 40]))
+        strict = it & 1
+        _check(eng, text, n_samples, strict)
+        if it % 5 == 0:
+            _check(eng, text, n_samples, strict, max_lines=max(1, text.count(b"\n") // 2))
+
+
 def test_bgzf_crc_check_on_the_gpu_against_zlib():
     # hpgv_bgzf_verify_dev: CRC-32 of every decoded block against its BGZF trailer (a damaged stream can inflate to
     # ISIZE bytes of the wrong text).  Lengths around every boundary of the kernel (the 0 - 3 bytes before the first aligned
