@@ -98,7 +98,7 @@ struct hpgv_ctx {
     long scan_lds = 0;         // bytes of (unused) LDS per workgroup of the stats / tdt scans: caps the waves in flight per CU
     long fisher_width = 16;    // lanes per variant in the Fisher p-pass (64, 32, 16 or 8): 64 / width variants per wave
     long inflate_wave = 1;     // bgzip decoder: 2 = one wave per block (hpgv_inflate2_kernels.h), 0 = one lane per block, 1 = by the number of blocks
-    long tokenizer_tiles = 1;  // VCF text tokenizer: 1 = tile-parallel, two sweeps (count, scan, parse: the fastest); 2 = ONE sweep, the segments' states by look-back (k_tok_parse3: reads the text once, 16 - 20 % slower); 0 = count / mark / parse per line
+    long tokenizer_tiles = 1;  // VCF text tokenizer: 1 = tile-parallel, two sweeps (count, scan, parse: the fastest); 2 = ONE sweep, the segments' states by look-back (k_tok_parse3: reads the text once, a third slower); 0 = count / mark / parse per line
     long batch_copy = 0;       // per-batch host entry points: 1 = copy page-locked rows to the device first (copy engine) instead of reading them in place
     long batch_fused = 1;      // per-batch host entry points: one fused kernel per call (0: copy + layout + scan + statistics kernels)
     long batch_lds_max = 65536;   // largest raw-row window the fused kernel stages in LDS (raised at hpgv_create when the device allows)

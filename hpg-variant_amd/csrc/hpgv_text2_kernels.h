@@ -1,19 +1,25 @@
-// hpgv_text2_kernels.h -- tile-parallel VCF tokenizer (round 2): two sweeps of the text instead of three, and no
-// workgroup walks a line tile by tile (k_tok_parse of hpgv_text_kernels.h does: one memory round trip per 4 KiB of a line).
+// hpgv_text2_kernels.h -- tile-parallel VCF tokenizer (round 2; the shape recogniser and the walk by kind: round 3): two sweeps of
+// the text instead of three, and no workgroup walks a line tile by tile (k_tok_parse of hpgv_text_kernels.h does: one memory
+// round trip per 4 KiB of a line).  A tile is 8 KiB: 256 threads x 32 bytes.
 //
-//   k_tok_count2 : per 4 KiB tile its newline count, the TABs after its last newline (all its TABs when it has none) and
-//                  where that last newline is;
+//   k_tok_count2 : per tile its newline count, the TABs after its last newline (all its TABs when it has none) and where that
+//                  last newline is;
 //   k_tok_scan2a/b: the state at every tile's start -- lines before it, TABs since the current line began, where that line
 //                  began -- as a two-level scan (1024 tiles per workgroup, then the workgroups' totals), and the line count;
-//   k_tok_parse2 : one workgroup per TILE.  A segmented block scan gives every thread the (line, TABs so far, line start)
-//                  at its 16 bytes; a second one the GT position of its line (defined by whoever holds the line's 8th
-//                  TAB, i.e. the start of FORMAT).  A tile in the middle of a line whose FORMAT lies in an earlier tile
-//                  ASSUMES GT is the first FORMAT key (the VCF specification requires it when GT is present); the thread
-//                  that does see a FORMAT with GT elsewhere or absent flags its line, and k_tok_parse (the line-by-line
-//                  kernel) re-does exactly the flagged lines afterwards.  Then every thread walks its TABs and newlines: a TAB from the ninth on starts
-//                  a sample field and is encoded out of the thread's registers, a newline closes its line (status, the
-//                  0xFF tail of a short row), the first nine TABs give CHROM .. FORMAT, the first one chromosome "X".
-// Same outputs as k_tok_count / k_tok_scan / k_tok_mark / k_tok_parse, bit for bit (tests/test_gpu_text.py runs both).
+//   k_tok_parse2 : one workgroup per TILE.  tok_read recognises the EVERYDAY SHAPE of a thread's 32 bytes from the bytes themselves
+//                  (eight genotypes d/d, d|d, ./. or .|. behind TABs four bytes apart: tok_pattern) and encodes them at once; other
+//                  threads compute exact TAB / newline masks.  A segmented block scan gives every thread the (line, TABs so far,
+//                  line start) at its first byte; a second one the GT position of its line (defined by whoever holds the line's
+//                  8th TAB, i.e. the start of FORMAT).  A tile in the middle of a line whose FORMAT lies in an earlier tile
+//                  ASSUMES GT is the first FORMAT key (the VCF specification requires it when GT is present); the thread that
+//                  does see a FORMAT with GT elsewhere or absent LISTS its line, and k_tok_parse_listed (the line-by-line
+//                  parse) re-does exactly the listed lines afterwards.  A thread with the shape stores its eight codes; any other
+//                  handles its TABs and newlines by kind -- a TAB from the ninth on starts a sample field, a newline closes its
+//                  line (status, the 0xFF tail of a short row), the first nine TABs give CHROM .. FORMAT, the first one
+//                  chromosome "X" -- each from the state at its byte, which follows from the masks (tok_parse_tile);
+//   k_tok_parse3 : count + scan + parse in ONE sweep, the tiles' start states by decoupled look-back (an option, see below).
+// Same outputs as k_tok_count / k_tok_scan / k_tok_mark / k_tok_parse, bit for bit (tests/test_gpu_text.py runs all three forms
+// against the oracle, down to random bytes from the tokenizer's own alphabet).
 // Reference: the per-genotype strdup + get_alleles of assoc.c:45-56 / tdt.c:97-108,150-157 (what is being replaced).
 #pragma once
 #include "hpgv_text_kernels.h"
