@@ -578,3 +578,67 @@ def test_fisher_table_sweep():
     big = exp > 1e-280
     assert np.all(np.abs(got[big] - exp[big]) <= 1e-11 * exp[big]), np.max(np.abs(got[big] - exp[big]) / exp[big])
     e.close()
+
+
+# ------------------------------------------------------ every code byte ----
+
+def test_every_code_byte_through_every_scan():
+    # HPGV8 is (first allele << 4 | second allele) with alleles 0 .. 14 and 15 = missing: every byte value is a code.  The matrices
+    # of the other tests hold what a VCF commonly holds (alleles 0 .. 2, missing, half missing); here every one of the 256 values
+    # occurs, so the nibble arithmetic of the scans (SWAR identities, class LUTs, v_perm tables) meets alleles 3 .. 14, bit 3 of a
+    # nibble, and every mixture with a missing allele -- through the host batch calls, the device-resident scans and the text entry
+    # points' row kernels, against the oracle.
+    rng = np.random.default_rng(256)
+    n_samples, nv = 1203, 211
+    gt = rng.integers(0, 256, size=(nv, n_samples), dtype=np.uint8)
+    gt[:16] = np.arange(256, dtype=np.uint8).reshape(16, 16).repeat(76, axis=1)[:, :n_samples]     # rows of one code each, sixteen codes per row
+    is_x = (rng.random(nv) < 0.4).astype(np.uint8)
+    # assoc
+    cond = rng.choice([0, 1, 2], size=n_samples, p=[0.45, 0.45, 0.1]).astype(np.uint8)
+    e = fresh()
+    e.set_cohort(cond)
+    for x in (is_x, None):
+        check_assoc(e.assoc(hpgv.TASK_CHISQ, gt, x), oracle_assoc(orc.TASK_CHISQ, gt, cond, x), hpgv.TASK_CHISQ)
+    e.close()
+    # TDT: single-child families (the class planes) and families with several children (the scalar rule)
+    for n_fam, max_children in ((390, 1), (150, 5)):
+        fam = make_families(rng, n_samples, n_fam, max_children, p_absent=0.03)
+        e = fresh()
+        e.set_families(n_samples, *fam)
+        _tdt_check(e, gt, fam, None)
+        _tdt_check(e, gt, fam, is_x)
+        e.close()
+    # variant statistics, per-sample missing counters
+    e = fresh()
+    e.set_stats_cohort(n_samples)
+    res = e.stats(gt)
+    for i in range(nv):
+        vs = orc.variant_stats(gt[i], 2)
+        c8 = res["counts8"][i]
+        assert list(c8[:4]) == list(vs.genotypes_count)[:4], i
+        assert c8[4] == vs.missing_genotypes and c8[5] == vs.missing_alleles and c8[6] == vs.alleles_count[0] and c8[7] == vs.alleles_count[1], i
+        assert_close([res["hwe_p"][i]], [vs.hw_p], "hwe p")
+    acc = np.zeros(n_samples, np.int32)
+    e.stats_ex(gt, sample_missing=acc, multi_cap=nv)
+    assert np.array_equal(acc, orc.sample_missing(gt))
+    e.close()
+    # Mendelian errors
+    n_trios = 400
+    cols = rng.permutation(n_samples)
+    f, m, c = cols[:n_trios], cols[n_trios: 2 * n_trios], cols[2 * n_trios: 3 * n_trios]
+    sex = rng.integers(0, 2, size=n_trios).astype(np.uint8)
+    e = fresh()
+    pitch = e.set_pedigree(n_samples, f, m, c, sex)
+    d_raw, d_lay = e.alloc(nv * n_samples), e.alloc(nv * pitch)
+    d_err, d_child, d_isx = e.alloc(nv * 4), e.alloc(n_trios * 4), e.alloc(nv)
+    e.h2d(d_raw, gt); e.h2d(d_isx, is_x)
+    e.layout(hpgv.LAYOUT_MENDEL, d_raw, n_samples, nv, d_lay)
+    for x, dx in ((is_x, d_isx), (None, None)):
+        e.h2d(d_child, np.zeros(n_trios, np.int32))
+        e.mendel_scan(d_lay, nv, d_err, dx)
+        e.mendel_children(d_lay, nv, d_child, dx)
+        e.sync()
+        exp_err, exp_trio = orc.mendel_counts(gt, f, m, c, sex, x)
+        assert np.array_equal(e.d2h(d_err, (nv,), np.int32), exp_err)
+        assert np.array_equal(e.d2h(d_child, (n_trios,), np.int32), exp_trio)
+    e.close()

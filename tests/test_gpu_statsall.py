@@ -108,3 +108,53 @@ def test_stats_all2_equals_row_staging_kernel_and_oracle(n_samples, n_groups, al
                 gs = orc.variant_stats(np.ascontiguousarray(codes[v][groups == gi]), 4)
                 assert gc8[gi, v, 4] == gs.missing_genotypes and gc8[gi, v, 0] == gs.genotypes_count[0]
                 assert gc8[gi, v, 6] == gs.alleles_count[0] and gc8[gi, v, 7] == gs.alleles_count[1]
+
+
+def test_every_code_byte_through_the_text_entry_points():
+    # every HPGV8 code (alleles 0 .. 14 and missing, in both positions) as VCF text -- "13/.", "./7", "14/14" ... -- through the
+    # tokenizer and the kernels that read its raw rows: k_stats_all2 (stats), k_assoc_rows (assoc), k_batch (tdt), against the oracle
+    from helpers import check_assoc, make_families, oracle_assoc
+    rng = np.random.default_rng(4096)
+    n_samples, m = 1000, 48
+    codes = rng.integers(0, 256, size=(m, n_samples), dtype=np.uint8)
+    codes[:16] = np.arange(256, dtype=np.uint8).reshape(16, 16).repeat(63, axis=1)[:, :n_samples]
+    chroms = np.where(rng.random(m) < 0.3, "X", "7")
+    is_x = (chroms == "X").astype(np.uint8)
+    text = _text(codes, chroms)
+    # stats: everything on, two groups (the second derived)
+    n_trios = 300
+    cols = rng.permutation(n_samples)
+    f, mo, c = cols[:n_trios], cols[n_trios: 2 * n_trios], cols[2 * n_trios: 3 * n_trios]
+    sex = rng.integers(0, 2, n_trios).astype(np.uint8)
+    groups = rng.integers(0, 2, n_samples).astype(np.int32)
+    e = hpgv.Engine(0)
+    e.set_stats_cohort(n_samples)
+    e.set_pedigree(n_samples, f, mo, c, sex)
+    e.set_stats_groups(groups, 2)
+    a = _call(e, text, m, n_samples, n_trios, 2, ("sm", "me", "ce", "groups"))
+    e.close()
+    assert np.array_equal(a["smiss"], orc.sample_missing(codes))
+    exp_err, exp_trio = orc.mendel_counts(codes, f, mo, c, sex, is_x)
+    assert np.array_equal(a["merr"], exp_err) and np.array_equal(a["cerr"][:n_trios], exp_trio)
+    c8, gc8 = a["c8"].reshape(m, 8), a["gc8"].reshape(2, m, 8)
+    for v in range(m):
+        vs = orc.variant_stats(np.ascontiguousarray(codes[v]), 15)
+        assert c8[v, 4] == vs.missing_genotypes and c8[v, 5] == vs.missing_alleles, v
+        assert c8[v, 0] == vs.genotypes_count[0] and c8[v, 6] == vs.alleles_count[0] and c8[v, 7] == vs.alleles_count[1], v
+        for gi in range(2):
+            gs = orc.variant_stats(np.ascontiguousarray(codes[v][groups == gi]), 15)
+            assert gc8[gi, v, 4] == gs.missing_genotypes and gc8[gi, v, 0] == gs.genotypes_count[0] and gc8[gi, v, 7] == gs.alleles_count[1], (v, gi)
+    # assoc and tdt on the same text (strict: a half-called genotype is a missing one)
+    strict = np.where(((codes >> 4) == 15) | ((codes & 15) == 15), 0xFF, codes).astype(np.uint8)
+    cond = rng.choice([0, 1, 2], size=n_samples, p=[0.45, 0.45, 0.1]).astype(np.uint8)
+    e = hpgv.Engine(0)
+    e.set_cohort(cond)
+    check_assoc(e.assoc_text(hpgv.TASK_CHISQ, text), oracle_assoc(orc.TASK_CHISQ, strict, cond, is_x, None), hpgv.TASK_CHISQ)
+    e.close()
+    fam = make_families(rng, n_samples, 250, 3, p_absent=0.03)
+    e = hpgv.Engine(0)
+    e.set_families(n_samples, *fam)
+    res = e.tdt_text(text)
+    t1, t2 = orc.tdt_counts(strict, *fam, chrom_is_x=is_x)
+    assert np.array_equal(res["t1"], t1) and np.array_equal(res["t2"], t2)
+    e.close()
