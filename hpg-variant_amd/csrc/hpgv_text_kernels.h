@@ -99,14 +99,24 @@ static __global__ __launch_bounds__(256) void k_tok_mark(const char *__restrict_
     if (blockIdx.x == 0 && threadIdx.x == 0) line_off[0] = 0;
 }
 
-// atoi() on [p, e): optional blanks, sign, digits (what get_alleles applies to an allele token)
+// atoi() on [p, e): optional blanks, sign, digits (what get_alleles applies to an allele token) -- as the C library does it:
+// (int) strtol(): the digits accumulate in 64 bits and stick at LONG_MAX / LONG_MIN, the result is cut to 32 bits.  A VCF
+// writer never produces an allele index of ten digits; a text that holds one anyway ("11111111111/0") gets what the reference's
+// atoi gives it (found by tests/test_gpu_text.py::test_random_bytes_from_a_small_alphabet)
 __device__ __forceinline__ int tok_atoi(const char *__restrict__ t, size_t p, size_t e) {
     while (p < e && (t[p] == ' ' || (t[p] >= '\t' && t[p] <= '\r'))) p++;
     bool neg = false;
     if (p < e && (t[p] == '+' || t[p] == '-')) { neg = t[p] == '-'; p++; }
-    int v = 0;
-    while (p < e && t[p] >= '0' && t[p] <= '9') { v = v < 100000 ? v * 10 + (t[p] - '0') : v; p++; }
-    return neg ? -v : v;
+    unsigned long long v = 0;
+    bool stuck = false;
+    while (p < e && t[p] >= '0' && t[p] <= '9') {
+        const unsigned d = (unsigned)(t[p] - '0');
+        if (v > 922337203685477580ull || (v == 922337203685477580ull && d > 7u)) stuck = true;      // v * 10 + d > LONG_MAX
+        else v = v * 10 + d;
+        p++;
+    }
+    const long long r = stuck ? (neg ? (long long)0x8000000000000000ull : 0x7FFFFFFFFFFFFFFFll) : (neg ? -(long long)v : (long long)v);
+    return (int)r;
 }
 
 // one sample field starting at p (line ends at e, exclusive): the product's statement of
