@@ -1745,7 +1745,7 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
     }
     if (ctx->tokenizer_tiles) {
         // two sweeps of the text: tile records, tile states, then one workgroup per tile parses (hpgv_text2_kernels.h)
-        const size_t n_tiles = (text_bytes + hpgv::TOK2_TILE - 1) / hpgv::TOK2_TILE;      // 8 KiB tiles (the scratch is sized for 4 KiB ones)
+        const size_t n_tiles = (text_bytes + hpgv::TOK2_TILE - 1) / hpgv::TOK2_TILE;      // 4 KiB tiles
         hpgv::TokAgg *agg = (hpgv::TokAgg *)ts->d_blocks;
         hpgv::TokPre *pre = (hpgv::TokPre *)(agg + n_tiles + 1);
         const int n_groups = (int)((n_tiles + hpgv::TOK_SCAN_THREADS - 1) / hpgv::TOK_SCAN_THREADS);
@@ -1778,13 +1778,13 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
             return HPGV_OK;
         }
         if (n_tiles > 0) {
-            hipLaunchKernelGGL(hpgv::k_tok_count2, dim3((unsigned)n_tiles), dim3(256), 0, st, d_text, text_bytes, agg);
+            hipLaunchKernelGGL(hpgv::k_tok_count2, dim3((unsigned)((n_tiles + 1) / 2)), dim3(256), 0, st, d_text, text_bytes, (int)n_tiles, agg);
             hipLaunchKernelGGL(hpgv::k_tok_scan2a, dim3((unsigned)n_groups), dim3(hpgv::TOK_SCAN_THREADS), 0, st, (const hpgv::TokAgg *)agg, (int)n_tiles, pre, gtot);
         }
         hipLaunchKernelGGL(hpgv::k_tok_scan2b, dim3((unsigned)(n_groups > 0 ? n_groups : 1)), dim3(hpgv::TOK_SCAN_THREADS), 0, st, pre, (int)n_tiles, gtot, n_groups,
                            d_text, text_bytes, d_n_lines, line_off, max_lines, redo_n);
         if (n_tiles > 0 && max_lines > 0) {
-            hipLaunchKernelGGL(hpgv::k_tok_parse2, dim3((unsigned)n_tiles), dim3(256), 0, st, d_text, text_bytes, (const hpgv::TokPre *)pre,
+            hipLaunchKernelGGL(hpgv::k_tok_parse2, dim3((unsigned)n_tiles), dim3(hpgv::TOK2_THREADS), 0, st, d_text, text_bytes, (const hpgv::TokPre *)pre,
                                max_lines, n_samples, strict, d_gt, pitch, d_is_x, line_off, d_field_off, d_status, redo, redo_n);
             // the lines whose FORMAT does not begin with GT (listed by the thread that read it): once more, line by line
             hipLaunchKernelGGL(hpgv::k_tok_parse_listed, dim3(redo_grid), dim3(256), 0, st, d_text, line_off,

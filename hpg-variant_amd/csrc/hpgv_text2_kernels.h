@@ -28,7 +28,12 @@ namespace hpgv {
 
 constexpr int TOK2_TB = 32;                                          // bytes per thread: 32 TAB / newline bits in one register
 constexpr int TOK2_NW = TOK2_TB / 8 + 1;                             // 8-byte words a thread holds: its bytes and the 8 after them
-constexpr int TOK2_TILE = 256 * TOK2_TB;                             // bytes per workgroup tile (8 KiB)
+// A tile of the two sweeps is 4 KiB: 128 threads, TWO waves per parsing workgroup.  The parse waits at two workgroup barriers per
+// tile and a workgroup's place is free again only when its slowest wave is done: 16 000 x 10 k samples took 190 us with four waves
+// per workgroup (8 KiB tiles), 165 with two, 154 with one -- but one-wave tiles double the records the scans and the counting sweep
+// handle (profiles/r03_tokenizer_bench.jsonl).  The counting sweep keeps 256 threads: a workgroup counts two tiles.
+constexpr int TOK2_THREADS = 128;
+constexpr int TOK2_TILE = TOK2_THREADS * TOK2_TB;                    // bytes per tile (4 KiB)
 struct TokAgg { int nl, tabs, last_nl, pad; };                       // last_nl: offset inside the tile, -1 when none
 struct TokPre { int lines, tabs; unsigned long long line_start; };   // state at the tile's first byte
 constexpr int TOK_GT_UNDEF = -2;                                     // "FORMAT of this line not seen yet"
@@ -146,14 +151,17 @@ template <int CTRL, int ROWS> __device__ __forceinline__ int tok_dpp(int identit
 #define TOK_RFL(x) __builtin_amdgcn_readfirstlane(x)                  // a value every lane holds alike, into a scalar register
 #define TOK_SCAN_STEPS(STEP) STEP(0x111, 0xF) STEP(0x112, 0xF) STEP(0x114, 0xF) STEP(0x118, 0xF) STEP(0x142, 0xA) STEP(0x143, 0xC)
 
-static __global__ __launch_bounds__(256) void k_tok_count2(const char *__restrict__ text, size_t n, TokAgg *__restrict__ agg) {
+static __global__ __launch_bounds__(256) void k_tok_count2(const char *__restrict__ text, size_t n, int n_tiles, TokAgg *__restrict__ agg) {
     __shared__ int s_nl[4], s_last[4], s_tabs[4];
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t base = (size_t)blockIdx.x * TOK2_TILE + (size_t)tid * TOK2_TB;
+    // waves 0, 1 count tile 2 b, waves 2, 3 tile 2 b + 1 (b = the workgroup's index); `tid` is the thread's place inside its tile
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), half = w >> 1;
+    const int tid = (int)threadIdx.x & (TOK2_THREADS - 1);
+    const int tile = 2 * (int)blockIdx.x + half;
+    const size_t base = (size_t)tile * TOK2_TILE + (size_t)tid * TOK2_TB;
     int nl, tabs_after, last_bit;                                     // tabs_after: all the thread's TABs when it holds no newline
     tok_count_thread(text, base, n, &nl, &tabs_after, &last_bit);
     const int all_tabs = nl ? 0 : tabs_after;                         // (only asked of threads behind the tile's last newline: they hold none)
-    // the last thread of the workgroup that holds a newline, and how many newlines there are: a wave without one (19 of 20 at 10 k
+    // the last thread of the tile that holds a newline, and how many newlines there are: a wave without one (19 of 20 at 10 k
     // samples) knows from its ballot; sums over the wave are DPP scans (the total arrives in lane 63)
     const unsigned long long has = __ballot(nl != 0);
     int c = 0;
@@ -163,22 +171,22 @@ static __global__ __launch_bounds__(256) void k_tok_count2(const char *__restric
         TOK_SCAN_STEPS(TOK_STEP_C)
 #undef TOK_STEP_C
     }
-    if (lane == 63) { s_nl[w] = c; s_last[w] = has ? w * 64 + 63 - __clzll(has) : -1; }
+    if (lane == 63) { s_nl[w] = c; s_last[w] = has ? (w & 1) * 64 + 63 - __clzll(has) : -1; }
     __syncthreads();
-    const int tlast = __builtin_amdgcn_readfirstlane(max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3])));
+    const int tlast = __builtin_amdgcn_readfirstlane(max(s_last[2 * half], s_last[2 * half + 1]));
     int mine = tid > tlast ? all_tabs : (tid == tlast ? tabs_after : 0);
 #define TOK_STEP_M(CTRL, ROWS) mine += tok_dpp<CTRL, ROWS>(0, mine);
     TOK_SCAN_STEPS(TOK_STEP_M)
 #undef TOK_STEP_M
     if (lane == 63) s_tabs[w] = mine;
     __syncthreads();
-    if (tid == (tlast < 0 ? 0 : tlast)) {                             // one thread writes the whole record
+    if (tid == (tlast < 0 ? 0 : tlast) && tile < n_tiles) {           // one thread writes the tile's whole record
         TokAgg a;
-        a.nl = s_nl[0] + s_nl[1] + s_nl[2] + s_nl[3];
-        a.tabs = s_tabs[0] + s_tabs[1] + s_tabs[2] + s_tabs[3];
+        a.nl = s_nl[2 * half] + s_nl[2 * half + 1];
+        a.tabs = s_tabs[2 * half] + s_tabs[2 * half + 1];
         a.last_nl = tlast < 0 ? -1 : tid * TOK2_TB + last_bit;
         a.pad = 0;
-        agg[blockIdx.x] = a;
+        agg[tile] = a;
     }
 }
 
@@ -544,7 +552,7 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
         tok_close_line(t, line, ntab, gtpos, ls, n, n_samples, gt, pitch, is_x, field_off, status);
 }
 
-static __global__ __launch_bounds__(256) void k_tok_parse2(const char *__restrict__ text, size_t n, const TokPre *__restrict__ pre,
+static __global__ __launch_bounds__(TOK2_THREADS) void k_tok_parse2(const char *__restrict__ text, size_t n, const TokPre *__restrict__ pre,
                                                     int max_lines, int n_samples, int strict, uint8_t *__restrict__ gt, size_t pitch,
                                                     uint8_t *__restrict__ is_x, unsigned long long *__restrict__ line_off,
                                                     uint32_t *__restrict__ field_off, int *__restrict__ status,
@@ -582,7 +590,8 @@ static __global__ __launch_bounds__(256) void k_tok_parse2(const char *__restric
 // error flag, the kernel drains, k_tok_finish reports -1 lines, and the caller falls back to the two-sweep kernels.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int TOK3_TILES = 2;
-constexpr int TOK3_SEG = TOK3_TILES * TOK2_TILE;
+constexpr int TOK3_TILE = 256 * TOK2_TB;                            // this form's tile: 8 KiB, the 256 threads of its workgroup
+constexpr int TOK3_SEG = TOK3_TILES * TOK3_TILE;
 constexpr int TOK3_SUPER = 64;                      // segments per super (2 MB of text)
 struct TokRec { unsigned long long w0, w1; };           // w0: status:2 | lines:31 | tabs:31;  w1: status:2 | (line start + 1):62 (0: no newline)
 __device__ __forceinline__ void tok_rec_store(TokRec *r, unsigned status, const TokState st) {
@@ -635,7 +644,7 @@ static __global__ __launch_bounds__(256) void k_tok_parse3(const char *__restric
     TokThread T[TOK3_TILES];
     int last_bit[TOK3_TILES];
 #pragma unroll
-    for (int k = 0; k < TOK3_TILES; ++k) tok_read(text, seg_base + (size_t)k * TOK2_TILE + (size_t)tid * TOK2_TB, n, T[k]);
+    for (int k = 0; k < TOK3_TILES; ++k) tok_read(text, seg_base + (size_t)k * TOK3_TILE + (size_t)tid * TOK2_TB, n, T[k]);
 #pragma unroll
     for (int k = 0; k < TOK3_TILES; ++k) {
         const int nl = __popc(T[k].nls);
@@ -674,7 +683,7 @@ static __global__ __launch_bounds__(256) void k_tok_parse3(const char *__restric
 #pragma unroll
     for (int k = 0; k < TOK3_TILES; ++k) {
         TokState a = rel[k + 1];
-        a.ls = tlast[k] >= 0 ? (long long)(seg_base + (size_t)k * TOK2_TILE + (size_t)tlast[k] * TOK2_TB + (size_t)s_last[k][0] + 1) : -1;
+        a.ls = tlast[k] >= 0 ? (long long)(seg_base + (size_t)k * TOK3_TILE + (size_t)tlast[k] * TOK2_TB + (size_t)s_last[k][0] + 1) : -1;
         rel[k + 1] = tok_fold(rel[k], a);
     }
     const TokState seg_agg = rel[TOK3_TILES];
@@ -743,7 +752,7 @@ static __global__ __launch_bounds__(256) void k_tok_parse3(const char *__restric
     const TokOut O = {max_lines, n_samples, strict, gt, pitch, is_x, line_off, field_off, status, redo, redo_n};
 #pragma unroll
     for (int k = 0; k < TOK3_TILES; ++k) {
-        const size_t tile_base = seg_base + (size_t)k * TOK2_TILE;
+        const size_t tile_base = seg_base + (size_t)k * TOK3_TILE;
         if (tile_base >= n) break;                                   // (uniform)
         const TokState st = tok_fold(start, rel[k]);
         TokPre P; P.lines = st.lines; P.tabs = st.tabs; P.line_start = (unsigned long long)st.ls;
