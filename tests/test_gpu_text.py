@@ -619,10 +619,10 @@ def test_one_sweep_tokenizer_on_a_large_text_equals_two_sweeps():
         bodies = ["\t".join(codes[rng.choice(6, size=n_samples, p=[0.5, 0.25, 0.15, 0.02, 0.05, 0.03])]) for _ in range(16)]
         text = "".join("%s\t%d\trs%d\tA\tG,T\t.\tPASS\t%s\tGT\t%s\n" % (["1", "X"][i % 2], 100 + i, i, "X" * int(rng.integers(1, 200)), bodies[i % 16])
                        for i in range(n_lines))
-        for tiles in (2, 1):
+        for tiles in (2, 1, 0):
             e = hpgv.Engine(0)
             e.set_option("tokenizer_tiles", tiles)
-            out = [e.tokenize(text, n_samples, True, None) for _ in range(2)]
+            out = [e.tokenize(text, n_samples, True, None) for _ in range(2 if tiles else 1)]
             e.close()
             res[tiles] = out
         for call in range(2):
@@ -630,6 +630,14 @@ def test_one_sweep_tokenizer_on_a_large_text_equals_two_sweeps():
             assert a["n_lines"] == b["n_lines"] == n_lines
             for k in ("gt", "is_x", "status", "line_off", "field_off"):
                 assert np.array_equal(a[k], b[k]), (n_samples, k)
+        # the line-by-line form shares no parsing code with the tile-parallel ones (tok_parse_tile): the same matrix from it as well
+        c = res[0][0]
+        assert c["n_lines"] == n_lines
+        for k in ("gt", "is_x", "status", "line_off", "field_off"):
+            assert np.array_equal(res[1][0][k], c[k]), (n_samples, k)
+        # and the matrix is what the text says: every line's body is one of the 16, whose codes the oracle gives
+        want = np.stack([orc.tokenize(("1\t1\t.\tA\tG,T\t.\t.\t.\tGT\t" + bd + "\n"), n_samples, True)["gt"][0] for bd in bodies])
+        assert np.array_equal(res[1][0]["gt"], want[np.arange(n_lines) % 16])
 
 
 @pytest.mark.parametrize("n_samples", [17, 1000, 4100, 8200, 16390, 33000])
