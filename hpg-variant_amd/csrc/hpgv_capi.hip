@@ -1728,7 +1728,7 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
     // from here on `ts` is only touched by calls on stream `st`, which the caller does not issue concurrently
     // scratch per tile: the newline counts of the three-sweep form (4 B), or the tile records and tile states of the
     // tile-parallel form (16 B + 16 B)
-    const size_t scratch_ints = (n_blocks + 1) * 8 + 64;            // (+ the one-sweep form's 64-byte head and the records of a text of a few bytes)
+    const size_t scratch_ints = (n_blocks + 1) * 8 * (hpgv::TOK_TILE / hpgv::TOK2_TILE > 1 ? hpgv::TOK_TILE / hpgv::TOK2_TILE : 1) + 64;            // (+ the one-sweep form's 64-byte head and the records of a text of a few bytes)
     if (ts->blocks_cap < scratch_ints) {
         if (ts->d_blocks) { HIPCHK(ctx, hipStreamSynchronize(st)); (void)hipFree(ts->d_blocks); ts->d_blocks = nullptr; ts->blocks_cap = 0; }
         HIPCHK(ctx, hipMalloc(&ts->d_blocks, scratch_ints * sizeof(int)));
@@ -1745,7 +1745,7 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
     }
     if (ctx->tokenizer_tiles) {
         // two sweeps of the text: tile records, tile states, then one workgroup per tile parses (hpgv_text2_kernels.h)
-        const size_t n_tiles = (text_bytes + hpgv::TOK2_TILE - 1) / hpgv::TOK2_TILE;      // 4 KiB tiles
+        const size_t n_tiles = (text_bytes + hpgv::TOK2_TILE - 1) / hpgv::TOK2_TILE;      // 2 KiB tiles
         hpgv::TokAgg *agg = (hpgv::TokAgg *)ts->d_blocks;
         hpgv::TokPre *pre = (hpgv::TokPre *)(agg + n_tiles + 1);
         const int n_groups = (int)((n_tiles + hpgv::TOK_SCAN_THREADS - 1) / hpgv::TOK_SCAN_THREADS);
@@ -1778,7 +1778,7 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
             return HPGV_OK;
         }
         if (n_tiles > 0) {
-            hipLaunchKernelGGL(hpgv::k_tok_count2, dim3((unsigned)((n_tiles + 1) / 2)), dim3(256), 0, st, d_text, text_bytes, (int)n_tiles, agg);
+            hipLaunchKernelGGL(hpgv::k_tok_count2, dim3((unsigned)((n_tiles + hpgv::TOK2_COUNT_TILES - 1) / hpgv::TOK2_COUNT_TILES)), dim3(256), 0, st, d_text, text_bytes, (int)n_tiles, agg);
             hipLaunchKernelGGL(hpgv::k_tok_scan2a, dim3((unsigned)n_groups), dim3(hpgv::TOK_SCAN_THREADS), 0, st, (const hpgv::TokAgg *)agg, (int)n_tiles, pre, gtot);
         }
         hipLaunchKernelGGL(hpgv::k_tok_scan2b, dim3((unsigned)(n_groups > 0 ? n_groups : 1)), dim3(hpgv::TOK_SCAN_THREADS), 0, st, pre, (int)n_tiles, gtot, n_groups,

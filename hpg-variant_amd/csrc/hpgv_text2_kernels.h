@@ -28,12 +28,16 @@ namespace hpgv {
 
 constexpr int TOK2_TB = 32;                                          // bytes per thread: 32 TAB / newline bits in one register
 constexpr int TOK2_NW = TOK2_TB / 8 + 1;                             // 8-byte words a thread holds: its bytes and the 8 after them
-// A tile of the two sweeps is 4 KiB: 128 threads, TWO waves per parsing workgroup.  The parse waits at two workgroup barriers per
-// tile and a workgroup's place is free again only when its slowest wave is done: 16 000 x 10 k samples took 190 us with four waves
-// per workgroup (8 KiB tiles), 165 with two, 154 with one -- but one-wave tiles double the records the scans and the counting sweep
-// handle (profiles/r03_tokenizer_bench.jsonl).  The counting sweep keeps 256 threads: a workgroup counts two tiles.
-constexpr int TOK2_THREADS = 128;
-constexpr int TOK2_TILE = TOK2_THREADS * TOK2_TB;                    // bytes per tile (4 KiB)
+// A tile of the two sweeps is 2 KiB: 64 threads, ONE wave per parsing workgroup.  The parse meets two workgroup barriers per tile and
+// a workgroup's place is free again only when its slowest wave is done (a wave with a line's header costs several times a wave of
+// sample columns): 16 000 x 10 k samples took 0.314 ms with four waves per workgroup (8 KiB tiles), 0.295 with two, 0.287 with one;
+// 64 000 x 2 504 samples 0.419 / 0.36 / 0.34 ms; 800 000 x 200 0.72 / 0.71 / 0.70 ms (same box, profiles/r03_tokenizer_bench.jsonl).
+// The counting sweep keeps workgroups of 256 threads, which count four tiles: with smaller ones it is slower.
+#ifndef HPGV_TOK2_THREADS
+#define HPGV_TOK2_THREADS 64
+#endif
+constexpr int TOK2_THREADS = HPGV_TOK2_THREADS;
+constexpr int TOK2_TILE = TOK2_THREADS * TOK2_TB;                    // bytes per tile (2 KiB)
 struct TokAgg { int nl, tabs, last_nl, pad; };                       // last_nl: offset inside the tile, -1 when none
 struct TokPre { int lines, tabs; unsigned long long line_start; };   // state at the tile's first byte
 constexpr int TOK_GT_UNDEF = -2;                                     // "FORMAT of this line not seen yet"
@@ -151,12 +155,14 @@ template <int CTRL, int ROWS> __device__ __forceinline__ int tok_dpp(int identit
 #define TOK_RFL(x) __builtin_amdgcn_readfirstlane(x)                  // a value every lane holds alike, into a scalar register
 #define TOK_SCAN_STEPS(STEP) STEP(0x111, 0xF) STEP(0x112, 0xF) STEP(0x114, 0xF) STEP(0x118, 0xF) STEP(0x142, 0xA) STEP(0x143, 0xC)
 
+constexpr int TOK2_WPT = TOK2_THREADS / 64;                          // waves per tile
+constexpr int TOK2_COUNT_TILES = 256 / TOK2_THREADS;                 // tiles a workgroup of the counting sweep takes
 static __global__ __launch_bounds__(256) void k_tok_count2(const char *__restrict__ text, size_t n, int n_tiles, TokAgg *__restrict__ agg) {
     __shared__ int s_nl[4], s_last[4], s_tabs[4];
-    // waves 0, 1 count tile 2 b, waves 2, 3 tile 2 b + 1 (b = the workgroup's index); `tid` is the thread's place inside its tile
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), half = w >> 1;
+    // waves [g WPT, (g + 1) WPT) count tile (tiles per workgroup) b + g (b = the workgroup's index); `tid` is the thread's place inside its tile
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), g = w / TOK2_WPT, w0 = g * TOK2_WPT;
     const int tid = (int)threadIdx.x & (TOK2_THREADS - 1);
-    const int tile = 2 * (int)blockIdx.x + half;
+    const int tile = TOK2_COUNT_TILES * (int)blockIdx.x + g;
     const size_t base = (size_t)tile * TOK2_TILE + (size_t)tid * TOK2_TB;
     int nl, tabs_after, last_bit;                                     // tabs_after: all the thread's TABs when it holds no newline
     tok_count_thread(text, base, n, &nl, &tabs_after, &last_bit);
@@ -171,9 +177,12 @@ static __global__ __launch_bounds__(256) void k_tok_count2(const char *__restric
         TOK_SCAN_STEPS(TOK_STEP_C)
 #undef TOK_STEP_C
     }
-    if (lane == 63) { s_nl[w] = c; s_last[w] = has ? (w & 1) * 64 + 63 - __clzll(has) : -1; }
+    if (lane == 63) { s_nl[w] = c; s_last[w] = has ? (w - w0) * 64 + 63 - __clzll(has) : -1; }
     __syncthreads();
-    const int tlast = __builtin_amdgcn_readfirstlane(max(s_last[2 * half], s_last[2 * half + 1]));
+    int tl = -1;
+#pragma unroll
+    for (int k = 0; k < TOK2_WPT; ++k) tl = max(tl, s_last[w0 + k]);
+    const int tlast = __builtin_amdgcn_readfirstlane(tl);
     int mine = tid > tlast ? all_tabs : (tid == tlast ? tabs_after : 0);
 #define TOK_STEP_M(CTRL, ROWS) mine += tok_dpp<CTRL, ROWS>(0, mine);
     TOK_SCAN_STEPS(TOK_STEP_M)
@@ -182,8 +191,9 @@ static __global__ __launch_bounds__(256) void k_tok_count2(const char *__restric
     __syncthreads();
     if (tid == (tlast < 0 ? 0 : tlast) && tile < n_tiles) {           // one thread writes the tile's whole record
         TokAgg a;
-        a.nl = s_nl[2 * half] + s_nl[2 * half + 1];
-        a.tabs = s_tabs[2 * half] + s_tabs[2 * half + 1];
+        a.nl = 0; a.tabs = 0;
+#pragma unroll
+        for (int k = 0; k < TOK2_WPT; ++k) { a.nl += s_nl[w0 + k]; a.tabs += s_tabs[w0 + k]; }
         a.last_nl = tlast < 0 ? -1 : tid * TOK2_TB + last_bit;
         a.pad = 0;
         agg[tile] = a;
