@@ -158,3 +158,18 @@ def test_every_code_byte_through_the_text_entry_points():
     t1, t2 = orc.tdt_counts(strict, *fam, chrom_is_x=is_x)
     assert np.array_equal(res["t1"], t1) and np.array_equal(res["t2"], t2)
     e.close()
+
+
+def test_random_shapes():
+    # cohort widths, group counts and output selections drawn at random (HPGV_SOAK_SHAPES of them: 6 in the suite, hundreds in a
+    # soak run): the column-owning kernels pick chunks per thread and workgroup sizes from the width, and a width next to any of
+    # their boundaries must do
+    rng = np.random.default_rng(int(os.environ.get("HPGV_FUZZ_SEED", "77")))
+    outs = ("sm", "me", "ce", "groups")
+    for _ in range(int(os.environ.get("HPGV_SOAK_SHAPES", "6"))):
+        n_samples = int(rng.choice([int(rng.integers(1, 200)), int(rng.integers(200, 4200)), int(rng.integers(4200, 16500)), 16 * int(rng.integers(1, 1030))]))
+        n_groups = int(rng.integers(0, 5))
+        want = tuple(o for o in outs if rng.random() < 0.7) or ("sm",)
+        if n_samples < 3:
+            want = tuple(o for o in want if o not in ("me", "ce")) or ("sm",)
+        test_stats_all2_equals_row_staging_kernel_and_oracle(n_samples, n_groups, bool(rng.integers(0, 2)), want)

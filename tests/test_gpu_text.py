@@ -665,3 +665,12 @@ def test_assoc_text_rows_kernel_equals_the_per_row_kernel(n_samples):
     for k in ("A1", "A2", "U1", "U2", "odds", "chisq", "p", "status"):
         assert np.array_equal(out["1"][k], out["0"][k], equal_nan=True), k
     check_assoc(out["1"], oracle_assoc(orc.TASK_CHISQ, tok["gt"], cond, tok["is_x"], None), hpgv.TASK_CHISQ)
+
+
+def test_assoc_text_rows_kernel_on_random_widths():
+    # cohort widths drawn at random (HPGV_SOAK_SHAPES of them: 5 in the suite, hundreds in a soak run) through hpgv_assoc_text's two
+    # counting kernels and the oracle
+    rng = np.random.default_rng(int(os.environ.get("HPGV_FUZZ_SEED", "78")))
+    for _ in range(int(os.environ.get("HPGV_SOAK_SHAPES", "5"))):
+        n_samples = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(300, 5000)), int(rng.integers(5000, 34000)), 16 * int(rng.integers(1, 2100))]))
+        test_assoc_text_rows_kernel_equals_the_per_row_kernel(n_samples)
