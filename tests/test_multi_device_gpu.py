@@ -153,3 +153,13 @@ def test_bgzip_file_staged_in_parts_one_per_device_is_byte_identical(tmp_path, d
     for k in range(len(exts)):
         assert outs["one"][k] == outs["parts"][k], exts[k]
     assert all(len(x) > 100 for x in outs["one"])
+
+
+def test_bgzip_parts_with_random_block_sizes(tmp_path_factory):
+    # block sizes and part counts drawn at random (HPGV_SOAK_SHAPES of them: one in the suite, dozens in a soak run): the parts' seams
+    # fall anywhere in a line, a block, a window
+    rng = np.random.default_rng(int(os.environ.get("HPGV_FUZZ_SEED", "79")))
+    for _ in range(int(os.environ.get("HPGV_SOAK_SHAPES", "1"))):
+        devs = ",".join(["0"] * int(rng.integers(2, 5)))
+        block = int(rng.choice([int(rng.integers(0x200, 0x1000)), int(rng.integers(0x1000, 0x8000)), int(rng.integers(0x8000, 0xff01))]))
+        test_bgzip_file_staged_in_parts_one_per_device_is_byte_identical(tmp_path_factory.mktemp("parts"), devs, block)
