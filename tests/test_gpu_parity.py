@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path, called through the C ABI (include/hpgv.h),
 against the CPU oracle on the same inputs.  Integer tallies bit-exact, FP64
 statistics within 1e-10 (NaN == NaN).  Run with -m gpu on an MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -578,6 +580,38 @@ def test_fisher_table_sweep():
     big = exp > 1e-280
     assert np.all(np.abs(got[big] - exp[big]) <= 1e-11 * exp[big]), np.max(np.abs(got[big] - exp[big]) / exp[big])
     e.close()
+
+
+def test_fisher_random_tables():
+    # 2x2 tables drawn at random (HPGV_SOAK_SHAPES thousand of them: 3 in the suite): totals from 1 to 400 k log-uniform, margins
+    # anywhere, the observed table from the hypergeometric law or anywhere in its support; every sub-wave width of the p-pass
+    rng = np.random.default_rng(int(os.environ.get("HPGV_FUZZ_SEED", "80")))
+    n = 1000 * int(os.environ.get("HPGV_SOAK_SHAPES", "3"))
+    nn = np.maximum(1, np.exp(rng.uniform(0, np.log(400_000), n)).astype(np.int64))
+    r1 = (rng.random(n) * (nn + 1)).astype(np.int64)
+    c1 = (rng.random(n) * (nn + 1)).astype(np.int64)
+    lo, hi = np.maximum(0, c1 - (nn - r1)), np.minimum(r1, c1)
+    x = np.where(rng.random(n) < 0.7, rng.hypergeometric(np.maximum(r1, 0), np.maximum(nn - r1, 0), np.maximum(c1, 0)) if True else 0,
+                 lo + (rng.random(n) * (hi - lo + 1)).astype(np.int64))
+    x = np.clip(x, lo, hi)
+    tabs = np.stack([x, r1 - x, c1 - x, (nn - r1) - (c1 - x)], axis=1).astype(np.int32)
+    assert (tabs >= 0).all()
+    lf = orc.logfact(400_000 + 16)
+    _, _, exp = orc.assoc_stats(orc.TASK_FISHER, tabs[:, 0], tabs[:, 1], tabs[:, 2], tabs[:, 3], lf)
+    for width in (16, 64, 32, 8):
+        e = fresh()
+        e.set_option("fisher_width", width)
+        e.set_cohort(np.zeros(4, np.uint8))
+        e.set_logfact(lf)
+        d_counts, d_st = e.alloc(n * 16), e.alloc(n * 16)
+        e.h2d(d_counts, tabs)
+        e.assoc_fisher(d_counts, n, d_st.value, d_st.value + 8 * n)
+        e.sync()
+        got = e.d2h(d_st.value + 8 * n, (n,), np.float64)
+        assert_close(got, exp, "fisher p over random tables, width %d" % width)
+        big = exp > 1e-280
+        assert np.all(np.abs(got[big] - exp[big]) <= 1e-11 * exp[big]), (width, np.max(np.abs(got[big] - exp[big]) / exp[big]))
+        e.close()
 
 
 # ------------------------------------------------------ every code byte ----
