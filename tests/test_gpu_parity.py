@@ -614,6 +614,24 @@ def test_fisher_random_tables():
         e.close()
 
 
+def test_tdt_random_pedigrees_every_code():
+    # pedigrees and matrices drawn at random (HPGV_SOAK_SHAPES of them: 4 in the suite): family counts, children per family,
+    # absent parents, cohort widths; matrices of all 256 codes or of the common ones; chromosome X rows
+    rng = np.random.default_rng(int(os.environ.get("HPGV_FUZZ_SEED", "81")))
+    for _ in range(int(os.environ.get("HPGV_SOAK_SHAPES", "4"))):
+        n_fam = int(rng.choice([1, int(rng.integers(2, 60)), int(rng.integers(60, 3000))]))
+        max_children = int(rng.choice([1, 1, 2, int(rng.integers(3, 12))]))
+        n_samples = n_fam * (2 + max_children) + int(rng.integers(0, 40))
+        fam = make_families(rng, n_samples, n_fam, max_children, p_absent=float(rng.choice([0.0, 0.05, 0.3])))
+        nv = int(rng.integers(1, 80))
+        gt = rng.integers(0, 256, size=(nv, n_samples), dtype=np.uint8) if rng.random() < 0.5 else random_codes(rng, nv, n_samples, quirks=bool(rng.integers(0, 2)))
+        is_x = (rng.random(nv) < 0.4).astype(np.uint8)
+        e = fresh()
+        e.set_families(n_samples, *fam)
+        _tdt_check(e, gt, fam, is_x if rng.random() < 0.7 else None)
+        e.close()
+
+
 # ------------------------------------------------------ every code byte ----
 
 def test_every_code_byte_through_every_scan():
