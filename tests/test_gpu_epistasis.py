@@ -228,19 +228,21 @@ def test_ranking_with_every_model_kept_is_the_dense_scan(eng, nA, nU, k):
         for f in range(k):
             a = np.where(np.isnan(acc[f]), -np.inf, acc[f])
             order = [p for p in sorted(range(len(pairs)), key=lambda p: (-a[p], pairs[p])) if a[p] > -np.inf]
-            assert res["n"][f] == len(order)
-            assert [(int(x), int(y)) for x, y in zip(res["i"][f], res["j"][f])] == [pairs[p] for p in order]
-            assert np.array_equal(res["accuracy"][f], acc[f][order]) and np.array_equal(res["risky"][f], rm[f][order])
+            n = len(order)                                            # (a fold without cases or without controls ranks nothing)
+            assert res["n"][f] == n
+            assert [(int(x), int(y)) for x, y in zip(res["i"][f][:n], res["j"][f][:n])] == [pairs[p] for p in order]
+            assert np.array_equal(res["accuracy"][f][:n], acc[f][order]) and np.array_equal(res["risky"][f][:n], rm[f][order])
         acc3, rm3 = eng.epi_scan_triples(subset)
         res3 = eng.epi_rank_triples(subset, len(triples))
         for f in range(k):
             vals = np.array([acc3[f][t] for t in triples])
             vals = np.where(np.isnan(vals), -np.inf, vals)
             order = [p for p in sorted(range(len(triples)), key=lambda p: (-vals[p], triples[p])) if vals[p] > -np.inf]
-            assert res3["n"][f] == len(order)
-            assert [(int(a_), int(b_), int(c_)) for a_, b_, c_ in zip(res3["i"][f], res3["j"][f], res3["k"][f])] == [triples[p] for p in order]
-            assert np.array_equal(res3["accuracy"][f], np.array([acc3[f][triples[p]] for p in order]))
-            assert np.array_equal(res3["risky"][f], np.array([rm3[f][triples[p]] for p in order], np.uint32))
+            n = len(order)
+            assert res3["n"][f] == n
+            assert [(int(a_), int(b_), int(c_)) for a_, b_, c_ in zip(res3["i"][f][:n], res3["j"][f][:n], res3["k"][f][:n])] == [triples[p] for p in order]
+            assert np.array_equal(res3["accuracy"][f][:n], np.array([acc3[f][triples[p]] for p in order]))
+            assert np.array_equal(res3["risky"][f][:n], np.array([rm3[f][triples[p]] for p in order], np.uint32))
 
 
 def test_epistasis_error_paths(eng):
@@ -416,3 +418,18 @@ def test_folds_that_lack_a_class(eng, nA, nU, k):
             assert np.array_equal(rm3[:, a, b, c], em), (a, b, c)
             got = acc3[:, a, b, c]
             assert np.all((got == ea) | (np.isnan(got) & np.isnan(ea))), (a, b, c, got, ea)
+
+
+def test_random_cohorts_through_every_scan(eng):
+    # cohorts drawn at random (HPGV_SOAK_SHAPES of them: 3 in the suite): SNP counts, class sizes equal and unequal, 1 to 16 folds --
+    # the scans are instantiated per fold count and per "classes are equal", and the dispatch picks by both
+    import os
+    rng = np.random.default_rng(int(os.environ.get("HPGV_FUZZ_SEED", "82")))
+    for _ in range(int(os.environ.get("HPGV_SOAK_SHAPES", "3"))):
+        k = int(rng.integers(1, 17))
+        nA = int(rng.choice([int(rng.integers(k, 60)), int(rng.integers(60, 700)), int(rng.integers(700, 1500))]))
+        nU = nA if rng.random() < 0.4 else int(max(k, nA * rng.uniform(0.3, 2.5)))
+        test_pair_scan_matches_the_oracle(eng, int(rng.integers(3, 90)), nA, nU, k)
+        test_pair_scan_on_a_dataset_without_missing_calls(eng, int(rng.integers(34, 80)), nA, nU, k)
+        test_triple_scan_matches_the_oracle(eng, int(rng.integers(6, 24)), nA, nU, k)
+        test_ranking_with_every_model_kept_is_the_dense_scan(eng, min(nA, 400), min(nU, 400), min(k, 10))
