@@ -599,17 +599,20 @@ def worker(args):
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; this engine has no CPU path", file=sys.stderr)
         return 2
-    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if local_rank >= torch.cuda.device_count() and args.backend == "nccl":
+    if local_rank >= torch.cuda.device_count() and args.backend == "nccl":      # before set_device, which would raise
         print("bench.py: rank %d wants GPU %d but this machine shows %d GPU(s): one rank per GPU over RCCL"
               % (rank, local_rank, torch.cuda.device_count()), file=sys.stderr)
         return 2
+    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     pg = world > 1 or args.force_process_group
     if pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
+        if "MASTER_PORT" not in os.environ:             # a forced one-rank process group: any free port (two runs side by side)
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
         else:

@@ -16,6 +16,7 @@ import numpy as np
 from . import _build
 
 OK = 0
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_UNSUPPORTED = 1, 2, 3, 4, 5, 6
 TASK_CHISQ, TASK_FISHER = 1, 2
 EPI_TESTING, EPI_TRAINING = 0, 1
 COND_UNAFFECTED, COND_AFFECTED, COND_OTHER = 0, 1, 2
@@ -40,7 +41,7 @@ SYMBOLS = [
     "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_stats_groups",
     "hpgv_epi_dataset_text", "hpgv_set_text_filters", "hpgv_stats_text", "hpgv_stats_text_groups", "hpgv_epi_set_dataset", "hpgv_epi_set_folds", "hpgv_epi_set_fold_masks", "hpgv_epi_counts",
     "hpgv_epi_counts_all_folds", "hpgv_epi_scan_pairs", "hpgv_epi_rank_pairs", "hpgv_epi_rank_pairs_rows", "hpgv_epi_scan_triples", "hpgv_epi_rank_triples", "hpgv_read_probe",
-    "hpgv_group_comm_init", "hpgv_group_comm_ranks", "hpgv_group_shard", "hpgv_group_assoc", "hpgv_group_tdt", "hpgv_group_stats", "hpgv_group_sync",
+    "hpgv_group_comm_init", "hpgv_group_comm_ranks", "hpgv_group_rccl_probe", "hpgv_group_shard", "hpgv_group_assoc", "hpgv_group_tdt", "hpgv_group_stats", "hpgv_group_sync",
 ]
 
 
@@ -154,6 +155,7 @@ def load():
     i64 = C.c_int64
     L.hpgv_group_comm_init.argtypes = [vp]
     L.hpgv_group_comm_ranks.argtypes = [vp]
+    L.hpgv_group_rccl_probe.argtypes = [C.c_char_p, C.c_size_t]
     L.hpgv_group_shard.argtypes = [vp, i64, i32, C.POINTER(i64), C.POINTER(i64)]
     L.hpgv_group_assoc.argtypes = [vp, i32, vp, vp, i64, vp, vp, vp, vp]
     L.hpgv_group_tdt.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
@@ -188,9 +190,15 @@ class Engine:
         self.h = h
         self.device = device
         self._bufs = []
+        self._views = []
 
     def close(self):
         if getattr(self, "h", None):
+            # member views of a group hold their member's raw handle: they go first (their buffers are freed while the
+            # member context is alive, and their handle is cleared so that a later close()/__del__ of the view is a no-op)
+            for v in getattr(self, "_views", []):
+                v.close()
+            self._views = []
             for b in self._bufs:
                 self.L.hpgv_dev_free(self.h, b)
             self._bufs = []
@@ -595,6 +603,9 @@ class Engine:
             raise HpgvError("no member %d" % i)
         m = Engine.__new__(Engine)
         m.L, m.h, m.device, m._bufs, m._host_bufs, m._view = self.L, C.c_void_p(h), self.L.hpgv_member_device(self.h, i), [], [], True
+        m._views = []
+        m._parent = self                # the view keeps its group alive; the group's close() closes its views first
+        self._views.append(m)
         return m
 
     def group_comm_init(self):

@@ -17,7 +17,28 @@
 #include "hpgv_internal.h"
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>      // types and enums only: every function is reached through dlsym
+// types and enums only: every function is reached through dlsym.  A build box without the RCCL headers still builds the
+// library: the few declarations the group scan uses are restated below (values as in rccl.h; RCCL keeps them ABI-stable).
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclInt32 = 2 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+extern "C" {
+ncclResult_t ncclCommInitAll(ncclComm_t *comms, int ndev, const int *devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count);
+const char *ncclGetErrorString(ncclResult_t result);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclReduce(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, int root,
+                        ncclComm_t comm, hipStream_t stream);
+}
+#endif
 
 struct GroupMember {
     hipStream_t scan = nullptr, xfer = nullptr;
@@ -65,17 +86,24 @@ __global__ void k_add_i32(int32_t *__restrict__ dst, const int32_t *__restrict__
             return fail(g, HPGV_ERR_HIP, "%s failed: %s (%s:%d)", #call, (S)->GetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 
-int load_rccl(hpgv_ctx *g, GroupState *S) {
-    if (S->dl) return HPGV_OK;
+// dlopen of librccl under its usual names ($HPGV_RCCL_LIB first); `tried` collects why each candidate failed
+void *open_rccl(std::string &tried) {
     const char *env = getenv("HPGV_RCCL_LIB");
     const char *names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    std::string tried;
     for (const char *n : names) {
         if (!n || !*n) continue;
-        S->dl = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (S->dl) break;
-        tried += std::string(tried.empty() ? "" : "; ") + (dlerror() ? dlerror() : n);
+        void *dl = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (dl) return dl;
+        const char *e = dlerror();                      // ONE call: dlerror() clears the message it returns
+        tried += std::string(tried.empty() ? "" : "; ") + std::string(e ? e : n);
     }
+    return nullptr;
+}
+
+int load_rccl(hpgv_ctx *g, GroupState *S) {
+    if (S->dl) return HPGV_OK;
+    std::string tried;
+    S->dl = open_rccl(tried);
     if (!S->dl)
         return fail(g, HPGV_ERR_UNSUPPORTED, "the group-wide scan gathers its results over RCCL and librccl could not be loaded (%s); "
                                              "set HPGV_RCCL_LIB to its path", tried.c_str());
@@ -146,6 +174,20 @@ int plan_call(hpgv_ctx *g, int64_t V, size_t bytes_per_variant, Plan &P) {
         P.base[k] = (char *)M.scratch[P.gen];
     }
     return HPGV_OK;
+}
+
+// a call that fails after plan_call has kernels queued on members' scan streams and no event recorded for them: the
+// streams are drained, so that the scratch of this generation and the caller's arrays are quiet when the error returns
+int drain(const Plan &P, int rc) {
+    for (int k = 0; k < P.G; ++k) {
+        GroupMember &M = P.S->m[(size_t)k];
+        DeviceGuard dg(P.g->members[(size_t)k]->device);
+        if (M.scan) (void)hipStreamSynchronize(M.scan);
+        if (M.xfer) (void)hipStreamSynchronize(M.xfer);
+        M.xfer_pending[0] = M.xfer_pending[1] = false;
+    }
+    (void)hipGetLastError();
+    return rc;
 }
 
 // address of member k's piece i (`before` = bytes per variant of the pieces in front of it)
@@ -295,8 +337,23 @@ int hpgv_group_comm_init(hpgv_ctx *g) {
     HPGV_ABI_CATCH(g)
 }
 
+int hpgv_group_rccl_probe(char *why, size_t why_cap) {
+    try {
+        std::string tried;
+        void *dl = open_rccl(tried);
+        if (why && why_cap) snprintf(why, why_cap, "%s", tried.c_str());
+        if (!dl) return HPGV_ERR_UNSUPPORTED;
+        const bool ok = dlsym(dl, "ncclCommInitAll") && dlsym(dl, "ncclSend") && dlsym(dl, "ncclRecv") && dlsym(dl, "ncclReduce");
+        dlclose(dl);
+        return ok ? HPGV_OK : HPGV_ERR_UNSUPPORTED;
+    } catch (...) { return HPGV_ERR_NOMEM; }
+}
+
 int hpgv_group_comm_ranks(const hpgv_ctx *g) {
-    if (!is_group(g) || !g->grp || !g->grp->ready || g->grp->comms.empty()) return 0;
+    if (!is_group(g)) return 0;
+    // g->mu guards g->grp itself: hpgv_group_comm_init may delete the state on a failure path
+    std::lock_guard<std::mutex> lk(const_cast<hpgv_ctx *>(g)->mu);
+    if (!g->grp || !g->grp->ready || g->grp->comms.empty()) return 0;
     int n = 0;
     if (g->grp->CommCount(g->grp->comms[0], &n) != ncclSuccess) return 0;
     return n;
@@ -312,8 +369,13 @@ int hpgv_group_shard(const hpgv_ctx *g, int64_t n_variants, int member, int64_t 
 
 int hpgv_group_sync(hpgv_ctx *g) {
     if (!is_group(g)) return fail(g, HPGV_ERR_INVALID, "hpgv_group_sync needs a group context");
-    if (!g->grp || !g->grp->ready) return HPGV_OK;
-    std::lock_guard<std::mutex> lk(g->grp->mu);
+    GroupState *S = nullptr;
+    {   // g->mu guards g->grp itself (see hpgv_group_comm_ranks); a ready state lives until hpgv_destroy
+        std::lock_guard<std::mutex> lk(g->mu);
+        if (g->grp && g->grp->ready) S = g->grp;
+    }
+    if (!S) return HPGV_OK;
+    std::lock_guard<std::mutex> lk(S->mu);
     for (size_t k = 0; k < g->members.size(); ++k) {
         hpgv_ctx *mc = g->members[k];
         GroupMember &M = g->grp->m[k];
@@ -344,7 +406,7 @@ int hpgv_group_assoc(hpgv_ctx *g, int task, const uint8_t *const *d_gt, const ui
         if (P.n[k] == 0) continue;
         hpgv_ctx *mc = g->members[(size_t)k];
         GroupMember &M = P.S->m[(size_t)k];
-        if (!d_gt[k]) return fail(g, HPGV_ERR_INVALID, "member %d has %lld variants but no matrix", k, (long long)P.n[k]);
+        if (!d_gt[k]) return drain(P, fail(g, HPGV_ERR_INVALID, "member %d has %lld variants but no matrix", k, (long long)P.n[k]));
         const int n = (int)P.n[k];
         int32_t *c = (int32_t *)piece_src(P, k, pieces[0], 0);
         double *o = (double *)piece_src(P, k, pieces[1], 16);
@@ -352,9 +414,10 @@ int hpgv_group_assoc(hpgv_ctx *g, int task, const uint8_t *const *d_gt, const ui
         double *p = (double *)piece_src(P, k, pieces[3], 32);
         rc = hpgv_assoc_scan_dev(mc, d_gt[k], n, d_is_x ? d_is_x[k] : nullptr, c, M.scan);
         if (!rc) rc = chisq ? hpgv_assoc_chisq_dev(mc, c, n, o, x, p, M.scan) : hpgv_assoc_fisher_dev(mc, c, n, o, p, M.scan);
-        if (rc) return rc;
+        if (rc) return drain(P, rc);
     }
-    return exchange(P, pieces);
+    rc = exchange(P, pieces);
+    return rc ? drain(P, rc) : HPGV_OK;
     HPGV_ABI_CATCH(g)
 }
 
@@ -374,15 +437,16 @@ int hpgv_group_tdt(hpgv_ctx *g, const uint8_t *const *d_gt, const uint8_t *const
         if (P.n[k] == 0) continue;
         hpgv_ctx *mc = g->members[(size_t)k];
         GroupMember &M = P.S->m[(size_t)k];
-        if (!d_gt[k]) return fail(g, HPGV_ERR_INVALID, "member %d has %lld variants but no matrix", k, (long long)P.n[k]);
+        if (!d_gt[k]) return drain(P, fail(g, HPGV_ERR_INVALID, "member %d has %lld variants but no matrix", k, (long long)P.n[k]));
         const int n = (int)P.n[k];
         int32_t *tu = (int32_t *)piece_src(P, k, pieces[0], 0);
         rc = hpgv_tdt_scan_dev(mc, d_gt[k], n, d_is_x ? d_is_x[k] : nullptr, tu, M.scan);
         if (!rc) rc = hpgv_tdt_stats_dev(mc, tu, n, (double *)piece_src(P, k, pieces[1], 8), (double *)piece_src(P, k, pieces[2], 16),
                                          (double *)piece_src(P, k, pieces[3], 24), M.scan);
-        if (rc) return rc;
+        if (rc) return drain(P, rc);
     }
-    return exchange(P, pieces);
+    rc = exchange(P, pieces);
+    return rc ? drain(P, rc) : HPGV_OK;
     HPGV_ABI_CATCH(g)
 }
 
@@ -400,7 +464,21 @@ int hpgv_group_stats(hpgv_ctx *g, const uint8_t *const *d_gt, int64_t V, int32_t
     if (rc) return rc;
     GroupState *S = P.S;
     const int n_samples = g->members[0]->stats.n_samples;
-    if (d_sample_missing && !g->members[0]->stats.set) return fail(g, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called");
+    // everything queued from here on is one unit: any failure inside it drains the members' streams before it returns
+    const auto queued = [&]() -> int {
+    if (d_sample_missing && !g->members[0]->stats.set) return drain(P, fail(g, HPGV_ERR_STATE, "hpgv_set_stats_cohort has not been called"));
+    if (d_sample_missing && n_samples > 0) {
+        // the counter array is the one destination every member ADDS into: the previous call's adds and its ncclReduce (the
+        // OTHER generation's transfers) may still be running when this call's memset is queued.  plan_call made member 0's
+        // scan wait for this generation only; with counters, it also waits for the other one.
+        GroupMember &M0 = S->m[0];
+        DeviceGuard dg(g->members[0]->device);
+        const int other = P.gen ^ 1;
+        if (M0.xfer_pending[other]) {
+            const hipError_t e = hipStreamWaitEvent(M0.scan, M0.xfer_done[other], 0);
+            if (e != hipSuccess) return drain(P, fail(g, HPGV_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(e)));
+        }
+    }
     for (int k = 0; k < P.G; ++k) {
         hpgv_ctx *mc = g->members[(size_t)k];
         GroupMember &M = S->m[(size_t)k];
@@ -421,7 +499,7 @@ int hpgv_group_stats(hpgv_ctx *g, const uint8_t *const *d_gt, int64_t V, int32_t
             HIPCHK(mc, hipMemsetAsync(miss, 0, (size_t)n_samples * sizeof(int32_t), M.scan));
         }
         if (P.n[k] == 0) continue;
-        if (!d_gt[k]) return fail(g, HPGV_ERR_INVALID, "member %d has %lld variants but no matrix", k, (long long)P.n[k]);
+        if (!d_gt[k]) return drain(P, fail(g, HPGV_ERR_INVALID, "member %d has %lld variants but no matrix", k, (long long)P.n[k]));
         const int n = (int)P.n[k];
         int32_t *c8 = (int32_t *)piece_src(P, k, pieces[0], 0);
         rc = hpgv_stats_scan_dev(mc, d_gt[k], n, c8, M.scan);
@@ -433,10 +511,11 @@ int hpgv_group_stats(hpgv_ctx *g, const uint8_t *const *d_gt, int64_t V, int32_t
             for (int v0 = 0; v0 < n && !rc; v0 += step)
                 rc = hpgv_sample_missing_dev(mc, d_gt[k] + (size_t)v0 * pitch, std::min(step, n - v0), miss, M.scan);
         }
-        if (rc) return rc;
+        if (rc) return drain(P, rc);
     }
     rc = exchange(P, pieces);
-    if (rc || !d_sample_missing || n_samples <= 0) return rc;
+    if (rc) return drain(P, rc);
+    if (!d_sample_missing || n_samples <= 0) return HPGV_OK;
     // the per-sample counters: a context on member 0's device adds its own on ITS transfer stream (which the next call of
     // this generation waits for before it overwrites them), then one ncclReduce (sum, in place on member 0) over the
     // communicator's ranks on member 0's transfer stream, behind those adds and member 0's own scan.
@@ -471,6 +550,9 @@ int hpgv_group_stats(hpgv_ctx *g, const uint8_t *const *d_gt, int64_t V, int32_t
         M.xfer_pending[P.gen] = true;
     }
     return HPGV_OK;
+    };
+    rc = queued();
+    return rc ? drain(P, rc) : HPGV_OK;
     HPGV_ABI_CATCH(g)
 }
 

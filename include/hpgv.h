@@ -249,6 +249,9 @@ int  hpgv_stats_filter_dev(hpgv_ctx *ctx, const int32_t *d_counts8, int n_varian
  *      over by a device-local copy instead of RCCL, which refuses one device twice. ------------------------------ */
 int  hpgv_group_comm_init(hpgv_ctx *group);               /* idempotent; HPGV_ERR_UNSUPPORTED without librccl */
 int  hpgv_group_comm_ranks(const hpgv_ctx *group);        /* ranks of the group's communicator (ncclCommCount); 0 before init */
+/* can librccl be loaded in this process ($HPGV_RCCL_LIB, then the usual names)?  HPGV_OK or HPGV_ERR_UNSUPPORTED;
+ * `why` (may be NULL) receives the loader's messages for the candidates that failed.  Needs no context and no device. */
+int  hpgv_group_rccl_probe(char *why, size_t why_cap);
 int  hpgv_group_shard(const hpgv_ctx *group, int64_t n_variants, int member, int64_t *lo, int64_t *hi);
 int  hpgv_group_assoc(hpgv_ctx *group, int task, const uint8_t *const *d_gt, const uint8_t *const *d_is_x,
                       int64_t n_variants, int32_t *d_counts /* V x 4 */, double *d_odds,

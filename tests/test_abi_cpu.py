@@ -54,6 +54,20 @@ def test_no_device_fails_loudly():
     assert "no CPU fallback" in str(e.value)
 
 
+def test_rccl_loader_survives_a_wrong_library_path():
+    """a candidate that fails to dlopen (a wrong HPGV_RCCL_LIB) must end in the fallback names or in
+    HPGV_ERR_UNSUPPORTED with the loader's text -- never in a crash.  Own process: a segfault would take pytest down."""
+    code = ("import importlib, ctypes as C, sys; sys.path.insert(0, %r); h = importlib.import_module('hpg-variant_amd'); "
+            "L = h.load(); b = C.create_string_buffer(2048); rc = L.hpgv_group_rccl_probe(b, 2048); "
+            "print(rc, b.value.decode()); sys.exit(0 if rc in (h.OK, h.ERR_UNSUPPORTED) else 3)" % ROOT)
+    for lib in ("/nonexistent/librccl.so", ""):
+        env = dict(os.environ, HPGV_RCCL_LIB=lib)
+        r = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+        if lib:
+            assert "/nonexistent/librccl.so" in r.stdout      # the failed candidate is named in the message
+
+
 def test_product_does_not_link_or_import_the_oracle():
     pkg = os.path.join(ROOT, "hpg-variant_amd")
     for dirpath, _, files in os.walk(pkg):
