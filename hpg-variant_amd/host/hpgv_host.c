@@ -245,6 +245,100 @@ file_stats_t *file_stats_new(void) {
 void file_stats_free(file_stats_t *f) { if (f) { pthread_mutex_destroy(&f->lock); free(f); } }
 
 /* ------------------------------------------------------------------------ */
+/* a small team of threads that sleep between jobs (condition variables, no spinning: a caller inside a CPU-limited      */
+/* container must not burn its quota waiting): the runners' reader / formatter teams and a lone caller's staging        */
+/* ------------------------------------------------------------------------ */
+
+typedef void (*pool_fn)(void *arg, int task);
+typedef struct {
+    pthread_t *th; int n_threads;
+    pthread_mutex_t mu; pthread_cond_t cv_work, cv_done;
+    pool_fn fn; void *arg; int n_tasks, next, running, gen, stop;
+} io_pool_t;
+
+static void pool_drain(io_pool_t *p) {                  /* called with mu held; returns with mu held */
+    while (p->next < p->n_tasks) {
+        const int t = p->next++;
+        pthread_mutex_unlock(&p->mu);
+        p->fn(p->arg, t);
+        pthread_mutex_lock(&p->mu);
+    }
+}
+
+static void *pool_worker(void *v) {
+    io_pool_t *p = (io_pool_t *)v;
+    int seen = 0;
+    pthread_mutex_lock(&p->mu);
+    for (;;) {
+        while (!p->stop && p->gen == seen) pthread_cond_wait(&p->cv_work, &p->mu);
+        if (p->stop) break;
+        seen = p->gen;
+        p->running++;
+        pool_drain(p);
+        if (--p->running == 0) pthread_cond_broadcast(&p->cv_done);
+    }
+    pthread_mutex_unlock(&p->mu);
+    return NULL;
+}
+
+/* n_threads counts the caller, which works too: n_threads - 1 threads are created */
+static void pool_init(io_pool_t *p, int n_threads) {
+    memset(p, 0, sizeof *p);
+    pthread_mutex_init(&p->mu, NULL);
+    pthread_cond_init(&p->cv_work, NULL);
+    pthread_cond_init(&p->cv_done, NULL);
+    if (n_threads > 1) p->th = (pthread_t *)calloc((size_t)n_threads - 1, sizeof(pthread_t));
+    for (int i = 0; p->th && i < n_threads - 1; i++) {
+        if (pthread_create(&p->th[p->n_threads], NULL, pool_worker, p) == 0) p->n_threads++;
+    }
+}
+
+/* the pool's threads spread over the CPUs the process may use, one each (the caller's own CPU last): a thread woken from a
+ * condition variable starts on its waker's CPU, and some schedulers (small VMs) leave it queued there for a whole slice
+ * instead of moving it to an idle core -- a 2 ms job cannot wait for that */
+static void pool_spread(io_pool_t *p) {
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    const int self = sched_getcpu();
+    int cpus[CPU_SETSIZE], n = 0;
+    for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed) && c != self) cpus[n++] = c;
+    if (self >= 0 && CPU_ISSET(self, &allowed)) cpus[n++] = self;
+    if (n < 2) return;
+    for (int i = 0; i < p->n_threads; i++) {
+        cpu_set_t one;
+        CPU_ZERO(&one);
+        CPU_SET(cpus[i % n], &one);
+        (void)pthread_setaffinity_np(p->th[i], sizeof one, &one);
+    }
+}
+
+static void pool_destroy(io_pool_t *p) {
+    pthread_mutex_lock(&p->mu);
+    p->stop = 1;
+    pthread_cond_broadcast(&p->cv_work);
+    pthread_mutex_unlock(&p->mu);
+    for (int i = 0; i < p->n_threads; i++) pthread_join(p->th[i], NULL);
+    free(p->th);
+    pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_work); pthread_cond_destroy(&p->cv_done);
+    memset(p, 0, sizeof *p);
+}
+
+/* runs fn(arg, 0 .. n_tasks-1), each task once, on the pool's threads and the caller; one job at a time per
+ * pool.  p == NULL, or a pool without threads, runs the tasks inline. */
+static void pool_run(io_pool_t *p, pool_fn fn, void *arg, int n_tasks) {
+    if (!p || p->n_threads == 0 || n_tasks <= 1) { for (int t = 0; t < n_tasks; t++) fn(arg, t); return; }
+    pthread_mutex_lock(&p->mu);
+    p->fn = fn; p->arg = arg; p->n_tasks = n_tasks; p->next = 0; p->gen++;
+    pthread_cond_broadcast(&p->cv_work);
+    p->running++;
+    pool_drain(p);
+    p->running--;
+    while (p->running > 0) pthread_cond_wait(&p->cv_done, &p->mu);
+    p->n_tasks = 0;
+    pthread_mutex_unlock(&p->mu);
+}
+
+/* ------------------------------------------------------------------------ */
 /* text -> HPGV8                                                              */
 /* ------------------------------------------------------------------------ */
 
@@ -286,23 +380,8 @@ int get_alleles(char *sample, int genotype_position, int *allele1, int *allele2)
     return ret;
 }
 
-static inline uint8_t encode_gt(const char *s, int gt_position, int strict) {
-    /* fast path: "a/b" or "a|b" with one-digit alleles in the first field */
-    if (gt_position == 0) {
-        unsigned char c0 = (unsigned char)s[0];
-        if (c0 && (s[1] == '/' || s[1] == '|')) {
-            unsigned char c2 = (unsigned char)s[2];
-            if (c2 && (s[3] == 0 || s[3] == ':')) {
-                int d0 = c0 - '0', d2 = c2 - '0';
-                int ok0 = (d0 >= 0 && d0 <= 9), ok2 = (d2 >= 0 && d2 <= 9);
-                if (ok0 && ok2) return (uint8_t)((d0 << 4) | d2);
-                if ((ok0 || c0 == '.') && (ok2 || c2 == '.')) {
-                    if (strict) return 0xFF;
-                    return (uint8_t)(((ok0 ? d0 : 0xF) << 4) | (ok2 ? d2 : 0xF));
-                }
-            }
-        }
-    }
+/* the general case of one sample string: any FORMAT position, multi-digit alleles, haploid and half-missing calls */
+static uint8_t encode_gt_general(const char *s, int gt_position, int strict) {
     int a1, a2;
     int st = get_alleles((char *)s, gt_position, &a1, &a2);
     if (strict && st != 0) return 0xFF;
@@ -314,25 +393,164 @@ static inline uint8_t encode_gt(const char *s, int gt_position, int strict) {
     return (uint8_t)((n1 << 4) | n2);
 }
 
+/* nibble of one allele character: '0'..'9' -> 0..9, '.' -> 0x4F (low nibble 0xF = missing, bit 6 marks it), anything else
+ * 0x80 (not the short shape) */
+#define GT_BAD4(c) [c] = 0x80, [(c) + 1] = 0x80, [(c) + 2] = 0x80, [(c) + 3] = 0x80
+#define GT_BAD16(c) GT_BAD4(c), GT_BAD4((c) + 4), GT_BAD4((c) + 8), GT_BAD4((c) + 12)
+static const uint8_t GT_NIBBLE[256] = {
+    ['0'] = 0, ['1'] = 1, ['2'] = 2, ['3'] = 3, ['4'] = 4, ['5'] = 5, ['6'] = 6, ['7'] = 7, ['8'] = 8, ['9'] = 9, ['.'] = 0x4F,
+    GT_BAD16(0), GT_BAD16(16), GT_BAD4(32), GT_BAD4(36), GT_BAD4(40), [44] = 0x80, [45] = 0x80, [47] = 0x80,
+    [58] = 0x80, [59] = 0x80, GT_BAD4(60), GT_BAD16(64), GT_BAD16(80), GT_BAD16(96), GT_BAD16(112), GT_BAD16(128), GT_BAD16(144),
+    GT_BAD16(160), GT_BAD16(176), GT_BAD16(192), GT_BAD16(208), GT_BAD16(224), GT_BAD16(240),
+};
+#undef GT_BAD16
+#undef GT_BAD4
+
+/* The first four bytes of a sample string in ONE load, with no branch on the data.  The hot shape is "a/b" or "a|b" with
+ * one-character alleles, closed by NUL or ':' -- four bytes decide it.  A string shorter than four bytes is still safe to
+ * read as a word when the word does not cross into the next page: reading past the NUL inside a mapped page cannot fault,
+ * and what is read there is ignored (a NUL in byte 0..2 fails the shape test, and the string goes the general way, which
+ * reads byte by byte).  A string within 3 bytes of its page's end is not touched here at all (it reads a block of zeros
+ * instead, fails the shape test and goes the general way).  The instrumented builds of the CPU suite (ASan) never take the
+ * word path. */
+#if defined(__SANITIZE_ADDRESS__)
+#define GT_WORD_LOADS 0
+#elif defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define GT_WORD_LOADS 0
+#endif
+#endif
+#ifndef GT_WORD_LOADS
+#define GT_WORD_LOADS 1
+#endif
+static const char GT_ZEROS[8];
+/* code of the string if it has the hot shape (whatever otherwise); *bad |= 1 when it has not */
+static inline unsigned encode_gt0_word(const char *s, int strict, unsigned *bad) {
+    const char *p = (((uintptr_t)s & 4095u) <= 4092u) ? s : GT_ZEROS;
+    uint32_t w;
+    memcpy(&w, p, 4);
+    const uint32_t ends = w & 0xFF00FF00u;                 /* separator (byte 1) and closer (byte 3) */
+    const unsigned n0 = GT_NIBBLE[w & 0xFF], n2 = GT_NIBBLE[(w >> 16) & 0xFF], m = n0 | n2;
+    const unsigned ok = ((ends == 0x00002F00u) | (ends == 0x00007C00u) | (ends == 0x3A002F00u) | (ends == 0x3A007C00u)) & ((m >> 7) ^ 1u);
+    *bad |= ok ^ 1u;
+    unsigned code = ((n0 << 4) | (n2 & 0xFu)) & 0xFFu;
+    /* strict (assoc.c:53, tdt.c:103-108: only ALLELES_OK counts): a missing allele makes the whole call missing */
+    if (strict) code |= (0u - ((m >> 6) & 1u)) & 0xFFu;
+    return code;
+}
+
+/* a row whose GT is the FIRST field of FORMAT (the usual case).  Eight strings per step, each decided by its first four
+ * bytes without a branch, so that the loads of several strings are in flight at once: every string is a heap block of its
+ * own (hpg-libs strdup's one per sample) and the loop runs at the rate those cache lines arrive.  A row that holds any
+ * string of another shape (multi-digit alleles, haploid calls, an empty string) is staged again the general way. */
+static void stage_row_gt0(char *const *samples, int num_samples, int strict, uint8_t *row) {
+    unsigned bad = 0;
+    int j = 0;
+#if GT_WORD_LOADS
+    for (; j + 8 <= num_samples; j += 8) {
+        uint64_t v = 0;
+        _Pragma("GCC unroll 8")
+        for (int k = 0; k < 8; k++) v |= (uint64_t)encode_gt0_word(samples[j + k], strict, &bad) << (8 * k);
+        memcpy(row + j, &v, 8);
+    }
+    for (; j < num_samples; j++) row[j] = (uint8_t)encode_gt0_word(samples[j], strict, &bad);
+#else
+    bad = 1;
+#endif
+    if (bad) for (j = 0; j < num_samples; j++) row[j] = encode_gt_general(samples[j], 0, strict);
+}
+
+/* position of "GT" among the ':'-separated keys of a FORMAT given by pointer and length (no copy, any length: the
+ * reference strndup's the whole field, assoc.c:45-47) */
+static int gt_position_in_format(const char *format, int format_len) {
+    int pos = 0;
+    const char *p = format, *end = format + (format_len > 0 ? format_len : 0);
+    while (p <= end) {
+        const char *e = p;
+        while (e < end && *e != ':' && *e) e++;
+        if (e - p == 2 && p[0] == 'G' && p[1] == 'T') return pos;
+        if (e >= end || !*e) return -1;
+        p = e + 1; pos++;
+    }
+    return -1;
+}
+
+/* one record's row */
+static void stage_one_record(const vcf_record_t *record, int num_samples, int strict, uint8_t *row, uint8_t *is_x) {
+    const int gt_position = record->format ? gt_position_in_format(record->format, record->format_len) : -1;
+    if (gt_position < 0 || (int)record->samples->size < num_samples) {
+        memset(row, 0xFF, (size_t)num_samples);
+    } else if (gt_position == 0) {
+        stage_row_gt0((char *const *)record->samples->items, num_samples, strict, row);
+    } else {
+        char *const *samples = (char *const *)record->samples->items;
+        for (int j = 0; j < num_samples; j++) row[j] = encode_gt_general(samples[j], gt_position, strict);
+    }
+    /* assoc.c:94: !strncmp("X", record->chromosome, record->chromosome_len) */
+    if (is_x) *is_x = !strncmp("X", record->chromosome, (size_t)record->chromosome_len);
+}
+
+/* workers a lone caller's staging is split over (0 = not yet read from HPGV_STAGE_THREADS; 1 = never split) */
+static int g_stage_threads = 0;
+static int stage_threads(void) {
+    int t = __atomic_load_n(&g_stage_threads, __ATOMIC_RELAXED);
+    if (t > 0) return t;
+    t = 8;
+    const char *e = getenv("HPGV_STAGE_THREADS");
+    if (e && *e) t = atoi(e);
+    const long cores = sysconf(_SC_NPROCESSORS_ONLN);
+    if (cores > 0 && t > cores) t = (int)cores;
+    if (t < 1) t = 1;
+    __atomic_store_n(&g_stage_threads, t, __ATOMIC_RELAXED);
+    return t;
+}
+
+void hpgv_host_set_stage_threads(int n) { __atomic_store_n(&g_stage_threads, n > 0 ? n : 0, __ATOMIC_RELAXED); }
+
+/* a lone caller's staging team: created at first use, one job at a time (a second lone caller arriving meanwhile stages
+ * its batch itself), released by hpgv_host_shutdown */
+static io_pool_t g_stage_team;
+static int g_stage_team_threads = 0;
+static pthread_mutex_t g_stage_team_mu = PTHREAD_MUTEX_INITIALIZER;
+typedef struct { vcf_record_t **variants; int num_variants, num_samples, strict, chunk; uint8_t *out, *is_x; } stage_job_t;
+static void stage_task(void *v, int t) {
+    const stage_job_t *J = (const stage_job_t *)v;
+    const int lo = t * J->chunk, hi = lo + J->chunk < J->num_variants ? lo + J->chunk : J->num_variants;
+    for (int i = lo; i < hi; i++)
+        stage_one_record(J->variants[i], J->num_samples, J->strict, J->out + (size_t)i * (size_t)J->num_samples, J->is_x ? J->is_x + i : NULL);
+}
+static void stage_team_release(void) {
+    pthread_mutex_lock(&g_stage_team_mu);
+    if (g_stage_team_threads) { pool_destroy(&g_stage_team); g_stage_team_threads = 0; }
+    pthread_mutex_unlock(&g_stage_team_mu);
+}
+
 int hpgv_host_stage_records(vcf_record_t **variants, int num_variants, int num_samples, int strict,
                             uint8_t *out, uint8_t *is_x) {
-    for (int i = 0; i < num_variants; i++) {
-        vcf_record_t *record = variants[i];
-        char fmt[256];
-        int fl = record->format_len < 255 ? record->format_len : 255;
-        memcpy(fmt, record->format, (size_t)fl);
-        fmt[fl] = 0;
-        int gt_position = get_field_position_in_format("GT", fmt);        /* assoc.c:45-47 */
-        uint8_t *row = out + (size_t)i * (size_t)num_samples;
-        if (gt_position < 0 || (int)record->samples->size < num_samples) {
-            memset(row, 0xFF, (size_t)num_samples);
-        } else {
-            char **samples = (char **)record->samples->items;
-            for (int j = 0; j < num_samples; j++) row[j] = encode_gt(samples[j], gt_position, strict);
+    /* The reference's runner calls the per-batch functions from its own OpenMP workers, one batch each
+     * (assoc_runner.c:106-207): there the workers ARE the parallelism and a batch is staged by its caller.  A caller that
+     * is alone (not inside an active parallel region) has idle cores: its batch's records are dealt to a small team. */
+    const size_t work = (size_t)(num_variants > 0 ? num_variants : 0) * (size_t)(num_samples > 0 ? num_samples : 0);
+    int alone = 1;
+#ifdef _OPENMP
+    alone = !omp_in_parallel();
+#endif
+    const int team = (alone && work >= ((size_t)1 << 18) && num_variants >= 8) ? stage_threads() : 1;
+    if (team > 1 && pthread_mutex_trylock(&g_stage_team_mu) == 0) {
+        if (g_stage_team_threads != team) {
+            if (g_stage_team_threads) pool_destroy(&g_stage_team);
+            pool_init(&g_stage_team, team);
+            pool_spread(&g_stage_team);
+            g_stage_team_threads = team;
         }
-        /* assoc.c:94: !strncmp("X", record->chromosome, record->chromosome_len) */
-        if (is_x) is_x[i] = !strncmp("X", record->chromosome, (size_t)record->chromosome_len);
+        stage_job_t J = { variants, num_variants, num_samples, strict, 1, out, is_x };
+        J.chunk = (num_variants + team * 4 - 1) / (team * 4);
+        pool_run(&g_stage_team, stage_task, &J, (num_variants + J.chunk - 1) / J.chunk);
+        pthread_mutex_unlock(&g_stage_team_mu);
+        return 0;
     }
+    for (int i = 0; i < num_variants; i++)
+        stage_one_record(variants[i], num_samples, strict, out + (size_t)i * (size_t)num_samples, is_x ? is_x + i : NULL);
     return 0;
 }
 
@@ -621,6 +839,7 @@ void hpgv_host_shutdown(void) {
      * context's, and the slot serves the next engine.) */
     pthread_rwlock_wrlock(&g_cohort_lock);
     if (g_ctx) { text_cache_release(); stage_pool_release(); hpgv_destroy(g_ctx); g_ctx = NULL; }
+    stage_team_release();
     pthread_rwlock_unlock(&g_cohort_lock);
     free(g_assoc_key.cond);
     memset(&g_assoc_key, 0, sizeof g_assoc_key);
@@ -642,6 +861,33 @@ static int thread_id(void) {
 #else
     return 0;
 #endif
+}
+
+/* where a per-batch adapter call spends its time (hpgv_host.h "hpgv_host_adapter_times"): nanoseconds, added atomically */
+static int g_adapter_profile = 0;
+static uint64_t g_adapter_ns[4];
+static long g_adapter_calls;
+void hpgv_host_adapter_profile(int on) { __atomic_store_n(&g_adapter_profile, on, __ATOMIC_RELAXED); }
+void hpgv_host_adapter_times(double *seconds4, long *calls, int reset) {
+    for (int k = 0; k < 4; k++) {
+        if (seconds4) seconds4[k] = 1e-9 * (double)__atomic_load_n(&g_adapter_ns[k], __ATOMIC_RELAXED);
+        if (reset) __atomic_store_n(&g_adapter_ns[k], 0, __ATOMIC_RELAXED);
+    }
+    if (calls) *calls = __atomic_load_n(&g_adapter_calls, __ATOMIC_RELAXED);
+    if (reset) __atomic_store_n(&g_adapter_calls, 0, __ATOMIC_RELAXED);
+}
+typedef struct { int on; uint64_t t[4]; } adapter_clock_t;
+static inline uint64_t mono_ns(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }
+static inline void adapter_clock_start(adapter_clock_t *c) { memset(c, 0, sizeof *c); c->on = __atomic_load_n(&g_adapter_profile, __ATOMIC_RELAXED); if (c->on) c->t[0] = mono_ns(); }
+static inline void adapter_clock_mark(adapter_clock_t *c, int k) { if (c->on) c->t[k] = mono_ns(); }     /* k = 1 staged, 2 engine done */
+static inline void adapter_clock_stop(adapter_clock_t *c) {
+    if (!c->on) return;
+    c->t[3] = mono_ns();
+    __atomic_fetch_add(&g_adapter_ns[0], c->t[1] - c->t[0], __ATOMIC_RELAXED);
+    __atomic_fetch_add(&g_adapter_ns[1], c->t[2] - c->t[1], __ATOMIC_RELAXED);
+    __atomic_fetch_add(&g_adapter_ns[2], c->t[3] - c->t[2], __ATOMIC_RELAXED);
+    __atomic_fetch_add(&g_adapter_ns[3], c->t[3] - c->t[0], __ATOMIC_RELAXED);
+    __atomic_fetch_add(&g_adapter_calls, 1, __ATOMIC_RELAXED);
 }
 
 /* hpg-libs init_logarithm_array: table[i] = ln(i!) */
@@ -728,7 +974,10 @@ static int assoc_test_impl(enum ASSOC_task test_type, vcf_record_t **variants, i
     double *st = (double *)malloc(n * 3 * sizeof(double));
     if (!gt || !cnt || !st) { if (gt) stage_put(gt, gt_slot); free(cnt); free(st); snprintf(g_err, sizeof g_err, "out of memory"); return HPGV_ERR_NOMEM; }
     uint8_t *is_x = gt + n * pitch;
+    adapter_clock_t clk;
+    adapter_clock_start(&clk);
     hpgv_host_stage_records(variants, num_variants, num_samples, 1, gt, is_x);   /* assoc.c:45-57 */
+    adapter_clock_mark(&clk, 1);
 
     pthread_rwlock_rdlock(&g_cohort_lock);
     rc = assoc_prepare(test_type, samples, num_samples, opt_input);
@@ -738,6 +987,7 @@ static int assoc_test_impl(enum ASSOC_task test_type, vcf_record_t **variants, i
         if (rc != HPGV_OK) host_fail("hpgv_assoc", rc);
     }
     pthread_rwlock_unlock(&g_cohort_lock);
+    adapter_clock_mark(&clk, 2);
 
     if (rc == HPGV_OK) {
         for (size_t i = 0; i < n; i++) {
@@ -770,6 +1020,7 @@ static int assoc_test_impl(enum ASSOC_task test_type, vcf_record_t **variants, i
         }
     }
     stage_put(gt, gt_slot); free(cnt); free(st);
+    adapter_clock_stop(&clk);
     return rc;
 }
 
@@ -873,7 +1124,10 @@ int tdt_test(vcf_record_t **variants, int num_variants, family_t **families, int
     double *st = (double *)malloc(n * 3 * sizeof(double));
     if (!gt || !tu || !st) { if (gt) stage_put(gt, gt_slot); free(tu); free(st); snprintf(g_err, sizeof g_err, "out of memory"); return HPGV_ERR_NOMEM; }
     uint8_t *is_x = gt + n * pitch;
+    adapter_clock_t clk;
+    adapter_clock_start(&clk);
     hpgv_host_stage_records(variants, num_variants, num_columns, 1, gt, is_x);
+    adapter_clock_mark(&clk, 1);
 
     pthread_rwlock_rdlock(&g_cohort_lock);
     rc = tdt_prepare(families, num_families, sample_ids, num_columns);
@@ -882,6 +1136,7 @@ int tdt_test(vcf_record_t **variants, int num_variants, family_t **families, int
         if (rc != HPGV_OK) host_fail("hpgv_tdt", rc);
     }
     pthread_rwlock_unlock(&g_cohort_lock);
+    adapter_clock_mark(&clk, 2);
 
     if (rc == HPGV_OK) {
         for (size_t i = 0; i < n; i++) {                                       /* tdt.c:262-268 */
@@ -898,6 +1153,7 @@ int tdt_test(vcf_record_t **variants, int num_variants, family_t **families, int
         }
     }
     stage_put(gt, gt_slot); free(tu); free(st);
+    adapter_clock_stop(&clk);
     return rc;
 }
 
@@ -951,7 +1207,10 @@ int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t *
         snprintf(g_err, sizeof g_err, "out of memory");
         return HPGV_ERR_NOMEM;
     }
+    adapter_clock_t clk;
+    adapter_clock_start(&clk);
     hpgv_host_stage_records(variants, num_variants, num_samples, 0, gt, NULL);
+    adapter_clock_mark(&clk, 1);
     int n_multi = num_variants;
 
     /* per-phenotype counters (one report per phenotype, stats_runner.c:300-303,319-323): the group of VCF
@@ -1001,6 +1260,7 @@ int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t *
         }
     }
     pthread_rwlock_unlock(&g_cohort_lock);
+    adapter_clock_mark(&clk, 2);
 
     if (rc == HPGV_OK) {
         int next_multi = 0;
@@ -1082,6 +1342,7 @@ int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t *
         }
     }
     stage_put(gt, gt_slot); free(c8); free(hw); free(midx); free(mtab); free(group); free(gc8); free(ghw);
+    adapter_clock_stop(&clk);
     return rc;
 }
 
@@ -1378,76 +1639,6 @@ int hpgv_run_epistasis_order(const char *dataset_path, int order, int num_folds,
 /* by a counter (a nested OpenMP team is created anew on every entry, which   */
 /* costs milliseconds per batch on a many-core host)                           */
 /* ------------------------------------------------------------------------ */
-
-typedef void (*pool_fn)(void *arg, int task);
-typedef struct {
-    pthread_t *th; int n_threads;
-    pthread_mutex_t mu; pthread_cond_t cv_work, cv_done;
-    pool_fn fn; void *arg; int n_tasks, next, running, gen, stop;
-} io_pool_t;
-
-static void pool_drain(io_pool_t *p) {                  /* called with mu held; returns with mu held */
-    while (p->next < p->n_tasks) {
-        const int t = p->next++;
-        pthread_mutex_unlock(&p->mu);
-        p->fn(p->arg, t);
-        pthread_mutex_lock(&p->mu);
-    }
-}
-
-static void *pool_worker(void *v) {
-    io_pool_t *p = (io_pool_t *)v;
-    int seen = 0;
-    pthread_mutex_lock(&p->mu);
-    for (;;) {
-        while (!p->stop && p->gen == seen) pthread_cond_wait(&p->cv_work, &p->mu);
-        if (p->stop) break;
-        seen = p->gen;
-        p->running++;
-        pool_drain(p);
-        if (--p->running == 0) pthread_cond_broadcast(&p->cv_done);
-    }
-    pthread_mutex_unlock(&p->mu);
-    return NULL;
-}
-
-/* n_threads counts the caller, which works too: n_threads - 1 threads are created */
-static void pool_init(io_pool_t *p, int n_threads) {
-    memset(p, 0, sizeof *p);
-    pthread_mutex_init(&p->mu, NULL);
-    pthread_cond_init(&p->cv_work, NULL);
-    pthread_cond_init(&p->cv_done, NULL);
-    if (n_threads > 1) p->th = (pthread_t *)calloc((size_t)n_threads - 1, sizeof(pthread_t));
-    for (int i = 0; p->th && i < n_threads - 1; i++) {
-        if (pthread_create(&p->th[p->n_threads], NULL, pool_worker, p) == 0) p->n_threads++;
-    }
-}
-
-static void pool_destroy(io_pool_t *p) {
-    pthread_mutex_lock(&p->mu);
-    p->stop = 1;
-    pthread_cond_broadcast(&p->cv_work);
-    pthread_mutex_unlock(&p->mu);
-    for (int i = 0; i < p->n_threads; i++) pthread_join(p->th[i], NULL);
-    free(p->th);
-    pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_work); pthread_cond_destroy(&p->cv_done);
-    memset(p, 0, sizeof *p);
-}
-
-/* runs fn(arg, 0 .. n_tasks-1), each task once, on the pool's threads and the caller; one job at a time per
- * pool.  p == NULL, or a pool without threads, runs the tasks inline. */
-static void pool_run(io_pool_t *p, pool_fn fn, void *arg, int n_tasks) {
-    if (!p || p->n_threads == 0 || n_tasks <= 1) { for (int t = 0; t < n_tasks; t++) fn(arg, t); return; }
-    pthread_mutex_lock(&p->mu);
-    p->fn = fn; p->arg = arg; p->n_tasks = n_tasks; p->next = 0; p->gen++;
-    pthread_cond_broadcast(&p->cv_work);
-    p->running++;
-    pool_drain(p);
-    p->running--;
-    while (p->running > 0) pthread_cond_wait(&p->cv_done, &p->mu);
-    p->n_tasks = 0;
-    pthread_mutex_unlock(&p->mu);
-}
 
 static int default_io_threads(void) {
     long n = sysconf(_SC_NPROCESSORS_ONLN);

@@ -359,9 +359,20 @@ int  hpgv_host_copy_lines(const char *in_path, const char *out_path, size_t batc
 /* ---- staging (GT text -> HPGV8), exposed for tests ---------------------------- */
 int  get_field_position_in_format(const char *field, char *format);
 int  get_alleles(char *sample, int genotype_position, int *allele1, int *allele2);
-/* out: num_variants x num_samples bytes, row-major; is_x: num_variants flags */
+/* out: num_variants x num_samples bytes, row-major; is_x: num_variants flags.  A caller that is alone (not inside an
+ * OpenMP parallel region) has its batch's records dealt to HPGV_STAGE_THREADS workers (environment; default 8, at
+ * most the cores; 1 = never); inside the runner's own worker team the caller stages its batch itself. */
 int  hpgv_host_stage_records(vcf_record_t **variants, int num_variants, int num_samples,
                              int strict, uint8_t *out, uint8_t *is_x);
+
+/* ---- where a per-batch adapter call spends its time (tools/bench_adapter.c) ---------------------------------
+ * hpgv_host_adapter_profile(1) switches the clocks on (four clock_gettime per call); hpgv_host_adapter_times
+ * returns what assoc_test / tdt_test / get_variants_stats calls have accumulated since the last reset, summed over
+ * the calling threads: seconds4 = {staging (sample strings -> bytes), engine (cohort check + the hpgv_* call),
+ * records (result structs, strings, list inserts), whole call}; *calls (may be NULL) their number. */
+void hpgv_host_set_stage_threads(int n);        /* the team of a lone caller's staging; 0 = back to HPGV_STAGE_THREADS / default */
+void hpgv_host_adapter_profile(int on);
+void hpgv_host_adapter_times(double *seconds4, long *calls, int reset);
 
 #ifdef __cplusplus
 }

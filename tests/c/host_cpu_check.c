@@ -192,8 +192,44 @@ static int cmd_inflate(void) {
     return 0;
 }
 
+/* sample strings that end exactly at the end of a mapped page whose successor is not accessible: the staging's four-byte
+ * loads must not reach over the edge */
+#include <sys/mman.h>
+static int cmd_pageedge(void) {
+    const size_t pg = 4096;
+    char *m = (char *)mmap(NULL, 2 * pg, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) return 2;
+    if (mprotect(m + pg, pg, PROT_NONE)) return 2;
+    static const char *const tails[4] = {"0/1", "1/", "1", ""};          /* 4, 3, 2, 1 bytes with their NUL */
+    static const uint8_t expect_strict[4] = {0x01, 0xFF, 0xFF, 0xFF}, expect_loose[4] = {0x01, 0x1F, 0x1F, 0xFF};
+    int bad = 0;
+    for (int t = 0; t < 4; t++) {
+        const size_t len = strlen(tails[t]) + 1;
+        memset(m, 'Z', pg);
+        char *edge = m + pg - len;
+        memcpy(edge, tails[t], len);
+        vcf_record_t *rec = vcf_record_new();
+        set_vcf_record_chromosome("1", 1, rec);
+        set_vcf_record_format("GT", 2, rec);
+        for (int j = 0; j < 19; j++) array_list_insert(j % 3 == 1 ? (void *)edge : (void *)"1/1", rec->samples);
+        uint8_t gt[19], isx[1];
+        for (int strict = 1; strict >= 0; strict--) {
+            hpgv_host_stage_records(&rec, 1, 19, strict, gt, isx);
+            for (int j = 0; j < 19; j++) {
+                const uint8_t want = j % 3 == 1 ? (strict ? expect_strict[t] : expect_loose[t]) : 0x11;
+                if (gt[j] != want) { printf("tail '%s' strict %d sample %d: %02x, expected %02x\n", tails[t], strict, j, gt[j], want); bad++; }
+            }
+        }
+        vcf_record_free(rec);
+    }
+    munmap(m, 2 * pg);
+    printf("%s\n", bad ? "PAGEEDGE FAILED" : "PAGEEDGE OK");
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
     if (argc >= 2 && !strcmp(argv[1], "containers")) return cmd_containers();
+    if (argc >= 2 && !strcmp(argv[1], "pageedge")) return cmd_pageedge();
     if (argc >= 2 && !strcmp(argv[1], "inflate")) return cmd_inflate();
     if (argc >= 3 && !strcmp(argv[1], "stage")) return cmd_stage(argv[2]);
     if (argc >= 3 && !strcmp(argv[1], "sort")) return hpgv_host_sort_output_file(argv[2]);

@@ -12,19 +12,33 @@ from oracle import pyoracle as orc
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def exe(tmp_path_factory):
+def _host_sources():
+    hdir = os.path.join(ROOT, "hpg-variant_amd", "host")
+    return [os.path.join(hdir, f) for f in sorted(os.listdir(hdir)) if f.endswith(".c")]
+
+
+def _compile(tmp_path_factory, name, flags):
     hpgv.build()
     from importlib import import_module
     b = import_module("hpg-variant_amd._build")
-    out = str(tmp_path_factory.mktemp("hostcpu") / "host_cpu_check")
+    out = str(tmp_path_factory.mktemp("hostcpu") / name)
     # the adapters' source is compiled in directly so that it is instrumented too
-    subprocess.check_call(["gcc", "-O1", "-g", "-std=gnu99", "-fopenmp", "-fsanitize=address,undefined",
-                           "-fno-omit-frame-pointer", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "c", "host_cpu_check.c"),
-                           os.path.join(ROOT, "hpg-variant_amd", "host", "hpgv_host.c"),
-                           "-o", out, "-L", b.LIBDIR, "-lhpgv", "-Wl,-rpath," + b.LIBDIR, "-lm", "-lz", "-lpthread"])
+    subprocess.check_call(["gcc", "-g", "-std=gnu99", "-fopenmp"] + flags +
+                          ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "hpg-variant_amd", "host"),
+                           os.path.join(ROOT, "tests", "c", "host_cpu_check.c")] + _host_sources() +
+                          ["-o", out, "-L", b.LIBDIR, "-lhpgv", "-Wl,-rpath," + b.LIBDIR, "-lm", "-lz", "-lpthread"])
     return out
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    return _compile(tmp_path_factory, "host_cpu_check", ["-O1", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"])
+
+
+@pytest.fixture(scope="module")
+def exe_plain(tmp_path_factory):
+    """the shipped optimisation level, no sanitizer: the word-at-a-time staging path (which the ASan build never takes)"""
+    return _compile(tmp_path_factory, "host_cpu_check_plain", ["-O2"])
 
 
 def _run(exe, *args):
@@ -38,11 +52,16 @@ def test_containers_and_result_list_under_sanitizers(exe):
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
 
 
-def test_staging_matches_the_oracle_encoder(exe, tmp_path):
+@pytest.mark.parametrize("build", ["asan", "plain"])
+def test_staging_matches_the_oracle_encoder(exe, exe_plain, tmp_path, build):
+    exe = exe if build == "asan" else exe_plain
     rng = np.random.default_rng(4)
     pool = QUIRK_GTS + ["0/1:12:99", ".:3", "1/", "/1", "0|0:.", "10/2", "a/1", "-1/0", "+1/1", "0/1/2", "2", "<empty>",
                         "./.:0,0", "0/0:1,2:3", "7:1/0", "7:./1:5", "7", "7:"]
-    fmts = ["GT", "GT:DP", "DP:GT", "DP:GQ:GT", "DP:GQ"]
+    pool += ["1/.", "./1", "1|.", ".|.", "9/9", "0/1:", "0/:", "1/1x", "0/1\t", "./.:", ".", "0", "1:3"]
+    hot = ["0/0", "0/1", "1|0", "1/1", "./.", "./1", "1/.", "9/9", "0/1:12:99", "./.:0,0", ".|.", "2/0", "0|9:."]
+    long_fmt = ":".join("K%d" % k for k in range(120)) + ":GT"            # > 255 bytes in front of GT (assoc.c:45 strndup's it all)
+    fmts = ["GT", "GT:DP", "DP:GT", "DP:GQ:GT", "DP:GQ", "GTX:GT", "XGT", long_fmt]
     chroms = ["1", "X", "XY", "x", "23"]
     n, v = 37, 60
     rows = []
@@ -50,7 +69,10 @@ def test_staging_matches_the_oracle_encoder(exe, tmp_path):
         f.write("%d %d\n" % (n, v))
         for i in range(v):
             fmt, chrom = fmts[i % len(fmts)], chroms[i % len(chroms)]
-            ss = [pool[int(k)] for k in rng.integers(0, len(pool), size=n)]
+            # two rows in three hold only strings of the hot shape ("a/b", one-character alleles): those rows take the
+            # word-at-a-time path of the plain build; a row with any other string is staged the general way
+            src = pool if i % 3 == 0 else hot
+            ss = [src[int(k)] for k in rng.integers(0, len(src), size=n)]
             f.write("%s %s %s\n" % (chrom, fmt, " ".join(ss)))
             rows.append((chrom, fmt, ss))
     r = _run(exe, "stage", str(tmp_path / "in.txt"))
@@ -69,6 +91,13 @@ def test_staging_matches_the_oracle_encoder(exe, tmp_path):
         pos = keys.index("GT")
         exp = ["%02x" % orc.encode_sample("" if s == "<empty>" else s, pos, strict) for s in ss]
         assert t[2:] == exp, (i, strict, list(zip(ss, t[2:], exp)))
+
+
+@pytest.mark.parametrize("build", ["asan", "plain"])
+def test_staging_never_reads_over_a_page_edge(exe, exe_plain, build):
+    r = _run(exe if build == "asan" else exe_plain, "pageedge")
+    assert r.returncode == 0 and "PAGEEDGE OK" in r.stdout, r.stdout + r.stderr
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
 
 
 def test_in_process_sort_equals_gnu_sort(exe, tmp_path):
