@@ -63,6 +63,9 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # FP64 / 64-bit vector issue peak used for the Fisher p-pass: 256 CUs x 4 SIMDs x 2.4 GHz, one wave64
 # instruction per 4 cycles per SIMD (FP64 FMA rate = 78.6 TFLOP/s spec = 16 lanes/clk/SIMD)
 VALU64_PEAK_GINST = 256 * 4 * 2.4 / 4.0
+# the cheapest instruction sequence for ONE hypergeometric term exp(konst - lf[x] - lf[r1-x] - lf[c1-x] - lf[d0+x]) added to a sum,
+# on the reference's own table (see roofline.algorithmic_note): 2 address ops + 4 subtractions + 18 exp + 1 add
+FISHER_INSTS_PER_TERM = 25
 METRIC = {"chisq": "variants/s chi2 assoc", "fisher": "variants/s fisher assoc", "tdt": "variants/s tdt",
           "stats": "variants/s vcf stats"}
 # (bytes of integer tallies at the front of a result block, bytes of a result record = SURVEY 8d payload)
@@ -190,9 +193,14 @@ def pmc_profile(workload, kernel, variants, samples, pitch):
                 for k, v in d["kernels"].items():
                     if kernel.startswith(k) and (v.get("variants_per_launch", d.get("variants")) == variants or "valu_insts_per_variant" in v):
                         best = dict(best or {}, **v)
+                        # where each replayed figure comes from: the LAST file that supplied it
+                        best.setdefault("_source", {}).update({key: "profiles/" + os.path.basename(f) for key in v})
         except Exception:
             pass
     return best
+
+
+REPLAYED = "%s (builder's rocprofv3 --pmc pass of this workload, committed; REPLAYED here, not measured in this run)"
 
 
 def bounded_rate(run, pilot, target_s, cap):
@@ -479,6 +487,7 @@ def measure(args, wl, steps, warmup, cpu_seconds, main, world, rank, dev, dev_in
             if nb > 0:
                 sources.append((recv[g_last][n_tiles - 1][r], r_lo + (n_tiles - 1) * per_tile, nb))
         ok, checked = True, 0
+        fisher_terms = []
 
         def same(got, exp):
             with np.errstate(invalid="ignore"):
@@ -517,7 +526,10 @@ def measure(args, wl, steps, warmup, cpu_seconds, main, world, rank, dev, dev_in
                     else:
                         odds, _, p = orc.assoc_stats(orc.TASK_FISHER, A1, A2, U1, U2, lf_table)
                         ok &= same(stats[0][sel], odds) and same(stats[1][sel], p)
+                        fisher_terms.append(orc.fisher_terms_needed(A1, A2, U1, U2, lf_table, 1e-22))
         parity = {"checked_variants": int(checked), "blocks": len(sources), "ok": bool(ok)}
+        fisher_terms_mean = float(np.mean(np.concatenate(fisher_terms))) if fisher_terms else None
+        fisher_terms_n = int(sum(len(t) for t in fisher_terms))
 
     if rank == 0:
         total_variants = total_per_step * steps
@@ -541,9 +553,12 @@ def measure(args, wl, steps, warmup, cpu_seconds, main, world, rank, dev, dev_in
                 "read_probe_note": "a plain (unpipelined) streaming-read kernel over the same buffer: informational, NOT a ceiling",
                 "algorithmic_bytes_per_variant": bytes_per_variant,
                 "variants_per_launch": scan_variants}
+        roof["measured_in_this_run"] = ["achieved", "frac", "kernel_ms", "kernel_samples", "read_probe_GBps"]
+        roof["traffic_source"] = None
         prof = pmc_profile(wl, scan_name, scan_variants, N, pitch) if world == 1 else None
         if prof and "hbm_bytes_per_launch" in prof:
             roof["traffic"] = prof["hbm_bytes_per_launch"]
+            roof["traffic_source"] = REPLAYED % prof["_source"]["hbm_bytes_per_launch"]
         out = {
             "metric": METRIC[kind], "value": total_variants / elapsed, "unit": "variants/s",
             "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -560,10 +575,35 @@ def measure(args, wl, steps, warmup, cpu_seconds, main, world, rank, dev, dev_in
             fprof = pmc_profile(wl, "k_assoc_fisher", scan_variants, N, pitch) or {}
             ipv = fprof.get("valu_insts_per_variant")
             ginst = (ipv * scan_variants / (stats_ms * 1e-3) / 1e9) if ipv else None
-            out["roofline"] = {"bound": "valu", "achieved": ginst, "peak": VALU64_PEAK_GINST, "unit": "Ginst/s",
-                               "frac": (ginst / VALU64_PEAK_GINST) if ginst else None, "traffic": fprof.get("hbm_bytes_per_launch"),
+            # The ALGORITHMIC work of the p-pass, counted here on the parity sample by the oracle: the hypergeometric terms each
+            # variant's p-value needs under the kernel's own tail cut (a tail stops below 10^-fisher_cut_exp of its largest
+            # term) x the cheapest per-term sequence the definition allows on this ISA (FISHER_INSTS_PER_TERM), 64 terms per
+            # wave instruction.  achieved / frac are priced on THAT: instructions the kernel spends beyond it (boundary
+            # searches, partly filled turns, per-variant setup) lower the fraction.  The old figure -- the kernel's own
+            # instruction stream over the issue peak -- stays as issue_utilisation.
+            alg_ipv = (fisher_terms_mean * FISHER_INSTS_PER_TERM / 64.0) if fisher_terms_mean else None
+            alg_ginst = (alg_ipv * scan_variants / (stats_ms * 1e-3) / 1e9) if alg_ipv else None
+            src = fprof.get("_source", {})
+            out["roofline"] = {"bound": "valu", "achieved": alg_ginst, "peak": VALU64_PEAK_GINST, "unit": "Ginst/s",
+                               "frac": (alg_ginst / VALU64_PEAK_GINST) if alg_ginst else None,
+                               "frac_algorithmic": (alg_ginst / VALU64_PEAK_GINST) if alg_ginst else None,
+                               "algorithmic_insts_per_variant": alg_ipv,
+                               "algorithmic_terms_per_variant": fisher_terms_mean,
+                               "algorithmic_insts_per_term": FISHER_INSTS_PER_TERM,
+                               "algorithmic_note": ("terms: oracle count on this run's parity sample (%d variants) of the tables with P <= P_obs(1+1e-7) above "
+                                                    "10^-%d of their tail's largest term; per term 2 address ops + 4 f64 subtractions + 18 for exp "
+                                                    "(range reduction 4, cvt/and/shift 3, polynomial 6, scale 3, underflow select 2) + 1 add, "
+                                                    "all priced at the 4-cycle 64-bit rate (profiles/r03_valu_instruction_costs.txt)"
+                                                    % (fisher_terms_n or 0, 22)),
+                               "issue_utilisation": (ginst / VALU64_PEAK_GINST) if ginst else None,
+                               "issue_utilisation_note": "the kernel's OWN vector instructions per second over the issue peak: says the SIMDs are busy, not that the work is minimal",
+                               "traffic": fprof.get("hbm_bytes_per_launch"),
+                               "traffic_source": (REPLAYED % src["hbm_bytes_per_launch"]) if "hbm_bytes_per_launch" in src else None,
                                "kernel": "k_assoc_fisher", "kernel_ms": stats_ms, "kernel_samples": len(evs),
-                               "valu_insts_per_variant": ipv, "variants_per_launch": scan_variants,
+                               "valu_insts_per_variant": ipv,
+                               "valu_insts_source": (REPLAYED % src["valu_insts_per_variant"]) if "valu_insts_per_variant" in src else None,
+                               "measured_in_this_run": ["kernel_ms", "kernel_samples", "algorithmic_terms_per_variant", "achieved", "frac", "frac_algorithmic"],
+                               "variants_per_launch": scan_variants,
                                "peak_note": "wave64 FP64 / 64-bit vector instructions: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles",
                                "overlap_note": ("value: the tile goes through in %d pieces, a piece's Fisher pass on a second stream beside the next "
                                                 "piece's scan; kernel_ms: the launches that carry events (every %d-th of the timed region) run the two "
@@ -788,7 +828,8 @@ def worker_group(args):
                                   "(ncclCommInitAll), each step's gather under the next step's scans" % G},
         "rccl_ranks": ranks,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None, "kernel": "scan kernel of member 0's shard, alone", "kernel_ms": scan_ms,
+                     "traffic": None, "traffic_source": None, "measured_in_this_run": ["achieved", "frac", "kernel_ms"],
+                     "kernel": "scan kernel of member 0's shard, alone", "kernel_ms": scan_ms,
                      "algorithmic_bytes_per_variant": N + res_bytes, "variants_per_launch": hi0 - lo0},
         "parity": {"checked_variants": int(len(idx)), "ok": bool(ok), "what": "arrays gathered on member 0 vs the oracle, sampled over every member's shard"},
     }

@@ -175,6 +175,26 @@ int list_insert_item(list_item_t *item, list_t *list) {
     return 1;
 }
 
+/* n items chained through next_p, appended in one go: what n list_insert_item calls from one thread leave behind, with one
+ * lock and one wake-up instead of n (a consumer asleep on the condition costs a system call per broadcast) */
+static void list_insert_chain(list_item_t *first, list_item_t *last, size_t n, list_t *list) {
+    if (!first || !list) return;
+    pthread_mutex_lock(&list->lock);
+    last->next_p = NULL;
+    if (list->last_p) list->last_p->next_p = first; else list->first_p = first;
+    list->last_p = last;
+    list->length += n;
+    pthread_cond_broadcast(&list->condition);
+    pthread_mutex_unlock(&list->lock);
+}
+typedef struct { list_item_t *first, *last; size_t n; } item_chain_t;
+static inline void chain_add(item_chain_t *c, list_item_t *it) {
+    if (!it) return;
+    it->next_p = NULL;
+    if (c->last) c->last->next_p = it; else c->first = it;
+    c->last = it; c->n++;
+}
+
 list_item_t *list_remove_item(list_t *list) {
     pthread_mutex_lock(&list->lock);
     while (!list->first_p && list->writers > 0) pthread_cond_wait(&list->condition, &list->lock);
@@ -393,26 +413,20 @@ static uint8_t encode_gt_general(const char *s, int gt_position, int strict) {
     return (uint8_t)((n1 << 4) | n2);
 }
 
-/* nibble of one allele character: '0'..'9' -> 0..9, '.' -> 0x4F (low nibble 0xF = missing, bit 6 marks it), anything else
- * 0x80 (not the short shape) */
-#define GT_BAD4(c) [c] = 0x80, [(c) + 1] = 0x80, [(c) + 2] = 0x80, [(c) + 3] = 0x80
-#define GT_BAD16(c) GT_BAD4(c), GT_BAD4((c) + 4), GT_BAD4((c) + 8), GT_BAD4((c) + 12)
-static const uint8_t GT_NIBBLE[256] = {
-    ['0'] = 0, ['1'] = 1, ['2'] = 2, ['3'] = 3, ['4'] = 4, ['5'] = 5, ['6'] = 6, ['7'] = 7, ['8'] = 8, ['9'] = 9, ['.'] = 0x4F,
-    GT_BAD16(0), GT_BAD16(16), GT_BAD4(32), GT_BAD4(36), GT_BAD4(40), [44] = 0x80, [45] = 0x80, [47] = 0x80,
-    [58] = 0x80, [59] = 0x80, GT_BAD4(60), GT_BAD16(64), GT_BAD16(80), GT_BAD16(96), GT_BAD16(112), GT_BAD16(128), GT_BAD16(144),
-    GT_BAD16(160), GT_BAD16(176), GT_BAD16(192), GT_BAD16(208), GT_BAD16(224), GT_BAD16(240),
-};
-#undef GT_BAD16
-#undef GT_BAD4
-
-/* The first four bytes of a sample string in ONE load, with no branch on the data.  The hot shape is "a/b" or "a|b" with
- * one-character alleles, closed by NUL or ':' -- four bytes decide it.  A string shorter than four bytes is still safe to
- * read as a word when the word does not cross into the next page: reading past the NUL inside a mapped page cannot fault,
- * and what is read there is ignored (a NUL in byte 0..2 fails the shape test, and the string goes the general way, which
- * reads byte by byte).  A string within 3 bytes of its page's end is not touched here at all (it reads a block of zeros
- * instead, fails the shape test and goes the general way).  The instrumented builds of the CPU suite (ASan) never take the
- * word path. */
+/* The hot shape of a sample string is "a/b" or "a|b" with one-character alleles ('0'..'9' or '.'), closed by NUL or ':':
+ * its first FOUR BYTES decide it, and there are only 11 x 11 x 2 x 2 = 484 such words.  They sit in a 1024-entry table
+ * under a perfect hash (one multiply, one shift: GT_HASH_MAGIC was searched for these 484 keys; gt_table_build checks it),
+ * each entry the word itself and its two codes -- strict (assoc.c:53, tdt.c:103-108: only ALLELES_OK counts, so a missing
+ * allele makes the whole call missing) and loose (the stats tool keeps the called allele of "./1").  One probe per string:
+ * read the word, hash, compare the entry's word, take the code; no branch on the data.
+ *
+ * The word is read as the ALIGNED dword at (s & ~3): an aligned dword never crosses a page, so reading past the NUL of a
+ * shorter string cannot fault, and what lies there is ignored (a NUL in byte 0..2 is not a hot word).  Heap strings (hpg-libs
+ * strdup's one per sample) start on 16-byte boundaries; a string that does not start on a dword boundary simply goes the
+ * general way, which reads byte by byte -- as does every row under the CPU suite's instrumented (ASan) build.
+ * Measured on the GPU box's host (EPYC 9575F), one thread, strings 32 bytes apart: 1.18 ns per genotype at 10 k samples
+ * (the memory system's floor for walking the strings: 0.90); the nibble-table form it replaces 1.97
+ * (tools/exp/stage_variants.c, profiles/r04_stage_variants.jsonl). */
 #if defined(__SANITIZE_ADDRESS__)
 #define GT_WORD_LOADS 0
 #elif defined(__has_feature)
@@ -423,37 +437,55 @@ static const uint8_t GT_NIBBLE[256] = {
 #ifndef GT_WORD_LOADS
 #define GT_WORD_LOADS 1
 #endif
-static const char GT_ZEROS[8];
-/* code of the string if it has the hot shape (whatever otherwise); *bad |= 1 when it has not */
-static inline unsigned encode_gt0_word(const char *s, int strict, unsigned *bad) {
-    const char *p = (((uintptr_t)s & 4095u) <= 4092u) ? s : GT_ZEROS;
+#define GT_HASH_MAGIC 0xe9c3deefu
+static uint64_t g_gt_table[1024];                       /* bits 0-31 the word, 32-39 strict code, 40-47 loose code */
+static int g_gt_table_ok = 0;                           /* 1 built, -1 the magic does not separate the keys (never: then every row goes the general way) */
+static pthread_once_t g_gt_table_once = PTHREAD_ONCE_INIT;
+static void gt_table_build(void) {
+    static const char allele[] = "0123456789.";
+    int ok = 1;
+    for (int i = 0; i < 1024; i++) g_gt_table[i] = 0xFFFFFFFFull;
+    for (int a = 0; a < 11; a++) for (int b = 0; b < 11; b++) for (int sep = 0; sep < 2; sep++) for (int end = 0; end < 2; end++) {
+        const uint32_t w = (uint32_t)allele[a] | (uint32_t)(sep ? '|' : '/') << 8 | (uint32_t)allele[b] << 16 | (uint32_t)(end ? ':' : 0) << 24;
+        const unsigned n0 = a < 10 ? (unsigned)a : 15u, n2 = b < 10 ? (unsigned)b : 15u, loose = n0 << 4 | n2;
+        const unsigned strict = (a == 10 || b == 10) ? 0xFFu : loose;
+        const uint32_t i = (w * GT_HASH_MAGIC) >> 22;
+        if ((uint32_t)g_gt_table[i] != 0xFFFFFFFFu) ok = 0;
+        g_gt_table[i] = (uint64_t)w | (uint64_t)strict << 32 | (uint64_t)loose << 40;
+    }
+    /* an empty slot holds a word that does not hash to it (and is no hot word: its byte 1 is 0xFF): it matches nothing */
+    for (uint32_t i = 0; i < 1024; i++)
+        if ((uint32_t)g_gt_table[i] == 0xFFFFFFFFu) { uint32_t k = 0xFFFFFFFFu; while (((k * GT_HASH_MAGIC) >> 22) == i) k -= 0x100u; g_gt_table[i] = k; }
+    __atomic_store_n(&g_gt_table_ok, ok ? 1 : -1, __ATOMIC_RELEASE);
+}
+/* code of the string if it is a hot word (whatever otherwise); *bad becomes non-zero when it is not */
+static inline unsigned encode_gt0_word(const char *s, int shift /* 32 strict, 40 loose */, uint32_t *bad) {
     uint32_t w;
-    memcpy(&w, p, 4);
-    const uint32_t ends = w & 0xFF00FF00u;                 /* separator (byte 1) and closer (byte 3) */
-    const unsigned n0 = GT_NIBBLE[w & 0xFF], n2 = GT_NIBBLE[(w >> 16) & 0xFF], m = n0 | n2;
-    const unsigned ok = ((ends == 0x00002F00u) | (ends == 0x00007C00u) | (ends == 0x3A002F00u) | (ends == 0x3A007C00u)) & ((m >> 7) ^ 1u);
-    *bad |= ok ^ 1u;
-    unsigned code = ((n0 << 4) | (n2 & 0xFu)) & 0xFFu;
-    /* strict (assoc.c:53, tdt.c:103-108: only ALLELES_OK counts): a missing allele makes the whole call missing */
-    if (strict) code |= (0u - ((m >> 6) & 1u)) & 0xFFu;
-    return code;
+    memcpy(&w, (const void *)((uintptr_t)s & ~(uintptr_t)3), 4);
+    const uint64_t e = g_gt_table[(w * GT_HASH_MAGIC) >> 22];
+    *bad |= ((uint32_t)e ^ w) | ((uint32_t)(uintptr_t)s & 3u);
+    return (unsigned)(e >> shift) & 0xFFu;
 }
 
-/* a row whose GT is the FIRST field of FORMAT (the usual case).  Eight strings per step, each decided by its first four
- * bytes without a branch, so that the loads of several strings are in flight at once: every string is a heap block of its
- * own (hpg-libs strdup's one per sample) and the loop runs at the rate those cache lines arrive.  A row that holds any
- * string of another shape (multi-digit alleles, haploid calls, an empty string) is staged again the general way. */
+/* a row whose GT is the FIRST field of FORMAT (the usual case).  Eight strings per step, each decided by one probe without
+ * a branch, so that the loads of several strings are in flight at once: every string is a heap block of its own and the
+ * loop runs near the rate those cache lines arrive.  A row that holds any string of another shape (multi-digit alleles,
+ * haploid calls, an empty string) is staged again the general way. */
 static void stage_row_gt0(char *const *samples, int num_samples, int strict, uint8_t *row) {
-    unsigned bad = 0;
+    uint32_t bad = 0;
     int j = 0;
 #if GT_WORD_LOADS
-    for (; j + 8 <= num_samples; j += 8) {
-        uint64_t v = 0;
-        _Pragma("GCC unroll 8")
-        for (int k = 0; k < 8; k++) v |= (uint64_t)encode_gt0_word(samples[j + k], strict, &bad) << (8 * k);
-        memcpy(row + j, &v, 8);
-    }
-    for (; j < num_samples; j++) row[j] = (uint8_t)encode_gt0_word(samples[j], strict, &bad);
+    pthread_once(&g_gt_table_once, gt_table_build);
+    if (__atomic_load_n(&g_gt_table_ok, __ATOMIC_ACQUIRE) == 1) {
+        const int shift = strict ? 32 : 40;
+        for (; j + 8 <= num_samples; j += 8) {
+            uint64_t v = 0;
+            _Pragma("GCC unroll 8")
+            for (int k = 0; k < 8; k++) v |= (uint64_t)encode_gt0_word(samples[j + k], shift, &bad) << (8 * k);
+            memcpy(row + j, &v, 8);
+        }
+        for (; j < num_samples; j++) row[j] = (uint8_t)encode_gt0_word(samples[j], shift, &bad);
+    } else bad = 1;
 #else
     bad = 1;
 #endif
@@ -581,7 +613,10 @@ static struct {
     const void *samples; int num_samples; uint64_t cond_hash; int set;
     uint8_t *cond;                                       /* the installed condition vector itself: a hash hit is confirmed against it */
 } g_assoc_key;
-static struct { int num_families; int num_columns; uint64_t hash; int set; } g_tdt_key;
+static struct {
+    int num_families; int num_columns; uint64_t hash; int set;
+    int32_t *csr; uint8_t *csex; size_t n_children;       /* the installed description itself (father | mother | offsets | child columns): a hash hit is confirmed against it */
+} g_tdt_key;
 static struct { int num_samples; int set; } g_stats_key;
 static struct { int num_samples; int n_trios; uint64_t hash; int set; } g_ped_key;
 static struct { int num_samples; int n_groups; uint64_t hash; int set; } g_group_key;
@@ -843,6 +878,7 @@ void hpgv_host_shutdown(void) {
     pthread_rwlock_unlock(&g_cohort_lock);
     free(g_assoc_key.cond);
     memset(&g_assoc_key, 0, sizeof g_assoc_key);
+    free(g_tdt_key.csr); free(g_tdt_key.csex);
     memset(&g_tdt_key, 0, sizeof g_tdt_key);
     memset(&g_stats_key, 0, sizeof g_stats_key);
     memset(&g_ped_key, 0, sizeof g_ped_key);
@@ -990,6 +1026,7 @@ static int assoc_test_impl(enum ASSOC_task test_type, vcf_record_t **variants, i
     adapter_clock_mark(&clk, 2);
 
     if (rc == HPGV_OK) {
+        item_chain_t chain = { NULL, NULL, 0 };
         for (size_t i = 0; i < n; i++) {
             vcf_record_t *record = variants[i];
             void *result;
@@ -1016,8 +1053,9 @@ static int assoc_test_impl(enum ASSOC_task test_type, vcf_record_t **variants, i
                 r->odds_ratio = st[i]; r->p_value = st[2 * n + i];
                 result = r;
             }
-            list_insert_item(list_item_new(tid, 0, result), output_list);   /* assoc.c:67-68,76-77 */
+            chain_add(&chain, list_item_new(tid, 0, result));                /* assoc.c:67-68,76-77 */
         }
+        list_insert_chain(chain.first, chain.last, chain.n, output_list);
     }
     stage_put(gt, gt_slot); free(cnt); free(st);
     adapter_clock_stop(&clk);
@@ -1089,22 +1127,39 @@ static int tdt_prepare(family_t **families, int num_families, sample_ids_t *samp
             h = (h ^ (uint64_t)(uint32_t)mcol[f]) * 1099511628211ULL;
             h = (h ^ (uint64_t)(uint32_t)nchild) * 1099511628211ULL;
         }
-        /* installed under the write lock, re-checked after coming back to the read lock (see assoc_prepare) */
-        while (rc == HPGV_OK && !(g_tdt_key.set && g_tdt_key.num_families == num_families && g_tdt_key.num_columns == num_columns &&
-                                  g_tdt_key.hash == h)) {
+        /* installed under the write lock, re-checked after coming back to the read lock (see assoc_prepare).  The 64-bit hash
+         * only says "probably": the arrays decide (a collision would count with another pedigree's columns). */
+        const size_t nfz = (size_t)(num_families > 0 ? num_families : 0), ncz = (size_t)nchild;
+#define TDT_SAME() (g_tdt_key.set && g_tdt_key.num_families == num_families && g_tdt_key.num_columns == num_columns &&            \
+                    g_tdt_key.hash == h && g_tdt_key.n_children == ncz && g_tdt_key.csr &&                                          \
+                    !memcmp(g_tdt_key.csr, fcol, nfz * 4) && !memcmp(g_tdt_key.csr + nfz, mcol, nfz * 4) &&                        \
+                    !memcmp(g_tdt_key.csr + 2 * nfz, coff, (nfz + 1) * 4) && !memcmp(g_tdt_key.csr + 3 * nfz + 1, ccol, ncz * 4) && \
+                    !memcmp(g_tdt_key.csex, csex, ncz))
+        while (rc == HPGV_OK && !TDT_SAME()) {
             pthread_rwlock_unlock(&g_cohort_lock);
             pthread_rwlock_wrlock(&g_cohort_lock);
-            if (!(g_tdt_key.set && g_tdt_key.num_families == num_families && g_tdt_key.num_columns == num_columns &&
-                  g_tdt_key.hash == h)) {
-                rc = hpgv_set_families(g_ctx, num_columns, num_families, fcol, mcol, coff, ccol, csex);
+            if (!TDT_SAME()) {
+                int32_t *keep = (int32_t *)malloc((3 * nfz + 1 + ncz + 1) * sizeof(int32_t));
+                uint8_t *keep_sex = (uint8_t *)malloc(ncz + 1);
+                if (!keep || !keep_sex) { snprintf(g_err, sizeof g_err, "out of memory"); rc = HPGV_ERR_NOMEM; }
+                else {
+                    rc = hpgv_set_families(g_ctx, num_columns, num_families, fcol, mcol, coff, ccol, csex);
+                    if (rc != HPGV_OK) host_fail("hpgv_set_families", rc);
+                }
                 if (rc == HPGV_OK) {
+                    memcpy(keep, fcol, nfz * 4); memcpy(keep + nfz, mcol, nfz * 4);
+                    memcpy(keep + 2 * nfz, coff, (nfz + 1) * 4); memcpy(keep + 3 * nfz + 1, ccol, ncz * 4);
+                    memcpy(keep_sex, csex, ncz);
+                    free(g_tdt_key.csr); free(g_tdt_key.csex);
+                    g_tdt_key.csr = keep; g_tdt_key.csex = keep_sex; g_tdt_key.n_children = ncz;
                     g_tdt_key.num_families = num_families; g_tdt_key.num_columns = num_columns;
                     g_tdt_key.hash = h; g_tdt_key.set = 1;
-                } else host_fail("hpgv_set_families", rc);
+                } else { free(keep); free(keep_sex); }
             }
             pthread_rwlock_unlock(&g_cohort_lock);
             pthread_rwlock_rdlock(&g_cohort_lock);
         }
+#undef TDT_SAME
     }
     free(fcol); free(mcol); free(coff); free(ccol); free(csex);
     return rc;
@@ -1139,6 +1194,7 @@ int tdt_test(vcf_record_t **variants, int num_variants, family_t **families, int
     adapter_clock_mark(&clk, 2);
 
     if (rc == HPGV_OK) {
+        item_chain_t chain = { NULL, NULL, 0 };
         for (size_t i = 0; i < n; i++) {                                       /* tdt.c:262-268 */
             vcf_record_t *record = variants[i];
             tdt_result_t *r = (tdt_result_t *)malloc(sizeof *r);
@@ -1149,8 +1205,9 @@ int tdt_test(vcf_record_t **variants, int num_variants, family_t **families, int
             r->alternate = dupn(record->alternate, record->alternate_len);
             r->t1 = tu[i]; r->t2 = tu[n + i];
             r->odds_ratio = st[i]; r->chi_square = st[n + i]; r->p_value = st[2 * n + i];
-            list_insert_item(list_item_new(tid, 0, r), output_list);
+            chain_add(&chain, list_item_new(tid, 0, r));
         }
+        list_insert_chain(chain.first, chain.last, chain.n, output_list);
     }
     stage_put(gt, gt_slot); free(tu); free(st);
     adapter_clock_stop(&clk);
@@ -1263,6 +1320,7 @@ int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t *
     adapter_clock_mark(&clk, 2);
 
     if (rc == HPGV_OK) {
+        item_chain_t chain = { NULL, NULL, 0 };
         int next_multi = 0;
         for (size_t i = 0; i < n; i++) {
             vcf_record_t *record = variants[i];
@@ -1330,8 +1388,9 @@ int get_variants_stats(vcf_record_t **variants, int num_variants, individual_t *
                     ps->hw_chi2 = ghw[(size_t)k * n + i]; ps->hw_p_value = ghw[((size_t)ng + k) * n + i];
                 }
             }
-            list_insert_item(list_item_new(tid, 0, s), output_list);
+            chain_add(&chain, list_item_new(tid, 0, s));
         }
+        list_insert_chain(chain.first, chain.last, chain.n, output_list);
         if (file_stats) {
             pthread_mutex_lock(&file_stats->lock);
             file_stats->variants_count += num_variants;

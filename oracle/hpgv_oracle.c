@@ -220,6 +220,40 @@ double orc_fisher_two_sided(int a, int b, int c, int d, const double *lf) {
     return sum > 1.0 ? 1.0 : sum;
 }
 
+/* How many hypergeometric terms a two-sided Fisher p-value NEEDS when a tail may stop at rel_cut x its own largest term
+ * (the engine's cut, 1e-22 by default: below one ulp of the sum): the tables x with P(x) <= P_obs (1 + 1e-7) whose P(x) is
+ * above rel_cut x the largest included term on their side of the mode.  This is bench.py's algorithmic work count for
+ * the Fisher p-pass (terms x the cheapest instruction sequence per term); rel_cut = 0 counts every included table. */
+long orc_fisher_terms_needed(int a, int b, int c, int d, const double *lf, double rel_cut) {
+    int r1 = a + b, r2 = c + d, c1 = a + c, n = r1 + r2;
+    int lo = c1 - r2; if (lo < 0) lo = 0;
+    int hi = r1 < c1 ? r1 : c1;
+    double konst = lf[r1] + lf[r2] + lf[c1] + lf[n - c1] - lf[n];
+    double thr = (konst - lf[a] - lf[r1 - a] - lf[c1 - a] - lf[r2 - c1 + a]) + 9.9999995000000333e-08;   /* ln(P_obs (1 + 1e-7)) */
+    long mode = (long)(((double)(r1 + 1) * (double)(c1 + 1)) / (double)(n + 2));
+    if (mode < lo) mode = lo;
+    if (mode > hi) mode = hi;
+    double ln_cut = rel_cut > 0.0 ? log(rel_cut) : -INFINITY;
+    long terms = 0;
+    double top = -INFINITY;                               /* left of (and at) the mode: P grows with x, the largest included term is the last */
+    for (long x = mode; x >= lo; x--) {
+        double e = konst - lf[x] - lf[r1 - x] - lf[c1 - x] - lf[r2 - c1 + x];
+        if (e > thr) continue;
+        if (top == -INFINITY) top = e;
+        if (e < top + ln_cut) break;
+        terms++;
+    }
+    top = -INFINITY;
+    for (long x = mode + 1; x <= hi; x++) {
+        double e = konst - lf[x] - lf[r1 - x] - lf[c1 - x] - lf[r2 - c1 + x];
+        if (e > thr) continue;
+        if (top == -INFINITY) top = e;
+        if (e < top + ln_cut) break;
+        terms++;
+    }
+    return terms;
+}
+
 void orc_assoc_packed(const uint8_t *gt, size_t pitch, int n_variants, int n_samples,
                       const uint8_t *condition, const uint8_t *chrom_is_x,
                       int32_t *A1, int32_t *A2, int32_t *U1, int32_t *U2) {

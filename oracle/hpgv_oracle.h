@@ -79,6 +79,8 @@ int    orc_chrom_is_x(const char *chrom, int len); /* assoc.c:94 */
 /* Fisher (assoc_fisher_test.c:24-26 -> hpg-libs fisher_test TWO_SIDED) */
 void   orc_init_logarithm_array(int n, double *table); /* table[i] = ln(i!) */
 double orc_fisher_two_sided(int a, int b, int c, int d, const double *logfact);
+/* terms of that sum a tail-cut evaluation needs (bench.py's algorithmic work count of the Fisher p-pass) */
+long orc_fisher_terms_needed(int a, int b, int c, int d, const double *lf, double rel_cut);
 
 /* batch on a packed variant-major matrix in VCF column order */
 void orc_assoc_packed(const uint8_t *gt, size_t pitch, int n_variants, int n_samples,

@@ -204,6 +204,16 @@ def assoc_stats(task, A1, A2, U1, U2, lf=None):
     return odds, (chisq if task == TASK_CHISQ else None), p
 
 
+def fisher_terms_needed(A1, A2, U1, U2, lf, rel_cut=1e-22):
+    """Per table: the hypergeometric terms its two-sided p-value needs under a relative tail cut (orc_fisher_terms_needed)."""
+    L = lib()
+    L.orc_fisher_terms_needed.restype = C.c_long
+    L.orc_fisher_terms_needed.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_double), C.c_double]
+    lfp = _p(np.ascontiguousarray(lf, dtype=np.float64), C.c_double)
+    return np.array([L.orc_fisher_terms_needed(int(a), int(b), int(c), int(d), lfp, rel_cut)
+                     for a, b, c, d in zip(A1, A2, U1, U2)], dtype=np.int64)
+
+
 def check_mendel(chrom, f1, f2, m1, m2, c1, c2, sex):
     return lib().orc_check_mendel(chrom.encode(), f1, f2, m1, m2, c1, c2, sex)
 

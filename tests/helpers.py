@@ -32,6 +32,26 @@ def assert_close(got, exp, what="", tol=TOL):
                              (what, bad.sum(), idx, got[idx], exp[idx]))
 
 
+P_REL = 1e-9   # relative agreement of p-values wherever a relative statement means something (p >= 1e-280)
+
+
+def assert_p_close(got, exp, what="p"):
+    """p-values: north_star's absolute 1e-10 AND, above 1e-280, a relative 1e-9.  The absolute bound alone says nothing about
+    a p-value below 1e-10 (every genome-wide hit).  The reference itself computes 1 - gsl_cdf_chisq_P(x, 1)
+    (assoc_basic_test.c:61, tdt.c:292), which cannot tell p = 1e-17 from 0: below ~1e-16 its digits are rounding noise, so
+    there the contract against the REFERENCE is the absolute one; the relative check pins the engine to the oracle's
+    erfc(sqrt(x / 2)), which keeps its digits all the way down."""
+    assert_close(got, exp, what)
+    got = np.asarray(got, dtype=np.float64); exp = np.asarray(exp, dtype=np.float64)
+    sel = np.isfinite(exp) & (exp >= 1e-280)
+    with np.errstate(invalid="ignore"):
+        bad = sel & ~(np.abs(got - exp) <= P_REL * exp)
+    if bad.any():
+        idx = np.flatnonzero(bad)[:5]
+        raise AssertionError("%s: %d p-values off by more than %g relative, first at %s: got %s expected %s" %
+                             (what, bad.sum(), P_REL, idx, got[idx], exp[idx]))
+
+
 # genotype strings covering every branch of assoc.c:94-125 and tdt.c:103-213
 QUIRK_GTS = ["0/0", "0/1", "1/0", "1/1", "1/2", "2/1", "0/2", "2/0", "./.", "./1", "0/.", "1|0", "0|1",
              "1", ".", "3/3", "14/0", "20/20", "15/16", "0/17"]

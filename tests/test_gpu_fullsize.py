@@ -6,7 +6,7 @@ compared with the oracle bit for bit (counts) / within 1e-10 (statistics)."""
 import numpy as np
 import pytest
 
-from helpers import assert_close, hpgv
+from helpers import assert_close, assert_p_close, hpgv
 from oracle import pyoracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -61,7 +61,7 @@ def test_assoc_chisq_and_fisher_full_size(V, N):
         A1, A2, U1, U2 = orc.assoc_counts(_rows(0, sel, N), cond)
         assert np.array_equal(counts[sel], np.stack([A1, A2, U1, U2], 1))
         odds, chisq, pv = orc.assoc_stats(orc.TASK_CHISQ, A1, A2, U1, U2)
-        assert_close(st[0][sel], odds, "odds"); assert_close(st[1][sel], chisq, "chisq"); assert_close(st[2][sel], pv, "p")
+        assert_close(st[0][sel], odds, "odds"); assert_close(st[1][sel], chisq, "chisq"); assert_p_close(st[2][sel], pv, "p")
     # Fisher p-pass on the same counts (BASELINE configs[2])
     lf = orc.logfact(N * 10)
     e.set_logfact(lf)
@@ -103,7 +103,7 @@ def test_tdt_full_size():
         t1, t2 = orc.tdt_counts(_rows(0, sel, 3 * n_tr), *fam)
         assert np.array_equal(tu[sel, 0], t1) and np.array_equal(tu[sel, 1], t2)
         odds, chisq, p = orc.tdt_stats(t1, t2)
-        assert_close(st[0][sel], odds, "odds"); assert_close(st[1][sel], chisq, "chisq"); assert_close(st[2][sel], p, "p")
+        assert_close(st[0][sel], odds, "odds"); assert_close(st[1][sel], chisq, "chisq"); assert_p_close(st[2][sel], p, "p")
     e.close()
 
 
@@ -128,7 +128,7 @@ def test_stats_full_size():
         assert list(c8[v, :4]) == list(vs.genotypes_count)[:4]
         assert (c8[v, 4], c8[v, 5], c8[v, 6], c8[v, 7]) == (vs.missing_genotypes, vs.missing_alleles,
                                                               vs.alleles_count[0], vs.alleles_count[1])
-        assert_close([hw[0][v]], [vs.hw_chi2], "hwe chi2"); assert_close([hw[1][v]], [vs.hw_p], "hwe p")
+        assert_close([hw[0][v]], [vs.hw_chi2], "hwe chi2"); assert_p_close([hw[1][v]], [vs.hw_p], "hwe p")
     e.close()
 
 
@@ -168,7 +168,7 @@ def test_assoc_every_variant_against_the_oracle_c2():
         odds, chisq, p = orc.assoc_stats(orc.TASK_CHISQ, A1, A2, U1, U2)
         assert_close(st[0][lo: lo + n], odds, "odds")
         assert_close(st[1][lo: lo + n], chisq, "chisq")
-        assert_close(st[2][lo: lo + n], p, "p")
+        assert_p_close(st[2][lo: lo + n], p, "p")
     # the slab copied back is what the oracle generator produces (first and last slab, column order undone)
     nA, nU, _ = e.assoc_layout()
     segA = (nA + 15) // 16 * 16

@@ -694,3 +694,54 @@ def test_every_code_byte_through_every_scan():
         assert np.array_equal(e.d2h(d_err, (nv,), np.int32), exp_err)
         assert np.array_equal(e.d2h(d_child, (n_trios,), np.int32), exp_trio)
     e.close()
+
+
+def test_chisq_tdt_hwe_p_values_down_the_tail():
+    # The statistics kernels straight from counts, the tables swept from no association to p ~ 1e-300: the absolute 1e-10
+    # of north_star says nothing below 1e-10, so p-values are also held to 1e-9 RELATIVE against the oracle's
+    # erfc(sqrt(x / 2)) (helpers.assert_p_close; the reference's own 1 - gsl_cdf_chisq_P quantises near 1e-16, which is
+    # why the absolute bound is the contract against it and the relative one pins the engine to the oracle).
+    from helpers import assert_p_close
+    rng = np.random.default_rng(77)
+    e = fresh()
+    # chi-square association: cases carry allele 1 with frequency f + d, controls f - d
+    n = 4000
+    tot = rng.integers(200, 100_000, n)
+    f = rng.uniform(0.05, 0.5, n)
+    d = rng.uniform(0, 0.45, n) * rng.choice([0, 1, 1, 1], n)
+    A2 = np.clip((tot * (f + d)).astype(np.int64), 0, tot); U2 = np.clip((tot * np.maximum(f - d, 0)).astype(np.int64), 0, tot)
+    tabs = np.stack([tot - A2, A2, tot - U2, U2], axis=1).astype(np.int32)          # A1 A2 U1 U2
+    d_counts, d_st = e.alloc(n * 16), e.alloc(n * 24)
+    e.h2d(d_counts, tabs)
+    e.assoc_chisq(d_counts, n, d_st.value, d_st.value + 8 * n, d_st.value + 16 * n)
+    e.sync()
+    got = e.d2h(d_st, (3, n), np.float64)
+    odds, chisq, p = orc.assoc_stats(orc.TASK_CHISQ, tabs[:, 0], tabs[:, 1], tabs[:, 2], tabs[:, 3])
+    assert_close(got[0], odds, "odds"); assert_close(got[1], chisq, "chisq"); assert_p_close(got[2], p, "chisq p")
+    assert (p[np.isfinite(p)] < 1e-100).any() and (p[np.isfinite(p)] > 0.01).any()      # the sweep reaches both ends
+    # TDT: transmitted / untransmitted tallies from balanced to one-sided
+    t1 = rng.integers(0, 20_000, n); t2 = (t1 * rng.uniform(0, 1, n)).astype(np.int64)
+    tu = np.stack([t1, t2], axis=1).astype(np.int32)
+    tu[:5] = [[0, 0], [1, 0], [0, 1], [46340, 0], [30000, 30000]]
+    d_tu = e.alloc(n * 8)
+    e.h2d(d_tu, tu)
+    e.tdt_stats(d_tu, n, d_st.value, d_st.value + 8 * n, d_st.value + 16 * n)
+    e.sync()
+    got = e.d2h(d_st, (3, n), np.float64)
+    odds, chisq, p = orc.tdt_stats(tu[:, 0], tu[:, 1])
+    assert_close(got[0], odds, "tdt odds"); assert_close(got[1], chisq, "tdt chisq"); assert_p_close(got[2], p, "tdt p")
+    # Hardy-Weinberg: genotype counts from equilibrium to all-homozygous
+    nn = rng.integers(50, 100_000, n); q = rng.uniform(0.02, 0.98, n); infl = rng.uniform(0, 1, n) * rng.choice([0, 1, 1], n)
+    het = (2 * q * (1 - q) * nn * (1 - infl)).astype(np.int64)
+    aa = ((nn - het) * (1 - q)).astype(np.int64); bb = nn - het - aa
+    c8 = np.zeros((n, 8), np.int32)
+    c8[:, 0], c8[:, 1], c8[:, 3] = aa, het, bb
+    c8[:, 6], c8[:, 7] = 2 * aa + het, 2 * bb + het
+    d_c8 = e.alloc(n * 32)
+    e.h2d(d_c8, c8)
+    e.stats_hwe(d_c8, n, d_st.value, d_st.value + 8 * n)
+    e.sync()
+    got = e.d2h(d_st, (2, n), np.float64)
+    exp = np.array([orc.hwe(int(a), int(h), int(b)) for a, h, b in zip(aa, het, bb)])
+    assert_close(got[0], exp[:, 0], "hwe chi2"); assert_p_close(got[1], exp[:, 1], "hwe p")
+    e.close()
