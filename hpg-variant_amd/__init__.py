@@ -40,7 +40,7 @@ SYMBOLS = [
     "hpgv_mendel", "hpgv_epi_dataset", "hpgv_tokenize_dev", "hpgv_tokenize", "hpgv_assoc_text", "hpgv_tdt_text",
     "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_stats_groups",
     "hpgv_epi_dataset_text", "hpgv_set_text_filters", "hpgv_stats_text", "hpgv_stats_text_groups", "hpgv_epi_set_dataset", "hpgv_epi_set_folds", "hpgv_epi_set_fold_masks", "hpgv_epi_counts",
-    "hpgv_epi_counts_all_folds", "hpgv_epi_scan_pairs", "hpgv_epi_rank_pairs", "hpgv_epi_rank_pairs_rows", "hpgv_epi_scan_triples", "hpgv_epi_rank_triples", "hpgv_read_probe",
+    "hpgv_epi_counts_all_folds", "hpgv_epi_scan_pairs", "hpgv_epi_rank_pairs", "hpgv_epi_rank_pairs_rows", "hpgv_epi_scan_triples", "hpgv_epi_rank_triples", "hpgv_epi_eval_combs", "hpgv_epi_rank_order", "hpgv_epi_rank_order_rows", "hpgv_read_probe",
     "hpgv_group_comm_init", "hpgv_group_comm_ranks", "hpgv_group_rccl_probe", "hpgv_group_shard", "hpgv_group_assoc", "hpgv_group_tdt", "hpgv_group_stats", "hpgv_group_sync",
 ]
 
@@ -150,6 +150,9 @@ def load():
     L.hpgv_epi_rank_pairs.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
     L.hpgv_epi_scan_triples.argtypes = [vp, i32, vp, vp]
     L.hpgv_epi_rank_triples.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
+    L.hpgv_epi_eval_combs.argtypes = [vp, i32, vp, i32, i32, vp, vp]
+    L.hpgv_epi_rank_order.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, C.POINTER(C.c_float)]
+    L.hpgv_epi_rank_order_rows.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(C.c_float)]
     L.hpgv_epi_rank_pairs_rows.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
     L.hpgv_read_probe.argtypes = [vp, vp, sz, i32, C.POINTER(C.c_float)]
     i64 = C.c_int64
@@ -435,6 +438,24 @@ class Engine:
         ms = C.c_float(0)
         self._chk(self.L.hpgv_epi_rank_triples(self.h, subset, n, _ptr(ci), _ptr(cj), _ptr(ck), _ptr(acc), _ptr(mask), _ptr(cnt), C.byref(ms)))
         return dict(i=ci, j=cj, k=ck, accuracy=acc, risky=mask, n=cnt, scan_ms=ms.value)
+
+    def epi_eval_combs(self, combs, subset):
+        """the MDR model of listed combinations of any order 2 .. 5: accuracy (n, folds), risky masks (n, folds, 8) u32"""
+        c = _np(combs, np.int32)
+        n, order = c.shape
+        k = self._epi[3]
+        acc, mask = np.zeros((n, k), np.float64), np.zeros((n, k, 8), np.uint32)
+        self._chk(self.L.hpgv_epi_eval_combs(self.h, order, _ptr(c), n, subset, _ptr(acc), _ptr(mask)))
+        return acc, mask
+
+    def epi_rank_order(self, order, subset, max_ranking_size, rows=None):
+        k, n = self._epi[3], max_ranking_size
+        combs = np.zeros((k, n, order), np.int32)
+        acc, mask, cnt = np.zeros((k, n), np.float64), np.zeros((k, n, 8), np.uint32), np.zeros(k, np.int32)
+        ms = C.c_float(0)
+        lo, hi = (0, self._epi[0]) if rows is None else rows
+        self._chk(self.L.hpgv_epi_rank_order_rows(self.h, order, lo, hi, subset, n, _ptr(combs), _ptr(acc), _ptr(mask), _ptr(cnt), C.byref(ms)))
+        return dict(combs=combs, accuracy=acc, risky=mask, n=cnt, scan_ms=ms.value)
 
     def epi_dataset(self, gt):
         gt = _np(gt, np.uint8)

@@ -247,15 +247,17 @@ int hpgv_epi_set_fold_masks(hpgv_ctx *ctx, const uint8_t *fold_masks, int num_fo
     HPGV_ABI_CATCH(ctx)
 }
 
+static int epi_cells(int order) { int c = 1; for (int k = 0; k < order; ++k) c *= 3; return c; }
+
 // in-fold counts of listed combinations: host vector [(comb * n_groups + g) * cells + c]
 static int epi_infold_counts(hpgv_ctx *ctx, int order, const int32_t *combs, int n_combs, std::vector<int32_t> &out) {
     EpiState &E = ctx->epi;
     if (!E.have_folds) return fail(ctx, HPGV_ERR_STATE, "hpgv_epi_set_dataset has not been called");
-    if (order != 2 && order != 3) return fail(ctx, HPGV_ERR_UNSUPPORTED, "combinations of %d SNPs are not supported (2 or 3)", order);
+    if (order < 2 || order > 5) return fail(ctx, HPGV_ERR_UNSUPPORTED, "combinations of %d SNPs are not supported (2 to 5)", order);
     if (n_combs < 0 || (n_combs > 0 && !combs)) return fail(ctx, HPGV_ERR_INVALID, "bad combination list");
     for (int k = 0; k < n_combs * order; ++k)
         if (combs[k] < 0 || combs[k] >= E.V) return fail(ctx, HPGV_ERR_INVALID, "SNP index %d outside the dataset", combs[k]);
-    const int cells = order == 2 ? 9 : 27, ng = E.num_folds * 2;
+    const int cells = epi_cells(order), ng = E.num_folds * 2;
     out.assign((size_t)n_combs * ng * cells, 0);
     if (n_combs == 0) return HPGV_OK;
     int32_t *d_combs = nullptr, *d_out = nullptr;
@@ -264,9 +266,12 @@ static int epi_infold_counts(hpgv_ctx *ctx, int order, const int32_t *combs, int
     if (e == hipSuccess) e = hipMemcpy(d_combs, combs, (size_t)n_combs * order * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         const dim3 grid((unsigned)((n_combs + 3) / 4));
+        int rc4 = HPGV_OK;
         if (order == 2) hipLaunchKernelGGL((hpgv::k_epi_counts<2>), grid, dim3(256), 0, nullptr, E.d_planes, E.W, d_combs, n_combs, E.d_group_w0, ng, d_out);
-        else hipLaunchKernelGGL((hpgv::k_epi_counts<3>), grid, dim3(256), 0, nullptr, E.d_planes, E.W, d_combs, n_combs, E.d_group_w0, ng, d_out);
+        else if (order == 3) hipLaunchKernelGGL((hpgv::k_epi_counts<3>), grid, dim3(256), 0, nullptr, E.d_planes, E.W, d_combs, n_combs, E.d_group_w0, ng, d_out);
+        else rc4 = hpgv_epi_generic_counts(ctx, order, d_combs, n_combs, d_out);      // one lane per cell (hpgv_epi_generic_kernels.h)
         e = hipGetLastError();
+        if (rc4) { (void)hipFree(d_combs); (void)hipFree(d_out); return rc4; }
     }
     if (e == hipSuccess) e = hipMemcpy(out.data(), d_out, out.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
     (void)hipFree(d_combs);
@@ -285,7 +290,7 @@ int hpgv_epi_counts(hpgv_ctx *ctx, int order, const int32_t *combs, int n_combs,
     std::vector<int32_t> in;
     int rc = epi_infold_counts(ctx, order, combs, n_combs, in);
     if (rc) return rc;
-    const int cells = order == 2 ? 9 : 27, ng = ctx->epi.num_folds * 2;
+    const int cells = epi_cells(order), ng = ctx->epi.num_folds * 2;
     for (int k = 0; k < n_combs; ++k)
         for (int c = 0; c < cells; ++c) {
             int a = 0, u = 0;
@@ -306,7 +311,7 @@ int hpgv_epi_counts_all_folds(hpgv_ctx *ctx, int order, const int32_t *combs, in
     std::vector<int32_t> in;
     int rc = epi_infold_counts(ctx, order, combs, n_combs, in);
     if (rc) return rc;
-    const int cells = order == 2 ? 9 : 27, nf = ctx->epi.num_folds, ng = nf * 2;
+    const int cells = epi_cells(order), nf = ctx->epi.num_folds, ng = nf * 2;
     for (int k = 0; k < n_combs; ++k)
         for (int c = 0; c < cells; ++c) {
             int a = 0, u = 0;

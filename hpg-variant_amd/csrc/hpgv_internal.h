@@ -319,5 +319,7 @@ int hpgv_launch_stats_all2(hpgv_ctx *ctx, hpgv::StatsAllArgs &A, void **cnt_buf,
 int hpgv_launch_assoc_rows(hpgv_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int n_variants, const uint8_t *d_is_x, int32_t *d_counts, hipStream_t st);
 // defined in hpgv_epi_capi.hip
 void hpgv_epi_release(EpiState &E);
+// defined in hpgv_epi_generic_capi.hip: in-fold counts of listed combinations of order 2 .. 5, device to device (the caller holds epi_mu)
+int hpgv_epi_generic_counts(hpgv_ctx *ctx, int order, const int32_t *d_combs, int n_combs, int32_t *d_out);
 // defined in hpgv_group_capi.hip: streams, scratch and communicator of a group context (before its members go)
 void hpgv_group_release(hpgv_ctx *group);

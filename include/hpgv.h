@@ -350,8 +350,8 @@ int  hpgv_epi_set_folds(hpgv_ctx *ctx, const int32_t *fold_of_sample, int num_fo
  * num_folds x num_samples_with_padding bytes, 1 = training part, both classes padded to 16.  Masks that
  * are not a partition (a sample left out of no fold, or of two) are refused with HPGV_ERR_UNSUPPORTED. */
 int  hpgv_epi_set_fold_masks(hpgv_ctx *ctx, const uint8_t *fold_masks, int num_folds);
-/* combination_counts (model.c:76-124) of listed combinations (order 2 or 3; combs = n_combs x order SNP
- * indices): counts_*[comb * cells + cell] */
+/* combination_counts (model.c:76-124) of listed combinations (order 2 to 5, 3^order cells; combs = n_combs x order
+ * SNP indices): counts_*[comb * cells + cell] */
 int  hpgv_epi_counts(hpgv_ctx *ctx, int order, const int32_t *combs, int n_combs,
                      int32_t *counts_aff, int32_t *counts_unaff);
 /* combination_counts_all_folds (model.c:126-206), the reference's layout for n_combs combinations in a
@@ -384,6 +384,25 @@ int  hpgv_epi_rank_pairs_rows(hpgv_ctx *ctx, int i_begin, int i_end, int subset,
 int  hpgv_epi_scan_triples(hpgv_ctx *ctx, int subset, double *accuracy, uint32_t *risky_mask);
 int  hpgv_epi_rank_triples(hpgv_ctx *ctx, int subset, int max_ranking_size, int32_t *comb_i, int32_t *comb_j,
                            int32_t *comb_k, double *accuracy, uint32_t *risky_mask, int32_t *n_ranked, float *scan_ms);
+
+/* ANY order the reference's --order takes (main_epistasis.c:128,142), here 2 <= order <= 5 (3^order cells, cell = the
+ * genotypes of the SNPs as base-3 digits, the last SNP the lowest: get_genotype_combinations, dataset.c:170-200; at most
+ * 65535 samples per class).  The pair and triple scans above are the fast forms of orders 2 and 3; these take the
+ * combinations as a LIST and work one lane per cell.
+ * hpgv_epi_eval_combs: process_set_of_combinations (epistasis.c:14-95) of n_combs listed combinations (n_combs x order SNP
+ * indices): accuracy[comb * num_folds + fold], risky_mask[(comb * num_folds + fold) * 8 + w] (bit c % 32 of word c / 32 =
+ * cell c is high risk; may be NULL).
+ * hpgv_epi_rank_order: every combination i0 < i1 < ... of the dataset, per fold the best max_ranking_size (the runner's
+ * add_to_model_ranking, model.c:478-517; ties: higher accuracy, then the smaller combination):
+ * combs_out[(fold * max_ranking_size + k) * order + s], accuracy[fold * max_ranking_size + k],
+ * risky_mask[(fold * max_ranking_size + k) * 8 + w], n_ranked[fold].  _rows: only the combinations whose FIRST SNP lies in
+ * [i_begin, i_end) -- one device's share when the first SNPs are dealt out; the shares' lists merge into the whole ranking. */
+int  hpgv_epi_eval_combs(hpgv_ctx *ctx, int order, const int32_t *combs, int n_combs, int subset, double *accuracy,
+                         uint32_t *risky_mask);
+int  hpgv_epi_rank_order(hpgv_ctx *ctx, int order, int subset, int max_ranking_size, int32_t *combs_out, double *accuracy,
+                         uint32_t *risky_mask, int32_t *n_ranked, float *scan_ms);
+int  hpgv_epi_rank_order_rows(hpgv_ctx *ctx, int order, int i_begin, int i_end, int subset, int max_ranking_size,
+                              int32_t *combs_out, double *accuracy, uint32_t *risky_mask, int32_t *n_ranked, float *scan_ms);
 
 /* Mendelian errors of a host batch: errors[v] per variant (may be NULL) and child_errors[t] per trio of
  * hpgv_set_pedigree, ACCUMULATED into (may be NULL) */
