@@ -1585,13 +1585,12 @@ uint8_t *get_k_folds_masks(unsigned int num_samples_affected, unsigned int num_s
     return masks;
 }
 
-typedef struct { int i, j, k, count; unsigned risky; double accuracy; } epi_model_t;     /* k = -1 for a pair */
+enum { EPI_ORDER_MAX = 5, EPI_MASK_WORDS = 8 };            /* 3^5 = 243 cells in 8 x 32 bits (hpgv.h "ANY order") */
+typedef struct { int c[EPI_ORDER_MAX]; int count; uint32_t risky[EPI_MASK_WORDS]; double accuracy; } epi_model_t;     /* unused SNP slots: -1 */
 
 static int cmp_model_comb(const void *a, const void *b) {            /* compare_risky, epistasis.c:162-175 */
     const epi_model_t *x = (const epi_model_t *)a, *y = (const epi_model_t *)b;
-    if (x->i != y->i) return x->i < y->i ? -1 : 1;
-    if (x->j != y->j) return x->j < y->j ? -1 : 1;
-    if (x->k != y->k) return x->k < y->k ? -1 : 1;
+    for (int s = 0; s < EPI_ORDER_MAX; s++) if (x->c[s] != y->c[s]) return x->c[s] < y->c[s] ? -1 : 1;
     return 0;
 }
 static int cmp_model_cva(const void *a, const void *b) {             /* CV-a: accuracy, then the combination */
@@ -1605,12 +1604,6 @@ static int cmp_model_cvc(const void *a, const void *b) {             /* CV-c: fo
     return cmp_model_cva(a, b);
 }
 
-/* run_epistasis (singlenode/epistasis_runner.c:23-330) for combinations of two SNPs: loads the vcf2epi dataset
- * (dataset.c:63-76: uint32 num_variants, num_affected, num_unaffected, then one row of genotypes per SNP), and for
- * every cross-validation repetition deals the folds, has the engine rank the pairs in every fold, merges the folds'
- * rankings (merge_rankings, epistasis.c:97-160: accuracies of a pair are summed over the folds that ranked it and
- * divided by num_folds; CV-c counts those folds) and writes <out_prefix>.cv<r>.epi in the format of
- * epistasis_report.c:30-81.  eval_mode 0 = CV-c, 1 = CV-a (enum evaluation_mode, model.h:74). */
 int hpgv_run_epistasis(const char *dataset_path, int num_folds, int num_cv_repetitions, int max_ranking_size,
                        int eval_subset, int eval_mode, const char *out_prefix) {
     return hpgv_run_epistasis_order(dataset_path, 2, num_folds, num_cv_repetitions, max_ranking_size, eval_subset, eval_mode, out_prefix);
@@ -1620,7 +1613,8 @@ int hpgv_run_epistasis_order(const char *dataset_path, int order, int num_folds,
                              int eval_subset, int eval_mode, const char *out_prefix) {
     int rc = ensure_engine();
     if (rc) return rc;
-    if (order != 2 && order != 3) { snprintf(g_err, sizeof g_err, "combinations of %d SNPs are not supported (2 or 3)", order); return HPGV_ERR_UNSUPPORTED; }
+    /* the reference's --order is any integer (main_epistasis.c:128,142); the engine takes 2 to 5 (243 cells) */
+    if (order < 2 || order > EPI_ORDER_MAX) { snprintf(g_err, sizeof g_err, "combinations of %d SNPs are not supported (2 to %d)", order, EPI_ORDER_MAX); return HPGV_ERR_UNSUPPORTED; }
     if (num_folds < 1 || num_cv_repetitions < 1 || max_ranking_size < 1 || !dataset_path || !out_prefix) {
         snprintf(g_err, sizeof g_err, "bad epistasis arguments");
         return HPGV_ERR_INVALID;
@@ -1635,32 +1629,41 @@ int hpgv_run_epistasis_order(const char *dataset_path, int order, int num_folds,
     rc = hpgv_epi_set_dataset(g_ctx, data, (int)V, (int)nA, (int)nU);
     free(data);
     if (rc) return host_fail("hpgv_epi_set_dataset", rc);
-    const size_t N = (size_t)max_ranking_size, K = (size_t)num_folds;
+    const size_t N = (size_t)max_ranking_size, K = (size_t)num_folds, O = (size_t)order;
     int32_t *ci = (int32_t *)malloc(sizeof(int32_t) * K * N), *cj = (int32_t *)malloc(sizeof(int32_t) * K * N), *cnt = (int32_t *)malloc(sizeof(int32_t) * K);
     int32_t *ck = (int32_t *)malloc(sizeof(int32_t) * K * N);
-    uint32_t *risky = (uint32_t *)malloc(sizeof(uint32_t) * K * N);
+    int32_t *cn = (int32_t *)malloc(sizeof(int32_t) * K * N * O);                    /* orders 4, 5: the combinations themselves */
+    uint32_t *risky = (uint32_t *)calloc(K * N * EPI_MASK_WORDS, sizeof(uint32_t));
     double *acc = (double *)malloc(sizeof(double) * K * N);
     epi_model_t *all = (epi_model_t *)malloc(sizeof(epi_model_t) * (K * N + 1));
     char *path = (char *)malloc(strlen(out_prefix) + 32);
-    if (!ci || !cj || !ck || !cnt || !risky || !acc || !all || !path) rc = HPGV_ERR_NOMEM;
+    if (!ci || !cj || !ck || !cn || !cnt || !risky || !acc || !all || !path) rc = HPGV_ERR_NOMEM;
     for (int r = 0; r < num_cv_repetitions && !rc; r++) {
         unsigned int *sizes = NULL;
         int **folds = get_k_folds((unsigned)nA, (unsigned)nU, (unsigned)num_folds, &sizes);
         uint8_t *masks = folds ? get_k_folds_masks((unsigned)nA, (unsigned)nU, (unsigned)num_folds, folds, sizes) : NULL;
         if (!masks) rc = HPGV_ERR_NOMEM;
         if (!rc && (rc = hpgv_epi_set_fold_masks(g_ctx, masks, num_folds))) host_fail("hpgv_epi_set_fold_masks", rc);
+        /* orders 2 and 3: the tile scans (one mask word per model); any other order: the listed-combination kernel */
         if (!rc && order == 2 && (rc = hpgv_epi_rank_pairs(g_ctx, eval_subset, max_ranking_size, ci, cj, acc, risky, cnt, NULL))) host_fail("hpgv_epi_rank_pairs", rc);
         if (!rc && order == 3 && (rc = hpgv_epi_rank_triples(g_ctx, eval_subset, max_ranking_size, ci, cj, ck, acc, risky, cnt, NULL))) host_fail("hpgv_epi_rank_triples", rc);
+        if (!rc && order > 3 && (rc = hpgv_epi_rank_order(g_ctx, order, eval_subset, max_ranking_size, cn, acc, risky, cnt, NULL))) host_fail("hpgv_epi_rank_order", rc);
         if (folds) { for (int k = 0; k < num_folds; k++) free(folds[k]); free(folds); }
         free(sizes); free(masks);
         if (rc) break;
         size_t n = 0;
         for (size_t k = 0; k < K; k++)
             for (int e = 0; e < cnt[k]; e++) {
-                epi_model_t m = { ci[k * N + (size_t)e], cj[k * N + (size_t)e], order == 3 ? ck[k * N + (size_t)e] : -1, 1, risky[k * N + (size_t)e], acc[k * N + (size_t)e] };
+                const size_t o = k * N + (size_t)e;
+                epi_model_t m;
+                memset(&m, 0, sizeof m);
+                for (int s = 0; s < EPI_ORDER_MAX; s++) m.c[s] = -1;
+                if (order <= 3) { m.c[0] = ci[o]; m.c[1] = cj[o]; if (order == 3) m.c[2] = ck[o]; m.risky[0] = risky[o]; }
+                else { for (size_t s = 0; s < O; s++) m.c[s] = cn[o * O + s]; memcpy(m.risky, risky + o * EPI_MASK_WORDS, sizeof m.risky); }
+                m.count = 1; m.accuracy = acc[o];
                 all[n++] = m;
             }
-        qsort(all, n, sizeof *all, cmp_model_comb);                  /* stable enough: equal pairs differ only by fold */
+        qsort(all, n, sizeof *all, cmp_model_comb);                  /* stable enough: equal combinations differ only by fold */
         size_t m = 0;
         for (size_t e = 0; e < n; e++) {
             if (m > 0 && !cmp_model_comb(&all[m - 1], &all[e])) { all[m - 1].accuracy += all[e].accuracy; all[m - 1].count += 1; }
@@ -1675,20 +1678,27 @@ int hpgv_run_epistasis_order(const char *dataset_path, int order, int num_folds,
         fprintf(fd, eval_mode == 1 ? "#EVALUATION MODE: Cross-validation accuracy\n" : "#EVALUATION MODE: Cross-validation consistency\n");
         fprintf(fd, eval_subset == HPGV_EPI_TRAINING ? "#EVALUATION PARTITION: Training\n" : "#EVALUATION PARTITION: Testing\n");
         fprintf(fd, "#POSITION\tSNPs\tGENOTYPES\tCV-C\tCV-A\n");
+        int cells = 1;
+        for (int s = 0; s < order; s++) cells *= 3;
         for (size_t e = 0; e < m && e < N; e++) {
-            /* epistasis_report.c:62-77: "( i, j )" / "( i, j, k )"; genotypes "(a-b), " / "(a-b, c), " */
-            if (order == 2) {
-                fprintf(fd, "%d\t( %d, %d )\t", (int)e + 1, all[e].i, all[e].j);
-                for (int c = 0; c < 9; c++) if (all[e].risky >> c & 1) fprintf(fd, "(%d-%d), ", c / 3, c % 3);
-            } else {
-                fprintf(fd, "%d\t( %d, %d, %d )\t", (int)e + 1, all[e].i, all[e].j, all[e].k);
-                for (int c = 0; c < 27; c++) if (all[e].risky >> c & 1) fprintf(fd, "(%d-%d, %d), ", c / 9, (c / 3) % 3, c % 3);
+            /* epistasis_report.c:62-77: "( i, j, ... )"; a risky cell "(g0-g1, g2, ..., gn), " -- '-' after the first genotype,
+             * ", " after the ones between, the last one closes */
+            fprintf(fd, "%d\t(", (int)e + 1);
+            for (int s = 0; s < order - 1; s++) fprintf(fd, " %d,", all[e].c[s]);
+            fprintf(fd, " %d )\t", all[e].c[order - 1]);
+            for (int c = 0; c < cells; c++) {
+                if (!(all[e].risky[c >> 5] >> (c & 31) & 1u)) continue;
+                int g[EPI_ORDER_MAX], q = c;
+                for (int s = order - 1; s >= 0; s--) { g[s] = q % 3; q /= 3; }         /* the last SNP varies fastest */
+                fprintf(fd, "(%d-", g[0]);
+                for (int s = 1; s < order - 1; s++) fprintf(fd, "%d, ", g[s]);
+                fprintf(fd, "%d), ", g[order - 1]);
             }
             fprintf(fd, "%d\t%.3f\n", all[e].count, all[e].accuracy);
         }
         fclose(fd);
     }
-    free(ci); free(cj); free(ck); free(cnt); free(risky); free(acc); free(all); free(path);
+    free(ci); free(cj); free(ck); free(cn); free(cnt); free(risky); free(acc); free(all); free(path);
     if (rc == HPGV_ERR_NOMEM) snprintf(g_err, sizeof g_err, "out of memory");
     return rc;
 }

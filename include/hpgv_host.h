@@ -346,7 +346,9 @@ uint8_t *get_k_folds_masks(unsigned int num_samples_affected, unsigned int num_s
  * HPGV_EPI_TRAINING; eval_mode 0 = CV-c (consistency), 1 = CV-a (accuracy). */
 int  hpgv_run_epistasis(const char *dataset_path, int num_folds, int num_cv_repetitions, int max_ranking_size,
                         int eval_subset, int eval_mode, const char *out_prefix);
-/* the same for combinations of `order` = 2 or 3 SNPs (the --order option) */
+/* the same for combinations of `order` SNPs (the --order option, main_epistasis.c:128,142): 2 and 3 through the tile scans,
+ * 4 and 5 through the listed-combination kernel (hpgv.h "ANY order"); report lines as epistasis_report.c:62-77 writes them
+ * for any order: "( i, j, k, l )" and risky cells "(a-b, c, d), " */
 int  hpgv_run_epistasis_order(const char *dataset_path, int order, int num_folds, int num_cv_repetitions,
                               int max_ranking_size, int eval_subset, int eval_mode, const char *out_prefix);
 

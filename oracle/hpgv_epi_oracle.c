@@ -134,9 +134,11 @@ double orc_epi_evaluate(const uint32_t m[4], int function) {
  * epistasis.c:30-34), confusion matrix on the chosen subset with the fold's training / testing
  * sizes (test_model, model.c:320-335) and balanced accuracy.  Outputs per fold: accuracy,
  * bit c of risky_mask = cell c is high risk, and the confusion matrix. */
-void orc_epi_model(int order, const uint8_t *const *rows, int n_affected, int n_unaffected,
-                   const uint8_t *fold_masks, int num_folds, int subset,
-                   double *accuracy, uint32_t *risky_mask, uint32_t *matrices /* num_folds x 4, may be NULL */) {
+/* risky_mask: mask_words 32-bit words per fold (bit c % 32 of word c / 32 = cell c is high risk): 1 word holds the 9 or 27
+ * cells of orders 2 and 3, 8 words the 243 of order 5 */
+void orc_epi_model_wide(int order, const uint8_t *const *rows, int n_affected, int n_unaffected,
+                        const uint8_t *fold_masks, int num_folds, int subset, int mask_words,
+                        double *accuracy, uint32_t *risky_mask, uint32_t *matrices /* num_folds x 4, may be NULL */) {
     const int cells = ipow3(order), n = n_affected + n_unaffected;
     int32_t *ca = (int32_t *)malloc(sizeof(int32_t) * (size_t)cells * num_folds);
     int32_t *cu = (int32_t *)malloc(sizeof(int32_t) * (size_t)cells * num_folds);
@@ -145,12 +147,12 @@ void orc_epi_model(int order, const uint8_t *const *rows, int n_affected, int n_
     for (int f = 0; f < num_folds; f++) {
         const uint8_t *mask = fold_masks + (size_t)f * n;
         int n_risky = 0;
-        uint32_t bits = 0;
+        for (int w = 0; w < mask_words; w++) risky_mask[(size_t)f * mask_words + w] = 0;
         for (int c = 0; c < cells; c++)
             if (orc_mdr_high_risk2(ca[f * cells + c], cu[f * cells + c], (unsigned)n_affected, (unsigned)n_unaffected)) {
                 for (int j = 0; j < order; j++) risky[n_risky * order + j] = (uint8_t)cell_genotype(order, c, j);
                 n_risky++;
-                bits |= 1u << c;
+                if (c / 32 < mask_words) risky_mask[(size_t)f * mask_words + c / 32] |= 1u << (c % 32);
             }
         /* training_sizes / testing_sizes of the fold (epistasis_runner.c:96-101) */
         int32_t train[2] = {0, 0}, size[2];
@@ -160,10 +162,15 @@ void orc_epi_model(int order, const uint8_t *const *rows, int n_affected, int n_
         uint32_t m[4];
         orc_epi_confusion(order, risky, n_risky, rows, n_affected, n_unaffected, mask, subset, size, m);
         accuracy[f] = orc_epi_evaluate(m, 1);
-        risky_mask[f] = bits;
         if (matrices) memcpy(matrices + 4 * f, m, sizeof m);
     }
     free(ca); free(cu); free(risky);
+}
+
+void orc_epi_model(int order, const uint8_t *const *rows, int n_affected, int n_unaffected,
+                   const uint8_t *fold_masks, int num_folds, int subset,
+                   double *accuracy, uint32_t *risky_mask, uint32_t *matrices /* num_folds x 4, may be NULL */) {
+    orc_epi_model_wide(order, rows, n_affected, n_unaffected, fold_masks, num_folds, subset, 1, accuracy, risky_mask, matrices);
 }
 
 /* every pair i < j of the dataset (the union of the runner's blocks, dataset.c:94-168):

@@ -190,6 +190,9 @@ double orc_epi_evaluate(const uint32_t matrix[4], int function);                
 void orc_epi_model(int order, const uint8_t *const *rows, int n_affected, int n_unaffected,
                    const uint8_t *fold_masks, int num_folds, int subset,
                    double *accuracy, uint32_t *risky_mask, uint32_t *matrices);          /* epistasis.c:14-95 */
+void orc_epi_model_wide(int order, const uint8_t *const *rows, int n_affected, int n_unaffected,
+                        const uint8_t *fold_masks, int num_folds, int subset, int mask_words,
+                        double *accuracy, uint32_t *risky_mask, uint32_t *matrices);
 void orc_epi_scan_pairs(const uint8_t *dataset, int n_variants, int n_affected, int n_unaffected,
                         const uint8_t *fold_masks, int num_folds, int subset,
                         double *accuracy, uint32_t *risky_mask);

@@ -426,6 +426,17 @@ def epi_model(rows, n_affected, n_unaffected, fold_masks, subset):
     return acc, rm, mat
 
 
+def epi_model_wide(rows, n_affected, n_unaffected, fold_masks, subset, mask_words=8):
+    """orc_epi_model_wide: any order; risky masks as (folds, mask_words) u32 (bit c % 32 of word c / 32 = cell c)."""
+    rows, arr = _rows(rows)
+    fm = np.ascontiguousarray(fold_masks, dtype=np.uint8)
+    k = fm.shape[0]
+    acc, rm, mat = np.zeros(k, np.float64), np.zeros((k, mask_words), np.uint32), np.zeros((k, 4), np.uint32)
+    lib().orc_epi_model_wide(len(rows), arr, n_affected, n_unaffected, _p(fm, C.c_uint8), k, subset, mask_words,
+                             _p(acc, C.c_double), _p(rm, C.c_uint32), _p(mat, C.c_uint32))
+    return acc, rm, mat
+
+
 def epi_scan_pairs(dataset, n_affected, n_unaffected, fold_masks, subset):
     """Every pair i < j in lexicographic order: accuracy[f][p], risky_mask[f][p]."""
     d = np.ascontiguousarray(dataset, dtype=np.uint8)

@@ -5,6 +5,7 @@ the affected and the unaffected group to multiples of 16 samples for its SSE loa
 that padded shape (`padded`: [affected block | unaffected block]) exactly as the tests write them, and
 tests/helpers strip it with the group sizes.
 
+  test/test_epistasis_model.c:34-100    test_get_masks                     (order 4: the genotype masks of four SNPs)
   test/test_epistasis_model.c:116-194   test_get_counts                    (order 2 and 3)
   test/test_epistasis_model.c:196-289   test_get_counts_all_folds_order_2
   test/test_epistasis_model.c:291-366   test_get_counts_all_folds_order_3
@@ -33,6 +34,23 @@ kat["counts"] = {
     "num_affected": 4, "num_unaffected": 4, "padded_rows": [gt0, gt1, gt2],
     "order2": {"rows": [0, 1], "aff": [2, 1, 0, 0, 1, 0, 0, 0, 0], "unaff": [0, 1, 0, 1, 0, 0, 1, 1, 0]},
     "order3": {"rows": [0, 1, 2], "aff": o3_aff, "unaff": o3_unaff},
+}
+
+# ---- test_get_masks: the fourth SNP of the file's `genotypes` array and the expected 0 / 255 masks of all four SNPs, per
+# SNP [genotype 0 | genotype 1 | genotype 2], 32 padded samples each (4 affected + 12 pad + 4 unaffected + 12 pad).  The
+# order-4 cell counts follow from THESE masks by combination_counts' own arithmetic (AND the four masks of a cell, count
+# the set bytes: model.c:76-124): tests derive them from the vectors below, nothing else is assumed.
+gt3 = [0, 0, 0, 2] + Z + [1, 1, 0, 2] + Z
+def _m(aff, unaff):
+    return [255 * x for x in aff] + Z + [255 * x for x in unaff] + Z
+kat["masks_order4"] = {
+    "num_affected": 4, "num_unaffected": 4, "padded_rows": [gt0, gt1, gt2, gt3],
+    "masks": [
+        _m([1, 1, 0, 1], [0, 0, 1, 0]) + _m([0, 0, 1, 0], [0, 1, 0, 0]) + _m([0, 0, 0, 0], [1, 0, 0, 1]),
+        _m([1, 0, 0, 1], [1, 1, 0, 0]) + _m([0, 1, 1, 0], [0, 0, 1, 1]) + _m([0, 0, 0, 0], [0, 0, 0, 0]),
+        _m([0, 0, 1, 0], [1, 0, 1, 1]) + _m([1, 0, 0, 1], [0, 0, 0, 0]) + _m([0, 1, 0, 0], [0, 1, 0, 0]),
+        _m([1, 1, 1, 0], [0, 0, 1, 0]) + _m([0, 0, 0, 0], [1, 1, 0, 0]) + _m([0, 0, 0, 1], [0, 0, 0, 1]),
+    ],
 }
 
 # ---- test_get_counts_all_folds_order_{2,3}: 5 affected + 10 unaffected, 5 folds ------------------

@@ -132,3 +132,20 @@ def epi_random_folds(rng, n_affected, n_unaffected, num_folds):
     f[rng.permutation(n_affected)] = np.arange(n_affected) % num_folds
     f[n_affected + rng.permutation(n_unaffected)] = np.arange(n_unaffected) % num_folds
     return f
+
+
+def epi_counts_from_reference_masks(kat_masks, num_affected, num_unaffected, order):
+    """combination_counts (model.c:76-124) on the reference's own expected mask arrays (test_get_masks): per SNP
+    [genotype 0 | 1 | 2] x 32 padded samples of 0 / 255 bytes.  For every cell (the last SNP's genotype varying fastest)
+    AND the SNPs' masks and count the set bytes (the reference counts bits and divides by 8), cases and controls apart."""
+    m = np.array(kat_masks, np.uint8).reshape(order, 3, 32)
+    pad_a = (num_affected + 15) // 16 * 16
+    aff, unaff = [], []
+    for c in range(3 ** order):
+        digits = [(c // 3 ** (order - 1 - s)) % 3 for s in range(order)]
+        x = np.full(32, 255, np.uint8)
+        for s, g in enumerate(digits):
+            x &= m[s][g]
+        aff.append(int(np.unpackbits(x[:num_affected]).sum() // 8))
+        unaff.append(int(np.unpackbits(x[pad_a: pad_a + num_unaffected]).sum() // 8))
+    return aff, unaff

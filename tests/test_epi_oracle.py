@@ -4,7 +4,7 @@ against an independent numpy statement of the same definitions.  CPU only."""
 import numpy as np
 import pytest
 
-from helpers import epi_random_dataset, epi_random_folds, epi_unpad
+from helpers import epi_counts_from_reference_masks, epi_random_dataset, epi_random_folds, epi_unpad
 from oracle import pyoracle as orc
 
 
@@ -20,6 +20,49 @@ def test_counts_reference_kat(kat):
     for name in ("order2", "order3"):
         aff, unaff = orc.epi_counts([rows[i] for i in k[name]["rows"]], nA, nU)
         assert list(aff) == k[name]["aff"] and list(unaff) == k[name]["unaff"], name
+
+
+def test_counts_order_4_from_the_reference_masks(kat):
+    # test_get_masks (test/test_epistasis_model.c:34-100) holds the masks of FOUR SNPs: the order-4 counts are
+    # combination_counts' arithmetic on them, and sub-combinations of two and three of the SNPs give the same answer as
+    # the reference's own order-2 / order-3 count vectors
+    k = kat["masks_order4"]
+    nA, nU = k["num_affected"], k["num_unaffected"]
+    rows = [epi_unpad(r, nA, nU) for r in k["padded_rows"]]
+    ea, eu = epi_counts_from_reference_masks(k["masks"], nA, nU, 4)
+    aff, unaff = orc.epi_counts(rows, nA, nU)
+    assert len(ea) == 81 and list(aff) == ea and list(unaff) == eu
+    assert sum(ea) == nA and sum(eu) == nU                            # no missing call in the vectors: every sample is in one cell
+    c = kat["counts"]
+    a2, u2 = epi_counts_from_reference_masks(k["masks"][:2], nA, nU, 2)
+    a3, u3 = epi_counts_from_reference_masks(k["masks"][:3], nA, nU, 3)
+    assert a2 == c["order2"]["aff"] and u2 == c["order2"]["unaff"] and a3 == c["order3"]["aff"] and u3 == c["order3"]["unaff"]
+
+
+@pytest.mark.parametrize("order", [4, 5])
+def test_model_of_higher_orders_is_consistent_with_its_counts(order):
+    # orc_epi_model_wide for orders beyond the reference's tests: its risky cells are the MDR rule on the training counts, its
+    # confusion matrix the sums of the evaluated part's counts over those cells (two independent routes through the oracle)
+    rng = np.random.default_rng(order)
+    nA, nU, k = 90, 70, 4
+    data = epi_random_dataset(rng, order, nA, nU, p_missing=0.03)
+    fold = epi_random_folds(rng, nA, nU, k)
+    masks = orc.fold_masks_from_assignment(fold, k)
+    rows = [data[s] for s in range(order)]
+    tr_a, tr_u = orc.epi_counts_all_folds(rows, nA, nU, masks)
+    all_a, all_u = orc.epi_counts(rows, nA, nU)
+    for subset in (0, 1):
+        acc, rm, mat = orc.epi_model_wide(rows, nA, nU, masks, subset)
+        for f in range(k):
+            risky = [c for c in range(3 ** order) if orc.mdr_high_risk2(int(tr_a[f][c]), int(tr_u[f][c]), nA, nU)]
+            bits = np.zeros(8, np.uint32)
+            for c in risky:
+                bits[c // 32] |= np.uint32(1) << np.uint32(c % 32)
+            assert np.array_equal(rm[f], bits)
+            ev_a = tr_a[f] if subset == 1 else all_a - tr_a[f]
+            ev_u = tr_u[f] if subset == 1 else all_u - tr_u[f]
+            tp, fp = int(ev_a[risky].sum()), int(ev_u[risky].sum())
+            assert mat[f][0] == tp and mat[f][2] == fp
 
 
 def test_counts_all_folds_reference_kat(kat):

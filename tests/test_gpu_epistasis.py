@@ -4,7 +4,7 @@ balanced accuracy is a handful of IEEE double operations on those integers, so i
 import numpy as np
 import pytest
 
-from helpers import epi_random_dataset, epi_random_folds, epi_unpad, hpgv
+from helpers import epi_counts_from_reference_masks, epi_random_dataset, epi_random_folds, epi_unpad, hpgv
 from oracle import pyoracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -160,7 +160,23 @@ def test_mdr_rule_on_cells_at_the_boundary(eng, nA, nU):
     assert ties > 0
 
 
-def test_counts_against_the_oracle_order_2_and_3(eng):
+def test_counts_order_4_reference_masks_kat(eng, goldens):
+    # the four SNPs of test_get_masks (test/test_epistasis_model.c:34-100): the engine's order-4 counts are what
+    # combination_counts' arithmetic gives on the reference's own expected masks
+    k = goldens["kats"]["epistasis_model"]["masks_order4"]
+    nA, nU = k["num_affected"], k["num_unaffected"]
+    rows = np.stack([epi_unpad(r, nA, nU) for r in k["padded_rows"]])
+    eng.epi_set_dataset(rows, nA, nU)
+    aff, unaff = eng.epi_counts([[0, 1, 2, 3]])
+    ea, eu = epi_counts_from_reference_masks(k["masks"], nA, nU, 4)
+    assert aff[0].tolist() == ea and unaff[0].tolist() == eu
+    for sub in ([0, 1, 2], [1, 2, 3], [0, 3]):
+        a, u = eng.epi_counts([sub])
+        ea, eu = epi_counts_from_reference_masks([k["masks"][s] for s in sub], nA, nU, len(sub))
+        assert a[0].tolist() == ea and u[0].tolist() == eu, sub
+
+
+def test_counts_against_the_oracle_order_2_to_5(eng):
     rng = np.random.default_rng(99)
     v, nA, nU, k = 25, 333, 401, 7
     data = epi_random_dataset(rng, v, nA, nU, p_missing=0.05)
@@ -168,8 +184,8 @@ def test_counts_against_the_oracle_order_2_and_3(eng):
     eng.epi_set_dataset(data, nA, nU)
     eng.epi_set_folds(fold, k)
     masks = orc.fold_masks_from_assignment(fold, k)
-    for order in (2, 3):
-        combs = np.array([sorted(rng.choice(v, size=order, replace=False)) for _ in range(40)], np.int32)
+    for order in (2, 3, 4, 5):
+        combs = np.array([sorted(rng.choice(v, size=order, replace=False)) for _ in range(40 if order < 4 else 11)], np.int32)
         aff, unaff = eng.epi_counts(combs)
         faff, funaff = eng.epi_counts(combs, all_folds=True)
         for n, comb in enumerate(combs):
@@ -394,7 +410,7 @@ def test_run_epistasis_order_3_report(tmp_path):
     cells = genos.split("), ")
     assert count == "4" and all(len(c.strip("()").replace("-", ",").replace(" ", "").split(",")) == 3 for c in cells)
     assert "(1-1, 1)" in first[2] and "(2-2, 2)" in first[2] and "(0-" not in first[2]      # the planted carriers
-    assert L.hpgv_run_epistasis_order(str(path).encode(), 4, 4, 1, 6, 0, 1, prefix.encode()) != 0      # order 4: refused
+    assert L.hpgv_run_epistasis_order(str(path).encode(), 6, 4, 1, 6, 0, 1, prefix.encode()) != 0      # order 6: refused (2 to 5)
 
 
 @pytest.mark.parametrize("nA,nU,k", [(20, 2, 4), (2, 21, 4), (3, 3, 3), (1, 40, 2)])
@@ -433,3 +449,131 @@ def test_random_cohorts_through_every_scan(eng):
         test_pair_scan_on_a_dataset_without_missing_calls(eng, int(rng.integers(34, 80)), nA, nU, k)
         test_triple_scan_matches_the_oracle(eng, int(rng.integers(6, 24)), nA, nU, k)
         test_ranking_with_every_model_kept_is_the_dense_scan(eng, min(nA, 400), min(nU, 400), min(k, 10))
+
+
+# ---- any order the reference's --order takes (2 to 5): the listed-combination kernel, one lane per cell ---------------------
+
+@pytest.mark.parametrize("order,v,nA,nU,k", [(2, 14, 120, 150, 5), (3, 11, 97, 64, 4), (4, 9, 210, 190, 10), (5, 8, 130, 310, 3),
+                                             (4, 7, 33, 1200, 16), (5, 7, 500, 500, 1)])
+def test_listed_combinations_of_any_order_match_the_oracle(eng, order, v, nA, nU, k):
+    import itertools
+    rng = np.random.default_rng(1000 * order + v)
+    data = epi_random_dataset(rng, v, nA, nU, p_missing=0.03)
+    fold = epi_random_folds(rng, nA, nU, k)
+    eng.epi_set_dataset(data, nA, nU)
+    eng.epi_set_folds(fold, k)
+    masks = orc.fold_masks_from_assignment(fold, k)
+    combs = np.array(list(itertools.combinations(range(v), order)), np.int32)
+    if len(combs) > 60:
+        combs = combs[np.sort(rng.choice(len(combs), 60, replace=False))]
+    for subset in (hpgv.EPI_TESTING, hpgv.EPI_TRAINING):
+        acc, mask = eng.epi_eval_combs(combs, subset)
+        for n, comb in enumerate(combs):
+            ea, em, _ = orc.epi_model_wide([data[c] for c in comb], nA, nU, masks, subset)
+            assert _same(acc[n], ea), (comb, subset, acc[n], ea)
+            assert np.array_equal(mask[n], em), (comb, subset)
+
+
+def test_listed_combinations_agree_with_the_pair_and_triple_scans(eng):
+    # two implementations of orders 2 and 3: the tile scans and the one-lane-per-cell kernel
+    import itertools
+    rng = np.random.default_rng(5)
+    v, nA, nU, k = 40, 700, 650, 6
+    data = epi_random_dataset(rng, v, nA, nU)
+    eng.epi_set_dataset(data, nA, nU)
+    eng.epi_set_folds(epi_random_folds(rng, nA, nU, k), k)
+    for subset in (hpgv.EPI_TESTING, hpgv.EPI_TRAINING):
+        pa, pm = eng.epi_scan_pairs(subset)
+        pairs = np.array(list(itertools.combinations(range(v), 2)), np.int32)
+        acc, mask = eng.epi_eval_combs(pairs, subset)
+        assert _same(acc.T, pa) and np.array_equal(mask[:, :, 0].T, pm.astype(np.uint32)) and not mask[:, :, 1:].any()
+        ta, tm = eng.epi_scan_triples(subset)
+        triples = np.array(list(itertools.combinations(range(v), 3)), np.int32)
+        acc, mask = eng.epi_eval_combs(triples, subset)
+        assert _same(acc.T, ta[:, triples[:, 0], triples[:, 1], triples[:, 2]])
+        assert np.array_equal(mask[:, :, 0].T, tm[:, triples[:, 0], triples[:, 1], triples[:, 2]])
+
+
+def _rank_from_dense(acc, combs, n):
+    """per fold the best n of a dense evaluation (folds x combos), ties to the smaller combination (= the listing order)"""
+    out = []
+    for f in range(acc.shape[0]):
+        ok = np.flatnonzero(~np.isnan(acc[f]))
+        order = ok[np.lexsort((ok, -acc[f][ok]))][:n]
+        out.append(order)
+    return out
+
+
+@pytest.mark.parametrize("order,v", [(4, 13), (5, 11), (2, 30)])
+def test_ranking_of_any_order_is_the_top_of_the_dense_evaluation(eng, order, v):
+    import itertools
+    rng = np.random.default_rng(order * 31 + v)
+    nA, nU, k, n = 150, 170, 5, 9
+    data = epi_random_dataset(rng, v, nA, nU)
+    carriers = rng.choice(v, size=order, replace=False)
+    data[np.ix_(carriers, np.arange(nA))] = rng.choice([1, 2], size=(order, nA))         # a planted model: the cases carry the variants
+    eng.epi_set_dataset(data, nA, nU)
+    eng.epi_set_folds(epi_random_folds(rng, nA, nU, k), k)
+    combs = np.array(list(itertools.combinations(range(v), order)), np.int32)
+    for subset in (hpgv.EPI_TESTING, hpgv.EPI_TRAINING):
+        acc, mask = eng.epi_eval_combs(combs, subset)
+        res = eng.epi_rank_order(order, subset, n)
+        best = _rank_from_dense(acc.T, combs, n)
+        for f in range(k):
+            assert res["n"][f] == len(best[f])
+            assert np.array_equal(res["combs"][f][: len(best[f])], combs[best[f]])
+            assert _same(res["accuracy"][f][: len(best[f])], acc[best[f], f])
+            assert np.array_equal(res["risky"][f][: len(best[f])], mask[best[f], f])
+        # the first SNPs dealt to three "devices": the shares' lists merge into the same ranking
+        parts = [eng.epi_rank_order(order, subset, n, rows=r) for r in ((0, 2), (2, 5), (5, v))]
+        for f in range(k):
+            cand = [(-p["accuracy"][f][e], tuple(p["combs"][f][e])) for p in parts for e in range(p["n"][f])]
+            cand.sort()
+            assert [c[1] for c in cand[:n]] == [tuple(c) for c in res["combs"][f][: res["n"][f]]]
+    if order == 2:                                                   # ... and the pair scan's own ranking
+        rp = eng.epi_rank_pairs(hpgv.EPI_TRAINING, n)
+        for f in range(k):
+            assert np.array_equal(rp["i"][f], res["combs"][f][:, 0]) and np.array_equal(rp["j"][f], res["combs"][f][:, 1])
+            assert _same(rp["accuracy"][f], res["accuracy"][f]) and np.array_equal(rp["risky"][f], res["risky"][f][:, 0])
+
+
+def test_any_order_error_paths(eng):
+    data = np.zeros((6, 10), np.uint8)
+    eng.epi_set_dataset(data, 5, 5)
+    with pytest.raises(hpgv.HpgvError):
+        eng.epi_eval_combs(np.zeros((1, 6), np.int32), hpgv.EPI_TESTING)          # order 6
+    with pytest.raises(hpgv.HpgvError):
+        eng.epi_eval_combs(np.array([[0, 1, 2, 9]], np.int32), hpgv.EPI_TESTING)   # SNP outside the dataset
+    with pytest.raises(hpgv.HpgvError):
+        eng.epi_rank_order(4, 7, 3)                                                # no such subset
+    res = eng.epi_rank_order(5, hpgv.EPI_TESTING, 4, rows=(3, 6))                  # no combination of 5 starts at SNP 3 of 6
+    assert res["n"].tolist() == [0]
+
+
+def test_run_epistasis_order_4_report(tmp_path):
+    import ctypes as C
+    import struct
+    from importlib import import_module
+    b = import_module("hpg-variant_amd._build")
+    L = C.CDLL(b.HOSTLIB)
+    L.hpgv_run_epistasis_order.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    L.hpgv_host_last_error.restype = C.c_char_p
+    rng = np.random.default_rng(44)
+    v, nA, nU = 12, 140, 150
+    data = epi_random_dataset(rng, v, nA, nU)
+    for s_ in (1, 4, 6, 10):
+        data[s_, :nA] = rng.choice([1, 2], size=nA)
+    path = tmp_path / "epi4.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<III", v, nA, nU)); f.write(data.tobytes())
+    prefix = str(tmp_path / "o4")
+    rc = L.hpgv_run_epistasis_order(str(path).encode(), 4, 4, 1, 5, hpgv.EPI_TRAINING, 1, prefix.encode())
+    assert rc == 0, L.hpgv_host_last_error()
+    lines = open(prefix + ".cv1.epi").read().splitlines()
+    assert lines[1] == "#COMBINATIONS OF: 4 SNPs"
+    first = lines[5].split("\t")
+    # epistasis_report.c:62-77 for order 4: "( i, j, k, l )" and cells "(a-b, c, d), "
+    assert first[0] == "1" and first[1] == "( 1, 4, 6, 10 )"
+    genos, count = first[2].rsplit("), ", 1)
+    assert count == "4" and "(1-1, 1, 1)" in first[2] and "(2-2, 2, 2)" in first[2] and "(0-" not in first[2]
+    assert all(len(c.strip("()").replace("-", ",").replace(" ", "").split(",")) == 4 for c in genos.split("), "))
