@@ -41,7 +41,7 @@ SYMBOLS = [
     "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_stats_groups",
     "hpgv_epi_dataset_text", "hpgv_set_text_filters", "hpgv_stats_text", "hpgv_stats_text_groups", "hpgv_epi_set_dataset", "hpgv_epi_set_folds", "hpgv_epi_set_fold_masks", "hpgv_epi_counts",
     "hpgv_epi_counts_all_folds", "hpgv_epi_scan_pairs", "hpgv_epi_rank_pairs", "hpgv_epi_rank_pairs_rows", "hpgv_epi_scan_triples", "hpgv_epi_rank_triples", "hpgv_epi_eval_combs", "hpgv_epi_rank_order", "hpgv_epi_rank_order_rows", "hpgv_read_probe",
-    "hpgv_group_comm_init", "hpgv_group_comm_ranks", "hpgv_group_rccl_probe", "hpgv_group_shard", "hpgv_group_assoc", "hpgv_group_tdt", "hpgv_group_stats", "hpgv_group_sync",
+    "hpgv_group_comm_init", "hpgv_group_comm_ranks", "hpgv_group_rccl_probe", "hpgv_group_shard", "hpgv_group_assoc", "hpgv_group_tdt", "hpgv_group_stats", "hpgv_group_sync", "hpgv_group_epi_share", "hpgv_group_epi_rank", "hpgv_epi_rank_triples_rows",
 ]
 
 
@@ -164,6 +164,9 @@ def load():
     L.hpgv_group_tdt.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
     L.hpgv_group_stats.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     L.hpgv_group_sync.argtypes = [vp]
+    L.hpgv_group_epi_share.argtypes = [vp, i32, i32, vp, vp]
+    L.hpgv_group_epi_rank.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, C.POINTER(C.c_float)]
+    L.hpgv_epi_rank_triples_rows.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
     _lib = L
     return L
 
@@ -653,6 +656,19 @@ class Engine:
 
     def group_stats(self, d_gt, n_variants, d_counts8, d_chi2, d_p, d_sample_missing=None):
         self._chk(self.L.hpgv_group_stats(self.h, self._ptr_array(d_gt), n_variants, d_counts8, d_chi2, d_p, d_sample_missing))
+
+    def group_epi_share(self, order, member):
+        lo, hi = C.c_int(), C.c_int()
+        self._chk(self.L.hpgv_group_epi_share(self.h, order, member, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def group_epi_rank(self, order, subset, max_ranking_size):
+        k, n = self._epi[3], max_ranking_size
+        combs = np.zeros((k, n, order), np.int32)
+        acc, mask, cnt = np.zeros((k, n), np.float64), np.zeros((k, n, 8), np.uint32), np.zeros(k, np.int32)
+        ms = C.c_float(0)
+        self._chk(self.L.hpgv_group_epi_rank(self.h, order, subset, n, _ptr(combs), _ptr(acc), _ptr(mask), _ptr(cnt), C.byref(ms)))
+        return dict(combs=combs, accuracy=acc, risky=mask, n=cnt, scan_ms=ms.value)
 
     def group_sync(self):
         self._chk(self.L.hpgv_group_sync(self.h))

@@ -194,6 +194,9 @@ unsigned long long epi_rank(unsigned long long V, unsigned long long i) { return
 void hpgv_epi_release(EpiState &E) { epi_free(E); }
 
 int hpgv_epi_set_dataset(hpgv_ctx *ctx, const uint8_t *genotypes, int n_variants, int n_affected, int n_unaffected) {
+    // a group context: the dataset and the folds go to EVERY member (hpgv_group_epi_rank deals the scan out to them); the
+    // scans and rankings of one context work on the first member
+    GROUP_ALL(ctx, hpgv_epi_set_dataset(m_, genotypes, n_variants, n_affected, n_unaffected))
     ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (n_variants < 0 || n_affected < 0 || n_unaffected < 0 || (n_variants > 0 && n_affected + n_unaffected > 0 && !genotypes))
@@ -213,6 +216,7 @@ int hpgv_epi_set_dataset(hpgv_ctx *ctx, const uint8_t *genotypes, int n_variants
 }
 
 int hpgv_epi_set_folds(hpgv_ctx *ctx, const int32_t *fold_of_sample, int num_folds) {
+    GROUP_ALL(ctx, hpgv_epi_set_folds(m_, fold_of_sample, num_folds))
     ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     if (!ctx->epi.have_data) return fail(ctx, HPGV_ERR_STATE, "hpgv_epi_set_dataset has not been called");
@@ -225,6 +229,7 @@ int hpgv_epi_set_folds(hpgv_ctx *ctx, const int32_t *fold_of_sample, int num_fol
 }
 
 int hpgv_epi_set_fold_masks(hpgv_ctx *ctx, const uint8_t *fold_masks, int num_folds) {
+    GROUP_ALL(ctx, hpgv_epi_set_fold_masks(m_, fold_masks, num_folds))
     HPGV_ABI_TRY
     ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
@@ -613,12 +618,19 @@ int hpgv_epi_scan_triples(hpgv_ctx *ctx, int subset, double *accuracy, uint32_t 
 
 int hpgv_epi_rank_triples(hpgv_ctx *ctx, int subset, int max_ranking_size, int32_t *comb_i, int32_t *comb_j, int32_t *comb_k,
                           double *accuracy, uint32_t *risky_mask, int32_t *n_ranked, float *scan_ms) {
+    const hpgv_ctx *c = first_member(ctx);
+    return hpgv_epi_rank_triples_rows(ctx, 0, c ? c->epi.V : 0, subset, max_ranking_size, comb_i, comb_j, comb_k, accuracy, risky_mask, n_ranked, scan_ms);
+}
+
+int hpgv_epi_rank_triples_rows(hpgv_ctx *ctx, int i_begin, int i_end, int subset, int max_ranking_size, int32_t *comb_i, int32_t *comb_j,
+                               int32_t *comb_k, double *accuracy, uint32_t *risky_mask, int32_t *n_ranked, float *scan_ms) {
     HPGV_ABI_TRY
     ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
     int rc = epi_triples_check(ctx, subset);
     if (rc) return rc;
     EpiState &E = ctx->epi;
+    if (i_begin < 0 || i_end < i_begin || i_end > E.V) return fail(ctx, HPGV_ERR_INVALID, "first SNPs [%d, %d) outside the dataset", i_begin, i_end);
     if (max_ranking_size < 1 || max_ranking_size > 65536 || !comb_i || !comb_j || !comb_k || !accuracy || !risky_mask || !n_ranked)
         return fail(ctx, HPGV_ERR_INVALID, "bad ranking arguments");
     DeviceGuard g(ctx->device);
@@ -651,9 +663,10 @@ int hpgv_epi_rank_triples(hpgv_ctx *ctx, int subset, int max_ranking_size, int32
     // a launch stays below 2^23 tiles: at most n_jb * n_kt tiles per first SNP
     const long long per_row_tiles = ((V + hpgv::EPI_TI - 1) / hpgv::EPI_TI) * ((V + hpgv::EPI_TJ - 1) / hpgv::EPI_TJ) + 1;
     const int max_rows = (int)std::max<long long>(1, (1ll << 23) / per_row_tiles);
-    int i = 0, step = 1;
-    while (i < V - 2 && !rc) {
-        const int n_i = (int)std::min<long long>(std::min<long long>(step, max_rows), V - 2 - i);
+    const long long i_last = std::min<long long>(V - 2, i_end);    // first SNPs V - 2 and V - 1 begin no triple
+    int i = i_begin, step = 1;
+    while (i < i_last && !rc) {
+        const int n_i = (int)std::min<long long>(std::min<long long>(step, max_rows), i_last - i);
         HIPCHK(ctx, hipMemsetAsync(E.d_cand_count, 0, hpgv::EPI_MAX_FOLDS * sizeof(unsigned), nullptr));
         HIPCHK(ctx, hipMemcpyAsync(E.d_thr, thr.data(), hpgv::EPI_MAX_FOLDS * sizeof(double), hipMemcpyHostToDevice, nullptr));
         if (scan_ms) HIPCHK(ctx, hipEventRecord(ev0, nullptr));

@@ -17,6 +17,7 @@
 #include "hpgv_internal.h"
 
 #include <dlfcn.h>
+#include <thread>
 // types and enums only: every function is reached through dlsym.  A build box without the RCCL headers still builds the
 // library: the few declarations the group scan uses are restated below (values as in rccl.h; RCCL keeps them ABI-stable).
 #if __has_include(<rccl/rccl.h>)
@@ -553,6 +554,172 @@ int hpgv_group_stats(hpgv_ctx *g, const uint8_t *const *d_gt, int64_t V, int32_t
     };
     rc = queued();
     return rc ? drain(P, rc) : HPGV_OK;
+    HPGV_ABI_CATCH(g)
+}
+
+}  // extern "C"
+
+// ---- the epistasis scan over the devices of a group (the reference deals block coordinates to its workers,
+//      singlenode/epistasis_runner.c:114-145).  Every combination of `order` SNPs belongs to its FIRST SNP; the first SNPs are
+//      cut into G runs of (nearly) equal numbers of combinations -- for pairs at multiples of 64 rows, the tile scan's unit --
+//      member g ranks its run on its own device (hpgv_epi_rank_{pairs,triples,order}_rows, one host thread per member), and the
+//      ONE exchange is the gather of the members' per-fold top lists (num_folds x max_ranking_size records of 64 bytes) onto
+//      member 0 over the group's communicator, where they merge into the whole ranking: a model is in the whole top N only if
+//      it is in the top N of its own share.
+
+namespace {
+
+struct EpiRec { double accuracy; int32_t c[5]; int32_t used; uint32_t risky[8]; };     // 64 bytes; used = 0: an empty slot
+static_assert(sizeof(EpiRec) == 64, "one record of the gathered top lists");
+
+// combinations of `order` SNPs out of V that begin with one of the first `rows` SNPs
+long double epi_combs_before(int V, int order, int rows) {
+    auto choose = [](int n, int k) -> long double { if (k < 0 || n < k) return 0.0L; long double r = 1.0L; for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i; return r; };
+    return choose(V, order) - choose(V - std::min(rows, V), order);
+}
+
+// first SNP where member k's share begins: the first boundary (a multiple of `unit`) with at least k / G of the work before it
+int epi_cut(int V, int order, int G, int k, int unit) {
+    if (k <= 0) return 0;
+    if (k >= G) return V;
+    const long double target = epi_combs_before(V, order, V) * k / G;
+    int lo = 0, hi = (V + unit - 1) / unit;
+    while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        if (epi_combs_before(V, order, std::min(mid * unit, V)) >= target) hi = mid; else lo = mid + 1;
+    }
+    return std::min(lo * unit, V);
+}
+
+}  // namespace
+
+extern "C" {
+
+int hpgv_group_epi_share(const hpgv_ctx *g, int order, int member, int *i_begin, int *i_end) {
+    if (!g || !i_begin || !i_end || order < 2 || order > 5) return HPGV_ERR_INVALID;
+    const int G = hpgv_group_size(g);
+    if (member < 0 || member >= G) return HPGV_ERR_INVALID;
+    const hpgv_ctx *m0 = first_member(g);
+    const int V = m0->epi.V, unit = order == 2 ? 64 : 1;
+    *i_begin = epi_cut(V, order, G, member, unit);
+    *i_end = epi_cut(V, order, G, member + 1, unit);
+    return HPGV_OK;
+}
+
+int hpgv_group_epi_rank(hpgv_ctx *g, int order, int subset, int max_ranking_size, int32_t *combs_out, double *accuracy,
+                        uint32_t *risky_mask, int32_t *n_ranked, float *scan_ms) {
+    HPGV_ABI_TRY
+    if (!is_group(g)) return fail(g, HPGV_ERR_INVALID, "hpgv_group_epi_rank needs a group context (hpgv_create_multi)");
+    if (order < 2 || order > 5) return fail(g, HPGV_ERR_UNSUPPORTED, "combinations of %d SNPs are not supported (2 to 5)", order);
+    if (max_ranking_size < 1 || max_ranking_size > 65536 || !combs_out || !accuracy || !risky_mask || !n_ranked)
+        return fail(g, HPGV_ERR_INVALID, "bad ranking arguments");
+    int rc = hpgv_group_comm_init(g);
+    if (rc) return rc;
+    GroupState *S = g->grp;
+    std::lock_guard<std::mutex> lk(S->mu);
+    const int G = (int)g->members.size(), N = max_ranking_size;
+    const int nf = g->members[0]->epi.num_folds;
+    if (!g->members[0]->epi.have_folds) return fail(g, HPGV_ERR_STATE, "hpgv_epi_set_dataset has not been called");
+    for (int k = 1; k < G; ++k)
+        if (!g->members[(size_t)k]->epi.have_folds || g->members[(size_t)k]->epi.V != g->members[0]->epi.V || g->members[(size_t)k]->epi.num_folds != nf)
+            return fail(g, HPGV_ERR_STATE, "member %d does not hold the dataset and folds of member 0: set them through the group context", k);
+    const size_t n_rec = (size_t)nf * (size_t)N, bytes = n_rec * sizeof(EpiRec);
+    // ---- every member ranks its share on a host thread of its own ----
+    std::vector<std::vector<EpiRec>> lists((size_t)G, std::vector<EpiRec>(n_rec));
+    std::vector<int> rcs((size_t)G, HPGV_OK);
+    std::vector<float> ms((size_t)G, 0.f);
+    {
+        std::vector<std::thread> th;
+        for (int k = 0; k < G; ++k)
+            th.emplace_back([&, k]() {
+                try {
+                    hpgv_ctx *mc = g->members[(size_t)k];
+                    int lo = 0, hi = 0;
+                    (void)hpgv_group_epi_share(g, order, k, &lo, &hi);
+                    std::vector<int32_t> ci(n_rec), cj(n_rec), ck(n_rec), cn(n_rec * (size_t)order), cnt((size_t)hpgv::EPI_MAX_FOLDS, 0);
+                    std::vector<uint32_t> rk(n_rec * 8, 0u);
+                    std::vector<double> acc(n_rec, 0.0);
+                    int r = HPGV_OK;
+                    if (order == 2) r = hpgv_epi_rank_pairs_rows(mc, lo, hi, subset, N, ci.data(), cj.data(), acc.data(), rk.data(), cnt.data(), scan_ms ? &ms[(size_t)k] : nullptr);
+                    else if (order == 3) r = hpgv_epi_rank_triples_rows(mc, lo, hi, subset, N, ci.data(), cj.data(), ck.data(), acc.data(), rk.data(), cnt.data(), scan_ms ? &ms[(size_t)k] : nullptr);
+                    else r = hpgv_epi_rank_order_rows(mc, order, lo, hi, subset, N, cn.data(), acc.data(), rk.data(), cnt.data(), scan_ms ? &ms[(size_t)k] : nullptr);
+                    rcs[(size_t)k] = r;
+                    if (r) return;
+                    auto &L = lists[(size_t)k];
+                    std::memset(L.data(), 0, bytes);
+                    for (int f = 0; f < nf; ++f)
+                        for (int e = 0; e < cnt[(size_t)f]; ++e) {
+                            const size_t o = (size_t)f * (size_t)N + (size_t)e;
+                            EpiRec &R = L[o];
+                            R.accuracy = acc[o]; R.used = 1;
+                            for (int s2 = 0; s2 < 5; ++s2) R.c[s2] = -1;
+                            if (order <= 3) { R.c[0] = ci[o]; R.c[1] = cj[o]; if (order == 3) R.c[2] = ck[o]; R.risky[0] = rk[o]; }      // one mask word per model
+                            else { for (int s2 = 0; s2 < order; ++s2) R.c[s2] = cn[o * (size_t)order + (size_t)s2]; for (int w = 0; w < 8; ++w) R.risky[w] = rk[o * 8 + (size_t)w]; }
+                        }
+                } catch (...) { rcs[(size_t)k] = HPGV_ERR_NOMEM; }
+            });
+        for (auto &t : th) t.join();
+    }
+    for (int k = 0; k < G; ++k)
+        if (rcs[(size_t)k]) return fail(g, rcs[(size_t)k], "member %d: %s", k, hpgv_last_error(g->members[(size_t)k]));
+    // ---- the exchange: every member's lists onto member 0 (through the communicator from another device -- and from member 0
+    //      itself with the test switch group_self_exchange --, a device-local copy from a context on member 0's device) ----
+    struct Bufs { std::vector<void *> p; std::vector<int> dev; ~Bufs() { for (size_t i = 0; i < p.size(); ++i) if (p[i]) { DeviceGuard dg(dev[i]); (void)hipFree(p[i]); } } } bufs;
+    auto dev_alloc = [&](int dev, size_t n, void **out) -> hipError_t { DeviceGuard dg(dev); hipError_t e = hipMalloc(out, n); if (e == hipSuccess) { bufs.p.push_back(*out); bufs.dev.push_back(dev); } return e; };
+    const int dev0 = g->members[0]->device;
+    void *d_all = nullptr;                                            // member 0's device: G lists in member order
+    HIPCHK(g, dev_alloc(dev0, bytes * (size_t)G, &d_all));
+    std::vector<void *> d_send((size_t)G, nullptr);
+    auto by_rccl = [&](int k) { return (k > 0 || g->group_self_exchange) && (!S->m[(size_t)k].local || k == 0); };
+    for (int k = 0; k < G; ++k) {
+        hpgv_ctx *mc = g->members[(size_t)k];
+        GroupMember &M = S->m[(size_t)k];
+        DeviceGuard dg(mc->device);
+        if (k == 0 && !g->group_self_exchange) { HIPCHK(g, hipMemcpyAsync(d_all, lists[0].data(), bytes, hipMemcpyHostToDevice, M.xfer)); continue; }
+        HIPCHK(g, dev_alloc(mc->device, bytes, &d_send[(size_t)k]));
+        HIPCHK(g, hipMemcpyAsync(d_send[(size_t)k], lists[(size_t)k].data(), bytes, hipMemcpyHostToDevice, M.xfer));
+        if (!by_rccl(k)) HIPCHK(g, hipMemcpyAsync((char *)d_all + bytes * (size_t)k, d_send[(size_t)k], bytes, hipMemcpyDeviceToDevice, M.xfer));
+    }
+    bool any = false;
+    for (int k = 0; k < G; ++k) any = any || by_rccl(k);
+    if (any) {
+        GroupMember &M0 = S->m[0];
+        NCCLCHK(g, S, S->GroupStart());
+        for (int k = 0; k < G; ++k) {
+            if (!by_rccl(k)) continue;
+            GroupMember &M = S->m[(size_t)k];
+            NCCLCHK(g, S, S->Send(d_send[(size_t)k], bytes, ncclInt8, 0, S->comms[(size_t)M.rank], M.xfer));
+            NCCLCHK(g, S, S->Recv((char *)d_all + bytes * (size_t)k, bytes, ncclInt8, M.rank, S->comms[0], M0.xfer));
+        }
+        NCCLCHK(g, S, S->GroupEnd());
+    }
+    for (int k = 0; k < G; ++k) { DeviceGuard dg(g->members[(size_t)k]->device); HIPCHK(g, hipStreamSynchronize(S->m[(size_t)k].xfer)); }
+    std::vector<EpiRec> all(n_rec * (size_t)G);
+    { DeviceGuard dg(dev0); HIPCHK(g, hipMemcpy(all.data(), d_all, bytes * (size_t)G, hipMemcpyDeviceToHost)); }
+    // ---- merge: per fold the best N of the members' lists (add_to_model_ranking, model.c:478-517: higher accuracy, then the
+    //      smaller combination) ----
+    auto better = [](const EpiRec &a, const EpiRec &b) {
+        if (a.accuracy != b.accuracy) return a.accuracy > b.accuracy;
+        for (int s2 = 0; s2 < 5; ++s2) if (a.c[s2] != b.c[s2]) return a.c[s2] < b.c[s2];
+        return false;
+    };
+    std::vector<EpiRec> t;
+    for (int f = 0; f < nf; ++f) {
+        t.clear();
+        for (int k = 0; k < G; ++k)
+            for (int e = 0; e < N; ++e) { const EpiRec &R = all[(size_t)k * n_rec + (size_t)f * (size_t)N + (size_t)e]; if (R.used) t.push_back(R); }
+        std::sort(t.begin(), t.end(), better);
+        if ((int)t.size() > N) t.resize((size_t)N);
+        n_ranked[f] = (int32_t)t.size();
+        for (size_t e = 0; e < t.size(); ++e) {
+            const size_t o = (size_t)f * (size_t)N + e;
+            for (int s2 = 0; s2 < order; ++s2) combs_out[o * (size_t)order + (size_t)s2] = t[e].c[s2];
+            accuracy[o] = t[e].accuracy;
+            for (int w = 0; w < 8; ++w) risky_mask[o * 8 + (size_t)w] = t[e].risky[w];
+        }
+    }
+    if (scan_ms) { float m = 0.f; for (float x : ms) m = std::max(m, x); *scan_ms = m; }       // the members scan side by side: the slowest one
+    return HPGV_OK;
     HPGV_ABI_CATCH(g)
 }
 

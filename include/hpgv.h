@@ -262,6 +262,17 @@ int  hpgv_group_tdt(hpgv_ctx *group, const uint8_t *const *d_gt, const uint8_t *
 int  hpgv_group_stats(hpgv_ctx *group, const uint8_t *const *d_gt, int64_t n_variants, int32_t *d_counts8 /* V x 8 */,
                       double *d_hwe_chi2, double *d_hwe_p, int32_t *d_sample_missing);
 int  hpgv_group_sync(hpgv_ctx *group);
+/* The epistasis scan over the group's devices (the reference deals block coordinates to its workers,
+ * singlenode/epistasis_runner.c:114-145).  hpgv_epi_set_dataset / hpgv_epi_set_folds / hpgv_epi_set_fold_masks on a GROUP
+ * context give every member the dataset and the folds.  A combination belongs to its first SNP; hpgv_group_epi_share tells
+ * which first SNPs [i_begin, i_end) member `member` takes -- runs with (nearly) equal numbers of combinations, for pairs cut
+ * at multiples of 64.  hpgv_group_epi_rank: every member ranks its share on its own device (order 2 and 3: the tile scans;
+ * 4 and 5: the listed-combination kernel), the members' per-fold top lists are gathered onto member 0 over the group's
+ * communicator and merged: outputs as hpgv_epi_rank_order (8 mask words per model; orders 2 and 3 use the first),
+ * identical to the one-device ranking.  Synchronous.  *scan_ms (may be NULL): the slowest member's scan time. */
+int  hpgv_group_epi_share(const hpgv_ctx *group, int order, int member, int *i_begin, int *i_end);
+int  hpgv_group_epi_rank(hpgv_ctx *group, int order, int subset, int max_ranking_size, int32_t *combs_out,
+                         double *accuracy, uint32_t *risky_mask, int32_t *n_ranked, float *scan_ms);
 
 /* duration (ms) of the last scan / statistics kernel launched through this ctx
  * when option "profile" = 1 (HIP events on the launch stream; synchronises) */
@@ -384,6 +395,10 @@ int  hpgv_epi_rank_pairs_rows(hpgv_ctx *ctx, int i_begin, int i_end, int subset,
 int  hpgv_epi_scan_triples(hpgv_ctx *ctx, int subset, double *accuracy, uint32_t *risky_mask);
 int  hpgv_epi_rank_triples(hpgv_ctx *ctx, int subset, int max_ranking_size, int32_t *comb_i, int32_t *comb_j,
                            int32_t *comb_k, double *accuracy, uint32_t *risky_mask, int32_t *n_ranked, float *scan_ms);
+/* ... over the triples whose FIRST SNP lies in [i_begin, i_end) only (one device's share, as hpgv_epi_rank_pairs_rows) */
+int  hpgv_epi_rank_triples_rows(hpgv_ctx *ctx, int i_begin, int i_end, int subset, int max_ranking_size, int32_t *comb_i,
+                                int32_t *comb_j, int32_t *comb_k, double *accuracy, uint32_t *risky_mask, int32_t *n_ranked,
+                                float *scan_ms);
 
 /* ANY order the reference's --order takes (main_epistasis.c:128,142), here 2 <= order <= 5 (3^order cells, cell = the
  * genotypes of the SNPs as base-3 digits, the last SNP the lowest: get_genotype_combinations, dataset.c:170-200; at most

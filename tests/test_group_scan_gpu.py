@@ -28,6 +28,61 @@ def driver(tmp_path_factory):
     return exe
 
 
+@pytest.fixture(scope="module")
+def epi_driver(tmp_path_factory):
+    hpgv.build()
+    exe = str(tmp_path_factory.mktemp("grp") / "group_epi")
+    lib = os.path.join(ROOT, "hpg-variant_amd", "lib")
+    subprocess.check_call(["gcc", "-O1", "-g", "-std=gnu99", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "group_epi.c"), "-o", exe, "-L", lib, "-lhpgv",
+                           "-Wl,-rpath," + lib, "-lm"])
+    return exe
+
+
+@pytest.mark.parametrize("members,v,nA,nU,k,order,extra", [
+    (1, 300, 400, 380, 5, 2, []),          # one member: the whole triangle, its list copied into place
+    (1, 300, 400, 380, 5, 2, ["self"]),    # ... through ncclSend / ncclRecv to itself
+    (2, 300, 400, 380, 5, 2, []),          # [0, 0]: two row bands, merged
+    (3, 700, 150, 170, 10, 2, []),         # [0, 0, 0]
+    (3, 100, 150, 170, 4, 2, []),          # fewer 64-row blocks than members want: an empty share
+    (3, 60, 120, 140, 4, 3, []),           # triples dealt by first SNP
+    (2, 60, 120, 140, 4, 3, ["self"]),
+    (3, 16, 90, 110, 3, 4, []),            # order 4: the listed-combination kernel per member
+    (2, 12, 90, 110, 3, 5, ["self"]),
+])
+def test_c_host_deals_the_epistasis_scan_to_a_group(epi_driver, members, v, nA, nU, k, order, extra):
+    r = subprocess.run([epi_driver, str(members), str(v), str(nA), str(nU), str(k), str(order)] + extra, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "rccl_ranks=1" in r.stdout and "group epistasis ok" in r.stdout and r.stdout.count("bit-identical") == 2
+
+
+def test_group_epistasis_against_the_dense_evaluation():
+    """The group's ranking of a [0, 0, 0] group from Python, against the dense evaluation of every pair on one context."""
+    from helpers import epi_random_dataset, epi_random_folds
+    rng = np.random.default_rng(8)
+    v, nA, nU, k, n = 200, 300, 260, 6, 15
+    data = epi_random_dataset(rng, v, nA, nU)
+    fold = epi_random_folds(rng, nA, nU, k)
+    g = hpgv.Engine([0, 0, 0])
+    g.epi_set_dataset(data, nA, nU)
+    g.epi_set_folds(fold, k)
+    shares = [g.group_epi_share(2, m) for m in range(3)]
+    assert shares[0][0] == 0 and shares[-1][1] == v and all(a[1] == b[0] for a, b in zip(shares, shares[1:]))
+    res = g.group_epi_rank(2, hpgv.EPI_TESTING, n)
+    one = hpgv.Engine(0)
+    one.epi_set_dataset(data, nA, nU)
+    one.epi_set_folds(fold, k)
+    acc, rm = one.epi_scan_pairs(hpgv.EPI_TESTING)
+    pairs = [(i, j) for i in range(v) for j in range(i + 1, v)]
+    for f in range(k):
+        a = np.where(np.isnan(acc[f]), -np.inf, acc[f])
+        order = sorted(range(len(pairs)), key=lambda p: (-a[p], pairs[p]))[:n]
+        assert [tuple(c) for c in res["combs"][f].tolist()] == [pairs[p] for p in order]
+        assert np.array_equal(res["accuracy"][f], acc[f][order]) and np.array_equal(res["risky"][f][:, 0], rm[f][order].astype(np.uint32))
+    one.close()
+    g.close()
+
+
 @pytest.mark.parametrize("members,variants,samples,extra", [
     (1, 20011, 3001, []),            # one member, communicator created (ncclCommInitAll, n = 1), member 0 scans in place
     (1, 20011, 3001, ["self"]),      # the same through ncclSend / ncclRecv to itself: RCCL moves every result byte
