@@ -21,8 +21,8 @@ $(LIBDIR)/obj/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/hpgv.h
 $(LIBDIR)/libhpgv.so: $(OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS)
 
-$(LIBDIR)/libhpgv_host.so: $(HOST)/hpgv_host.c include/hpgv_host.h include/hpgv.h $(LIBDIR)/libhpgv.so
-	$(CC) -O2 -g -std=gnu99 -fPIC -shared -fopenmp -Wall -Wextra -Iinclude -o $@ $(HOST)/hpgv_host.c \
+$(LIBDIR)/libhpgv_host.so: $(wildcard $(HOST)/*.c) $(HOST)/hpgv_host_internal.h include/hpgv_host.h include/hpgv.h $(LIBDIR)/libhpgv.so
+	$(CC) -O2 -g -std=gnu99 -fPIC -shared -fopenmp -Wall -Wextra -Iinclude -I$(HOST) -o $@ $(wildcard $(HOST)/*.c) \
 	    -L$(LIBDIR) -lhpgv -Wl,-rpath,'$$ORIGIN' -lm -lz
 
 oracle:

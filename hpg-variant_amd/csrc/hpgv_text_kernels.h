@@ -120,7 +120,7 @@ __device__ __forceinline__ int tok_atoi(const char *__restrict__ t, size_t p, si
 }
 
 // one sample field starting at p (line ends at e, exclusive): the product's statement of
-// get_alleles + the HPGV8 encoding (host twin: hpgv_host.c encode_gt)
+// get_alleles + the HPGV8 encoding (host twin: host/host_stage.c encode_gt_general)
 __device__ __forceinline__ uint32_t tok_encode(const char *__restrict__ t, size_t p, size_t e, int gt_position, int strict) {
     size_t fe = p;                                      // end of this sample field: the next TAB -- or a NUL byte before it: the
     while (fe < e && t[fe] != '\t' && t[fe] != 0) fe++;  // reference's sample fields are C strings (vcf_record_t.samples), get_alleles stops there
