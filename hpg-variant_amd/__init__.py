@@ -57,7 +57,8 @@ def build(force=False, verbose=False):
 
 
 def lib_path():
-    return _build.LIB
+    """libhpgv.so of this tree; HPGV_LIB names another build of it (tools/build_ablation.py: the forms that lost their A/B)."""
+    return os.environ.get("HPGV_LIB") or _build.LIB
 
 
 def load():
@@ -65,10 +66,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_build.LIB):
+    path = lib_path()
+    if not os.path.exists(path):
         raise HpgvError("%s is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
-                        "there is no CPU fallback" % _build.LIB)
-    L = C.CDLL(_build.LIB)
+                        "there is no CPU fallback" % path)
+    L = C.CDLL(path)
     vp, sz, i32, u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
     L.hpgv_version.restype = C.c_char_p
     L.hpgv_last_error.restype = C.c_char_p

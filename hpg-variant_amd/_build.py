@@ -32,15 +32,21 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-def build_device_lib(force=False, verbose=False):
+ABLATION_LIB = os.path.join(LIBDIR, "ablation", "libhpgv.so")
+
+
+def build_device_lib(force=False, verbose=False, ablation=False):
     """libhpgv.so from its translation units (csrc/*.hip), compiled side by side: the epistasis unit instantiates its
-    scans per fold count and takes minutes, the rest seconds."""
+    scans per fold count and takes minutes, the rest seconds.  ablation=True: the same sources with -DHPGV_ABLATION -- every
+    kernel form that lost an A/B comparison compiled in and selectable (hpgv.h "Options") -- into lib/ablation/libhpgv.so,
+    for tools/ and for running the GPU suite over those forms (HPGV_LIB=<that file>)."""
     hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(ROOT, "include", "hpgv.h"))
     units = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, "ablation", "obj") if ablation else os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + (["-DHPGV_ABLATION"] if ablation else [])
+    LIB = ABLATION_LIB if ablation else globals()["LIB"]
     jobs = []
     objs = []
     for u in units:

@@ -120,13 +120,14 @@ static int stats_all_call(hpgv_ctx *ctx, Slot *s, const uint8_t *d_src, size_t s
     // costs as much as several rows, and fewer workgroups than slots leave units idle: 16 000 rows, 8 / 21 / 42 per band:
     // 105 / 65 / 84 us)
     int rows = (n_variants + 3 * ctx->n_cus - 1) / (3 * ctx->n_cus);
-    if (const char *rb = getenv("HPGV_STATS_ROWS")) rows = atoi(rb);        // tuning: the band length
+#ifdef HPGV_ABLATION
+    if (ctx->stats_rows) rows = (int)ctx->stats_rows;               // tuning: the band length
+#endif
     rows = rows < 1 ? 1 : (rows > 255 ? 255 : rows);
     A.rows_per_block = rows; A.lds_row = (int)(((size_t)ns + 32 + 15) / 16 * 16);
     // columns owned by threads across the band (hpgv_statsall_kernels.h); what that kernel does not take -- unaligned rows,
     // very wide cohorts, many groups -- goes to the row-staging kernel
-    const char *a2 = getenv("HPGV_STATS_ALL2");                     // diagnosis: 0 = the row-staging kernel for every batch
-    if ((a2 && atoi(a2) == 0) || hpgv_launch_stats_all2(ctx, A, &s->cnt_buf, &s->cnt_cap, s->stream) != 0) {
+    if (!ctx->stats_all2 || hpgv_launch_stats_all2(ctx, A, &s->cnt_buf, &s->cnt_cap, s->stream) != 0) {
         const size_t lds = stats_all_lds(ctx, want_mendel);
         hipLaunchKernelGGL(hpgv::k_stats_all, dim3((unsigned)((n_variants + rows - 1) / rows)), dim3(256), lds, s->stream, A);
     }
@@ -177,6 +178,28 @@ int hpgv_device_count(void) {
 
 const char *hpgv_last_error(const hpgv_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+// The environment is read HERE, once per context, and nowhere else in the library (include/hpgv.h "Environment").
+static void read_environment(hpgv_ctx *ctx) {
+    auto num = [](const char *name, long lo, long hi, long *out) { const char *e = getenv(name); if (e && *e) { long v = atol(e); *out = v < lo ? lo : v > hi ? hi : v; } };
+    num("HPGV_BATCH_COPY", 0, 1, &ctx->batch_copy);
+    num("HPGV_BATCH_FUSED", 0, 1, &ctx->batch_fused);
+    num("HPGV_STATS_ALL2", 0, 1, &ctx->stats_all2);
+    num("HPGV_ASSOC_ROWS", 0, 1, &ctx->assoc_rows);
+    num("HPGV_PINNED_NONCOHERENT", 0, 1, &ctx->pinned_noncoherent);
+    num("HPGV_VMM_TRACE", 0, 1, &ctx->vmm_trace);
+#ifdef HPGV_ABLATION
+    num("HPGV_INFLATE_WAVE", 0, 4, &ctx->inflate_wave);
+    num("HPGV_TOKENIZER_TILES", 0, 2, &ctx->tokenizer_tiles);
+    num("HPGV_STATS_ROWS", 1, 255, &ctx->stats_rows);
+    num("HPGV_STATS_BS", 64, 1024, &ctx->stats_bs);
+    num("HPGV_STATS_DEBUG", 0, 1, &ctx->stats_debug);
+    num("HPGV_FISHER_LDS", 0, 160 * 1024, &ctx->fisher_lds);
+    num("HPGV_INFLATE_LDS_PAD", 0, 160 * 1024, &ctx->inflate_lds_pad);
+    num("HPGV_INFLATE_WAVE_WGS", 0, 64, &ctx->inflate_wave_wgs);
+    num("HPGV_INFLATE_LANE_WGS", 0, 64, &ctx->inflate_lane_wgs);
+#endif
+}
+
 int hpgv_create(int device_id, hpgv_ctx **out) {
     if (!out) return fail(nullptr, HPGV_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -216,10 +239,7 @@ int hpgv_create(int device_id, hpgv_ctx **out) {
         else if (ok && prop.maxSharedMemoryPerMultiProcessor >= (size_t)want) ctx->batch_lds_max = want;
         (void)hipGetLastError();
     }
-    if (const char *bc = getenv("HPGV_BATCH_COPY")) ctx->batch_copy = atoi(bc) ? 1 : 0;
-    if (const char *bf = getenv("HPGV_BATCH_FUSED")) ctx->batch_fused = atoi(bf) ? 1 : 0;      // diagnosis: 0 = the kernel chains
-    if (const char *iw = getenv("HPGV_INFLATE_WAVE")) ctx->inflate_wave = atoi(iw) < 0 ? 0 : atoi(iw) > 4 ? 4 : atoi(iw);   // diagnosis: 0 = lane per block, 2 = wave per block, 1 = by size
-    if (const char *tt = getenv("HPGV_TOKENIZER_TILES")) ctx->tokenizer_tiles = atoi(tt) < 0 ? 0 : atoi(tt) > 2 ? 2 : atoi(tt);   // diagnosis: 0 = the three-sweep tokenizer
+    read_environment(ctx);
     e = hipMalloc(&ctx->d_sink, 256);
     if (e != hipSuccess) {
         int rc = fail(nullptr, HPGV_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
@@ -321,6 +341,14 @@ void hpgv_destroy(hpgv_ctx *ctx) {
     delete ctx;
 }
 
+// the forms that lost their A/B (profiles/experiments_that_did_not_pay.md) are compiled only with -DHPGV_ABLATION (tools/): the
+// shipped library holds one form of each kernel and refuses an option value that names another
+#ifdef HPGV_ABLATION
+#define HPGV_SHIPPED_ONLY(ok, what)
+#else
+#define HPGV_SHIPPED_ONLY(ok, what) if (!(ok)) return fail(ctx, HPGV_ERR_UNSUPPORTED, what ": that form is an ablation build's (-DHPGV_ABLATION, tools/build_ablation.py)");
+#endif
+
 int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
     if (is_group(ctx) && key && !strcmp(key, "group_self_exchange")) { ctx->group_self_exchange = value ? 1 : 0; return HPGV_OK; }
     GROUP_ALL(ctx, hpgv_set_option(m_, key, value))
@@ -339,14 +367,17 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
         if (value < 1 || value > 1024) return fail(ctx, HPGV_ERR_INVALID, "variants_per_wave out of range");
         ctx->vpw = value;
     } else if (!strcmp(key, "nontemporal")) {
+        HPGV_SHIPPED_ONLY(value != 0, "nontemporal = 0")
         ctx->nontemporal = value ? 1 : 0;
     } else if (!strcmp(key, "profile")) {
         ctx->profile = value ? 1 : 0;
     } else if (!strcmp(key, "scan_unroll")) {
         if (value != 4 && value != 8 && value != 10 && value != 12 && value != 16)
             return fail(ctx, HPGV_ERR_INVALID, "scan_unroll must be one of 4, 8, 10, 12, 16");
+        HPGV_SHIPPED_ONLY(value == 4, "scan_unroll other than 4")
         ctx->scan_unroll = value;
     } else if (!strcmp(key, "pipeline")) {
+        HPGV_SHIPPED_ONLY(value != 0, "pipeline = 0")
         ctx->pipeline = value ? 1 : 0;
     } else if (!strcmp(key, "fisher_cut_exp")) {
         if (value < 12 || value > 300) return fail(ctx, HPGV_ERR_INVALID, "fisher_cut_exp must be in [12, 300]");
@@ -362,19 +393,24 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
         ctx->batch_copy = value ? 1 : 0;
     } else if (!strcmp(key, "inflate_wave")) {
         if (value < 0 || value > 4) return fail(ctx, HPGV_ERR_INVALID, "inflate_wave must be 0 (lane per block), 1 (by the number of blocks), 2 (wave per block), 4 (wave per block, several symbols per round) or 3 (lane per block, symbol tables in LDS)");
+        HPGV_SHIPPED_ONLY(value == 1 || value == 4, "inflate_wave other than 1 / 4 (a wave per block, several symbols per round)")
         ctx->inflate_wave = value;
     } else if (!strcmp(key, "tokenizer_tiles")) {
         if (value < 0 || value > 2) return fail(ctx, HPGV_ERR_INVALID, "tokenizer_tiles must be 2 (one sweep), 1 (two sweeps) or 0 (line by line)");
+        HPGV_SHIPPED_ONLY(value == 1, "tokenizer_tiles other than 1 (two sweeps)")
         ctx->tokenizer_tiles = value;
     } else if (!strcmp(key, "fisher_width")) {
         if (value != 64 && value != 32 && value != 16 && value != 8) return fail(ctx, HPGV_ERR_INVALID, "fisher_width must be 64, 32, 16 or 8");
+        HPGV_SHIPPED_ONLY(value == 16, "fisher_width other than 16")
         ctx->fisher_width = value;
     } else if (!strcmp(key, "batch_fused")) {
         ctx->batch_fused = value ? 1 : 0;
     } else if (!strcmp(key, "pipe_waves")) {
         if (value != 4 && value != 6 && value != 8) return fail(ctx, HPGV_ERR_INVALID, "pipe_waves must be 4, 6 or 8");
+        HPGV_SHIPPED_ONLY(value == 4, "pipe_waves other than 4")
         ctx->pipe_waves = value;
     } else if (!strcmp(key, "persistent")) {
+        HPGV_SHIPPED_ONLY(value == 0, "persistent = 1")
         ctx->persistent = value ? 1 : 0;
     } else if (!strcmp(key, "blocks_per_cu")) {
         if (value < 1 || value > 8) return fail(ctx, HPGV_ERR_INVALID, "blocks_per_cu must be in 1..8");
@@ -696,7 +732,7 @@ int hpgv_dev_commit(hpgv_ctx *ctx, void *dptr, size_t bytes) {
             while (add > 0) {
                 const size_t n = piece < add ? piece : add;
                 hipMemGenericAllocationHandle_t h;
-                const bool trace = getenv("HPGV_VMM_TRACE") != nullptr;
+                const bool trace = ctx->vmm_trace != 0;
                 last = hipMemCreate(&h, n, &prop, 0);
                 if (trace) fprintf(stderr, "vmm: create %zu MB: %s\n", n >> 20, hipGetErrorString(last));
                 if (last != hipSuccess) break;
@@ -815,7 +851,7 @@ int hpgv_host_alloc(hpgv_ctx *ctx, size_t bytes, void **hptr) {
     if (!ctx || !hptr) return HPGV_ERR_INVALID;
     DeviceGuard g(ctx->device);
     // visible to every device of a group.  (experiment: HPGV_PINNED_NONCOHERENT=1 -- no difference measured, profiles/experiments_that_did_not_pay.md)
-    const unsigned flags = hipHostMallocPortable | (getenv("HPGV_PINNED_NONCOHERENT") ? hipHostMallocNonCoherent : 0u);
+    const unsigned flags = hipHostMallocPortable | (ctx->pinned_noncoherent ? hipHostMallocNonCoherent : 0u);
     HIPCHK(ctx, hipHostMalloc(hptr, bytes ? bytes : 16, flags));
     return HPGV_OK;
 }
@@ -1004,6 +1040,13 @@ int hpgv_assoc_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, cons
     int4 *out = (int4 *)d_counts;
     const int cA = ctx->chunksA, ch = L.chunks;
     const size_t pitch = L.pitch;
+#define HPGV_LAUNCH_PIPE(NT, U, W)                                                                \
+    hipLaunchKernelGGL((hpgv::k_assoc_scan_pipe<NT, U, W>), dim3(blocks), dim3(256), 0, st, gt, pitch, \
+                       n_variants, cA, ch, d_is_x, out, vpw)
+#ifndef HPGV_ABLATION
+    // the shipped form: software-pipelined, non-temporal loads, four tiles in flight, four waves per SIMD
+    return launch_profiled(ctx, st, 0, [&] { HPGV_LAUNCH_PIPE(true, 4, 4); });
+#else
 #define HPGV_LAUNCH_ASSOC(NT, U, S)                                                              \
     hipLaunchKernelGGL((hpgv::k_assoc_scan<NT, U, S>), dim3(blocks), dim3(256), 0, st, gt, pitch, \
                        n_variants, cA, ch, d_is_x, out, vpw)
@@ -1015,9 +1058,6 @@ int hpgv_assoc_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, cons
         case 16: HPGV_LAUNCH_ASSOC(NT, 16, S); break;                                            \
         default: HPGV_LAUNCH_ASSOC(NT, 8, S); break;                                             \
     }
-#define HPGV_LAUNCH_PIPE(NT, U, W)                                                                \
-    hipLaunchKernelGGL((hpgv::k_assoc_scan_pipe<NT, U, W>), dim3(blocks), dim3(256), 0, st, gt, pitch, \
-                       n_variants, cA, ch, d_is_x, out, vpw)
 #define HPGV_PIPE_W(NT, U)                                                                       \
     do {                                                                                         \
         if (ctx->pipe_waves == 8) { HPGV_LAUNCH_PIPE(NT, U, 8); }                                \
@@ -1040,9 +1080,10 @@ int hpgv_assoc_scan_dev(hpgv_ctx *ctx, const uint8_t *d_gt, int n_variants, cons
         }
     });
 #undef HPGV_DISPATCH_U
-#undef HPGV_LAUNCH_PIPE
 #undef HPGV_PIPE_W
 #undef HPGV_LAUNCH_ASSOC
+#endif
+#undef HPGV_LAUNCH_PIPE
 }
 
 int hpgv_assoc_chisq_dev(hpgv_ctx *ctx, const int32_t *d_counts, int n_variants, double *d_odds,
@@ -1077,16 +1118,19 @@ int hpgv_assoc_fisher_dev(hpgv_ctx *ctx, const int32_t *d_counts, int n_variants
         // fisher_width lanes per variant: 64 / width variants per wave, 4 waves per workgroup
         const long per_block = 4 * (64 / ctx->fisher_width);
         const unsigned blocks = (unsigned)(((long)n_variants + per_block - 1) / per_block);
-        const char *fl = getenv("HPGV_FISHER_LDS");                 // experiment: unused LDS per workgroup caps the pass's waves per unit (room for a scan beside it)
-        const unsigned pad = fl ? (unsigned)atoi(fl) : 0u;
+#ifdef HPGV_ABLATION
+        const unsigned pad = (unsigned)ctx->fisher_lds;             // experiment: unused LDS per workgroup caps the pass's waves per unit (room for a scan beside it)
         if (ctx->fisher_width == 64)
             hipLaunchKernelGGL(hpgv::k_assoc_fisher<64>, dim3(blocks), dim3(256), pad, st, (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, cut);
         else if (ctx->fisher_width == 8)
             hipLaunchKernelGGL(hpgv::k_assoc_fisher<8>, dim3(blocks), dim3(256), pad, st, (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, cut);
-        else if (ctx->fisher_width == 16)
-            hipLaunchKernelGGL(hpgv::k_assoc_fisher<16>, dim3(blocks), dim3(256), pad, st, (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, cut);
-        else
+        else if (ctx->fisher_width == 32)
             hipLaunchKernelGGL(hpgv::k_assoc_fisher<32>, dim3(blocks), dim3(256), pad, st, (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, cut);
+        else
+#else
+        const unsigned pad = 0u;
+#endif
+            hipLaunchKernelGGL(hpgv::k_assoc_fisher<16>, dim3(blocks), dim3(256), pad, st, (const int4 *)d_counts, n_variants, ctx->d_lf, d_odds, d_p, cut);
     });
 }
 
@@ -1759,6 +1803,7 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
         hpgv::TokState *gtot = (hpgv::TokState *)ts->d_extra;
         int *redo = (int *)(gtot + n_groups + 2), *redo_n = redo + max_lines + 1;      // the list of lines to parse again, its length
         const unsigned redo_grid = (unsigned)(max_lines < 1024 ? max_lines : 1024);
+#ifdef HPGV_ABLATION
         if (ctx->tokenizer_tiles >= 2 && n_tiles > 0 && max_lines > 0) {
             // ONE sweep: count, scan and parse in one kernel, the segments' start states by look-back (k_tok_parse3).  The
             // records, the ticket and the error flag share the tile scratch (zeroed per call: 16 bytes per 32 KiB of text).
@@ -1777,6 +1822,7 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
             HIPCHK(ctx, hipGetLastError());
             return HPGV_OK;
         }
+#endif
         if (n_tiles > 0) {
             hipLaunchKernelGGL(hpgv::k_tok_count2, dim3((unsigned)((n_tiles + hpgv::TOK2_COUNT_TILES - 1) / hpgv::TOK2_COUNT_TILES)), dim3(256), 0, st, d_text, text_bytes, (int)n_tiles, agg);
             hipLaunchKernelGGL(hpgv::k_tok_scan2a, dim3((unsigned)n_groups), dim3(hpgv::TOK_SCAN_THREADS), 0, st, (const hpgv::TokAgg *)agg, (int)n_tiles, pre, gtot);
@@ -1793,6 +1839,9 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
         HIPCHK(ctx, hipGetLastError());
         return HPGV_OK;
     }
+#ifndef HPGV_ABLATION
+    return fail(ctx, HPGV_ERR_UNSUPPORTED, "the line-by-line tokenizer is an ablation build's");
+#else
     if (n_blocks > 0)
         hipLaunchKernelGGL(hpgv::k_tok_count, dim3((unsigned)n_blocks), dim3(256), 0, st, d_text, text_bytes, ts->d_blocks);
     hipLaunchKernelGGL(hpgv::k_tok_scan, dim3(1), dim3(hpgv::TOK_SCAN_THREADS), 0, st, ts->d_blocks, (int)n_blocks, d_text, text_bytes,
@@ -1807,6 +1856,7 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
                            (const int *)d_n_lines, max_lines, n_samples, strict, d_gt, pitch, d_is_x, d_field_off, d_status);
     HIPCHK(ctx, hipGetLastError());
     return HPGV_OK;
+#endif
     HPGV_ABI_CATCH(ctx)
 }
 
@@ -1999,7 +2049,7 @@ int hpgv_assoc_text(hpgv_ctx *ctx, int task, const char *text, size_t text_bytes
     if ((rc = text_front(ctx, s, HPGV_LAYOUT_ASSOC, ctx->assoc, text, text_bytes, max_lines, n_lines, line_off, field_off, status, &nl, !fused))) return rc;
     if (nl == 0) { HIPCHK(ctx, hipStreamSynchronize(s->stream)); return HPGV_OK; }
     const size_t n = (size_t)nl;
-    if (fused && !(getenv("HPGV_ASSOC_ROWS") && atoi(getenv("HPGV_ASSOC_ROWS")) == 0)) {
+    if (fused && ctx->assoc_rows) {
         // the raw matrix read once by threads that own columns (k_assoc_rows), then the scans' own statistics kernels
         const int ns = ctx->assoc.n_samples;
         if ((rc = ensure(ctx, s, 3, n * 16))) return rc;

@@ -1,7 +1,9 @@
 // hpgv_inflate_capi.hip -- C ABI of the bgzip decoder (its own translation unit of libhpgv.so: the wave-per-block kernel has
 // wave-uniform branches only and is compiled with -mllvm -structurizecfg-skip-uniform-regions, which leaves them as written).
 #include "hpgv_internal.h"
-#include "hpgv_inflate_kernels.h"
+#ifdef HPGV_ABLATION
+#include "hpgv_inflate_kernels.h"      // one lane per block (two forms): lost to the wave-per-block decoder
+#endif
 #include "hpgv_inflate2_kernels.h"
 #include "hpgv_bgzf_kernels.h"
 #include "hpgv_crc_kernels.h"
@@ -10,9 +12,9 @@ extern "C" {
 
 // raw-DEFLATE blocks (the payloads of BGZF blocks) -> text, all on the device: block b occupies d_comp[in_off[b] .. +in_len[b])
 // and decodes to exactly out_len[b] bytes at d_text + out_off[b]; d_status[b] = 0, or a non-zero code for a block this decoder
-// does not take (the host then decodes that block).  Option inflate_wave: 1 (default) or 4 = one wave per block, several symbols
-// per round of its loop; 2 = one wave per block, one symbol per round; 0 = one lane per block (wants a hundred thousand blocks
-// per call), 3 = the lane kernel with its symbol tables in LDS.
+// does not take (the host then decodes that block).  One wave per block, several symbols per round of its loop.  (An ablation
+// build, -DHPGV_ABLATION, also holds the forms it beat -- option inflate_wave: 2 = one symbol per round; 0 = one lane per block
+// (wants a hundred thousand blocks per call), 3 = the lane kernel with its symbol tables in LDS.)
 int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
                             const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, uint8_t *d_text,
                             int32_t *d_status, void *stream) {
@@ -26,16 +28,18 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
     // 125 000 blocks on (one symbol per round: 262 - 267), and only the job's own bytes move; one lane per block
     // (inflate_wave = 0): 13 - 38 ms for a launch of any size, 230 - 258 GB/s from 125 000 blocks on, ten times the job's bytes
     // through HBM.  inflate_wave = 1 is "the library's choice": the wave kernel with several symbols per round
-    const char *iw = getenv("HPGV_INFLATE_WAVE");                    // diagnosis: the decoder of this call, whatever the option says
-    const long mode = iw && atoi(iw) >= 0 && atoi(iw) <= 4 ? atoi(iw) : ctx->inflate_wave;
+#ifndef HPGV_ABLATION
+    // the shipped decoder: a wave per block, several symbols per round of its loop (hpgv_inflate2_kernels.h)
+    hipLaunchKernelGGL(hpgv::k_inflate_wave<true>, dim3((unsigned)n_blocks), dim3(64), 0, (hipStream_t)stream,
+                       d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
+#else
+    const long mode = ctx->inflate_wave;
     const bool wave = mode == 2 || mode == 1 || mode == 4;
     // (experiment: unused dynamic LDS per wave caps the waves per compute unit and leaves LDS for the kernels beside it)
-    const char *lp = getenv("HPGV_INFLATE_LDS_PAD");
-    const unsigned lds_pad = lp ? (unsigned)atoi(lp) : 0u;
+    const unsigned lds_pad = (unsigned)ctx->inflate_lds_pad;
     if (wave) {
-        // (experiment: HPGV_INFLATE_WAVE_WGS = waves per compute unit in flight, each going on to further blocks; 0 = a wave per block)
-        const char *pw = getenv("HPGV_INFLATE_WAVE_WGS");
-        const unsigned per_cu = pw ? (unsigned)atoi(pw) : 0u;
+        // (experiment: inflate_wave_wgs = waves per compute unit in flight, each going on to further blocks; 0 = a wave per block)
+        const unsigned per_cu = (unsigned)ctx->inflate_wave_wgs;
         unsigned grid = (unsigned)n_blocks;
         if (per_cu && grid > per_cu * (unsigned)ctx->n_cus) grid = per_cu * (unsigned)ctx->n_cus;
         if (mode != 2)                                               // several symbols per round (hpgv_inflate2_kernels.h); 2: one symbol per round (A/B)
@@ -46,9 +50,8 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
                                d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
     }
     else if (mode != 3) {
-        // (experiment: HPGV_INFLATE_LANE_WGS = workgroups per compute unit in flight; 0 = one per 64 blocks)
-        const char *pc = getenv("HPGV_INFLATE_LANE_WGS");
-        const unsigned per_cu = pc ? (unsigned)atoi(pc) : 0u;
+        // (experiment: inflate_lane_wgs = workgroups per compute unit in flight; 0 = one per 64 blocks)
+        const unsigned per_cu = (unsigned)ctx->inflate_lane_wgs;
         unsigned grid = (unsigned)((n_blocks + 63) / 64);
         if (per_cu && grid > per_cu * (unsigned)ctx->n_cus) grid = per_cu * (unsigned)ctx->n_cus;
         hipLaunchKernelGGL(hpgv::k_inflate_blocks, dim3(grid), dim3(64), 0, (hipStream_t)stream,
@@ -56,6 +59,7 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
     } else                                                           // (A/B: the lane kernel with its symbol tables in LDS; profiles/experiments_that_did_not_pay.md)
         hipLaunchKernelGGL(hpgv::k_inflate_blocks_lds, dim3((unsigned)((n_blocks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
                            d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status);
+#endif
     HIPCHK(ctx, hipGetLastError());
     return HPGV_OK;
 }

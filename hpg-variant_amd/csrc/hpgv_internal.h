@@ -102,6 +102,16 @@ struct hpgv_ctx {
     long batch_copy = 0;       // per-batch host entry points: 1 = copy page-locked rows to the device first (copy engine) instead of reading them in place
     long batch_fused = 1;      // per-batch host entry points: one fused kernel per call (0: copy + layout + scan + statistics kernels)
     long batch_lds_max = 65536;   // largest raw-row window the fused kernel stages in LDS (raised at hpgv_create when the device allows)
+    // switches read ONCE from the environment at hpgv_create (include/hpgv.h "Environment"); no entry point reads the environment
+    long stats_all2 = 1;       // HPGV_STATS_ALL2=0: every stats batch through the row-staging kernel (what shapes k_stats_all2 does not take use anyway)
+    long assoc_rows = 1;       // HPGV_ASSOC_ROWS=0: text batches counted one workgroup per row (what wider cohorts fall back to)
+    long pinned_noncoherent = 0;   // HPGV_PINNED_NONCOHERENT=1: page-locked buffers allocated non-coherent
+    long vmm_trace = 0;        // HPGV_VMM_TRACE=1: hpgv_dev_commit narrates its mappings on stderr
+#ifdef HPGV_ABLATION
+    long stats_rows = 0, stats_bs = 0, stats_debug = 0;      // HPGV_STATS_ROWS / _BS / _DEBUG: band length, workgroup size, chosen form of k_stats_all2
+    long fisher_lds = 0;       // HPGV_FISHER_LDS: unused LDS bytes per workgroup of the Fisher pass
+    long inflate_lds_pad = 0, inflate_wave_wgs = 0, inflate_lane_wgs = 0;      // HPGV_INFLATE_*: the decoder's occupancy experiments
+#endif
     int n_cus = 256;
     // assoc
     Layout assoc;

@@ -65,25 +65,34 @@ int hpgv_launch_stats_all2(hpgv_ctx *ctx, hpgv::StatsAllArgs &A, void **cnt_buf,
     unsigned bs = 0;
     double best = 0.0;
     const size_t lds32 = hpgv::stats_all2_lds(32);
-    const char *fb = getenv("HPGV_STATS_BS");                       // tuning: threads per workgroup
+#ifdef HPGV_ABLATION
+    const long fb = ctx->stats_bs;                                  // tuning: threads per workgroup (0: chosen below)
+#endif
     for (int c = 1; c <= 4; ++c) {
         // with trios (a barrier per row) 1, 2, 4 or 8 waves: a workgroup of 5 waves puts two on one SIMD, and every row waits
         // for that SIMD; without, the fewest waves that cover the row
         unsigned b = (unsigned)(((chunks + c - 1) / c + 63) / 64 * 64);
         if (mendel) { b = 64; while (b < 512 && (int)b * c < chunks) b *= 2; }
         if ((int)b * c < chunks) continue;
-        if (fb) { b = (unsigned)atoi(fb); if (b < 64 || b % 64 || (int)((chunks + b - 1) / b) != c) continue; }
+#ifdef HPGV_ABLATION
+        if (fb) { b = (unsigned)fb; if (b < 64 || b % 64 || (int)((chunks + b - 1) / b) != c) continue; }
+#endif
         if (b > 512 || (mendel && (long)b * 16 < (long)A.n_trios)) continue;
         const int occ = run(c, G.n_masked, 1, mendel, 0, b, lds32, st, A, G);
         const double useful = (double)occ * (double)chunks / (double)c;      // = occ x b x chunks / (b x c)
         if (occ > 0 && useful > best * 1.02) { best = useful; cpt = c; bs = b; per_cu = occ; }
     }
     if (!cpt) return 1;
-    if (getenv("HPGV_STATS_DEBUG")) fprintf(stderr, "k_stats_all2<%d, %d, %d>: %u threads, %d workgroups per unit\n", cpt, G.n_masked, (int)mendel, bs, per_cu);
+#ifdef HPGV_ABLATION
+    if (ctx->stats_debug) fprintf(stderr, "k_stats_all2<%d, %d, %d>: %u threads, %d workgroups per unit\n", cpt, G.n_masked, (int)mendel, bs, per_cu);
+#endif
     // the band length: the grid is ONE round of the workgroups the chip holds (or k rounds, bands of at most 32 rows).  A band's
     // end -- its column counters' atomics -- costs as much as several rows, and a round that is not full leaves units idle
     // (16 000 rows of 10 k samples, counters + per-sample missing: 8 / 21 / 42 rows per band 105 / 65 / 84 us).
-    if (!getenv("HPGV_STATS_ROWS")) {
+#ifdef HPGV_ABLATION
+    if (!ctx->stats_rows)
+#endif
+    {
         const long slots = (long)per_cu * ctx->n_cus;
         long k = 1;
         while (((long)A.n_variants + slots * k - 1) / (slots * k) > 32) ++k;

@@ -6,10 +6,7 @@
  * and zlib's gzread do -- a damaged stream can still inflate to ISIZE bytes.  On the device path the check runs on the device
  * (hpgv_bgzf_verify_dev); a block it rejects comes here like any block the device decoder refused, and fails the run. */
 char g_input_err[192];
-static int bgzf_verify_on(void) {
-    const char *e = getenv("HPGV_BGZF_VERIFY");
-    return !e || atoi(e) != 0;
-}
+static int bgzf_verify_on(void) { return g_env.bgzf_verify != 0; }
 /* in[clen .. clen + 4) is the block's CRC-32 (the BGZF trailer follows the payload) */
 static int block_crc_bad(const unsigned char *in, size_t clen, const unsigned char *out, size_t isize) {
     const unsigned char *t = in + clen;
@@ -21,7 +18,7 @@ static int block_crc_bad(const unsigned char *in, size_t clen, const unsigned ch
     return 1;
 }
 int inflate_block(const unsigned char *in, size_t clen, unsigned char *out, size_t isize) {
-    if (!getenv("HPGV_ZLIB_INFLATE") && fast_inflate(in, clen, out, isize) == 0)       /* anything unusual: zlib decides */
+    if (!g_env.zlib_inflate && fast_inflate(in, clen, out, isize) == 0)       /* anything unusual: zlib decides */
         return bgzf_verify_on() ? block_crc_bad(in, clen, out, isize) : 0;
     z_stream zs;
     memset(&zs, 0, sizeof zs);
@@ -104,8 +101,7 @@ static void *bgzf_uploader(void *v) {
     (void)SRC_CTX(s);                                               /* this thread works on the part's member device from here on */
     void *up = NULL;
     int ok = stream_get(0, &up) == HPGV_OK;
-    const char *us = getenv("HPGV_UPLOAD_SEGMENT_MB");
-    g_up_seg = us && atoi(us) >= 1 && atoi(us) <= 64 ? (size_t)atoi(us) << 20 : (size_t)UP_SEG_DEFAULT;
+    g_up_seg = g_env.upload_segment_mb >= 1 && g_env.upload_segment_mb <= 64 ? (size_t)g_env.upload_segment_mb << 20 : (size_t)UP_SEG_DEFAULT;
     const size_t pin_cap = (size_t)UP_SEG * UP_SLOTS;
     char *pin = text_buf_get(pin_cap + 1);                          /* from the runs' cache of page-locked buffers */
     up_ring_t r;
@@ -124,8 +120,7 @@ static void *bgzf_uploader(void *v) {
     double t_wait = 0, t_copy = 0; const double t_begin = now_s();
     /* UP_INFLIGHT copies in flight: one is waited for while the others are queued or running */
     enum { UP_INFLIGHT_MAX = 8 };
-    const char *uf = getenv("HPGV_UPLOAD_INFLIGHT");
-    const int depth = uf && atoi(uf) >= 1 && atoi(uf) <= UP_INFLIGHT_MAX ? atoi(uf) : UP_INFLIGHT;
+    const int depth = g_env.upload_inflight >= 1 && g_env.upload_inflight <= UP_INFLIGHT_MAX ? (int)g_env.upload_inflight : UP_INFLIGHT;
     void *stq[UP_INFLIGHT_MAX] = { up };
     for (int k = 1; ok && k < depth; k++) ok = stream_get(0, &stq[k]) == HPGV_OK;
     for (size_t i = 0; ok && i < r.n_seg + (size_t)depth - 1; i++) {
@@ -150,7 +145,7 @@ static void *bgzf_uploader(void *v) {
         pthread_cond_broadcast(&r.cv);
         pthread_mutex_unlock(&r.mu);
         if (!ok) break;
-        if (j == 0 && getenv("HPGV_RUN_TRACE")) fprintf(stderr, "uploader: first segment up %.4f s after its start\n", now_s() - t_begin);
+        if (j == 0 && g_env.run_trace) fprintf(stderr, "uploader: first segment up %.4f s after its start\n", now_s() - t_begin);
         pthread_mutex_lock(&s->g_mu);
         s->up_done = off + len;
         const int cancel = s->u_cancel;
@@ -160,7 +155,7 @@ static void *bgzf_uploader(void *v) {
     }
     for (int k = 1; k < depth; k++) if (stq[k]) { (void)hpgv_stream_sync(CTX, stq[k]); stream_put(0, stq[k]); }
     if (up) (void)hpgv_stream_sync(CTX, up);
-    if (getenv("HPGV_RUN_TRACE"))
+    if (g_env.run_trace)
         fprintf(stderr, "uploader: %.1f MB in %.4f s: %.4f s waiting for the readers (%d), %.4f s in copies\n", s->size / 1e6, now_s() - t_begin, t_wait, n_th, t_copy);
     pthread_mutex_lock(&r.mu); r.stop = 1; pthread_cond_broadcast(&r.cv); pthread_mutex_unlock(&r.mu);
     for (int k = 0; k < n_th; k++) pthread_join(th[k], NULL);
@@ -202,7 +197,7 @@ static void *bgzf_gpu_stager(void *v) {
     for (int q = 1; ok && q < inflight; q++) ok = stream_get(0, &cs[q]) == HPGV_OK;
     size_t q_hi[GPU_INFLIGHT];                           /* the stretches in flight end at these blocks; the oldest starts at g_done */
     int qh = 0, qn = 0;
-    const int dbg = getenv("HPGV_RUN_TRACE") != NULL; const double T0 = now_s();
+    const int dbg = (g_env.run_trace != 0); const double T0 = now_s();
     size_t up_hi = 0;                                    /* compressed bytes [0, up_hi) are on the device */
     for (size_t first = 0; ok && (first < nb || qn > 0);) {
         if (first < nb && qn < inflight) {               /* upload the next stretch while the earlier ones decode */
@@ -239,8 +234,7 @@ static void *bgzf_gpu_stager(void *v) {
         if (ok && qn > 0) {                              /* the oldest stretch in flight: wait, check, publish */
             const size_t a = s->g_done, n = q_hi[qh] - a;
             ok = hpgv_memcpy_d2h(CTX, st, (char *)s->d_status + a * 4, n * 4, cs[qh]) == HPGV_OK;      /* synchronises that stream */
-            const char *fe = getenv("HPGV_TEST_GPU_INFLATE_REFUSE_EVERY");     /* tests: exercise the host patch path */
-            const size_t refuse_every = fe ? (size_t)atol(fe) : 0;
+            const size_t refuse_every = (size_t)g_env.test_refuse_every;     /* tests: exercise the host patch path */
             for (size_t k = 0; ok && k < n; k++)
                 if (st[k] || (refuse_every && (a + k) % refuse_every == 0)) {                             /* not taken by the device decoder: the host decodes it, the text is patched */
                     const size_t bb = a + k;
@@ -538,8 +532,7 @@ static void *bgzf_publisher(void *v) {
     unsigned char *tmp = (unsigned char *)malloc(65536);
     int32_t *st = (int32_t *)malloc(sizeof(int32_t) * SCAN_ROWS_MAX);
     int ok = tmp && st;
-    const char *fe = getenv("HPGV_TEST_GPU_INFLATE_REFUSE_EVERY");     /* tests: exercise the host patch path */
-    const size_t refuse_every = fe ? (size_t)atol(fe) : 0;
+    const size_t refuse_every = (size_t)g_env.test_refuse_every;       /* tests: exercise the host patch path */
     size_t done_blocks = 0;
     for (size_t k = 0; ok; k++) {
         pthread_mutex_lock(&R->mu);
@@ -580,7 +573,7 @@ static void *bgzf_gpu_stream_stager(void *v) {
     s->blk = NULL;
     scan_ring_t R;
     memset(&R, 0, sizeof R);
-    R.s = s; R.S = S; R.dbg = getenv("HPGV_RUN_TRACE") != NULL; R.T0 = now_s();
+    R.s = s; R.S = S; R.dbg = (g_env.run_trace != 0); R.T0 = now_s();
     const int dbg = R.dbg; const double T0 = R.T0;
     pthread_mutex_init(&R.mu, NULL); pthread_cond_init(&R.cv, NULL);
     pthread_t pub;
@@ -655,11 +648,11 @@ static void *bgzf_gpu_stream_stager(void *v) {
 
 /* 0 = the streaming stager has the file; 1 = not taken (the caller goes on with the host's table; nothing is left behind) */
 static int bgzf_stream_stage(source_t *s) {
-    const int dbg = getenv("HPGV_RUN_TRACE") != NULL; const double T0 = now_s();
+    const int dbg = (g_env.run_trace != 0); const double T0 = now_s();
     scan_state_t *S = (scan_state_t *)calloc(1, sizeof *S);
     if (!S) return 1;
     /* the decoder's streams have the lowest priority: the batches' kernels go first whenever a compute unit has room */
-    const int low = !getenv("HPGV_NO_LOW_PRIORITY");
+    const int low = !g_env.no_low_priority;
     s->c_low = low;
     int ok = stream_get(0, &s->rstream) == HPGV_OK && stream_get(low, &s->cstream) == HPGV_OK;
     const size_t slot_bytes = (size_t)SCAN_ROWS_MAX * 28;
@@ -680,8 +673,7 @@ static int bgzf_stream_stage(source_t *s) {
     if (ok) S->d_scratch = (char *)s->d_scan + slot_bytes * SCAN_SLOTS;
     if (dbg) fprintf(stderr, "stage: streams and tables at %.4f\n", now_s() - T0);
     /* the first blocks, from the file's first megabytes: is this a file the device can chain, and how much text is it? */
-    const char *tr = getenv("HPGV_TEST_SCAN_ROWS");
-    S->rows_cap = tr && atol(tr) > 0 ? (size_t)atol(tr) : 0;
+    S->rows_cap = g_env.test_scan_rows > 0 ? (size_t)g_env.test_scan_rows : 0;
     if (ok) ok = scan_next_rows(s, S, &S->slot[0], S->rows_cap && S->rows_cap < 4096 ? S->rows_cap : 4096, 1, dbg, T0) == 1 && S->slot[0].n > 0;
     size_t est = 0;
     if (ok) {
@@ -691,16 +683,16 @@ static int bgzf_stream_stage(source_t *s) {
         if (est > ((size_t)48 << 30)) ok = 0;                        /* as with the host's table: such a text stays on the host path, */
         if (S->chain_pos >= (size_t)s->size && S->blocks < 256 && !s->is_part && !s->mp) ok = 0;      /* and a small file is as quick there */
     }
-    const char *tp = getenv("HPGV_TEST_TEXT_ESTIMATE_PERCENT");    /* tests: a text that outgrows what was committed for it */
-    if (ok && tp && atoi(tp) > 0 && S->chain_pos < (size_t)s->size) {
-        est = (size_t)((double)S->text_pos / (double)S->chain_pos * (double)s->size) / 100 * (size_t)atoi(tp);
+    const long tp = g_env.test_text_estimate_percent;              /* tests: a text that outgrows what was committed for it */
+    if (ok && tp > 0 && S->chain_pos < (size_t)s->size) {
+        est = (size_t)((double)S->text_pos / (double)S->chain_pos * (double)s->size) / 100 * (size_t)tp;
         if (est < S->text_pos + 16) est = S->text_pos + 16;
         dev_text_drop_cached();
     }
     if (ok) {
         s->text_est = S->chain_pos >= (size_t)s->size ? S->text_pos : (size_t)((double)S->text_pos / (double)S->chain_pos * (double)s->size);
         s->d_text = dev_text_get(est, &s->d_text_cap, &s->d_text_kind);
-        ok = s->d_text != NULL && ((s->d_text_kind == DEV_TEXT_GROWS && !getenv("HPGV_NO_GROWING_TEXT")) || S->chain_pos >= (size_t)s->size);
+        ok = s->d_text != NULL && ((s->d_text_kind == DEV_TEXT_GROWS && !g_env.no_growing_text) || S->chain_pos >= (size_t)s->size);
         if (!ok && s->d_text) { dev_text_put(s->d_text, s->d_text_cap, s->d_text_kind); s->d_text = NULL; }
     }
     if (dbg) fprintf(stderr, "stage: first %zu blocks found, text estimate %.1f MB, %s at %.4f\n", S->slot[0].n, est / 1e6, ok ? "streaming" : "not taken", now_s() - T0);
@@ -777,10 +769,8 @@ static size_t bgzf_find_block_start(const source_t *s, size_t from) {
 /* 0 = the file is staged in parts (s is part 0); 1 = not taken, s is as it was */
 static int bgzf_parts_stage(source_t *s) {
     const int G = g_ctx ? hpgv_group_size(g_ctx) : 1;
-    if (G < 2 || getenv("HPGV_BGZF_ONE_DEVICE") || getenv("HPGV_NO_DEVICE_WINDOWS") || getenv("HPGV_BGZF_HOST_TABLE") ||
-        getenv("HPGV_SERIAL_BGZF_WALK") || getenv("HPGV_NO_GROWING_TEXT")) return 1;
-    const char *pm = getenv("HPGV_BGZF_PART_MIN_KB");               /* tests: parts of small files */
-    const size_t part_min = pm && atol(pm) > 0 ? (size_t)atol(pm) << 10 : (size_t)64 << 20;
+    if (G < 2 || g_env.bgzf_one_device || g_env.no_device_windows || g_env.bgzf_host_table || g_env.serial_bgzf_walk || g_env.no_growing_text) return 1;
+    const size_t part_min = g_env.bgzf_part_min_kb > 0 ? (size_t)g_env.bgzf_part_min_kb << 10 : (size_t)64 << 20;      /* (tests: parts of small files) */
     int n = G < MEMBERS_MAX ? G : MEMBERS_MAX;
     if ((size_t)s->size / part_min < (size_t)n) n = (int)((size_t)s->size / part_min);
     if (n < 2) return 1;
@@ -793,7 +783,7 @@ static int bgzf_parts_stage(source_t *s) {
     src_parts_t *mp = (src_parts_t *)calloc(1, sizeof *mp);
     if (!mp) return 1;
     mp->n = n; mp->p[0] = s; mp->whole_size = s->size;
-    const int dbg = getenv("HPGV_RUN_TRACE") != NULL;
+    const int dbg = (g_env.run_trace != 0);
     int ok = 1;
     for (int k = 1; ok && k < n; k++) {                              /* the later parts first: if one of them is not taken, part 0 is still the whole file */
         source_t *p = (source_t *)calloc(1, sizeof *p);
@@ -824,9 +814,9 @@ static int bgzf_parts_stage(source_t *s) {
 
 int bgzf_gpu_stage(source_t *s) {
     s->gpu_tried = 1;
-    if (getenv("HPGV_NO_GPU_INFLATE") || !g_ctx || s->map_pos != 0) return 1;
+    if (g_env.no_gpu_inflate || !g_ctx || s->map_pos != 0) return 1;
     if (!s->is_part && !s->mp && (size_t)s->size >= ((size_t)64 << 10) && bgzf_parts_stage(s) == 0) return 0;
-    const int dbg = getenv("HPGV_RUN_TRACE") != NULL; double T0 = now_s();
+    const int dbg = (g_env.run_trace != 0); double T0 = now_s();
     size_t nb = 0, cap = 1 << 16, text = 0;
     uint64_t *in_off = NULL, *out_off = NULL;
     uint32_t *in_len = NULL, *out_len = NULL;
@@ -842,8 +832,8 @@ int bgzf_gpu_stage(source_t *s) {
         else { (void)hpgv_dev_free(CTX, s->d_comp); s->d_comp = NULL; }
     }
     if (!s->u_started) { pthread_mutex_destroy(&s->g_mu); pthread_cond_destroy(&s->g_cv); s->g_sync = 0; return 1; }
-    if (!getenv("HPGV_BGZF_HOST_TABLE") && !getenv("HPGV_SERIAL_BGZF_WALK") && bgzf_stream_stage(s) == 0) return 0;
-    if (getenv("HPGV_SERIAL_BGZF_WALK") || bgzf_walk_parallel(s->fd, (size_t)s->size, &in_off, &out_off, &in_len, &out_len, &nb, &text)) {
+    if (!g_env.bgzf_host_table && !g_env.serial_bgzf_walk && bgzf_stream_stage(s) == 0) return 0;
+    if (g_env.serial_bgzf_walk || bgzf_walk_parallel(s->fd, (size_t)s->size, &in_off, &out_off, &in_len, &out_len, &nb, &text)) {
         nb = 0; text = 0;
         if (dbg) fprintf(stderr, "stage: serial walk\n");
         in_off = (uint64_t *)malloc(cap * 8); out_off = (uint64_t *)malloc(cap * 8);

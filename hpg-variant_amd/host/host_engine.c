@@ -22,6 +22,42 @@ pthread_rwlock_t g_cohort_lock = PTHREAD_RWLOCK_INITIALIZER;
 char g_err[512];
 
 
+host_env_t g_env;
+void host_env_read(void) {
+    host_env_t e;
+    memset(&e, 0, sizeof e);
+#define ENV_NUM(name, field, lo, hi) do { const char *v_ = getenv(name); if (v_ && *v_) { long x_ = atol(v_); e.field = x_ < (lo) ? (lo) : x_ > (hi) ? (hi) : x_; } } while (0)
+#define ENV_FLAG(name, field) do { e.field = getenv(name) != NULL; } while (0)       /* set at all (as before: "HPGV_X=0" also switches it on) */
+    e.bgzf_verify = 1;
+    e.devices_set = getenv("HPGV_DEVICES") != NULL;
+    ENV_NUM("HPGV_IO_THREADS", io_threads, 0, 64);
+    ENV_NUM("HPGV_STAGE_THREADS", stage_threads, 0, 1024);
+    ENV_NUM("HPGV_ENGINE_THREADS", engine_threads, 0, 64);
+    ENV_FLAG("HPGV_RUN_TRACE", run_trace);
+    ENV_NUM("HPGV_BGZF_VERIFY", bgzf_verify, 0, 1);
+    ENV_FLAG("HPGV_ZLIB_INFLATE", zlib_inflate);
+    ENV_FLAG("HPGV_NO_GPU_INFLATE", no_gpu_inflate);
+    ENV_FLAG("HPGV_NO_DEVICE_WINDOWS", no_device_windows);
+    ENV_FLAG("HPGV_NO_LARGE_WINDOWS", no_large_windows);
+    ENV_FLAG("HPGV_BGZF_ONE_DEVICE", bgzf_one_device);
+    ENV_FLAG("HPGV_BGZF_HOST_TABLE", bgzf_host_table);
+    ENV_FLAG("HPGV_SERIAL_BGZF_WALK", serial_bgzf_walk);
+    ENV_FLAG("HPGV_NO_GROWING_TEXT", no_growing_text);
+    ENV_FLAG("HPGV_NO_LOW_PRIORITY", no_low_priority);
+    ENV_FLAG("HPGV_NO_NUMA_BIND", no_numa_bind);
+    ENV_FLAG("HPGV_NO_WRITER_THREAD", no_writer_thread);
+    ENV_FLAG("HPGV_ALWAYS_SORT", always_sort);
+    ENV_NUM("HPGV_UPLOAD_SEGMENT_MB", upload_segment_mb, 0, 1 << 20);
+    ENV_NUM("HPGV_UPLOAD_INFLIGHT", upload_inflight, 0, 1 << 20);
+    ENV_NUM("HPGV_TEST_GPU_INFLATE_REFUSE_EVERY", test_refuse_every, 0, 1L << 40);
+    ENV_NUM("HPGV_TEST_SCAN_ROWS", test_scan_rows, 0, 1L << 40);
+    ENV_NUM("HPGV_TEST_TEXT_ESTIMATE_PERCENT", test_text_estimate_percent, 0, 1000);
+    ENV_NUM("HPGV_BGZF_PART_MIN_KB", bgzf_part_min_kb, 0, 1L << 40);
+#undef ENV_NUM
+#undef ENV_FLAG
+    g_env = e;
+}
+
 const char *hpgv_host_last_error(void) { return g_err; }
 
 int host_fail(const char *what, int rc) {
@@ -34,6 +70,7 @@ int host_fail(const char *what, int rc) {
  * dealt to the devices, hpgv.h hpgv_create_multi); with neither, the first call of an adapter or runner reads the
  * environment variable HPGV_DEVICES -- "0,1,2,3" or "all" -- and falls back to device 0 */
 int hpgv_host_init_devices(const int *device_ids, int n_devices) {
+    host_env_read();
     pthread_mutex_lock(&g_init_mu);
     int rc = HPGV_OK;
     if (!g_ctx) {
@@ -53,7 +90,8 @@ int hpgv_host_init(int device_id) { return hpgv_host_init_devices(&device_id, 1)
 int hpgv_host_device_count(void) { return g_ctx ? hpgv_group_size(g_ctx) : 0; }
 
 static int init_from_environment(void) {
-    const char *e = getenv("HPGV_DEVICES");
+    host_env_read();
+    const char *e = getenv("HPGV_DEVICES");                 /* (the list itself: parsed here, once, when the engine is bound) */
     int ids[64], n = 0;
     if (e && *e) {
         if (!strcmp(e, "all")) {
@@ -186,7 +224,7 @@ void *dev_text_get(size_t bytes, size_t *cap, int *kind) {
         dev_text_free(p, *kind);
         p = NULL;
     }
-    if (bytes <= DEV_TEXT_RESERVE && !getenv("HPGV_NO_GROWING_TEXT") && hpgv_dev_reserve(CTX, DEV_TEXT_RESERVE, &p) == HPGV_OK) {
+    if (bytes <= DEV_TEXT_RESERVE && !g_env.no_growing_text && hpgv_dev_reserve(CTX, DEV_TEXT_RESERVE, &p) == HPGV_OK) {
         if (hpgv_dev_commit(CTX, p, bytes) == HPGV_OK) { *cap = bytes; *kind = DEV_TEXT_GROWS; return p; }
         (void)hpgv_dev_release(CTX, p);
         p = NULL;

@@ -153,6 +153,7 @@ static void sort_task_merge(void *v, int task) {
 }
 
 int hpgv_host_sort_output_file(const char *path) {
+    if (!g_ctx) host_env_read();                                   /* called on its own (inside a run the run has read it) */
     FILE *f = fopen(path, "rb");
     if (!f) return 1;
     fseek(f, 0, SEEK_END);

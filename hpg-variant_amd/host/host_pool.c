@@ -105,8 +105,7 @@ int default_io_threads(void) {
         fclose(q);
     }
     int t = n >= 32 ? 16 : n >= 16 ? (int)n : n >= 4 ? (int)(n / 2) : 1;
-    const char *e = getenv("HPGV_IO_THREADS");
-    if (e && atoi(e) > 0) t = atoi(e) < 64 ? atoi(e) : 64;
+    if (g_env.io_threads > 0) t = (int)g_env.io_threads;
     return t;
 }
 
@@ -117,7 +116,7 @@ int default_io_threads(void) {
  * (the threads it creates inherit it, its allocations are first touched there) and put back afterwards.
  * HPGV_NO_NUMA_BIND=1 switches this off. */
 int numa_bind_to_device(cpu_set_t *saved) {
-    if (getenv("HPGV_NO_NUMA_BIND") || !g_ctx) return 0;
+    if (g_env.no_numa_bind || !g_ctx) return 0;
     int node = -1;
     if (hpgv_device_numa_node(g_ctx, &node) != HPGV_OK || node < 0) return 0;
     char path[96], list[4096];

@@ -214,6 +214,7 @@ static void write_group_lines(FILE **gfd, const run_batch_t *b) {
 
 static int run_file(const char *vcf_path, const char *ped_path, const char *out_path, int kind, size_t batch_bytes,
                     long *n_variants_out) {
+    host_env_read();                                               /* the environment: once per run (hpgv_host.h "Environment") */
     const double t_enter = now_s();
     g_write_split[0] = g_write_split[1] = 0;
     g_input_err[0] = 0;
@@ -425,16 +426,15 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
         P->n_engines = 2 * (devs < 1 ? 1 : devs);
         /* windows of a text decoded on member 0's device stay there; a batch is then a chain of short kernels and two
          * small copies back, which four in flight overlap better than two (8 GB of text: 0.111 -> 0.100 s) */
-        if (rd.src.d_text && !getenv("HPGV_NO_DEVICE_WINDOWS")) P->n_engines = rd.src.mp && 2 * rd.src.mp->n > 4 ? 2 * rd.src.mp->n : 4;
-        const char *et = getenv("HPGV_ENGINE_THREADS");              /* diagnosis: engine threads (batches in flight on the devices) */
-        if (et && atoi(et) > 0) P->n_engines = atoi(et);
+        if (rd.src.d_text && !g_env.no_device_windows) P->n_engines = rd.src.mp && 2 * rd.src.mp->n > 4 ? 2 * rd.src.mp->n : 4;
+        if (g_env.engine_threads > 0) P->n_engines = (int)g_env.engine_threads;      /* diagnosis: engine threads (batches in flight on the devices) */
         if (P->n_engines > RUN_ENGINES_MAX) P->n_engines = RUN_ENGINES_MAX;
         P->nb = P->n_engines + 3;
     }
     /* windows of a text that is on the device are not copied anywhere, so they need not be as small as the caller's batches:
      * about 64 of them per file, 256 MB at most, amortise what a batch costs whatever its size (three waits for the
      * device and 50 us of short kernels beside 100 us per 64 MB of tokenizing and scanning) */
-    if (P && rd.src.d_text && !getenv("HPGV_NO_DEVICE_WINDOWS") && !getenv("HPGV_NO_LARGE_WINDOWS")) {
+    if (P && rd.src.d_text && !g_env.no_device_windows && !g_env.no_large_windows) {
         size_t w = rd.src.text_est / 64;
         if (w > ((size_t)256 << 20)) w = (size_t)256 << 20;
         if (w > batch_bytes) batch_bytes = w;
@@ -476,14 +476,14 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
         pool_init(&rpool, io_threads);
         pool_init(&wpool, io_threads);
         rd.src.pool = &rpool;
-        if (rd.src.d_text && !getenv("HPGV_NO_DEVICE_WINDOWS")) {      /* bgzip decoded on the device: windows of the device text from the first data line on */
+        if (rd.src.d_text && !g_env.no_device_windows) {      /* bgzip decoded on the device: windows of the device text from the first data line on */
             rd.src.dev_pos -= rd.carry_len; rd.carry_len = 0; rd.devwin = 1;
         }
         const int n_fmt = io_threads < RUN_FMT_BUFS / 2 ? io_threads : RUN_FMT_BUFS / 2;      /* two sets of buffers: one is written while the other is filled */
         file_writer_t fw;
         memset(&fw, 0, sizeof fw);
         /* (the vcf2epi rows are written out of the batch itself, and the stats tool's group files by this thread) */
-        const int use_fw = kind != 4 && !getenv("HPGV_NO_WRITER_THREAD") && file_writer_start(&fw, out);
+        const int use_fw = kind != 4 && !g_env.no_writer_thread && file_writer_start(&fw, out);
         int fmt_set = 0;
         pthread_t th[1 + RUN_ENGINES_MAX];
         int n_th = 0;
@@ -532,9 +532,9 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     {
         const double t0 = now_s();
         /* (in order as written: nothing to do; HPGV_ALWAYS_SORT=1 reads the file back and checks all the same) */
-        if (!rc && kind < 4 && (ord.disorder || !ord.have || getenv("HPGV_ALWAYS_SORT")) && hpgv_host_sort_output_file(out_path))      /* assoc_runner.c:255-261: only a warning there */
+        if (!rc && kind < 4 && (ord.disorder || !ord.have || g_env.always_sort) && hpgv_host_sort_output_file(out_path))      /* assoc_runner.c:255-261: only a warning there */
             fprintf(stderr, "WARN: results could not be sorted by chromosome and position\n");
-        else if (!rc && kind < 4 && getenv("HPGV_RUN_TRACE") && !(ord.disorder || !ord.have || getenv("HPGV_ALWAYS_SORT")))
+        else if (!rc && kind < 4 && g_env.run_trace && !(ord.disorder || !ord.have || g_env.always_sort))
             fprintf(stderr, "hpgv run: the result file is in order as written\n");
         t_sort = now_s() - t0;
         free(ord.last);
@@ -552,14 +552,14 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
     if (dev_filters) (void)hpgv_set_text_filters(g_ctx, -1.0, -1.0, -1);
     numa_unbind(&saved_cpus, numa_bound);
     g_run_times[3] = t_sort; g_run_times[4] = now_s() - t_start;
-    if (getenv("HPGV_RUN_TRACE"))
+    if (g_env.run_trace)
         fprintf(stderr, "hpgv run: %ld records, %.0f batches, %d io threads: read %.3f s, engine %.3f s (%d threads), write %.3f s (stages overlap), sort %.3f s, total %.3f s\n",
                 written, g_run_times[5], io_threads, g_run_times[0], g_run_times[1], n_engines_used, g_run_times[2], t_sort, g_run_times[4]);
     const double t_done = now_s();
     source_close(&rd.src); free(rd.carry); free(rd.tailbuf); free(hdr); free(names); ped_table_free(&ped);
     if (n_variants_out) *n_variants_out = written;
     pthread_rwlock_unlock(&g_cohort_lock);
-    if (getenv("HPGV_RUN_TRACE"))
+    if (g_env.run_trace)
         fprintf(stderr, "hpgv run: before the pipeline: PED and open %.4f s, VCF header %.4f s, cohort and buffers %.4f s; after it: %.4f s; of the write stage: formatting %.4f s, writing %.4f s\n",
                 t_opened - t_enter, t_header - t_opened, t_start - t_header, now_s() - t_done, g_write_split[0], g_write_split[1]);
     return rc;
@@ -568,6 +568,7 @@ static int run_file(const char *vcf_path, const char *ped_path, const char *out_
 /* the runners' reader on its own: copies `in_path` (plain, gzip or BGZF) to `out_path` in whole-line batches
  * of at most batch_bytes; what the runners feed to the engine, batch by batch */
 int hpgv_host_copy_lines(const char *in_path, const char *out_path, size_t batch_bytes, int skip_vcf_header, long *n_batches) {
+    host_env_read();
     line_reader_t rd;
     memset(&rd, 0, sizeof rd);
     if (batch_bytes < (1u << 16)) batch_bytes = 1u << 16;

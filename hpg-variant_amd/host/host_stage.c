@@ -171,9 +171,9 @@ static int g_stage_threads = 0;
 static int stage_threads(void) {
     int t = __atomic_load_n(&g_stage_threads, __ATOMIC_RELAXED);
     if (t > 0) return t;
-    t = 8;
-    const char *e = getenv("HPGV_STAGE_THREADS");
-    if (e && *e) t = atoi(e);
+    static int env_read = 0;                               /* an adapter may be the process's first call into the library */
+    if (!__atomic_exchange_n(&env_read, 1, __ATOMIC_RELAXED) && !g_ctx) host_env_read();
+    t = g_env.stage_threads > 0 ? (int)g_env.stage_threads : 8;
     const long cores = sysconf(_SC_NPROCESSORS_ONLN);
     if (cores > 0 && t > cores) t = (int)cores;
     if (t < 1) t = 1;

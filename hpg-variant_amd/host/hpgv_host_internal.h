@@ -179,6 +179,38 @@ extern struct host_group_key g_group_key;
 struct host_lf_key { const void *table; int n; };
 extern struct host_lf_key g_lf_key;
 
+/* The environment of libhpgv_host.so (include/hpgv_host.h "Environment"): read by host_env_read() when the engine is bound and
+ * at the start of every file run -- never on a per-batch or per-block path -- into this one structure. */
+typedef struct {
+    long devices_set;                /* HPGV_DEVICES given (its text is parsed by the engine binding) */
+    long io_threads;                 /* HPGV_IO_THREADS: reader / formatter team (0: by the cores) */
+    long stage_threads;              /* HPGV_STAGE_THREADS: team of a lone adapter caller's staging (0: 8) */
+    long engine_threads;             /* HPGV_ENGINE_THREADS: batches in flight on the devices (0: by the input) */
+    long run_trace;                  /* HPGV_RUN_TRACE=1: stage times of a run on stderr */
+    long bgzf_verify;                /* HPGV_BGZF_VERIFY=0: no CRC-32 check of decoded blocks (default 1) */
+    long zlib_inflate;               /* HPGV_ZLIB_INFLATE=1: host blocks through zlib instead of the built-in decoder */
+    long no_gpu_inflate;             /* HPGV_NO_GPU_INFLATE=1: bgzip decoded on the host */
+    long no_device_windows;          /* HPGV_NO_DEVICE_WINDOWS=1: device-decoded text copied back whole */
+    long no_large_windows;           /* HPGV_NO_LARGE_WINDOWS=1: windows of the caller's batch size */
+    long bgzf_one_device;            /* HPGV_BGZF_ONE_DEVICE=1: a group decodes the file on member 0 only */
+    long bgzf_host_table;            /* HPGV_BGZF_HOST_TABLE=1: the block table walked by the host's team */
+    long serial_bgzf_walk;           /* HPGV_SERIAL_BGZF_WALK=1: ... by one thread */
+    long no_growing_text;            /* HPGV_NO_GROWING_TEXT=1: a fixed device buffer for the decoded text */
+    long no_low_priority;            /* HPGV_NO_LOW_PRIORITY=1: the decoder's streams at normal priority */
+    long no_numa_bind;               /* HPGV_NO_NUMA_BIND=1: a run's threads stay where the scheduler puts them */
+    long no_writer_thread;           /* HPGV_NO_WRITER_THREAD=1: result lines written by the formatting thread */
+    long always_sort;                /* HPGV_ALWAYS_SORT=1: the output is sorted even when it came out in order */
+    long upload_segment_mb;          /* HPGV_UPLOAD_SEGMENT_MB (1..64, default 4), upload_inflight: HPGV_UPLOAD_INFLIGHT (1..8, default 2) */
+    long upload_inflight;
+    /* tests only */
+    long test_refuse_every;          /* HPGV_TEST_GPU_INFLATE_REFUSE_EVERY: every n-th block handed back to the host decoder */
+    long test_scan_rows;             /* HPGV_TEST_SCAN_ROWS: blocks per stretch of the streaming stager */
+    long test_text_estimate_percent; /* HPGV_TEST_TEXT_ESTIMATE_PERCENT: the first commitment as a share of the estimate */
+    long bgzf_part_min_kb;           /* HPGV_BGZF_PART_MIN_KB: smallest part of a file staged in parts (default 65536) */
+} host_env_t;
+extern host_env_t g_env;
+void host_env_read(void);
+
 /* ---- functions and data the units share ---- */
 /* host_containers.c */
 void list_insert_chain(list_item_t *first, list_item_t *last, size_t n, list_t *list);

@@ -85,8 +85,32 @@ void hpgv_destroy(hpgv_ctx *ctx);
 /* text of the last failure on this ctx (ctx == NULL: last hpgv_create failure
  * of the calling thread) */
 const char *hpgv_last_error(const hpgv_ctx *ctx);
-/* tuning knobs: "row_align" (bytes, power of two >= 16, default 16),
- * "variants_per_wave", "nontemporal" (0/1), "profile" (0/1) */
+/* Options of a context (key, value; before the cohort is set where noted):
+ *   "row_align"   bytes, power of two >= 16 (default 16; before the cohort)      "row_pad"  extra bytes per row, multiple of 16
+ *   "variants_per_wave" (default 2), "blocks_per_cu" (1..8), "scan_lds"          launch shape of the resident scans
+ *   "profile" 0/1                HIP events around the scan / statistics kernels (hpgv_last_kernel_ms)
+ *   "fisher_cut_exp" 12..300     a Fisher tail stops below 10^-this of its largest term (default 22: below one ulp of the sum)
+ *   "batch_fused" 0/1, "batch_copy" 0/1   per-batch host entry points: one fused kernel reading page-locked rows in place
+ *                                (default) / the kernel chain / copy the rows first
+ *   "epi_complete" 0/1, "epi_triples_1pass" 0/1     epistasis scans: the shortcuts for data without missing calls / <= 10 folds
+ *   "group_self_exchange" 0/1    (group contexts; tests) member 0 hands its results over through the communicator too
+ * Every kernel ships in ONE form.  The forms that lost their A/B comparisons (profiles/experiments_that_did_not_pay.md) are
+ * compiled only into an ablation build (-DHPGV_ABLATION: tools/build_ablation.py, used by tools/ only); there the keys
+ * "pipeline", "persistent", "scan_unroll", "pipe_waves", "nontemporal", "fisher_width", "inflate_wave", "tokenizer_tiles"
+ * select them, and in the shipped library any value but the shipped one is refused with HPGV_ERR_UNSUPPORTED.
+ *
+ * Environment.  The library reads the environment in exactly two places: hpgv_create (the table below, once per context,
+ * into the context) and hpgv_group_comm_init (HPGV_RCCL_LIB).  No entry point that launches work reads it.
+ *   HPGV_BATCH_FUSED=0        as option "batch_fused" 0: the per-batch calls as a chain of kernels       (default 1)
+ *   HPGV_BATCH_COPY=1         as option "batch_copy" 1                                                    (default 0)
+ *   HPGV_STATS_ALL2=0         every stats batch through the row-staging kernel k_stats_all -- the fall-back of the shapes
+ *                             k_stats_all2 does not take (unaligned rows, very wide cohorts, > 3 masked groups)  (default 1)
+ *   HPGV_ASSOC_ROWS=0         text batches counted one workgroup per row (k_batch) -- the fall-back of cohorts wider than
+ *                             k_assoc_rows takes                                                          (default 1)
+ *   HPGV_PINNED_NONCOHERENT=1 hpgv_host_alloc asks for non-coherent page-locked memory                   (default 0)
+ *   HPGV_VMM_TRACE=1          hpgv_dev_commit narrates its mappings on stderr                             (default 0)
+ *   HPGV_RCCL_LIB=<path>      librccl to load first (then librccl.so.1, librccl.so, /opt/rocm/lib/...)
+ * (libhpgv_host.so has a table of its own: include/hpgv_host.h "Environment".) */
 int  hpgv_set_option(hpgv_ctx *ctx, const char *key, long value);
 
 /* ---- cohort description (replicated per device; tiny) --------------------- */

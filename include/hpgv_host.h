@@ -376,6 +376,25 @@ void hpgv_host_set_stage_threads(int n);        /* the team of a lone caller's s
 void hpgv_host_adapter_profile(int on);
 void hpgv_host_adapter_times(double *seconds4, long *calls, int reset);
 
+/* ---- Environment ----------------------------------------------------------------------------------------------
+ * libhpgv_host.so reads the environment when the engine is bound (the first adapter / runner call, or hpgv_host_init*)
+ * and at the start of every file run (hpgv_run_*, hpgv_host_copy_lines) -- never per batch, per block or per launch.
+ *   HPGV_DEVICES=0,1,2,3 | all   devices of the engine when no hpgv_host_init* call named them (default: device 0)
+ *   HPGV_IO_THREADS=n            reader / formatter team of a run (default: half the cores, at most 16)
+ *   HPGV_STAGE_THREADS=n         team a lone adapter caller's staging is dealt to (default 8; 1 = never)
+ *   HPGV_ENGINE_THREADS=n        batches in flight on the devices (default: by the input)
+ *   HPGV_RUN_TRACE=1             stage times of a run on stderr
+ *   HPGV_BGZF_VERIFY=0           no CRC-32 check of decoded BGZF blocks (default 1: checked, on the device where decoded there)
+ *   HPGV_NO_GPU_INFLATE=1        bgzip decoded on the host          HPGV_ZLIB_INFLATE=1     ... through zlib
+ *   HPGV_BGZF_ONE_DEVICE=1       a group decodes a bgzip file on its first device only (default: in parts, one per device)
+ *   HPGV_NO_NUMA_BIND=1          a run's threads are not moved to the GPU's NUMA node
+ *   HPGV_ALWAYS_SORT=1           the output file is sorted even when it came out in order
+ * Diagnosis and tests (each switches one stage of the bgzip device path to its fall-back): HPGV_NO_DEVICE_WINDOWS,
+ * HPGV_NO_LARGE_WINDOWS, HPGV_BGZF_HOST_TABLE, HPGV_SERIAL_BGZF_WALK, HPGV_NO_GROWING_TEXT, HPGV_NO_LOW_PRIORITY,
+ * HPGV_NO_WRITER_THREAD, HPGV_UPLOAD_SEGMENT_MB, HPGV_UPLOAD_INFLIGHT, HPGV_TEST_GPU_INFLATE_REFUSE_EVERY,
+ * HPGV_TEST_SCAN_ROWS, HPGV_TEST_TEXT_ESTIMATE_PERCENT, HPGV_BGZF_PART_MIN_KB (host/hpgv_host_internal.h: host_env_t).
+ * The engine underneath has its own short table: include/hpgv.h "Environment". */
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,32 @@ from oracle import pyoracle as orc
 
 hpgv = importlib.import_module("hpg-variant_amd")
 
+def shipped(key, values):
+    """The values of option `key` this build of libhpgv.so takes.  The shipped library holds ONE form of each kernel; the forms
+    that lost their A/B live in an ablation build (tools/build_ablation.py, HPGV_LIB=...), where these tests cover them too."""
+    e = hpgv.Engine(0)
+    ok = []
+    for v in values:
+        try:
+            e.set_option(key, v)
+            ok.append(v)
+        except hpgv.HpgvError:
+            pass
+    e.close()
+    return ok
+
+
+def set_or_skip(engine, key, value):
+    """set_option, or skip the test when the value names a form only an ablation build holds"""
+    import pytest
+    try:
+        engine.set_option(key, value)
+    except hpgv.HpgvError as err:
+        if "ablation" in str(err):
+            pytest.skip("%s = %s is an ablation build's form" % (key, value))
+        raise
+
+
 TOL = 1e-10   # north_star: chi2 / Fisher / HWE p-values within 1e-10 of the reference path
 
 
