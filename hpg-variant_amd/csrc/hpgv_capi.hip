@@ -385,7 +385,9 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
     } else if (!strcmp(key, "epi_complete")) {
         ctx->epi_complete = value ? 1 : 0;
     } else if (!strcmp(key, "epi_triples_1pass")) {
-        ctx->epi_triples_1pass = value ? 1 : 0;
+        if (value < 0 || value > 2) return fail(ctx, HPGV_ERR_INVALID, "epi_triples_1pass must be 0 (two passes), 1 (the cells nine at a time) or 2 (one pass, one wave per SIMD)");
+        HPGV_SHIPPED_ONLY(value != 2, "epi_triples_1pass = 2")
+        ctx->epi_triples_1pass = value;
     } else if (!strcmp(key, "scan_lds")) {
         if (value < 0 || value > 160 * 1024) return fail(ctx, HPGV_ERR_INVALID, "scan_lds must be in [0, 163840]");
         ctx->scan_lds = value;

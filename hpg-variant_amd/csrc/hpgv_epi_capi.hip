@@ -1,6 +1,7 @@
 // hpgv_epi_capi.hip -- C ABI of the epistasis / MDR path (its own translation unit of libhpgv.so: the pair and triple
 // scans are instantiated per fold count and compile for minutes).
 #include "hpgv_internal.h"
+#include "hpgv_epi_triples3_kernels.h"
 
 
 namespace {
@@ -550,10 +551,22 @@ int epi_launch_triples(hpgv_ctx *ctx, int i_first, int n_i, double *d_acc, uint3
     HIPCHK(ctx, hipMemcpyAsync(d_rb, rb.data(), rb.size() * sizeof(unsigned), hipMemcpyHostToDevice, nullptr));
     const dim3 grid((unsigned)total);
     const bool balanced = E.nA == E.nU && E.nA < (1 << 22);
-    // ranking, at most 10 folds: the one-pass kernel (all folds' counts in registers).  Not for unequal classes above 5 folds: that
-    // instantiation (270 packed counters + the float decision of every cell) does not fit the register file -- 1 534 registers in
-    // scratch, 128 ms where the two-pass form below takes 37 (512 SNPs x 10 k samples x 10 folds, 4 000 cases)
-    if (ctx->epi_triples_1pass && candidates && !d_acc && E.num_folds <= 10 && E.nA < 65536 && E.nU < 65536 && (balanced || E.num_folds <= 5)) {
+    // ranking, at most 10 folds, classes below 65 536 samples: the 27 cells nine at a time (hpgv_epi_triples3_kernels.h): three walks
+    // over the samples with a third of the state each, three waves per SIMD
+    if (ctx->epi_triples_1pass == 1 && candidates && !d_acc && E.num_folds <= 10 && E.nA < 65536 && E.nU < 65536) {
+#define HPGV_EPI3B_LAUNCH(KK, BAL)                                                                                                              \
+        hipLaunchKernelGGL((hpgv::k_epi_triples3<KK, TRAINING, BAL>), grid, dim3(256), 0, nullptr, E.d_planes, E.W, E.V, i_first, d_rb, n_i, d_jbp, n_jb, \
+                           E.d_chunks, E.n_chunks, E.d_folds, E.nA, E.nU, E.d_thr, d_cand, E.d_cand_count, cap)
+        if (E.num_folds <= 5) { if (balanced) HPGV_EPI3B_LAUNCH(5, true); else HPGV_EPI3B_LAUNCH(5, false); }
+        else { if (balanced) HPGV_EPI3B_LAUNCH(10, true); else HPGV_EPI3B_LAUNCH(10, false); }
+#undef HPGV_EPI3B_LAUNCH
+        HIPCHK(ctx, hipGetLastError());
+        return HPGV_OK;
+    }
+#ifdef HPGV_ABLATION
+    // (option epi_triples_1pass = 2: the one-pass kernel it replaced -- all 27 K counts in one lane, one wave per SIMD.  Not for unequal
+    // classes above 5 folds: that instantiation does not fit the register file)
+    if (ctx->epi_triples_1pass == 2 && candidates && !d_acc && E.num_folds <= 10 && E.nA < 65536 && E.nU < 65536 && (balanced || E.num_folds <= 5)) {
 #define HPGV_EPI3_LAUNCH(KK, BAL)                                                                                                               \
         hipLaunchKernelGGL((hpgv::k_epi_triples1<KK, TRAINING, BAL>), grid, dim3(256), 0, nullptr, E.d_planes, E.W, E.V, i_first, d_rb, n_i, d_jbp, n_jb, \
                            E.d_chunks, E.n_chunks, E.d_folds, E.nA, E.nU, E.d_thr, d_cand, E.d_cand_count, cap)
@@ -563,6 +576,7 @@ int epi_launch_triples(hpgv_ctx *ctx, int i_first, int n_i, double *d_acc, uint3
         HIPCHK(ctx, hipGetLastError());
         return HPGV_OK;
     }
+#endif
     if (balanced)
         hipLaunchKernelGGL((hpgv::k_epi_triples<TRAINING, true>), grid, dim3(256), 0, nullptr, E.d_planes, E.W, E.V, i_first, d_rb, n_i, d_jbp, n_jb, E.d_chunks, E.n_chunks,
                            E.num_folds, E.d_folds, E.nA, E.nU, d_acc, d_mask, candidates ? E.d_thr : nullptr, d_cand, E.d_cand_count, cap);

@@ -89,8 +89,21 @@ __global__ void k_add_i32(int32_t *__restrict__ dst, const int32_t *__restrict__
 
 // dlopen of librccl under its usual names ($HPGV_RCCL_LIB first); `tried` collects why each candidate failed
 void *open_rccl(std::string &tried) {
+    // The communicator must sit on the SAME HIP / HSA runtime this library is bound to.  A process may hold a second ROCm stack
+    // (importing torch after this library loads torch's bundled copies beside /opt/rocm's): a bare dlopen("librccl.so.1") then
+    // hands back whichever librccl is already loaded, and one bound to the other stack finds its HSA uninitialised
+    // ("no ROCm-capable device").  So the librccl NEXT TO the HIP runtime in use is tried first, by full path.
+    std::string beside1, beside2;
+    {
+        Dl_info info;
+        if (dladdr((const void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) { dir.resize(slash + 1); beside1 = dir + "librccl.so.1"; beside2 = dir + "librccl.so"; }
+        }
+    }
     const char *env = getenv("HPGV_RCCL_LIB");
-    const char *names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    const char *names[] = {env, beside1.c_str(), beside2.c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const char *n : names) {
         if (!n || !*n) continue;
         void *dl = dlopen(n, RTLD_NOW | RTLD_LOCAL);

@@ -94,7 +94,7 @@ struct hpgv_ctx {
     long pipe_waves = 4;       // register budget of the pipelined scan, as waves per SIMD (4, 6 or 8)
     long fisher_cut_exp = 22;  // Fisher tails stop after a round whose terms are all below 10^-this of the tail's largest term
     long epi_complete = 1;     // epistasis pair scan on a dataset without missing calls: count four cells, derive the other five
-    long epi_triples_1pass = 1; // epistasis triple ranking with at most 10 folds: one pass, all folds' counts in registers (one wave per SIMD)
+    long epi_triples_1pass = 1; // epistasis triple ranking with at most 10 folds: 1 = the 27 cells nine at a time (three walks, three waves per SIMD); 0 = the two-pass kernel; 2 (ablation build) = one pass with all counts in one lane
     long scan_lds = 0;         // bytes of (unused) LDS per workgroup of the stats / tdt scans: caps the waves in flight per CU
     long fisher_width = 16;    // lanes per variant in the Fisher p-pass (64, 32, 16 or 8): 64 / width variants per wave
     long inflate_wave = 1;     // bgzip decoder: 2 = one wave per block (hpgv_inflate2_kernels.h), 0 = one lane per block, 1 = by the number of blocks

@@ -109,7 +109,8 @@ const char *hpgv_last_error(const hpgv_ctx *ctx);
  *                             k_assoc_rows takes                                                          (default 1)
  *   HPGV_PINNED_NONCOHERENT=1 hpgv_host_alloc asks for non-coherent page-locked memory                   (default 0)
  *   HPGV_VMM_TRACE=1          hpgv_dev_commit narrates its mappings on stderr                             (default 0)
- *   HPGV_RCCL_LIB=<path>      librccl to load first (then librccl.so.1, librccl.so, /opt/rocm/lib/...)
+ *   HPGV_RCCL_LIB=<path>      librccl to load first (then the librccl beside the HIP runtime this library is bound to,
+ *                             then librccl.so.1, librccl.so, /opt/rocm/lib/...)
  * (libhpgv_host.so has a table of its own: include/hpgv_host.h "Environment".) */
 int  hpgv_set_option(hpgv_ctx *ctx, const char *key, long value);
 

@@ -290,6 +290,7 @@ def test_run_epistasis_from_a_dataset_file(tmp_path):
     L.hpgv_run_epistasis.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
     L.hpgv_host_last_error.restype = C.c_char_p
     libc = C.CDLL(None)
+    assert L.hpgv_host_init(0) == 0          # the engine bound BEFORE the seeds below: the runtime's start-up may draw from rand()
     rng = np.random.default_rng(23)
     v, nA, nU, k, n, reps = 45, 90, 110, 5, 8, 2
     data = epi_random_dataset(rng, v, nA, nU)
