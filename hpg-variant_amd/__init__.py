@@ -41,7 +41,7 @@ SYMBOLS = [
     "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_stats_groups",
     "hpgv_epi_dataset_text", "hpgv_set_text_filters", "hpgv_stats_text", "hpgv_stats_text_groups", "hpgv_epi_set_dataset", "hpgv_epi_set_folds", "hpgv_epi_set_fold_masks", "hpgv_epi_counts",
     "hpgv_epi_counts_all_folds", "hpgv_epi_scan_pairs", "hpgv_epi_rank_pairs", "hpgv_epi_rank_pairs_rows", "hpgv_epi_scan_triples", "hpgv_epi_rank_triples", "hpgv_epi_eval_combs", "hpgv_epi_rank_order", "hpgv_epi_rank_order_rows", "hpgv_read_probe",
-    "hpgv_group_comm_init", "hpgv_group_comm_ranks", "hpgv_group_rccl_probe", "hpgv_group_shard", "hpgv_group_assoc", "hpgv_group_tdt", "hpgv_group_stats", "hpgv_group_sync", "hpgv_group_epi_share", "hpgv_group_epi_rank", "hpgv_epi_rank_triples_rows",
+    "hpgv_group_comm_init", "hpgv_group_comm_ranks", "hpgv_group_rccl_probe", "hpgv_group_shard", "hpgv_group_assoc", "hpgv_group_tdt", "hpgv_group_stats", "hpgv_group_sync", "hpgv_group_epi_share", "hpgv_group_epi_rank", "hpgv_epi_rank_triples_rows", "hpgv_text_alias_tiles", "hpgv_text_tiles_bytes", "hpgv_bgzf_verify_tiles_dev",
 ]
 
 
@@ -119,6 +119,10 @@ def load():
     L.hpgv_tokenize_dev.argtypes = [vp, vp, sz, i32, i32, i32, vp, vp, vp, vp, sz, vp, vp, vp]
     L.hpgv_inflate_blocks_dev.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]
     L.hpgv_bgzf_verify_dev.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]
+    L.hpgv_bgzf_verify_tiles_dev.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, u64, vp]
+    L.hpgv_text_tiles_bytes.restype = sz
+    L.hpgv_text_tiles_bytes.argtypes = [u64]
+    L.hpgv_text_alias_tiles.argtypes = [vp, vp, vp, vp, vp, u64]
     L.hpgv_bgzf_scan_scratch_bytes.argtypes = [u64, i32]
     L.hpgv_bgzf_scan_scratch_bytes.restype = sz
     L.hpgv_bgzf_scan_dev.argtypes = [vp, vp, u64, u64, u64, i32, vp, vp, vp, vp, vp, sz, vp, vp]
@@ -565,6 +569,9 @@ class Engine:
 
     def inflate_blocks(self, d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status, stream=None):
         self._chk(self.L.hpgv_inflate_blocks_dev(self.h, d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status, stream))
+
+    def bgzf_verify_tiles(self, d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status, d_tiles, n_tiles, stream=None):
+        self._chk(self.L.hpgv_bgzf_verify_tiles_dev(self.h, d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status, d_tiles, n_tiles, stream))
 
     def bgzf_verify(self, d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status, stream=None):
         self._chk(self.L.hpgv_bgzf_verify_dev(self.h, d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status, stream))

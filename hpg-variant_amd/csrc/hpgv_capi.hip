@@ -187,6 +187,7 @@ static void read_environment(hpgv_ctx *ctx) {
     num("HPGV_ASSOC_ROWS", 0, 1, &ctx->assoc_rows);
     num("HPGV_PINNED_NONCOHERENT", 0, 1, &ctx->pinned_noncoherent);
     num("HPGV_VMM_TRACE", 0, 1, &ctx->vmm_trace);
+    num("HPGV_DECODE_TILES", 0, 1, &ctx->decode_tiles);
 #ifdef HPGV_ABLATION
     num("HPGV_INFLATE_WAVE", 0, 4, &ctx->inflate_wave);
     num("HPGV_TOKENIZER_TILES", 0, 2, &ctx->tokenizer_tiles);
@@ -834,9 +835,37 @@ int hpgv_text_alias(hpgv_ctx *ctx, const char *host_text, const char *d_text) {
     if (!ctx || !host_text) return HPGV_ERR_INVALID;
     std::lock_guard<std::mutex> lk(ctx->alias_mu);
     for (size_t i = 0; i < ctx->text_alias.size(); ++i)
-        if (ctx->text_alias[i].first == host_text) { ctx->text_alias.erase(ctx->text_alias.begin() + (long)i); break; }
+        if (ctx->text_alias[i].first == host_text) {
+            const char *old = ctx->text_alias[i].second;
+            for (size_t k = 0; k < ctx->text_tiles.size(); ++k) if (ctx->text_tiles[k].d_text == old) { ctx->text_tiles.erase(ctx->text_tiles.begin() + (long)k); break; }
+            ctx->text_alias.erase(ctx->text_alias.begin() + (long)i);
+            break;
+        }
     if (d_text) ctx->text_alias.emplace_back(host_text, d_text);
     return HPGV_OK;
+}
+int hpgv_text_alias_tiles(hpgv_ctx *ctx, const char *host_text, const char *d_text, const char *d_text_base, const void *d_tiles, uint64_t n_tiles) {
+    HPGV_ABI_TRY
+    ctx = first_member(ctx);
+    if (!ctx || !host_text) return HPGV_ERR_INVALID;
+    if (d_text && d_tiles && (!d_text_base || d_text < d_text_base)) return fail(ctx, HPGV_ERR_INVALID, "the window lies in front of its text");
+    std::lock_guard<std::mutex> lk(ctx->alias_mu);
+    const char *old = nullptr;
+    for (size_t i = 0; i < ctx->text_alias.size(); ++i)
+        if (ctx->text_alias[i].first == host_text) { old = ctx->text_alias[i].second; ctx->text_alias.erase(ctx->text_alias.begin() + (long)i); break; }
+    for (size_t i = 0; i < ctx->text_tiles.size(); ++i)
+        if (ctx->text_tiles[i].d_text == (d_text ? d_text : old)) { ctx->text_tiles.erase(ctx->text_tiles.begin() + (long)i); break; }
+    if (d_text) {
+        ctx->text_alias.emplace_back(host_text, d_text);
+        if (d_tiles && n_tiles > 0) ctx->text_tiles.push_back({d_text, d_text_base, d_tiles, n_tiles});
+    }
+    return HPGV_OK;
+    HPGV_ABI_CATCH(ctx)
+}
+static bool tiles_of_device_text(hpgv_ctx *ctx, const char *d_text, hpgv_ctx::TextTiles *out) {
+    std::lock_guard<std::mutex> lk(ctx->alias_mu);
+    for (const auto &t : ctx->text_tiles) if (t.d_text == d_text) { *out = t; return true; }
+    return false;
 }
 static const char *text_on_device(hpgv_ctx *ctx, const char *host_text) {
     std::lock_guard<std::mutex> lk(ctx->alias_mu);
@@ -1763,6 +1792,18 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
     if (text_bytes > ((size_t)1 << 40)) return fail(ctx, HPGV_ERR_UNSUPPORTED, "text buffer too large for one call");
     DeviceGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
+    // a window of text the bgzip decoder left with its tile records (hpgv_text_alias_tiles): tokenized on the decoder's tile grid,
+    // from the start of the tile the window begins in (grid_skip bytes in front of the window: the tail of the line before it)
+    hpgv_ctx::TextTiles TT = {nullptr, nullptr, nullptr, 0};
+    bool grid = false;
+    size_t grid_t0 = 0, grid_skip = 0;
+    if (ctx->tokenizer_tiles == 1 && ctx->decode_tiles && text_bytes > 0 && tiles_of_device_text(ctx, d_text, &TT)) {
+        const size_t a = (size_t)(d_text - TT.d_base), e = a + text_bytes;
+        if ((e - 1) / hpgv::TOK2_TILE < TT.n_tiles) {
+            grid = true; grid_t0 = a / hpgv::TOK2_TILE; grid_skip = a - grid_t0 * hpgv::TOK2_TILE;
+            d_text -= grid_skip; text_bytes += grid_skip;
+        }
+    }
     const size_t n_blocks = (text_bytes + hpgv::TOK_TILE - 1) / hpgv::TOK_TILE;
     if (n_blocks > 0x7FFFFFFFu) return fail(ctx, HPGV_ERR_UNSUPPORTED, "text buffer too large for one call");
     hpgv_ctx::TokScratch *ts = nullptr;
@@ -1825,19 +1866,29 @@ int hpgv_tokenize_dev(hpgv_ctx *ctx, const char *d_text, size_t text_bytes, int 
             return HPGV_OK;
         }
 #endif
-        if (n_tiles > 0) {
+        if (grid && n_tiles > 0) {
+            // the decoder's records serve every tile but the window's last, which is counted again up to the window's end
+            // (and the bytes in front of the window, for the number of lines that end there)
+            const size_t lt = n_tiles - 1;
+            hipLaunchKernelGGL(hpgv::k_tok_count2, dim3(1), dim3(256), 0, st, d_text + lt * hpgv::TOK2_TILE, text_bytes - lt * hpgv::TOK2_TILE, 1, agg);
+            if (grid_skip) hipLaunchKernelGGL(hpgv::k_tok_count2, dim3(1), dim3(256), 0, st, d_text, grid_skip, 1, agg + 1);
+            hipLaunchKernelGGL(hpgv::k_tok_scan2a_grid, dim3((unsigned)n_groups), dim3(hpgv::TOK_SCAN_THREADS), 0, st, (const hpgv::TokAgg2 *)TT.d_tiles, (long)grid_t0,
+                               (const hpgv::TokAgg *)agg, d_text, text_bytes, (int)n_tiles, pre, gtot);
+        } else if (n_tiles > 0) {
             hipLaunchKernelGGL(hpgv::k_tok_count2, dim3((unsigned)((n_tiles + hpgv::TOK2_COUNT_TILES - 1) / hpgv::TOK2_COUNT_TILES)), dim3(256), 0, st, d_text, text_bytes, (int)n_tiles, agg);
             hipLaunchKernelGGL(hpgv::k_tok_scan2a, dim3((unsigned)n_groups), dim3(hpgv::TOK_SCAN_THREADS), 0, st, (const hpgv::TokAgg *)agg, (int)n_tiles, pre, gtot);
         }
         hipLaunchKernelGGL(hpgv::k_tok_scan2b, dim3((unsigned)(n_groups > 0 ? n_groups : 1)), dim3(hpgv::TOK_SCAN_THREADS), 0, st, pre, (int)n_tiles, gtot, n_groups,
-                           d_text, text_bytes, d_n_lines, line_off, max_lines, redo_n);
+                           d_text, text_bytes, d_n_lines, line_off, max_lines, redo_n, grid_skip ? (const hpgv::TokAgg *)(agg + 1) : (const hpgv::TokAgg *)nullptr);
         if (n_tiles > 0 && max_lines > 0) {
             hipLaunchKernelGGL(hpgv::k_tok_parse2, dim3((unsigned)n_tiles), dim3(hpgv::TOK2_THREADS), 0, st, d_text, text_bytes, (const hpgv::TokPre *)pre,
-                               max_lines, n_samples, strict, d_gt, pitch, d_is_x, line_off, d_field_off, d_status, redo, redo_n);
+                               max_lines, n_samples, strict, d_gt, pitch, d_is_x, line_off, d_field_off, d_status, redo, redo_n, (int)grid_skip);
             // the lines whose FORMAT does not begin with GT (listed by the thread that read it): once more, line by line
             hipLaunchKernelGGL(hpgv::k_tok_parse_listed, dim3(redo_grid), dim3(256), 0, st, d_text, line_off,
                                (const int *)d_n_lines, max_lines, n_samples, strict, d_gt, pitch, d_is_x, d_field_off, d_status, (const int *)redo, (const int *)redo_n);
         }
+        if (grid_skip)                                               // positions counted from the first tile's start: back to the window's
+            hipLaunchKernelGGL(hpgv::k_tok_grid_finish, dim3((unsigned)((max_lines + 256) / 256)), dim3(256), 0, st, line_off, (const int *)d_n_lines, max_lines, (unsigned)grid_skip);
         HIPCHK(ctx, hipGetLastError());
         return HPGV_OK;
     }

@@ -9,9 +9,14 @@
 // advanced by multiplying with x^(32 (64 - i)) mod P, one conditional multiplication per bit of 64 - i with the constants
 // x^(32 * 2^b), and the 64 registers are XORed together.  The bytes in front of the first aligned dword (at most three) and
 // behind the last full 256-byte row are taken byte by byte.  Reflected polynomial 0xEDB88320, as zlib.
+//
+// Round 4: the same wave, which has just read its block's text, also leaves the TOKENIZER's tile records of that text
+// (k_bgzf_crc<true>: TokAgg2 per 2 KiB tile of the absolute grid over the decoded text, hpgv_text2_kernels.h) -- the second read
+// comes out of the L2, and the tokenizer's counting sweep over windows of this text is not run at all.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "hpgv_text2_kernels.h"
 
 namespace hpgv {
 
@@ -46,17 +51,52 @@ inline void crc_build_tables(uint32_t *tab) {
         for (uint32_t b = 0; b < 256; ++b) tab[CRC_W + 256 * j + b] = crc_multmodp(x2048, b << (8 * j));
 }
 
+// the tile records of block b's text [o, o + len): per tile of the absolute grid the half this block owns -- h[0] when the block
+// holds the tile's first byte, h[1] when it begins inside the tile.  A second block that begins inside the same tile (blocks
+// shorter than a tile) marks the tile TOK_AGG_COMPLEX: the tokenizer's scan counts such a tile again.  One wave.
+__device__ __forceinline__ void bgzf_block_agg(const char *__restrict__ text, size_t o, size_t len, TokAgg2 *__restrict__ agg2, long agg_tiles) {
+    if (len == 0) return;
+    const int lane = threadIdx.x & 63;
+    const size_t end = o + len;
+    for (size_t tile = o / TOK2_TILE; tile * TOK2_TILE < end; ++tile) {
+        if ((long)tile >= agg_tiles) break;
+        const size_t tb = tile * TOK2_TILE, lo = o > tb ? o : tb, hi = end < tb + TOK2_TILE ? end : tb + TOK2_TILE;
+        const TokAgg a = tok_wave_agg(text, tb, lo, hi);
+        if (lane == 0) {
+            if (tb >= o) {                                           // (the flags only ever by atomics: another block may be marking the tile)
+                agg2[tile].h[0].nl = a.nl; agg2[tile].h[0].tabs = a.tabs; agg2[tile].h[0].last_nl = a.last_nl;
+                atomicOr(&agg2[tile].h[0].pad, (int)TOK_AGG_WRITTEN);
+            } else {
+                // this block begins inside the tile: it owns h[1] -- unless a block before it did too
+                const int old = atomicOr(&agg2[tile].h[1].pad, (int)TOK_AGG_WRITTEN);
+                if (old & TOK_AGG_WRITTEN) atomicOr(&agg2[tile].h[0].pad, (int)TOK_AGG_COMPLEX);
+                else { agg2[tile].h[1].nl = a.nl; agg2[tile].h[1].tabs = a.tabs; agg2[tile].h[1].last_nl = a.last_nl; }
+            }
+        }
+    }
+}
+// text of block b that the decoder did not write (status != 0: the host decodes it and patches the text): its tiles are counted
+// again by the tokenizer
+__device__ __forceinline__ void bgzf_block_agg_void(size_t o, size_t len, TokAgg2 *__restrict__ agg2, long agg_tiles) {
+    if (len == 0) return;
+    const size_t t_lo = o / TOK2_TILE, t_hi = (o + len - 1) / TOK2_TILE;
+    for (size_t tile = t_lo + (threadIdx.x & 63); tile <= t_hi && (long)tile < agg_tiles; tile += 64) atomicOr(&agg2[tile].h[0].pad, (int)TOK_AGG_COMPLEX);
+}
+
+template <bool AGG>
 static __global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t *__restrict__ comp, const uint64_t *__restrict__ in_off,
                                                    const uint32_t *__restrict__ in_len, const uint64_t *__restrict__ out_off,
                                                    const uint32_t *__restrict__ out_len, int n_blocks,
                                                    const uint8_t *__restrict__ text, int32_t *__restrict__ status,
-                                                   const uint32_t *__restrict__ tab) {
+                                                   const uint32_t *__restrict__ tab, TokAgg2 *__restrict__ agg2, long agg_tiles) {
     __shared__ uint32_t s_tab[CRC_TAB_WORDS];
     for (int i = threadIdx.x; i < CRC_TAB_WORDS; i += 256) s_tab[i] = tab[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int b = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
-    if (b >= n_blocks || status[b] != 0) return;
+    if (b >= n_blocks) return;
+    if (status[b] != 0) { if constexpr (AGG) bgzf_block_agg_void((size_t)out_off[b], out_len[b], agg2, agg_tiles); return; }
+    if constexpr (AGG) bgzf_block_agg((const char *)text, (size_t)out_off[b], out_len[b], agg2, agg_tiles);
     const uint8_t *p = text + out_off[b];
     uint32_t L = out_len[b];
     const uint8_t *t = comp + in_off[b] + in_len[b];            // the block's trailer: CRC32, ISIZE

@@ -71,6 +71,16 @@ int hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t
 int hpgv_bgzf_verify_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
                          const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, const uint8_t *d_text,
                          int32_t *d_status, void *stream) {
+    return hpgv_bgzf_verify_tiles_dev(ctx, d_comp, d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_text, d_status, nullptr, 0, stream);
+}
+
+size_t hpgv_text_tiles_bytes(uint64_t text_bytes) { return (size_t)((text_bytes + hpgv::TOK2_TILE - 1) / hpgv::TOK2_TILE + 1) * sizeof(hpgv::TokAgg2); }
+
+// ... and, with d_tiles, the tokenizer's records of the decoded text (hpgv.h "hpgv_text_alias_tiles"): d_tiles holds
+// hpgv_text_tiles_bytes(text) bytes, ZEROED before the first block of the text is verified; n_tiles of them may be written
+int hpgv_bgzf_verify_tiles_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                               const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, const uint8_t *d_text,
+                               int32_t *d_status, void *d_tiles, uint64_t n_tiles, void *stream) {
     HPGV_ABI_TRY
     ctx = first_member(ctx);
     if (!ctx) return HPGV_ERR_INVALID;
@@ -88,8 +98,12 @@ int hpgv_bgzf_verify_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d
             HIPCHK(ctx, hipMemcpy(ctx->d_crc_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
     }
-    hipLaunchKernelGGL(hpgv::k_bgzf_crc, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_comp, d_in_off, d_in_len,
-                       d_out_off, d_out_len, n_blocks, d_text, d_status, (const uint32_t *)ctx->d_crc_tab);
+    if (d_tiles && n_tiles > 0)
+        hipLaunchKernelGGL(hpgv::k_bgzf_crc<true>, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_comp, d_in_off, d_in_len,
+                           d_out_off, d_out_len, n_blocks, d_text, d_status, (const uint32_t *)ctx->d_crc_tab, (hpgv::TokAgg2 *)d_tiles, (long)n_tiles);
+    else
+        hipLaunchKernelGGL(hpgv::k_bgzf_crc<false>, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_comp, d_in_off, d_in_len,
+                           d_out_off, d_out_len, n_blocks, d_text, d_status, (const uint32_t *)ctx->d_crc_tab, (hpgv::TokAgg2 *)nullptr, 0L);
     HIPCHK(ctx, hipGetLastError());
     return HPGV_OK;
     HPGV_ABI_CATCH(ctx)

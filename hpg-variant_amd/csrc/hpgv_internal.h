@@ -87,6 +87,8 @@ struct hpgv_ctx {
     long profile = 0;
     std::mutex alias_mu;
     std::vector<std::pair<const char *, const char *>> text_alias;   // host text buffer -> the same text already on the device
+    struct TextTiles { const char *d_text, *d_base; const void *d_tiles; uint64_t n_tiles; };
+    std::vector<TextTiles> text_tiles;                               // device windows whose text comes with the decoder's tile records (hpgv_text_alias_tiles)
     long scan_unroll = 4;
     long persistent = 0;       // 0: one wave per vpw consecutive rows; 1: persistent strided grid
     long blocks_per_cu = 8;
@@ -107,6 +109,7 @@ struct hpgv_ctx {
     long assoc_rows = 1;       // HPGV_ASSOC_ROWS=0: text batches counted one workgroup per row (what wider cohorts fall back to)
     long pinned_noncoherent = 0;   // HPGV_PINNED_NONCOHERENT=1: page-locked buffers allocated non-coherent
     long vmm_trace = 0;        // HPGV_VMM_TRACE=1: hpgv_dev_commit narrates its mappings on stderr
+    long decode_tiles = 1;     // HPGV_DECODE_TILES=0: windows of device-decoded text are tokenized with the counting sweep even when the decoder left its tile records
 #ifdef HPGV_ABLATION
     long stats_rows = 0, stats_bs = 0, stats_debug = 0;      // HPGV_STATS_ROWS / _BS / _DEBUG: band length, workgroup size, chosen form of k_stats_all2
     long fisher_lds = 0;       // HPGV_FISHER_LDS: unused LDS bytes per workgroup of the Fisher pass

@@ -242,9 +242,13 @@ static __global__ __launch_bounds__(TOK_SCAN_THREADS) void k_tok_scan2a(const To
 
 // the fold of the first `count` group totals onto the text's start, by the whole workgroup (the same value in every thread):
 // a thousand totals per round, a wave scan by shuffles and the 16 wave totals through LDS
-__device__ __forceinline__ TokState tok_fold_groups(const TokState *__restrict__ group_total, int count, int *w_lines, int *w_tabs, long long *w_ls) {
+__device__ __forceinline__ TokState tok_fold_groups(const TokState *__restrict__ group_total, int count, int *w_lines, int *w_tabs, long long *w_ls,
+                                                    const TokAgg *__restrict__ prefix = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    TokState c = {0, 0, 0};                                          // the text's start begins a line
+    // the text's start begins a line; on the decoder's grid the first tile begins `skip` bytes IN FRONT of the window, inside
+    // the lines before it: prefix->nl of them end there -- lines -nl .. -1, the first of which is taken to be past its FORMAT
+    // (nine TABs: what follows are sample columns).  Lines below 0 are kept nowhere.
+    TokState c = {prefix ? -prefix->nl : 0, prefix ? 9 : 0, 0};
     for (int g0 = 0; g0 < count; g0 += TOK_SCAN_THREADS) {
         TokState inc = {0, 0, -1};
         if (g0 + tid < count) inc = group_total[g0 + tid];
@@ -263,15 +267,15 @@ __device__ __forceinline__ TokState tok_fold_groups(const TokState *__restrict__
 static __global__ __launch_bounds__(TOK_SCAN_THREADS) void k_tok_scan2b(TokPre *__restrict__ pre, int n_tiles, TokState *__restrict__ group_total,
                                                                       int n_groups, const char *__restrict__ text, size_t n,
                                                                       int *__restrict__ n_lines, unsigned long long *__restrict__ line_off, int max_lines,
-                                                                      int *__restrict__ redo_n) {
+                                                                      int *__restrict__ redo_n, const TokAgg *__restrict__ prefix = nullptr) {
     // every workgroup folds the totals of the groups in front of its own (n_groups = n_tiles / 1024: 77 for 640 MB of text) and
     // fixes up its group; workgroup 0 folds them all for the line count (one thread doing this took 11 us per call)
     __shared__ int w_lines[TOK_SCAN_THREADS / 64], w_tabs[TOK_SCAN_THREADS / 64];
     __shared__ long long w_ls[TOK_SCAN_THREADS / 64];
     const int mine = (int)blockIdx.x < n_groups ? (int)blockIdx.x : n_groups;
-    const TokState base = tok_fold_groups(group_total, mine, w_lines, w_tabs, w_ls);
+    const TokState base = tok_fold_groups(group_total, mine, w_lines, w_tabs, w_ls, prefix);
     if (blockIdx.x == 0) {
-        const TokState all = tok_fold_groups(group_total, n_groups, w_lines, w_tabs, w_ls);
+        const TokState all = tok_fold_groups(group_total, n_groups, w_lines, w_tabs, w_ls, prefix);
         if (threadIdx.x == 0) {
             const int tail = (n > 0 && text[n - 1] != '\n') ? 1 : 0;      // unterminated last line
             *n_lines = all.lines + tail;
@@ -334,6 +338,9 @@ struct TokShared { int s_f[4], s_v[4], s_n[4], s_d[4], s_g[4]; unsigned long lon
 // tok_read of this thread's bytes.  Two workgroup barriers; the shared arrays may be used again right after the call.
 __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const size_t n, const size_t tile_base, const bool first_tile, const TokPre P,
                                                const TokThread &T, TokShared &S, const TokOut &O) {
+    // line indices below 0 exist on the decoder's tile grid only (k_tok_parse2 with skip > 0): the bytes of the window's first tile
+    // that lie in front of the window are the tail of the line before it, parsed as line -1 and kept nowhere
+#define TOK_LINE_OK(L) ((unsigned)(L) < (unsigned)max_lines)
     const uint32_t tabs = T.tabs, nls = T.nls;
     const int tid = threadIdx.x, lane = tid & 63, w = TOK_RFL(tid >> 6);
     const size_t base = tile_base + (size_t)tid * TOK2_TB;
@@ -453,7 +460,7 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
     //      d/d, d|d, ./. or .|.): tok_read has recognised the shape and encoded the eight genotypes that begin here; with GT first
     //      in FORMAT and all eight samples inside the row they leave as one 8-byte store.  Anything else walks.
     bool everyday = false;
-    if (T.pat && ntab >= 9 && gtpos == 0 && line < max_lines) {
+    if (T.pat && ntab >= 9 && gtpos == 0 && TOK_LINE_OK(line)) {
         const int s0 = ntab - 8;                                       // the sample whose field begins after the first TAB
         if (s0 + 8 <= n_samples) {
             __builtin_memcpy(gt + (size_t)line * pitch + s0, &T.codes, 8);
@@ -474,7 +481,7 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
         uint32_t th = tabs & ~ts;                                    // header TABs: they set field offsets (the ninth is both)
         if (ntab < 9) th |= ts & (0u - ts);
         // -- sample fields
-        if (line < max_lines && gt_seg0 >= 0) {
+        if (TOK_LINE_OK(line) && gt_seg0 >= 0) {
             uint8_t *row = gt + (size_t)line * pitch;
             for (uint32_t m = ts; m; m &= m - 1) {
                 const int j = __ffs((int)m) - 1;
@@ -505,6 +512,7 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
             if (nb == 0) { ntab_j = ntab + __popc(tabs & below) + 1; ls_j = ls; }
             else { const int last = 31 - __clz((int)nb); ntab_j = __popc(tabs & below & ~((2u << last) - 1u)) + 1; ls_j = base + last + 1; }
             if (line_j >= max_lines) break;                          // (the lines only grow)
+            if (line_j < 0) continue;                                // (the tail of the line before the window: nothing of it is kept)
             const size_t pos = base + j;
             if (ntab_j == 1 && is_x) { const size_t clen = pos - ls_j; is_x[line_j] = (clen == 0 || (clen == 1 && t[ls_j] == 'X')) ? 1 : 0; }
             if (field_off) field_off[(size_t)line_j * 10 + ntab_j] = (uint32_t)(pos + 1 - ls_j);
@@ -519,9 +527,9 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
             if (nb == 0) { ntab_j = ntab + __popc(tabs & below); ls_j = ls; g_j = gt_seg0; }
             else { const int last = 31 - __clz((int)nb); ntab_j = __popc(tabs & below & ~((2u << last) - 1u)); ls_j = base + last + 1; g_j = TOK_GT_UNDEF; }
             const size_t pos = base + j;
-            if (line_j < max_lines) tok_close_line(t, line_j, ntab_j, g_j, ls_j, pos, n_samples, gt, pitch, is_x, field_off, status);
-            if (line_j + 1 <= max_lines) line_off[line_j + 1] = pos + 1;
-            if (line_j + 1 < max_lines && pos + 1 < n && field_off) field_off[(size_t)(line_j + 1) * 10] = 0;
+            if (TOK_LINE_OK(line_j)) tok_close_line(t, line_j, ntab_j, g_j, ls_j, pos, n_samples, gt, pitch, is_x, field_off, status);
+            if (line_j + 1 >= 0 && line_j + 1 <= max_lines) line_off[line_j + 1] = pos + 1;      // (line_j = -1: where the window's first line begins)
+            if (TOK_LINE_OK(line_j + 1) && pos + 1 < n && field_off) field_off[(size_t)(line_j + 1) * 10] = 0;
         }
     }
     // the state behind the thread's last byte (all the unterminated last line needs)
@@ -534,7 +542,7 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
         const int j = __ffs((int)m) - 1;
         m &= m - 1;
         const size_t pos = base + j;
-        const bool ok_line = line < max_lines;
+        const bool ok_line = TOK_LINE_OK(line);
         if ((tabs >> j) & 1u) {
             ntab++;
             if (ntab == 1 && ok_line && is_x) {                     // CHROM ends here: assoc.c:94
@@ -553,26 +561,119 @@ __device__ __forceinline__ void tok_parse_tile(const char *__restrict__ t, const
         } else {                                                     // newline: the line ends at pos
             if (ok_line) tok_close_line(t, line, ntab, gtpos, ls, pos, n_samples, gt, pitch, is_x, field_off, status);
             line++; ntab = 0; ls = pos + 1; gtpos = TOK_GT_UNDEF;
-            if (line <= max_lines) line_off[line] = pos + 1;
-            if (line < max_lines && pos + 1 < n && field_off) field_off[(size_t)line * 10] = 0;
+            if (line >= 0 && line <= max_lines) line_off[line] = pos + 1;
+            if (TOK_LINE_OK(line) && pos + 1 < n && field_off) field_off[(size_t)line * 10] = 0;
         }
     }
     // the unterminated last line ends at n: closed by the thread that holds the text's last byte
-    if (n > 0 && base <= n - 1 && n - 1 < base + TOK2_TB && t[n - 1] != '\n' && line < max_lines)
+    if (n > 0 && base <= n - 1 && n - 1 < base + TOK2_TB && t[n - 1] != '\n' && TOK_LINE_OK(line))
         tok_close_line(t, line, ntab, gtpos, ls, n, n_samples, gt, pitch, is_x, field_off, status);
+#undef TOK_LINE_OK
 }
 
 static __global__ __launch_bounds__(TOK2_THREADS) void k_tok_parse2(const char *__restrict__ text, size_t n, const TokPre *__restrict__ pre,
                                                     int max_lines, int n_samples, int strict, uint8_t *__restrict__ gt, size_t pitch,
                                                     uint8_t *__restrict__ is_x, unsigned long long *__restrict__ line_off,
                                                     uint32_t *__restrict__ field_off, int *__restrict__ status,
-                                                    int *__restrict__ redo, int *__restrict__ redo_n /* the lines to parse again line by line */) {
+                                                    int *__restrict__ redo, int *__restrict__ redo_n /* the lines to parse again line by line */,
+                                                    int skip = 0 /* the decoder's grid: bytes of the first tile in front of the window */) {
     __shared__ TokShared S;
     const size_t tile_base = (size_t)blockIdx.x * TOK2_TILE;
     TokThread T;
     tok_read(text, tile_base + (size_t)threadIdx.x * TOK2_TB, n, T);
     const TokOut O = {max_lines, n_samples, strict, gt, pitch, is_x, line_off, field_off, status, redo, redo_n};
-    tok_parse_tile(text, n, tile_base, blockIdx.x == 0, pre[blockIdx.x], T, S, O);
+    tok_parse_tile(text, n, tile_base, blockIdx.x == 0 && skip == 0, pre[blockIdx.x], T, S, O);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Windows of text the bgzip decoder left on the device (round 4): the counting sweep is NOT run.  The CRC kernel of the decoder
+// (hpgv_crc_kernels.h, which reads every decoded byte anyway) has left, per 2 KiB tile of an ABSOLUTE grid over the decoded
+// text, the tile's record in two halves: TokAgg2.h[0] from the block that holds the tile's first byte, h[1] from the block that
+// follows it inside the tile (BGZF blocks are 65 280 bytes: their seams fall inside tiles).  A window begins at a line start,
+// anywhere: its first tile is taken WHOLE -- the `skip` bytes in front of the window are the ends of the lines before it, which the
+// parse walks as lines -k .. -1 and keeps nowhere (k = the newlines among them: one more small count) --, its last tile is counted
+// again up to the window's end (one workgroup).  Everything else -- the scan, the parse -- is the two-sweep form's, on
+// positions that count from the first tile's start; k_tok_grid_finish moves line_off to the window's start at the end.
+// A tile that more than two blocks touch, or that holds text the decoder did not write (a block handed back to the host), is
+// marked (TOK_AGG_COMPLEX) and counted again by the scan's thread.
+struct TokAgg2 { TokAgg h[2]; };                                     // TokAgg.last_nl holds offset + 1 here (0 = none: zeroed memory is "nothing yet"); .pad: flags
+enum { TOK_AGG_WRITTEN = 1, TOK_AGG_COMPLEX = 2 };
+
+// lane's view of its 32 bytes of a tile, clipped to [lo, hi): newlines, the TABs behind the last one (all when none), its bit
+__device__ __forceinline__ void tok_count_thread_clip(const char *__restrict__ t, size_t base, size_t lo, size_t hi, int *nl, int *tabs_after, int *last_bit) {
+    if (base >= lo && base + TOK2_TB <= hi) { tok_count_thread(t, base, hi, nl, tabs_after, last_bit); return; }
+    uint32_t tabs = 0, nls = 0;
+    for (int j = 0; j < TOK2_TB; ++j)
+        if (base + j >= lo && base + j < hi) { const char c = t[base + j]; if (c == '\t') tabs |= 1u << j; else if (c == '\n') nls |= 1u << j; }
+    *nl = __popc(nls);
+    *last_bit = *nl ? 31 - __clz((int)nls) : -1;
+    *tabs_after = *nl ? tok_tabs_after(tabs, *last_bit) : __popc(tabs);
+}
+
+// ONE WAVE: the record of the bytes [lo, hi) of the tile that begins at tile_base (every lane returns it; last_nl = offset + 1)
+__device__ __forceinline__ TokAgg tok_wave_agg(const char *__restrict__ t, size_t tile_base, size_t lo, size_t hi) {
+    const int lane = threadIdx.x & 63;
+    int nl, tabs_after, last_bit;
+    tok_count_thread_clip(t, tile_base + (size_t)lane * TOK2_TB, lo, hi, &nl, &tabs_after, &last_bit);
+    const unsigned long long has = __ballot(nl != 0);
+    const int tlast = has ? 63 - __clzll(has) : -1;
+    int c = nl, mine = lane > tlast ? tabs_after : (lane == tlast ? tabs_after : 0);       // (a lane behind the last newline holds none: all its TABs)
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off); mine += __shfl_xor(mine, off); }
+    const int lb = __shfl(last_bit, tlast < 0 ? 0 : tlast);
+    TokAgg a;
+    a.nl = c; a.tabs = mine; a.last_nl = tlast < 0 ? 0 : tlast * TOK2_TB + lb + 1; a.pad = TOK_AGG_WRITTEN;
+    return a;
+}
+
+// as k_tok_scan2a, the tiles' records taken from the decoder's grid: tile i of the window = grid tile t0 + i; the last tile's
+// record comes from `last` (counted again up to the window's end)
+static __global__ __launch_bounds__(TOK_SCAN_THREADS) void k_tok_scan2a_grid(const TokAgg2 *__restrict__ agg2, long t0, const TokAgg *__restrict__ last,
+                                                                           const char *__restrict__ text /* from the first tile's start */, size_t n,
+                                                                           int n_tiles, TokPre *__restrict__ pre, TokState *__restrict__ group_total) {
+    __shared__ int w_lines[16], w_tabs[16];
+    __shared__ long long w_ls[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = blockIdx.x * TOK_SCAN_THREADS + tid;
+    TokState me = {0, 0, -1};
+    if (i < n_tiles) {
+        TokAgg a;
+        if (i == n_tiles - 1) { a = last[0]; a.last_nl += 1; }      // (k_tok_count2 writes the offset itself, -1 = none)
+        else {
+            const TokAgg2 r = agg2[t0 + i];
+            if ((r.h[0].pad | r.h[1].pad) & TOK_AGG_COMPLEX) {       // rare: counted again, byte by byte
+                a.nl = 0; a.tabs = 0; a.last_nl = 0;
+                const size_t b0 = (size_t)i * TOK2_TILE;
+                for (int j = 0; j < TOK2_TILE && b0 + j < n; ++j) {
+                    const char ch = text[b0 + j];
+                    if (ch == '\n') { a.nl++; a.tabs = 0; a.last_nl = j + 1; } else if (ch == '\t') a.tabs++;
+                }
+            } else if (r.h[1].nl > 0) { a.nl = r.h[0].nl + r.h[1].nl; a.tabs = r.h[1].tabs; a.last_nl = r.h[1].last_nl; }
+            else { a.nl = r.h[0].nl; a.tabs = r.h[0].tabs + r.h[1].tabs; a.last_nl = r.h[0].last_nl; }
+        }
+        me.lines = a.nl; me.tabs = a.tabs; me.ls = a.last_nl > 0 ? (long long)i * TOK2_TILE + a.last_nl : -1;
+    }
+    TokState inc = me;
+    for (int off = 1; off < 64; off <<= 1) {
+        TokState o; o.lines = __shfl_up(inc.lines, off); o.tabs = __shfl_up(inc.tabs, off); o.ls = __shfl_up(inc.ls, off);
+        if (lane >= off) inc = tok_fold(o, inc);
+    }
+    if (lane == 63) { w_lines[w] = inc.lines; w_tabs[w] = inc.tabs; w_ls[w] = inc.ls; }
+    TokState exc; exc.lines = __shfl_up(inc.lines, 1); exc.tabs = __shfl_up(inc.tabs, 1); exc.ls = __shfl_up(inc.ls, 1);
+    if (lane == 0) { exc.lines = 0; exc.tabs = 0; exc.ls = -1; }
+    __syncthreads();
+    TokState before = {0, 0, -1};
+    for (int k = 0; k < w; ++k) { TokState o = {w_lines[k], w_tabs[k], w_ls[k]}; before = tok_fold(before, o); }
+    const TokState st = tok_fold(before, exc);
+    if (i < n_tiles) { TokPre p; p.lines = st.lines; p.tabs = st.tabs; p.line_start = (unsigned long long)st.ls; pre[i] = p; }
+    if (tid == TOK_SCAN_THREADS - 1) group_total[blockIdx.x] = tok_fold(st, me);
+}
+
+// line_off counts from the first tile's start: moved to the window's start (skip bytes further on)
+static __global__ void k_tok_grid_finish(unsigned long long *__restrict__ line_off, const int *__restrict__ n_lines, int max_lines, unsigned skip) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = *n_lines < max_lines ? *n_lines : max_lines;
+    if (i <= n) line_off[i] -= skip;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -109,6 +109,8 @@ const char *hpgv_last_error(const hpgv_ctx *ctx);
  *                             k_assoc_rows takes                                                          (default 1)
  *   HPGV_PINNED_NONCOHERENT=1 hpgv_host_alloc asks for non-coherent page-locked memory                   (default 0)
  *   HPGV_VMM_TRACE=1          hpgv_dev_commit narrates its mappings on stderr                             (default 0)
+ *   HPGV_DECODE_TILES=0       windows of text the bgzip decoder left with its tile records (hpgv_text_alias_tiles) are
+ *                             tokenized with the counting sweep all the same (A/B of that short cut)     (default 1)
  *   HPGV_RCCL_LIB=<path>      librccl to load first (then the librccl beside the HIP runtime this library is bound to,
  *                             then librccl.so.1, librccl.so, /opt/rocm/lib/...)
  * (libhpgv_host.so has a table of its own: include/hpgv_host.h "Environment".) */
@@ -461,6 +463,13 @@ int  hpgv_mendel(hpgv_ctx *ctx, const uint8_t *gt, size_t pitch, int n_variants,
  * line when it has fewer than ten fields -- back to back; line_off[i] is the offset of line i's head in host_text, field_off
  * stays relative to the line start.  d_text = NULL removes the entry. */
 int  hpgv_text_alias(hpgv_ctx *ctx, const char *host_text, const char *d_text);
+/* ... and d_text is a WINDOW of a text the bgzip decoder left on the device together with the tokenizer's tile records
+ * (hpgv_bgzf_verify_tiles_dev): d_text_base = where that text begins (d_text lies text-bytes inside it and begins a line),
+ * d_tiles its records, n_tiles how many of them are valid.  The *_text entry points then tokenize the window WITHOUT their
+ * counting sweep over it -- the text is read once (the window's last tile is counted again up to the window's end; a window
+ * that reaches beyond the valid records is tokenized the ordinary way).  Same results, bit for bit. */
+int  hpgv_text_alias_tiles(hpgv_ctx *ctx, const char *host_text, const char *d_text, const char *d_text_base,
+                           const void *d_tiles, uint64_t n_tiles);
 int  hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
                              const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, uint8_t *d_text,
                              int32_t *d_status, void *stream);
@@ -472,6 +481,16 @@ int  hpgv_inflate_blocks_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_
 int  hpgv_bgzf_verify_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
                           const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, const uint8_t *d_text,
                           int32_t *d_status, void *stream);
+/* The same check, and -- the wave that has just read a block's text being the cheapest place to do it -- the VCF tokenizer's
+ * records of that text: per 2 KiB tile of the decoded text (tile k = bytes [2048 k, 2048 k + 2048) from d_text on) its newline
+ * count, the TABs behind its last newline and where that newline is, which is all the tokenizer's first sweep computes.
+ * d_tiles: hpgv_text_tiles_bytes(text bytes) bytes of device memory, ZEROED before the first call for a text; n_tiles: how
+ * many records it may write (blocks whose text lies beyond are only checked).  Blocks the decoder refused (d_status != 0
+ * on entry) mark their tiles "count again".  See hpgv_text_alias_tiles. */
+size_t hpgv_text_tiles_bytes(uint64_t text_bytes);
+int  hpgv_bgzf_verify_tiles_dev(hpgv_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                                const uint64_t *d_out_off, const uint32_t *d_out_len, int n_blocks, const uint8_t *d_text,
+                                int32_t *d_status, void *d_tiles, uint64_t n_tiles, void *stream);
 /* The rows of those tables from the compressed bytes of a bgzip file on the device (bgzf.c of htslib writes the blocks the
  * reference reads with --compression bgzip, shared_options.c:60-61): the blocks that form a chain from byte `lo` (a block
  * start; 0 at first) and end at or before `hi` (bytes [0, hi) are on the device), at most max_rows of them, written from

@@ -1,5 +1,6 @@
 """GPU text staging (VCF data lines -> HPGV8 on the device)
 against the oracle's TAB-split + get_alleles tokenizer."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -685,3 +686,84 @@ def test_assoc_text_rows_kernel_on_random_widths():
     for _ in range(int(os.environ.get("HPGV_SOAK_SHAPES", "5"))):
         n_samples = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(300, 5000)), int(rng.integers(5000, 34000)), 16 * int(rng.integers(1, 2100))]))
         test_assoc_text_rows_kernel_equals_the_per_row_kernel(n_samples)
+
+
+@pytest.mark.parametrize("n_samples,block_bytes", [(200, [65280]), (2504, [65280]), (37, [65280, 1000, 500, 700, 3000, 65280, 10]), (900, [4096, 65280, 2047, 2048, 2049])])
+def test_windows_of_decoded_text_tokenized_from_the_decoders_tile_records(n_samples, block_bytes):
+    """The bgzip decoder's CRC kernel leaves the tokenizer's tile records of the text it checks (hpgv_bgzf_verify_tiles_dev); windows of
+    that text -- starting at any line, ending at any line -- are then tokenized WITHOUT the counting sweep (hpgv_text_alias_tiles).
+    Same outputs, bit for bit, as the ordinary two-sweep call on the same window, and as the oracle: blocks of the size bgzip writes
+    (seams inside tiles), blocks shorter than a tile (several seams in one tile: counted again), a block the decoder refused (its
+    text patched afterwards: counted again)."""
+    import zlib
+    rng = np.random.default_rng(n_samples)
+    fmts = ["GT", "GT:DP", "DP:GT", "GT"]
+    lines = [_line(rng, n_samples, fmts[i % 4], ["1", "X", "7"][i % 3], int(rng.integers(3, 300))) for i in range(max(40, 600_000 // (4 * n_samples + 60)))]
+    text = ("\n".join(lines) + "\n").encode()
+    raws, pos, k = [], 0, 0
+    while pos < len(text):
+        n = block_bytes[k % len(block_bytes)]; k += 1
+        raws.append(text[pos: pos + n]); pos += n
+    comps = []
+    for r in raws:
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comps.append(co.compress(r) + co.flush() + zlib.crc32(r).to_bytes(4, "little") + len(r).to_bytes(4, "little"))      # payload + the BGZF trailer
+    refused = len(raws) // 3
+    comps[refused] = bytes([comps[refused][0] | 0x06]) + comps[refused][1:]          # block type 3: the decoder refuses it
+    n = len(raws)
+    in_len = np.array([len(c) - 8 for c in comps], np.uint32); out_len = np.array([len(r) for r in raws], np.uint32)
+    in_off = np.concatenate([[0], np.cumsum([len(c) for c in comps[:-1]], dtype=np.uint64)]).astype(np.uint64)
+    out_off = np.concatenate([[0], np.cumsum(out_len[:-1], dtype=np.uint64)]).astype(np.uint64)
+    cbytes = np.frombuffer(b"".join(comps) + b"\0" * 16, np.uint8)
+    total = len(text)
+    e = hpgv.Engine(0)
+    d_comp, d_text = e.alloc(len(cbytes)), e.alloc(total + 64)
+    d_io, d_il, d_oo, d_ol, d_st = e.alloc(8 * n), e.alloc(4 * n), e.alloc(8 * n), e.alloc(4 * n), e.alloc(4 * n)
+    for d, a in ((d_comp, cbytes), (d_io, in_off), (d_il, in_len), (d_oo, out_off), (d_ol, out_len)):
+        e.h2d(d, a)
+    tiles_bytes = int(e.L.hpgv_text_tiles_bytes(total))
+    n_tiles = tiles_bytes // 32 - 1
+    d_tiles = e.alloc(tiles_bytes)
+    e.h2d(d_tiles, np.zeros(tiles_bytes, np.uint8))
+    e.inflate_blocks(d_comp, d_io, d_il, d_oo, d_ol, n, d_text, d_st)
+    e.bgzf_verify_tiles(d_comp, d_io, d_il, d_oo, d_ol, n, d_text, d_st, d_tiles, n_tiles)
+    e.sync()
+    status = e.d2h(d_st, (n,), np.int32)
+    assert status[refused] != 0 and (np.delete(status, refused) == 0).all()
+    # the host decodes the refused block and patches the text, as the file runner does
+    e.h2d(C.c_void_p(d_text.value + int(out_off[refused])), np.frombuffer(raws[refused], np.uint8))
+    assert e.d2h(d_text, (total,), np.uint8).tobytes() == text
+    starts = [0] + [i + 1 for i, ch in enumerate(text) if ch == 10]
+    ends = starts[1:]
+    picks = [(0, len(ends) - 1), (1, len(ends) - 1), (0, 0), (len(ends) // 2, len(ends) // 2)]
+    picks += [tuple(sorted(int(x) for x in rng.integers(0, len(ends), 2))) for _ in range(12)]
+    max_lines = len(ends) + 2
+    pitch = (n_samples + 15) // 16 * 16
+    d_nl, d_lo, d_fo = e.alloc(16), e.alloc(8 * (max_lines + 2)), e.alloc(40 * max_lines + 16)
+    d_gt, d_x, d_stt = e.alloc(max_lines * pitch + 16), e.alloc(max_lines + 16), e.alloc(4 * max_lines + 16)
+    host_key = C.create_string_buffer(16)                            # the alias table is keyed by a host address: any will do
+    L = e.L
+    for first, last in picks:
+        a, b = starts[first], ends[last]
+        win = C.c_void_p(d_text.value + a)
+        out = {}
+        for mode in ("tiles", "plain"):
+            if mode == "tiles":
+                assert L.hpgv_text_alias_tiles(e.h, host_key, win, d_text, d_tiles, n_tiles) == 0
+            else:
+                assert L.hpgv_text_alias(e.h, host_key, None) == 0
+            for d, nb in ((d_gt, max_lines * pitch), (d_x, max_lines), (d_stt, 4 * max_lines), (d_fo, 40 * max_lines), (d_lo, 8 * (max_lines + 2))):
+                e.h2d(d, np.full(nb, 0xA5, np.uint8))
+            e._chk(L.hpgv_tokenize_dev(e.h, win, b - a, n_samples, 1, max_lines, d_nl, d_lo, d_fo, d_gt, pitch, d_x, d_stt, None))
+            e.sync()
+            nl = int(e.d2h(d_nl, (1,), np.int32)[0])
+            out[mode] = dict(n=nl, gt=e.d2h(d_gt, (nl, pitch), np.uint8)[:, :n_samples], x=e.d2h(d_x, (nl,), np.uint8), st=e.d2h(d_stt, (nl,), np.int32),
+                             lo=e.d2h(d_lo, (nl + 1,), np.uint64), fo=e.d2h(d_fo, (nl, 10), np.uint32))
+        assert L.hpgv_text_alias(e.h, host_key, None) == 0
+        assert out["tiles"]["n"] == out["plain"]["n"] == last - first + 1, (first, last)
+        for kk in ("gt", "x", "st", "lo", "fo"):
+            assert np.array_equal(out["tiles"][kk], out["plain"][kk]), (first, last, kk)
+        tok = orc.tokenize(text[a:b].decode(), n_samples, True)
+        assert np.array_equal(out["tiles"]["gt"], tok["gt"]) and np.array_equal(out["tiles"]["st"], tok["status"])
+        assert out["tiles"]["lo"].tolist() == [s - a for s in starts[first: last + 2]]
+    e.close()
