@@ -41,7 +41,7 @@ SYMBOLS = [
     "hpgv_last_kernel_ms", "hpgv_assoc", "hpgv_tdt", "hpgv_stats", "hpgv_stats_ex", "hpgv_stats_groups",
     "hpgv_epi_dataset_text", "hpgv_set_text_filters", "hpgv_stats_text", "hpgv_stats_text_groups", "hpgv_epi_set_dataset", "hpgv_epi_set_folds", "hpgv_epi_set_fold_masks", "hpgv_epi_counts",
     "hpgv_epi_counts_all_folds", "hpgv_epi_scan_pairs", "hpgv_epi_rank_pairs", "hpgv_epi_rank_pairs_rows", "hpgv_epi_scan_triples", "hpgv_epi_rank_triples", "hpgv_epi_eval_combs", "hpgv_epi_rank_order", "hpgv_epi_rank_order_rows", "hpgv_read_probe",
-    "hpgv_group_comm_init", "hpgv_group_comm_ranks", "hpgv_group_rccl_probe", "hpgv_group_shard", "hpgv_group_assoc", "hpgv_group_tdt", "hpgv_group_stats", "hpgv_group_sync", "hpgv_group_epi_share", "hpgv_group_epi_rank", "hpgv_epi_rank_triples_rows", "hpgv_text_alias_tiles", "hpgv_text_tiles_bytes", "hpgv_bgzf_verify_tiles_dev",
+    "hpgv_group_comm_init", "hpgv_group_comm_ranks", "hpgv_group_rccl_probe", "hpgv_group_shard", "hpgv_group_assoc", "hpgv_group_tdt", "hpgv_group_stats", "hpgv_group_sync", "hpgv_group_epi_share", "hpgv_group_epi_rank", "hpgv_epi_rank_triples_rows", "hpgv_text_alias_tiles", "hpgv_text_tiles_bytes", "hpgv_bgzf_verify_tiles_dev", "hpgv_memset_dev",
 ]
 
 

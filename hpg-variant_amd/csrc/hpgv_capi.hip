@@ -830,6 +830,14 @@ int hpgv_stream_destroy(hpgv_ctx *ctx, void *stream) {
 // "the text at host_text is already on the device at d_text": the *_text entry points then tokenize d_text in place
 // instead of copying host_text over (d_text = NULL takes the entry away).  For readers that produce the text on the
 // device (hpgv_inflate_blocks_dev) and keep a host copy for the result writers.
+int hpgv_memset_dev(hpgv_ctx *ctx, void *dptr, int byte_value, size_t bytes, void *stream) {
+    ctx = first_member(ctx);
+    if (!ctx || (bytes > 0 && !dptr)) return HPGV_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    if (stream) HIPCHK(ctx, hipMemsetAsync(dptr, byte_value, bytes, (hipStream_t)stream));
+    else HIPCHK(ctx, hipMemset(dptr, byte_value, bytes));
+    return HPGV_OK;
+}
 int hpgv_text_alias(hpgv_ctx *ctx, const char *host_text, const char *d_text) {
     ctx = first_member(ctx);
     if (!ctx || !host_text) return HPGV_ERR_INVALID;

@@ -603,27 +603,82 @@ enum { TOK_AGG_WRITTEN = 1, TOK_AGG_COMPLEX = 2 };
 __device__ __forceinline__ void tok_count_thread_clip(const char *__restrict__ t, size_t base, size_t lo, size_t hi, int *nl, int *tabs_after, int *last_bit) {
     if (base >= lo && base + TOK2_TB <= hi) { tok_count_thread(t, base, hi, nl, tabs_after, last_bit); return; }
     uint32_t tabs = 0, nls = 0;
-    for (int j = 0; j < TOK2_TB; ++j)
-        if (base + j >= lo && base + j < hi) { const char c = t[base + j]; if (c == '\t') tabs |= 1u << j; else if (c == '\n') nls |= 1u << j; }
+    if (((uintptr_t)(t + base) & 3u) == 0 && hi > lo) {
+        // eight aligned dwords, all in flight at once: one that holds no byte of [lo, hi) is replaced by one that does (an aligned
+        // dword with a byte of the text in it lies inside the text's pages), and the bits outside the range are dropped
+        const size_t safe = ((size_t)(uintptr_t)(t + lo) & ~(size_t)3) - (size_t)(uintptr_t)t;
+        uint32_t d[TOK2_TB / 4];
+        #pragma unroll
+        for (int k = 0; k < TOK2_TB / 4; ++k) {
+            const size_t a = base + 4 * (size_t)k;
+            d[k] = *reinterpret_cast<const uint32_t *>(t + (a < hi && a + 4 > lo ? a : safe));
+        }
+        #pragma unroll
+        for (int k = 0; k < TOK2_TB / 8; ++k) {
+            const uint64_t w = ((uint64_t)d[2 * k + 1] << 32) | d[2 * k];
+            tabs |= tok_byte_mask(w, '\t') << (8 * k); nls |= tok_byte_mask(w, '\n') << (8 * k);
+        }
+        const size_t first = lo > base ? (lo - base < (size_t)TOK2_TB ? lo - base : (size_t)TOK2_TB) : 0;
+        const size_t last = hi > base ? (hi - base < (size_t)TOK2_TB ? hi - base : (size_t)TOK2_TB) : 0;
+        const uint32_t m = last > first ? (uint32_t)(((1ull << last) - 1ull) & ~((1ull << first) - 1ull)) : 0u;
+        tabs &= m; nls &= m;
+    } else
+        for (int j = 0; j < TOK2_TB; ++j)
+            if (base + j >= lo && base + j < hi) { const char c = t[base + j]; if (c == '\t') tabs |= 1u << j; else if (c == '\n') nls |= 1u << j; }
     *nl = __popc(nls);
     *last_bit = *nl ? 31 - __clz((int)nls) : -1;
     *tabs_after = *nl ? tok_tabs_after(tabs, *last_bit) : __popc(tabs);
 }
 
-// ONE WAVE: the record of the bytes [lo, hi) of the tile that begins at tile_base (every lane returns it; last_nl = offset + 1)
+// a lane's 32 bytes already in registers (eight dwords, all inside the text): newlines, the TABs behind the last one (all when
+// none), its bit -- tok_count_thread's fast path without its load
+__device__ __forceinline__ void tok_count_regs(const uint32_t (&d)[TOK2_TB / 4], int *nl, int *tabs_after, int *last_bit) {
+    int ct = 0; uint32_t any = 0;
+    #pragma unroll
+    for (int k = 0; k < TOK2_TB / 4; ++k) { ct += __popc(tok_eq_flags(d[k], 0x09090909u)); any |= tok_eq_flags(d[k], 0x0A0A0A0Au); }
+    if (any == 0) { *nl = 0; *tabs_after = ct; *last_bit = -1; return; }
+    uint32_t tabs = 0, nls = 0;
+    #pragma unroll
+    for (int k = 0; k < TOK2_TB / 8; ++k) {
+        const uint64_t w = ((uint64_t)d[2 * k + 1] << 32) | d[2 * k];
+        tabs |= tok_byte_mask(w, '\t') << (8 * k); nls |= tok_byte_mask(w, '\n') << (8 * k);
+    }
+    *nl = __popc(nls);
+    *last_bit = 31 - __clz((int)nls);
+    *tabs_after = tok_tabs_after(tabs, *last_bit);
+}
+
+// ONE WAVE: the lanes' counts of a tile folded into its record, which LANE 63 returns (last_nl = offset + 1, 0 = none).  A tile
+// without a newline (nineteen in twenty at 10 k samples) is one DPP sum of the TABs.
+__device__ __forceinline__ TokAgg tok_wave_fold(int nl, int tabs_after, int last_bit) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long has = __ballot(nl != 0);
+    TokAgg a;
+    a.pad = TOK_AGG_WRITTEN;
+    if (has == 0) {
+        int v = tabs_after;
+#define TOK_STEP_F0(CTRL, ROWS) v += tok_dpp<CTRL, ROWS>(0, v);
+        TOK_SCAN_STEPS(TOK_STEP_F0)
+#undef TOK_STEP_F0
+        a.nl = 0; a.tabs = v; a.last_nl = 0;
+        return a;
+    }
+    const int tlast = 63 - __clzll(has);
+    int c = nl, mine = lane >= tlast ? tabs_after : 0;               // (a lane behind the last newline holds none: all its TABs)
+#define TOK_STEP_F1(CTRL, ROWS) { c += tok_dpp<CTRL, ROWS>(0, c); mine += tok_dpp<CTRL, ROWS>(0, mine); }
+    TOK_SCAN_STEPS(TOK_STEP_F1)
+#undef TOK_STEP_F1
+    const int lb = __builtin_amdgcn_readlane(last_bit, tlast);
+    a.nl = c; a.tabs = mine; a.last_nl = tlast * TOK2_TB + lb + 1;
+    return a;
+}
+
+// ONE WAVE: the record of the bytes [lo, hi) of the tile that begins at tile_base (lane 63 returns it)
 __device__ __forceinline__ TokAgg tok_wave_agg(const char *__restrict__ t, size_t tile_base, size_t lo, size_t hi) {
     const int lane = threadIdx.x & 63;
     int nl, tabs_after, last_bit;
     tok_count_thread_clip(t, tile_base + (size_t)lane * TOK2_TB, lo, hi, &nl, &tabs_after, &last_bit);
-    const unsigned long long has = __ballot(nl != 0);
-    const int tlast = has ? 63 - __clzll(has) : -1;
-    int c = nl, mine = lane > tlast ? tabs_after : (lane == tlast ? tabs_after : 0);       // (a lane behind the last newline holds none: all its TABs)
-    #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off); mine += __shfl_xor(mine, off); }
-    const int lb = __shfl(last_bit, tlast < 0 ? 0 : tlast);
-    TokAgg a;
-    a.nl = c; a.tabs = mine; a.last_nl = tlast < 0 ? 0 : tlast * TOK2_TB + lb + 1; a.pad = TOK_AGG_WRITTEN;
-    return a;
+    return tok_wave_fold(nl, tabs_after, last_bit);
 }
 
 // as k_tok_scan2a, the tiles' records taken from the decoder's grid: tile i of the window = grid tile t0 + i; the last tile's

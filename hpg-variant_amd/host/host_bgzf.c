@@ -7,6 +7,19 @@
  * (hpgv_bgzf_verify_dev); a block it rejects comes here like any block the device decoder refused, and fails the run. */
 char g_input_err[192];
 static int bgzf_verify_on(void) { return g_env.bgzf_verify != 0; }
+/* the tokenizer's tile records of a text of about `bytes` bytes that the device is going to decode and check: zeroed device
+ * memory (hpgv.h "hpgv_bgzf_verify_tiles_dev").  Not having them only means the windows are tokenized the ordinary way. */
+static void tiles_alloc(source_t *s, size_t bytes) {
+    s->d_tiles = NULL; s->n_tiles = 0; s->d_tiles_cap = 0;
+    if (!bgzf_verify_on() || g_env.no_decode_tiles) return;
+    const size_t nb = hpgv_text_tiles_bytes((uint64_t)bytes);
+    size_t cap = 0;
+    void *p = dev_tiles_get(nb, &cap);
+    if (!p) return;
+    if (hpgv_memset_dev(CTX, p, 0, nb, NULL) != HPGV_OK) { dev_tiles_put(p, cap); return; }
+    s->d_tiles = p; s->n_tiles = nb / 32 - 1; s->d_tiles_cap = cap;
+}
+static void tiles_free(source_t *s) { if (s->d_tiles) { dev_tiles_put(s->d_tiles, s->d_tiles_cap); s->d_tiles = NULL; s->n_tiles = 0; s->d_tiles_cap = 0; } }
 /* in[clen .. clen + 4) is the block's CRC-32 (the BGZF trailer follows the payload) */
 static int block_crc_bad(const unsigned char *in, size_t clen, const unsigned char *out, size_t isize) {
     const unsigned char *t = in + clen;
@@ -218,9 +231,9 @@ static void *bgzf_gpu_stager(void *v) {
                                                (const uint64_t *)(t + nb * 8) + first, (const uint32_t *)(t + nb * 20) + first, (int)(next - first),
                                                (uint8_t *)s->d_text, (int32_t *)s->d_status + first, cs[q]) == HPGV_OK;
             if (bgzf_verify_on())                         /* the blocks' CRC-32, on the device behind the decoder */
-                ok = ok && hpgv_bgzf_verify_dev(CTX, (const uint8_t *)s->d_comp, (const uint64_t *)t + first, (const uint32_t *)(t + nb * 16) + first,
-                                                (const uint64_t *)(t + nb * 8) + first, (const uint32_t *)(t + nb * 20) + first, (int)(next - first),
-                                                (const uint8_t *)s->d_text, (int32_t *)s->d_status + first, cs[q]) == HPGV_OK;
+                ok = ok && hpgv_bgzf_verify_tiles_dev(CTX, (const uint8_t *)s->d_comp, (const uint64_t *)t + first, (const uint32_t *)(t + nb * 16) + first,
+                                                      (const uint64_t *)(t + nb * 8) + first, (const uint32_t *)(t + nb * 20) + first, (int)(next - first),
+                                                      (const uint8_t *)s->d_text, (int32_t *)s->d_status + first, s->d_tiles, (uint64_t)s->n_tiles, cs[q]) == HPGV_OK;
             q_hi[q] = next; qn++;
             if (ok && first == 0 && next < nb) {
                 /* launches that run side by side finish together, so the first stretch decodes alone (the time of one
@@ -607,8 +620,8 @@ static void *bgzf_gpu_stream_stager(void *v) {
         ok = ok && hpgv_inflate_blocks_dev(CTX, (const uint8_t *)s->d_comp, q->d_in_off, q->d_in_len, q->d_out_off, q->d_out_len,
                                            (int)q->n, (uint8_t *)s->d_text, q->d_status, q->stream) == HPGV_OK;
         if (bgzf_verify_on())                                        /* the blocks' CRC-32, on the device behind the decoder */
-            ok = ok && hpgv_bgzf_verify_dev(CTX, (const uint8_t *)s->d_comp, q->d_in_off, q->d_in_len, q->d_out_off, q->d_out_len,
-                                            (int)q->n, (const uint8_t *)s->d_text, q->d_status, q->stream) == HPGV_OK;
+            ok = ok && hpgv_bgzf_verify_tiles_dev(CTX, (const uint8_t *)s->d_comp, q->d_in_off, q->d_in_len, q->d_out_off, q->d_out_len,
+                                                  (int)q->n, (const uint8_t *)s->d_text, q->d_status, s->d_tiles, (uint64_t)s->n_tiles, q->stream) == HPGV_OK;
         if (!ok) break;
         if (dbg && k == 0) fprintf(stderr, "stager: first stretch launched at %.4f\n", now_s() - T0);
         launched += q->n;
@@ -694,6 +707,7 @@ static int bgzf_stream_stage(source_t *s) {
         s->d_text = dev_text_get(est, &s->d_text_cap, &s->d_text_kind);
         ok = s->d_text != NULL && ((s->d_text_kind == DEV_TEXT_GROWS && !g_env.no_growing_text) || S->chain_pos >= (size_t)s->size);
         if (!ok && s->d_text) { dev_text_put(s->d_text, s->d_text_cap, s->d_text_kind); s->d_text = NULL; }
+        if (ok) tiles_alloc(s, est);
     }
     if (dbg) fprintf(stderr, "stage: first %zu blocks found, text estimate %.1f MB, %s at %.4f\n", S->slot[0].n, est / 1e6, ok ? "streaming" : "not taken", now_s() - T0);
     if (ok) {
@@ -708,6 +722,7 @@ static int bgzf_stream_stage(source_t *s) {
         for (int k = 0; k < SCAN_SLOTS; k++) free(S->slot[k].h_in_off);
         free(S);
         if (s->d_text) { dev_text_put(s->d_text, s->d_text_cap, s->d_text_kind); s->d_text = NULL; }
+        tiles_free(s);
         if (s->d_scan) { (void)hpgv_dev_free(CTX, s->d_scan); s->d_scan = NULL; }
         stream_put(0, s->rstream); s->rstream = NULL;
         stream_put(low, s->cstream); s->cstream = NULL; s->c_low = 0;
@@ -862,6 +877,7 @@ int bgzf_gpu_stage(source_t *s) {
     if (ok) { s->c_low = 0; ok = stream_get(0, &s->rstream) == HPGV_OK && stream_get(0, &s->cstream) == HPGV_OK; }
     if (ok) ok = hpgv_dev_alloc(CTX, nb * 24 + 64, &s->d_tab) == HPGV_OK;
     if (ok) { s->text_est = text; s->d_text = dev_text_get(text + 16, &s->d_text_cap, &s->d_text_kind); ok = s->d_text != NULL; }
+    if (ok) tiles_alloc(s, text + 16);
     if (ok) ok = hpgv_dev_alloc(CTX, nb * 4 + 16, &s->d_status) == HPGV_OK;
     if (dbg) fprintf(stderr, "stage: alloc %.4f\n", now_s() - T0);
     if (ok) {
@@ -890,6 +906,7 @@ int bgzf_gpu_stage(source_t *s) {
         if (s->d_tab) { (void)hpgv_dev_free(CTX, s->d_tab); s->d_tab = NULL; }
         if (s->d_status) { (void)hpgv_dev_free(CTX, s->d_status); s->d_status = NULL; }
         if (s->d_text) { dev_text_put(s->d_text, s->d_text_cap, s->d_text_kind); s->d_text = NULL; }
+        tiles_free(s);
         stream_put(0, s->rstream); s->rstream = NULL;
         stream_put(0, s->cstream); s->cstream = NULL;
         return 1;

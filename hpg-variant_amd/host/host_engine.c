@@ -44,6 +44,7 @@ void host_env_read(void) {
     ENV_FLAG("HPGV_SERIAL_BGZF_WALK", serial_bgzf_walk);
     ENV_FLAG("HPGV_NO_GROWING_TEXT", no_growing_text);
     ENV_FLAG("HPGV_NO_LOW_PRIORITY", no_low_priority);
+    { const char *v_ = getenv("HPGV_DECODE_TILES"); e.no_decode_tiles = v_ && *v_ && atol(v_) == 0; }
     ENV_FLAG("HPGV_NO_NUMA_BIND", no_numa_bind);
     ENV_FLAG("HPGV_NO_WRITER_THREAD", no_writer_thread);
     ENV_FLAG("HPGV_ALWAYS_SORT", always_sort);
@@ -266,6 +267,31 @@ void dev_text_put(void *p, size_t bytes, int kind) {
     dev_text_free(p, kind);
 }
 
+/* the tile records that go with such a text (32 bytes per 2 KiB of it), kept between runs the same way */
+static void *g_dev_tiles_m[MEMBERS_MAX]; static size_t g_dev_tiles_cap_m[MEMBERS_MAX];
+void *dev_tiles_get(size_t bytes, size_t *cap) {
+    void *p = NULL;
+    pthread_mutex_lock(&g_text_mu);
+    if (g_dev_tiles_m[t_member] && g_dev_tiles_cap_m[t_member] >= bytes) {
+        p = g_dev_tiles_m[t_member]; *cap = g_dev_tiles_cap_m[t_member];
+        g_dev_tiles_m[t_member] = NULL; g_dev_tiles_cap_m[t_member] = 0;
+    }
+    pthread_mutex_unlock(&g_text_mu);
+    if (p) return p;
+    if (hpgv_dev_alloc(CTX, bytes, &p) != HPGV_OK) return NULL;
+    *cap = bytes;
+    return p;
+}
+void dev_tiles_put(void *p, size_t cap) {
+    if (!p) return;
+    void *old = NULL;
+    pthread_mutex_lock(&g_text_mu);
+    if (g_dev_tiles_cap_m[t_member] < cap) { old = g_dev_tiles_m[t_member]; g_dev_tiles_m[t_member] = p; g_dev_tiles_cap_m[t_member] = cap; p = NULL; }
+    pthread_mutex_unlock(&g_text_mu);
+    if (old) (void)hpgv_dev_free(CTX, old);
+    if (p) (void)hpgv_dev_free(CTX, p);
+}
+
 /* streams of the bgzip device path, kept between runs: creating the seven a run uses took 18 ms of a 0.14 s run (they are
  * idle when they come back) */
 enum { STREAM_CACHE_N = 16 };
@@ -304,6 +330,11 @@ static void text_cache_release(void) {                  /* g_ctx still alive */
         g_dev_text = NULL; g_dev_text_cap = 0;
         pthread_mutex_unlock(&g_text_mu);
         dev_text_free(dt, dk);
+        pthread_mutex_lock(&g_text_mu);
+        void *tl = g_dev_tiles_m[t_member];
+        g_dev_tiles_m[t_member] = NULL; g_dev_tiles_cap_m[t_member] = 0;
+        pthread_mutex_unlock(&g_text_mu);
+        if (tl) (void)hpgv_dev_free(CTX, tl);
         ctx_back(o);
     }
     pthread_mutex_lock(&g_text_mu);

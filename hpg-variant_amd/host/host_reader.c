@@ -98,6 +98,7 @@ static size_t read_window(line_reader_t *r, source_t *s, size_t cap, int last) {
     size_t ret = (size_t)-1;
     r->last_dev = (const char *)s->d_text + start;
     r->last_ctx = s->ctx;
+    r->last_base = (const char *)s->d_text; r->last_tiles = s->d_tiles; r->last_n_tiles = s->n_tiles;
     pthread_mutex_lock(&s->g_mu);                                    /* until the stager has decoded that far (or knows where the text ends) */
     for (;;) {
         const size_t lim = s->dev_len_known ? s->dev_len : (size_t)-1;
@@ -174,7 +175,7 @@ size_t read_lines_dev(line_reader_t *r, char *buf, size_t bufcap, size_t cap) {
             memcpy(buf, mp->seam, mp->seam_len);
             const size_t n = mp->seam_len;
             mp->seam_len = 0;
-            r->last_dev = NULL; r->last_ctx = NULL;
+            r->last_dev = NULL; r->last_ctx = NULL; r->last_tiles = NULL;
             return n;
         }
         source_t *s = mp->p[mp->cur];
@@ -226,6 +227,7 @@ size_t read_lines(line_reader_t *r, char *buf, size_t cap) {
      * the device bytes from (position - carry) on */
     if (!r->src.gpu_tried && r->src.kind == SRC_BGZF) (void)bgzf_gpu_stage(&r->src);
     r->last_dev = r->src.d_text ? (const char *)r->src.d_text + (r->src.dev_pos - r->carry_len) : NULL;
+    r->last_base = (const char *)r->src.d_text; r->last_tiles = r->src.d_text ? r->src.d_tiles : NULL; r->last_n_tiles = r->src.n_tiles;
     if (r->carry_len) {                                 /* may exceed cap: what followed the header in its read buffer */
         n = r->carry_len < cap ? r->carry_len : cap;
         memcpy(buf, r->carry, n);

@@ -40,6 +40,7 @@ static void *pipe_reader(void *v) {
         if (!P->bt[k].text) P->bt[k].text = text_buf_get(P->bt[k].text_cap);
         const size_t n = !P->bt[k].text ? (size_t)-1 : P->rd->devwin ? read_lines_dev(P->rd, P->bt[k].text, P->bt[k].text_cap, P->batch_bytes) : read_lines(P->rd, P->bt[k].text, P->batch_bytes);
         P->bt[k].dev_text = P->rd->last_dev; P->bt[k].dev_ctx = P->rd->devwin ? P->rd->last_ctx : NULL;
+        P->bt[k].dev_base = P->rd->last_base; P->bt[k].dev_tiles = P->rd->last_dev ? P->rd->last_tiles : NULL; P->bt[k].dev_n_tiles = P->rd->last_n_tiles;
         const double dt = now_s() - t0;
         pthread_mutex_lock(&P->mu);
         P->t_read += dt;
@@ -68,7 +69,9 @@ static void *pipe_engine(void *v) {
         const double t0 = now_s();
         run_batch_t *b = &P->bt[k];
         int rc = HPGV_OK;
-        if (b->dev_text) (void)hpgv_text_alias(b->dev_ctx ? b->dev_ctx : g_ctx, b->text, b->dev_text);       /* tokenize the device copy in place (on the device that holds it): no H2D of the text */
+        /* tokenize the device copy in place (on the device that holds it): no H2D of the text -- and, when the decoder left its tile
+         * records, no counting sweep over it either */
+        if (b->dev_text) (void)hpgv_text_alias_tiles(b->dev_ctx ? b->dev_ctx : g_ctx, b->text, b->dev_text, b->dev_base, b->dev_tiles, (uint64_t)b->dev_n_tiles);
         /* max_lines is sized for complete records; a batch of short (damaged) lines can hold more: the
          * engine reports the true count, the arrays grow and the batch is done again */
         for (int attempt = 0; attempt < 4; attempt++) {

@@ -144,6 +144,7 @@ void source_close(source_t *s) {
         if (s->d_tab) (void)hpgv_dev_free(CTX, s->d_tab);
         if (s->d_status) (void)hpgv_dev_free(CTX, s->d_status);
         if (s->d_text) dev_text_put(s->d_text, s->d_text_cap, s->d_text_kind);
+        if (s->d_tiles) dev_tiles_put(s->d_tiles, s->d_tiles_cap);
         if (s->d_scan) (void)hpgv_dev_free(CTX, s->d_scan);
         stream_put(0, s->rstream);
         stream_put(s->c_low, s->cstream);

@@ -95,6 +95,7 @@ typedef struct {
     uint64_t *g_in_off, *g_out_off; uint32_t *g_in_len, *g_out_len; size_t g_nb, g_done;      /* the stager's block tables */
     size_t dev_ready;                                   /* text bytes decoded so far (under g_mu) */
     size_t d_text_cap; int d_text_kind;
+    void *d_tiles; size_t n_tiles, d_tiles_cap;                    /* the tokenizer's tile records of the decoded text, left by the CRC check (hpgv_bgzf_verify_tiles_dev) */
     size_t text_est;                                     /* about how much text the file holds (known when the stage has chosen its path) */
     int dev_len_known;                                  /* 0 while the stager is still finding the file's blocks (under g_mu) */
     void *d_scan;                                       /* the streaming stager's tables, statuses and scan scratch */
@@ -125,6 +126,7 @@ typedef struct {
     int eof;
     const char *last_dev;                               /* device copy of the batch read_lines just returned (BGZF on the GPU), or NULL */
     hpgv_ctx *last_ctx;                                 /* ... and the member context of that device when the file is staged in parts */
+    const char *last_base; const void *last_tiles; size_t last_n_tiles;      /* ... where that device text begins, and its tile records */
     int devwin;                                         /* batches are windows of the device text; nothing but their cut points is read back */
     char *tailbuf; size_t tailcap;
 } line_reader_t;
@@ -133,6 +135,7 @@ typedef struct {
     char *text; size_t text_cap;                         /* page-locked, taken from the cache when the batch is first filled */
     const char *dev_text;                                /* the same bytes on the device (BGZF decoded there), or NULL */
     hpgv_ctx *dev_ctx;                                   /* the member context of that device (a file staged in parts), or NULL */
+    const char *dev_base; const void *dev_tiles; size_t dev_n_tiles;      /* where the decoded text begins on the device, and its tile records (or NULL) */
     size_t bytes; int max_lines, n_lines;
     uint64_t *line_off; uint32_t *field_off; int32_t *status;
     int32_t *ints; double *dbl;                          /* 4 (assoc) or 2 (tdt) int arrays, 3 double arrays */
@@ -197,6 +200,7 @@ typedef struct {
     long serial_bgzf_walk;           /* HPGV_SERIAL_BGZF_WALK=1: ... by one thread */
     long no_growing_text;            /* HPGV_NO_GROWING_TEXT=1: a fixed device buffer for the decoded text */
     long no_low_priority;            /* HPGV_NO_LOW_PRIORITY=1: the decoder's streams at normal priority */
+    long no_decode_tiles;            /* HPGV_DECODE_TILES=0: the CRC check leaves no tile records (windows tokenized with the counting sweep) */
     long no_numa_bind;               /* HPGV_NO_NUMA_BIND=1: a run's threads stay where the scheduler puts them */
     long no_writer_thread;           /* HPGV_NO_WRITER_THREAD=1: result lines written by the formatting thread */
     long always_sort;                /* HPGV_ALWAYS_SORT=1: the output is sorted even when it came out in order */
@@ -235,6 +239,8 @@ void *dev_text_get(size_t bytes, size_t *cap, int *kind);
 int dev_text_grow(void *p, size_t bytes, size_t *cap);
 void dev_text_drop_cached(void);
 void dev_text_put(void *p, size_t bytes, int kind);
+void *dev_tiles_get(size_t bytes, size_t *cap);
+void dev_tiles_put(void *p, size_t cap);
 int stream_get(int low, void **out);
 void stream_put(int low, void *st);
 int ensure_engine(void);

@@ -158,6 +158,7 @@ int  hpgv_mendel_layout(const hpgv_ctx *ctx, size_t *pitch);
  *      another runtime, e.g. a torch tensor's data_ptr) ---------------------- */
 int  hpgv_dev_alloc(hpgv_ctx *ctx, size_t bytes, void **dptr);
 int  hpgv_dev_free(hpgv_ctx *ctx, void *dptr);
+int  hpgv_memset_dev(hpgv_ctx *ctx, void *dptr, int byte_value, size_t bytes, void *stream);   /* stream NULL: done when it returns */
 /* device memory that grows in place: reserve an address range of max_bytes (costs no memory), make its first `bytes` bytes
  * usable with hpgv_dev_commit (what is backed stays backed; pieces of 64 MB), give everything back with hpgv_dev_release.
  * For a text whose size is known only when its last block has been seen.  HPGV_ERR_UNSUPPORTED: no virtual memory management.

@@ -389,6 +389,8 @@ void hpgv_host_adapter_times(double *seconds4, long *calls, int reset);
  *   HPGV_BGZF_ONE_DEVICE=1       a group decodes a bgzip file on its first device only (default: in parts, one per device)
  *   HPGV_NO_NUMA_BIND=1          a run's threads are not moved to the GPU's NUMA node
  *   HPGV_ALWAYS_SORT=1           the output file is sorted even when it came out in order
+ *   HPGV_DECODE_TILES=0          the device's CRC check leaves no tokenizer tile records (windows of decoded text are then
+ *                                tokenized with their counting sweep: the A/B of that short cut)
  * Diagnosis and tests (each switches one stage of the bgzip device path to its fall-back): HPGV_NO_DEVICE_WINDOWS,
  * HPGV_NO_LARGE_WINDOWS, HPGV_BGZF_HOST_TABLE, HPGV_SERIAL_BGZF_WALK, HPGV_NO_GROWING_TEXT, HPGV_NO_LOW_PRIORITY,
  * HPGV_NO_WRITER_THREAD, HPGV_UPLOAD_SEGMENT_MB, HPGV_UPLOAD_INFLIGHT, HPGV_TEST_GPU_INFLATE_REFUSE_EVERY,
