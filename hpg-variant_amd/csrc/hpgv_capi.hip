@@ -385,6 +385,8 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
         ctx->fisher_cut_exp = value;
     } else if (!strcmp(key, "epi_complete")) {
         ctx->epi_complete = value ? 1 : 0;
+    } else if (!strcmp(key, "epi_pairs_mfma")) {
+        ctx->epi_pairs_mfma = value ? 1 : 0;
     } else if (!strcmp(key, "epi_triples_1pass")) {
         if (value < 0 || value > 2) return fail(ctx, HPGV_ERR_INVALID, "epi_triples_1pass must be 0 (two passes), 1 (the cells nine at a time) or 2 (one pass, one wave per SIMD)");
         HPGV_SHIPPED_ONLY(value != 2, "epi_triples_1pass = 2")

@@ -2,6 +2,7 @@
 // scans are instantiated per fold count and compile for minutes).
 #include "hpgv_internal.h"
 #include "hpgv_epi_triples3_kernels.h"
+#include "hpgv_epi_mfma_kernels.h"
 
 
 namespace {
@@ -18,6 +19,7 @@ void epi_free_folds(EpiState &E) {
     if (E.d_chunks) (void)hipFree(E.d_chunks);
     if (E.d_folds) (void)hipFree(E.d_folds);
     if (E.d_group_w0) (void)hipFree(E.d_group_w0);
+    E.rev_off = 0;
     E.d_planes = nullptr; E.d_chunks = nullptr; E.d_folds = nullptr; E.d_group_w0 = nullptr;
     E.have_folds = false;
 }
@@ -89,7 +91,11 @@ int epi_build_folds(hpgv_ctx *ctx, const int32_t *fold_of_sample, int num_folds)
     int32_t *d_src = nullptr;
     HIPCHK(ctx, hipMalloc(&d_src, src.size() * sizeof(int32_t)));
     hipError_t e = hipMemcpy(d_src, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(&E.d_planes, ((size_t)E.V_alloc * 3 * (size_t)E.W + hpgv::EPI_CH) * sizeof(uint32_t));   // + slack: the LDS-DMA staging fetches whole 32-word rows
+    // + slack: the LDS-DMA staging fetches whole 32-word rows.  Behind the planes, while the scans' 32-bit word offsets reach it, their
+    // copy with the low seven bits of every byte reversed (hpgv_epi_mfma_kernels.h)
+    const size_t plane_words = (size_t)E.V_alloc * 3 * (size_t)E.W + hpgv::EPI_CH;
+    E.rev_off = 2 * plane_words < (1ull << 32) ? (uint32_t)plane_words : 0u;
+    if (e == hipSuccess) e = hipMalloc(&E.d_planes, (plane_words + E.rev_off) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&E.d_chunks, chunks.size() * sizeof(hpgv::EpiChunk));
     if (e == hipSuccess) e = hipMemcpy(E.d_chunks, chunks.data(), chunks.size() * sizeof(hpgv::EpiChunk), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&E.d_folds, hpgv::EPI_MAX_FOLDS * sizeof(hpgv::EpiFold));
@@ -104,6 +110,8 @@ int epi_build_folds(hpgv_ctx *ctx, const int32_t *fold_of_sample, int num_folds)
         hipLaunchKernelGGL(hpgv::k_epi_planes, dim3((unsigned)E.V_alloc), dim3(256), 0, nullptr, E.d_data, E.V, n, d_src, E.W, E.d_planes, d_flag);
         // genotype counts per SNP and group: what the complete-data pair scan derives the cells with a genotype 2 from
         hipLaunchKernelGGL(hpgv::k_epi_marginals, dim3((unsigned)E.V_alloc), dim3(256), 0, nullptr, E.d_planes, E.W, E.d_group_w0, num_folds * 2, E.d_marg);
+        if (E.rev_off)                                               // the column side's copy for the matrix-core pair scan
+            hipLaunchKernelGGL(hpgv::k_epi_planes_rev, dim3((unsigned)((plane_words + 255) / 256)), dim3(256), 0, nullptr, E.d_planes, plane_words, E.d_planes + E.rev_off);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpy(&flag, d_flag, sizeof(unsigned), hipMemcpyDeviceToHost);      // synchronises
     }
@@ -115,10 +123,52 @@ int epi_build_folds(hpgv_ctx *ctx, const int32_t *fold_of_sample, int num_folds)
     return HPGV_OK;
 }
 
+// the ranking scan with the cell counts on the matrix cores (hpgv_epi_mfma_kernels.h): tiles of 16 rows x 64 columns
+template <bool TRAINING, bool BALANCED>
+int epi_launch_pairs_mfma(hpgv_ctx *ctx, int i_begin, int i_end, hipStream_t st) {
+    EpiState &E = ctx->epi;
+    const int i_first = i_begin;
+    i_begin = i_begin / 64 * 64;
+    const int tiles_j = (E.V + hpgv::EPI_TJ - 1) / hpgv::EPI_TJ, row_blocks = (i_end - i_begin + hpgv::EPM_TI - 1) / hpgv::EPM_TI;
+    const int n_cols = tiles_j - i_begin / 64;
+    if (n_cols <= 0 || row_blocks <= 0) return HPGV_OK;
+    std::vector<unsigned> tile_base((size_t)n_cols + 1);
+    unsigned long long total = 0;
+    for (int c = 0; c < n_cols; ++c) {                               // column tile c holds pairs with the rows above its last column
+        tile_base[(size_t)c] = (unsigned)total;
+        total += (unsigned long long)std::min<long long>(row_blocks, (64ll / hpgv::EPM_TI) * (c + 1));
+    }
+    tile_base[(size_t)n_cols] = (unsigned)total;
+    if (total + 8 > 0x7FFFFFFFull / 256) return fail(ctx, HPGV_ERR_UNSUPPORTED, "row band too large for one launch");
+    if (total == 0) return HPGV_OK;
+    if (E.tile_base_cap < tile_base.size()) {
+        if (E.d_tile_base) (void)hipFree(E.d_tile_base);
+        E.d_tile_base = nullptr; E.tile_base_cap = 0;
+        HIPCHK(ctx, hipMalloc(&E.d_tile_base, (tile_base.size() + 64) * sizeof(unsigned)));
+        E.tile_base_cap = tile_base.size() + 64;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(E.d_tile_base, tile_base.data(), tile_base.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    const unsigned n_tiles = (unsigned)total;
+    const dim3 grid((n_tiles + 7u) / 8u * 8u);
+    hpgv::EpiFold folds[hpgv::EPI_MAX_FOLDS];
+    for (int f = 0; f < hpgv::EPI_MAX_FOLDS; ++f) {
+        folds[f].test_a = E.group_size[(size_t)2 * f]; folds[f].test_u = E.group_size[(size_t)2 * f + 1];
+        const int sa = TRAINING ? E.nA - folds[f].test_a : folds[f].test_a, su = TRAINING ? E.nU - folds[f].test_u : folds[f].test_u;
+        folds[f].inv_a = 1.0 / (double)sa; folds[f].inv_u = 1.0 / (double)su;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(E.d_folds, folds, sizeof folds, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL((hpgv::k_epi_pairs_mfma<TRAINING, BALANCED>), grid, dim3(256), 0, st, E.d_planes, E.rev_off, E.W,
+                       E.V, i_begin, i_first, i_end, E.d_tile_base, n_cols, n_tiles, E.d_chunks, E.n_chunks, E.d_folds, E.num_folds, E.nA, E.nU, E.d_thr, E.d_cand, E.d_cand_count, E.cand_cap);
+    HIPCHK(ctx, hipGetLastError());
+    return HPGV_OK;
+}
+
 template <bool TRAINING, bool BALANCED>
 int epi_launch_pairs2(hpgv_ctx *ctx, int i_begin, int i_end, double *d_acc, uint16_t *d_mask, unsigned long long n_pairs_out,
                       unsigned long long rank_base, bool candidates, hipStream_t st) {
     EpiState &E = ctx->epi;
+    if (candidates && !d_acc && ctx->epi_pairs_mfma && E.rev_off && E.n_chunks <= hpgv::EPM_MAX_CHUNKS && E.nA < 65536 && E.nU < 65536 && !(E.complete && ctx->epi_complete))
+        return epi_launch_pairs_mfma<TRAINING, BALANCED>(ctx, i_begin, i_end, st);
     // tiles that hold at least one pair, numbered column tile by column tile: column tile tj0 + c pairs with the row
     // blocks from the band's first row down to the diagonal, min(row_blocks, 16 (c + 1)) of them
     const int i_first = i_begin;

@@ -1,0 +1,265 @@
+// hpgv_epi_mfma_kernels.h -- the pair ranking of the epistasis / MDR path with the cell counts on the MATRIX cores
+// (model.c:76-206 combination_counts_all_folds, mdr.c:45-76, model.c:320-476; what k_epi_pairs of hpgv_epi_kernels.h does on
+// the vector ALU).
+//
+// The nine cell counts of the pairs of 16 row SNPs x 16 column SNPs over 128 samples are nine products of 0/1 matrices:
+// count(a, b)[i][j] = sum over samples of plane_i[a] * plane_j[b], i.e. v_mfma_scale_f32_16x16x128_f8f6f4 with the genotype
+// planes as FP4 operands (scales 1) -- A holds plane a of the 16 row SNPs, B plane b of the 16 column SNPs; sums of 0 / 1 are
+// exact in the f32 accumulators far beyond a group's 65 535 samples.  The result tile of that instruction has its column on the
+// lane (lane & 15) and rows 4 (lane >> 4) + 0 .. 3 in the lane's four registers, so with the nine (a, b) tiles side by side every
+// lane ends up with the WHOLE 3 x 3 table of four pairs: (i0 + 4 (lane >> 4) + q, j0 + (lane & 15)), q = 0 .. 3, and the
+// evaluation needs no exchange between lanes.
+//
+// Operands: the planes are bits.  Lane (r, h) = (lane & 15, lane >> 4) supplies 32 samples of SNP r to each MFMA -- the
+// instruction sums over the four h groups and the lane's 32 four-bit values, in an order that does not matter to a count as
+// long as A and B agree.  Per 128-sample step (the unit the (fold, class) groups are padded to) a lane reads ONE 32-bit word
+// per plane (word h of its SNP's four, out of the LDS image that k_epi_pairs' staging scheme keeps ahead): exactly one MFMA's
+// worth.  The four-bit values are NOT 0 / 1: an operand register is the word ANDed with one bit of every nibble,
+// x & 0x22222222 = eight samples as E2M1 1.0 where the bit is set, x & 0x11111111 = 0.5, x & 0x44444444 = 2.0 -- ONE
+// instruction per eight samples (the nibble's top bit is the sign: those samples are shifted down to 0.5).  The other side
+// must weigh the same samples 2.0, 1.0, 0.5, 2.0 so that every product is 1: the column side reads a second copy of the planes
+// with bits 0 and 2 of every nibble swapped, again one instruction per register.  Five instructions per word and plane, 30
+// per step, against nine MFMAs of 16 cycles.  (The first form used v_mfma_i32_16x16x64_i8 with one bit of every BYTE per
+// register: 54 instructions and 18 MFMAs per step -- and that instruction takes 32 cycles here, not the 16 of its bf16
+// sibling: 576 cycles of matrix core per step, no faster than k_epi_pairs.)
+//
+// State and passes: see k_epi_pairs_mfma below (two passes over the samples, two waves per SIMD).
+#pragma once
+#include "hpgv_epi_kernels.h"
+
+namespace hpgv {
+
+constexpr int EPM_MAX_CHUNKS = 128;   // chunk descriptors kept in LDS (131 072 samples and their padding)
+constexpr int EPM_TI = 16;            // rows of a workgroup's tile (its 64 columns: 16 per wave)
+typedef int epm_v8i __attribute__((ext_vector_type(8)));
+typedef float epm_v4f __attribute__((ext_vector_type(4)));
+
+// the column side's copy of the planes: bits 0 and 2 of every nibble swapped (same layout, right behind the planes)
+__device__ __forceinline__ uint32_t epm_swap02(uint32_t x) {
+    return (x & 0xAAAAAAAAu) | ((x & 0x11111111u) << 2) | ((x >> 2) & 0x11111111u);
+}
+static __global__ void __launch_bounds__(256) k_epi_planes_rev(const uint32_t *__restrict__ planes, size_t n_words, uint32_t *__restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (idx < n_words) out[idx] = epm_swap02(planes[idx]);
+}
+
+// the operand registers of one MFMA (FP4: the first four of the eight): samples 4 m + 0 / 1 / 2 / 3 of the word weighted
+// 0.5 / 1 / 2 / 0.5 on the row side and 2 / 1 / 0.5 / 2 on the column side (from the swapped copy)
+__device__ __forceinline__ epm_v8i epm_row_operand(uint32_t x) {
+    return epm_v8i{(int)(x & 0x11111111u), (int)(x & 0x22222222u), (int)(x & 0x44444444u), (int)((x >> 3) & 0x11111111u), 0, 0, 0, 0};
+}
+__device__ __forceinline__ epm_v8i epm_col_operand(uint32_t y) {
+    return epm_v8i{(int)(y & 0x44444444u), (int)(y & 0x22222222u), (int)(y & 0x11111111u), (int)((y >> 1) & 0x44444444u), 0, 0, 0, 0};
+}
+#define HPGV_EPM_MFMA(A, B, C) __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, C, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F)   /* FP4 x FP4, scales 2^0 */
+
+// Ranking only (thresholds + candidate lists), classes below 65 536 samples, any number of folds.  TWO passes over the
+// samples, like the triple scan's: the first leaves every pair's nine totals (cases low, controls high half), the second visits
+// the groups in (fold, class) order and, each time a fold's groups are complete, evaluates that fold at once from totals -
+// fold counts.  What this buys over one pass that keeps all folds' counts: the state is 36 + 36 + 36 registers instead of
+// 36 (K + 1), so TWO waves share a SIMD -- one wave's vector work (operands, banking, evaluation) runs under the other's
+// MFMAs, which a single wave's own instruction stream does not do -- there is one copy of the evaluation whatever the fold
+// (its counts sit in fixed registers), and neither the fold count nor unequal classes change the code.  The second pass of
+// MFMAs is the cheap part.
+// Tiles: 16 rows x 64 columns, numbered column tile by column tile and dealt to the XCDs in spans like k_epi_pairs'
+// (tile_base[c] = tiles before column tile i_begin / 64 + c; inside it the 16-row blocks from the band's first row down to the
+// diagonal).  Staging as k_epi_pairs: an LDS image of (64 + 16) SNPs x 3 planes x 32 words per chunk, rows of 128 bytes,
+// the 16-byte pieces of a row swizzled by the SNP so that the 64 lanes of a read (16 SNPs x 4 words) fall on 64 different
+// banks; double buffered, one barrier per chunk.  The columns' rows come from the swapped copy (rev_off words behind the planes).
+template <bool TRAINING, bool BALANCED>
+__global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__restrict__ planes, uint32_t rev_off, int W,
+                                                         int n_variants, int i_begin, int i_first, int i_end,
+                                                         const unsigned *__restrict__ tile_base, int n_cols, unsigned n_tiles,
+                                                         const EpiChunk *__restrict__ chunks, int n_chunks,
+                                                         const EpiFold *__restrict__ folds, int num_folds, int n_affected, int n_unaffected,
+                                                         const double *__restrict__ thr, EpiCand *__restrict__ cand,
+                                                         unsigned *__restrict__ cand_count, unsigned cand_cap) {
+    constexpr int SNPS = EPI_TJ + EPM_TI, ROWS = SNPS * 3, NDMA = ROWS / 8;      // 80 SNPs, 240 rows, 30 LDS-DMA instructions per chunk
+    static_assert(ROWS % 8 == 0, "whole LDS-DMA instructions");
+    // two separate arrays, not lds[2][...]: the compiler then sees that the LDS-DMA writes into one buffer cannot touch the other
+    __shared__ __attribute__((aligned(16))) uint32_t lds_a[ROWS * EPI_CH];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_b[ROWS * EPI_CH];
+    // the chunk descriptors and the folds' constants in LDS (a scalar load that misses costs a microsecond)
+    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[EPM_MAX_CHUNKS * 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_fold[EPI_MAX_FOLDS * 8];
+    const unsigned span = (n_tiles + 7u) / 8u;
+    const unsigned tile = (blockIdx.x & 7u) * span + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    int c_lo = 0, c_hi = n_cols;
+    while (c_hi - c_lo > 1) { const int mid = (c_lo + c_hi) >> 1; if (tile_base[mid] <= tile) c_lo = mid; else c_hi = mid; }
+    for (int q = threadIdx.x; q < n_chunks * 4; q += 256) s_chunk[q] = reinterpret_cast<const uint32_t *>(chunks)[q];
+    for (int q = threadIdx.x; q < num_folds * 8; q += 256) {         // per fold: test_a, test_u, inv_a, inv_u, the threshold
+        const int f = q >> 3, e = q & 7;
+        s_fold[q] = e < 6 ? reinterpret_cast<const uint32_t *>(folds + f)[e] : reinterpret_cast<const uint32_t *>(thr + f)[e - 6];
+    }
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 15, h = lane >> 4;
+    const int jt = ((i_begin >> 6) + c_lo) * EPI_TJ, j0 = jt + 16 * wave, i0 = i_begin + (int)(tile - tile_base[c_lo]) * EPM_TI;
+    const bool active = !(j0 + 15 <= i0 || i0 >= i_end || i0 + 15 < i_first);       // is any pair of this wave's block asked for
+
+    // LDS-DMA: one global_load_lds_dwordx4 = 8 rows of the image; lane l fetches row 8 k + l / 8, physical piece l % 8 = the
+    // logical piece (l % 8) ^ swizzle(row's SNP).  Kept per instruction: the word offset of the lane's piece in the planes.
+    uint32_t dma_off[8];
+    #pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int k = wave + 4 * q, row8 = 8 * k + (lane >> 3), row = row8 < ROWS ? row8 : 0;
+        const int snp_idx = row / 3, plane = row % 3;
+        const int piece = (lane & 7) ^ ((snp_idx >> 1) & 7);
+        const int snp = snp_idx < EPI_TJ ? jt + snp_idx : i0 + (snp_idx - EPI_TJ);
+        dma_off[q] = ((uint32_t)snp * 3u + (uint32_t)plane) * (uint32_t)W + (uint32_t)piece * 4u + (snp_idx < EPI_TJ ? rev_off : 0u);
+    }
+    auto load_chunk = [&](uint32_t w0, uint32_t *dst) {
+        #pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int k = wave + 4 * q;
+            if (k < NDMA)
+                __builtin_amdgcn_global_load_lds(planes + (dma_off[q] + w0), (__attribute__((address_space(3))) uint32_t *)(dst + 8 * k * EPI_CH), 16, 0, 0);
+        }
+    };
+    load_chunk(chunks[0].w0, lds_a);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                 // (the tables above are in place too)
+
+    // byte offsets of the lane's words in the image: row (SNP * 3 + plane) * 128 + piece (step ^ swizzle) * 16 + h * 4
+    const int sa = EPI_TJ + r, sb = 16 * wave + r;
+    const int base_a = sa * 3 * (EPI_CH * 4) + h * 4, base_b = sb * 3 * (EPI_CH * 4) + h * 4, swz_a = (sa >> 1) & 7, swz_b = (sb >> 1) & 7;
+    const float f_na = (float)(unsigned)n_affected, f_nu = (float)(unsigned)n_unaffected;
+    const float ratio = f_na / f_nu;
+    const int j = j0 + r;
+    bool asked[4];
+    #pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int i = i0 + 4 * h + q;
+        asked[q] = !(i < i_first || i >= i_end || i >= n_variants || j >= n_variants || j <= i);
+    }
+
+    epm_v4f acc[9];
+    uint32_t totp[9][4], part[9][4];                                 // totals; the fold under way (cases low, controls high halves)
+    #pragma unroll
+    for (int c = 0; c < 9; c++) {
+        acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f};
+        #pragma unroll
+        for (int q = 0; q < 4; q++) { totp[c][q] = 0; part[c][q] = 0; }
+    }
+
+#define HPGV_EPM_READ(X, Y, KSTEP)                                                                       \
+    {                                                                                                    \
+        const int k_ = (KSTEP) < 7 ? (KSTEP) : 7;                    /* (past the chunk's last step: any step, never used) */ \
+        const char *qa = cur_bytes + (base_a + ((k_ ^ swz_a) << 4)), *qb = cur_bytes + (base_b + ((k_ ^ swz_b) << 4)); \
+        _Pragma("unroll") for (int a = 0; a < 3; a++) {                                                  \
+            X[a] = *reinterpret_cast<const uint32_t *>(qa + a * (EPI_CH * 4)); Y[a] = *reinterpret_cast<const uint32_t *>(qb + a * (EPI_CH * 4)); \
+        }                                                                                                \
+    }
+    // a (fold, class) group has ended: the accumulators hold its counts.  First pass: into the totals.  Second pass: into the
+    // fold under way; when the fold has no further group, it is evaluated and the fold under way starts empty again.
+    auto bank = [&](int g, int pass) {
+        const int f = g >> 1, sh = (g & 1) * 16;
+        if (pass == 0) {
+            #pragma unroll
+            for (int c = 0; c < 9; c++) {
+                totp[c][0] += (uint32_t)acc[c].x << sh; totp[c][1] += (uint32_t)acc[c].y << sh;
+                totp[c][2] += (uint32_t)acc[c].z << sh; totp[c][3] += (uint32_t)acc[c].w << sh;
+            }
+        } else {
+            #pragma unroll
+            for (int c = 0; c < 9; c++) {
+                part[c][0] += (uint32_t)acc[c].x << sh; part[c][1] += (uint32_t)acc[c].y << sh;
+                part[c][2] += (uint32_t)acc[c].z << sh; part[c][3] += (uint32_t)acc[c].w << sh;
+            }
+            EpiFold fo;
+            fo.test_a = __builtin_amdgcn_readfirstlane((int)s_fold[f * 8]); fo.test_u = __builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + 1]);
+            if ((g & 1) || fo.test_u <= 0) {                         // the fold's last group (its controls, or its cases when it has no controls)
+                fo.inv_a = __builtin_bit_cast(double, (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + 2]) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + 3]) << 32));
+                fo.inv_u = __builtin_bit_cast(double, (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + 4]) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + 5]) << 32));
+                const double thr_f = __builtin_bit_cast(double, (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + 6]) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + 7]) << 32));
+                const int size_a = TRAINING ? n_affected - fo.test_a : fo.test_a, size_u = TRAINING ? n_unaffected - fo.test_u : fo.test_u;
+                const float finv_a = (float)fo.inv_a, finv_u = (float)fo.inv_u, fthr = (float)thr_f;
+                #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (asked[q]) {
+                        uint32_t sel = 0;                            // TP (low half), FP (high half)
+                        #pragma unroll
+                        for (int c = 0; c < 9; c++) {
+                            const uint32_t in = part[c][q], tr = totp[c][q] - in;
+                            bool high;
+                            // balanced: cases >= controls, compared as (cases:controls) >= (controls:cases); an empty training cell is not
+                            // high risk (on the testing part its samples must stay out: compared against max(tr, 1))
+                            if constexpr (BALANCED) high = __builtin_amdgcn_alignbit(tr, tr, 16) >= (TRAINING ? tr : (tr > 1u ? tr : 1u));
+                            else high = mdr_high_risk<false>((int)(tr & 0xFFFFu), (int)(tr >> 16), ratio, f_na, f_nu);
+                            sel += high ? (TRAINING ? tr : in) : 0u;
+                        }
+                        const int tp = (int)(sel & 0xFFFFu), fp = (int)(sel >> 16);
+                        // nearly every model is far below its fold's threshold: single precision (error below 1e-6) says so at a fraction of the cost
+                        if (!(0.5f * ((float)tp * finv_a + (float)(size_u - fp) * finv_u) + 1e-5f < fthr)) {
+                            const double TP = (double)tp, TN = (double)(size_u - fp), ya = (double)size_a, yu = (double)size_u;
+                            double qa = TP * fo.inv_a, qu = TN * fo.inv_u;       // the two quotients, correctly rounded (Markstein)
+                            qa = __builtin_fma(__builtin_fma(-qa, ya, TP), fo.inv_a, qa);
+                            qu = __builtin_fma(__builtin_fma(-qu, yu, TN), fo.inv_u, qu);
+                            const double accy = (qa + qu) / 2;
+                            if (accy >= thr_f) {
+                                uint32_t mask = 0;
+                                #pragma unroll
+                                for (int c = 0; c < 9; c++) {
+                                    const uint32_t tr = totp[c][q] - part[c][q];
+                                    if (mdr_high_risk<BALANCED>((int)(tr & 0xFFFFu), (int)(tr >> 16), ratio, f_na, f_nu)) mask |= 1u << c;
+                                }
+                                const unsigned slot = atomicAdd(&cand_count[f], 1u);
+                                if (slot < cand_cap) {
+                                    EpiCand e;
+                                    e.accuracy = accy; e.i = i0 + 4 * h + q; e.j = j; e.risky = mask; e.pad = 0;
+                                    cand[(size_t)f * cand_cap + slot] = e;
+                                }
+                            }
+                        }
+                    }
+                }
+                #pragma unroll
+                for (int c = 0; c < 9; c++)
+                    #pragma unroll
+                    for (int q = 0; q < 4; q++) part[c][q] = 0;
+            }
+        }
+        #pragma unroll
+        for (int c = 0; c < 9; c++) acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f};
+    };
+
+    // 2 x n_chunks chunks, one after the other (the same code for both passes); the next chunk's loads fly into the other
+    // buffer during the work on this one.  Inside a chunk the words are read from the image a step ahead and the next
+    // step's operand registers are made beside this step's MFMAs.
+    uint32_t *cur = lds_a, *nxt = lds_b;
+    for (int cc = 0; cc < 2 * n_chunks; cc++) {
+        const int c = cc < n_chunks ? cc : cc - n_chunks, pass = cc < n_chunks ? 0 : 1;
+        if (cc + 1 < 2 * n_chunks) {
+            const int cn = cc + 1 < n_chunks ? cc + 1 : cc + 1 - n_chunks;
+            load_chunk((uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[cn * 4]), nxt);
+        }
+        if (active) {
+            const int ns = __builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 1]) >> 2;
+            const uint64_t flush = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 2])      // wave-uniform
+                                   | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 3]) << 32);
+            const char *cur_bytes = reinterpret_cast<const char *>(cur);
+            uint32_t xa[3], xb[3];
+            HPGV_EPM_READ(xa, xb, 0)
+            epm_v8i A0[3], B0[3];
+            #pragma unroll
+            for (int a = 0; a < 3; a++) { A0[a] = epm_row_operand(xa[a]); B0[a] = epm_col_operand(xb[a]); }
+            for (int k = 0; k < ns; k++) {
+                uint32_t na[3], nb[3];
+                HPGV_EPM_READ(na, nb, k + 1)
+                #pragma unroll
+                for (int a = 0; a < 3; a++)
+                    #pragma unroll
+                    for (int b = 0; b < 3; b++) acc[a * 3 + b] = HPGV_EPM_MFMA(A0[a], B0[b], acc[a * 3 + b]);
+                #pragma unroll
+                for (int a = 0; a < 3; a++) { A0[a] = epm_row_operand(na[a]); B0[a] = epm_col_operand(nb[a]); }
+                const int g = (int)((flush >> (8 * k)) & 0xFFu);     // the same in every lane
+                if (g != 0xFF) bank(g, pass);                        // (clears the accumulators: starting a group's first MFMAs from a zero operand instead needs two copies of the step, and measured slower)
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's part of the next chunk has landed
+        __syncthreads();
+        uint32_t *t = cur; cur = nxt; nxt = t;
+    }
+#undef HPGV_EPM_READ
+}
+
+}  // namespace hpgv

@@ -52,6 +52,7 @@ struct EpiState {
     int V = 0, nA = 0, nU = 0, num_folds = 0, W = 0, V_alloc = 0, n_chunks = 0;
     uint8_t *d_data = nullptr;
     uint32_t *d_planes = nullptr;
+    uint32_t rev_off = 0;             // words from the planes to their copy with the low seven bits of every byte reversed (0: none; k_epi_pairs_mfma's column side)
     uint32_t *d_marg = nullptr;       // per SNP and (fold, class) group: samples with genotype 0 / 1 (16 bits each)
     bool complete = false;            // the dataset holds no call other than 0 / 1 / 2
     hpgv::EpiChunk *d_chunks = nullptr;
@@ -96,6 +97,7 @@ struct hpgv_ctx {
     long pipe_waves = 4;       // register budget of the pipelined scan, as waves per SIMD (4, 6 or 8)
     long fisher_cut_exp = 22;  // Fisher tails stop after a round whose terms are all below 10^-this of the tail's largest term
     long epi_complete = 1;     // epistasis pair scan on a dataset without missing calls: count four cells, derive the other five
+    long epi_pairs_mfma = 1;   // epistasis pair ranking, <= 10 folds, data with missing calls: cell counts on the matrix cores (k_epi_pairs_mfma); 0 = k_epi_pairs
     long epi_triples_1pass = 1; // epistasis triple ranking with at most 10 folds: 1 = the 27 cells nine at a time (three walks, three waves per SIMD); 0 = the two-pass kernel; 2 (ablation build) = one pass with all counts in one lane
     long scan_lds = 0;         // bytes of (unused) LDS per workgroup of the stats / tdt scans: caps the waves in flight per CU
     long fisher_width = 16;    // lanes per variant in the Fisher p-pass (64, 32, 16 or 8): 64 / width variants per wave
