@@ -151,19 +151,23 @@ __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__res
     }
     // a (fold, class) group has ended: the accumulators hold its counts.  First pass: into the totals.  Second pass: into the
     // fold under way; when the fold has no further group, it is evaluated and the fold under way starts empty again.
-    auto bank = [&](int g, int pass) {
+    auto bank_totals = [&](int g) {
+        const int sh = (g & 1) * 16;
+        #pragma unroll
+        for (int c = 0; c < 9; c++) {
+            totp[c][0] += (uint32_t)acc[c].x << sh; totp[c][1] += (uint32_t)acc[c].y << sh;
+            totp[c][2] += (uint32_t)acc[c].z << sh; totp[c][3] += (uint32_t)acc[c].w << sh;
+            acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto bank_fold = [&](int g) {
         const int f = g >> 1, sh = (g & 1) * 16;
-        if (pass == 0) {
-            #pragma unroll
-            for (int c = 0; c < 9; c++) {
-                totp[c][0] += (uint32_t)acc[c].x << sh; totp[c][1] += (uint32_t)acc[c].y << sh;
-                totp[c][2] += (uint32_t)acc[c].z << sh; totp[c][3] += (uint32_t)acc[c].w << sh;
-            }
-        } else {
+        {
             #pragma unroll
             for (int c = 0; c < 9; c++) {
                 part[c][0] += (uint32_t)acc[c].x << sh; part[c][1] += (uint32_t)acc[c].y << sh;
                 part[c][2] += (uint32_t)acc[c].z << sh; part[c][3] += (uint32_t)acc[c].w << sh;
+                acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f};
             }
             EpiFold fo;
             fo.test_a = __builtin_amdgcn_readfirstlane((int)s_fold[f * 8]); fo.test_u = __builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + 1]);
@@ -218,47 +222,45 @@ __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__res
                     for (int q = 0; q < 4; q++) part[c][q] = 0;
             }
         }
-        #pragma unroll
-        for (int c = 0; c < 9; c++) acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f};
     };
 
-    // 2 x n_chunks chunks, one after the other (the same code for both passes); the next chunk's loads fly into the other
-    // buffer during the work on this one.  Inside a chunk the words are read from the image a step ahead and the next
-    // step's operand registers are made beside this step's MFMAs.
+    // n_chunks chunks, twice (a copy of the code per pass: what a group's end does differs; written as one loop the compiler
+    // merges the two with a select per register); the next chunk's loads fly into the other buffer during the work on this
+    // one.  Inside a chunk the words are read from the image a step ahead and the next step's operand registers are made
+    // beside this step's MFMAs.
     uint32_t *cur = lds_a, *nxt = lds_b;
-    for (int cc = 0; cc < 2 * n_chunks; cc++) {
-        const int c = cc < n_chunks ? cc : cc - n_chunks, pass = cc < n_chunks ? 0 : 1;
-        if (cc + 1 < 2 * n_chunks) {
-            const int cn = cc + 1 < n_chunks ? cc + 1 : cc + 1 - n_chunks;
-            load_chunk((uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[cn * 4]), nxt);
-        }
-        if (active) {
-            const int ns = __builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 1]) >> 2;
-            const uint64_t flush = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 2])      // wave-uniform
-                                   | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 3]) << 32);
-            const char *cur_bytes = reinterpret_cast<const char *>(cur);
-            uint32_t xa[3], xb[3];
-            HPGV_EPM_READ(xa, xb, 0)
-            epm_v8i A0[3], B0[3];
-            #pragma unroll
-            for (int a = 0; a < 3; a++) { A0[a] = epm_row_operand(xa[a]); B0[a] = epm_col_operand(xb[a]); }
-            for (int k = 0; k < ns; k++) {
-                uint32_t na[3], nb[3];
-                HPGV_EPM_READ(na, nb, k + 1)
-                #pragma unroll
-                for (int a = 0; a < 3; a++)
-                    #pragma unroll
-                    for (int b = 0; b < 3; b++) acc[a * 3 + b] = HPGV_EPM_MFMA(A0[a], B0[b], acc[a * 3 + b]);
-                #pragma unroll
-                for (int a = 0; a < 3; a++) { A0[a] = epm_row_operand(na[a]); B0[a] = epm_col_operand(nb[a]); }
-                const int g = (int)((flush >> (8 * k)) & 0xFFu);     // the same in every lane
-                if (g != 0xFF) bank(g, pass);                        // (clears the accumulators: starting a group's first MFMAs from a zero operand instead needs two copies of the step, and measured slower)
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's part of the next chunk has landed
-        __syncthreads();
-        uint32_t *t = cur; cur = nxt; nxt = t;
+#define HPGV_EPM_PASS(PASS)                                                                              \
+    for (int c = 0; c < n_chunks; c++) {                                                                 \
+        if (PASS == 0 || c + 1 < n_chunks)                                                               \
+            load_chunk((uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[(c + 1 < n_chunks ? c + 1 : 0) * 4]), nxt); \
+        if (active) {                                                                                    \
+            const int ns = __builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 1]) >> 2;                 \
+            const uint64_t flush = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 2])      /* wave-uniform */ \
+                                   | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 3]) << 32); \
+            const char *cur_bytes = reinterpret_cast<const char *>(cur);                                 \
+            uint32_t xa[3], xb[3];                                                                       \
+            HPGV_EPM_READ(xa, xb, 0)                                                                     \
+            epm_v8i A0[3], B0[3];                                                                        \
+            _Pragma("unroll") for (int a = 0; a < 3; a++) { A0[a] = epm_row_operand(xa[a]); B0[a] = epm_col_operand(xb[a]); } \
+            for (int k = 0; k < ns; k++) {                                                               \
+                uint32_t na[3], nb[3];                                                                   \
+                HPGV_EPM_READ(na, nb, k + 1)                                                             \
+                _Pragma("unroll") for (int a = 0; a < 3; a++)                                            \
+                    _Pragma("unroll") for (int b = 0; b < 3; b++) acc[a * 3 + b] = HPGV_EPM_MFMA(A0[a], B0[b], acc[a * 3 + b]); \
+                _Pragma("unroll") for (int a = 0; a < 3; a++) { A0[a] = epm_row_operand(na[a]); B0[a] = epm_col_operand(nb[a]); } \
+                const int g = (int)((flush >> (8 * k)) & 0xFFu);     /* the same in every lane */         \
+                /* (the banking clears the accumulators: starting a group's first MFMAs from a zero operand instead needs two \
+                   copies of the step, and measured slower) */                                           \
+                if (g != 0xFF) { if (PASS == 0) bank_totals(g); else bank_fold(g); }                     \
+            }                                                                                            \
+        }                                                                                                \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             /* this wave's part of the next chunk has landed */ \
+        __syncthreads();                                                                                 \
+        uint32_t *t = cur; cur = nxt; nxt = t;                                                           \
     }
+    HPGV_EPM_PASS(0)
+    HPGV_EPM_PASS(1)
+#undef HPGV_EPM_PASS
 #undef HPGV_EPM_READ
 }
 
