@@ -167,7 +167,7 @@ template <bool TRAINING, bool BALANCED>
 int epi_launch_pairs2(hpgv_ctx *ctx, int i_begin, int i_end, double *d_acc, uint16_t *d_mask, unsigned long long n_pairs_out,
                       unsigned long long rank_base, bool candidates, hipStream_t st) {
     EpiState &E = ctx->epi;
-    if (candidates && !d_acc && ctx->epi_pairs_mfma && E.rev_off && E.n_chunks <= hpgv::EPM_MAX_CHUNKS && E.nA < 65536 && E.nU < 65536 && !(E.complete && ctx->epi_complete))
+    if (candidates && !d_acc && ctx->epi_pairs_mfma && E.rev_off && E.n_chunks <= hpgv::EPM_MAX_CHUNKS && E.nA < 65536 && E.nU < 65536)
         return epi_launch_pairs_mfma<TRAINING, BALANCED>(ctx, i_begin, i_end, st);
     // tiles that hold at least one pair, numbered column tile by column tile: column tile tj0 + c pairs with the row
     // blocks from the band's first row down to the diagonal, min(row_blocks, 16 (c + 1)) of them

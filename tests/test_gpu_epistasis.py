@@ -261,6 +261,35 @@ def test_ranking_with_every_model_kept_is_the_dense_scan(eng, nA, nU, k):
             assert np.array_equal(res3["risky"][f][:n], np.array([rm3[f][triples[p]] for p in order], np.uint32))
 
 
+@pytest.mark.parametrize("v,nA,nU,k,p_missing", [(300, 2500, 1700, 3, 0.05), (200, 900, 900, 16, 0.02), (131, 1030, 1030, 10, 0.0),
+                                                  (97, 40, 3000, 2, 0.1), (260, 5000, 5000, 10, 0.01), (70, 129, 127, 12, 0.12)])
+def test_matrix_core_ranking_is_the_vector_alu_ranking(eng, v, nA, nU, k, p_missing):
+    # k_epi_pairs_mfma (cell counts as FP4 MFMAs, two passes) against k_epi_pairs (popcounts, one pass): several column
+    # tiles and row blocks, blocks on the diagonal, groups longer and shorter than a staging chunk, up to 16 folds, classes of
+    # equal and of unequal size, data with many, few and no missing calls; both subsets; a short list and every model
+    rng = np.random.default_rng(v + nA + 3 * k)
+    data = epi_random_dataset(rng, v, nA, nU, p_missing=p_missing)
+    data[7, :nA] = rng.choice([1, 2], size=nA); data[v - 3, :nA] = rng.choice([1, 2], size=nA)
+    data[11] = 1                                                     # a monomorphic SNP: empty cells everywhere
+    fold = epi_random_folds(rng, nA, nU, k)
+    eng.epi_set_dataset(data, nA, nU)
+    eng.epi_set_folds(fold, k)
+    try:
+        for subset in (hpgv.EPI_TESTING, hpgv.EPI_TRAINING):
+            for n in (25, v * (v - 1) // 2):
+                res = {}
+                for mfma in (1, 0):
+                    eng.set_option("epi_pairs_mfma", mfma)
+                    res[mfma] = eng.epi_rank_pairs(subset, n)
+                for f in range(k):
+                    m = int(res[0]["n"][f])
+                    assert int(res[1]["n"][f]) == m and m > 0
+                    for key in ("i", "j", "accuracy", "risky"):
+                        assert np.array_equal(res[1][key][f][:m], res[0][key][f][:m]), (key, f, subset, n)
+    finally:
+        eng.set_option("epi_pairs_mfma", 1)
+
+
 def test_epistasis_error_paths(eng):
     e = hpgv.Engine(0)
     with pytest.raises(hpgv.HpgvError):
