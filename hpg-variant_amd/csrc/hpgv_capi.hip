@@ -385,6 +385,8 @@ int hpgv_set_option(hpgv_ctx *ctx, const char *key, long value) {
         ctx->fisher_cut_exp = value;
     } else if (!strcmp(key, "epi_complete")) {
         ctx->epi_complete = value ? 1 : 0;
+    } else if (!strcmp(key, "epi_triples_mfma")) {
+        ctx->epi_triples_mfma = value ? 1 : 0;
     } else if (!strcmp(key, "epi_pairs_mfma")) {
         ctx->epi_pairs_mfma = value ? 1 : 0;
     } else if (!strcmp(key, "epi_triples_1pass")) {

@@ -599,8 +599,35 @@ int epi_launch_triples(hpgv_ctx *ctx, int i_first, int n_i, double *d_acc, uint3
     unsigned *d_jbp = E.d_tile_base, *d_rb = E.d_tile_base + jbp.size();
     HIPCHK(ctx, hipMemcpyAsync(d_jbp, jbp.data(), jbp.size() * sizeof(unsigned), hipMemcpyHostToDevice, nullptr));
     HIPCHK(ctx, hipMemcpyAsync(d_rb, rb.data(), rb.size() * sizeof(unsigned), hipMemcpyHostToDevice, nullptr));
-    const dim3 grid((unsigned)total);
     const bool balanced = E.nA == E.nU && E.nA < (1 << 22);
+    // ranking, at most 10 folds, classes below 65 536 samples: the cell counts on the matrix cores (hpgv_epi_mfma_kernels.h:
+    // k_epi_triples_mfma), tiles of one first SNP x 16 second x 64 third
+    if (ctx->epi_triples_mfma && candidates && !d_acc && E.rev_off && E.n_chunks <= hpgv::EPM_MAX_CHUNKS && E.num_folds <= 10 && E.nA < 65536 && E.nU < 65536) {
+        const int n_jb16 = (E.V + hpgv::EPM_TI - 1) / hpgv::EPM_TI;
+        std::vector<unsigned> jbp16((size_t)n_jb16 + 1), rb16((size_t)n_i + 1);
+        unsigned long long acc16 = 0;
+        for (int jb = 0; jb < n_jb16; ++jb) { jbp16[(size_t)jb] = (unsigned)acc16; acc16 += (unsigned long long)std::max(0, n_kt - ((hpgv::EPM_TI * jb + 1) >> 6)); }
+        jbp16[(size_t)n_jb16] = (unsigned)acc16;
+        unsigned long long total16 = 0;
+        for (int r = 0; r < n_i; ++r) {
+            rb16[(size_t)r] = (unsigned)total16;
+            total16 += acc16 - jbp16[(size_t)std::min(n_jb16, (i_first + r + 1) >> 4)];
+        }
+        rb16[(size_t)n_i] = (unsigned)total16;
+        if (total16 == 0) return HPGV_OK;
+        if (total16 > (0x7FFFFFFFull >> 8)) return fail(ctx, HPGV_ERR_UNSUPPORTED, "too many first SNPs for one launch of the triple scan");
+        HIPCHK(ctx, hipMemcpyAsync(d_jbp, jbp16.data(), jbp16.size() * sizeof(unsigned), hipMemcpyHostToDevice, nullptr));    // (no longer than the lists above: same buffer)
+        HIPCHK(ctx, hipMemcpyAsync(d_rb, rb16.data(), rb16.size() * sizeof(unsigned), hipMemcpyHostToDevice, nullptr));
+#define HPGV_EPM3_LAUNCH(KK, BAL)                                                                                                               \
+        hipLaunchKernelGGL((hpgv::k_epi_triples_mfma<KK, TRAINING, BAL>), dim3((unsigned)total16), dim3(256), 0, nullptr, E.d_planes, E.rev_off, E.W, E.V, i_first, d_rb, n_i, \
+                           d_jbp, n_jb16, E.d_chunks, E.n_chunks, E.d_folds, E.num_folds, E.nA, E.nU, E.d_thr, d_cand, E.d_cand_count, cap)
+        if (E.num_folds <= 5) { if (balanced) HPGV_EPM3_LAUNCH(5, true); else HPGV_EPM3_LAUNCH(5, false); }
+        else { if (balanced) HPGV_EPM3_LAUNCH(10, true); else HPGV_EPM3_LAUNCH(10, false); }
+#undef HPGV_EPM3_LAUNCH
+        HIPCHK(ctx, hipGetLastError());
+        return HPGV_OK;
+    }
+    const dim3 grid((unsigned)total);
     // ranking, at most 10 folds, classes below 65 536 samples: the 27 cells nine at a time (hpgv_epi_triples3_kernels.h): three walks
     // over the samples with a third of the state each, three waves per SIMD
     if (ctx->epi_triples_1pass == 1 && candidates && !d_acc && E.num_folds <= 10 && E.nA < 65536 && E.nU < 65536) {

@@ -264,4 +264,230 @@ __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__res
 #undef HPGV_EPM_READ
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Triples (i, j, k), i < j < k, on the matrix cores.  For a fixed first SNP i and a fixed genotype a of it, the nine cells
+// (a, b, c) of the triples of 16 second SNPs j x 16 third SNPs k are nine products again: A = plane_i[a] & plane_j[b]
+// (one more AND per word), B = plane_k[c].  A wave owns (i, 16 j, 16 k) -- four triples per lane --, walks the samples once
+// per genotype a like k_epi_triples3 (a cell's verdict is its own: it only adds to its fold's TP | FP sum and high-risk
+// bits), and every walk is k_epi_pairs_mfma's two passes.  Across the walks a lane keeps K x 4 sums and masks; everything
+// else is the pair kernel's state, so two waves share a SIMD here too.  Image: 64 k columns (swapped copy) + 16 j rows + the
+// i row, three planes each.  Tiles: first SNP i, then the j blocks of 16 from (i + 1) / 16 on, then the k tiles of 64 from the
+// one that holds 16 jb + 1 on (row_base / jb_prefix as k_epi_triples3's, with blocks of 16).
+template <int K, bool TRAINING, bool BALANCED>
+__global__ void __launch_bounds__(256, 2) k_epi_triples_mfma(const uint32_t *__restrict__ planes, uint32_t rev_off, int W, int n_variants, int i_first,
+                                                           const unsigned *__restrict__ row_base /* n_i + 1 */, int n_i,
+                                                           const unsigned *__restrict__ jb_prefix /* n_jb + 1 */, int n_jb,
+                                                           const EpiChunk *__restrict__ chunks, int n_chunks,
+                                                           const EpiFold *__restrict__ folds, int num_folds, int n_affected, int n_unaffected,
+                                                           const double *__restrict__ thr, EpiCand3 *__restrict__ cand,
+                                                           unsigned *__restrict__ cand_count, unsigned cand_cap) {
+    constexpr int SNPS = EPI_TJ + EPM_TI + 1, ROWS = SNPS * 3, NDMA = (ROWS + 7) / 8;     // 81 SNPs, 243 rows, 31 LDS-DMA instructions per chunk
+    __shared__ __attribute__((aligned(16))) uint32_t lds_a[NDMA * 8 * EPI_CH];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_b[NDMA * 8 * EPI_CH];
+    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[EPM_MAX_CHUNKS * 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_fold[EPI_MAX_FOLDS * 8];
+    int r_lo = 0, r_hi = n_i;
+    while (r_hi - r_lo > 1) { const int mid = (r_lo + r_hi) >> 1; if (row_base[mid] <= blockIdx.x) r_lo = mid; else r_hi = mid; }
+    const int i = i_first + r_lo;
+    const int jb_min = (i + 1) >> 4;
+    const unsigned want = (blockIdx.x - row_base[r_lo]) + jb_prefix[jb_min];
+    int b_lo = jb_min, b_hi = n_jb;
+    while (b_hi - b_lo > 1) { const int mid = (b_lo + b_hi) >> 1; if (jb_prefix[mid] <= want) b_lo = mid; else b_hi = mid; }
+    const int j0 = b_lo * EPM_TI;
+    const int kt = (((j0 + 1) >> 6) + (int)(want - jb_prefix[b_lo])) * EPI_TJ;
+    for (int q = threadIdx.x; q < n_chunks * 4; q += 256) s_chunk[q] = reinterpret_cast<const uint32_t *>(chunks)[q];
+    for (int q = threadIdx.x; q < num_folds * 8; q += 256) {
+        const int f = q >> 3, e = q & 7;
+        s_fold[q] = e < 6 ? reinterpret_cast<const uint32_t *>(folds + f)[e] : reinterpret_cast<const uint32_t *>(thr + f)[e - 6];
+    }
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 15, h = lane >> 4;
+    const int k0 = kt + 16 * wave, k = k0 + r;
+    const bool active = k0 + 15 > j0 && j0 + 15 > i;                 // is any triple of this wave's block in order
+    uint32_t dma_off[8];
+    #pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int d = wave + 4 * q, row8 = 8 * d + (lane >> 3), row = row8 < ROWS ? row8 : 0;
+        const int snp_idx = row / 3, plane = row % 3;
+        const int piece = (lane & 7) ^ ((snp_idx >> 1) & 7);
+        const int snp = snp_idx < EPI_TJ ? kt + snp_idx : snp_idx < EPI_TJ + EPM_TI ? j0 + (snp_idx - EPI_TJ) : i;
+        dma_off[q] = ((uint32_t)snp * 3u + (uint32_t)plane) * (uint32_t)W + (uint32_t)piece * 4u + (snp_idx < EPI_TJ ? rev_off : 0u);
+    }
+    auto load_chunk = [&](uint32_t w0, uint32_t *dst) {
+        #pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int d = wave + 4 * q;
+            if (d < NDMA)
+                __builtin_amdgcn_global_load_lds(planes + (dma_off[q] + w0), (__attribute__((address_space(3))) uint32_t *)(dst + 8 * d * EPI_CH), 16, 0, 0);
+        }
+    };
+    load_chunk(chunks[0].w0, lds_a);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int sj = EPI_TJ + r, sk = 16 * wave + r, si = EPI_TJ + EPM_TI;
+    const int base_j = sj * 3 * (EPI_CH * 4) + h * 4, base_k = sk * 3 * (EPI_CH * 4) + h * 4, base_i = si * 3 * (EPI_CH * 4) + h * 4;
+    const int swz = (sj >> 1) & 7, swz_i = (si >> 1) & 7;            // ((sk >> 1) & 7 is the same value)
+    const float f_na = (float)(unsigned)n_affected, f_nu = (float)(unsigned)n_unaffected;
+    const float ratio = f_na / f_nu;
+    bool asked[4];
+    #pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int j = j0 + 4 * h + q;
+        asked[q] = j > i && k > j && j < n_variants && k < n_variants;
+    }
+    uint32_t sel[K][4], mask[K][4];                                  // per fold and triple: TP (low half) | FP (high half); the high-risk cells
+    #pragma unroll
+    for (int f = 0; f < K; f++)
+        #pragma unroll
+        for (int q = 0; q < 4; q++) { sel[f][q] = 0; mask[f][q] = 0; }
+
+    uint32_t *cur = lds_a, *nxt = lds_b;
+    #pragma unroll 1
+    for (int a = 0; a < 3; a++) {
+        epm_v4f acc[9];
+        uint32_t totp[9][4], part[9][4];
+        #pragma unroll
+        for (int c = 0; c < 9; c++) {
+            acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f};
+            #pragma unroll
+            for (int q = 0; q < 4; q++) { totp[c][q] = 0; part[c][q] = 0; }
+        }
+        auto bank_totals = [&](int g) {
+            const int sh = (g & 1) * 16;
+            #pragma unroll
+            for (int c = 0; c < 9; c++) {
+                totp[c][0] += (uint32_t)acc[c].x << sh; totp[c][1] += (uint32_t)acc[c].y << sh;
+                totp[c][2] += (uint32_t)acc[c].z << sh; totp[c][3] += (uint32_t)acc[c].w << sh;
+                acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        auto bank_fold = [&](int g) {
+            const int f = g >> 1, sh = (g & 1) * 16;
+            #pragma unroll
+            for (int c = 0; c < 9; c++) {
+                part[c][0] += (uint32_t)acc[c].x << sh; part[c][1] += (uint32_t)acc[c].y << sh;
+                part[c][2] += (uint32_t)acc[c].z << sh; part[c][3] += (uint32_t)acc[c].w << sh;
+                acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f};
+            }
+            const int test_u = __builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + 1]);
+            if ((g & 1) || test_u <= 0) {                            // the fold's last group: the nine cells' verdicts
+                uint32_t ds[4], dm[4];
+                #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    ds[q] = 0; dm[q] = 0;
+                    #pragma unroll
+                    for (int c = 0; c < 9; c++) {
+                        const uint32_t in = part[c][q], tr = totp[c][q] - in;
+                        bool high;
+                        if constexpr (BALANCED) high = __builtin_amdgcn_alignbit(tr, tr, 16) >= (TRAINING ? tr : (tr > 1u ? tr : 1u));   // as k_epi_pairs
+                        else high = mdr_high_risk<false>((int)(tr & 0xFFFFu), (int)(tr >> 16), ratio, f_na, f_nu);
+                        ds[q] += high ? (TRAINING ? tr : in) : 0u;
+                        // (balanced, training part: an EMPTY cell passes the packed comparison and adds nothing to the sums; it is not high risk)
+                        dm[q] |= (high && tr != 0u) ? 1u << c : 0u;
+                        part[c][q] = 0;
+                    }
+                    dm[q] <<= 9 * a;
+                }
+                switch (f) {
+#define HPGV_EPM_CASE(FF)                                                                                \
+                    case FF:                                                                             \
+                        if constexpr (FF < K) {                                                          \
+                            _Pragma("unroll") for (int q = 0; q < 4; q++) { sel[FF < K ? FF : 0][q] += ds[q]; mask[FF < K ? FF : 0][q] |= dm[q]; } \
+                        }                                                                                \
+                        break;
+                    HPGV_EPM_CASE(0) HPGV_EPM_CASE(1) HPGV_EPM_CASE(2) HPGV_EPM_CASE(3) HPGV_EPM_CASE(4)
+                    HPGV_EPM_CASE(5) HPGV_EPM_CASE(6) HPGV_EPM_CASE(7) HPGV_EPM_CASE(8) HPGV_EPM_CASE(9)
+#undef HPGV_EPM_CASE
+                    default: break;
+                }
+            }
+        };
+#define HPGV_EPM3_READ(XI, YJ, ZK, KSTEP)                                                                \
+        {                                                                                                \
+            const int k_ = (KSTEP) < 7 ? (KSTEP) : 7;                                                    \
+            const char *qj = cur_bytes + (base_j + ((k_ ^ swz) << 4)), *qk = cur_bytes + (base_k + ((k_ ^ swz) << 4)); \
+            XI = *reinterpret_cast<const uint32_t *>(cur_bytes + (base_i + ((k_ ^ swz_i) << 4)) + a * (EPI_CH * 4)); \
+            _Pragma("unroll") for (int b = 0; b < 3; b++) {                                              \
+                YJ[b] = *reinterpret_cast<const uint32_t *>(qj + b * (EPI_CH * 4)); ZK[b] = *reinterpret_cast<const uint32_t *>(qk + b * (EPI_CH * 4)); \
+            }                                                                                            \
+        }
+#define HPGV_EPM3_PASS(PASS)                                                                             \
+        for (int c = 0; c < n_chunks; c++) {                                                             \
+            if (!(PASS == 1 && a == 2 && c + 1 == n_chunks))                                             \
+                load_chunk((uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[(c + 1 < n_chunks ? c + 1 : 0) * 4]), nxt); \
+            if (active) {                                                                                \
+                const int ns = __builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 1]) >> 2;             \
+                const uint64_t flush = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 2]) \
+                                       | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 3]) << 32); \
+                const char *cur_bytes = reinterpret_cast<const char *>(cur);                             \
+                uint32_t xi, yj[3], zk[3];                                                               \
+                HPGV_EPM3_READ(xi, yj, zk, 0)                                                            \
+                epm_v8i A0[3], B0[3];                                                                    \
+                _Pragma("unroll") for (int b = 0; b < 3; b++) { A0[b] = epm_row_operand(xi & yj[b]); B0[b] = epm_col_operand(zk[b]); } \
+                for (int st = 0; st < ns; st++) {                                                        \
+                    uint32_t nxi, nyj[3], nzk[3];                                                        \
+                    HPGV_EPM3_READ(nxi, nyj, nzk, st + 1)                                                \
+                    _Pragma("unroll") for (int b = 0; b < 3; b++)                                        \
+                        _Pragma("unroll") for (int d = 0; d < 3; d++) acc[b * 3 + d] = HPGV_EPM_MFMA(A0[b], B0[d], acc[b * 3 + d]); \
+                    _Pragma("unroll") for (int b = 0; b < 3; b++) { A0[b] = epm_row_operand(nxi & nyj[b]); B0[b] = epm_col_operand(nzk[b]); } \
+                    const int g = (int)((flush >> (8 * st)) & 0xFFu);                                    \
+                    if (g != 0xFF) { if (PASS == 0) bank_totals(g); else bank_fold(g); }                 \
+                }                                                                                        \
+            }                                                                                            \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+            __syncthreads();                                                                             \
+            uint32_t *t = cur; cur = nxt; nxt = t;                                                       \
+        }
+        HPGV_EPM3_PASS(0)
+        HPGV_EPM3_PASS(1)
+#undef HPGV_EPM3_PASS
+#undef HPGV_EPM3_READ
+    }
+    if (!active) return;
+
+    #pragma unroll 1
+    for (int f = 0; f < K; f++) {
+        if (f >= num_folds) break;
+        uint32_t s4[4], m4[4];
+        switch (f) {
+#define HPGV_EPM_CASE(FF)                                                                                \
+            case FF:                                                                                     \
+                if constexpr (FF < K) { _Pragma("unroll") for (int q = 0; q < 4; q++) { s4[q] = sel[FF < K ? FF : 0][q]; m4[q] = mask[FF < K ? FF : 0][q]; } } \
+                break;
+            HPGV_EPM_CASE(0) HPGV_EPM_CASE(1) HPGV_EPM_CASE(2) HPGV_EPM_CASE(3) HPGV_EPM_CASE(4)
+            HPGV_EPM_CASE(5) HPGV_EPM_CASE(6) HPGV_EPM_CASE(7) HPGV_EPM_CASE(8) HPGV_EPM_CASE(9)
+#undef HPGV_EPM_CASE
+            default:
+                #pragma unroll
+                for (int q = 0; q < 4; q++) { s4[q] = 0; m4[q] = 0; }
+                break;
+        }
+        EpiFold fo;
+        fo.test_a = __builtin_amdgcn_readfirstlane((int)s_fold[f * 8]); fo.test_u = __builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + 1]);
+        if (fo.test_a < 0) continue;
+        fo.inv_a = __builtin_bit_cast(double, (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + 2]) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + 3]) << 32));
+        fo.inv_u = __builtin_bit_cast(double, (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + 4]) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + 5]) << 32));
+        const double thr_f = __builtin_bit_cast(double, (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + 6]) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + 7]) << 32));
+        const int size_a = TRAINING ? n_affected - fo.test_a : fo.test_a, size_u = TRAINING ? n_unaffected - fo.test_u : fo.test_u;
+        #pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (!asked[q]) continue;
+            const int tp = (int)(s4[q] & 0xFFFFu), fp = (int)(s4[q] >> 16);
+            const double TP = (double)tp, TN = (double)(size_u - fp), ya_ = (double)size_a, yu_ = (double)size_u;
+            double qa = TP * fo.inv_a, qu = TN * fo.inv_u;           // the two quotients as in k_epi_pairs (Markstein)
+            qa = __builtin_fma(__builtin_fma(-qa, ya_, TP), fo.inv_a, qa);
+            qu = __builtin_fma(__builtin_fma(-qu, yu_, TN), fo.inv_u, qu);
+            const double accy = (qa + qu) / 2;
+            if (accy >= thr_f) {
+                const unsigned slot = atomicAdd(&cand_count[f], 1u);
+                if (slot < cand_cap) {
+                    EpiCand3 e;
+                    e.accuracy = accy; e.i = i; e.j = j0 + 4 * h + q; e.k = k; e.risky = m4[q];
+                    cand[(size_t)f * cand_cap + slot] = e;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace hpgv

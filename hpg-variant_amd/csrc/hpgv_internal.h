@@ -98,6 +98,7 @@ struct hpgv_ctx {
     long fisher_cut_exp = 22;  // Fisher tails stop after a round whose terms are all below 10^-this of the tail's largest term
     long epi_complete = 1;     // epistasis pair scan on a dataset without missing calls: count four cells, derive the other five
     long epi_pairs_mfma = 1;   // epistasis pair ranking, <= 10 folds, data with missing calls: cell counts on the matrix cores (k_epi_pairs_mfma); 0 = k_epi_pairs
+    long epi_triples_mfma = 1; // epistasis triple ranking, <= 10 folds: cell counts on the matrix cores (k_epi_triples_mfma); 0 = the vector-ALU scans below
     long epi_triples_1pass = 1; // epistasis triple ranking with at most 10 folds: 1 = the 27 cells nine at a time (three walks, three waves per SIMD); 0 = the two-pass kernel; 2 (ablation build) = one pass with all counts in one lane
     long scan_lds = 0;         // bytes of (unused) LDS per workgroup of the stats / tdt scans: caps the waves in flight per CU
     long fisher_width = 16;    // lanes per variant in the Fisher p-pass (64, 32, 16 or 8): 64 / width variants per wave

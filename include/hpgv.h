@@ -93,7 +93,7 @@ const char *hpgv_last_error(const hpgv_ctx *ctx);
  *   "batch_fused" 0/1, "batch_copy" 0/1   per-batch host entry points: one fused kernel reading page-locked rows in place
  *                                (default) / the kernel chain / copy the rows first
  *   "epi_complete" 0/1, "epi_triples_1pass" 0/1     epistasis scans: the shortcuts for data without missing calls / <= 10 folds
- *   "epi_pairs_mfma" 0/1 (default 1)                 epistasis pair ranking: cell counts on the matrix cores (0: the vector-ALU scan)
+ *   "epi_pairs_mfma", "epi_triples_mfma" 0/1 (default 1)   epistasis pair / triple ranking: cell counts on the matrix cores (0: the vector-ALU scans)
  *   "group_self_exchange" 0/1    (group contexts; tests) member 0 hands its results over through the communicator too
  * Every kernel ships in ONE form.  The forms that lost their A/B comparisons (profiles/experiments_that_did_not_pay.md) are
  * compiled only into an ablation build (-DHPGV_ABLATION: tools/build_ablation.py, used by tools/ only); there the keys
