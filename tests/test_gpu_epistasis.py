@@ -290,6 +290,34 @@ def test_matrix_core_ranking_is_the_vector_alu_ranking(eng, v, nA, nU, k, p_miss
         eng.set_option("epi_pairs_mfma", 1)
 
 
+@pytest.mark.parametrize("v,nA,nU,k,p_missing", [(70, 700, 500, 3, 0.05), (40, 900, 900, 10, 0.02), (66, 260, 260, 5, 0.0), (33, 40, 1500, 2, 0.1)])
+def test_matrix_core_triple_ranking_is_the_vector_alu_ranking(eng, v, nA, nU, k, p_missing):
+    # k_epi_triples_mfma against k_epi_triples3 / k_epi_triples: blocks of 16 second SNPs on and off the diagonals, third SNPs
+    # in one and in two tiles of 64, groups longer and shorter than a staging chunk, equal and unequal classes; both subsets; a
+    # short list and every model
+    rng = np.random.default_rng(v + nA + 3 * k)
+    data = epi_random_dataset(rng, v, nA, nU, p_missing=p_missing)
+    data[2, :nA] = rng.choice([1, 2], size=nA); data[v // 2, :nA] = rng.choice([1, 2], size=nA); data[v - 2, :nA] = rng.choice([1, 2], size=nA)
+    data[5] = 1                                                      # a monomorphic SNP: empty cells everywhere
+    fold = epi_random_folds(rng, nA, nU, k)
+    eng.epi_set_dataset(data, nA, nU)
+    eng.epi_set_folds(fold, k)
+    try:
+        for subset in (hpgv.EPI_TESTING, hpgv.EPI_TRAINING):
+            for n in (25, v * (v - 1) * (v - 2) // 6):
+                res = {}
+                for mfma in (1, 0):
+                    eng.set_option("epi_triples_mfma", mfma)
+                    res[mfma] = eng.epi_rank_triples(subset, n)
+                for f in range(k):
+                    m = int(res[0]["n"][f])
+                    assert int(res[1]["n"][f]) == m and m > 0
+                    for key in ("i", "j", "k", "accuracy", "risky"):
+                        assert np.array_equal(res[1][key][f][:m], res[0][key][f][:m]), (key, f, subset, n)
+    finally:
+        eng.set_option("epi_triples_mfma", 1)
+
+
 def test_epistasis_error_paths(eng):
     e = hpgv.Engine(0)
     with pytest.raises(hpgv.HpgvError):
