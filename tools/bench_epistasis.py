@@ -55,11 +55,23 @@ if ORDER == 3:
     words = (-(-(nA // K) // 128) + -(-(nU // K) // 128)) * 4 * K
     wave_instr = triples * words * 54 / 64
     peak = 256 * 4 * CLOCK_GHZ * 1e9 / 4
-    print(json.dumps({"order": 3, "V": V, "samples": N, "affected": nA, "folds": K, "triples": triples, "wall_s": round(wall, 4), "scan_ms": round(scan_ms, 3),
-                      "triples_per_s": triples / (scan_ms * 1e-3),
-                      "roofline": {"bound": "valu", "achieved": wave_instr / (scan_ms * 1e-3) / 1e9, "peak": peak / 1e9,
-                                   "unit": "G wave64 VALU instructions/s", "frac": wave_instr / (scan_ms * 1e-3) / peak,
-                                   "algorithmic_ops_per_triple_word": 54}}))
+    line = {"order": 3, "V": V, "samples": N, "affected": nA, "folds": K, "triples": triples, "wall_s": round(wall, 4), "scan_ms": round(scan_ms, 3),
+            "triples_per_s": triples / (scan_ms * 1e-3),
+            "roofline": {"bound": "valu", "achieved": wave_instr / (scan_ms * 1e-3) / 1e9, "peak": peak / 1e9,
+                         "unit": "G wave64 VALU instructions/s", "frac": wave_instr / (scan_ms * 1e-3) / peak,
+                         "algorithmic_ops_per_triple_word": 54}}
+    opts = dict(a[len('--option='):].split('=') for a in sys.argv[1:] if a.startswith('--option='))
+    if int(opts.get("epi_triples_mfma", 1)) and K <= 10:
+        # the matrix-core scan (k_epi_triples_mfma): 27 cells x samples (padded) x 2 flop per triple are the algorithm's; dense FP4
+        # peak from MI355X_MICROARCH.md (see the pair line's note on the issue rate measured here)
+        flops = triples * 27 * words * 32 * 2
+        line["kernel"] = "k_epi_triples_mfma"
+        line["roofline_vector_scan_equivalent"] = line["roofline"]
+        line["roofline"] = {"bound": "mfma", "achieved": flops / (scan_ms * 1e-3) / 1e12, "peak": 10000.0, "unit": "TFLOP/s (FP4, dense)",
+                            "frac": flops / (scan_ms * 1e-3) / 1e16, "algorithmic_flop_per_triple_and_sample": 54}
+    else:
+        line["kernel"] = "k_epi_triples3" if K <= 10 and int(opts.get("epi_triples_1pass", 1)) else "k_epi_triples"
+    print(json.dumps(line))
     e.close()
     sys.exit(0)
 e.epi_rank_pairs(hpgv.EPI_TESTING, 10)                        # warm

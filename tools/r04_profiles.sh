@@ -12,9 +12,15 @@ for args in "16384 10000 10" "16384 10000 10 --option=epi_pairs_mfma=0" "16384 1
   timeout -k 10 300 python3 tools/bench_epistasis.py $args >> $P || exit 1
 done
 T=$O/r04_epi3_bench.jsonl; : > $T
-for args in "1024 10000 10 --order=3" "1024 10000 5 --order=3" "512 10000 10 --order=3 --unbalanced" "1024 10000 10 --order=3 --option=epi_triples_1pass=0"; do
+for args in "1024 10000 10 --order=3 --option=epi_triples_mfma=0" "1024 10000 5 --order=3 --option=epi_triples_mfma=0" "512 10000 10 --order=3 --unbalanced --option=epi_triples_mfma=0" \
+            "1024 10000 10 --order=3 --option=epi_triples_mfma=0 --option=epi_triples_1pass=0"; do
   timeout -k 10 600 python3 tools/bench_epistasis.py $args >> $T || exit 1
 done
+T3=$O/r04_epi3_mfma_bench.jsonl; : > $T3
+for args in "1024 10000 10 --order=3" "1024 10000 5 --order=3" "512 10000 10 --order=3 --unbalanced" "2048 10000 10 --order=3" "1024 100000 10 --order=3"; do
+  timeout -k 10 600 python3 tools/bench_epistasis.py $args >> $T3 || exit 1
+done
+cat $T3 | cut -c1-220
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/r04_epm_stats -o epm --output-format csv -- python3 $R/tools/bench_epistasis.py 16384 10000 10 > $O/r04_epm_stats.json 2> $O/r04_epm_stats.err || exit 1
 bash $R/tools/epm_prof.sh > $O/r04_epm_counters.txt 2>&1 || exit 1
