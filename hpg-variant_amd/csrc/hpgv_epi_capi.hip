@@ -107,7 +107,10 @@ int epi_build_folds(hpgv_ctx *ctx, const int32_t *fold_of_sample, int num_folds)
     if (e == hipSuccess) e = hipMalloc(&d_flag, sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(d_flag, 0, sizeof(unsigned));
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(hpgv::k_epi_planes, dim3((unsigned)E.V_alloc), dim3(256), 0, nullptr, E.d_data, E.V, n, d_src, E.W, E.d_planes, d_flag);
+        if (n <= 65000)                                              // the row goes through LDS
+            hipLaunchKernelGGL(hpgv::k_epi_planes, dim3((unsigned)E.V_alloc), dim3(256), (size_t)n + 8, nullptr, E.d_data, E.V, n, d_src, E.W, E.d_planes, d_flag);
+        else
+            hipLaunchKernelGGL(hpgv::k_epi_planes_gather, dim3((unsigned)E.V_alloc), dim3(256), 0, nullptr, E.d_data, E.V, n, d_src, E.W, E.d_planes, d_flag);
         // genotype counts per SNP and group: what the complete-data pair scan derives the cells with a genotype 2 from
         hipLaunchKernelGGL(hpgv::k_epi_marginals, dim3((unsigned)E.V_alloc), dim3(256), 0, nullptr, E.d_planes, E.W, E.d_group_w0, num_folds * 2, E.d_marg);
         if (E.rev_off)                                               // the column side's copy for the matrix-core pair scan

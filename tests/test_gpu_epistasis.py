@@ -73,7 +73,7 @@ def test_confusion_reference_kats_through_the_pair_scan(eng, goldens):
 
 
 @pytest.mark.parametrize("v,nA,nU,k", [(70, 37, 52, 5), (9, 16, 16, 2), (130, 300, 420, 10), (65, 5, 4, 3), (40, 1100, 1300, 4),
-                                       (33, 64, 64, 1), (20, 700, 650, 16), (12, 2500, 2300, 8)])
+                                       (33, 64, 64, 1), (20, 700, 650, 16), (12, 2500, 2300, 8), (6, 36000, 34000, 2)])   # (the last: rows too long for the LDS form of the plane builder)
 def test_pair_scan_matches_the_oracle(eng, v, nA, nU, k):
     rng = np.random.default_rng(v * 7 + k)
     data = epi_random_dataset(rng, v, nA, nU, p_missing=0.03)
