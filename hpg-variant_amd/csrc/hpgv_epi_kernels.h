@@ -168,7 +168,8 @@ __device__ __forceinline__ bool mdr_high_risk(int count_aff, int count_unaff, fl
         const float p1 = ca * f_nu, p2 = cu * f_na;
         const float d = p1 - p2, tol = (p1 + p2) * 0x1p-16f;
         if (__builtin_fabsf(d) > tol) return d > 0.0f;
-        return mdr_high_risk_exact(ca, cu, ratio);
+        if ((count_aff | count_unaff) == 0) return false;            // the empty cell (0 / 0 = NaN in the sequence: false) -- common enough that
+        return mdr_high_risk_exact(ca, cu, ratio);                   // without this line some lane of nearly every wave takes the division
     }
 }
 
