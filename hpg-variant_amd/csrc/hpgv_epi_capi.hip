@@ -17,6 +17,8 @@ void epi_free_folds(EpiState &E) {
     if (E.d_marg) (void)hipFree(E.d_marg);
     E.d_marg = nullptr;
     if (E.d_chunks) (void)hipFree(E.d_chunks);
+    if (E.d_chunk_cls) (void)hipFree(E.d_chunk_cls);
+    E.d_chunk_cls = nullptr;
     if (E.d_folds) (void)hipFree(E.d_folds);
     if (E.d_group_w0) (void)hipFree(E.d_group_w0);
     E.rev_off = 0;
@@ -70,6 +72,7 @@ int epi_build_folds(hpgv_ctx *ctx, const int32_t *fold_of_sample, int num_folds)
     // staging blocks of up to EPI_CH words; a block may hold the runs of several groups: byte s of `flush` names the
     // group whose run ends with the block's step s
     std::vector<hpgv::EpiChunk> chunks;
+    std::vector<uint32_t> chunk_cls;
     const size_t n_steps = group_of_step.size(), steps_per_block = hpgv::EPI_CH / 4;
     for (size_t s0 = 0; s0 < n_steps; s0 += steps_per_block) {
         hpgv::EpiChunk c;
@@ -80,6 +83,9 @@ int epi_build_folds(hpgv_ctx *ctx, const int32_t *fold_of_sample, int num_folds)
             if (last_of_group) c.flush = (c.flush & ~(0xFFull << (8 * k))) | ((uint64_t)group_of_step[s0 + k] << (8 * k));
         }
         chunks.push_back(c);
+        uint32_t m = 0;                                              // bit k: step k of the block holds controls (k_epi_pairs_mfma's first pass)
+        for (size_t k = 0; k < ns; ++k) if (group_of_step[s0 + k] >= 0 && (group_of_step[s0 + k] & 1)) m |= 1u << k;
+        chunk_cls.push_back(m);
     }
     E.W = (int)(src.size() / 32);
     E.num_folds = num_folds;
@@ -98,6 +104,8 @@ int epi_build_folds(hpgv_ctx *ctx, const int32_t *fold_of_sample, int num_folds)
     if (e == hipSuccess) e = hipMalloc(&E.d_planes, (plane_words + E.rev_off) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&E.d_chunks, chunks.size() * sizeof(hpgv::EpiChunk));
     if (e == hipSuccess) e = hipMemcpy(E.d_chunks, chunks.data(), chunks.size() * sizeof(hpgv::EpiChunk), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&E.d_chunk_cls, chunk_cls.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(E.d_chunk_cls, chunk_cls.data(), chunk_cls.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&E.d_folds, hpgv::EPI_MAX_FOLDS * sizeof(hpgv::EpiFold));
     if (e == hipSuccess) e = hipMalloc(&E.d_group_w0, w0.size() * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(E.d_group_w0, w0.data(), w0.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
@@ -161,7 +169,7 @@ int epi_launch_pairs_mfma(hpgv_ctx *ctx, int i_begin, int i_end, hipStream_t st)
     }
     HIPCHK(ctx, hipMemcpyAsync(E.d_folds, folds, sizeof folds, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL((hpgv::k_epi_pairs_mfma<TRAINING, BALANCED>), grid, dim3(256), 0, st, E.d_planes, E.rev_off, E.W,
-                       E.V, i_begin, i_first, i_end, E.d_tile_base, n_cols, n_tiles, E.d_chunks, E.n_chunks, E.d_folds, E.num_folds, E.nA, E.nU, E.d_thr, E.d_cand, E.d_cand_count, E.cand_cap);
+                       E.V, i_begin, i_first, i_end, E.d_tile_base, n_cols, n_tiles, E.d_chunks, E.d_chunk_cls, E.n_chunks, E.d_folds, E.num_folds, E.nA, E.nU, E.d_thr, E.d_cand, E.d_cand_count, E.cand_cap);
     HIPCHK(ctx, hipGetLastError());
     return HPGV_OK;
 }

@@ -70,7 +70,7 @@ template <bool TRAINING, bool BALANCED>
 __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__restrict__ planes, uint32_t rev_off, int W,
                                                          int n_variants, int i_begin, int i_first, int i_end,
                                                          const unsigned *__restrict__ tile_base, int n_cols, unsigned n_tiles,
-                                                         const EpiChunk *__restrict__ chunks, int n_chunks,
+                                                         const EpiChunk *__restrict__ chunks, const uint32_t *__restrict__ chunk_cls /* bit k: step k of the chunk holds controls */, int n_chunks,
                                                          const EpiFold *__restrict__ folds, int num_folds, int n_affected, int n_unaffected,
                                                          const double *__restrict__ thr, EpiCand *__restrict__ cand,
                                                          unsigned *__restrict__ cand_count, unsigned cand_cap) {
@@ -82,12 +82,14 @@ __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__res
     // the chunk descriptors and the folds' constants in LDS (a scalar load that misses costs a microsecond)
     __shared__ __attribute__((aligned(16))) uint32_t s_chunk[EPM_MAX_CHUNKS * 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_fold[EPI_MAX_FOLDS * 8];
+    __shared__ uint32_t s_cls[EPM_MAX_CHUNKS];
     const unsigned span = (n_tiles + 7u) / 8u;
     const unsigned tile = (blockIdx.x & 7u) * span + (blockIdx.x >> 3);
     if (tile >= n_tiles) return;
     int c_lo = 0, c_hi = n_cols;
     while (c_hi - c_lo > 1) { const int mid = (c_lo + c_hi) >> 1; if (tile_base[mid] <= tile) c_lo = mid; else c_hi = mid; }
     for (int q = threadIdx.x; q < n_chunks * 4; q += 256) s_chunk[q] = reinterpret_cast<const uint32_t *>(chunks)[q];
+    for (int q = threadIdx.x; q < n_chunks; q += 256) s_cls[q] = chunk_cls[q];
     for (int q = threadIdx.x; q < num_folds * 8; q += 256) {         // per fold: test_a, test_u, inv_a, inv_u, the threshold
         const int f = q >> 3, e = q & 7;
         s_fold[q] = e < 6 ? reinterpret_cast<const uint32_t *>(folds + f)[e] : reinterpret_cast<const uint32_t *>(thr + f)[e - 6];
@@ -132,11 +134,11 @@ __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__res
         asked[q] = !(i < i_first || i >= i_end || i >= n_variants || j >= n_variants || j <= i);
     }
 
-    epm_v4f acc[9];
+    epm_v4f acc[9], acc_u[9];                                        // (acc_u: the first pass's controls; dead when `part` comes to life)
     uint32_t totp[9][4], part[9][4];                                 // totals; the fold under way (cases low, controls high halves)
     #pragma unroll
     for (int c = 0; c < 9; c++) {
-        acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f};
+        acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f}; acc_u[c] = epm_v4f{0.f, 0.f, 0.f, 0.f};
         #pragma unroll
         for (int q = 0; q < 4; q++) { totp[c][q] = 0; part[c][q] = 0; }
     }
@@ -151,15 +153,6 @@ __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__res
     }
     // a (fold, class) group has ended: the accumulators hold its counts.  First pass: into the totals.  Second pass: into the
     // fold under way; when the fold has no further group, it is evaluated and the fold under way starts empty again.
-    auto bank_totals = [&](int g) {
-        const int sh = (g & 1) * 16;
-        #pragma unroll
-        for (int c = 0; c < 9; c++) {
-            totp[c][0] += (uint32_t)acc[c].x << sh; totp[c][1] += (uint32_t)acc[c].y << sh;
-            totp[c][2] += (uint32_t)acc[c].z << sh; totp[c][3] += (uint32_t)acc[c].w << sh;
-            acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f};
-        }
-    };
     auto bank_fold = [&](int g) {
         const int f = g >> 1, sh = (g & 1) * 16;
         {
@@ -235,6 +228,7 @@ __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__res
             load_chunk((uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[(c + 1 < n_chunks ? c + 1 : 0) * 4]), nxt); \
         if (active) {                                                                                    \
             const int ns = __builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 1]) >> 2;                 \
+            const uint32_t clsm = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cls[c]);             \
             const uint64_t flush = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 2])      /* wave-uniform */ \
                                    | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 3]) << 32); \
             const char *cur_bytes = reinterpret_cast<const char *>(cur);                                 \
@@ -245,13 +239,18 @@ __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__res
             for (int k = 0; k < ns; k++) {                                                               \
                 uint32_t na[3], nb[3];                                                                   \
                 HPGV_EPM_READ(na, nb, k + 1)                                                             \
-                _Pragma("unroll") for (int a = 0; a < 3; a++)                                            \
-                    _Pragma("unroll") for (int b = 0; b < 3; b++) acc[a * 3 + b] = HPGV_EPM_MFMA(A0[a], B0[b], acc[a * 3 + b]); \
+                if (PASS == 0 && ((clsm >> k) & 1u)) {               /* first pass: cases and controls each into accumulators of their own, no banking */ \
+                    _Pragma("unroll") for (int a = 0; a < 3; a++)                                        \
+                        _Pragma("unroll") for (int b = 0; b < 3; b++) acc_u[a * 3 + b] = HPGV_EPM_MFMA(A0[a], B0[b], acc_u[a * 3 + b]); \
+                } else {                                                                                 \
+                    _Pragma("unroll") for (int a = 0; a < 3; a++)                                        \
+                        _Pragma("unroll") for (int b = 0; b < 3; b++) acc[a * 3 + b] = HPGV_EPM_MFMA(A0[a], B0[b], acc[a * 3 + b]); \
+                }                                                                                        \
                 _Pragma("unroll") for (int a = 0; a < 3; a++) { A0[a] = epm_row_operand(na[a]); B0[a] = epm_col_operand(nb[a]); } \
                 const int g = (int)((flush >> (8 * k)) & 0xFFu);     /* the same in every lane */         \
                 /* (the banking clears the accumulators: starting a group's first MFMAs from a zero operand instead needs two \
                    copies of the step, and measured slower) */                                           \
-                if (g != 0xFF) { if (PASS == 0) bank_totals(g); else bank_fold(g); }                     \
+                if (PASS == 1 && g != 0xFF) bank_fold(g);                                                \
             }                                                                                            \
         }                                                                                                \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             /* this wave's part of the next chunk has landed */ \
@@ -259,6 +258,12 @@ __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__res
         uint32_t *t = cur; cur = nxt; nxt = t;                                                           \
     }
     HPGV_EPM_PASS(0)
+    #pragma unroll
+    for (int c = 0; c < 9; c++) {                                    // the totals, packed; the second pass starts from zero
+        totp[c][0] = (uint32_t)acc[c].x + ((uint32_t)acc_u[c].x << 16); totp[c][1] = (uint32_t)acc[c].y + ((uint32_t)acc_u[c].y << 16);
+        totp[c][2] = (uint32_t)acc[c].z + ((uint32_t)acc_u[c].z << 16); totp[c][3] = (uint32_t)acc[c].w + ((uint32_t)acc_u[c].w << 16);
+        acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f};
+    }
     HPGV_EPM_PASS(1)
 #undef HPGV_EPM_PASS
 #undef HPGV_EPM_READ

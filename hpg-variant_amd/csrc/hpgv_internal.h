@@ -56,6 +56,7 @@ struct EpiState {
     uint32_t *d_marg = nullptr;       // per SNP and (fold, class) group: samples with genotype 0 / 1 (16 bits each)
     bool complete = false;            // the dataset holds no call other than 0 / 1 / 2
     hpgv::EpiChunk *d_chunks = nullptr;
+    uint32_t *d_chunk_cls = nullptr;  // per staging block: bit k = its step k holds controls
     hpgv::EpiFold *d_folds = nullptr;
     uint32_t *d_group_w0 = nullptr;
     std::vector<int32_t> group_size;
