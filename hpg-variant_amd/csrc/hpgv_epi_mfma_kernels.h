@@ -20,8 +20,8 @@
 // must weigh the same samples 2.0, 1.0, 0.5, 2.0 so that every product is 1: the column side reads a second copy of the planes
 // with bits 0 and 2 of every nibble swapped, again one instruction per register.  Five instructions per word and plane, 30
 // per step, against nine MFMAs of 16 cycles.  (The first form used v_mfma_i32_16x16x64_i8 with one bit of every BYTE per
-// register: 54 instructions and 18 MFMAs per step -- and that instruction takes 32 cycles here, not the 16 of its bf16
-// sibling: 576 cycles of matrix core per step, no faster than k_epi_pairs.)
+// register: 54 instructions and 18 MFMAs per step -- and back to back that instruction issues every 45 cycles
+// (tools/exp/mfma_rate.hip; the FP4 form every 33): 800 cycles of matrix core per step, no faster than k_epi_pairs.)
 //
 // State and passes: see k_epi_pairs_mfma below (two passes over the samples, two waves per SIMD).
 #pragma once

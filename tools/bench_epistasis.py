@@ -100,7 +100,7 @@ if not COMPLETE and int(opts.get("epi_pairs_mfma", 1)):
     # the matrix-core scan (hpgv_epi_mfma_kernels.h): 9 cells x samples (padded to 128 per group) x 2 flop per pair are the
     # algorithm's; the kernel walks the samples twice.  Peak: dense FP4 (MI355X_MICROARCH.md); the kernel is vector-issue
     # bound (16.7 k vector instructions per 256 pairs) and v_mfma_scale_f32_16x16x128_f8f6f4 issues every 33 cycles here
-    # (tools/exp/mfma_rate.hip), half the rate that peak assumes
+    # back to back (tools/exp/mfma_rate.hip), about half the rate that peak assumes
     flops = pairs * 9 * words * 32 * 2
     out["kernel"] = "k_epi_pairs_mfma"
     out["roofline_vector_scan_equivalent"] = out["roofline"]
