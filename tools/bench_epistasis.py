@@ -96,7 +96,7 @@ out["roofline"] = {"bound": "valu", "achieved": wave_instr / (scan_ms * 1e-3) / 
                    "unit": "G wave64 VALU instructions/s", "frac": wave_instr / (scan_ms * 1e-3) / peak_wave_instr,
                    "algorithmic_ops_per_pair_word": 18}
 opts = dict(a[len('--option='):].split('=') for a in sys.argv[1:] if a.startswith('--option='))
-if not COMPLETE and int(opts.get("epi_pairs_mfma", 1)):
+if int(opts.get("epi_pairs_mfma", 1)):                        # (data without missing calls takes the matrix-core scan too)
     # the matrix-core scan (hpgv_epi_mfma_kernels.h): 9 cells x samples (padded to 128 per group) x 2 flop per pair are the
     # algorithm's; the kernel walks the samples twice.  Peak: dense FP4 (MI355X_MICROARCH.md); the kernel is vector-issue
     # bound (16.7 k vector instructions per 256 pairs) and v_mfma_scale_f32_16x16x128_f8f6f4 issues every 33 cycles here
@@ -108,7 +108,7 @@ if not COMPLETE and int(opts.get("epi_pairs_mfma", 1)):
                        "frac": flops / (scan_ms * 1e-3) / 1e16, "algorithmic_flop_per_pair_and_sample": 18}
 else:
     out["kernel"] = "k_epi_pairs"
-if COMPLETE:
+if COMPLETE and out["kernel"] == "k_epi_pairs":
     out["roofline"]["note"] = "complete data: 8 operations per pair and word are executed; frac is quoted at the general case's 18"
     out["roofline"]["frac_at_8_ops"] = out["roofline"]["frac"] * 8 / 18
 del out["valu_lane_ops_per_s"]
