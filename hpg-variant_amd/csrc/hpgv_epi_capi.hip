@@ -134,6 +134,21 @@ int epi_build_folds(hpgv_ctx *ctx, const int32_t *fold_of_sample, int num_folds)
     return HPGV_OK;
 }
 
+// per fold: testing sizes and the reciprocals of the evaluated part's sizes (RN(1 / y): IEEE double division on the host), for
+// the scan kernels' evaluation
+template <bool TRAINING>
+int epi_upload_folds(hpgv_ctx *ctx, hipStream_t st) {
+    EpiState &E = ctx->epi;
+    hpgv::EpiFold folds[hpgv::EPI_MAX_FOLDS];
+    for (int f = 0; f < hpgv::EPI_MAX_FOLDS; ++f) {
+        folds[f].test_a = E.group_size[(size_t)2 * f]; folds[f].test_u = E.group_size[(size_t)2 * f + 1];
+        const int sa = TRAINING ? E.nA - folds[f].test_a : folds[f].test_a, su = TRAINING ? E.nU - folds[f].test_u : folds[f].test_u;
+        folds[f].inv_a = 1.0 / (double)sa; folds[f].inv_u = 1.0 / (double)su;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(E.d_folds, folds, sizeof folds, hipMemcpyHostToDevice, st));
+    return HPGV_OK;
+}
+
 // the ranking scan with the cell counts on the matrix cores (hpgv_epi_mfma_kernels.h): tiles of 16 rows x 64 columns
 template <bool TRAINING, bool BALANCED>
 int epi_launch_pairs_mfma(hpgv_ctx *ctx, int i_begin, int i_end, hipStream_t st) {
@@ -161,13 +176,7 @@ int epi_launch_pairs_mfma(hpgv_ctx *ctx, int i_begin, int i_end, hipStream_t st)
     HIPCHK(ctx, hipMemcpyAsync(E.d_tile_base, tile_base.data(), tile_base.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
     const unsigned n_tiles = (unsigned)total;
     const dim3 grid((n_tiles + 7u) / 8u * 8u);
-    hpgv::EpiFold folds[hpgv::EPI_MAX_FOLDS];
-    for (int f = 0; f < hpgv::EPI_MAX_FOLDS; ++f) {
-        folds[f].test_a = E.group_size[(size_t)2 * f]; folds[f].test_u = E.group_size[(size_t)2 * f + 1];
-        const int sa = TRAINING ? E.nA - folds[f].test_a : folds[f].test_a, su = TRAINING ? E.nU - folds[f].test_u : folds[f].test_u;
-        folds[f].inv_a = 1.0 / (double)sa; folds[f].inv_u = 1.0 / (double)su;
-    }
-    HIPCHK(ctx, hipMemcpyAsync(E.d_folds, folds, sizeof folds, hipMemcpyHostToDevice, st));
+    if (int rc = epi_upload_folds<TRAINING>(ctx, st)) return rc;
     hipLaunchKernelGGL((hpgv::k_epi_pairs_mfma<TRAINING, BALANCED>), grid, dim3(256), 0, st, E.d_planes, E.rev_off, E.W,
                        E.V, i_begin, i_first, i_end, E.d_tile_base, n_cols, n_tiles, E.d_chunks, E.d_chunk_cls, E.n_chunks, E.d_folds, E.num_folds, E.nA, E.nU, E.d_thr, E.d_cand, E.d_cand_count, E.cand_cap);
     HIPCHK(ctx, hipGetLastError());
@@ -205,14 +214,7 @@ int epi_launch_pairs2(hpgv_ctx *ctx, int i_begin, int i_end, double *d_acc, uint
     HIPCHK(ctx, hipMemcpyAsync(E.d_tile_base, tile_base.data(), tile_base.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
     const unsigned n_tiles = (unsigned)total;
     const dim3 grid((n_tiles + 7u) / 8u * 8u);                       // eight spans, one per XCD
-    // per fold: testing sizes and the reciprocals of the evaluated part's sizes (RN(1 / y): IEEE double division on the host)
-    hpgv::EpiFold folds[hpgv::EPI_MAX_FOLDS];
-    for (int f = 0; f < hpgv::EPI_MAX_FOLDS; ++f) {
-        folds[f].test_a = E.group_size[(size_t)2 * f]; folds[f].test_u = E.group_size[(size_t)2 * f + 1];
-        const int sa = TRAINING ? E.nA - folds[f].test_a : folds[f].test_a, su = TRAINING ? E.nU - folds[f].test_u : folds[f].test_u;
-        folds[f].inv_a = 1.0 / (double)sa; folds[f].inv_u = 1.0 / (double)su;
-    }
-    HIPCHK(ctx, hipMemcpyAsync(E.d_folds, folds, sizeof folds, hipMemcpyHostToDevice, st));
+    if (int rc = epi_upload_folds<TRAINING>(ctx, st)) return rc;
 #define HPGV_EPI_LAUNCH(KK)                                                                                                         \
     hipLaunchKernelGGL((hpgv::k_epi_pairs<KK, TRAINING, BALANCED, COMPLETEV>), grid, dim3(256), 0, st, E.d_planes, E.d_marg, E.W, E.V, i_begin, i_first, i_end, \
                        E.d_tile_base, n_cols, n_tiles, E.d_chunks, E.n_chunks, E.d_folds, E.nA, E.nU, d_acc, d_mask, n_pairs_out, rank_base,                          \
@@ -576,13 +578,7 @@ template <bool TRAINING>
 int epi_launch_triples(hpgv_ctx *ctx, int i_first, int n_i, double *d_acc, uint32_t *d_mask, bool candidates,
                        hpgv::EpiCand3 *d_cand, unsigned cap) {
     EpiState &E = ctx->epi;
-    hpgv::EpiFold folds[hpgv::EPI_MAX_FOLDS];
-    for (int f = 0; f < hpgv::EPI_MAX_FOLDS; ++f) {
-        folds[f].test_a = E.group_size[(size_t)2 * f]; folds[f].test_u = E.group_size[(size_t)2 * f + 1];
-        const int sa = TRAINING ? E.nA - folds[f].test_a : folds[f].test_a, su = TRAINING ? E.nU - folds[f].test_u : folds[f].test_u;
-        folds[f].inv_a = 1.0 / (double)sa; folds[f].inv_u = 1.0 / (double)su;
-    }
-    HIPCHK(ctx, hipMemcpyAsync(E.d_folds, folds, sizeof folds, hipMemcpyHostToDevice, nullptr));
+    if (int rc = epi_upload_folds<TRAINING>(ctx, nullptr)) return rc;
     // tiles that hold a triple: for the j block jb (rows 4 jb .. 4 jb + 3) the k tiles from the one that holds 4 jb + 1
     // on; a first SNP i takes the j blocks from (i + 1) / 4 on
     const int n_kt = (E.V + hpgv::EPI_TJ - 1) / hpgv::EPI_TJ, n_jb = (E.V + hpgv::EPI_TI - 1) / hpgv::EPI_TI;

@@ -495,4 +495,6 @@ __global__ void __launch_bounds__(256, 2) k_epi_triples_mfma(const uint32_t *__r
     }
 }
 
+#undef HPGV_EPM_MFMA
+
 }  // namespace hpgv
