@@ -13,7 +13,7 @@ for d in ("epm_pmc1","epm_pmc2"):
     acc={}
     for f in glob.glob("$O/%s/**/*counter_collection.csv"%d, recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_epi_pairs" not in r["Kernel_Name"]: continue
+            if "k_epi_" not in r["Kernel_Name"] or "k_epi_planes" in r["Kernel_Name"] or "k_epi_marg" in r["Kernel_Name"]: continue
             a=acc.setdefault(r["Counter_Name"],[0.0,0]); a[0]+=float(r["Counter_Value"]); a[1]+=1
     print(d,{k:(round(v[0]/v[1]),v[1]) for k,v in acc.items()})
 PY
