@@ -177,8 +177,12 @@ int epi_launch_pairs_mfma(hpgv_ctx *ctx, int i_begin, int i_end, hipStream_t st)
     const unsigned n_tiles = (unsigned)total;
     const dim3 grid((n_tiles + 7u) / 8u * 8u);
     if (int rc = epi_upload_folds<TRAINING>(ctx, st)) return rc;
-    hipLaunchKernelGGL((hpgv::k_epi_pairs_mfma<TRAINING, BALANCED>), grid, dim3(256), 0, st, E.d_planes, E.rev_off, E.W,
-                       E.V, i_begin, i_first, i_end, E.d_tile_base, n_cols, n_tiles, E.d_chunks, E.d_chunk_cls, E.n_chunks, E.d_folds, E.num_folds, E.nA, E.nU, E.d_thr, E.d_cand, E.d_cand_count, E.cand_cap);
+#define HPGV_EPM_LAUNCH(COMPLETEV)                                                                                                   \
+    hipLaunchKernelGGL((hpgv::k_epi_pairs_mfma<TRAINING, BALANCED, COMPLETEV>), grid, dim3(256), 0, st, E.d_planes, E.d_marg, E.rev_off, E.W, \
+                       E.V, i_begin, i_first, i_end, E.d_tile_base, n_cols, n_tiles, E.d_chunks, E.d_chunk_cls, E.n_chunks, E.d_folds, E.num_folds, E.nA, E.nU, E.d_thr, E.d_cand, E.d_cand_count, E.cand_cap)
+    if (E.complete && ctx->epi_complete) HPGV_EPM_LAUNCH(true);      // no missing call in the dataset: four cells counted, five derived
+    else HPGV_EPM_LAUNCH(false);
+#undef HPGV_EPM_LAUNCH
     HIPCHK(ctx, hipGetLastError());
     return HPGV_OK;
 }

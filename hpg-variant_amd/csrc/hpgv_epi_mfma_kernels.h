@@ -66,15 +66,21 @@ __device__ __forceinline__ epm_v8i epm_col_operand(uint32_t y) {
 // diagonal).  Staging as k_epi_pairs: an LDS image of (64 + 16) SNPs x 3 planes x 32 words per chunk, rows of 128 bytes,
 // the 16-byte pieces of a row swizzled by the SNP so that the 64 lanes of a read (16 SNPs x 4 words) fall on 64 different
 // banks; double buffered, one barrier per chunk.  The columns' rows come from the swapped copy (rev_off words behind the planes).
-template <bool TRAINING, bool BALANCED>
-__global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__restrict__ planes, uint32_t rev_off, int W,
+// COMPLETE: a dataset WITHOUT missing calls -- only the four cells of genotypes {0, 1} x {0, 1} are counted (two planes per SNP
+// staged, four MFMAs per step) and the other five follow at a group's end from the per-SNP, per-group genotype counts `marg`
+// (k_epi_marginals) exactly as in k_epi_pairs: n(a, 2) = n_i(a) - n(a, 0) - n(a, 1), n(2, b) = n_j(b) - n(0, b) - n(1, b), n(2, 2) =
+// the rest of the group.  Its image is plane-major (row = plane * 80 + SNP: with two planes per SNP an SNP-major image would
+// put the 16 SNPs of a read on 32 banks).
+template <bool TRAINING, bool BALANCED, bool COMPLETE>
+__global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ marg, uint32_t rev_off, int W,
                                                          int n_variants, int i_begin, int i_first, int i_end,
                                                          const unsigned *__restrict__ tile_base, int n_cols, unsigned n_tiles,
                                                          const EpiChunk *__restrict__ chunks, const uint32_t *__restrict__ chunk_cls /* bit k: step k of the chunk holds controls */, int n_chunks,
                                                          const EpiFold *__restrict__ folds, int num_folds, int n_affected, int n_unaffected,
                                                          const double *__restrict__ thr, EpiCand *__restrict__ cand,
                                                          unsigned *__restrict__ cand_count, unsigned cand_cap) {
-    constexpr int SNPS = EPI_TJ + EPM_TI, ROWS = SNPS * 3, NDMA = ROWS / 8;      // 80 SNPs, 240 rows, 30 LDS-DMA instructions per chunk
+    constexpr int NP = COMPLETE ? 2 : 3, NC = NP * NP;               // planes staged per SNP, cells counted
+    constexpr int SNPS = EPI_TJ + EPM_TI, ROWS = SNPS * NP, NDMA = ROWS / 8;     // 80 SNPs, 240 (160) rows, 30 (20) LDS-DMA instructions per chunk
     static_assert(ROWS % 8 == 0, "whole LDS-DMA instructions");
     // two separate arrays, not lds[2][...]: the compiler then sees that the LDS-DMA writes into one buffer cannot touch the other
     __shared__ __attribute__((aligned(16))) uint32_t lds_a[ROWS * EPI_CH];
@@ -83,6 +89,7 @@ __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__res
     __shared__ __attribute__((aligned(16))) uint32_t s_chunk[EPM_MAX_CHUNKS * 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_fold[EPI_MAX_FOLDS * 8];
     __shared__ uint32_t s_cls[EPM_MAX_CHUNKS];
+    __shared__ uint32_t s_marg[COMPLETE ? 2 * EPI_MAX_FOLDS * SNPS : 1];        // complete data: genotype counts of the tile's SNPs per group, [g][SNP]
     const unsigned span = (n_tiles + 7u) / 8u;
     const unsigned tile = (blockIdx.x & 7u) * span + (blockIdx.x >> 3);
     if (tile >= n_tiles) return;
@@ -97,6 +104,11 @@ __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__res
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 15, h = lane >> 4;
     const int jt = ((i_begin >> 6) + c_lo) * EPI_TJ, j0 = jt + 16 * wave, i0 = i_begin + (int)(tile - tile_base[c_lo]) * EPM_TI;
     const bool active = !(j0 + 15 <= i0 || i0 >= i_end || i0 + 15 < i_first);       // is any pair of this wave's block asked for
+    if constexpr (COMPLETE)
+        for (int q = threadIdx.x; q < 2 * num_folds * SNPS; q += 256) {
+            const int g = q / SNPS, e = q % SNPS;
+            s_marg[q] = marg[(size_t)(e < EPI_TJ ? jt + e : i0 + (e - EPI_TJ)) * (2 * EPI_MAX_FOLDS) + g];
+        }
 
     // LDS-DMA: one global_load_lds_dwordx4 = 8 rows of the image; lane l fetches row 8 k + l / 8, physical piece l % 8 = the
     // logical piece (l % 8) ^ swizzle(row's SNP).  Kept per instruction: the word offset of the lane's piece in the planes.
@@ -104,7 +116,7 @@ __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__res
     #pragma unroll
     for (int q = 0; q < 8; q++) {
         const int k = wave + 4 * q, row8 = 8 * k + (lane >> 3), row = row8 < ROWS ? row8 : 0;
-        const int snp_idx = row / 3, plane = row % 3;
+        const int snp_idx = COMPLETE ? row % SNPS : row / 3, plane = COMPLETE ? row / SNPS : row % 3;
         const int piece = (lane & 7) ^ ((snp_idx >> 1) & 7);
         const int snp = snp_idx < EPI_TJ ? jt + snp_idx : i0 + (snp_idx - EPI_TJ);
         dma_off[q] = ((uint32_t)snp * 3u + (uint32_t)plane) * (uint32_t)W + (uint32_t)piece * 4u + (snp_idx < EPI_TJ ? rev_off : 0u);
@@ -123,7 +135,9 @@ __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__res
 
     // byte offsets of the lane's words in the image: row (SNP * 3 + plane) * 128 + piece (step ^ swizzle) * 16 + h * 4
     const int sa = EPI_TJ + r, sb = 16 * wave + r;
-    const int base_a = sa * 3 * (EPI_CH * 4) + h * 4, base_b = sb * 3 * (EPI_CH * 4) + h * 4, swz_a = (sa >> 1) & 7, swz_b = (sb >> 1) & 7;
+    constexpr int PS = COMPLETE ? SNPS * EPI_CH * 4 : EPI_CH * 4;    // bytes from one plane of an SNP to the next
+    const int base_a = sa * (COMPLETE ? 1 : 3) * (EPI_CH * 4) + h * 4, base_b = sb * (COMPLETE ? 1 : 3) * (EPI_CH * 4) + h * 4;
+    const int swz_a = (sa >> 1) & 7, swz_b = (sb >> 1) & 7;
     const float f_na = (float)(unsigned)n_affected, f_nu = (float)(unsigned)n_unaffected;
     const float ratio = f_na / f_nu;
     const int j = j0 + r;
@@ -134,21 +148,37 @@ __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__res
         asked[q] = !(i < i_first || i >= i_end || i >= n_variants || j >= n_variants || j <= i);
     }
 
-    epm_v4f acc[9], acc_u[9];                                        // (acc_u: the first pass's controls; dead when `part` comes to life)
+    epm_v4f acc[NC], acc_u[NC];                                       // (acc_u: the first pass's controls; dead when `part` comes to life)
     uint32_t totp[9][4], part[9][4];                                 // totals; the fold under way (cases low, controls high halves)
     #pragma unroll
-    for (int c = 0; c < 9; c++) {
-        acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f}; acc_u[c] = epm_v4f{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NC; c++) { acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f}; acc_u[c] = epm_v4f{0.f, 0.f, 0.f, 0.f}; }
+    #pragma unroll
+    for (int c = 0; c < 9; c++)
         #pragma unroll
         for (int q = 0; q < 4; q++) { totp[c][q] = 0; part[c][q] = 0; }
-    }
+    // the nine cells of one pair in one group from what was counted (all nine, or the four of genotypes 0 / 1 and the genotype
+    // counts of the pair's SNPs in that group: mi, mj = count of genotype 0 | count of genotype 1 << 16; ng = the group's size)
+    auto cells_of = [&](const epm_v4f (&x)[NC], int q, uint32_t mi, uint32_t mj, uint32_t ng, uint32_t (&cell)[9]) {
+        auto at = [&](int c) { return (uint32_t)(q == 0 ? x[c].x : q == 1 ? x[c].y : q == 2 ? x[c].z : x[c].w); };
+        if constexpr (COMPLETE) {
+            const uint32_t n00 = at(0), n01 = at(1), n10 = at(2), n11 = at(3);
+            const uint32_t mi0 = mi & 0xFFFFu, mi1 = mi >> 16, mj0 = mj & 0xFFFFu, mj1 = mj >> 16;
+            cell[0] = n00; cell[1] = n01; cell[2] = mi0 - n00 - n01;
+            cell[3] = n10; cell[4] = n11; cell[5] = mi1 - n10 - n11;
+            cell[6] = mj0 - n00 - n10; cell[7] = mj1 - n01 - n11;
+            cell[8] = ng - mi0 - mi1 - cell[6] - cell[7];
+        } else {
+            #pragma unroll
+            for (int c = 0; c < 9; c++) cell[c] = at(c < NC ? c : 0);
+        }
+    };
 
 #define HPGV_EPM_READ(X, Y, KSTEP)                                                                       \
     {                                                                                                    \
         const int k_ = (KSTEP) < 7 ? (KSTEP) : 7;                    /* (past the chunk's last step: any step, never used) */ \
         const char *qa = cur_bytes + (base_a + ((k_ ^ swz_a) << 4)), *qb = cur_bytes + (base_b + ((k_ ^ swz_b) << 4)); \
-        _Pragma("unroll") for (int a = 0; a < 3; a++) {                                                  \
-            X[a] = *reinterpret_cast<const uint32_t *>(qa + a * (EPI_CH * 4)); Y[a] = *reinterpret_cast<const uint32_t *>(qb + a * (EPI_CH * 4)); \
+        _Pragma("unroll") for (int a = 0; a < NP; a++) {                                                 \
+            X[a] = *reinterpret_cast<const uint32_t *>(qa + a * PS); Y[a] = *reinterpret_cast<const uint32_t *>(qb + a * PS); \
         }                                                                                                \
     }
     // a (fold, class) group has ended: the accumulators hold its counts.  First pass: into the totals.  Second pass: into the
@@ -156,11 +186,22 @@ __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__res
     auto bank_fold = [&](int g) {
         const int f = g >> 1, sh = (g & 1) * 16;
         {
-            #pragma unroll
-            for (int c = 0; c < 9; c++) {
-                part[c][0] += (uint32_t)acc[c].x << sh; part[c][1] += (uint32_t)acc[c].y << sh;
-                part[c][2] += (uint32_t)acc[c].z << sh; part[c][3] += (uint32_t)acc[c].w << sh;
-                acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f};
+            {
+                uint32_t mj = 0, ng = 0;
+                if constexpr (COMPLETE) {
+                    mj = s_marg[g * SNPS + sb];
+                    const int n = __builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + (g & 1)]);
+                    ng = n > 0 ? (uint32_t)n : 0u;
+                }
+                #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t cell[9];
+                    cells_of(acc, q, COMPLETE ? s_marg[g * SNPS + EPI_TJ + 4 * h + q] : 0u, mj, ng, cell);
+                    #pragma unroll
+                    for (int c = 0; c < 9; c++) part[c][q] += cell[c] << sh;
+                }
+                #pragma unroll
+                for (int c = 0; c < NC; c++) acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f};
             }
             EpiFold fo;
             fo.test_a = __builtin_amdgcn_readfirstlane((int)s_fold[f * 8]); fo.test_u = __builtin_amdgcn_readfirstlane((int)s_fold[f * 8 + 1]);
@@ -232,21 +273,21 @@ __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__res
             const uint64_t flush = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 2])      /* wave-uniform */ \
                                    | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 3]) << 32); \
             const char *cur_bytes = reinterpret_cast<const char *>(cur);                                 \
-            uint32_t xa[3], xb[3];                                                                       \
+            uint32_t xa[NP], xb[NP];                                                                     \
             HPGV_EPM_READ(xa, xb, 0)                                                                     \
-            epm_v8i A0[3], B0[3];                                                                        \
-            _Pragma("unroll") for (int a = 0; a < 3; a++) { A0[a] = epm_row_operand(xa[a]); B0[a] = epm_col_operand(xb[a]); } \
+            epm_v8i A0[NP], B0[NP];                                                                      \
+            _Pragma("unroll") for (int a = 0; a < NP; a++) { A0[a] = epm_row_operand(xa[a]); B0[a] = epm_col_operand(xb[a]); } \
             for (int k = 0; k < ns; k++) {                                                               \
-                uint32_t na[3], nb[3];                                                                   \
+                uint32_t na[NP], nb[NP];                                                                 \
                 HPGV_EPM_READ(na, nb, k + 1)                                                             \
                 if (PASS == 0 && ((clsm >> k) & 1u)) {               /* first pass: cases and controls each into accumulators of their own, no banking */ \
-                    _Pragma("unroll") for (int a = 0; a < 3; a++)                                        \
-                        _Pragma("unroll") for (int b = 0; b < 3; b++) acc_u[a * 3 + b] = HPGV_EPM_MFMA(A0[a], B0[b], acc_u[a * 3 + b]); \
+                    _Pragma("unroll") for (int a = 0; a < NP; a++)                                       \
+                        _Pragma("unroll") for (int b = 0; b < NP; b++) acc_u[a * NP + b] = HPGV_EPM_MFMA(A0[a], B0[b], acc_u[a * NP + b]); \
                 } else {                                                                                 \
-                    _Pragma("unroll") for (int a = 0; a < 3; a++)                                        \
-                        _Pragma("unroll") for (int b = 0; b < 3; b++) acc[a * 3 + b] = HPGV_EPM_MFMA(A0[a], B0[b], acc[a * 3 + b]); \
+                    _Pragma("unroll") for (int a = 0; a < NP; a++)                                       \
+                        _Pragma("unroll") for (int b = 0; b < NP; b++) acc[a * NP + b] = HPGV_EPM_MFMA(A0[a], B0[b], acc[a * NP + b]); \
                 }                                                                                        \
-                _Pragma("unroll") for (int a = 0; a < 3; a++) { A0[a] = epm_row_operand(na[a]); B0[a] = epm_col_operand(nb[a]); } \
+                _Pragma("unroll") for (int a = 0; a < NP; a++) { A0[a] = epm_row_operand(na[a]); B0[a] = epm_col_operand(nb[a]); } \
                 const int g = (int)((flush >> (8 * k)) & 0xFFu);     /* the same in every lane */         \
                 /* (the banking clears the accumulators: starting a group's first MFMAs from a zero operand instead needs two \
                    copies of the step, and measured slower) */                                           \
@@ -258,11 +299,24 @@ __global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__res
         uint32_t *t = cur; cur = nxt; nxt = t;                                                           \
     }
     HPGV_EPM_PASS(0)
-    #pragma unroll
-    for (int c = 0; c < 9; c++) {                                    // the totals, packed; the second pass starts from zero
-        totp[c][0] = (uint32_t)acc[c].x + ((uint32_t)acc_u[c].x << 16); totp[c][1] = (uint32_t)acc[c].y + ((uint32_t)acc_u[c].y << 16);
-        totp[c][2] = (uint32_t)acc[c].z + ((uint32_t)acc_u[c].z << 16); totp[c][3] = (uint32_t)acc[c].w + ((uint32_t)acc_u[c].w << 16);
-        acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f};
+    {                                                                // the totals, packed; the second pass starts from zero
+        uint32_t mj[2] = {0, 0}, mi[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+        if constexpr (COMPLETE)                                      // the SNPs' genotype counts per class: sums over the class's groups (below 65 536 each)
+            for (int g = 0; g < 2 * num_folds; g++) {
+                mj[g & 1] += s_marg[g * SNPS + sb];
+                #pragma unroll
+                for (int q = 0; q < 4; q++) mi[q][g & 1] += s_marg[g * SNPS + EPI_TJ + 4 * h + q];
+            }
+        #pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t ca[9], cu[9];
+            cells_of(acc, q, mi[q][0], mj[0], (uint32_t)n_affected, ca);
+            cells_of(acc_u, q, mi[q][1], mj[1], (uint32_t)n_unaffected, cu);
+            #pragma unroll
+            for (int c = 0; c < 9; c++) totp[c][q] = ca[c] + (cu[c] << 16);
+        }
+        #pragma unroll
+        for (int c = 0; c < NC; c++) acc[c] = epm_v4f{0.f, 0.f, 0.f, 0.f};
     }
     HPGV_EPM_PASS(1)
 #undef HPGV_EPM_PASS
