@@ -72,7 +72,7 @@ __device__ __forceinline__ epm_v8i epm_col_operand(uint32_t y) {
 // the rest of the group.  Its image is plane-major (row = plane * 80 + SNP: with two planes per SNP an SNP-major image would
 // put the 16 SNPs of a read on 32 banks).
 template <bool TRAINING, bool BALANCED, bool COMPLETE>
-__global__ void __launch_bounds__(256, 2) k_epi_pairs_mfma(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ marg, uint32_t rev_off, int W,
+__global__ void __launch_bounds__(256, COMPLETE ? 3 : 2) k_epi_pairs_mfma(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ marg, uint32_t rev_off, int W,
                                                          int n_variants, int i_begin, int i_first, int i_end,
                                                          const unsigned *__restrict__ tile_base, int n_cols, unsigned n_tiles,
                                                          const EpiChunk *__restrict__ chunks, const uint32_t *__restrict__ chunk_cls /* bit k: step k of the chunk holds controls */, int n_chunks,
