@@ -611,9 +611,9 @@ int epi_launch_triples(hpgv_ctx *ctx, int i_first, int n_i, double *d_acc, uint3
     HIPCHK(ctx, hipMemcpyAsync(d_jbp, jbp.data(), jbp.size() * sizeof(unsigned), hipMemcpyHostToDevice, nullptr));
     HIPCHK(ctx, hipMemcpyAsync(d_rb, rb.data(), rb.size() * sizeof(unsigned), hipMemcpyHostToDevice, nullptr));
     const bool balanced = E.nA == E.nU && E.nA < (1 << 22);
-    // ranking, at most 10 folds, classes below 65 536 samples: the cell counts on the matrix cores (hpgv_epi_mfma_kernels.h:
+    // ranking, classes below 65 536 samples: the cell counts on the matrix cores (hpgv_epi_mfma_kernels.h:
     // k_epi_triples_mfma), tiles of one first SNP x 16 second x 64 third
-    if (ctx->epi_triples_mfma && candidates && !d_acc && E.rev_off && E.n_chunks <= hpgv::EPM_MAX_CHUNKS && E.num_folds <= 10 && E.nA < 65536 && E.nU < 65536) {
+    if (ctx->epi_triples_mfma && candidates && !d_acc && E.rev_off && E.n_chunks <= hpgv::EPM_MAX_CHUNKS && E.nA < 65536 && E.nU < 65536) {
         const int n_jb16 = (E.V + hpgv::EPM_TI - 1) / hpgv::EPM_TI;
         std::vector<unsigned> jbp16((size_t)n_jb16 + 1), rb16((size_t)n_i + 1);
         unsigned long long acc16 = 0;
@@ -633,7 +633,8 @@ int epi_launch_triples(hpgv_ctx *ctx, int i_first, int n_i, double *d_acc, uint3
         hipLaunchKernelGGL((hpgv::k_epi_triples_mfma<KK, TRAINING, BAL>), dim3((unsigned)total16), dim3(256), 0, nullptr, E.d_planes, E.rev_off, E.W, E.V, i_first, d_rb, n_i, \
                            d_jbp, n_jb16, E.d_chunks, E.n_chunks, E.d_folds, E.num_folds, E.nA, E.nU, E.d_thr, d_cand, E.d_cand_count, cap)
         if (E.num_folds <= 5) { if (balanced) HPGV_EPM3_LAUNCH(5, true); else HPGV_EPM3_LAUNCH(5, false); }
-        else { if (balanced) HPGV_EPM3_LAUNCH(10, true); else HPGV_EPM3_LAUNCH(10, false); }
+        else if (E.num_folds <= 10) { if (balanced) HPGV_EPM3_LAUNCH(10, true); else HPGV_EPM3_LAUNCH(10, false); }
+        else { if (balanced) HPGV_EPM3_LAUNCH(16, true); else HPGV_EPM3_LAUNCH(16, false); }      // one wave per SIMD
 #undef HPGV_EPM3_LAUNCH
         HIPCHK(ctx, hipGetLastError());
         return HPGV_OK;

@@ -329,11 +329,12 @@ __global__ void __launch_bounds__(256, COMPLETE ? 3 : 2) k_epi_pairs_mfma(const 
 // (one more AND per word), B = plane_k[c].  A wave owns (i, 16 j, 16 k) -- four triples per lane --, walks the samples once
 // per genotype a like k_epi_triples3 (a cell's verdict is its own: it only adds to its fold's TP | FP sum and high-risk
 // bits), and every walk is k_epi_pairs_mfma's two passes.  Across the walks a lane keeps K x 4 sums and masks; everything
-// else is the pair kernel's state, so two waves share a SIMD here too.  Image: 64 k columns (swapped copy) + 16 j rows + the
+// else is the pair kernel's state, so two waves share a SIMD here too (up to 10 folds; with 11 to 16 the sums and masks take a
+// wave the whole register file of its SIMD).  Image: 64 k columns (swapped copy) + 16 j rows + the
 // i row, three planes each.  Tiles: first SNP i, then the j blocks of 16 from (i + 1) / 16 on, then the k tiles of 64 from the
 // one that holds 16 jb + 1 on (row_base / jb_prefix as k_epi_triples3's, with blocks of 16).
 template <int K, bool TRAINING, bool BALANCED>
-__global__ void __launch_bounds__(256, 2) k_epi_triples_mfma(const uint32_t *__restrict__ planes, uint32_t rev_off, int W, int n_variants, int i_first,
+__global__ void __launch_bounds__(256, K <= 10 ? 2 : 1) k_epi_triples_mfma(const uint32_t *__restrict__ planes, uint32_t rev_off, int W, int n_variants, int i_first,
                                                            const unsigned *__restrict__ row_base /* n_i + 1 */, int n_i,
                                                            const unsigned *__restrict__ jb_prefix /* n_jb + 1 */, int n_jb,
                                                            const EpiChunk *__restrict__ chunks, int n_chunks,
@@ -456,6 +457,7 @@ __global__ void __launch_bounds__(256, 2) k_epi_triples_mfma(const uint32_t *__r
                         break;
                     HPGV_EPM_CASE(0) HPGV_EPM_CASE(1) HPGV_EPM_CASE(2) HPGV_EPM_CASE(3) HPGV_EPM_CASE(4)
                     HPGV_EPM_CASE(5) HPGV_EPM_CASE(6) HPGV_EPM_CASE(7) HPGV_EPM_CASE(8) HPGV_EPM_CASE(9)
+                    HPGV_EPM_CASE(10) HPGV_EPM_CASE(11) HPGV_EPM_CASE(12) HPGV_EPM_CASE(13) HPGV_EPM_CASE(14) HPGV_EPM_CASE(15)
 #undef HPGV_EPM_CASE
                     default: break;
                 }
@@ -515,6 +517,7 @@ __global__ void __launch_bounds__(256, 2) k_epi_triples_mfma(const uint32_t *__r
                 break;
             HPGV_EPM_CASE(0) HPGV_EPM_CASE(1) HPGV_EPM_CASE(2) HPGV_EPM_CASE(3) HPGV_EPM_CASE(4)
             HPGV_EPM_CASE(5) HPGV_EPM_CASE(6) HPGV_EPM_CASE(7) HPGV_EPM_CASE(8) HPGV_EPM_CASE(9)
+            HPGV_EPM_CASE(10) HPGV_EPM_CASE(11) HPGV_EPM_CASE(12) HPGV_EPM_CASE(13) HPGV_EPM_CASE(14) HPGV_EPM_CASE(15)
 #undef HPGV_EPM_CASE
             default:
                 #pragma unroll

@@ -290,7 +290,7 @@ def test_matrix_core_ranking_is_the_vector_alu_ranking(eng, v, nA, nU, k, p_miss
         eng.set_option("epi_pairs_mfma", 1)
 
 
-@pytest.mark.parametrize("v,nA,nU,k,p_missing", [(70, 700, 500, 3, 0.05), (40, 900, 900, 10, 0.02), (66, 260, 260, 5, 0.0), (33, 40, 1500, 2, 0.1)])
+@pytest.mark.parametrize("v,nA,nU,k,p_missing", [(70, 700, 500, 3, 0.05), (40, 900, 900, 10, 0.02), (66, 260, 260, 5, 0.0), (33, 40, 1500, 2, 0.1), (38, 640, 700, 13, 0.03), (30, 800, 800, 16, 0.02)])
 def test_matrix_core_triple_ranking_is_the_vector_alu_ranking(eng, v, nA, nU, k, p_missing):
     # k_epi_triples_mfma against k_epi_triples3 / k_epi_triples: blocks of 16 second SNPs on and off the diagonals, third SNPs
     # in one and in two tiles of 64, groups longer and shorter than a staging chunk, equal and unequal classes; both subsets; a

@@ -61,7 +61,7 @@ if ORDER == 3:
                          "unit": "G wave64 VALU instructions/s", "frac": wave_instr / (scan_ms * 1e-3) / peak,
                          "algorithmic_ops_per_triple_word": 54}}
     opts = dict(a[len('--option='):].split('=') for a in sys.argv[1:] if a.startswith('--option='))
-    if int(opts.get("epi_triples_mfma", 1)) and K <= 10:
+    if int(opts.get("epi_triples_mfma", 1)) and K <= 16:
         # the matrix-core scan (k_epi_triples_mfma): 27 cells x samples (padded) x 2 flop per triple are the algorithm's; dense FP4
         # peak from MI355X_MICROARCH.md (see the pair line's note on the issue rate measured here)
         flops = triples * 27 * words * 32 * 2
