@@ -477,7 +477,10 @@ int hpgv_epi_rank_pairs_rows(hpgv_ctx *ctx, int i_begin, int i_end, int subset, 
     // band's N-th best, so the scan need not list every pair of its first launches
     {
         const long long V0 = E.V;
-        const int r = (int)std::max<long long>(1, std::min<long long>(8, (1ll << 20) / std::max<long long>(V0, 1)));
+        // (a few tens of thousands of pairs, or four times the ranking size, are enough for a useful bound: the dense scan of these
+        // rows, its 8-byte accuracies over the bus and their selection are host time of every ranking call)
+        const long long want = std::max<long long>(32768, 4ll * N);
+        const int r = (int)std::max<long long>(1, std::min<long long>(8, want / std::max<long long>(V0, 1) + 1));
         const int pre_end = (int)std::min<long long>(i_end, (long long)i_begin + r);
         const unsigned long long base = epi_rank((unsigned long long)V0, (unsigned long long)i_begin);
         const unsigned long long np = (pre_end >= E.V ? (unsigned long long)V0 * (unsigned long long)(V0 - 1) / 2 : epi_rank((unsigned long long)V0, (unsigned long long)pre_end)) - base;
