@@ -30,6 +30,8 @@ void epi_free(EpiState &E) {
     epi_free_folds(E);
     if (E.d_data) (void)hipFree(E.d_data);
     if (E.d_cand) (void)hipFree(E.d_cand);
+    if (E.d_cand3) (void)hipFree(E.d_cand3);
+    E.d_cand3 = nullptr; E.cand3_cap = 0;
     if (E.d_cand_count) (void)hipFree(E.d_cand_count);
     if (E.d_thr) (void)hipFree(E.d_thr);
     if (E.d_tile_base) (void)hipFree(E.d_tile_base);
@@ -747,9 +749,13 @@ int hpgv_epi_rank_triples_rows(hpgv_ctx *ctx, int i_begin, int i_end, int subset
     const unsigned long long per_i0 = V > 2 ? (unsigned long long)(V - 1) * (unsigned long long)(V - 2) / 2 : 1;
     if (per_i0 > (1ull << 28)) return fail(ctx, HPGV_ERR_UNSUPPORTED, "too many SNPs for the candidate lists of the triple scan");
     const unsigned cap = (unsigned)std::max<unsigned long long>(1ull << 20, per_i0);
-    hpgv::EpiCand3 *d_cand = nullptr;
-    HIPCHK(ctx, hipMalloc(&d_cand, (size_t)nf * cap * sizeof(hpgv::EpiCand3)));
-    struct Free { void *p; ~Free() { (void)hipFree(p); } } free_cand{d_cand};
+    if (!E.d_cand3 || E.cand3_cap < (size_t)nf * cap) {              // (kept between calls: 240 MB at 1 024 SNPs)
+        if (E.d_cand3) (void)hipFree(E.d_cand3);
+        E.d_cand3 = nullptr; E.cand3_cap = 0;
+        HIPCHK(ctx, hipMalloc(&E.d_cand3, (size_t)nf * cap * sizeof(hpgv::EpiCand3)));
+        E.cand3_cap = (size_t)nf * cap;
+    }
+    hpgv::EpiCand3 *d_cand = E.d_cand3;
     if (!E.d_cand_count) HIPCHK(ctx, hipMalloc(&E.d_cand_count, hpgv::EPI_MAX_FOLDS * sizeof(unsigned)));
     if (!E.d_thr) HIPCHK(ctx, hipMalloc(&E.d_thr, hpgv::EPI_MAX_FOLDS * sizeof(double)));
     std::vector<std::vector<hpgv::EpiCand3>> top((size_t)nf);
@@ -770,9 +776,15 @@ int hpgv_epi_rank_triples_rows(hpgv_ctx *ctx, int i_begin, int i_end, int subset
     const long long per_row_tiles = ((V + hpgv::EPI_TI - 1) / hpgv::EPI_TI) * ((V + hpgv::EPI_TJ - 1) / hpgv::EPI_TJ) + 1;
     const int max_rows = (int)std::max<long long>(1, (1ll << 23) / per_row_tiles);
     const long long i_last = std::min<long long>(V - 2, i_end);    // first SNPs V - 2 and V - 1 begin no triple
-    int i = i_begin, step = 1;
-    while (i < i_last && !rc) {
-        const int n_i = (int)std::min<long long>(std::min<long long>(step, max_rows), i_last - i);
+    // From the LAST first SNP down: a first SNP i begins (V - i - 1)(V - i - 2) / 2 triples, so the first launches list a handful
+    // of models each and leave thresholds behind for the long rows (from the first SNP up, the very first launch listed every
+    // triple of SNP 0 -- half a million models per fold at 1 024 SNPs, 125 MB over the bus and a sort: 50 ms of a 130 ms call).
+    // The order of the launches does not show in the ranking: ties go by (i, j, k).
+    long long hi = i_last;
+    int step = 1;
+    while (hi > i_begin && !rc) {
+        const int n_i = (int)std::min<long long>(std::min<long long>(step, max_rows), hi - i_begin);
+        const int i = (int)(hi - n_i);
         HIPCHK(ctx, hipMemsetAsync(E.d_cand_count, 0, hpgv::EPI_MAX_FOLDS * sizeof(unsigned), nullptr));
         HIPCHK(ctx, hipMemcpyAsync(E.d_thr, thr.data(), hpgv::EPI_MAX_FOLDS * sizeof(double), hipMemcpyHostToDevice, nullptr));
         if (scan_ms) HIPCHK(ctx, hipEventRecord(ev0, nullptr));
@@ -800,7 +812,7 @@ int hpgv_epi_rank_triples_rows(hpgv_ctx *ctx, int i_begin, int i_end, int subset
             else std::sort(t.begin(), t.end(), better);
             if ((int)t.size() >= N && t.back().accuracy > thr[(size_t)f]) thr[(size_t)f] = t.back().accuracy;
         }
-        i += n_i;
+        hi = i;
         if (worst < cap / 8 && step < 4096) step *= 2;
     }
     if (rc) return rc;

@@ -61,6 +61,8 @@ struct EpiState {
     uint32_t *d_group_w0 = nullptr;
     std::vector<int32_t> group_size;
     hpgv::EpiCand *d_cand = nullptr;
+    hpgv::EpiCand3 *d_cand3 = nullptr;    // the triple ranking's candidate lists, kept between calls
+    size_t cand3_cap = 0;
     unsigned *d_cand_count = nullptr;
     unsigned cand_cap = 0;
     double *d_thr = nullptr;
