@@ -154,9 +154,12 @@ int hpgv_epi_rank_order_rows(hpgv_ctx *ctx, int order, int i_begin, int i_end, i
     for (int s = 0; s < order; ++s) cur[s] = i_begin + s;
     bool more = true;
     unsigned long long listed = 0;
+    // the first launch has no thresholds and lists every combination it evaluates: a short one, so that the long ones that follow
+    // have bounds to filter with (131 072 models x folds x 64 bytes over the bus and a sort otherwise)
+    unsigned limit = std::min<unsigned>(CHUNK, (unsigned)std::max(4096, 4 * N));
     while (more) {
         unsigned n = 0;
-        while (more && n < CHUNK && cur[0] < i_end) {
+        while (more && n < limit && cur[0] < i_end) {
             for (int s = 0; s < order; ++s) list[(size_t)n * (size_t)order + (size_t)s] = cur[s];
             ++n;
             more = next_comb(cur, order, V);
@@ -191,6 +194,7 @@ int hpgv_epi_rank_order_rows(hpgv_ctx *ctx, int order, int i_begin, int i_end, i
             if ((int)t.size() >= N && t.back().accuracy > thr[(size_t)f]) thr[(size_t)f] = t.back().accuracy;
         }
         listed += n;
+        limit = CHUNK;
     }
     for (int f = 0; f < nf; ++f) {
         const auto &t = top[(size_t)f];
