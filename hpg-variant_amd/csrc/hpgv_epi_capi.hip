@@ -475,62 +475,30 @@ int hpgv_epi_rank_pairs_rows(hpgv_ctx *ctx, int i_begin, int i_end, int subset, 
         if (a.i != b.i) return a.i < b.i;
         return a.j < b.j;
     };
-    // starting thresholds: the N-th best accuracy among the pairs of the band's first few rows is a lower bound of the
-    // band's N-th best, so the scan need not list every pair of its first launches
-    {
-        const long long V0 = E.V;
-        // (a few tens of thousands of pairs, or four times the ranking size, are enough for a useful bound: the dense scan of these
-        // rows, its 8-byte accuracies over the bus and their selection are host time of every ranking call)
-        const long long want = std::max<long long>(32768, 4ll * N);
-        const int r = (int)std::max<long long>(1, std::min<long long>(8, want / std::max<long long>(V0, 1) + 1));
-        const int pre_end = (int)std::min<long long>(i_end, (long long)i_begin + r);
-        const unsigned long long base = epi_rank((unsigned long long)V0, (unsigned long long)i_begin);
-        const unsigned long long np = (pre_end >= E.V ? (unsigned long long)V0 * (unsigned long long)(V0 - 1) / 2 : epi_rank((unsigned long long)V0, (unsigned long long)pre_end)) - base;
-        if (np >= (unsigned long long)N * 4 && i_begin < E.V - 1) {
-            double *d_acc = nullptr; uint16_t *d_mask = nullptr;
-            HIPCHK(ctx, hipMalloc(&d_acc, (size_t)nf * np * sizeof(double)));
-            hipError_t e = hipMalloc(&d_mask, (size_t)nf * np * sizeof(uint16_t));
-            int rc0 = HPGV_OK;
-            std::vector<double> acc0;
-            if (e == hipSuccess) {
-                rc0 = subset == HPGV_EPI_TRAINING ? epi_launch_pairs<true>(ctx, i_begin, pre_end, d_acc, d_mask, np, base, false, nullptr)
-                                                  : epi_launch_pairs<false>(ctx, i_begin, pre_end, d_acc, d_mask, np, base, false, nullptr);
-                if (!rc0) { acc0.resize((size_t)nf * np); e = hipMemcpy(acc0.data(), d_acc, acc0.size() * sizeof(double), hipMemcpyDeviceToHost); }
-            }
-            (void)hipFree(d_acc);
-            if (d_mask) (void)hipFree(d_mask);
-            if (rc0) return rc0;
-            if (e != hipSuccess) return fail(ctx, HPGV_ERR_HIP, "epistasis threshold pass failed: %s", hipGetErrorString(e));
-            for (int f = 0; f < nf; ++f) {
-                double *a = acc0.data() + (size_t)f * np;
-                size_t m = 0;
-                for (size_t k = 0; k < np; ++k) if (a[k] == a[k]) a[m++] = a[k];        // NaN accuracies rank nowhere
-                if (m >= (size_t)N) {
-                    std::nth_element(a, a + (N - 1), a + m, [](double x, double y) { return x > y; });
-                    thr[(size_t)f] = a[N - 1];
-                }
-            }
-        }
-    }
     EventPair evs;                                                   // destroyed on every return path
     hipEvent_t &ev0 = evs.a, &ev1 = evs.b;
     float total_ms = 0.f;
     if (scan_ms) { HIPCHK(ctx, hipEventCreate(&ev0)); HIPCHK(ctx, hipEventCreate(&ev1)); }
     const long long V = E.V;
     const long long last = std::min<long long>(V - 1, i_end);          // row V - 1 has no pair
-    long long band_pairs = cap;                                      // pairs per launch; grows while the candidate lists stay short
-    int i = i_begin, rc = HPGV_OK;
-    while (i < last && !rc) {
+    // Bands from the LAST rows up: row r begins V - 1 - r pairs, so the first launches list a few thousand models and leave
+    // thresholds behind for the long rows (no pre-pass for starting thresholds; the order of the launches does not show in the
+    // ranking: ties go by (i, j)).  Pairs per launch: a small first band, growing while the candidate lists stay short.
+    long long band_pairs = std::max<long long>(8192, 2ll * N);
+    long long hi = last;
+    int rc = HPGV_OK;
+    while (hi > i_begin && !rc) {
         long long pairs = 0;
-        int e_row = i;
+        long long lo = hi;
         // whole blocks of 64 rows (the tile numbering wants bands that start on a multiple of 64), at least one
-        while (e_row < last) {
-            const int nxt = (int)std::min<long long>(last, (long long)(e_row / 64 + 1) * 64);
+        while (lo > i_begin) {
+            const long long nxt = std::max<long long>(i_begin, (lo - 1) / 64 * 64);
             long long add = 0;
-            for (int r = e_row; r < nxt; ++r) add += V - 1 - r;
-            if (e_row > i && pairs + add > band_pairs) break;
-            pairs += add; e_row = nxt;
+            for (long long r = nxt; r < lo; ++r) add += V - 1 - r;
+            if (lo < hi && pairs + add > band_pairs) break;
+            pairs += add; lo = nxt;
         }
+        const int i = (int)lo, e_row = (int)hi;
         HIPCHK(ctx, hipMemsetAsync(E.d_cand_count, 0, hpgv::EPI_MAX_FOLDS * sizeof(unsigned), nullptr));
         HIPCHK(ctx, hipMemcpyAsync(E.d_thr, thr.data(), hpgv::EPI_MAX_FOLDS * sizeof(double), hipMemcpyHostToDevice, nullptr));
         if (scan_ms) HIPCHK(ctx, hipEventRecord(ev0, nullptr));
@@ -563,7 +531,7 @@ int hpgv_epi_rank_pairs_rows(hpgv_ctx *ctx, int i_begin, int i_end, int subset, 
             if ((int)t.size() >= N && t.back().accuracy > thr[(size_t)f]) thr[(size_t)f] = t.back().accuracy;
         }
         if (worst < cap / 8 && band_pairs < (long long)cap * 1024) band_pairs *= 4;
-        i = e_row;
+        hi = lo;
     }
     if (rc) return rc;
     for (int f = 0; f < nf; ++f) {
