@@ -1,6 +1,6 @@
-// hpgv_epi_mfma_kernels.h -- the pair ranking of the epistasis / MDR path with the cell counts on the MATRIX cores
-// (model.c:76-206 combination_counts_all_folds, mdr.c:45-76, model.c:320-476; what k_epi_pairs of hpgv_epi_kernels.h does on
-// the vector ALU).
+// hpgv_epi_mfma_kernels.h -- the pair and triple rankings of the epistasis / MDR path with the cell counts on the MATRIX
+// cores (model.c:76-206 combination_counts_all_folds, mdr.c:45-76, model.c:320-476; what k_epi_pairs / k_epi_triples3 of
+// hpgv_epi_kernels.h / hpgv_epi_triples3_kernels.h do on the vector ALU).
 //
 // The nine cell counts of the pairs of 16 row SNPs x 16 column SNPs over 128 samples are nine products of 0/1 matrices:
 // count(a, b)[i][j] = sum over samples of plane_i[a] * plane_j[b], i.e. v_mfma_scale_f32_16x16x128_f8f6f4 with the genotype
@@ -19,7 +19,7 @@
 // instruction per eight samples (the nibble's top bit is the sign: those samples are shifted down to 0.5).  The other side
 // must weigh the same samples 2.0, 1.0, 0.5, 2.0 so that every product is 1: the column side reads a second copy of the planes
 // with bits 0 and 2 of every nibble swapped, again one instruction per register.  Five instructions per word and plane, 30
-// per step, against nine MFMAs of 16 cycles.  (The first form used v_mfma_i32_16x16x64_i8 with one bit of every BYTE per
+// per step, against nine MFMAs.  (The first form used v_mfma_i32_16x16x64_i8 with one bit of every BYTE per
 // register: 54 instructions and 18 MFMAs per step -- and back to back that instruction issues every 45 cycles
 // (tools/exp/mfma_rate.hip; the FP4 form every 33): 800 cycles of matrix core per step, no faster than k_epi_pairs.)
 //
@@ -54,7 +54,8 @@ __device__ __forceinline__ epm_v8i epm_col_operand(uint32_t y) {
 #define HPGV_EPM_MFMA(A, B, C) __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, C, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F)   /* FP4 x FP4, scales 2^0 */
 
 // Ranking only (thresholds + candidate lists), classes below 65 536 samples, any number of folds.  TWO passes over the
-// samples, like the triple scan's: the first leaves every pair's nine totals (cases low, controls high half), the second visits
+// samples, like the triple scan's: the first leaves every pair's nine totals (cases and controls in accumulators of their own,
+// chosen step by step, packed cases low / controls high at its end), the second visits
 // the groups in (fold, class) order and, each time a fold's groups are complete, evaluates that fold at once from totals -
 // fold counts.  What this buys over one pass that keeps all folds' counts: the state is 36 + 36 + 36 registers instead of
 // 36 (K + 1), so TWO waves share a SIMD -- one wave's vector work (operands, banking, evaluation) runs under the other's
