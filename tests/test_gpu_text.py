@@ -688,8 +688,9 @@ def test_assoc_text_rows_kernel_on_random_widths():
         test_assoc_text_rows_kernel_equals_the_per_row_kernel(n_samples)
 
 
-@pytest.mark.parametrize("n_samples,block_bytes", [(200, [65280]), (2504, [65280]), (37, [65280, 1000, 500, 700, 3000, 65280, 10]), (900, [4096, 65280, 2047, 2048, 2049])])
-def test_windows_of_decoded_text_tokenized_from_the_decoders_tile_records(n_samples, block_bytes):
+@pytest.mark.parametrize("n_samples,block_bytes,text_shift", [(200, [65280], 0), (2504, [65280], 0), (37, [65280, 1000, 500, 700, 3000, 65280, 10], 0),
+                                                              (900, [4096, 65280, 2047, 2048, 2049], 0), (300, [65280, 5000], 4), (2504, [65280], 12)])
+def test_windows_of_decoded_text_tokenized_from_the_decoders_tile_records(n_samples, block_bytes, text_shift):
     """The bgzip decoder's CRC kernel leaves the tokenizer's tile records of the text it checks (hpgv_bgzf_verify_tiles_dev); windows of
     that text -- starting at any line, ending at any line -- are then tokenized WITHOUT the counting sweep (hpgv_text_alias_tiles).
     Same outputs, bit for bit, as the ordinary two-sweep call on the same window, and as the oracle: blocks of the size bgzip writes
@@ -717,7 +718,10 @@ def test_windows_of_decoded_text_tokenized_from_the_decoders_tile_records(n_samp
     cbytes = np.frombuffer(b"".join(comps) + b"\0" * 16, np.uint8)
     total = len(text)
     e = hpgv.Engine(0)
-    d_comp, d_text = e.alloc(len(cbytes)), e.alloc(total + 64)
+    # (text_shift: a text that does not begin on a 16-byte boundary -- the records then come from a sweep of their own, not out of
+    # the CRC loop's loads)
+    d_comp, d_text_alloc = e.alloc(len(cbytes)), e.alloc(total + 64 + 16)
+    d_text = C.c_void_p(d_text_alloc.value + text_shift)
     d_io, d_il, d_oo, d_ol, d_st = e.alloc(8 * n), e.alloc(4 * n), e.alloc(8 * n), e.alloc(4 * n), e.alloc(4 * n)
     for d, a in ((d_comp, cbytes), (d_io, in_off), (d_il, in_len), (d_oo, out_off), (d_ol, out_len)):
         e.h2d(d, a)
