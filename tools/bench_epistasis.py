@@ -3,7 +3,7 @@
 Bound: VALU integer issue -- 18 operations (9 v_and_b32 + 9 v_bcnt_u32_b32) per pair and 32 samples; peak =
 256 CUs x 64 lanes x clock.  Diagnostic tool (not the headline metric).
 
-  python tools/bench_epistasis.py [V] [N] [k] [--cpu] [--complete] [--order=3] [--unbalanced] [--option=key=value]
+  python tools/bench_epistasis.py [V] [N] [k] [--cpu] [--complete] [--order=3] [--unbalanced] [--affected=n] [--option=key=value]
 
 --complete: a dataset without missing calls (the scan then counts four cells per pair and derives the other five:
 8 operations per pair and word; the roofline line keeps the 18 of the general case so that the two are comparable).
@@ -28,6 +28,9 @@ rng = np.random.default_rng(1)
 nA = nU = N // 2
 if "--unbalanced" in sys.argv:                              # cases != controls: the threshold of a high-risk cell is a ratio, not 1
     nA = (2 * N) // 5; nU = N - nA
+for a in sys.argv[1:]:
+    if a.startswith("--affected="):                         # any split, e.g. one whose ratio never ties a cell (4987 of 10000)
+        nA = int(a[len("--affected="):]); nU = N - nA
 COMPLETE = "--complete" in sys.argv
 data = rng.choice(np.array([0, 1, 2, 255], np.uint8), size=(V, nA + nU), p=[0.5, 0.35, 0.15, 0.0] if COMPLETE else [0.5, 0.35, 0.14, 0.01])
 fold = np.empty(nA + nU, np.int32)

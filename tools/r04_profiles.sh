@@ -7,7 +7,7 @@ mkdir -p $O
 cd $R
 P=$O/r04_epi_pairs_mfma.jsonl; : > $P
 for args in "16384 10000 10" "16384 10000 10 --option=epi_pairs_mfma=0" "16384 10000 5" "16384 10000 5 --option=epi_pairs_mfma=0" \
-            "16384 10000 16" "16384 10000 16 --option=epi_pairs_mfma=0" "16384 10000 10 --unbalanced" "16384 10000 10 --unbalanced --option=epi_pairs_mfma=0" \
+            "16384 10000 16" "16384 10000 16 --option=epi_pairs_mfma=0" "16384 10000 10 --unbalanced" "16384 10000 10 --unbalanced --option=epi_pairs_mfma=0" "16384 10000 10 --affected=4987" "16384 10000 10 --affected=4987 --option=epi_pairs_mfma=0" \
             "4096 100000 10" "4096 100000 10 --option=epi_pairs_mfma=0" "16384 10000 10 --complete" "16384 10000 10 --complete --option=epi_pairs_mfma=0" \
             "16384 10000 5 --complete" "16384 10000 5 --complete --option=epi_pairs_mfma=0"; do
   timeout -k 10 300 python3 tools/bench_epistasis.py $args >> $P || exit 1
