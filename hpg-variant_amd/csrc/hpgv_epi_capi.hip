@@ -530,7 +530,10 @@ int hpgv_epi_rank_pairs_rows(hpgv_ctx *ctx, int i_begin, int i_end, int subset, 
             }
             if ((int)t.size() >= N && t.back().accuracy > thr[(size_t)f]) thr[(size_t)f] = t.back().accuracy;
         }
-        if (worst < cap / 8 && band_pairs < (long long)cap * 1024) band_pairs *= 4;
+        // (a launch of a few tiles takes as long as one workgroup's whole scan: once thresholds exist and the lists stay
+        // nearly empty the bands grow fast)
+        if (worst < cap / 64 && band_pairs < (long long)cap * 1024) band_pairs *= 32;
+        else if (worst < cap / 8 && band_pairs < (long long)cap * 1024) band_pairs *= 4;
         hi = lo;
     }
     if (rc) return rc;

@@ -24,7 +24,9 @@ done
 cat $T3 | cut -c1-220
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/r04_epm_stats -o epm --output-format csv -- python3 $R/tools/bench_epistasis.py 16384 10000 10 > $O/r04_epm_stats.json 2> $O/r04_epm_stats.err || exit 1
+rocprofv3 --kernel-trace --stats -d $O/r04_epm3_stats -o epm3 --output-format csv -- python3 $R/tools/bench_epistasis.py 1024 10000 10 --order=3 > $O/r04_epm3_stats.json 2> $O/r04_epm3_stats.err || exit 1
 bash $R/tools/epm_prof.sh > $O/r04_epm_counters.txt 2>&1 || exit 1
+EPI_ARGS="1024 10000 10 --order=3" bash $R/tools/epm_prof.sh > $O/r04_epm3_counters.txt 2>&1 || exit 1
 tail -2 $O/r04_epm_counters.txt
 cat $P | cut -c1-220
 cat $T | cut -c1-220
