@@ -103,7 +103,14 @@ int epi_build_folds(hpgv_ctx *ctx, const int32_t *fold_of_sample, int num_folds)
     // copy with the low seven bits of every byte reversed (hpgv_epi_mfma_kernels.h)
     const size_t plane_words = (size_t)E.V_alloc * 3 * (size_t)E.W + hpgv::EPI_CH;
     E.rev_off = 2 * plane_words < (1ull << 32) ? (uint32_t)plane_words : 0u;
-    if (e == hipSuccess) e = hipMalloc(&E.d_planes, (plane_words + E.rev_off) * sizeof(uint32_t));
+    if (e == hipSuccess) {
+        e = hipMalloc(&E.d_planes, (plane_words + E.rev_off) * sizeof(uint32_t));
+        if (e != hipSuccess && E.rev_off) {                          // no room for the copy: the vector-ALU scans do without it
+            (void)hipGetLastError();
+            E.rev_off = 0;
+            e = hipMalloc(&E.d_planes, plane_words * sizeof(uint32_t));
+        }
+    }
     if (e == hipSuccess) e = hipMalloc(&E.d_chunks, chunks.size() * sizeof(hpgv::EpiChunk));
     if (e == hipSuccess) e = hipMemcpy(E.d_chunks, chunks.data(), chunks.size() * sizeof(hpgv::EpiChunk), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&E.d_chunk_cls, chunk_cls.size() * sizeof(uint32_t));
