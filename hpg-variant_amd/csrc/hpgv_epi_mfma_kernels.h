@@ -32,6 +32,7 @@ namespace hpgv {
 constexpr int EPM_MAX_CHUNKS = 128;   // chunk descriptors kept in LDS (131 072 samples and their padding)
 constexpr int EPM_TI = 16;            // rows of a workgroup's tile (its 64 columns: 16 per wave)
 typedef int epm_v8i __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(3))) uint32_t *epm_lds_u32;           // a word of LDS by its 32-bit address
 typedef float epm_v4f __attribute__((ext_vector_type(4)));
 
 // the column side's copy of the planes: bits 0 and 2 of every nibble swapped (same layout, right behind the planes)
@@ -84,8 +85,9 @@ __global__ void __launch_bounds__(256, COMPLETE ? 3 : 2) k_epi_pairs_mfma(const 
     constexpr int SNPS = EPI_TJ + EPM_TI, ROWS = SNPS * NP, NDMA = ROWS / 8;     // 80 SNPs, 240 (160) rows, 30 (20) LDS-DMA instructions per chunk
     static_assert(ROWS % 8 == 0, "whole LDS-DMA instructions");
     // two separate arrays, not lds[2][...]: the compiler then sees that the LDS-DMA writes into one buffer cannot touch the other
-    __shared__ __attribute__((aligned(16))) uint32_t lds_a[ROWS * EPI_CH];
-    __shared__ __attribute__((aligned(16))) uint32_t lds_b[ROWS * EPI_CH];
+    // (128-byte aligned: the reads below fold the piece swizzle and the step into ONE xor on the word's LDS address)
+    __shared__ __attribute__((aligned(128))) uint32_t lds_a[ROWS * EPI_CH];
+    __shared__ __attribute__((aligned(128))) uint32_t lds_b[ROWS * EPI_CH];
     // the chunk descriptors and the folds' constants in LDS (a scalar load that misses costs a microsecond)
     __shared__ __attribute__((aligned(16))) uint32_t s_chunk[EPM_MAX_CHUNKS * 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_fold[EPI_MAX_FOLDS * 8];
@@ -174,12 +176,12 @@ __global__ void __launch_bounds__(256, COMPLETE ? 3 : 2) k_epi_pairs_mfma(const 
         }
     };
 
+    // the word of step k: row * 128 + ((k ^ swizzle) << 4) + h * 4 bytes into the buffer = (buffer + row * 128 + (swizzle << 4) + h * 4) ^ (k << 4)
 #define HPGV_EPM_READ(X, Y, KSTEP)                                                                       \
     {                                                                                                    \
-        const int k_ = (KSTEP) < 7 ? (KSTEP) : 7;                    /* (past the chunk's last step: any step, never used) */ \
-        const char *qa = cur_bytes + (base_a + ((k_ ^ swz_a) << 4)), *qb = cur_bytes + (base_b + ((k_ ^ swz_b) << 4)); \
+        const uint32_t kx = (uint32_t)((KSTEP) < 7 ? (KSTEP) : 7) << 4;      /* (past the chunk's last step: any step, never used) */ \
         _Pragma("unroll") for (int a = 0; a < NP; a++) {                                                 \
-            X[a] = *reinterpret_cast<const uint32_t *>(qa + a * PS); Y[a] = *reinterpret_cast<const uint32_t *>(qb + a * PS); \
+            X[a] = *(epm_lds_u32)(uintptr_t)((cur_a ^ kx) + (uint32_t)(a * PS)); Y[a] = *(epm_lds_u32)(uintptr_t)((cur_b ^ kx) + (uint32_t)(a * PS)); \
         }                                                                                                \
     }
     // a (fold, class) group has ended: the accumulators hold its counts.  First pass: into the totals.  Second pass: into the
@@ -273,7 +275,8 @@ __global__ void __launch_bounds__(256, COMPLETE ? 3 : 2) k_epi_pairs_mfma(const 
             const uint32_t clsm = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cls[c]);             \
             const uint64_t flush = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 2])      /* wave-uniform */ \
                                    | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_chunk[c * 4 + 3]) << 32); \
-            const char *cur_bytes = reinterpret_cast<const char *>(cur);                                 \
+            const uint32_t cur_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)cur;     \
+            const uint32_t cur_a = cur_lds + (uint32_t)(base_a | (swz_a << 4)), cur_b = cur_lds + (uint32_t)(base_b | (swz_b << 4)); \
             uint32_t xa[NP], xb[NP];                                                                     \
             HPGV_EPM_READ(xa, xb, 0)                                                                     \
             epm_v8i A0[NP], B0[NP];                                                                      \
